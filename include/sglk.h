@@ -1,0 +1,146 @@
+/*
+ * sglk.h — C-ABI of the MI355X (gfx950) sgl_kernel hot-path kernels.
+ *
+ * This is the drop-in boundary below the torch operator registry: one plain-C
+ * entry point per device kernel family, taking a HIP stream, raw device
+ * pointers and sizes. No torch types cross this line. The reference's
+ * precedent for this shape of interface is its JIT C API
+ * (reference include/sgl_kernel/jit_kernel/elementwise/activation.hpp:183-187:
+ * `extern "C" void act_and_mul_forward_<dtype>(void* queue, const void* in,
+ * void* out, int64 tokens, int64 dim, int32 act_kind)`).
+ *
+ * Each entry point cites the reference interface it replaces (file:line,
+ * relative to the reference checkout). The torch-level schemas that sit on
+ * top of these live in sgl-kernel-xpu_amd/csrc/torch_extension_hip.cc and
+ * mirror reference src/torch_extension_sycl.cc.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SGLK_E* code otherwise
+ *     and never throws; sglk_last_error() returns a thread-local message.
+ *   - all pointers are DEVICE pointers unless the name ends in _host.
+ *   - work is enqueued on `stream` (a hipStream_t) and is not waited for; no
+ *     function allocates, frees or synchronises (graph-capture safe).
+ *   - strides are in ELEMENTS unless the name says _bytes.
+ */
+#ifndef SGLK_H_
+#define SGLK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGLK_API __attribute__((visibility("default")))
+
+typedef void* sglk_stream_t; /* hipStream_t */
+
+enum sglk_dtype {
+  SGLK_F32 = 0,
+  SGLK_F16 = 1,
+  SGLK_BF16 = 2,
+  SGLK_FP8_E4M3 = 3, /* OCP e4m3fn */
+  SGLK_INT8 = 4,
+  SGLK_FP8_E5M2 = 5,
+  SGLK_U8 = 6,
+  SGLK_I32 = 7,
+  SGLK_I64 = 8,
+};
+
+enum sglk_status {
+  SGLK_OK = 0,
+  SGLK_EINVAL = -1,       /* bad argument (the torch layer turns this into RuntimeError) */
+  SGLK_EUNSUPPORTED = -2, /* shape/dtype combination has no kernel */
+  SGLK_ELAUNCH = -3,      /* hipLaunch failed */
+};
+
+/* Human-readable reason for the last non-zero return on this thread. */
+SGLK_API const char* sglk_last_error(void);
+/* Library version string, and the gfx arch the code objects were built for. */
+SGLK_API const char* sglk_version(void);
+SGLK_API const char* sglk_arch(void);
+
+/* Row addressing of a 2-D / 3-D last-dim-contiguous tensor:
+ * offset(row) = (row / inner_size) * outer_stride + (row % inner_size) * inner_stride.
+ * Mirrors RowStrides of reference src/sycl/RMSNorm.cpp:44-64. */
+typedef struct sglk_row_strides {
+  int64_t outer_stride;
+  int64_t inner_size;
+  int64_t inner_stride;
+} sglk_row_strides;
+
+/* ---- RMSNorm family -------------------------------------------------------
+ * rmsnorm / gemma_rmsnorm: reference src/sycl/RMSNorm.cpp:793-825, :850-878
+ * (schemas src/torch_extension_sycl.cc:41,47).
+ *   out[r,:] = T((w * rsqrt(mean(x[r,:]^2) + eps)) * x[r,:])   (gemma: (1+w))
+ * x/out dtype in {F32,F16,BF16}; weight dtype in {F32,F16,BF16}. */
+SGLK_API int sglk_rmsnorm(sglk_stream_t stream, void* out, const void* x, const void* weight,
+                          int64_t rows, int64_t n, sglk_row_strides x_strides,
+                          sglk_row_strides out_strides, float eps, int dtype, int weight_dtype,
+                          int gemma);
+
+/* fused_add_rmsnorm / gemma_fused_add_rmsnorm: reference
+ * src/sycl/RMSNorm.cpp:827-848, :880-905 (schemas torch_extension_sycl.cc:44,50).
+ *   r = T(x + residual); residual = r; x = T((w * rstd(r)) * r), contiguous [rows,n]. */
+SGLK_API int sglk_fused_add_rmsnorm(sglk_stream_t stream, void* x, void* residual,
+                                    const void* weight, int64_t rows, int64_t n, float eps,
+                                    int dtype, int weight_dtype, int gemma);
+
+/* ---- activation-and-mul ---------------------------------------------------
+ * silu_and_mul / gelu_tanh_and_mul / gelu_and_mul: reference
+ * src/sycl/TripleOps.cpp:140-153, :181, :222 (schemas :29,:35,:38).
+ *   out[t, j] = T(act(x[t, j]) * x[t, d + j]),  x is [tokens, 2d] contiguous. */
+enum sglk_act { SGLK_ACT_SILU = 0, SGLK_ACT_GELU_TANH = 1, SGLK_ACT_GELU = 2 };
+SGLK_API int sglk_act_and_mul(sglk_stream_t stream, void* out, const void* x, int64_t tokens,
+                              int64_t d, int dtype, int act);
+
+/* ---- per-token-group 8-bit quantisation -----------------------------------
+ * sgl_per_token_group_quant_8bit: reference
+ * src/sycl/per_token_group_quant_8bit.cpp:222-386 (schema :395-398).
+ *   per (row, group): amax = max(|x|, eps); s = amax / qmax;
+ *   [ue8m0: s = 2^ceil(log2(max(s,1e-10)))]; q = cast(clamp(x * (1/s), qmin, qmax)).
+ * x [rows, k] contiguous, F32/F16/BF16. q [rows,k] FP8_E4M3 (RN-even) or INT8
+ * (truncating). Scales:
+ *   scale_kind 0: float, element (row, g) at  row*s_stride_row + g*s_stride_col
+ *   scale_kind 1: ue8m0 bytes, row-major contiguous [rows, k/group]
+ *   scale_kind 2: ue8m0 packed 4-per-int32, column-major: byte address
+ *                 ((g/4)*s_stride_col + row)*4 + g%4   (s_stride_col in int32 units)
+ */
+SGLK_API int sglk_per_token_group_quant_8bit(sglk_stream_t stream, const void* x, void* q,
+                                             void* scales, int64_t rows, int64_t k,
+                                             int group_size, float eps, float qmin, float qmax,
+                                             int in_dtype, int out_dtype, int scale_kind,
+                                             int64_t s_stride_row, int64_t s_stride_col);
+
+/* ---- fp8 block-scaled GEMM --------------------------------------------------
+ * fp8_blockwise_scaled_mm: declared (never implemented) in reference
+ * include/sgl_kernel_ops.h:581-586; wrapper python/sgl_kernel/gemm.py:24-31;
+ * semantics pinned by tests/test_fp8_blockwise_gemm.py:23-85.
+ *   out[m,n] = T( sum_kb sa[m,kb] * sb[kb, n/128] * sum_{k in kb} a[m,k]*b[k,n] )
+ * a [M,K] e4m3 row-major (lda); b given as [N,K] K-contiguous (ldb) — i.e. the
+ * reference's column-major [K,N]; sa [M, K/128] fp32 with element strides
+ * (sa_stride_m, sa_stride_k); sb [K/128, N/128] fp32 (sb_stride_k, sb_stride_n).
+ * out [M,N] row-major (ldc), BF16 or F16. K % 128 == 0, N % 16 == 0. */
+SGLK_API int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const void* a,
+                                          const void* b, const float* sa, const float* sb,
+                                          int64_t M, int64_t N, int64_t K, int64_t lda,
+                                          int64_t ldb, int64_t ldc, int64_t sa_stride_m,
+                                          int64_t sa_stride_k, int64_t sb_stride_k,
+                                          int64_t sb_stride_n, int out_dtype);
+
+/* ---- per-token / per-channel scaled GEMM ------------------------------------
+ * fp8_scaled_mm / int8_scaled_mm: declared in reference
+ * include/sgl_kernel_ops.h:567-580; wrappers python/sgl_kernel/gemm.py:13-42;
+ * semantics pinned by tests/test_fp8_gemm.py:11-19 and tests/test_int8_gemm.py:16-22.
+ *   fp8 : out = T(T(acc * sa[m] * sb[n]) + bias[n])      (bias added after the cast)
+ *   int8: out = T(float(acc_i32) * sa[m] * sb[n] + bias[n])  (bias added in fp32)
+ * a [M,K] row-major; b as [N,K] K-contiguous; K % 16 == 0. */
+SGLK_API int sglk_scaled_mm(sglk_stream_t stream, void* out, const void* a, const void* b,
+                            const float* sa, const float* sb, const void* bias, int64_t M,
+                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                            int in_dtype, int out_dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGLK_H_ */

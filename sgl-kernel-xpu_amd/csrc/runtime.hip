@@ -1,0 +1,31 @@
+// Error plumbing and library identity for libsglk.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace sglk {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SGLK_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return SGLK_OK;
+}
+
+}  // namespace sglk
+
+extern "C" {
+const char* sglk_last_error(void) { return sglk::g_err; }
+const char* sglk_version(void) { return "0.1.0"; }
+const char* sglk_arch(void) { return "gfx950"; }
+}

@@ -1,0 +1,277 @@
+// TORCH_LIBRARY registration of the sgl_kernel operator surface for ROCm.
+//
+// Replaces reference src/torch_extension_sycl.cc (registry) and the host halves
+// of src/sycl/*.cpp: each op validates its tensors the way the reference's host
+// launcher does, then hands raw pointers + sizes + the current HIP stream to
+// the C-ABI in include/sglk.h. Schemas of ops the reference registers are kept
+// character for character (they are the drop-in contract; cited per op);
+// schemas of the ops it only declares are authored here from
+// include/sgl_kernel_ops.h and python/sgl_kernel/gemm.py call order.
+//
+// Dispatch key: CUDA (PyTorch-ROCm exposes HIP devices as "cuda").
+// Built as the CPython extension `sgl_kernel.common_ops` (limited API), the
+// module name python/sgl_kernel/__init__.py:14 of the reference imports.
+#include <Python.h>
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <optional>
+#include <tuple>
+
+#include "sglk.h"
+
+namespace {
+
+using at::Tensor;
+
+#define SGLK_CALL(expr)                                             \
+  do {                                                              \
+    const int sglk_rc_ = (expr);                                    \
+    TORCH_CHECK(sglk_rc_ == 0, "sgl_kernel: ", sglk_last_error()); \
+  } while (0)
+
+#define CHECK_GPU(x) TORCH_CHECK((x).is_cuda(), #x " must be a GPU (cuda/hip) tensor")
+#define CHECK_LAST_DIM_CONTIGUOUS(x) \
+  TORCH_CHECK((x).dim() == 0 || (x).stride(-1) == 1, #x " must be contiguous at the last dimension")
+#define CHECK_CONTIGUOUS(x) TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")
+
+sglk_stream_t stream_of(const Tensor& t) {
+  return (sglk_stream_t)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+}
+
+int dtype_code(at::ScalarType t, const char* what) {
+  switch (t) {
+    case at::kFloat: return SGLK_F32;
+    case at::kHalf: return SGLK_F16;
+    case at::kBFloat16: return SGLK_BF16;
+    case at::kFloat8_e4m3fn: return SGLK_FP8_E4M3;
+    case at::kFloat8_e5m2: return SGLK_FP8_E5M2;
+    case at::kChar: return SGLK_INT8;
+    case at::kByte: return SGLK_U8;
+    case at::kInt: return SGLK_I32;
+    case at::kLong: return SGLK_I64;
+    default: TORCH_CHECK(false, what, ": unsupported dtype ", t);
+  }
+  return -1;
+}
+
+// ---- RMSNorm family (reference src/sycl/RMSNorm.cpp:793-905, Norm.h:18-47) ----------------
+
+// RowStrides of reference RMSNorm.cpp:50-64
+sglk_row_strides row_strides(const Tensor& t) {
+  TORCH_CHECK(t.dim() == 2 || t.dim() == 3, "get_row_strides: expected a 2D or 3D tensor, got ", t.dim(), "D");
+  if (t.dim() == 2) return {t.stride(0), 1, 0};
+  const int64_t outer = t.stride(0), inner_size = t.size(1), inner_stride = t.stride(1);
+  if (t.size(0) == 1 || outer == inner_size * inner_stride) return {inner_stride, 1, 0};
+  return {outer, inner_size, inner_stride};
+}
+
+std::tuple<int64_t, int64_t> check_norm_inputs(const Tensor& input, const Tensor& weight) {
+  CHECK_GPU(input);
+  CHECK_LAST_DIM_CONTIGUOUS(input);
+  TORCH_CHECK(input.dim() == 2 || input.dim() == 3, "input must be a 2D or 3D tensor");
+  CHECK_LAST_DIM_CONTIGUOUS(weight);
+  TORCH_CHECK(weight.device() == input.device(), "weight must be on the same device as input");
+  TORCH_CHECK(weight.dim() == 1, "weight must be 1-D");
+  TORCH_CHECK(input.size(-1) == weight.size(0), "weight size must equal the hidden size");
+  const int64_t n = input.size(-1);
+  TORCH_CHECK(n > 0, "hidden size must be positive");
+  return {input.numel() / n, n};
+}
+
+void rmsnorm_impl(Tensor& output, const Tensor& input, const Tensor& weight, double eps, bool gemma) {
+  auto [rows, n] = check_norm_inputs(input, weight);
+  CHECK_GPU(output);
+  CHECK_LAST_DIM_CONTIGUOUS(output);
+  TORCH_CHECK(output.sizes() == input.sizes(), "output must have the shape of input");
+  TORCH_CHECK(output.scalar_type() == input.scalar_type(), "output must have the dtype of input");
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_rmsnorm(stream_of(input), output.data_ptr(), input.data_ptr(), weight.data_ptr(), rows, n,
+                         row_strides(input), row_strides(output), (float)eps,
+                         dtype_code(input.scalar_type(), "rmsnorm"),
+                         dtype_code(weight.scalar_type(), "rmsnorm weight"), gemma ? 1 : 0));
+}
+
+void fused_add_rmsnorm_impl(Tensor& input, Tensor& residual, const Tensor& weight, double eps, bool gemma,
+                            const char* name) {
+  TORCH_CHECK(input.is_contiguous(), name, ": input must be contiguous");
+  TORCH_CHECK(residual.is_contiguous(), name, ": residual must be contiguous");
+  auto [rows, n] = check_norm_inputs(input, weight);
+  CHECK_GPU(residual);
+  TORCH_CHECK(residual.sizes() == input.sizes(), name, ": residual must have the shape of input");
+  TORCH_CHECK(residual.scalar_type() == input.scalar_type(), name, ": residual must have the dtype of input");
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_fused_add_rmsnorm(stream_of(input), input.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                   rows, n, (float)eps, dtype_code(input.scalar_type(), name),
+                                   dtype_code(weight.scalar_type(), name), gemma ? 1 : 0));
+}
+
+void rmsnorm(Tensor& output, Tensor& input, Tensor& weight, double eps) {
+  rmsnorm_impl(output, input, weight, eps, false);
+}
+void gemma_rmsnorm(Tensor& output, Tensor& input, Tensor& weight, double eps) {
+  rmsnorm_impl(output, input, weight, eps, true);
+}
+void fused_add_rmsnorm(Tensor input, Tensor residual, Tensor weight, double eps) {
+  fused_add_rmsnorm_impl(input, residual, weight, eps, false, "fused_add_rmsnorm");
+}
+void gemma_fused_add_rmsnorm(Tensor& input, Tensor& residual, Tensor& weight, double eps) {
+  fused_add_rmsnorm_impl(input, residual, weight, eps, true, "gemma_fused_add_rmsnorm");
+}
+
+// ---- activation-and-mul (reference src/sycl/TripleOps.cpp:140-235) -------------------------
+
+void act_and_mul_impl(Tensor& out, Tensor& input, int act, const char* name) {
+  CHECK_GPU(input);
+  CHECK_GPU(out);
+  TORCH_CHECK(input.scalar_type() == at::kHalf || input.scalar_type() == at::kBFloat16 ||
+                  input.scalar_type() == at::kFloat,
+              name, ": input must be Half, BFloat16 or Float");
+  TORCH_CHECK(out.scalar_type() == input.scalar_type(), name, ": out must have the dtype of input");
+  TORCH_CHECK(input.dim() >= 1 && input.size(-1) % 2 == 0, name, ": last dimension of input must be even");
+  TORCH_CHECK(out.is_contiguous(), name, ": out must be contiguous");
+  const int64_t d = input.size(-1) / 2;
+  TORCH_CHECK(out.dim() == input.dim() && out.size(-1) == d && out.numel() * 2 == input.numel(), name,
+              ": out must be input's shape with the last dimension halved");
+  // the reference makes the input contiguous (TripleOps.cpp:141); out is written in place
+  const Tensor in_c = input.contiguous();
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_act_and_mul(stream_of(input), out.data_ptr(), in_c.data_ptr(), out.numel() / d, d,
+                             dtype_code(input.scalar_type(), name), act));
+}
+void silu_and_mul(Tensor& out, Tensor& input) { act_and_mul_impl(out, input, SGLK_ACT_SILU, "silu_and_mul"); }
+void gelu_tanh_and_mul(Tensor& out, Tensor& input) {
+  act_and_mul_impl(out, input, SGLK_ACT_GELU_TANH, "gelu_tanh_and_mul");
+}
+void gelu_and_mul(Tensor& out, Tensor& input) { act_and_mul_impl(out, input, SGLK_ACT_GELU, "gelu_and_mul"); }
+
+// ---- per-token-group quant (reference src/sycl/per_token_group_quant_8bit.cpp:222-386) ------
+
+void sgl_per_token_group_quant_8bit(Tensor input, Tensor output_q, Tensor output_s, int64_t group_size,
+                                    double eps, double min_8bit, double max_8bit, bool scale_ue8m0) {
+  CHECK_GPU(input);
+  CHECK_GPU(output_q);
+  CHECK_GPU(output_s);
+  CHECK_CONTIGUOUS(input);
+  CHECK_CONTIGUOUS(output_q);
+  TORCH_CHECK(group_size > 0 && input.numel() % group_size == 0, "input.numel() must be divisible by group_size");
+  TORCH_CHECK(output_s.dim() == 2, "output_s must be 2-D");
+  TORCH_CHECK(input.dim() >= 1 && input.size(-1) % group_size == 0,
+              "the hidden dimension must be divisible by group_size");
+  TORCH_CHECK(output_q.numel() == input.numel(), "output_q must have input's number of elements");
+  const auto in_t = input.scalar_type();
+  TORCH_CHECK(in_t == at::kHalf || in_t == at::kBFloat16 || in_t == at::kFloat,
+              "sgl_per_token_group_quant_8bit: input dtype must be Float16, BFloat16, or Float32, got ", in_t);
+  const auto q_t = output_q.scalar_type();
+  TORCH_CHECK(q_t == at::kChar || q_t == at::kFloat8_e4m3fn,
+              "sgl_per_token_group_quant_8bit: output_q dtype must be Int8 or Float8_e4m3fn, got ", q_t);
+  const int64_t k = input.size(-1);
+  const int64_t rows = input.numel() / k;
+  const int64_t groups_per_row = k / group_size;
+  // layout detection of reference :259
+  const bool column_major = output_s.stride(0) < output_s.stride(1);
+  int kind = 0;
+  int64_t s_row = 0, s_col = 0;
+  if (!scale_ue8m0) {
+    TORCH_CHECK(output_s.scalar_type() == at::kFloat, "output_s must be float32 unless scale_ue8m0");
+    TORCH_CHECK(output_s.numel() >= rows * groups_per_row, "output_s is too small");
+    if (column_major) {
+      // reference writes element (row, g) at g * stride(1) + row
+      s_row = 1;
+      s_col = output_s.stride(1);
+    } else {
+      // reference writes element (row, g) at the flat group index
+      s_row = groups_per_row;
+      s_col = 1;
+    }
+  } else if (column_major) {
+    TORCH_CHECK(output_s.element_size() == 4, "column-major ue8m0 scales must be packed 4 per 32-bit element");
+    kind = 2;
+    s_col = output_s.stride(1);
+  } else {
+    TORCH_CHECK(output_s.element_size() == 1, "row-major ue8m0 scales must be a uint8 tensor");
+    TORCH_CHECK(output_s.numel() >= rows * groups_per_row, "output_s is too small");
+    kind = 1;
+  }
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_per_token_group_quant_8bit(stream_of(input), input.data_ptr(), output_q.data_ptr(),
+                                            output_s.data_ptr(), rows, k, (int)group_size, (float)eps,
+                                            (float)min_8bit, (float)max_8bit, dtype_code(in_t, "input"),
+                                            dtype_code(q_t, "output_q"), kind, s_row, s_col));
+}
+
+// ---- fp8 blockwise GEMM (declared only: reference include/sgl_kernel_ops.h:581-586) ----------
+
+Tensor fp8_blockwise_scaled_mm(const Tensor& mat_a, const Tensor& mat_b, const Tensor& scales_a,
+                               const Tensor& scales_b, at::ScalarType out_dtype) {
+  CHECK_GPU(mat_a);
+  CHECK_GPU(mat_b);
+  CHECK_GPU(scales_a);
+  CHECK_GPU(scales_b);
+  TORCH_CHECK(mat_a.dim() == 2 && mat_b.dim() == 2, "mat_a and mat_b must be 2-D");
+  TORCH_CHECK(mat_a.stride(1) == 1, "mat_a must be a row major tensor");
+  TORCH_CHECK(mat_b.stride(0) == 1, "mat_b must be a column major tensor");
+  TORCH_CHECK(mat_a.size(1) == mat_b.size(0), "mat_a and mat_b shapes cannot be multiplied");
+  TORCH_CHECK(mat_a.scalar_type() == at::kFloat8_e4m3fn, "mat_a must be Float8_e4m3fn");
+  TORCH_CHECK(mat_b.scalar_type() == at::kFloat8_e4m3fn, "mat_b must be Float8_e4m3fn");
+  TORCH_CHECK(out_dtype == at::kHalf || out_dtype == at::kBFloat16, "out_dtype must be Half or BFloat16");
+  TORCH_CHECK(scales_a.scalar_type() == at::kFloat && scales_b.scalar_type() == at::kFloat,
+              "scales_a and scales_b must be Float32");
+  const int64_t M = mat_a.size(0), K = mat_a.size(1), N = mat_b.size(1);
+  TORCH_CHECK(K % 128 == 0, "mat_a.size(1) must be a multiple of 128 (one scale per 128-deep block)");
+  const int64_t kb = K / 128, nb = (N + 127) / 128;
+  TORCH_CHECK(scales_a.dim() == 2 && scales_a.size(0) == M && scales_a.size(1) == kb,
+              "scales_a must have shape [M, K/128]");
+  TORCH_CHECK(scales_b.dim() == 2 && scales_b.size(0) == kb && scales_b.size(1) == nb,
+              "scales_b must have shape [K/128, ceil(N/128)]");
+  Tensor out = at::empty({M, N}, mat_a.options().dtype(out_dtype));
+  if (M == 0) return out;
+  const c10::OptionalDeviceGuard guard(mat_a.device());
+  SGLK_CALL(sglk_fp8_blockwise_scaled_mm(stream_of(mat_a), out.data_ptr(), mat_a.data_ptr(), mat_b.data_ptr(),
+                                         scales_a.data_ptr<float>(), scales_b.data_ptr<float>(), M, N, K,
+                                         mat_a.stride(0), mat_b.stride(1), out.stride(0), scales_a.stride(0),
+                                         scales_a.stride(1), scales_b.stride(0), scales_b.stride(1),
+                                         dtype_code(out_dtype, "out_dtype")));
+  return out;
+}
+
+}  // namespace
+
+TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
+  // reference src/torch_extension_sycl.cc:29-51
+  m.def("silu_and_mul(Tensor! out, Tensor input) -> ()");
+  m.impl("silu_and_mul", c10::kCUDA, &silu_and_mul);
+  m.def("gelu_tanh_and_mul(Tensor! out, Tensor input) -> ()");
+  m.impl("gelu_tanh_and_mul", c10::kCUDA, &gelu_tanh_and_mul);
+  m.def("gelu_and_mul(Tensor! out, Tensor input) -> ()");
+  m.impl("gelu_and_mul", c10::kCUDA, &gelu_and_mul);
+  m.def("rmsnorm(Tensor! output, Tensor input, Tensor weight, float eps) -> ()");
+  m.impl("rmsnorm", c10::kCUDA, &rmsnorm);
+  m.def("fused_add_rmsnorm(Tensor! input, Tensor! residual, Tensor weight, float eps) -> ()");
+  m.impl("fused_add_rmsnorm", c10::kCUDA, &fused_add_rmsnorm);
+  m.def("gemma_rmsnorm(Tensor! output, Tensor input, Tensor weight, float eps) -> ()");
+  m.impl("gemma_rmsnorm", c10::kCUDA, &gemma_rmsnorm);
+  m.def("gemma_fused_add_rmsnorm(Tensor! input, Tensor! residual, Tensor weight, float eps) -> ()");
+  m.impl("gemma_fused_add_rmsnorm", c10::kCUDA, &gemma_fused_add_rmsnorm);
+
+  // reference src/torch_extension_sycl.cc:395-398
+  m.def(
+      "sgl_per_token_group_quant_8bit(Tensor input, Tensor output_q, Tensor output_s, int group_size,"
+      " float eps, float fp8_min, float fp8_max, bool scale_ue8m0) -> ()");
+  m.impl("sgl_per_token_group_quant_8bit", c10::kCUDA, &sgl_per_token_group_quant_8bit);
+
+  // authored: reference include/sgl_kernel_ops.h:581-586 + python/sgl_kernel/gemm.py:24-31
+  m.def(
+      "fp8_blockwise_scaled_mm(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype)"
+      " -> Tensor");
+  m.impl("fp8_blockwise_scaled_mm", c10::kCUDA, &fp8_blockwise_scaled_mm);
+}
+
+// The loader does `from sgl_kernel import common_ops` (reference python/sgl_kernel/__init__.py:14);
+// registration above runs at dlopen, the module itself is empty (reference sgl_kernel_ops.h:37-41).
+extern "C" __attribute__((visibility("default"))) PyObject* PyInit_common_ops(void) {
+  static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "common_ops", nullptr, 0, nullptr};
+  return PyModule_Create(&module);
+}
