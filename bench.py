@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: per_token_group_quant_fp8 + fp8_blockwise_scaled_mm at the Llama-3-8B FFN
+shape (BASELINE.json configs[1]: M=4096, N=14336, K=4096, 128-block scales) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+quantise x[M,K] bf16 -> (e4m3, column-major 1x128 scales), then out = fp8_blockwise_scaled_mm(...)
+in bf16. value = whole-job GEMM TFLOP/s (2*M*N*K per step per GPU; the quant pass is inside the timed
+region). N > 1: the path does not shard (per-GPU leaf kernels, SURVEY.md section 8e: "replicas only"),
+so every rank runs an independent replica; rank 0 prints ONE JSON line.
+
+roofline.achieved is measured live with HIP events recorded on the launch stream around each GEMM
+launch of the timed region. cpu_baseline times the CPU oracle (torch eager, all host cores) on a row
+sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sgl-kernel-xpu_amd", "python")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+M, N, K = 4096, 14336, 4096
+GROUP = 128
+FP8 = torch.float8_e4m3fn
+PEAK_FP8_TFLOPS = 5000.0  # MI355X_MICROARCH.md: dense FP8 MFMA peak (MX K=128 form), 2:1 sparsity excluded
+PEAK_HBM_GBS = 8000.0
+
+
+def make_inputs(dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    # weights as tests/test_fp8_blockwise_gemm.py:66-80: uniform over the e4m3 range, [N,K] == column-major [K,N]
+    b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev).t()
+    sb = (torch.rand(N // 128, K // 128, generator=g) * 1e-3 + 1e-4).to(dev).t()  # column-major [K/128, N/128]
+    q = torch.empty(M, K, dtype=FP8, device=dev)
+    s = torch.empty(K // GROUP, M, dtype=torch.float32, device=dev).t()  # column-major [M, K/128]
+    return x, b, sb, q, s
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """CPU oracle on a bounded row sample of the same workload (same N, K; fewer rows)."""
+    from oracle import gemm as ogemm
+    from oracle import quant as oquant
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    rows = 256
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(rows, K, generator=g).to(torch.bfloat16)
+    b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).t()
+    sb = (torch.rand(N // 128, K // 128, generator=g) * 1e-3 + 1e-4).t()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        q, s, _ = oquant.per_token_group_quant_8bit(x, GROUP, FP8)
+        ogemm.fp8_blockwise_scaled_mm(q, b, s, sb, torch.bfloat16)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget or reps >= 8:
+            break
+    tflops = 2.0 * rows * N * K * reps / dt / 1e12
+    return {
+        "value": round(tflops, 4),
+        "unit": "TFLOP/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{reps} pass(es) of quant+GEMM on {rows} of {M} rows (same N={N}, K={K}), torch-eager oracle",
+    }
+
+
+def side_metrics(sgl_kernel, dev):
+    """HBM-bound companions of the path (BASELINE configs[0] shapes), reported as extra evidence."""
+    out = {}
+
+    def timeit(fn, iters=30):
+        for _ in range(5):
+            fn()
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        for _ in range(iters):
+            fn()
+        en.record()
+        torch.cuda.synchronize()
+        return st.elapsed_time(en) / iters
+
+    x = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(4096, device=dev, dtype=torch.bfloat16)
+    y = torch.empty_like(x)
+    ms = timeit(lambda: sgl_kernel.rmsnorm(x, w, 1e-6, out=y))
+    out["rmsnorm_4096x4096_bf16_GBs"] = round((2 * x.numel() * 2 + 4096 * 2) / ms / 1e6, 1)
+    x2 = torch.randn(4096, 8192, device=dev, dtype=torch.bfloat16)
+    o2 = torch.empty(4096, 4096, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: sgl_kernel.silu_and_mul(x2, out=o2))
+    out["silu_and_mul_4096x8192_bf16_GBs"] = round(3 * o2.numel() * 2 / ms / 1e6, 1)
+    q = torch.empty(4096, 4096, dtype=FP8, device=dev)
+    s = torch.empty(32, 4096, dtype=torch.float32, device=dev).t()
+    ms = timeit(lambda: sgl_kernel.sgl_per_token_group_quant_8bit(x, q, s, 128, 1e-10, -448.0, 448.0, False,
+                                                                   enable_v2=False))
+    out["per_token_group_quant_fp8_4096x4096_GBs"] = round((x.numel() * 3 + s.numel() * 4) / ms / 1e6, 1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import sgl_kernel
+
+    x, b, sb, q, s = make_inputs(dev, 0x561 + rank)
+
+    def quant():
+        sgl_kernel.sgl_per_token_group_quant_8bit(x, q, s, GROUP, 1e-10, -448.0, 448.0, False, enable_v2=False)
+
+    def gemm():
+        return sgl_kernel.fp8_blockwise_scaled_mm(q, b, s, sb, torch.bfloat16)
+
+    for _ in range(args.warmup):
+        quant()
+        gemm()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        quant()
+        ev[i][0].record()  # current stream == the stream the ops launch on
+        gemm()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    gemm_ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
+    gemm_avg_ms = sum(gemm_ms) / len(gemm_ms)
+
+    flop = 2.0 * M * N * K
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * flop / (ms_per_step * 1e-3) / 1e12
+    achieved = flop / (gemm_avg_ms * 1e-3) / 1e12
+
+    result = {
+        "metric": "achieved TFLOPS (fp8 GEMM) + GB/s (flash decode) at Llama-3-8B shapes, 1 GPU",
+        "value": round(value, 2),
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "fp8_e4m3",
+        "data": "synthetic",
+        "config": {
+            "workload": "per_token_group_quant_fp8 + fp8_blockwise_scaled_mm, Llama-3-8B FFN gate/up "
+                        "(M=4096, N=14336, K=4096, 1x128 / 128x128 fp32 block scales, bf16 out)",
+            "M": M, "N": N, "K": K, "parallelism": "replicas" if world > 1 else "single",
+        },
+        "roofline": {
+            "bound": "mfma",
+            "kernel": "gemm_8bit_kernel<bf16, blockwise>",
+            "achieved": round(achieved, 2),
+            "peak": PEAK_FP8_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP8_TFLOPS, 4),
+            "traffic": None,
+            "kernel_ms_avg": round(gemm_avg_ms, 4),
+            "kernel_ms_median": round(gemm_ms[len(gemm_ms) // 2], 4),
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_extra:
+            result["extra"] = side_metrics(sgl_kernel, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

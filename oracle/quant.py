@@ -1,0 +1,50 @@
+"""Per-token-group 8-bit quantisation — restates the reference kernel
+src/sycl/per_token_group_quant_8bit.cpp:86-207 step for step in IEEE fp32:
+
+  amax = max(eps, max|x|)              :97, :139-141
+  y_s  = amax / qmax                   :157
+  ue8m0: e = ceil(log2(max(y_s,1e-10))), y_s = 2^e, byte = e + 127    :161-165
+  q    = cast(min(max(x * (1 / y_s), qmin), qmax))                    :171, :185
+  fp8 e4m3fn cast rounds to nearest even; the int8 cast truncates      :191-196
+
+Every step is an exactly-rounded fp32 operation, so the HIP kernel is compared
+BIT-EXACTLY with this (codes and scales). Pinned against golden vectors from
+tests/test_per_token_group_quant_8bit.py:17-54 (tolerances of :260-276; ue8m0
+bytes exact as :405). ceil(log2) is evaluated on the float's exponent/mantissa
+bits, which is the exact value of the reference's ceil(log2(.)) expression.
+"""
+import torch
+
+FP8_MAX = 448.0
+
+
+def _ceil_log2_exact(y: torch.Tensor) -> torch.Tensor:
+    bits = y.contiguous().view(torch.int32)
+    e = ((bits >> 23) & 0xFF) - 127
+    return e + ((bits & 0x7FFFFF) != 0).to(torch.int32)
+
+
+def per_token_group_quant_8bit(x: torch.Tensor, group_size: int, dst_dtype: torch.dtype, eps: float = 1e-10,
+                               qmin: float = None, qmax: float = None, scale_ue8m0: bool = False):
+    """x [rows, k] -> (q [rows, k] dst_dtype, scales [rows, k/group] fp32, ue8m0 bytes or None)."""
+    assert x.dim() == 2 and x.shape[1] % group_size == 0
+    if qmax is None:
+        qmax = FP8_MAX if dst_dtype == torch.float8_e4m3fn else 127.0
+    if qmin is None:
+        qmin = -qmax
+    rows, k = x.shape
+    xf = x.float().view(rows, k // group_size, group_size)
+    amax = xf.abs().amax(dim=-1).clamp_min(torch.tensor(eps, dtype=torch.float32))
+    y_s = amax / torch.tensor(qmax, dtype=torch.float32)
+    ue = None
+    if scale_ue8m0:
+        e = _ceil_log2_exact(y_s.clamp_min(torch.tensor(1e-10, dtype=torch.float32)))
+        ue = (e + 127).to(torch.uint8)
+        y_s = ((e + 127) << 23).to(torch.int32).view(torch.float32)
+    inv = 1.0 / y_s
+    qv = (xf * inv.unsqueeze(-1)).clamp(min=qmin, max=qmax)
+    if dst_dtype == torch.int8:
+        q = qv.to(torch.int32).to(torch.int8)  # float -> int conversion truncates toward zero
+    else:
+        q = qv.to(torch.float8_e4m3fn)
+    return q.view(rows, k), y_s, ue

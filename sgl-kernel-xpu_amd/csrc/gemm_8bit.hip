@@ -1,5 +1,7 @@
-// fp8_blockwise_scaled_mm for gfx950 (DeepSeek-style 1x128 / 128x128 block scales).
+// 8-bit scaled GEMMs for gfx950: fp8_blockwise_scaled_mm (DeepSeek-style 1x128 /
+// 128x128 block scales), fp8_scaled_mm and int8_scaled_mm (per-token x per-channel).
 //
+// ---- fp8_blockwise_scaled_mm ----
 // The reference only declares this op (include/sgl_kernel_ops.h:581-586) and
 // pins its meaning with tests/test_fp8_blockwise_gemm.py:23-85:
 //   out = T( (sa (x) a) @ (sb (x) b) ),  a [M,K] e4m3 row-major, b [K,N] e4m3
@@ -25,6 +27,16 @@
 // ds_read_b128 of a fragment conflict-free: lane (row j, k-group g) reads
 // chunks g and g+4. That k order is the same for both operands, so the MFMA
 // pairs equal k.
+//
+// ---- fp8_scaled_mm / int8_scaled_mm ----
+// Declared only in the reference (include/sgl_kernel_ops.h:567-580); meaning pinned by
+// tests/test_fp8_gemm.py:11-19 and tests/test_int8_gemm.py:16-22. Same tile, staging and
+// fragment addressing; the MFMA accumulates across K blocks directly (fp8: the MX K=128
+// form; int8: two v_mfma_i32_16x16x64_i8 per block) and the scales are applied once in the
+// epilogue:  fp8 : out = T(T(acc * sa[m] * sb[n]) + bias[n])   (bias added in T, after the cast)
+//            int8: out = T(float(acc) * sa[m] * sb[n] + bias[n]) (bias added in fp32)
+#include <type_traits>
+
 #include "common.h"
 
 namespace sglk {
@@ -51,21 +63,33 @@ __device__ __forceinline__ v8i read_frag(const char* tile, int off) {
   return r;
 }
 
+enum { MODE_BLOCKWISE = 0, MODE_FP8_ROWCOL = 1, MODE_INT8_ROWCOL = 2 };
+
+// fp8 e4m3 x e4m3, K = 128, D = A*B + C
 template <bool HW_SCALE>
-__device__ __forceinline__ v4f mfma_k128(const v8i& a, const v8i& b) {
-  const v4f z = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ v4f mfma_k128(const v8i& a, const v8i& b, const v4f& c) {
   if constexpr (HW_SCALE) {
     // E8M0 127 == 2^0 for both operands
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, z, 0, 0, 0, 127, 0, 127);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
   } else {
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, z, 0, 0, 0, 0, 0, 0);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
   }
 }
 
-template <typename OutT, bool VEC_STORE, bool HW_SCALE>
-__global__ __launch_bounds__(512) void fp8_blockwise_gemm_kernel(
+// int8 x int8, K = 128 as two K = 64 steps (each operand half is one 16-byte read)
+__device__ __forceinline__ v4i mfma_i8_k128(const v8i& a, const v8i& b, v4i c) {
+  const v4i a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
+  const v4i b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+  c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, c, 0, 0, 0);
+  return c;
+}
+
+template <typename OutT, int MODE, bool VEC_STORE, bool HW_SCALE>
+__global__ __launch_bounds__(512) void gemm_8bit_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-    const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda,
+    const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N,
+    int K, int64_t lda,
     int64_t ldb, int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m,
     int tiles_n) {
   __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
@@ -124,9 +148,11 @@ __global__ __launch_bounds__(512) void fp8_blockwise_gemm_kernel(
       __builtin_amdgcn_global_load_lds(SGLK_GLB(bg + off_b[i]),
                                        SGLK_LDS(base + kTileBytes + (wave * 4 + i) * 1024), 16, 0, 0);
     }
-    if (wave < 4) {
-      __builtin_amdgcn_global_load_lds(SGLK_GLB(sa_lane + (int64_t)kb * sa_sk),
-                                       SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, 0, 0);
+    if constexpr (MODE == MODE_BLOCKWISE) {
+      if (wave < 4) {
+        __builtin_amdgcn_global_load_lds(SGLK_GLB(sa_lane + (int64_t)kb * sa_sk),
+                                         SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, 0, 0);
+      }
     }
   };
 
@@ -138,11 +164,14 @@ __global__ __launch_bounds__(512) void fp8_blockwise_gemm_kernel(
   nblk = nblk < nblk_max ? nblk : nblk_max;
   const float* sb_wave = sb + (int64_t)nblk * sb_sn;
 
-  v4f acc[8][4];
+  using AccT = typename std::conditional<MODE == MODE_INT8_ROWCOL, v4i, v4f>::type;
+  AccT acc[8][4];
 #pragma unroll
   for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mf][nf][r] = 0;
 
   const int nkb = K / BK;
   stage(0, 0);
@@ -156,36 +185,53 @@ __global__ __launch_bounds__(512) void fp8_blockwise_gemm_kernel(
 
     const char* ta = smem + s * kStageBytes;  // rows of a   -> MFMA B operand (columns = m)
     const char* tb = ta + kTileBytes;         // rows of b^T -> MFMA A operand (rows = n)
-    const float* ts = reinterpret_cast<const float*>(ta + 2 * kTileBytes);
-    const float sbv = sb_wave[(int64_t)kb * sb_sk];
 
     v8i nfr[4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) nfr[nf] = read_frag(tb, (wn * 64 + nf * 16) * 128 + frag_off);
 
-    v4f prev[4];
-    float sprev = 0.f;
+    if constexpr (MODE == MODE_BLOCKWISE) {
+      const float* ts = reinterpret_cast<const float*>(ta + 2 * kTileBytes);
+      const float sbv = sb_wave[(int64_t)kb * sb_sk];
+      const v4f zero = {0.f, 0.f, 0.f, 0.f};
+      v4f prev[4];
+      float sprev = 0.f;
 #pragma unroll
-    for (int mf = 0; mf < 8; ++mf) {
-      const v8i mfr = read_frag(ta, (wm * 128 + mf * 16) * 128 + frag_off);
-      const float sc = ts[wm * 128 + mf * 16 + j] * sbv;
-      v4f cur[4];
+      for (int mf = 0; mf < 8; ++mf) {
+        const v8i mfr = read_frag(ta, (wm * 128 + mf * 16) * 128 + frag_off);
+        const float sc = ts[wm * 128 + mf * 16 + j] * sbv;
+        v4f cur[4];
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) cur[nf] = mfma_k128<HW_SCALE>(nfr[nf], mfr);
-      if (mf > 0) {
+        for (int nf = 0; nf < 4; ++nf) cur[nf] = mfma_k128<HW_SCALE>(nfr[nf], mfr, zero);
+        if (mf > 0) {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
+          for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mf - 1][nf][r] = __builtin_fmaf(prev[nf][r], sprev, acc[mf - 1][nf][r]);
+            for (int r = 0; r < 4; ++r)
+              acc[mf - 1][nf][r] = __builtin_fmaf(prev[nf][r], sprev, acc[mf - 1][nf][r]);
+        }
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) prev[nf] = cur[nf];
+        sprev = sc;
       }
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) prev[nf] = cur[nf];
-      sprev = sc;
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[7][nf][r] = __builtin_fmaf(prev[nf][r], sprev, acc[7][nf][r]);
+    } else {
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf) {
+        const v8i mfr = read_frag(ta, (wm * 128 + mf * 16) * 128 + frag_off);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          if constexpr (MODE == MODE_INT8_ROWCOL) {
+            acc[mf][nf] = mfma_i8_k128(nfr[nf], mfr, acc[mf][nf]);
+          } else {
+            acc[mf][nf] = mfma_k128<HW_SCALE>(nfr[nf], mfr, acc[mf][nf]);
+          }
+        }
+      }
     }
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[7][nf][r] = __builtin_fmaf(prev[nf][r], sprev, acc[7][nf][r]);
   }
 
   // ---- epilogue: lane owns out[m = .. + j][n = .. + 4g .. 4g+3]
@@ -194,49 +240,80 @@ __global__ __launch_bounds__(512) void fp8_blockwise_gemm_kernel(
     const int m = m0 + wm * 128 + mf * 16 + j;
     if (m >= M) continue;
     OutT* orow = out + (int64_t)m * ldc;
+    float sam = 1.f;
+    if constexpr (MODE != MODE_BLOCKWISE) sam = sa[m];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
       const int n = n0 + wn * 64 + nf * 16 + g * 4;
+      OutT v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (MODE == MODE_BLOCKWISE) {
+          v[r] = (OutT)acc[mf][nf][r];
+        } else {
+          const int nn = (n + r < N) ? (n + r) : (N - 1);
+          const float t = ((float)acc[mf][nf][r] * sam) * sb[nn];
+          if constexpr (MODE == MODE_FP8_ROWCOL) {
+            v[r] = (OutT)t;
+            if (bias != nullptr) v[r] = (OutT)((float)v[r] + (float)bias[nn]);
+          } else {
+            v[r] = (bias != nullptr) ? (OutT)(t + (float)bias[nn]) : (OutT)t;
+          }
+        }
+      }
       if constexpr (VEC_STORE) {
         if (n < N) {
-          Vec<OutT, 4> v;
+          Vec<OutT, 4> vv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (OutT)acc[mf][nf][r];
-          store_vec<OutT, 4>(orow + n, v);
+          for (int r = 0; r < 4; ++r) vv[r] = v[r];
+          store_vec<OutT, 4>(orow + n, vv);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (n + r < N) orow[n + r] = (OutT)acc[mf][nf][r];
+          if (n + r < N) orow[n + r] = v[r];
       }
     }
   }
 }
 
-template <typename OutT>
+template <typename OutT, int MODE>
 static int launch(hipStream_t st, void* out, const void* a, const void* b, const float* sa, const float* sb,
-                  int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_sm,
-                  int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, bool hw_scale) {
+                  const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                  int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, bool hw_scale) {
   const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
   const unsigned grid = (unsigned)(tiles_m * tiles_n);
   const bool vec = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)out % 8 == 0);
-#define SGLK_GO(V, H)                                                                                  \
-  fp8_blockwise_gemm_kernel<OutT, V, H><<<grid, 512, 0, st>>>(                                         \
-      (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc, \
-      sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
+#define SGLK_GO(V, H)                                                                                       \
+  gemm_8bit_kernel<OutT, MODE, V, H><<<grid, 512, 0, st>>>(                                                 \
+      (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
+      lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
   if (vec) {
     if (hw_scale) SGLK_GO(true, true); else SGLK_GO(true, false);
   } else {
     if (hw_scale) SGLK_GO(false, true); else SGLK_GO(false, false);
   }
 #undef SGLK_GO
-  return check_launch("fp8_blockwise_scaled_mm");
+  return check_launch("gemm_8bit");
+}
+
+static int check_common(const char* op, const void* a, const void* b, int64_t M, int64_t N, int64_t K,
+                        int64_t lda, int64_t ldb, int out_dtype) {
+  SGLK_REQUIRE(M >= 0 && N > 0 && K > 0, "%s: bad shape M=%lld N=%lld K=%lld", op, (long long)M, (long long)N,
+               (long long)K);
+  SGLK_REQUIRE(K % 128 == 0, "%s: K=%lld must be a multiple of 128", op, (long long)K);
+  SGLK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "%s: shape too large", op);
+  SGLK_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0,
+               "%s: mat_a / mat_b rows must be 16-byte aligned", op);
+  SGLK_REQUIRE(lda * 256 < (1ll << 32) && ldb * 256 < (1ll << 32), "%s: leading dimension too large", op);
+  SGLK_REQUIRE(out_dtype == SGLK_BF16 || out_dtype == SGLK_F16, "%s: out_dtype must be Half or BFloat16", op);
+  return SGLK_OK;
 }
 
 }  // namespace
 }  // namespace sglk
 
-// Test hook: 0 selects the plain (non-MX) encoding of the K=128 MFMA, 1 (default) the MX
+// Test hook: 0 selects the plain (non-MX) encoding of the K=128 fp8 MFMA, 1 (default) the MX
 // encoding with unit scales. Both must give identical results.
 static int g_fp8_hw_scale = 1;
 extern "C" SGLK_API void sglk_debug_set_fp8_mfma_form(int hw_scale) { g_fp8_hw_scale = hw_scale; }
@@ -247,20 +324,32 @@ extern "C" int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, con
                                             int64_t sa_stride_m, int64_t sa_stride_k,
                                             int64_t sb_stride_k, int64_t sb_stride_n, int out_dtype) {
   using namespace sglk;
-  SGLK_REQUIRE(M >= 0 && N > 0 && K > 0, "fp8_blockwise_scaled_mm: bad shape M=%lld N=%lld K=%lld",
-               (long long)M, (long long)N, (long long)K);
-  SGLK_REQUIRE(K % 128 == 0, "fp8_blockwise_scaled_mm: K=%lld must be a multiple of 128", (long long)K);
-  SGLK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "fp8_blockwise_scaled_mm: shape too large");
-  SGLK_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0,
-               "fp8_blockwise_scaled_mm: mat_a / mat_b rows must be 16-byte aligned");
-  SGLK_REQUIRE(lda * 256 < (1ll << 32) && ldb * 256 < (1ll << 32), "fp8_blockwise_scaled_mm: leading dimension too large");
-  SGLK_REQUIRE(out_dtype == SGLK_BF16 || out_dtype == SGLK_F16,
-               "fp8_blockwise_scaled_mm: out_dtype must be Half or BFloat16");
+  if (int rc = check_common("fp8_blockwise_scaled_mm", a, b, M, N, K, lda, ldb, out_dtype)) return rc;
   if (M == 0) return SGLK_OK;
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == SGLK_BF16)
-    return launch<bf16>(st, out, a, b, sa, sb, M, N, K, lda, ldb, ldc, sa_stride_m, sa_stride_k, sb_stride_k,
-                        sb_stride_n, g_fp8_hw_scale != 0);
-  return launch<f16>(st, out, a, b, sa, sb, M, N, K, lda, ldb, ldc, sa_stride_m, sa_stride_k, sb_stride_k,
-                     sb_stride_n, g_fp8_hw_scale != 0);
+    return launch<bf16, MODE_BLOCKWISE>(st, out, a, b, sa, sb, nullptr, M, N, K, lda, ldb, ldc, sa_stride_m,
+                                        sa_stride_k, sb_stride_k, sb_stride_n, g_fp8_hw_scale != 0);
+  return launch<f16, MODE_BLOCKWISE>(st, out, a, b, sa, sb, nullptr, M, N, K, lda, ldb, ldc, sa_stride_m,
+                                     sa_stride_k, sb_stride_k, sb_stride_n, g_fp8_hw_scale != 0);
+}
+
+extern "C" int sglk_scaled_mm(sglk_stream_t stream, void* out, const void* a, const void* b, const float* sa,
+                              const float* sb, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
+                              int64_t ldb, int64_t ldc, int in_dtype, int out_dtype) {
+  using namespace sglk;
+  const char* op = in_dtype == SGLK_INT8 ? "int8_scaled_mm" : "fp8_scaled_mm";
+  SGLK_REQUIRE(in_dtype == SGLK_INT8 || in_dtype == SGLK_FP8_E4M3, "scaled_mm: inputs must be Int8 or Float8_e4m3fn");
+  if (int rc = check_common(op, a, b, M, N, K, lda, ldb, out_dtype)) return rc;
+  if (M == 0) return SGLK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool hw = g_fp8_hw_scale != 0;
+  if (in_dtype == SGLK_INT8) {
+    if (out_dtype == SGLK_BF16)
+      return launch<bf16, MODE_INT8_ROWCOL>(st, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, hw);
+    return launch<f16, MODE_INT8_ROWCOL>(st, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, hw);
+  }
+  if (out_dtype == SGLK_BF16)
+    return launch<bf16, MODE_FP8_ROWCOL>(st, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, hw);
+  return launch<f16, MODE_FP8_ROWCOL>(st, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, hw);
 }

@@ -237,6 +237,53 @@ Tensor fp8_blockwise_scaled_mm(const Tensor& mat_a, const Tensor& mat_b, const T
   return out;
 }
 
+// ---- fp8 / int8 per-token x per-channel GEMM (declared only: reference
+// include/sgl_kernel_ops.h:567-580; call order python/sgl_kernel/gemm.py:13-42) -----------------
+
+Tensor scaled_mm_impl(const Tensor& mat_a, const Tensor& mat_b, const Tensor& scales_a, const Tensor& scales_b,
+                      at::ScalarType out_dtype, const std::optional<Tensor>& bias, bool is_int8, const char* name) {
+  CHECK_GPU(mat_a);
+  CHECK_GPU(mat_b);
+  CHECK_GPU(scales_a);
+  CHECK_GPU(scales_b);
+  TORCH_CHECK(mat_a.dim() == 2 && mat_b.dim() == 2, name, ": mat_a and mat_b must be 2-D");
+  TORCH_CHECK(mat_a.stride(1) == 1, name, ": mat_a must be a row major tensor");
+  TORCH_CHECK(mat_b.stride(0) == 1, name, ": mat_b must be a column major tensor");
+  TORCH_CHECK(mat_a.size(1) == mat_b.size(0), name, ": mat_a and mat_b shapes cannot be multiplied");
+  const auto want = is_int8 ? at::kChar : at::kFloat8_e4m3fn;
+  TORCH_CHECK(mat_a.scalar_type() == want && mat_b.scalar_type() == want, name, ": mat_a and mat_b must be ", want);
+  TORCH_CHECK(out_dtype == at::kHalf || out_dtype == at::kBFloat16, name, ": out_dtype must be Half or BFloat16");
+  const int64_t M = mat_a.size(0), K = mat_a.size(1), N = mat_b.size(1);
+  TORCH_CHECK(scales_a.numel() == M && scales_a.is_contiguous() && scales_a.scalar_type() == at::kFloat, name,
+              ": scales_a must be a contiguous Float32 tensor of M elements");
+  TORCH_CHECK(scales_b.numel() == N && scales_b.is_contiguous() && scales_b.scalar_type() == at::kFloat, name,
+              ": scales_b must be a contiguous Float32 tensor of N elements");
+  const void* bias_ptr = nullptr;
+  if (bias.has_value()) {
+    TORCH_CHECK(bias->numel() == N && bias->is_contiguous() && bias->scalar_type() == out_dtype, name,
+                ": bias must be a contiguous tensor of N elements of out_dtype");
+    CHECK_GPU(*bias);
+    bias_ptr = bias->data_ptr();
+  }
+  Tensor out = at::empty({M, N}, mat_a.options().dtype(out_dtype));
+  if (M == 0) return out;
+  const c10::OptionalDeviceGuard guard(mat_a.device());
+  SGLK_CALL(sglk_scaled_mm(stream_of(mat_a), out.data_ptr(), mat_a.data_ptr(), mat_b.data_ptr(),
+                           scales_a.data_ptr<float>(), scales_b.data_ptr<float>(), bias_ptr, M, N, K,
+                           mat_a.stride(0), mat_b.stride(1), out.stride(0),
+                           is_int8 ? SGLK_INT8 : SGLK_FP8_E4M3, dtype_code(out_dtype, "out_dtype")));
+  return out;
+}
+
+Tensor fp8_scaled_mm(const Tensor& mat_a, const Tensor& mat_b, const Tensor& scales_a, const Tensor& scales_b,
+                     at::ScalarType out_dtype, const std::optional<Tensor>& bias) {
+  return scaled_mm_impl(mat_a, mat_b, scales_a, scales_b, out_dtype, bias, false, "fp8_scaled_mm");
+}
+Tensor int8_scaled_mm(const Tensor& mat_a, const Tensor& mat_b, const Tensor& scales_a, const Tensor& scales_b,
+                      at::ScalarType out_dtype, const std::optional<Tensor>& bias) {
+  return scaled_mm_impl(mat_a, mat_b, scales_a, scales_b, out_dtype, bias, true, "int8_scaled_mm");
+}
+
 }  // namespace
 
 TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
@@ -267,6 +314,15 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "fp8_blockwise_scaled_mm(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype)"
       " -> Tensor");
   m.impl("fp8_blockwise_scaled_mm", c10::kCUDA, &fp8_blockwise_scaled_mm);
+  // authored: reference include/sgl_kernel_ops.h:567-580 + python/sgl_kernel/gemm.py:13-42
+  m.def(
+      "fp8_scaled_mm(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype,"
+      " Tensor? bias) -> Tensor");
+  m.impl("fp8_scaled_mm", c10::kCUDA, &fp8_scaled_mm);
+  m.def(
+      "int8_scaled_mm(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype,"
+      " Tensor? bias) -> Tensor");
+  m.impl("int8_scaled_mm", c10::kCUDA, &int8_scaled_mm);
 }
 
 // The loader does `from sgl_kernel import common_ops` (reference python/sgl_kernel/__init__.py:14);

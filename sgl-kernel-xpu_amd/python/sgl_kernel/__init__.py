@@ -29,6 +29,8 @@ from sgl_kernel.elementwise import (  # noqa: E402
 )
 from sgl_kernel.gemm import (  # noqa: E402
     fp8_blockwise_scaled_mm,
+    fp8_scaled_mm,
+    int8_scaled_mm,
     sgl_per_token_group_quant_8bit,
     sgl_per_token_group_quant_fp8,
     sgl_per_token_group_quant_int8,

@@ -9,6 +9,30 @@ from typing import Optional
 import torch
 
 
+def int8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
+    """``(mat_a @ mat_b) * scales_a[:, None] * scales_b[None, :] (+ bias)``; int8 in, int32 accumulate."""
+    return torch.ops.sgl_kernel.int8_scaled_mm.default(
+        mat_a,
+        mat_b,
+        scales_a,
+        scales_b,
+        out_dtype,
+        bias,
+    )
+
+
+def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
+    """``(mat_a @ mat_b) * scales_a[:, None] * scales_b[None, :] (+ bias)``; e4m3fn in, fp32 accumulate."""
+    return torch.ops.sgl_kernel.fp8_scaled_mm.default(
+        mat_a,
+        mat_b,
+        scales_a,
+        scales_b,
+        out_dtype,
+        bias,
+    )
+
+
 def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
     """``(scales_a (x) mat_a) @ (scales_b (x) mat_b)`` with 1x128 / 128x128 fp32 block
     scales; mat_a [M,K] e4m3fn row-major, mat_b [K,N] e4m3fn column-major."""

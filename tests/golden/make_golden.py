@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE's own torch-eager test references.
+
+Runs only in the authoring container (needs /root/reference). The reference
+package cannot be imported (its `common_ops` SYCL extension cannot be built
+here), so a stub module named `sgl_kernel` is seeded into sys.modules and the
+pure-torch reference functions are imported from /root/reference/tests/*.py.
+They are run on small seeded inputs; inputs and expected outputs are written to
+tests/golden/*.pt as plain tensors. Nothing from the reference travels: the
+fixtures are data only.
+
+    python tests/golden/make_golden.py
+"""
+import importlib
+import os
+import sys
+import types
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_TESTS = "/root/reference/tests"
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+
+        def _missing(*a, **k):
+            raise RuntimeError(f"stub sgl_kernel.{name} called while generating golden vectors")
+
+        return _missing
+
+
+def _import_ref(name):
+    sys.modules.setdefault("sgl_kernel", _Stub("sgl_kernel"))
+    if REF_TESTS not in sys.path:
+        sys.path.insert(0, REF_TESTS)
+    return importlib.import_module(name)
+
+
+def save(name, obj):
+    path = os.path.join(HERE, name + ".pt")
+    torch.save(obj, path)
+    print("wrote %-28s %7.1f KiB" % (name + ".pt", os.path.getsize(path) / 1024))
+
+
+def gen_norm():
+    t = _import_ref("test_norm")
+    cases = []
+    g = torch.Generator().manual_seed(0)
+    for rows, n, dt in [(19, 1024, torch.float16), (7, 111, torch.float16), (5, 3072, torch.bfloat16),
+                        (3, 500, torch.float32), (2, 8192, torch.float16)]:
+        x = torch.randn(rows, n, generator=g).to(dt)
+        r = torch.randn(rows, n, generator=g).to(dt)
+        w = torch.randn(n, generator=g).to(dt)
+        fa_y, fa_r = t.fused_add_rms_norm(x.clone(), r.clone(), w, 1e-6)
+        ga_y, ga_r = t.gemma_fused_add_rms_norm(x.clone(), r.clone(), w, 1e-6)
+        cases.append(dict(x=x, residual=r, w=w, eps=1e-6,
+                          rmsnorm=t.llama_rms_norm(x, w, 1e-6),
+                          gemma_rmsnorm=t.gemma_rms_norm(x, w, 1e-6),
+                          fused_add=(fa_y, fa_r), gemma_fused_add=(ga_y, ga_r)))
+    save("norm", cases)
+
+
+def gen_activation():
+    # tests/test_activation.py:18,28,38 are inline expressions; evaluate those expressions here
+    import torch.nn.functional as F
+    cases = []
+    g = torch.Generator().manual_seed(1)
+    for shape, dt in [((2, 4, 256), torch.float16), ((3, 1, 1024), torch.float16), ((5, 2, 4096), torch.bfloat16)]:
+        x = torch.randn(*shape, generator=g).to(dt)
+        d = shape[-1] // 2
+        cases.append(dict(x=x,
+                          silu=x[..., d:] * F.silu(x[..., :d]),
+                          gelu_tanh=x[..., d:] * F.gelu(x[..., :d], approximate="tanh"),
+                          gelu=x[..., d:] * F.gelu(x[..., :d], approximate="none")))
+    save("activation", cases)
+
+
+def gen_quant():
+    t = _import_ref("test_per_token_group_quant_8bit")
+    cases = []
+    g = torch.Generator().manual_seed(42)
+    for rows, k, gs, dt, scale in [(5, 512, 128, torch.bfloat16, 1.0), (40, 2048, 128, torch.float16, 1.0),
+                                   (7, 256, 64, torch.float32, 1.0), (9, 1024, 128, torch.bfloat16, 1e-3),
+                                   (9, 1024, 128, torch.bfloat16, 100.0), (4, 256, 32, torch.bfloat16, 1.0)]:
+        x = (torch.randn(rows, k, generator=g) * scale).to(dt)
+        q8, s8 = t.per_token_group_quant_fp8_ref(x, gs, 1e-10, False)
+        qu, su = t.per_token_group_quant_fp8_ref(x, gs, 1e-10, True)
+        qi, si = t.per_token_group_quant_int8_ref(x, gs, 1e-10)
+        cases.append(dict(x=x, group_size=gs, fp8_q=q8.view(torch.uint8), fp8_s=s8,
+                          fp8_ue8m0_q=qu.view(torch.uint8), fp8_ue8m0_s=su, int8_q=qi, int8_s=si))
+    save("quant", cases)
+
+
+def gen_fp8_blockwise():
+    t = _import_ref("test_fp8_blockwise_gemm")
+    cases = []
+    torch.manual_seed(0)
+    fmax = torch.finfo(torch.float8_e4m3fn).max
+    for M, N, K, dt in [(1, 128, 512, torch.bfloat16), (5, 512, 1024, torch.float16), (127, 128, 512, torch.bfloat16),
+                        (33, 384, 256, torch.bfloat16)]:
+        a = ((torch.rand(M, K) - 0.5) * 2 * fmax).clamp(-fmax, fmax).to(torch.float8_e4m3fn)
+        b = ((torch.rand(N, K) - 0.5) * 2 * fmax).clamp(-fmax, fmax).to(torch.float8_e4m3fn).t()
+        sa = (torch.randn(M, K // 128) * 0.001).t().contiguous().t()
+        sb = (torch.randn(K // 128, (N + 127) // 128) * 0.001).t().contiguous().t()
+        out = t.baseline_scaled_mm(a, b, sa, sb, dt)
+        cases.append(dict(a=a.view(torch.uint8), b_nk=b.t().contiguous().view(torch.uint8), sa=sa.contiguous(),
+                          sb=sb.contiguous(), out_dtype=dt, out=out))
+    save("fp8_blockwise_gemm", cases)
+
+
+def gen_scaled_mm():
+    t8 = _import_ref("test_fp8_gemm")
+    sys.modules["utils"].is_sm10x = lambda: False  # tests/test_int8_gemm.py:7 imports a helper utils.py lacks
+    ti = _import_ref("test_int8_gemm")
+    cases = []
+    torch.manual_seed(0)
+    fmax = torch.finfo(torch.float8_e4m3fn).max
+    for M, N, K, dt, with_bias in [(1, 16, 512, torch.bfloat16, True), (17, 128, 1024, torch.float16, False),
+                                   (128, 512, 512, torch.bfloat16, True)]:
+        a = ((torch.rand(M, K) - 0.5) * 2 * fmax).clamp(-fmax, fmax).to(torch.float8_e4m3fn)
+        b = ((torch.rand(N, K) - 0.5) * 2 * fmax).clamp(-fmax, fmax).to(torch.float8_e4m3fn).t()
+        sa, sb = torch.randn(M) * 0.001, torch.randn(N) * 0.001
+        bias = torch.randn(N).to(dt) if with_bias else None
+        out = t8.torch_scaled_mm(a, b, sa, sb, dt, bias)
+        cases.append(dict(kind="fp8", a=a.view(torch.uint8), b_nk=b.t().contiguous().view(torch.uint8), sa=sa, sb=sb,
+                          bias=bias, out_dtype=dt, out=out))
+        ai = ti.to_int8(torch.randn(M, K) * 5)
+        bi = ti.to_int8(torch.randn(N, K).t() * 5)
+        sa, sb = torch.randn(M), torch.randn(N)
+        bias = (torch.randn(N).to(dt) * 10) if with_bias else None
+        out = ti.torch_scaled_mm(ai, bi, sa, sb, dt, bias)
+        cases.append(dict(kind="int8", a=ai, b_nk=bi.t().contiguous(), sa=sa, sb=sb, bias=bias, out_dtype=dt, out=out))
+    save("scaled_mm", cases)
+
+
+GENERATORS = {
+    "norm": gen_norm,
+    "activation": gen_activation,
+    "quant": gen_quant,
+    "fp8_blockwise_gemm": gen_fp8_blockwise,
+    "scaled_mm": gen_scaled_mm,
+}
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF_TESTS):
+        sys.exit("reference tests not found at %s (this script only runs in the authoring container)" % REF_TESTS)
+    names = sys.argv[1:] or list(GENERATORS)
+    for n in names:
+        GENERATORS[n]()

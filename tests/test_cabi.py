@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads without torch and exports every symbol include/sglk.h declares.
+No compute call is made (there is no GPU here); argument validation that happens before any
+HIP call is exercised."""
+import ctypes
+import os
+import re
+
+from conftest import PKG, ROOT
+
+LIB = os.path.join(PKG, "sgl_kernel", "libsglk.so")
+HEADER = os.path.join(ROOT, "include", "sglk.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sglk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_entry_points():
+    syms = declared_symbols()
+    assert "sglk_rmsnorm" in syms and "sglk_fp8_blockwise_scaled_mm" in syms
+    assert len(syms) >= 8
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "libsglk.so is not built: run python sgl-kernel-xpu_amd/build.py"
+    lib = ctypes.CDLL(LIB)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in sglk.h but not exported: {missing}"
+
+
+def test_identity_and_error_reporting():
+    lib = ctypes.CDLL(LIB)
+    lib.sglk_version.restype = ctypes.c_char_p
+    lib.sglk_arch.restype = ctypes.c_char_p
+    lib.sglk_last_error.restype = ctypes.c_char_p
+    assert lib.sglk_arch() == b"gfx950"
+    assert re.match(rb"\d+\.\d+\.\d+", lib.sglk_version())
+    # bad arguments are rejected before any device work: K not a multiple of 128
+    i64 = ctypes.c_int64
+    rc = lib.sglk_fp8_blockwise_scaled_mm(None, None, None, None, None, None, i64(4), i64(128), i64(100),
+                                          i64(112), i64(112), i64(128), i64(1), i64(4), i64(1), i64(1),
+                                          ctypes.c_int(2))
+    assert rc == -1
+    assert b"multiple of 128" in lib.sglk_last_error()
+    rc = lib.sglk_act_and_mul(None, None, None, i64(4), i64(-1), ctypes.c_int(2), ctypes.c_int(0))
+    assert rc == -1 and b"bad shape" in lib.sglk_last_error()
+
+
+def test_code_objects_are_gfx950_only():
+    # the fat binary inside libsglk.so must carry gfx950 code objects and nothing else
+    data = open(LIB, "rb").read()
+    archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", data))
+    assert archs == {b"gfx950"}, archs

@@ -1,0 +1,180 @@
+"""GPU parity: fp8_blockwise_scaled_mm, fp8_scaled_mm, int8_scaled_mm vs the CPU oracle.
+
+Input construction and tolerances follow reference tests/test_fp8_blockwise_gemm.py:66-91,
+tests/test_fp8_gemm.py:22-48 and tests/test_int8_gemm.py:25-47. Sizes the CPU oracle finishes in
+seconds are compared in full; the full BASELINE sizes are compared on a random sample of rows and
+columns (the GEMM is separable: out[rows][:, cols] depends only on a[rows] and b[:, cols]) plus an exact
+integer known-answer case that pins the MFMA operand/accumulator lane maps."""
+import ctypes
+import os
+
+import pytest
+import torch
+from conftest import PKG, load_golden
+
+from oracle import gemm as ogemm
+
+pytestmark = pytest.mark.gpu
+
+FP8 = torch.float8_e4m3fn
+FMAX = 448.0
+
+
+def make_blockwise(M, N, K, seed, scale_mag=1e-3):
+    g = torch.Generator().manual_seed(seed)
+    a = ((torch.rand(M, K, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8)
+    b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8).t()
+    sa = (torch.randn(M, K // 128, generator=g) * scale_mag).t().contiguous().t()
+    sb = (torch.randn(K // 128, (N + 127) // 128, generator=g) * scale_mag).t().contiguous().t()
+    return a, b, sa, sb
+
+
+def to_dev_colmajor(t, dev):
+    # keep the reference's layouts: b [K,N] with stride (1,K); scales column-major
+    return t.t().contiguous().to(dev).t()
+
+
+def run_blockwise(sglk, dev, a, b, sa, sb, dtype):
+    return sglk.fp8_blockwise_scaled_mm(a.to(dev), to_dev_colmajor(b, dev), to_dev_colmajor(sa, dev),
+                                        to_dev_colmajor(sb, dev), dtype).cpu()
+
+
+def test_mfma_lane_maps_known_answer(sglk, dev):
+    """Exact small-integer data, asymmetric in m, n and k: any transposed or permuted operand/accumulator
+    map, or a K sub-block pairing error, changes the (exactly representable) result."""
+    M, N, K = 256, 256, 256
+    m = torch.arange(M).view(M, 1)
+    n = torch.arange(N).view(N, 1)
+    k = torch.arange(K).view(1, K)
+    a = (((m * 7 + k * 3) % 5) - 2).float()          # values in {-2..2}
+    b = (((n * 11 + k * 5 + (k // 16)) % 7) - 3).float()  # values in {-3..3}
+    sa = torch.ones(M, K // 128)
+    sb = torch.ones(K // 128, N // 128)
+    sa[:, 1] = 2.0  # makes the two K blocks distinguishable
+    out = run_blockwise(sglk, dev, a.to(FP8), b.to(FP8).t(), sa, sb, torch.float16).float()
+    ref = a[:, :128] @ b[:, :128].t() + 2.0 * (a[:, 128:] @ b[:, 128:].t())
+    assert ref.abs().max() < 2048  # exactly representable in fp16
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("M", [1, 3, 5, 127, 128, 512])
+@pytest.mark.parametrize("N,K", [(128, 512), (512, 1024), (1024, 4096), (4096, 512), (14080, 1024), (8192, 8192)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fp8_blockwise(sglk, dev, M, N, K, dtype):
+    if M > 128 and N * K > 4096 * 4096:
+        pytest.skip("CPU oracle too slow; covered by the sampled full-size test")
+    a, b, sa, sb = make_blockwise(M, N, K, seed=M * 7 + N + K)
+    out = run_blockwise(sglk, dev, a, b, sa, sb, dtype)
+    ref = ogemm.fp8_blockwise_scaled_mm(a, b, sa, sb, dtype)
+    torch.testing.assert_close(out, ref, rtol=0.02, atol=1)  # reference tolerance (:83-85)
+    # the reference tolerance is loose for |out| ~ 1e-2; also require agreement to output rounding
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 14336, 4096), (4096, 4096, 14336), (1024, 14080, 16384), (1, 14336, 4096),
+                                   (16, 14336, 4096), (64, 4096, 14336), (300, 768, 384)])
+def test_fp8_blockwise_full_size_sampled(sglk, dev, M, N, K):
+    a, b, sa, sb = make_blockwise(M, N, K, seed=5)
+    out = run_blockwise(sglk, dev, a, b, sa, sb, torch.bfloat16)
+    g = torch.Generator().manual_seed(6)
+    rows = torch.randperm(M, generator=g)[:48].sort().values
+    nblk = torch.randperm((N + 127) // 128, generator=g)[:3].sort().values
+    cols = torch.cat([torch.arange(i * 128, min(N, (i + 1) * 128)) for i in nblk.tolist()])
+    ref = ogemm.fp8_blockwise_scaled_mm(a[rows], b[:, cols], sa[rows], sb[:, nblk], torch.bfloat16)
+    torch.testing.assert_close(out[rows][:, cols].float(), ref.float(), rtol=2e-2, atol=2e-3)
+    # tile edges: last rows / last columns are written, nothing is left unwritten
+    assert torch.isfinite(out.float()).all()
+    # linearity in the scales: doubling sa doubles every partial exactly (power-of-two scaling is exact in
+    # fp32 and bf16), so the outputs must be bit-identical up to the factor
+    out2 = run_blockwise(sglk, dev, a, b, sa * 2, sb, torch.bfloat16)
+    assert torch.equal(out2.float(), out.float() * 2)
+
+
+def test_fp8_mfma_encodings_agree(sglk, dev):
+    """The MX encoding with unit E8M0 scales and the plain K=128 encoding must be the same arithmetic."""
+    lib = ctypes.CDLL(os.path.join(PKG, "sgl_kernel", "libsglk.so"))
+    a, b, sa, sb = make_blockwise(200, 640, 1024, seed=9)
+    try:
+        lib.sglk_debug_set_fp8_mfma_form(1)
+        o1 = run_blockwise(sglk, dev, a, b, sa, sb, torch.bfloat16)
+        lib.sglk_debug_set_fp8_mfma_form(0)
+        o0 = run_blockwise(sglk, dev, a, b, sa, sb, torch.bfloat16)
+    finally:
+        lib.sglk_debug_set_fp8_mfma_form(1)
+    assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
+
+
+def test_fp8_blockwise_golden(sglk, dev):
+    for c in load_golden("fp8_blockwise_gemm"):
+        a = c["a"].view(FP8)
+        b = c["b_nk"].view(FP8).t()
+        out = run_blockwise(sglk, dev, a, b, c["sa"], c["sb"], c["out_dtype"])
+        torch.testing.assert_close(out, c["out"], rtol=0.02, atol=1)
+        torch.testing.assert_close(out.float(), c["out"].float(), rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("M", [1, 128, 512, 777])
+@pytest.mark.parametrize("N,K", [(16, 512), (128, 1024), (512, 4096), (4096, 512), (1024, 8192)])
+@pytest.mark.parametrize("with_bias", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fp8_scaled_mm(sglk, dev, M, N, K, with_bias, dtype):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = ((torch.rand(M, K, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8)
+    b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8).t()
+    sa = torch.randn(M, generator=g) * 0.001
+    sb = torch.randn(N, generator=g) * 0.001
+    bias = torch.randn(N, generator=g).to(dtype) if with_bias else None
+    out = sglk.fp8_scaled_mm(a.to(dev), to_dev_colmajor(b, dev), sa.to(dev), sb.to(dev), dtype,
+                             bias.to(dev) if with_bias else None).cpu()
+    ref = ogemm.fp8_scaled_mm(a, b, sa, sb, dtype, bias)
+    torch.testing.assert_close(out, ref, rtol=0.02, atol=1)  # tests/test_fp8_gemm.py:38-40
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M", [1, 16, 64, 512, 1000])
+@pytest.mark.parametrize("N,K", [(16, 512), (128, 1024), (1024, 4096), (8192, 512), (16384, 1024)])
+@pytest.mark.parametrize("with_bias", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_int8_scaled_mm(sglk, dev, M, N, K, with_bias, dtype):
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    a = torch.round((torch.randn(M, K, generator=g) * 5).clamp(-128, 127)).to(torch.int8)
+    b = torch.round((torch.randn(N, K, generator=g) * 5).clamp(-128, 127)).to(torch.int8).t()
+    sa = torch.randn(M, generator=g)
+    sb = torch.randn(N, generator=g)
+    bias = (torch.randn(N, generator=g).to(dtype) * 10) if with_bias else None
+    out = sglk.int8_scaled_mm(a.to(dev), to_dev_colmajor(b, dev), sa.to(dev), sb.to(dev), dtype,
+                              bias.to(dev) if with_bias else None).cpu()
+    ref = ogemm.int8_scaled_mm(a, b, sa, sb, dtype, bias)
+    torch.testing.assert_close(out, ref)  # default tolerances, as tests/test_int8_gemm.py:36
+    # int32 accumulation is exact and the epilogue is the oracle's fp32 expression: expect bit-equality
+    # on all but the rare element where fp32 a*b*c association differs
+    assert (out != ref).float().mean() < 1e-3
+
+
+def test_scaled_mm_golden(sglk, dev):
+    for c in load_golden("scaled_mm"):
+        bias = c["bias"].to(dev) if c["bias"] is not None else None
+        if c["kind"] == "fp8":
+            out = sglk.fp8_scaled_mm(c["a"].view(FP8).to(dev), c["b_nk"].view(FP8).to(dev).t(), c["sa"].to(dev),
+                                     c["sb"].to(dev), c["out_dtype"], bias).cpu()
+            torch.testing.assert_close(out, c["out"], rtol=0.02, atol=1)
+        else:
+            out = sglk.int8_scaled_mm(c["a"].to(dev), c["b_nk"].to(dev).t(), c["sa"].to(dev), c["sb"].to(dev),
+                                      c["out_dtype"], bias).cpu()
+            torch.testing.assert_close(out, c["out"])
+
+
+def test_errors(sglk, dev):
+    a = torch.zeros(4, 256, dtype=FP8, device=dev)
+    b = torch.zeros(128, 256, dtype=FP8, device=dev).t()
+    sa = torch.ones(4, 2, device=dev)
+    sb = torch.ones(2, 1, device=dev)
+    with pytest.raises(RuntimeError, match="column major"):
+        sglk.fp8_blockwise_scaled_mm(a, b.contiguous(), sa, sb, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="scales_a"):
+        sglk.fp8_blockwise_scaled_mm(a, b, torch.ones(4, 3, device=dev), sb, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="out_dtype"):
+        sglk.fp8_blockwise_scaled_mm(a, b, sa, sb, torch.float32)
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        sglk.fp8_blockwise_scaled_mm(a[:, :192], b[:192], torch.ones(4, 1, device=dev), sb, torch.bfloat16)
+    assert sglk.fp8_blockwise_scaled_mm(a[:0], b, sa[:0], sb, torch.bfloat16).shape == (0, 128)
