@@ -104,6 +104,24 @@ def side_metrics(sgl_kernel, dev):
     ms = timeit(lambda: sgl_kernel.sgl_per_token_group_quant_8bit(x, q, s, 128, 1e-10, -448.0, 448.0, False,
                                                                    enable_v2=False))
     out["per_token_group_quant_fp8_4096x4096_GBs"] = round((x.numel() * 3 + s.numel() * 4) / ms / 1e6, 1)
+    del x, x2, o2, q, s, y
+    # flash_mla_decode, BASELINE configs[3]: bs=128, seq=8192, kv_lora 512 + rope 64, paged (64), bf16.
+    # Bytes as benchmark/bench_flash_mla_decode.py:109-115 of the reference: q + kv cache + table + seq_lens + out.
+    bs, seq, page = 128, 8192, 64
+    n_pages = seq // page
+    cache = torch.randn(bs * n_pages, page, 576, device=dev, dtype=torch.bfloat16)
+    table = torch.randint(0, bs * n_pages, (bs, n_pages), device=dev, dtype=torch.int32)
+    seq_lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+    for H in (128, 16):
+        qq = torch.randn(bs, H, 576, device=dev, dtype=torch.bfloat16) * 100
+        q_nope, q_pe = qq[..., :512], qq[..., 512:].contiguous()
+        ws = torch.empty(sgl_kernel.flash_mla_get_workspace_size(seq, bs, H, page, -1), device=dev, dtype=torch.uint8)
+        ms = timeit(lambda: sgl_kernel.flash_mla_decode(q_nope, q_pe, cache, seq_lens, table, ws, 576 ** -0.5, -1),
+                    iters=10)
+        nbytes = qq.numel() * 2 + cache.numel() * 2 + table.numel() * 4 + seq_lens.numel() * 4 + bs * H * 512 * 2
+        out[f"flash_mla_decode_bs128_seq8192_h{H}_GBs"] = round(nbytes / ms / 1e6, 1)
+        out[f"flash_mla_decode_bs128_seq8192_h{H}_ms"] = round(ms, 4)
+        out[f"flash_mla_decode_bs128_seq8192_h{H}_TFLOPs"] = round(2.0 * bs * H * seq * (576 + 512) / ms / 1e9, 1)
     return out
 
 

@@ -140,6 +140,28 @@ SGLK_API int sglk_scaled_mm(sglk_stream_t stream, void* out, const void* a, cons
                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                             int in_dtype, int out_dtype);
 
+/* ---- MLA decode -------------------------------------------------------------
+ * flash_mla_decode: reference src/sycl/mla_decode.cpp:135-175 (schema
+ * src/torch_extension_sycl.cc:364-368; wrapper python/sgl_kernel/attention.py:54-132).
+ *   out[b,h,:512] = softmax(sm_scale * [q_nope[b,h], q_pe[b,h]] . C_b^T) . C_b[:, :512]
+ * where C_b is the first seq_lens[b] rows of the pages page_table[b,:] of
+ * cache [pages, page_size, 576] (16-bit, same dtype as q). q strides in elements;
+ * cache_page_stride = elements between consecutive pages (rows are 576 contiguous).
+ * num_kv_splits < 1 selects sglk_mla_decode_auto_splits(batch, pages_per_seq*page_size);
+ * splits > 1 need `workspace` of sglk_mla_decode_workspace_size(...) bytes.
+ * flash_mla_get_workspace_size: reference src/sycl/mla_decode.cpp:192-223. */
+SGLK_API int64_t sglk_mla_decode_auto_splits(int64_t batch, int64_t max_seq_len);
+SGLK_API int64_t sglk_mla_decode_workspace_size(int64_t max_seq_len, int64_t batch, int64_t num_heads,
+                                                int64_t num_kv_splits);
+SGLK_API int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void* q_nope, const void* q_pe,
+                                   const void* cache, const int32_t* seq_lens, const int32_t* page_table,
+                                   void* workspace, int64_t workspace_bytes, int64_t batch,
+                                   int64_t num_heads, int64_t page_size, int64_t pages_per_seq,
+                                   int64_t q_nope_stride_b, int64_t q_nope_stride_h,
+                                   int64_t q_pe_stride_b, int64_t q_pe_stride_h,
+                                   int64_t cache_page_stride, int64_t table_stride, float sm_scale,
+                                   int64_t num_kv_splits, int dtype);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,492 @@
+// flash_mla_decode for gfx950: DeepSeek MLA decode over a paged latent KV cache.
+//
+// Replaces reference src/sycl/mla_decode.cpp:135-175 (host), :60-93 (split heuristic),
+// :192-223 (workspace size) and src/sycl/kernels/mla/* (CuTe kernels). Contract kept
+// (python/sgl_kernel/attention.py:54-132, tests/test_flash_mla_decode.py:38-59):
+//   out[b,h,:512] = softmax(sm_scale * [q_nope[b,h], q_pe[b,h]] . cache[b,:,:576]^T) . cache[b,:,:512]
+// over the first seq_lens[b] tokens of the pages page_table[b,:]; cache is [pages, PAGE, 576].
+//
+// Design (MI355X-first, the opposite of the reference's one-work-group-per-(batch,head) grid, which
+// re-streams the whole latent cache once per head): ONE workgroup owns ALL heads of a batch element for
+// a contiguous range of KV tokens, so each 1152-byte KV row is fetched from HBM once and is shared
+// through LDS by the QK^T and the PV products.
+//   - 8 waves (two per SIMD, 256 VGPRs each). Wave w owns heads 16w..16w+15: its Q^T fragments (72
+//     VGPRs) and its fp32 O accumulator [16 heads x 512] (128 VGPRs) stay in registers for the whole
+//     kernel. Waves beyond ceil(H/16) only help loading.
+//   - KV tiles of 32 tokens go global->LDS by LDS-DMA (16 B/lane), 4-stage ring, three tiles in
+//     flight behind a counted vmcnt, one raw s_barrier per tile.
+//   - S^T = K . Q^T (16x16x32 MFMA, K rows read with ds_read_b128): the lane then owns one head and
+//     8 of the tile's 32 tokens, so the online softmax is lane-local plus two cross-lane exchanges, and
+//     the 16-bit P registers are directly the A operand of O += P . V, whose B operand (V = the same
+//     LDS rows, first 512 columns) comes through ds_read_b64_tr_b16 (hardware transpose read).
+//   - LDS image per tile: four [32 tokens][256 B] column blocks with the 16-byte chunk c of row r at
+//     c ^ (((r&3)<<2)|((r>>2)&3)), plus a [32][128 B] block for the rope columns swizzled by (r>>1)&7.
+//     Two free permutations make every LDS read conflict-free on that image: (1) within a 32-deep k
+//     step, lane group g takes chunk pi(g), pi = (0,3,1,2), for BOTH MFMA operands; (2) MFMA row i
+//     of a token tile is token tau(i) = i with bits 2 and 3 swapped, so that the two 4-row blocks a
+//     32-lane half reads transposed are 8 rows apart.
+//   - split-KV: grid = (splits, batch); partial O (normalised, fp32) and log2-sum-exp go to the
+//     caller's workspace and a small second kernel merges them.
+#include <math.h>
+
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+constexpr int kLatent = 512, kRope = 64, kQK = 576;
+constexpr int kRowBytes = kQK * 2;     // 1152
+constexpr int kTile = 32;              // kv tokens per tile
+constexpr int kMainBytes = kTile * 1024;
+constexpr int kRopeBytes = kTile * 128;
+constexpr int kStageBytes = kMainBytes + kRopeBytes;  // 36 KiB
+constexpr int kStages = 4;
+constexpr int kXchgOff = kStages * kStageBytes;       // 8 waves x 16 floats
+constexpr int kLdsBytes = kXchgOff + 8 * 16 * 4;
+constexpr int kThreads = 512;
+
+#define SGLK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define SGLK_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<bf16> {
+  static __device__ __forceinline__ v4f run(const v8s& a, const v8s& b, const v4f& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ short cvt(float x) { return __builtin_bit_cast(short, (bf16)x); }
+};
+template <>
+struct Mfma<f16> {
+  static __device__ __forceinline__ v4f run(const v8s& a, const v8s& b, const v4f& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ short cvt(float x) { return __builtin_bit_cast(short, (f16)x); }
+};
+
+__device__ __forceinline__ int sw_main(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
+struct MlaParams {
+  void* out;                 // [B, H, 512] T
+  float* ws_o;               // [B, splits, H, 512] fp32 (splits > 1)
+  float* ws_lse;             // [B, splits, H]
+  int64_t qn_sb, qn_sh, qp_sb, qp_sh;
+  int64_t page_stride_bytes;
+  int64_t table_stride;
+  int H, page_shift, splits;
+  float scale_log2;
+};
+
+// q_nope [B,H,512] / q_pe [B,H,64] (strides in p), cache [pages, PAGE, 576], seq_lens [B], page_table
+// [B, table_stride]: read-only for the whole launch (__restrict__ lets the page lookups be scalar loads,
+// which keeps them off the vmcnt counter the LDS-DMA ring is timed with).
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, const T* __restrict__ q_nope,
+                                                                 const T* __restrict__ q_pe,
+                                                                 const char* __restrict__ cache,
+                                                                 const int32_t* __restrict__ seq_lens,
+                                                                 const int32_t* __restrict__ page_table) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using M = Mfma<T>;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int H = p.H;
+  const int ngroups = (H + 15) >> 4;
+  const bool active = wave < ngroups;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int seq = seq_lens[b];
+  const int ntiles = (seq + kTile - 1) / kTile;
+  const int tps = (ntiles + p.splits - 1) / p.splits;
+  const int t_begin = split * tps;
+  const int t_end = (t_begin + tps < ntiles) ? (t_begin + tps) : ntiles;
+
+  const int32_t* table = page_table + (int64_t)b * p.table_stride;
+  const int page_mask = (1 << p.page_shift) - 1;
+
+  // ---- LDS-DMA of one tile. Main part: 4 column blocks x 8 row groups of [4 rows][256 B]; wave w
+  // fills block w>>1, row groups 4(w&1)..+3. Rope part: waves 0..3 fill rows 8w..8w+7 of [32][128 B].
+  auto stage_tile = [&](int t, int st) {
+    char* base = smem + st * kStageBytes;
+    const int tok0 = t * kTile;
+    // a 32-token tile touches one page (PAGE >= 32) or two (PAGE == 16); if the second half of the tile is
+    // past the sequence its page entry may be unused: re-use the first page (those rows are masked)
+    const int pg0 = table[tok0 >> p.page_shift];
+    int pg1 = pg0;
+    if (p.page_shift == 4 && tok0 + 16 < seq) pg1 = table[(tok0 + 16) >> 4];
+    const char* src0 = cache + (int64_t)pg0 * p.page_stride_bytes;
+    const char* src1 = cache + (int64_t)pg1 * p.page_stride_bytes;
+    const int cb = wave >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rg = (wave & 1) * 4 + i;
+      const int row = rg * 4 + (lane >> 4);
+      const int ch = (lane & 15) ^ sw_main(row);
+      const int in_page = (tok0 + row) & page_mask;
+      const char* src = ((wave & 1) == 0 ? src0 : src1) + in_page * kRowBytes + cb * 256 + ch * 16;
+      __builtin_amdgcn_global_load_lds(SGLK_GLB(src), SGLK_LDS(base + cb * 8192 + rg * 1024), 16, 0, 0);
+    }
+    if (wave < 4) {
+      const int row = wave * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      const int in_page = (tok0 + row) & page_mask;
+      const char* src = (wave < 2 ? src0 : src1) + in_page * kRowBytes + 1024 + ch * 16;
+      __builtin_amdgcn_global_load_lds(SGLK_GLB(src), SGLK_LDS(base + kMainBytes + wave * 1024), 16, 0, 0);
+    }
+  };
+
+  if (t_begin >= t_end) {
+    // nothing to do for this split (or an empty sequence)
+    if (active) {
+      for (int i = lane; i < 16 * kLatent; i += 64) {
+        const int head = wave * 16 + i / kLatent, d = i % kLatent;
+        if (head < H) {
+          if (p.splits == 1) ((T*)p.out)[((int64_t)b * H + head) * kLatent + d] = (T)0.f;
+          else p.ws_o[(((int64_t)b * p.splits + split) * H + head) * kLatent + d] = 0.f;
+        }
+      }
+      if (p.splits > 1 && lane < 16 && wave * 16 + lane < H)
+        p.ws_lse[((int64_t)b * p.splits + split) * H + wave * 16 + lane] = -INFINITY;
+    }
+    return;
+  }
+
+  // k permutation inside a 32-deep MFMA step: lane group g takes the 8 elements at 8*pi(g)
+  const int pig = (0x2130 >> (4 * g)) & 3;  // pi = (0,3,1,2)
+
+  // ---- Q^T fragments (MFMA B operand): lane (head l15, group g) holds q[head][32 ks + 8 pi(g) .. +7]
+  v8s qf[18];
+  {
+    const int head = wave * 16 + l15;
+    const bool ok = active && head < H;
+    const T* qn = q_nope + (int64_t)b * p.qn_sb + (int64_t)(ok ? head : 0) * p.qn_sh + 8 * pig;
+    const T* qp = q_pe + (int64_t)b * p.qp_sb + (int64_t)(ok ? head : 0) * p.qp_sh + 8 * pig;
+    const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const v8s v = *reinterpret_cast<const v8s*>(qn + 32 * ks);
+      qf[ks] = ok ? v : zero;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const v8s v = *reinterpret_cast<const v8s*>(qp + 32 * ks);
+      qf[16 + ks] = ok ? v : zero;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q is in registers before any LDS-DMA is counted
+
+  // ---- per-lane LDS read offsets
+  // K row read (MFMA A operand): MFMA row l15 of token tile tt is token 16 tt + tau(l15)
+  const int tau = (l15 & 3) | (((l15 >> 2) & 1) << 3) | (((l15 >> 3) & 1) << 2);
+  // (the second token tile is 16 rows = +4096 / +2048 bytes further: the swizzles only use row bits 0..3;
+  //  stepping the chunk index by a power of two is an XOR on the byte offset, so one base per kind suffices)
+  const int kbase = 256 * tau + 16 * (pig ^ sw_main(tau));                       // ^ (k4 << 6): chunk 4 k4 + pi(g)
+  const int rbase = kMainBytes + 128 * tau + 16 * (pig ^ ((tau >> 1) & 7));      // ^ (k2 << 6)
+  // transposed V read (MFMA B operand, 16 dims x 32 tokens): lane group g reads the 4-row blocks starting
+  // at rows 8(g&1) + 4(g>>1) and +16; lane i = l15 supplies row q = i>>2, 8-byte piece pp = i&3 of the 32 bytes
+  // of 16-dim tile n8 (chunks 2 n8, 2 n8 + 1) of a 128-column block:  vbase0 ^ (n8 << 5)
+  int vbase0;
+  {
+    const int q = l15 >> 2, pp = l15 & 3;
+    const int r = 8 * (g & 1) + 4 * (g >> 1) + q;
+    vbase0 = 256 * r + 16 * ((pp >> 1) ^ sw_main(r)) + 8 * (pp & 1);
+  }
+
+  v4f o[32];
+#pragma unroll
+  for (int nt = 0; nt < 32; ++nt) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY;  // running max of the raw logits of head l15 (all four lane groups agree)
+  float l_run = 0.f;        // running sum over this lane's own tokens
+  float* xch = reinterpret_cast<float*>(smem + kXchgOff) + wave * 16;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
+
+  // ---- prologue: three tiles in flight
+  const int n_my = t_end - t_begin;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (i < n_my) stage_tile(t_begin + i, i);
+
+  for (int i = 0; i < n_my; ++i) {
+    const int t = t_begin + i;
+    const int st = i & 3;
+    const int rem = n_my - 1 - i;  // tiles after this one (at most two of them are already in flight)
+    if (wave < 4) {
+      if (rem >= 2) wait_vmcnt<10>(); else if (rem == 1) wait_vmcnt<5>(); else wait_vmcnt<0>();
+    } else {
+      if (rem >= 2) wait_vmcnt<8>(); else if (rem == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done with tile t-1
+    if (i + 3 < n_my) stage_tile(t + 3, (i + 3) & 3);
+
+    if (active) {
+      const char* base = smem + st * kStageBytes;
+      // ---- S^T[token, head] = K . Q^T for the two 16-token tiles
+      v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const v8s a0 = *reinterpret_cast<const v8s*>(base + (ks >> 2) * 8192 + (kbase ^ ((ks & 3) << 6)));
+        const v8s a1 = *reinterpret_cast<const v8s*>(base + (ks >> 2) * 8192 + 4096 + (kbase ^ ((ks & 3) << 6)));
+        s0 = M::run(a0, qf[ks], s0);
+        s1 = M::run(a1, qf[ks], s1);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const v8s a0 = *reinterpret_cast<const v8s*>(base + (rbase ^ (ks << 6)));
+        const v8s a1 = *reinterpret_cast<const v8s*>(base + 2048 + (rbase ^ (ks << 6)));
+        s0 = M::run(a0, qf[16 + ks], s0);
+        s1 = M::run(a1, qf[16 + ks], s1);
+      }
+      // ---- online softmax for head l15 over this lane's 8 tokens (+ the other three lane groups')
+      if (t * kTile + kTile > seq) {
+        const int tb = t * kTile + 8 * (g & 1) + 4 * (g >> 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (tb + r >= seq) s0[r] = -INFINITY;
+          if (tb + 16 + r >= seq) s1[r] = -INFINITY;
+        }
+      }
+      float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+      const float mneg = -m_new * p.scale_log2;
+      float psum = 0.f;
+      v8s pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2, mneg));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2, mneg));
+        psum += p0 + p1;
+        pf[r] = M::cvt(p0);
+        pf[4 + r] = M::cvt(p1);
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      // ---- rescale O when any head's maximum moved: O row (head) 4g + r needs alpha of head 4g + r
+      if (__any(alpha != 1.0f)) {
+        if (lane < 16) xch[lane] = alpha;
+        const v4f a4 = *reinterpret_cast<const v4f*>(xch + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < 32; ++nt) {
+          o[nt][0] *= a4[0]; o[nt][1] *= a4[1]; o[nt][2] *= a4[2]; o[nt][3] *= a4[3];
+        }
+      }
+      // ---- O[head, dim] += P . V   (A = P from registers, B = V via transposed LDS reads).
+      // The transposed reads are issued from inline asm: behind the builtin hipcc waits vmcnt(0) (it cannot
+      // tell these LDS reads from the LDS-DMA writes in flight) and that would drain the prefetch ring every
+      // tile. The 2 reads of one 16-dim tile are double buffered; LDS returns in order, so lgkmcnt(2) retires
+      // the older pair. No other LDS/SMEM traffic of this wave may sit inside this section.
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const uint32_t vbase = lds_base + (uint32_t)(st * kStageBytes);
+        v2i vb[2][2];
+#define SGLK_TR_ISSUE(G, BUF)                                                                    \
+  do {                                                                                           \
+    const uint32_t a_ = vbase + (uint32_t)(vbase0 ^ (((G) & 7) << 5));                           \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"    \
+                 : "=v"(vb[BUF][0]), "=v"(vb[BUF][1])                                            \
+                 : "v"(a_), "i"((((G) >> 3) * 8192)), "i"((((G) >> 3) * 8192 + 4096))            \
+                 : "memory");                                                                    \
+  } while (0)
+#define SGLK_TR_MMA(G, BUF)                                                                          \
+  do {                                                                                               \
+    v8s f_;                                                                                          \
+    const v4s x0_ = __builtin_bit_cast(v4s, vb[BUF][0]), x1_ = __builtin_bit_cast(v4s, vb[BUF][1]); \
+    f_[0] = x0_[0]; f_[1] = x0_[1]; f_[2] = x0_[2]; f_[3] = x0_[3];                                  \
+    f_[4] = x1_[0]; f_[5] = x1_[1]; f_[6] = x1_[2]; f_[7] = x1_[3];                                  \
+    o[G] = M::run(pf, f_, o[G]);                                                                     \
+  } while (0)
+#define SGLK_TR_WAIT(N, BUF) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(vb[BUF][0]), "+v"(vb[BUF][1])::"memory")
+#define SGLK_TR_STEP(G)                  \
+  SGLK_TR_ISSUE((G) + 1, ((G) + 1) & 1); \
+  SGLK_TR_WAIT(2, (G) & 1);              \
+  SGLK_TR_MMA(G, (G) & 1);
+        SGLK_TR_ISSUE(0, 0);
+        SGLK_TR_STEP(0) SGLK_TR_STEP(1) SGLK_TR_STEP(2) SGLK_TR_STEP(3) SGLK_TR_STEP(4) SGLK_TR_STEP(5)
+        SGLK_TR_STEP(6) SGLK_TR_STEP(7) SGLK_TR_STEP(8) SGLK_TR_STEP(9) SGLK_TR_STEP(10) SGLK_TR_STEP(11)
+        SGLK_TR_STEP(12) SGLK_TR_STEP(13) SGLK_TR_STEP(14) SGLK_TR_STEP(15) SGLK_TR_STEP(16) SGLK_TR_STEP(17)
+        SGLK_TR_STEP(18) SGLK_TR_STEP(19) SGLK_TR_STEP(20) SGLK_TR_STEP(21) SGLK_TR_STEP(22) SGLK_TR_STEP(23)
+        SGLK_TR_STEP(24) SGLK_TR_STEP(25) SGLK_TR_STEP(26) SGLK_TR_STEP(27) SGLK_TR_STEP(28) SGLK_TR_STEP(29)
+        SGLK_TR_STEP(30)
+        SGLK_TR_WAIT(0, 1);
+        SGLK_TR_MMA(31, 1);
+#undef SGLK_TR_STEP
+#undef SGLK_TR_WAIT
+#undef SGLK_TR_MMA
+#undef SGLK_TR_ISSUE
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if (!active) return;
+  // ---- epilogue: normalise by the row sums and write. O tile nt: lane holds dim 16 nt + l15, heads 4g + r
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  if (lane < 16) xch[lane] = inv_l;
+  const v4f i4 = *reinterpret_cast<const v4f*>(xch + 4 * g);
+  if (p.splits == 1) {
+    T* out = (T*)p.out + (int64_t)b * H * kLatent;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int head = wave * 16 + 4 * g + r;
+      if (head < H) {
+#pragma unroll
+        for (int nt = 0; nt < 32; ++nt) out[(int64_t)head * kLatent + nt * 16 + l15] = (T)(o[nt][r] * i4[r]);
+      }
+    }
+  } else {
+    float* wo = p.ws_o + ((int64_t)b * p.splits + split) * H * kLatent;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int head = wave * 16 + 4 * g + r;
+      if (head < H) {
+#pragma unroll
+        for (int nt = 0; nt < 32; ++nt) wo[(int64_t)head * kLatent + nt * 16 + l15] = o[nt][r] * i4[r];
+      }
+    }
+    if (lane < 16 && wave * 16 + lane < H)
+      p.ws_lse[((int64_t)b * p.splits + split) * H + wave * 16 + lane] = m_run * p.scale_log2 + log2f(l_tot);
+  }
+}
+
+// out[b,h,:] = sum_s w_s O_s / sum_s w_s,  w_s = 2^(lse_s - max lse)
+template <typename T>
+__global__ __launch_bounds__(128) void mla_reduce_kernel(T* __restrict__ out, const float* __restrict__ ws_o,
+                                                         const float* __restrict__ ws_lse, int H, int splits) {
+  const int h = blockIdx.x, b = blockIdx.y;
+  const float* lse = ws_lse + (int64_t)b * splits * H + h;
+  float mx = -INFINITY;
+  for (int s = 0; s < splits; ++s) mx = fmaxf(mx, lse[(int64_t)s * H]);
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  float wsum = 0.f;
+  const int d = threadIdx.x * 4;
+  for (int s = 0; s < splits; ++s) {
+    const float l = lse[(int64_t)s * H];
+    const float w = (l == -INFINITY) ? 0.f : exp2f(l - mx);
+    if (w != 0.f) {
+      const v4f v = *reinterpret_cast<const v4f*>(ws_o + (((int64_t)b * splits + s) * H + h) * kLatent + d);
+      acc[0] += w * v[0]; acc[1] += w * v[1]; acc[2] += w * v[2]; acc[3] += w * v[3];
+      wsum += w;
+    }
+  }
+  const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+  Vec<T, 4> o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (T)(acc[i] * inv);
+  store_vec<T, 4>(out + ((int64_t)b * H + h) * kLatent + d, o);
+}
+
+template <typename T>
+static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe, const void* cache,
+                  const int32_t* seq_lens, const int32_t* page_table) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_decode_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return fail(SGLK_ELAUNCH, "flash_mla_decode: cannot reserve %d B of LDS: %s", kLdsBytes,
+                                     hipGetErrorString(e));
+    attr_set = true;
+  }
+  mla_decode_kernel<T><<<dim3(p.splits, B), kThreads, kLdsBytes, st>>>(p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table);
+  if (int rc = check_launch("flash_mla_decode")) return rc;
+  if (p.splits > 1) {
+    mla_reduce_kernel<T><<<dim3(p.H, B), 128, 0, st>>>((T*)p.out, p.ws_o, p.ws_lse, p.H, p.splits);
+    return check_launch("flash_mla_decode(reduce)");
+  }
+  return SGLK_OK;
+}
+
+}  // namespace
+}  // namespace sglk
+
+// Number of KV splits used when the caller passes num_kv_splits < 1: about one workgroup per CU, and at
+// least 4 tiles (128 tokens) of work per split. (The reference's set_split_kv, mla_decode.cpp:60-93, is tuned
+// for its one-work-group-per-head grid on Xe2 and does not transfer.)
+extern "C" int64_t sglk_mla_decode_auto_splits(int64_t batch, int64_t max_seq_len) {
+  const int64_t tiles = (max_seq_len + 31) / 32;
+  int64_t s = 256 / (batch > 0 ? batch : 1);
+  const int64_t cap = (tiles + 3) / 4;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  if (s > 128) s = 128;
+  return s;
+}
+
+extern "C" int64_t sglk_mla_decode_workspace_size(int64_t max_seq_len, int64_t batch, int64_t num_heads,
+                                                  int64_t num_kv_splits) {
+  if (num_kv_splits < 1) num_kv_splits = sglk_mla_decode_auto_splits(batch, max_seq_len);
+  if (num_kv_splits == 1) return 0;
+  return batch * num_kv_splits * num_heads * (sglk::kLatent + 1) * 4;
+}
+
+extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void* q_nope, const void* q_pe,
+                                     const void* cache, const int32_t* seq_lens, const int32_t* page_table,
+                                     void* workspace, int64_t workspace_bytes, int64_t batch, int64_t num_heads,
+                                     int64_t page_size, int64_t pages_per_seq, int64_t q_nope_stride_b,
+                                     int64_t q_nope_stride_h, int64_t q_pe_stride_b, int64_t q_pe_stride_h,
+                                     int64_t cache_page_stride, int64_t table_stride, float sm_scale,
+                                     int64_t num_kv_splits, int dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(batch >= 0 && num_heads > 0 && num_heads <= 128, "flash_mla_decode: H must be in [1, 128], got %lld",
+               (long long)num_heads);
+  SGLK_REQUIRE(page_size == 16 || page_size == 32 || page_size == 64 || page_size == 128,
+               "flash_mla_decode: Unsupported page size: %lld", (long long)page_size);
+  SGLK_REQUIRE(pages_per_seq > 0, "flash_mla_decode: block num must be greater than 0");
+  SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "flash_mla_decode: dtype must be Half or BFloat16");
+  SGLK_REQUIRE(q_nope_stride_b % 8 == 0 && q_nope_stride_h % 8 == 0 && q_pe_stride_b % 8 == 0 &&
+                   q_pe_stride_h % 8 == 0 && (uintptr_t)q_nope % 16 == 0 && (uintptr_t)q_pe % 16 == 0 &&
+                   (uintptr_t)cache % 16 == 0 && cache_page_stride % 8 == 0,
+               "flash_mla_decode: q and cache rows must be 16-byte aligned");
+  if (batch == 0) return SGLK_OK;
+  const int64_t max_seq = pages_per_seq * page_size;
+  int64_t splits = num_kv_splits < 1 ? sglk_mla_decode_auto_splits(batch, max_seq) : num_kv_splits;
+  const int64_t max_tiles = (max_seq + 31) / 32;
+  if (splits > max_tiles) splits = max_tiles;
+  if (splits > 1) {
+    const int64_t need = batch * splits * num_heads * (kLatent + 1) * 4;
+    SGLK_REQUIRE(workspace != nullptr && workspace_bytes >= need,
+                 "flash_mla_decode: workspace too small: %lld bytes given, %lld needed for %lld splits",
+                 (long long)workspace_bytes, (long long)need, (long long)splits);
+    SGLK_REQUIRE((uintptr_t)workspace % 16 == 0, "flash_mla_decode: workspace must be 16-byte aligned");
+  }
+  MlaParams p;
+  p.out = out;
+  p.ws_o = (float*)workspace;
+  p.ws_lse = p.ws_o ? p.ws_o + batch * splits * num_heads * kLatent : nullptr;
+  p.qn_sb = q_nope_stride_b;
+  p.qn_sh = q_nope_stride_h;
+  p.qp_sb = q_pe_stride_b;
+  p.qp_sh = q_pe_stride_h;
+  p.page_stride_bytes = cache_page_stride * 2;
+  p.table_stride = table_stride;
+  p.H = (int)num_heads;
+  p.page_shift = page_size == 16 ? 4 : page_size == 32 ? 5 : page_size == 64 ? 6 : 7;
+  p.splits = (int)splits;
+  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGLK_BF16) return launch<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
+  return launch<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
+}

@@ -284,6 +284,65 @@ Tensor int8_scaled_mm(const Tensor& mat_a, const Tensor& mat_b, const Tensor& sc
   return scaled_mm_impl(mat_a, mat_b, scales_a, scales_b, out_dtype, bias, true, "int8_scaled_mm");
 }
 
+// ---- flash_mla_decode (reference src/sycl/mla_decode.cpp:135-175, :192-223) ------------------
+
+void flash_mla_decode(Tensor& out, Tensor& q_nope, Tensor& q_pe, Tensor& kv_c_and_k_pe_cache, Tensor& seq_lens,
+                      Tensor& page_table, Tensor& workspace, double sm_scale, int64_t num_kv_splits) {
+  CHECK_GPU(out);
+  CHECK_GPU(q_nope);
+  CHECK_GPU(q_pe);
+  CHECK_GPU(kv_c_and_k_pe_cache);
+  CHECK_GPU(seq_lens);
+  CHECK_GPU(page_table);
+  TORCH_CHECK(q_nope.dim() == 3 && q_pe.dim() == 3 && kv_c_and_k_pe_cache.dim() == 3 && out.dim() == 3,
+              "flash_mla_decode: q_nope, q_pe, kv cache and out must be 3-D");
+  const int64_t B = q_nope.size(0), H = q_nope.size(1);
+  TORCH_CHECK(q_nope.size(2) == 512 && q_pe.size(2) == 64 && kv_c_and_k_pe_cache.size(2) == 576,
+              "flash_mla_decode: expects kv_lora_rank 512 and qk_rope_head_dim 64");
+  TORCH_CHECK(q_pe.size(0) == B && q_pe.size(1) == H, "flash_mla_decode: q_nope / q_pe shape mismatch");
+  TORCH_CHECK(out.size(0) == B && out.size(1) == H && out.size(2) == 512 && out.is_contiguous(),
+              "flash_mla_decode: out must be a contiguous [B, H, 512] tensor");
+  const auto dt = q_nope.scalar_type();
+  TORCH_CHECK(dt == at::kHalf || dt == at::kBFloat16, "flash_mla_decode: dtype must be Half or BFloat16");
+  TORCH_CHECK(q_pe.scalar_type() == dt && kv_c_and_k_pe_cache.scalar_type() == dt && out.scalar_type() == dt,
+              "flash_mla_decode: q_nope, q_pe, kv cache and out must share one dtype");
+  TORCH_CHECK(q_nope.stride(2) == 1 && q_pe.stride(2) == 1, "flash_mla_decode: q last dimension must be contiguous");
+  TORCH_CHECK(kv_c_and_k_pe_cache.stride(2) == 1 && kv_c_and_k_pe_cache.stride(1) == 576,
+              "flash_mla_decode: kv cache rows must be contiguous");
+  TORCH_CHECK(seq_lens.scalar_type() == at::kInt && seq_lens.numel() == B && seq_lens.is_contiguous(),
+              "flash_mla_decode: seq_lens must be a contiguous int32 [B] tensor");
+  TORCH_CHECK(page_table.scalar_type() == at::kInt && page_table.dim() == 2 && page_table.size(0) == B &&
+                  page_table.stride(1) == 1,
+              "flash_mla_decode: page_table must be an int32 [B, n] tensor");
+  const int64_t page = kv_c_and_k_pe_cache.size(1);
+  TORCH_CHECK(page == 16 || page == 32 || page == 64 || page == 128, "Unsupported page size: ", page);
+  int64_t ws_bytes = 0;
+  void* ws_ptr = nullptr;
+  if (workspace.defined() && workspace.numel() > 0) {
+    CHECK_GPU(workspace);
+    TORCH_CHECK(workspace.is_contiguous(), "flash_mla_decode: workspace must be contiguous");
+    ws_bytes = workspace.numel() * workspace.element_size();
+    ws_ptr = workspace.data_ptr();
+  }
+  const c10::OptionalDeviceGuard guard(q_nope.device());
+  SGLK_CALL(sglk_flash_mla_decode(stream_of(q_nope), out.data_ptr(), q_nope.data_ptr(), q_pe.data_ptr(),
+                                  kv_c_and_k_pe_cache.data_ptr(), seq_lens.data_ptr<int32_t>(),
+                                  page_table.data_ptr<int32_t>(), ws_ptr, ws_bytes, B, H, page, page_table.size(1),
+                                  q_nope.stride(0), q_nope.stride(1), q_pe.stride(0), q_pe.stride(1),
+                                  kv_c_and_k_pe_cache.stride(0), page_table.stride(0), (float)sm_scale,
+                                  num_kv_splits, dtype_code(dt, "flash_mla_decode")));
+}
+
+int64_t flash_mla_get_workspace_size(int64_t max_seq_len, int64_t num_batches, int64_t num_heads, int64_t page_size,
+                                     int64_t num_kv_splits) {
+  if (num_kv_splits < 1) {
+    TORCH_CHECK(num_heads > 0, "num_heads must be > 0 when num_kv_splits is auto-selected");
+    TORCH_CHECK(page_size == 16 || page_size == 32 || page_size == 64 || page_size == 128,
+                "Unsupported page size: ", page_size);
+  }
+  return sglk_mla_decode_workspace_size(max_seq_len, num_batches, num_heads, num_kv_splits);
+}
+
 }  // namespace
 
 TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
@@ -323,6 +382,13 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "int8_scaled_mm(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype,"
       " Tensor? bias) -> Tensor");
   m.impl("int8_scaled_mm", c10::kCUDA, &int8_scaled_mm);
+
+  // reference src/torch_extension_sycl.cc:362-368
+  m.def("flash_mla_get_workspace_size", &flash_mla_get_workspace_size);
+  m.def(
+      "flash_mla_decode(Tensor! out, Tensor! q_nope, Tensor! q_pe, Tensor! kv_c_and_k_pe_cache, Tensor! seq_lens,"
+      " Tensor! page_table, Tensor! workspace, float sm_scale, int num_kv_splits) -> ()");
+  m.impl("flash_mla_decode", c10::kCUDA, &flash_mla_decode);
 }
 
 // The loader does `from sgl_kernel import common_ops` (reference python/sgl_kernel/__init__.py:14);

@@ -137,7 +137,37 @@ def gen_scaled_mm():
     save("scaled_mm", cases)
 
 
+def gen_mla_decode():
+    # tests/test_flash_mla_decode.py:14-18 skips the whole module without an XPU; patch the probe for the import
+    import torch as _t
+    if not hasattr(_t, "xpu"):
+        raise RuntimeError("torch.xpu missing")
+    orig = _t.xpu.is_available
+    _t.xpu.is_available = lambda: True
+    try:
+        t = _import_ref("test_flash_mla_decode")
+    finally:
+        _t.xpu.is_available = orig
+    cases = []
+    torch.manual_seed(42)
+    for dt, bs, H, page, seqs in [(torch.bfloat16, 2, 16, 64, [77, 200]), (torch.float16, 3, 32, 16, [5, 130, 64]),
+                                  (torch.bfloat16, 1, 128, 128, [300])]:
+        seq_lens = torch.tensor(seqs, dtype=torch.int32)
+        block_num = (max(seqs) + page - 1) // page
+        pack = 128 // page
+        block_num = (block_num + pack - 1) // pack * pack
+        q = torch.randn(bs, H, 576, dtype=dt) * 100
+        table = torch.randint(0, bs * block_num, (bs, block_num), dtype=torch.int32)
+        cache = torch.randn(table.numel(), page, 576, dtype=dt)
+        out = torch.zeros(bs, H, 512, dtype=dt)
+        scale = (128 + 64) ** -0.5
+        t.ref_mla(out, q, cache, scale, table, seq_lens)
+        cases.append(dict(q=q, cache=cache, table=table, seq_lens=seq_lens, scale=scale, out=out))
+    save("mla_decode", cases)
+
+
 GENERATORS = {
+    "mla_decode": gen_mla_decode,
     "norm": gen_norm,
     "activation": gen_activation,
     "quant": gen_quant,
