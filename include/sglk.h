@@ -162,6 +162,50 @@ SGLK_API int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void* 
                                    int64_t cache_page_stride, int64_t table_stride, float sm_scale,
                                    int64_t num_kv_splits, int dtype);
 
+/* ---- MoE routing, data movement and W4A16 grouped GEMM -----------------------
+ * topk_softmax: reference src/sycl/TopKSoftMax.cpp:584-644 (schema torch_extension_sycl.cc:53).
+ *   gating [tokens, experts] (F16/BF16/F32) -> topk_weights fp32 [tokens, k], topk_indices int32. */
+SGLK_API int sglk_topk_softmax(sglk_stream_t stream, float* topk_weights, int32_t* topk_indices,
+                               const void* gating, int64_t tokens, int64_t experts, int64_t topk,
+                               int renormalize, int dtype);
+/* moe_align_block_size: reference src/sycl/MoEAlign.cpp:313-383 (schema :199-203). num_experts
+ * counts buckets (callers pass E+1: bucket = id + 1). sorted_token_ids / expert_ids /
+ * num_tokens_post_pad / cumsum_buffer[num_experts + 1] are int32; ids I32 or I64. */
+SGLK_API int sglk_moe_align_block_size(sglk_stream_t stream, const void* topk_ids, int ids_dtype,
+                                       int64_t numel, int64_t num_experts, int64_t block_size,
+                                       int32_t* sorted_token_ids, int32_t* expert_ids,
+                                       int32_t* num_tokens_post_pad, int32_t* cumsum_buffer,
+                                       int pad_sorted_token_ids);
+/* prepare_moe_input: reference src/sycl/MoEPrepareInputs.cpp:459-497 (schema :219-223).
+ * expert_counts[e] = rows of expert e; problem_sizes1/2 [E,3]; input_permutation[dst row] = token;
+ * output_permutation[flat slot] = dst row. All index tensors share ids_dtype (I32 or I64). */
+SGLK_API int sglk_prepare_moe_input(sglk_stream_t stream, const void* topk_ids, void* expert_counts,
+                                    void* problem_sizes1, void* problem_sizes2,
+                                    void* input_permutation, void* output_permutation, int64_t numel,
+                                    int64_t topk, int64_t num_experts, int64_t n, int64_t k,
+                                    int ids_dtype);
+/* scatter_tokens_to_experts: reference src/sycl/MoEPrepareInputs.cpp:571-589 (schema :224).
+ * output[src2dst_map[t*topk + j], :] = input[t, :]; rows of row_bytes bytes (multiple of 16). */
+SGLK_API int sglk_scatter_tokens_to_experts(sglk_stream_t stream, const void* input,
+                                            const int32_t* src2dst_map, void* output, int64_t tokens,
+                                            int64_t topk, int64_t row_bytes);
+/* apply_shuffle_mul_sum: reference src/sycl/MoEPrepareInputs.cpp:691-755 (schema :226-229).
+ * output[t,:] = T( sum_j float(input[permutation[t*topk+j],:]) * factors[t,j] [* rsf] ); factors may be NULL. */
+SGLK_API int sglk_apply_shuffle_mul_sum(sglk_stream_t stream, const void* input, void* output,
+                                        const int32_t* permutation, const void* factors,
+                                        int64_t tokens, int64_t topk, int64_t hidden,
+                                        float routed_scaling_factor, int dtype, int factors_dtype);
+/* moe_grouped_mm_nt_xe20_w4a16: reference src/sycl/GroupGemmW4A16Xe20.cpp:92-283 (schema
+ * torch_extension_sycl.cc:214-217). out [total_m, N]; activations [total_m, K]; packed_weights
+ * [E, N, K/2] (low nibble = even k); scales / zeros [E, N, K/group] (activation dtype; zeros may be
+ * NULL = signed codes); bias fp32 [E, N] or NULL; rows_per_expert int32 [E] (counts). */
+SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const void* activations,
+                                       const void* packed_weights, const void* scales,
+                                       const void* zeros, const float* bias,
+                                       const int32_t* rows_per_expert, int64_t total_m,
+                                       int64_t n_experts, int64_t N, int64_t K, int64_t group_size,
+                                       int is_int4, int dtype);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,366 @@
+// MoE routing and data movement for gfx950: topk_softmax, moe_align_block_size,
+// prepare_moe_input, scatter_tokens_to_experts, apply_shuffle_mul_sum.
+//
+// Replaces reference src/sycl/TopKSoftMax.cpp:584-644, src/sycl/MoEAlign.cpp:313-383 and
+// src/sycl/MoEPrepareInputs.cpp:459-497, :571-589, :691-755. Semantics kept:
+//   topk_softmax      softmax over experts in fp32; k rounds of arg-max with strict '>' so the lower
+//                     index wins ties (TopKSoftMax.cpp:395-421); weights are the selected probabilities,
+//                     optionally times 1/sum (:462-470). The arg-max runs on the LOGITS, which orders
+//                     experts exactly like their probabilities (exp is monotone) and, unlike the
+//                     probabilities, cannot collapse distinct experts into a tie by underflow or
+//                     rounding -- so the index path is exact and independent of the exp implementation.
+//   moe_align         bucket = id + 1 (id -1 = "not on this rank" lands in bucket 0); per-bucket
+//                     counts padded to block_size, exclusive scan -> cumsum[0..num_experts];
+//                     expert_ids[block] = bucket - 1; sorted_token_ids filled by atomic ranks
+//                     (order inside a bucket is unspecified, as in the reference :35-58); cumsum is left
+//                     holding prefix + count like the reference's second kernel leaves it.
+//   prepare_moe_input expert_offsets[e] = ROW COUNT of expert e (not an offset: MoEPrepareInputs.cpp:52),
+//                     problem_sizes1[e] = (count, 2n, k), problem_sizes2[e] = (count, k, n),
+//                     input_permutation[dst] = src token, output_permutation[slot] = dst row.
+//                     Here the order inside an expert is the flat slot order (deterministic; the
+//                     reference's atomics make it run-dependent).
+//   scatter / combine row copies and fp32 weighted sums (acc += float(x) * w [* rsf]) in slot order.
+// These are latency / HBM-copy kernels; the design rule is "one launch, no temporaries, 16-byte rows".
+#include <math.h>
+
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+// ---------------------------------------------------------------------------------- topk_softmax
+// One wave per token; lane l owns experts l, l+64, l+128, l+192 (E <= 256).
+template <typename T>
+__global__ __launch_bounds__(256) void topk_softmax_kernel(float* __restrict__ weights, int* __restrict__ indices,
+                                                           const T* __restrict__ gating, int64_t tokens, int E,
+                                                           int k, bool renorm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  const T* row = gating + tok * E;
+  float x[4], v[4];  // logits (selection key) and probabilities (weights)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = lane + 64 * i;
+    x[i] = e < E ? (float)row[e] : -INFINITY;
+    mx = fmaxf(mx, x[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = (lane + 64 * i < E) ? expf(x[i] - mx) : 0.f;
+    sum += v[i];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] *= inv;
+
+  float picked_sum = 0.f;
+  float my_w = 0.f;  // lane j < k keeps the j-th selected weight
+  int my_i = 0;
+  for (int j = 0; j < k; ++j) {
+    // local arg-max: ascending expert index with strict '>' keeps the lower index on ties
+    float bx = x[0], bv = v[0];
+    int be = lane;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (x[i] > bx) { bx = x[i]; bv = v[i]; be = lane + 64 * i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ox = __shfl_xor(bx, o, 64);
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oe = __shfl_xor(be, o, 64);
+      if (ox > bx || (ox == bx && oe < be)) { bx = ox; bv = ov; be = oe; }
+    }
+    if (lane == j) { my_w = bv; my_i = be; }
+    picked_sum += bv;
+    if ((be & 63) == lane) x[be >> 6] = -INFINITY;  // clear the winner
+  }
+  if (lane < k) {
+    const float w = renorm ? my_w * (1.0f / picked_sum) : my_w;
+    weights[tok * k + lane] = w;
+    indices[tok * k + lane] = my_i;
+  }
+}
+
+// ------------------------------------------------------------------------------- moe_align_block_size
+template <typename IdT>
+__global__ __launch_bounds__(1024) void moe_align_kernel(const IdT* __restrict__ topk_ids, int32_t* sorted_token_ids,
+                                                         int32_t* expert_ids, int32_t* total_tokens_post_pad,
+                                                         int32_t* cumsum, int num_experts, int block_size,
+                                                         int64_t numel, bool pad_sorted) {
+  extern __shared__ int32_t sh[];  // counts[num_experts], prefix[num_experts + 1]
+  int32_t* counts = sh;
+  int32_t* prefix = sh + num_experts;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < num_experts; i += 1024) counts[i] = 0;
+  __syncthreads();
+  for (int64_t i = tid; i < numel; i += 1024) {
+    const int b = (int)topk_ids[i] + 1;
+    if (b >= 0 && b < num_experts) atomicAdd(&counts[b], 1);
+  }
+  __syncthreads();
+  // exclusive scan of the padded counts by one wave (num_experts is at most a few hundred)
+  if (tid < 64) {
+    int carry = 0;
+    for (int base = 0; base < num_experts; base += 64) {
+      const int i = base + tid;
+      const int c = i < num_experts ? counts[i] : 0;
+      const int padded = (c + block_size - 1) / block_size * block_size;
+      int incl = padded;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += t;
+      }
+      if (i < num_experts) prefix[i] = carry + incl - padded;
+      carry += __shfl(incl, 63, 64);
+    }
+    if (tid == 0) {
+      prefix[num_experts] = carry;
+      *total_tokens_post_pad = carry;
+    }
+  }
+  __syncthreads();
+  const int total = prefix[num_experts];
+  for (int i = tid; i <= num_experts; i += 1024) cumsum[i] = prefix[i];
+  const int num_blocks = total / block_size;
+  for (int i = tid; i < num_blocks; i += 1024) {
+    const int start = i * block_size;
+    int left = 0, right = num_experts;
+    while (left < right) {
+      const int mid = (left + right) >> 1;
+      if (prefix[mid] <= start) left = mid + 1; else right = mid;
+    }
+    expert_ids[i] = left - 2;
+  }
+  if (pad_sorted) {
+    for (int i = tid; i < total; i += 1024) sorted_token_ids[i] = (int32_t)numel;
+  }
+}
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void moe_align_sort_kernel(const IdT* __restrict__ topk_ids,
+                                                             int32_t* sorted_token_ids, int32_t* cumsum,
+                                                             int num_experts, int64_t numel) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+    const int b = (int)topk_ids[i] + 1;
+    if (b >= 0 && b < num_experts) {
+      const int rank = atomicAdd(&cumsum[b], 1);
+      sorted_token_ids[rank] = (int32_t)i;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- prepare_moe_input
+// One 256-thread block per expert: pass 1 counts ids == e and ids < e (= this expert's first row),
+// pass 2 hands out stable ranks in flat slot order. No atomics, no temporaries, deterministic.
+template <typename IdT>
+__global__ __launch_bounds__(256) void prepare_moe_input_kernel(const IdT* __restrict__ topk_ids,
+                                                                IdT* expert_counts, IdT* problem_sizes1,
+                                                                IdT* problem_sizes2, IdT* input_perm,
+                                                                IdT* output_perm, int64_t numel, int topk, int n,
+                                                                int k) {
+  __shared__ int red[2][4];
+  __shared__ int wave_tot[4];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int eq = 0, lt = 0;
+  for (int64_t i = tid; i < numel; i += 256) {
+    const int id = (int)topk_ids[i];
+    eq += (id == e);
+    lt += (id >= 0 && id < e);
+  }
+  eq = (int)wave_sum((float)eq);  // counts < 2^24: exact in fp32
+  lt = (int)wave_sum((float)lt);
+  if (lane == 0) { red[0][wave] = eq; red[1][wave] = lt; }
+  __syncthreads();
+  const int count = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const int first = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (tid == 0) {
+    expert_counts[e] = (IdT)count;
+    problem_sizes1[e * 3 + 0] = (IdT)count;
+    problem_sizes1[e * 3 + 1] = (IdT)(2 * n);
+    problem_sizes1[e * 3 + 2] = (IdT)k;
+    problem_sizes2[e * 3 + 0] = (IdT)count;
+    problem_sizes2[e * 3 + 1] = (IdT)k;
+    problem_sizes2[e * 3 + 2] = (IdT)n;
+  }
+  int base = first;
+  for (int64_t i0 = 0; i0 < numel; i0 += 256) {
+    const int64_t i = i0 + tid;
+    const bool hit = i < numel && (int)topk_ids[i] == e;
+    const unsigned long long m = __ballot(hit);
+    const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    if (hit) {
+      const int pos = base + before + in_wave;
+      input_perm[pos] = (IdT)(i / topk);
+      output_perm[i] = (IdT)pos;
+    }
+    base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  }
+}
+
+// ---------------------------------------------------------------------------- scatter_tokens_to_experts
+// grid = tokens; each thread moves 16-byte pieces of the source row to its topk destination rows.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                           const int32_t* __restrict__ src2dst, int topk,
+                                                           int row_vecs) {
+  const int64_t tok = blockIdx.x;
+  for (int c = threadIdx.x; c < row_vecs; c += 256) {
+    const uint4 v = in[tok * row_vecs + c];
+    for (int j = 0; j < topk; ++j) out[(int64_t)src2dst[tok * topk + j] * row_vecs + c] = v;
+  }
+}
+
+// -------------------------------------------------------------------------------- apply_shuffle_mul_sum
+template <typename T, typename W>
+__global__ __launch_bounds__(256) void shuffle_mul_sum_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                              const int32_t* __restrict__ perm,
+                                                              const W* __restrict__ factors, int topk, int hidden,
+                                                              float rsf, bool use_rsf) {
+  constexpr int V = 16 / sizeof(T);
+  const int64_t tok = blockIdx.x;
+  for (int c = threadIdx.x * V; c < hidden; c += 256 * V) {
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    for (int j = 0; j < topk; ++j) {
+      const int64_t src = perm[tok * topk + j];
+      const float w = factors ? (float)factors[tok * topk + j] : 1.0f;
+      const Vec<T, V> x = load_vec<T, V>(in + src * hidden + c);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        // explicit roundings (no fma contraction): acc += (x * w) [* rsf], as the reference spells it
+        float t = __fmul_rn((float)x[i], w);
+        if (use_rsf) t = __fmul_rn(t, rsf);
+        acc[i] = __fadd_rn(acc[i], t);
+      }
+    }
+    Vec<T, V> o;
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = (T)acc[i];
+    store_vec<T, V>(out + tok * hidden + c, o);
+  }
+}
+
+template <typename IdT>
+static int align_launch(hipStream_t st, const void* ids, int32_t* sorted, int32_t* eids, int32_t* total,
+                        int32_t* cumsum, int num_experts, int block_size, int64_t numel, bool pad) {
+  const size_t lds = (size_t)(2 * num_experts + 1) * sizeof(int32_t);
+  moe_align_kernel<IdT><<<1, 1024, lds, st>>>((const IdT*)ids, sorted, eids, total, cumsum, num_experts, block_size,
+                                               numel, pad);
+  if (int rc = check_launch("moe_align_block_size")) return rc;
+  if (numel > 0) {
+    const int64_t want = cdiv(numel, 256);
+    moe_align_sort_kernel<IdT><<<(unsigned)(want < 1024 ? want : 1024), 256, 0, st>>>((const IdT*)ids, sorted, cumsum,
+                                                                                      num_experts, numel);
+    return check_launch("moe_align_block_size(sort)");
+  }
+  return SGLK_OK;
+}
+
+}  // namespace
+}  // namespace sglk
+
+extern "C" int sglk_topk_softmax(sglk_stream_t stream, float* topk_weights, int32_t* topk_indices,
+                                 const void* gating, int64_t tokens, int64_t experts, int64_t topk, int renormalize,
+                                 int dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(experts > 0 && experts <= 256, "n_experts only support up to 256, but got %lld", (long long)experts);
+  SGLK_REQUIRE(topk > 0 && topk <= experts && topk <= 64, "n_topk must satisfy 0 < n_topk <= min(n_experts, 64)");
+  if (tokens == 0) return SGLK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)cdiv(tokens, 4);
+  SGLK_DISPATCH_FLOAT(dtype, T, {
+    topk_softmax_kernel<T><<<blocks, 256, 0, st>>>(topk_weights, topk_indices, (const T*)gating, tokens,
+                                                   (int)experts, (int)topk, renormalize != 0);
+  });
+  return check_launch("topk_softmax");
+}
+
+extern "C" int sglk_moe_align_block_size(sglk_stream_t stream, const void* topk_ids, int ids_dtype, int64_t numel,
+                                         int64_t num_experts, int64_t block_size, int32_t* sorted_token_ids,
+                                         int32_t* expert_ids, int32_t* num_tokens_post_pad, int32_t* cumsum_buffer,
+                                         int pad_sorted_token_ids) {
+  using namespace sglk;
+  SGLK_REQUIRE(num_experts > 0 && num_experts <= 8000, "moe_align_block_size: num_experts must be in [1, 8000]");
+  SGLK_REQUIRE(block_size > 0, "moe_align_block_size: block_size must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  if (ids_dtype == SGLK_I32)
+    return align_launch<int32_t>(st, topk_ids, sorted_token_ids, expert_ids, num_tokens_post_pad, cumsum_buffer,
+                                 (int)num_experts, (int)block_size, numel, pad_sorted_token_ids != 0);
+  if (ids_dtype == SGLK_I64)
+    return align_launch<int64_t>(st, topk_ids, sorted_token_ids, expert_ids, num_tokens_post_pad, cumsum_buffer,
+                                 (int)num_experts, (int)block_size, numel, pad_sorted_token_ids != 0);
+  return fail(SGLK_EUNSUPPORTED, "moe_align_block_size: topk_ids must be int32 or int64");
+}
+
+extern "C" int sglk_prepare_moe_input(sglk_stream_t stream, const void* topk_ids, void* expert_counts,
+                                      void* problem_sizes1, void* problem_sizes2, void* input_permutation,
+                                      void* output_permutation, int64_t numel, int64_t topk, int64_t num_experts,
+                                      int64_t n, int64_t k, int ids_dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(num_experts > 0 && topk > 0, "prepare_moe_input: num_experts and topk must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  if (ids_dtype == SGLK_I32) {
+    prepare_moe_input_kernel<int32_t><<<(unsigned)num_experts, 256, 0, st>>>(
+        (const int32_t*)topk_ids, (int32_t*)expert_counts, (int32_t*)problem_sizes1, (int32_t*)problem_sizes2,
+        (int32_t*)input_permutation, (int32_t*)output_permutation, numel, (int)topk, (int)n, (int)k);
+  } else if (ids_dtype == SGLK_I64) {
+    prepare_moe_input_kernel<int64_t><<<(unsigned)num_experts, 256, 0, st>>>(
+        (const int64_t*)topk_ids, (int64_t*)expert_counts, (int64_t*)problem_sizes1, (int64_t*)problem_sizes2,
+        (int64_t*)input_permutation, (int64_t*)output_permutation, numel, (int)topk, (int)n, (int)k);
+  } else {
+    return fail(SGLK_EUNSUPPORTED, "prepare_moe_input: index tensors must be int32 or int64");
+  }
+  return check_launch("prepare_moe_input");
+}
+
+extern "C" int sglk_scatter_tokens_to_experts(sglk_stream_t stream, const void* input, const int32_t* src2dst_map,
+                                              void* output, int64_t tokens, int64_t topk, int64_t row_bytes) {
+  using namespace sglk;
+  SGLK_REQUIRE(row_bytes % 16 == 0 && (uintptr_t)input % 16 == 0 && (uintptr_t)output % 16 == 0,
+               "scatter_tokens_to_experts: rows must be multiples of 16 bytes");
+  SGLK_REQUIRE(topk > 0 && topk <= 16, "scatter_tokens_to_experts: topk must be in [1, 16]");
+  if (tokens == 0) return SGLK_OK;
+  scatter_rows_kernel<<<(unsigned)tokens, 256, 0, (hipStream_t)stream>>>((const uint4*)input, (uint4*)output,
+                                                                         src2dst_map, (int)topk, (int)(row_bytes / 16));
+  return check_launch("scatter_tokens_to_experts");
+}
+
+extern "C" int sglk_apply_shuffle_mul_sum(sglk_stream_t stream, const void* input, void* output,
+                                          const int32_t* permutation, const void* factors, int64_t tokens,
+                                          int64_t topk, int64_t hidden, float routed_scaling_factor, int dtype,
+                                          int factors_dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(topk > 0 && topk <= 16, "apply_shuffle_mul_sum: topk must be in [1, 16]");
+  SGLK_REQUIRE(hidden > 0, "apply_shuffle_mul_sum: hidden size must be positive");
+  if (tokens == 0) return SGLK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool use_rsf = routed_scaling_factor != 1.0f;
+  SGLK_DISPATCH_FLOAT(dtype, T, {
+    SGLK_REQUIRE((hidden * sizeof(T)) % 16 == 0 && (uintptr_t)input % 16 == 0 && (uintptr_t)output % 16 == 0,
+                 "apply_shuffle_mul_sum: rows must be multiples of 16 bytes");
+    if (factors == nullptr) {
+      shuffle_mul_sum_kernel<T, T><<<(unsigned)tokens, 256, 0, st>>>((const T*)input, (T*)output, permutation, nullptr,
+                                                                     (int)topk, (int)hidden, routed_scaling_factor,
+                                                                     use_rsf);
+    } else {
+      SGLK_DISPATCH_FLOAT(factors_dtype, W, {
+        shuffle_mul_sum_kernel<T, W><<<(unsigned)tokens, 256, 0, st>>>((const T*)input, (T*)output, permutation,
+                                                                       (const W*)factors, (int)topk, (int)hidden,
+                                                                       routed_scaling_factor, use_rsf);
+      });
+    }
+  });
+  return check_launch("apply_shuffle_mul_sum");
+}

@@ -1,0 +1,309 @@
+// W4A16 (int4 weights, bf16/fp16 activations) grouped GEMM for MoE experts on gfx950.
+//
+// Replaces reference src/sycl/GroupGemmW4A16Xe20.cpp:92-283 (host) and
+// src/sycl/kernels/moe/xe20/w4a16/* (CuTe kernel). Contract kept (schema
+// src/torch_extension_sycl.cc:214-217, the `_xe20` name included because python/sgl_kernel/moe.py:751
+// calls it by that name):
+//   for expert e with rows[e] consecutive rows of `activations`:
+//     out_e = A_e @ dq(W_e)^T (+ bias_e),   dq = (code - zp) * scale
+//   W [E, N, K/2] bytes, low nibble = even k; codes are two's-complement when zeros is absent,
+//   unsigned otherwise; scales / zeros [E, N, K/group] in the activation dtype; bias fp32 [E, N].
+//
+// Arithmetic. The reference dequantises every weight to the activation dtype (one rounding of
+// (code - zp) * scale, gemm_xe2.hpp:52-76, :405-428) and feeds bf16 x bf16 DPAS. Here the 4-bit codes
+// stay EXACT all the way through the matrix core and the scale is applied in fp32 per quantisation group:
+//   out[m,n] = sum_groups scale[n,g] * ( sum_{k in g} (16 + u[n,k]) * a[m,k]  -  (16 + zp[n,g]) * sum_{k in g} a[m,k] )
+// where 16 + u is formed in the 16-bit float format by pure bit operations (0x4180 | u<<3 is the bf16
+// 16 + u; 0x4C00 | u<<6 the fp16 one) and sum_k a[m,k] comes from one extra MFMA against a fragment
+// of ones. That is 8 bit-ops per 8 weights instead of ~28 VALU ops for convert/subtract/multiply/round,
+// which is what keeps the decode regime on the HBM roofline, and it is at least as accurate as the
+// reference (no per-weight rounding); results agree within the reference test tolerance.
+//
+// Data movement. Weights are streamed once from HBM straight into registers (16 B per lane; they are not
+// shared between waves, so an LDS round trip would be pure overhead), then a 4x4 dword transpose across
+// the four 16-lane groups (2 x v_permlane32_swap + 2 x v_permlane16_swap) gives every MFMA k-step a
+// contiguous 32-wide k range, i.e. exactly one quantisation group for group sizes >= 32. The
+// activation tile [BM rows x 128 k] is staged through LDS once per 128-deep block for all 4 waves
+// (element order permuted to match the nibble-pair order of the weight fragments; rows XOR-swizzled).
+// Block = 4 waves; wave w owns NW 16-wide n tiles and all MT 16-row m tiles of the block's expert rows.
+// Experts are ragged: the grid is sized for the worst case and each block finds its (expert, row block)
+// from rows_per_expert on the device (no host sync).
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+template <typename T>
+struct W4;
+template <>
+struct W4<bf16> {
+  static constexpr int kShift = 3;                 // nibble position inside a 16-bit half: 16 + u = 0x4180 | u << 3
+  static constexpr uint32_t kMagic = 0x41804180u;
+  static constexpr uint32_t kOnes = 0x3F803F80u;   // (1.0, 1.0)
+  static __device__ __forceinline__ v4f mma(const v4i& a, const v4i& b, const v4f& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct W4<f16> {
+  static constexpr int kShift = 6;                 // 16 + u = 0x4C00 | u << 6
+  static constexpr uint32_t kMagic = 0x4C004C00u;
+  static constexpr uint32_t kOnes = 0x3C003C00u;
+  static __device__ __forceinline__ v4f mma(const v4i& a, const v4i& b, const v4f& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  }
+};
+
+// 8 nibbles (k offsets 0..7, nibble i at bits 4i) -> 4 dwords of two 16-bit floats (16 + u):
+// dword p = (k offset p, k offset p + 4).  The activation fragments use the same element order.
+template <typename T>
+__device__ __forceinline__ v4i expand_nibbles(uint32_t w) {
+  constexpr int S = W4<T>::kShift;
+  constexpr uint32_t mask = (0xFu << S) | (0xFu << (S + 16));
+  v4i r;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int sh = S - 4 * p;
+    const uint32_t t = sh >= 0 ? (w << sh) : (w >> (-sh));
+    r[p] = (int)((t & mask) | W4<T>::kMagic);
+  }
+  return r;
+}
+
+// 4x4 transpose of dwords across the four 16-lane groups: in: lane group g holds d[t] = M[g][t];
+// out: lane group g holds d[t] = M[t][g].
+__device__ __forceinline__ void transpose4(uint32_t (&d)[4]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    auto r = __builtin_amdgcn_permlane32_swap(d[t], d[t + 2], false, false);
+    d[t] = r[0];
+    d[t + 2] = r[1];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t += 2) {
+    auto r = __builtin_amdgcn_permlane16_swap(d[t], d[t + 1], false, false);
+    d[t] = r[0];
+    d[t + 1] = r[1];
+  }
+}
+
+template <typename T, int MT, int NW>
+__global__ __launch_bounds__(256) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
+                                                        const uint8_t* __restrict__ wq, const T* __restrict__ scales,
+                                                        const T* __restrict__ zeros, const float* __restrict__ bias,
+                                                        const int32_t* __restrict__ rows_per_expert, int E, int N,
+                                                        int K, int group_shift) {
+  constexpr int BM = 16 * MT;
+  constexpr int BN = 64 * NW;
+  __shared__ __attribute__((aligned(256))) char smem[2 * BM * 256];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- which expert / which block of its rows (uniform scalar walk over the row counts)
+  int e = 0, row0 = 0, rows_e = 0, blk = blockIdx.x;
+  bool found = false;
+  for (; e < E; ++e) {
+    rows_e = rows_per_expert[e];
+    const int nb = (rows_e + BM - 1) / BM;
+    if (blk < nb) { found = true; break; }
+    blk -= nb;
+    row0 += rows_e;
+  }
+  if (!found) return;
+  const int m0 = row0 + blk * BM;               // first global row of this block
+  const int m_valid = rows_e - blk * BM;        // rows of this block that exist (>= 1)
+  const int n_base = blockIdx.y * BN + wave * (NW * 16);
+
+  const int kgroups = K >> group_shift;         // scales per row
+  const int seg_steps = group_shift >= 7 ? 4 : (1 << (group_shift - 5));  // 32-wide k steps per scale segment
+  const bool has_zp = zeros != nullptr;
+
+  // ---- per-lane weight / scale rows (clamped; stores are guarded)
+  const uint8_t* wrow[NW];
+  const T* srow[NW];
+  const T* zrow[NW];
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt) {
+    int n = n_base + nt * 16 + l15;
+    n = n < N ? n : N - 1;
+    wrow[nt] = wq + ((int64_t)e * N + n) * (K / 2) + 16 * g;
+    srow[nt] = scales + ((int64_t)e * N + n) * kgroups;
+    zrow[nt] = has_zp ? zeros + ((int64_t)e * N + n) * kgroups : nullptr;
+  }
+
+  // ---- activation staging: thread handles 16-byte chunks (row, c) of the [BM][128] tile
+  auto stage_a = [&](int kb, int buf) {
+    char* base = smem + buf * (BM * 256);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx >> 4, c = idx & 15;
+      const int grow = m0 + (row < m_valid ? row : m_valid - 1);
+      v4i v = {0, 0, 0, 0};
+      if (kb * 128 + c * 8 < K) v = *reinterpret_cast<const v4i*>(act + (int64_t)grow * K + kb * 128 + c * 8);
+      // element order (a0,a4,a1,a5,a2,a6,a3,a7) to match expand_nibbles
+      v4i p;
+      p[0] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x05040100u);
+      p[1] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x07060302u);
+      p[2] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x05040100u);
+      p[3] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x07060302u);
+      *reinterpret_cast<v4i*>(base + row * 256 + ((c ^ (row & 15)) << 4)) = p;
+    }
+  };
+
+  v4f acc[MT][NW], part[MT][NW], asum[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    asum[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+      acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+      part[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const v4i ones = {(int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes};
+
+  const int nkb = (K + 127) >> 7;   // K is a multiple of 32; the last 128-block may hold 1..3 k steps
+  const int ksteps = K >> 5;
+  uint32_t wd[NW][4], wnext[NW][4];
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt) {
+    v4i t = {0, 0, 0, 0};
+    if (32 * g < K) t = *reinterpret_cast<const v4i*>(wrow[nt]);
+    wnext[nt][0] = t[0]; wnext[nt][1] = t[1]; wnext[nt][2] = t[2]; wnext[nt][3] = t[3];
+  }
+  stage_a(0, 0);
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int buf = kb & 1;
+    __syncthreads();  // tile kb is staged; everyone is done reading the other buffer
+    if (kb + 1 < nkb) stage_a(kb + 1, buf ^ 1);
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wd[nt][t] = wnext[nt][t];
+      if (kb + 1 < nkb) {
+        v4i t = {0, 0, 0, 0};
+        if ((kb + 1) * 128 + 32 * g < K) t = *reinterpret_cast<const v4i*>(wrow[nt] + (int64_t)(kb + 1) * 64);
+        wnext[nt][0] = t[0]; wnext[nt][1] = t[1]; wnext[nt][2] = t[2]; wnext[nt][3] = t[3];
+      }
+      if (!has_zp) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wd[nt][t] ^= 0x88888888u;  // two's complement -> offset binary (zp 8)
+      }
+      transpose4(wd[nt]);  // now wd[nt][j] = codes of k = 128 kb + 32 j + 8 g .. + 7 of row n
+    }
+    const char* abase = smem + buf * (BM * 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (kb * 4 + j >= ksteps) break;
+      v4i wf[NW];
+#pragma unroll
+      for (int nt = 0; nt < NW; ++nt) wf[nt] = expand_nibbles<T>(wd[nt][j]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + l15;
+        const v4i af = *reinterpret_cast<const v4i*>(abase + row * 256 + (((4 * j + g) ^ l15) << 4));
+        asum[mt] = W4<T>::mma(af, ones, asum[mt]);
+#pragma unroll
+        for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
+      }
+      // end of a scale segment: fold the exact integer partial sums into the fp32 accumulators
+      const int kstep = kb * 4 + j;
+      if (((kstep + 1) & (seg_steps - 1)) == 0) {
+        const int kg = (kstep * 32) >> group_shift;
+#pragma unroll
+        for (int nt = 0; nt < NW; ++nt) {
+          const float s = (float)srow[nt][kg];
+          const float z = has_zp ? 16.0f + (float)zrow[nt][kg] : 24.0f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float t = __builtin_fmaf(-z, asum[mt][r], part[mt][nt][r]);
+              acc[mt][nt][r] = __builtin_fmaf(s, t, acc[mt][nt][r]);
+            }
+            part[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asum[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns out[m = 16 mt + 4 g + r][n = n_base + 16 nt + l15]
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt) {
+    const int n = n_base + nt * 16 + l15;
+    if (n >= N) continue;
+    const float bv = bias ? bias[(int64_t)e * N + n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + 4 * g + r;
+        if (row < m_valid) out[(int64_t)(m0 + row) * N + n] = (T)(acc[mt][nt][r] + bv);
+      }
+    }
+  }
+}
+
+template <typename T, int MT, int NW>
+static int launch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
+                  const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
+  constexpr int BM = 16 * MT, BN = 64 * NW;
+  const int64_t max_mblocks = total_m / BM + E;  // sum_e ceil(rows_e / BM) <= total_m / BM + E
+  dim3 grid((unsigned)max_mblocks, (unsigned)cdiv(N, BN));
+  moe_w4a16_kernel<T, MT, NW><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, (const T*)scales,
+                                                    (const T*)zeros, bias, rows, E, N, K, group_shift);
+  return check_launch("moe_grouped_mm_nt_xe20_w4a16");
+}
+
+template <typename T>
+static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
+                    const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
+  // tile policy by average rows per expert (the reference switches policies the same way,
+  // GroupGemmW4A16Xe20.cpp:266-277): decode streams weights with one 16-row tile per block
+  const int64_t avg = total_m / E;
+  if (avg <= 16) return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  if (avg <= 32) return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  if (avg <= 128) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  return launch<T, 8, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+}
+
+}  // namespace
+}  // namespace sglk
+
+extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const void* activations,
+                                         const void* packed_weights, const void* scales, const void* zeros,
+                                         const float* bias, const int32_t* rows_per_expert, int64_t total_m,
+                                         int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
+                                         int dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(is_int4, "moe_grouped_mm_nt_xe20_w4a16: only the int4 weight format is built for gfx950 (mxfp4 is not)");
+  SGLK_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256,
+               "group_size must be 32, 64, 128 or 256; got %lld", (long long)group_size);
+  SGLK_REQUIRE(K > 0 && K % group_size == 0, "K must be a multiple of group_size");
+  SGLK_REQUIRE(N > 0 && N % 8 == 0, "N must be divisible by 8");
+  SGLK_REQUIRE(n_experts > 0, "n_experts must be positive");
+  SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "activations must be bfloat16 or half");
+  SGLK_REQUIRE((uintptr_t)activations % 16 == 0 && (uintptr_t)packed_weights % 16 == 0,
+               "moe_grouped_mm_nt_xe20_w4a16: activations and packed_weights must be 16-byte aligned");
+  if (total_m == 0) return SGLK_OK;
+  const int gs = group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGLK_BF16)
+    return dispatch<bf16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
+                          (int)n_experts, (int)N, (int)K, gs);
+  return dispatch<f16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
+                       (int)n_experts, (int)N, (int)K, gs);
+}

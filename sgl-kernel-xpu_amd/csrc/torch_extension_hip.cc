@@ -17,6 +17,7 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <algorithm>
 #include <optional>
 #include <tuple>
 
@@ -343,6 +344,200 @@ int64_t flash_mla_get_workspace_size(int64_t max_seq_len, int64_t num_batches, i
   return sglk_mla_decode_workspace_size(max_seq_len, num_batches, num_heads, num_kv_splits);
 }
 
+// ---- MoE (reference src/sycl/TopKSoftMax.cpp:584-644, MoEAlign.cpp:313-383, MoEPrepareInputs.cpp,
+//           GroupGemmW4A16Xe20.cpp:92-283) ----------------------------------------------------------
+
+void topk_softmax(Tensor& topk_weights, Tensor& topk_indices, Tensor& gating_output, bool renormalize) {
+  CHECK_GPU(gating_output);
+  CHECK_GPU(topk_weights);
+  CHECK_GPU(topk_indices);
+  TORCH_CHECK(gating_output.dim() == 2, "gating_output must be 2D tensor, but got ", gating_output.dim(), "D");
+  const int64_t n_tokens = gating_output.size(0), n_experts = gating_output.size(1);
+  TORCH_CHECK(n_experts <= 256, "n_experts only support up to 256, but got ", n_experts);
+  TORCH_CHECK(topk_weights.scalar_type() == at::kFloat, "topk_weights should be Float");
+  TORCH_CHECK(topk_indices.scalar_type() == at::kInt, "topk_indices should be Int");
+  TORCH_CHECK(topk_weights.dim() == 2, "topk_weights must be 2D tensor, but got ", topk_weights.dim(), "D");
+  TORCH_CHECK(topk_indices.dim() == 2, "topk_indices must be 2D tensor, but got ", topk_indices.dim(), "D");
+  TORCH_CHECK(topk_weights.size(0) == n_tokens, "topk_weights.size(0) must equal n_tokens, but got ",
+              topk_weights.size(0), " vs ", n_tokens);
+  TORCH_CHECK(topk_indices.size(0) == n_tokens, "topk_indices.size(0) must equal n_tokens, but got ",
+              topk_indices.size(0), " vs ", n_tokens);
+  const int64_t n_topk = topk_weights.size(1);
+  TORCH_CHECK(topk_indices.size(1) == n_topk, "topk_indices.size(1) must equal topk_weights.size(1), but got ",
+              topk_indices.size(1), " vs ", n_topk);
+  TORCH_CHECK(0 < n_topk && n_topk <= std::min<int64_t>(n_experts, 64),
+              "n_topk must satisfy 0 < n_topk <= min(n_experts, 64), but got n_topk=", n_topk,
+              " and n_experts=", n_experts);
+  CHECK_CONTIGUOUS(gating_output);
+  CHECK_CONTIGUOUS(topk_weights);
+  CHECK_CONTIGUOUS(topk_indices);
+  const auto dt = gating_output.scalar_type();
+  TORCH_CHECK(dt == at::kHalf || dt == at::kBFloat16 || dt == at::kFloat, "gating_output must be a floating tensor");
+  const c10::OptionalDeviceGuard guard(gating_output.device());
+  SGLK_CALL(sglk_topk_softmax(stream_of(gating_output), topk_weights.data_ptr<float>(),
+                              topk_indices.data_ptr<int32_t>(), gating_output.data_ptr(), n_tokens, n_experts, n_topk,
+                              renormalize ? 1 : 0, dtype_code(dt, "gating_output")));
+}
+
+void moe_align_block_size(Tensor topk_ids, int64_t num_experts, int64_t block_size, Tensor sorted_token_ids,
+                          Tensor experts_ids, Tensor num_tokens_post_pad, Tensor cumsum_buffer,
+                          bool pad_sorted_token_ids) {
+  CHECK_GPU(topk_ids);
+  CHECK_GPU(sorted_token_ids);
+  CHECK_GPU(experts_ids);
+  CHECK_GPU(num_tokens_post_pad);
+  CHECK_GPU(cumsum_buffer);
+  CHECK_CONTIGUOUS(topk_ids);
+  TORCH_CHECK(sorted_token_ids.scalar_type() == at::kInt && experts_ids.scalar_type() == at::kInt &&
+                  num_tokens_post_pad.scalar_type() == at::kInt && cumsum_buffer.scalar_type() == at::kInt,
+              "moe_align_block_size: output tensors must be int32");
+  TORCH_CHECK(cumsum_buffer.numel() >= num_experts + 1, "moe_align_block_size: cumsum_buffer needs num_experts + 1 elements");
+  const auto it = topk_ids.scalar_type();
+  TORCH_CHECK(it == at::kInt || it == at::kLong, "moe_align_block_size: topk_ids must be int32 or int64");
+  const c10::OptionalDeviceGuard guard(topk_ids.device());
+  SGLK_CALL(sglk_moe_align_block_size(stream_of(topk_ids), topk_ids.data_ptr(), dtype_code(it, "topk_ids"),
+                                      topk_ids.numel(), num_experts, block_size, sorted_token_ids.data_ptr<int32_t>(),
+                                      experts_ids.data_ptr<int32_t>(), num_tokens_post_pad.data_ptr<int32_t>(),
+                                      cumsum_buffer.data_ptr<int32_t>(), pad_sorted_token_ids ? 1 : 0));
+}
+
+void prepare_moe_input(const Tensor& topk_ids, Tensor& expert_offsets, const std::optional<Tensor>& blockscale_offsets,
+                       Tensor& problem_sizes1, Tensor& problem_sizes2, Tensor& input_permutation,
+                       Tensor& output_permutation, int64_t num_experts, int64_t n, int64_t k) {
+  CHECK_GPU(topk_ids);
+  const auto it = topk_ids.scalar_type();
+  TORCH_CHECK(it == problem_sizes1.scalar_type(), "problem_sizes1 must have same type as topk_ids");
+  TORCH_CHECK(it == expert_offsets.scalar_type(), "expert_offsets must have same type as topk_ids");
+  TORCH_CHECK(it == problem_sizes2.scalar_type(), "problem_sizes2 must have same type as topk_ids");
+  TORCH_CHECK(it == input_permutation.scalar_type(), "input_permutation must have same type as topk_ids");
+  TORCH_CHECK(it == output_permutation.scalar_type(), "output_permutation must have same type as topk_ids");
+  TORCH_CHECK(it == at::kInt || it == at::kLong, "prepare_moe_input: index tensors must be int32 or int64");
+  TORCH_CHECK(!blockscale_offsets.has_value(), "prepare_moe_input: blockscale_offsets is not supported on this build");
+  TORCH_CHECK(topk_ids.dim() == 2 && topk_ids.is_contiguous(), "prepare_moe_input: topk_ids must be contiguous [tokens, topk]");
+  TORCH_CHECK(expert_offsets.numel() >= num_experts && problem_sizes1.numel() >= 3 * num_experts &&
+                  problem_sizes2.numel() >= 3 * num_experts && input_permutation.numel() >= topk_ids.numel() &&
+                  output_permutation.numel() >= topk_ids.numel(),
+              "prepare_moe_input: an output tensor is too small");
+  const c10::OptionalDeviceGuard guard(topk_ids.device());
+  SGLK_CALL(sglk_prepare_moe_input(stream_of(topk_ids), topk_ids.data_ptr(), expert_offsets.data_ptr(),
+                                   problem_sizes1.data_ptr(), problem_sizes2.data_ptr(), input_permutation.data_ptr(),
+                                   output_permutation.data_ptr(), topk_ids.numel(), topk_ids.size(1), num_experts, n, k,
+                                   dtype_code(it, "topk_ids")));
+}
+
+void scatter_tokens_to_experts(const Tensor& input, const Tensor& src2dst_map, Tensor& output) {
+  CHECK_GPU(input);
+  CHECK_GPU(src2dst_map);
+  CHECK_GPU(output);
+  TORCH_CHECK(input.scalar_type() == output.scalar_type(), "Input and output tensors must have the same data type");
+  TORCH_CHECK(input.dim() == 2 && output.dim() == 2 && input.is_contiguous() && output.is_contiguous(),
+              "scatter_tokens_to_experts: input and output must be contiguous 2-D tensors");
+  TORCH_CHECK(input.size(1) == output.size(1), "scatter_tokens_to_experts: hidden sizes differ");
+  TORCH_CHECK(src2dst_map.scalar_type() == at::kInt && src2dst_map.is_contiguous(),
+              "scatter_tokens_to_experts: src2dst_map must be a contiguous int32 tensor");
+  const int64_t tokens = input.size(0);
+  if (tokens == 0) return;
+  TORCH_CHECK(output.size(0) % tokens == 0, "scatter_tokens_to_experts: output rows must be a multiple of input rows");
+  const int64_t topk = output.size(0) / tokens;
+  TORCH_CHECK(src2dst_map.numel() >= tokens * topk, "scatter_tokens_to_experts: src2dst_map is too small");
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_scatter_tokens_to_experts(stream_of(input), input.data_ptr(), src2dst_map.data_ptr<int32_t>(),
+                                           output.data_ptr(), tokens, topk, input.size(1) * input.element_size()));
+}
+
+void apply_shuffle_mul_sum(const Tensor& input, Tensor& output, const Tensor& permutation,
+                           double routed_scaling_factor, const std::optional<Tensor>& factors) {
+  CHECK_GPU(input);
+  CHECK_GPU(output);
+  CHECK_GPU(permutation);
+  TORCH_CHECK(input.dim() == 2 && output.dim() == 2 && input.is_contiguous() && output.is_contiguous(),
+              "apply_shuffle_mul_sum: input and output must be contiguous 2-D tensors");
+  TORCH_CHECK(input.scalar_type() == output.scalar_type() && input.size(1) == output.size(1),
+              "apply_shuffle_mul_sum: input and output must share dtype and hidden size");
+  TORCH_CHECK(permutation.scalar_type() == at::kInt && permutation.is_contiguous(),
+              "apply_shuffle_mul_sum: permutation must be a contiguous int32 tensor");
+  const int64_t m = output.size(0);
+  if (m == 0) return;
+  const int64_t topk = permutation.numel() / m;
+  const void* fptr = nullptr;
+  int fdt = SGLK_F32;
+  if (factors.has_value()) {
+    CHECK_GPU(*factors);
+    TORCH_CHECK(factors->is_contiguous() && factors->numel() >= m * topk, "apply_shuffle_mul_sum: bad factors tensor");
+    fptr = factors->data_ptr();
+    fdt = dtype_code(factors->scalar_type(), "factors");
+  }
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_apply_shuffle_mul_sum(stream_of(input), input.data_ptr(), output.data_ptr(),
+                                       permutation.data_ptr<int32_t>(), fptr, m, topk, output.size(1),
+                                       (float)routed_scaling_factor, dtype_code(input.scalar_type(), "input"), fdt));
+}
+
+void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
+                                  const Tensor& scales, const std::optional<Tensor>& zeros,
+                                  const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
+                                  bool is_int4, int64_t group_size) {
+  CHECK_GPU(output);
+  CHECK_GPU(activations);
+  CHECK_GPU(packed_weights);
+  CHECK_GPU(scales);
+  CHECK_GPU(rows_per_expert);
+  CHECK_CONTIGUOUS(output);
+  CHECK_CONTIGUOUS(activations);
+  CHECK_CONTIGUOUS(packed_weights);
+  CHECK_CONTIGUOUS(scales);
+  CHECK_CONTIGUOUS(rows_per_expert);
+  TORCH_CHECK(output.dim() == 2, "output must be 2D [total_m, N]");
+  TORCH_CHECK(activations.dim() == 2, "activations must be 2D [total_m, K]");
+  TORCH_CHECK(rows_per_expert.dim() == 1, "rows_per_expert must be 1D [E]");
+  const int64_t total_m = activations.size(0), gemm_k = activations.size(1);
+  TORCH_CHECK(packed_weights.dim() == 3, "packed_weights must be 3D [E, N, K/2]");
+  const int64_t gemm_n = packed_weights.size(1);
+  TORCH_CHECK(packed_weights.size(0) == n_experts, "packed_weights.size(0) must equal n_experts");
+  TORCH_CHECK(packed_weights.size(2) == gemm_k / 2, "packed_weights.size(2) must equal K/2 (two 4-bit values per byte)");
+  TORCH_CHECK(packed_weights.scalar_type() == at::kChar || packed_weights.scalar_type() == at::kByte,
+              "packed_weights must be int8 or uint8");
+  TORCH_CHECK(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256,
+              "group_size must be 32, 64, 128 or 256; got ", group_size);
+  TORCH_CHECK(gemm_k % group_size == 0, "K must be a multiple of group_size");
+  TORCH_CHECK(scales.dim() == 3, "scales must be 3D [E, N, K/group_size]");
+  TORCH_CHECK(scales.size(0) == n_experts, "scales.size(0) must equal n_experts");
+  TORCH_CHECK(scales.size(1) == gemm_n, "scales.size(1) must equal N");
+  TORCH_CHECK(scales.size(2) == gemm_k / group_size, "scales.size(2) must equal K/group_size");
+  TORCH_CHECK(is_int4, "moe_grouped_mm_nt_xe20_w4a16: mxfp4 weights are not built for gfx950 yet; int4 only");
+  TORCH_CHECK(scales.scalar_type() == activations.scalar_type(), "int4 scales dtype must match activations dtype");
+  TORCH_CHECK(n_experts > 0, "n_experts must be positive");
+  TORCH_CHECK(n_experts == rows_per_expert.size(0), "rows_per_expert must have n_experts elements");
+  TORCH_CHECK(rows_per_expert.scalar_type() == at::kInt, "rows_per_expert must be int32");
+  TORCH_CHECK(output.size(0) == total_m, "output rows must match activations rows");
+  TORCH_CHECK(output.size(1) == gemm_n, "output must have N columns");
+  TORCH_CHECK(gemm_n % 8 == 0, "N must be divisible by 8");
+  TORCH_CHECK(activations.scalar_type() == at::kBFloat16 || activations.scalar_type() == at::kHalf,
+              "activations must be bfloat16 or half");
+  TORCH_CHECK(output.scalar_type() == activations.scalar_type(), "output dtype must match activations dtype");
+  const float* bias_ptr = nullptr;
+  if (bias.has_value()) {
+    CHECK_GPU(*bias);
+    TORCH_CHECK(bias->scalar_type() == at::kFloat, "bias must be float32");
+    TORCH_CHECK(bias->dim() == 2 && bias->is_contiguous(), "bias must be 2D [E, N]");
+    TORCH_CHECK(bias->size(0) == n_experts && bias->size(1) == gemm_n, "bias shape must be [E, N]");
+    bias_ptr = bias->data_ptr<float>();
+  }
+  const void* zeros_ptr = nullptr;
+  if (zeros.has_value()) {
+    CHECK_GPU(*zeros);
+    TORCH_CHECK(zeros->scalar_type() == scales.scalar_type(), "zeros dtype must match int4 scales dtype");
+    TORCH_CHECK(zeros->sizes() == scales.sizes() && zeros->is_contiguous(),
+                "zeros shape must match scales shape [E, N, K/group_size]");
+    zeros_ptr = zeros->data_ptr();
+  }
+  const c10::OptionalDeviceGuard guard(activations.device());
+  SGLK_CALL(sglk_moe_grouped_mm_w4a16(stream_of(activations), output.data_ptr(), activations.data_ptr(),
+                                      packed_weights.data_ptr(), scales.data_ptr(), zeros_ptr, bias_ptr,
+                                      rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
+                                      group_size, is_int4 ? 1 : 0, dtype_code(activations.scalar_type(), "activations")));
+}
+
 }  // namespace
 
 TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
@@ -389,6 +584,30 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "flash_mla_decode(Tensor! out, Tensor! q_nope, Tensor! q_pe, Tensor! kv_c_and_k_pe_cache, Tensor! seq_lens,"
       " Tensor! page_table, Tensor! workspace, float sm_scale, int num_kv_splits) -> ()");
   m.impl("flash_mla_decode", c10::kCUDA, &flash_mla_decode);
+
+  // reference src/torch_extension_sycl.cc:53, :199-203, :214-229
+  m.def("topk_softmax(Tensor! topk_weights, Tensor! topk_indices, Tensor gating_output, bool renormalize) -> ()");
+  m.impl("topk_softmax", c10::kCUDA, &topk_softmax);
+  m.def(
+      "moe_align_block_size(Tensor topk_ids, int num_experts, int block_size, Tensor! sorted_token_ids, Tensor! "
+      "experts_ids, Tensor! num_tokens_post_pad, Tensor! cumsum_buffer, bool "
+      "pad_sorted_token_ids) -> ()");
+  m.impl("moe_align_block_size", c10::kCUDA, &moe_align_block_size);
+  m.def(
+      "moe_grouped_mm_nt_xe20_w4a16(Tensor! output, Tensor activations, Tensor packed_weights, Tensor scales, "
+      "Tensor? zeros, Tensor? bias, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size) -> ()");
+  m.impl("moe_grouped_mm_nt_xe20_w4a16", c10::kCUDA, &moe_grouped_mm_nt_xe20_w4a16);
+  m.def(
+      "prepare_moe_input(Tensor topk_ids, Tensor! expert_offsets, Tensor? blockscale_offsets, Tensor! problem_sizes1,"
+      " Tensor! problem_sizes2, Tensor! input_permutation, Tensor! output_permutation, int num_experts, int n, int k)"
+      " -> ()");
+  m.impl("prepare_moe_input", c10::kCUDA, &prepare_moe_input);
+  m.def("scatter_tokens_to_experts(Tensor input, Tensor src2dst_map, Tensor! output) -> ()");
+  m.impl("scatter_tokens_to_experts", c10::kCUDA, &scatter_tokens_to_experts);
+  m.def(
+      "apply_shuffle_mul_sum(Tensor input, Tensor! output, Tensor permutation, float routed_scaling_factor, Tensor? "
+      "factors) -> ()");
+  m.impl("apply_shuffle_mul_sum", c10::kCUDA, &apply_shuffle_mul_sum);
 }
 
 // The loader does `from sgl_kernel import common_ops` (reference python/sgl_kernel/__init__.py:14);

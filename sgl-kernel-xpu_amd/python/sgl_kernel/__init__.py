@@ -36,6 +36,14 @@ from sgl_kernel.gemm import (  # noqa: E402
     sgl_per_token_group_quant_fp8,
     sgl_per_token_group_quant_int8,
 )
+from sgl_kernel.moe import (  # noqa: E402
+    apply_shuffle_mul_sum,
+    fused_experts,
+    moe_align_block_size,
+    prepare_moe_input,
+    scatter_tokens_to_experts,
+    topk_softmax,
+)
 from sgl_kernel.utils import get_device_capability, is_gfx950_arch, is_xe2_arch  # noqa: E402
 from sgl_kernel.version import __version__  # noqa: E402
 

@@ -166,7 +166,58 @@ def gen_mla_decode():
     save("mla_decode", cases)
 
 
+def gen_moe():
+    t = _import_ref("test_moe_gemm")
+    cases = {"grouped_mm": [], "fused": []}
+    # tests/test_moe_gemm.py:347-386 (_check_int4_grouped_mm): E=8, 2 rows/expert, N=128, K=256
+    for explicit_zero, dt, gs in [(False, torch.bfloat16, 32), (True, torch.bfloat16, 64), (False, torch.float16, 128),
+                                  (True, torch.float16, 256)]:
+        torch.manual_seed(0)
+        E, rpe, n, k = 8, 2, 128, 256
+        act = torch.randn(E * rpe, k, dtype=dt) * 0.1
+        packed, scales, zeros, weights = t._make_int4_weight(E, n, k, gs, dt, explicit_zero)
+        expected = torch.cat([act[e * rpe:(e + 1) * rpe].float() @ weights[e].float().t() for e in range(E)]).to(dt)
+        cases["grouped_mm"].append(dict(act=act, packed=packed.view(torch.uint8), scales=scales, zeros=zeros,
+                                        group_size=gs, rows_per_expert=rpe, out=expected))
+    # tests/test_moe_gemm.py:408-471 (test_fused_experts_int4_w4a16): seed 1, T=5, k=2, E=8, H=128, I=64, g=32
+    for explicit_zero in (False, True):
+        for dt in (torch.bfloat16, torch.float16):
+            for with_bias in (False, True):
+                for activation in ("silu", "relu2"):
+                    torch.manual_seed(1)
+                    T, topk, E, H, I, gs = 5, 2, 8, 128, 64, 32
+                    gate = 1 if activation == "relu2" else 2
+                    x = torch.randn(T, H, dtype=dt) * 0.1
+                    w1, w1s, w1z, w1ref = t._make_int4_weight(E, gate * I, H, gs, dt, explicit_zero)
+                    w2, w2s, w2z, w2ref = t._make_int4_weight(E, H, I, gs, dt, explicit_zero)
+                    ids = torch.tensor([[0, 1], [2, 3], [4, 5], [6, 7], [0, 2]], dtype=torch.int64)
+                    tw = torch.rand(T, topk, dtype=torch.float32)
+                    tw /= tw.sum(dim=-1, keepdim=True)
+                    b1 = torch.randn(E, gate * I) * 0.005 if with_bias else None
+                    b2 = torch.randn(E, H) * 0.005 if with_bias else None
+                    exp = t.torch_naive_moe(x, w1ref, w2ref, ids, tw, topk, b1, b2, activations=activation)
+                    cases["fused"].append(dict(x=x, w1=w1.view(torch.uint8), w2=w2.view(torch.uint8), w1_scale=w1s,
+                                               w2_scale=w2s, w1_zp=w1z, w2_zp=w2z, topk_ids=ids, topk_weights=tw,
+                                               b1=b1, b2=b2, activation=activation, out=exp))
+    save("moe_w4a16", cases)
+
+
+def gen_topk_softmax():
+    t = _import_ref("test_topk_softmax")
+    cases = []
+    torch.manual_seed(1024)
+    for dt, n_token, n_expert, topk, renorm in [(torch.bfloat16, 32, 8, 2, True), (torch.float16, 32, 256, 4, False),
+                                                (torch.bfloat16, 7, 32, 1, True), (torch.float16, 64, 60, 3, True)]:
+        gating = torch.randn(n_token, n_expert).to(dt)  # unit scale: no exact ties, weights are meaningful
+        hidden = torch.randn(n_token, 100)
+        w, ids = t.fused_topk_torch_native(hidden, gating.float(), topk, renorm)
+        cases.append(dict(gating=gating, topk=topk, renormalize=renorm, weights=w, ids=ids.to(torch.int32)))
+    save("topk_softmax", cases)
+
+
 GENERATORS = {
+    "moe_w4a16": gen_moe,
+    "topk_softmax": gen_topk_softmax,
     "mla_decode": gen_mla_decode,
     "norm": gen_norm,
     "activation": gen_activation,

@@ -1,0 +1,225 @@
+"""GPU parity: MoE routing (exact integer paths), data movement, W4A16 grouped GEMM and fused_experts
+vs the CPU oracle and the reference-generated golden vectors. Grids follow reference tests/test_topk_softmax.py:61-73,
+tests/test_moe_align.py:141-155 and tests/test_moe_gemm.py:347-471."""
+import numpy as np
+import pytest
+import torch
+from conftest import load_golden
+
+from oracle import moe as omoe
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------ topk_softmax
+def check_topk(p, ref_idx, our_idx):
+    """tests/test_topk_softmax.py:12-37: sets must match except where the swapped members have equal scores."""
+    for r in (ref_idx != our_idx).any(dim=1).nonzero().flatten().tolist():
+        a, b = set(our_idx[r].tolist()), set(ref_idx[r].tolist())
+        assert sorted(p[r, list(a - b)].tolist()) == sorted(p[r, list(b - a)].tolist()), f"row {r}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n_token", [2, 32, 4096])
+@pytest.mark.parametrize("n_expert", [8, 32, 60, 256])
+@pytest.mark.parametrize("n_topk", [1, 2, 4, 8])
+@pytest.mark.parametrize("renormalize", [False, True])
+def test_topk_softmax(sglk, dev, dtype, n_token, n_expert, n_topk, renormalize):
+    g = torch.Generator().manual_seed(1024 + n_token + n_expert)
+    for scale in (1.0, 2.0 * n_token):  # unit-scale logits, and the reference test's (mostly one-hot) scale
+        gating = (torch.randn(n_token, n_expert, generator=g) * scale).to(dtype)
+        w = torch.empty(n_token, n_topk, dtype=torch.float32, device=dev)
+        idx = torch.empty(n_token, n_topk, dtype=torch.int32, device=dev)
+        sglk.topk_softmax(w, idx, gating.to(dev), renormalize)
+        rw, ridx, p = omoe.topk_softmax(gating, n_topk, renormalize)
+        # the index path is exact: arg-max on the logits, lower index on ties
+        assert torch.equal(idx.cpu(), ridx)
+        # and it is a valid top-k of the softmax in the reference test's sense
+        check_topk(p, torch.topk(p, n_topk, dim=-1).indices.to(torch.int32), idx.cpu())
+        torch.testing.assert_close(w.cpu(), rw, rtol=1e-4, atol=1e-7)
+
+
+def test_topk_softmax_ties_pick_lower_index(sglk, dev):
+    gating = torch.zeros(3, 16, dtype=torch.bfloat16)
+    gating[1, 5] = 1.0
+    gating[2, 9] = gating[2, 3] = 2.0
+    w = torch.empty(3, 3, dtype=torch.float32, device=dev)
+    idx = torch.empty(3, 3, dtype=torch.int32, device=dev)
+    sglk.topk_softmax(w, idx, gating.to(dev), False)
+    assert idx.cpu().tolist() == [[0, 1, 2], [5, 0, 1], [3, 9, 0]]
+
+
+# ---------------------------------------------------------------------------------- moe_align_block_size
+@pytest.mark.parametrize("block_size", [32, 64, 128, 256])
+@pytest.mark.parametrize("num_tokens,topk", [(1, 1), (2, 8), (16, 64), (128, 4), (1024, 2), (4096, 8), (4096, 64)])
+@pytest.mark.parametrize("num_experts", [16, 64, 160, 256, 257, 264])
+@pytest.mark.parametrize("pad", [True, False])
+def test_moe_align_block_size(sglk, dev, block_size, num_tokens, topk, num_experts, pad):
+    if topk > num_experts:
+        pytest.skip("topk > experts")
+    g = torch.Generator().manual_seed(num_tokens * 7 + topk + num_experts)
+    ids = torch.argsort(torch.rand(num_tokens, num_experts, generator=g), dim=1)[:, :topk].contiguous()
+    if num_tokens >= 16:
+        ids[::5, 0] = -1  # tokens routed off-rank land in bucket 0 (tests/test_moe_align.py:183-193 passes E + 1)
+    numel = ids.numel()
+    max_pad = numel + (num_experts + 1) * (block_size - 1)
+    sorted_ids = torch.full((max_pad,), numel, dtype=torch.int32, device=dev)
+    if pad:
+        sorted_ids.fill_(-7)
+    expert_ids = torch.zeros(max_pad // block_size, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    cumsum = torch.empty(num_experts + 2, dtype=torch.int32, device=dev)
+    sglk.moe_align_block_size(ids.to(dev), num_experts + 1, block_size, sorted_ids, expert_ids, total, cumsum, pad)
+    rs, re, rtotal, rprefix = omoe.moe_align_block_size(ids.numpy(), num_experts + 1, block_size)
+    assert total.item() == rtotal
+    nblk = rtotal // block_size
+    assert np.array_equal(expert_ids.cpu().numpy()[:nblk], re)
+    got = sorted_ids.cpu().numpy()[:rtotal]
+    # every bucket segment holds exactly the oracle's members (order inside a bucket is unspecified) + padding
+    for b in range(num_experts + 1):
+        lo, hi = rprefix[b], rprefix[b + 1]
+        assert np.array_equal(np.sort(got[lo:hi]), np.sort(rs[lo:hi])), f"bucket {b}"
+    counts = np.bincount(ids.numpy().reshape(-1) + 1, minlength=num_experts + 1)
+    assert np.array_equal(cumsum.cpu().numpy()[: num_experts + 1], rprefix[: num_experts + 1] + counts)
+
+
+# ------------------------------------------------------------------ prepare_moe_input / scatter / combine
+@pytest.mark.parametrize("tokens,topk,E", [(1, 2, 8), (5, 2, 8), (300, 8, 64), (4096, 2, 8), (1000, 6, 256)])
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_prepare_scatter_combine(sglk, dev, tokens, topk, E, idt):
+    g = torch.Generator().manual_seed(tokens + topk)
+    ids = torch.argsort(torch.rand(tokens, E, generator=g), dim=1)[:, :topk].to(idt).contiguous()
+    counts = torch.empty(E, dtype=idt, device=dev)
+    ps1 = torch.empty(E, 3, dtype=idt, device=dev)
+    ps2 = torch.empty(E, 3, dtype=idt, device=dev)
+    a_map = torch.empty(tokens * topk, dtype=idt, device=dev)
+    c_map = torch.empty(tokens * topk, dtype=idt, device=dev)
+    sglk.prepare_moe_input(ids.to(dev), counts, ps1, ps2, a_map, c_map, E, 1024, 77)
+    rc, r1, r2, ra, rcm = omoe.prepare_moe_input(ids.numpy(), E, 1024, 77)
+    assert np.array_equal(counts.cpu().numpy(), rc)
+    assert np.array_equal(ps1.cpu().numpy(), r1) and np.array_equal(ps2.cpu().numpy(), r2)
+    assert np.array_equal(a_map.cpu().numpy(), ra) and np.array_equal(c_map.cpu().numpy(), rcm)
+    if idt != torch.int32:
+        return
+    hidden = 520  # not a multiple of the 256-thread vector stride
+    for dt in (torch.bfloat16, torch.float16):
+        x = torch.randn(tokens, hidden, generator=g).to(dt)
+        out = torch.zeros(tokens * topk, hidden, dtype=dt, device=dev)
+        sglk.scatter_tokens_to_experts(x.to(dev), c_map, out)
+        assert torch.equal(out.cpu(), x[torch.from_numpy(ra).long()])
+        w = torch.rand(tokens, topk, generator=g)
+        y = torch.empty(tokens, hidden, dtype=dt, device=dev)
+        for rsf in (None, 2.5):
+            sglk.apply_shuffle_mul_sum(out, y, c_map, w.to(dev), rsf)
+            t = x.float().unsqueeze(1) * w.unsqueeze(-1)
+            if rsf:
+                t = t * rsf
+            acc = torch.zeros(tokens, hidden)
+            for j in range(topk):
+                acc = acc + t[:, j]
+            assert torch.equal(y.cpu(), acc.to(dt)), "fp32 slot-order accumulation must be bit-exact"
+        sglk.apply_shuffle_mul_sum(out, y, c_map, None)
+        torch.testing.assert_close(y.cpu().float(), x.float() * topk, rtol=1e-2, atol=1e-2)
+
+
+# ------------------------------------------------------------------------------- W4A16 grouped GEMM
+def make_int4(E, N, K, gs, dtype, explicit_zero, g):
+    if explicit_zero:
+        codes = torch.randint(0, 16, (E, N, K), generator=g, dtype=torch.int16)
+        zeros = torch.randint(3, 13, (E, N, K // gs), generator=g).to(dtype)
+    else:
+        codes = torch.randint(-8, 8, (E, N, K), generator=g, dtype=torch.int16)
+        zeros = None
+    scales = (torch.rand(E, N, K // gs, generator=g) * 0.02 + 0.005).to(dtype)
+    nib = codes & 0xF
+    packed = (nib[..., 0::2] | (nib[..., 1::2] << 4)).to(torch.uint8)
+    return packed, scales, zeros
+
+
+@pytest.mark.parametrize("explicit_zero", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gs", [32, 64, 128, 256])
+@pytest.mark.parametrize("rows,N,K", [([2] * 8, 128, 256), ([0, 5, 17, 0, 1, 33, 0, 129], 200, 512),
+                                      ([300, 0, 40, 7], 1024, 1280), ([1] * 8, 4096, 1024)])
+def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
+    if K % gs:
+        pytest.skip("K not a multiple of the group")
+    g = torch.Generator().manual_seed(len(rows) * 31 + N + K + gs)
+    E = len(rows)
+    total = sum(rows)
+    act = (torch.randn(total, K, generator=g) * 0.1).to(dtype)
+    packed, scales, zeros = make_int4(E, N, K, gs, dtype, explicit_zero, g)
+    bias = torch.randn(E, N, generator=g) * 0.01 if (N % 256 == 0) else None
+    rows_t = torch.tensor(rows, dtype=torch.int32)
+    out = torch.full((total, N), float("nan"), dtype=dtype, device=dev)
+    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(
+        out, act.to(dev), packed.view(torch.int8 if explicit_zero else torch.uint8).to(dev), scales.to(dev),
+        zeros.to(dev) if zeros is not None else None, bias.to(dev) if bias is not None else None, rows_t.to(dev), E,
+        True, gs)
+    ref = omoe.moe_grouped_mm_w4a16(act, packed, scales, zeros, bias, rows_t, gs)
+    torch.testing.assert_close(out.cpu(), ref, rtol=5e-2, atol=2e-2)  # reference tolerance (tests/test_moe_gemm.py:386)
+    # the kernel keeps the codes exact and scales in fp32; against that (more accurate) definition it is tight
+    codes = omoe.unpack_int4(packed, signed=zeros is None).float()
+    z = zeros.float().repeat_interleave(gs, dim=-1) if zeros is not None else 0.0
+    w_exact = (codes - z) * scales.float().repeat_interleave(gs, dim=-1)
+    r0, exact = 0, torch.empty(total, N)
+    for e, r in enumerate(rows):
+        exact[r0:r0 + r] = act[r0:r0 + r].float() @ w_exact[e].t() + (bias[e] if bias is not None else 0.0)
+        r0 += r
+    torch.testing.assert_close(out.cpu().float(), exact.to(dtype).float(), rtol=1e-2, atol=2e-3)
+
+
+def test_w4a16_golden(sglk, dev):
+    for c in load_golden("moe_w4a16")["grouped_mm"]:
+        E = c["packed"].shape[0]
+        rows = torch.full((E,), c["rows_per_expert"], dtype=torch.int32, device=dev)
+        out = torch.empty_like(c["out"], device=dev)
+        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(
+            out, c["act"].to(dev), c["packed"].to(dev), c["scales"].to(dev),
+            c["zeros"].to(dev) if c["zeros"] is not None else None, None, rows, E, True, c["group_size"])
+        torch.testing.assert_close(out.cpu(), c["out"], rtol=5e-2, atol=2e-2)
+
+
+def test_fused_experts_golden(sglk, dev):
+    d = lambda t: t.to(dev) if t is not None else None
+    for c in load_golden("moe_w4a16")["fused"]:
+        out = sglk.fused_experts(d(c["x"]), d(c["w1"].view(torch.int8)), d(c["w2"].view(torch.int8)),
+                                 d(c["topk_weights"]), d(c["topk_ids"]), d(c["b1"]), d(c["b2"]),
+                                 activation=c["activation"], use_int4_w4a16=True, w1_scale=d(c["w1_scale"]),
+                                 w2_scale=d(c["w2_scale"]), w1_zp=d(c["w1_zp"]), w2_zp=d(c["w2_zp"]))
+        torch.testing.assert_close(out.cpu(), c["out"], rtol=1e-1, atol=2e-2)  # tests/test_moe_gemm.py:471
+
+
+@pytest.mark.parametrize("T", [1, 32, 512])
+def test_fused_experts_mixtral_shape_sampled(sglk, dev, T):
+    """BASELINE configs[4] shape class (E=8, top-2, H=4096, int4 g=128) at a reduced intermediate size so the CPU
+    oracle stays in seconds; routing through topk_softmax(renormalize=True) as SGLang does."""
+    E, k, H, I, gs, dt = 8, 2, 4096, 1792, 128, torch.bfloat16
+    g = torch.Generator().manual_seed(T)
+    x = (torch.randn(T, H, generator=g) * 0.1).to(dt)
+    w1, s1, _ = make_int4(E, 2 * I, H, gs, dt, False, g)
+    w2, s2, _ = make_int4(E, H, I, gs, dt, False, g)
+    logits = torch.randn(T, E, generator=g).to(dt)
+    tw = torch.empty(T, k, dtype=torch.float32, device=dev)
+    ids = torch.empty(T, k, dtype=torch.int32, device=dev)
+    sglk.topk_softmax(tw, ids, logits.to(dev), True)
+    out = sglk.fused_experts(x.to(dev), w1.view(torch.int8).to(dev), w2.view(torch.int8).to(dev), tw, ids,
+                             use_int4_w4a16=True, w1_scale=s1.to(dev), w2_scale=s2.to(dev))
+    ref = omoe.fused_experts_int4(x, w1, w2, tw.cpu(), ids.cpu().long(), s1, s2)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-1, atol=2e-2)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=3e-2, atol=1e-2)
+
+
+def test_errors(sglk, dev):
+    with pytest.raises(NotImplementedError):
+        sglk.fused_experts(torch.zeros(1, 128, device=dev), torch.zeros(1, 2, 64, device=dev),
+                           torch.zeros(1, 128, 1, device=dev), torch.ones(1, 1, device=dev),
+                           torch.zeros(1, 1, dtype=torch.int32, device=dev))
+    with pytest.raises(RuntimeError, match="up to 256"):
+        sglk.topk_softmax(torch.empty(1, 1, device=dev), torch.empty(1, 1, dtype=torch.int32, device=dev),
+                          torch.zeros(1, 300, dtype=torch.bfloat16, device=dev), False)
+    with pytest.raises(RuntimeError, match="group_size"):
+        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(
+            torch.empty(2, 8, dtype=torch.bfloat16, device=dev), torch.zeros(2, 96, dtype=torch.bfloat16, device=dev),
+            torch.zeros(1, 8, 48, dtype=torch.uint8, device=dev), torch.ones(1, 8, 2, dtype=torch.bfloat16, device=dev),
+            None, None, torch.tensor([2], dtype=torch.int32, device=dev), 1, True, 48)

@@ -83,3 +83,49 @@ def test_scaled_mm_matches_reference_vectors():
         else:
             out = ogemm.int8_scaled_mm(c["a"], c["b_nk"].t(), c["sa"], c["sb"], c["out_dtype"], c["bias"])
             torch.testing.assert_close(out, c["out"])  # tests/test_int8_gemm.py:36
+
+
+def test_mla_decode_matches_reference_vectors():
+    from oracle import mla as omla
+    for c in load_golden("mla_decode"):
+        o = omla.mla_decode(c["q"], c["cache"], c["scale"], c["table"], c["seq_lens"])
+        tol = 1e-2 if c["q"].dtype == torch.bfloat16 else 1e-3  # tests/test_flash_mla_decode.py:145-146
+        torch.testing.assert_close(o.float(), c["out"].float(), atol=tol, rtol=tol)
+
+
+def test_moe_w4a16_matches_reference_vectors():
+    from oracle import moe as omoe
+    g = load_golden("moe_w4a16")
+    for c in g["grouped_mm"]:
+        E = c["packed"].shape[0]
+        rows = torch.full((E,), c["rows_per_expert"], dtype=torch.int32)
+        o = omoe.moe_grouped_mm_w4a16(c["act"], c["packed"], c["scales"], c["zeros"], None, rows, c["group_size"])
+        torch.testing.assert_close(o, c["out"], rtol=5e-2, atol=2e-2)  # tests/test_moe_gemm.py:386
+    for c in g["fused"]:
+        o = omoe.fused_experts_int4(c["x"], c["w1"], c["w2"], c["topk_weights"], c["topk_ids"], c["w1_scale"],
+                                    c["w2_scale"], c["w1_zp"], c["w2_zp"], c["b1"], c["b2"], c["activation"])
+        torch.testing.assert_close(o, c["out"], rtol=1e-1, atol=2e-2)  # tests/test_moe_gemm.py:471
+
+
+def test_topk_softmax_matches_reference_vectors():
+    from oracle import moe as omoe
+    for c in load_golden("topk_softmax"):
+        w, idx, p = omoe.topk_softmax(c["gating"], c["topk"], c["renormalize"])
+        for r in (idx != c["ids"]).any(dim=1).nonzero().flatten().tolist():
+            a, b = set(idx[r].tolist()), set(c["ids"][r].tolist())
+            # equal-score ties may be broken differently (tests/test_topk_softmax.py:12-37)
+            assert sorted(p[r, list(a - b)].tolist()) == sorted(p[r, list(b - a)].tolist())
+        torch.testing.assert_close(w.sort(dim=1).values, c["weights"].sort(dim=1).values, rtol=1e-5, atol=1e-6)
+
+
+def test_moe_align_and_prepare_known_answers():
+    import numpy as np
+    from oracle import moe as omoe
+    ids = np.array([[0, 2], [2, 1], [0, 0], [-1, 2]])
+    s, e, total, prefix = omoe.moe_align_block_size(ids, 4, 4)  # buckets: id+1; 3 real experts + the "-1" bucket
+    assert prefix.tolist() == [0, 4, 8, 12, 16] and total == 16
+    assert e.tolist() == [-1, 0, 1, 2]
+    assert s.tolist() == [6, 8, 8, 8, 0, 4, 5, 8, 3, 8, 8, 8, 1, 2, 7, 8]
+    cnt, ps1, ps2, a_map, c_map = omoe.prepare_moe_input(np.array([[0, 2], [2, 1], [0, 0]]), 3, 7, 2)
+    assert cnt.tolist() == [3, 1, 2] and ps1[0].tolist() == [3, 14, 2] and ps2[2].tolist() == [2, 2, 7]
+    assert a_map.tolist() == [0, 2, 2, 1, 0, 1] and c_map.tolist() == [0, 4, 5, 3, 1, 2]
