@@ -206,6 +206,55 @@ SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const vo
                                        int64_t n_experts, int64_t N, int64_t K, int64_t group_size,
                                        int is_int4, int dtype);
 
+/* ---- flash-attention forward ---------------------------------------------------
+ * fwd (mha_fwd): reference src/sycl/flash_attention.cpp:1332-1435 (schema
+ * src/torch_extension_sycl.cc:328-358; wrappers python/sgl_kernel/flash_attn.py:103-372).
+ *   q [total_q, Hq, D] ragged by cu_seqlens_q [b+1]; out same shape; lse fp32 [Hq, total_q].
+ *   paged  (page_table != NULL): k/v [pages, page, Hk, D] with strides (page, token, head),
+ *          seqlens_k = per-sequence lengths [b], page_table int32 [b, table_stride];
+ *   ragged (page_table == NULL): k/v [total_k, Hk, D] with strides (token, head, unused),
+ *          seqlens_k = cumulative [b+1].
+ *   is_causal / window (left,right; < 0 = unlimited), bottom-right aligned; softcap 0 = off;
+ *   sinks fp32 [Hq] or NULL; num_splits >= 1 (> 1 needs part_o fp32 [splits,total_q,Hq,D] and
+ *   part_lse fp32 [splits,Hq,total_q]); sglk_attn_auto_splits gives the "0 = auto" choice. */
+SGLK_API int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
+                                       int64_t max_seqlen_k);
+SGLK_API int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const void* q, const void* k,
+                           const void* v, const int32_t* cu_seqlens_q, const int32_t* seqlens_k,
+                           const int32_t* page_table, const float* sinks, float* part_o, float* part_lse,
+                           int64_t batch, int64_t total_q, int64_t max_seqlen_q, int64_t num_heads,
+                           int64_t num_heads_k, int64_t head_dim, int64_t page_size, int64_t q_stride0,
+                           int64_t q_stride1, int64_t o_stride0, int64_t o_stride1, int64_t k_stride0,
+                           int64_t k_stride1, int64_t k_stride2, int64_t v_stride0, int64_t v_stride1,
+                           int64_t v_stride2, int64_t table_stride, float softmax_scale, int is_causal,
+                           int64_t window_left, int64_t window_right, float softcap, int64_t num_splits,
+                           int dtype);
+
+/* sgl_per_token_group_quant_8bit_v2: reference src/sycl/per_token_group_quant_8bit_v2.cpp:714-842
+ * (schema src/torch_extension_sycl.cc:399-402). As v1 plus: fuse_silu_and_mul (x is [.., 2*hidden], the value
+ * quantised is T(T(silu(x1)) * x2)), and the expert-masked layout (x [experts, rows_per_expert, *], only rows
+ * < masked_m[e] are processed; masked_m NULL = all rows, experts = 1). scale_kind as v1; float scales go to
+ * e*s_stride_expert + row*s_stride_row + g*s_stride_col; packed ue8m0 to byte
+ * (e*s_stride_expert + (g/4)*s_stride_col + row)*4 + g%4. hidden = OUTPUT hidden size. 16-bit inputs only. */
+SGLK_API int sglk_per_token_group_quant_8bit_v2(sglk_stream_t stream, const void* x, void* q, void* scales,
+                                                const int32_t* masked_m, int64_t num_experts,
+                                                int64_t rows_per_expert, int64_t hidden, int group_size,
+                                                float eps, float qmin, float qmax, int in_dtype,
+                                                int out_dtype, int scale_kind, int64_t s_stride_expert,
+                                                int64_t s_stride_row, int64_t s_stride_col,
+                                                int fuse_silu_and_mul);
+
+/* rotary_embedding: reference src/sycl/Rope.cpp:453-471 (schema torch_extension_sycl.cc:117-120).
+ * In place when q_out == q (2-D form); out of place otherwise (3-D form). Strides in elements:
+ * (token, head) for inputs and outputs. cos_sin_cache [max_pos, rot_dim] in the dtype of q. */
+SGLK_API int sglk_rotary_embedding(sglk_stream_t stream, void* q_out, void* k_out, const void* q,
+                                   const void* k, const int64_t* positions, const void* cos_sin_cache,
+                                   int64_t tokens, int64_t num_heads, int64_t num_kv_heads,
+                                   int64_t head_size, int64_t rot_dim, int64_t q_tok_stride,
+                                   int64_t q_head_stride, int64_t k_tok_stride, int64_t k_head_stride,
+                                   int64_t qo_tok_stride, int64_t qo_head_stride, int64_t ko_tok_stride,
+                                   int64_t ko_head_stride, int is_neox, int dtype);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,3 +48,30 @@ def per_token_group_quant_8bit(x: torch.Tensor, group_size: int, dst_dtype: torc
     else:
         q = qv.to(torch.float8_e4m3fn)
     return q.view(rows, k), y_s, ue
+
+
+def per_token_group_quant_8bit_v2(x: torch.Tensor, group_size: int, dst_dtype: torch.dtype, scale_ue8m0: bool = False,
+                                  fuse_silu_and_mul: bool = False, masked_m: torch.Tensor = None):
+    """v2 = v1 arithmetic on T(T(silu(x1)) * x2) when fused, silu(v) = h (1 + tanh h), h = v / 2 (reference
+    src/sycl/per_token_group_quant_8bit_v2.cpp:113-117, :257-259); masked layout [E, T, *] processes rows
+    < masked_m[e] only (the rest of q / scales is left untouched -> returned as zeros here).
+    Returns (q [.., H], scales [.., H/group] fp32, ue8m0 bytes or None, row_valid mask [.., T])."""
+    T = x.dtype
+    lead = x.shape[:-1]
+    if fuse_silu_and_mul:
+        h2 = x.shape[-1] // 2
+        a, b = x[..., :h2].float(), x[..., h2:].float()
+        half = 0.5 * a
+        sv = (half * (1.0 + torch.tanh(half))).to(T)
+        v = (sv.float() * b).to(T)
+    else:
+        v = x
+    hidden = v.shape[-1]
+    q, s, ue = per_token_group_quant_8bit(v.reshape(-1, hidden), group_size, dst_dtype, scale_ue8m0=scale_ue8m0)
+    q = q.view(*lead, hidden)
+    s = s.view(*lead, hidden // group_size)
+    ue = ue.view(*lead, hidden // group_size) if ue is not None else None
+    valid = torch.ones(lead, dtype=torch.bool)
+    if masked_m is not None:
+        valid = torch.arange(lead[1]).view(1, -1) < masked_m.view(-1, 1)
+    return q, s, ue, valid

@@ -1,0 +1,526 @@
+// Flash-attention forward (`fwd` / mha_fwd) for gfx950: varlen Q, KV either ragged-contiguous or
+// paged, GQA, causal (bottom-right aligned) / sliding window, softcap, sinks, split-KV decode, LSE.
+//
+// Replaces reference src/sycl/flash_attention.cpp:1332-1435 (router), :273-676 (paged decode),
+// :83-270 / :686-876 (non-paged), :879-1214 (prefill), :1229-1328 (chunk-prefill) and the CuTe kernels in
+// src/sycl/kernels/flash_attention_v2/. One kernel covers all of those routes: the reference needs separate
+// decode / prefill / two-launch chunk-prefill kernels because its tiles are specialised per route; here the
+// query rows of a (batch, kv-head) pair are "packed GQA" rows r = (q_pos, g) so decode (seqlen_q = 1) is just
+// a short row list, and mixed batches run in a single launch without any host-side classification (the
+// reference's reason for the two-launch scheme, flash_attention.cpp:1426-1429).
+// Semantics (pinned by tests/test_flash_attention.py:349-476 attention_ref):
+//   s = q.k * scale; softcap: s = cap * tanh(s / cap); masked if k >= seqlen_k, k > q_abs + right,
+//   or (left >= 0 and k < q_abs - left) with q_abs = q_pos + seqlen_k - seqlen_q; optional per-head sink logit
+//   joins the softmax denominator; rows with no visible key give 0.
+//
+// Design: workgroup = 4 waves, wave w owns 16 packed rows; 32-token K and V tiles are staged
+// global -> registers -> LDS (issue early / write late, 3-slot LDS ring, one barrier per tile) so that
+// any head dim (multiple of 8), page size, stride and mask shape goes through one path; S^T = K.Q^T with
+// 16x16x32 MFMA keeps the softmax lane-local and P directly usable as the A operand of O += P.V; V is read
+// with the hardware transpose read. LDS images are [256-byte column block][32 rows][256 B] with the chunk
+// swizzle / k-permutation / token-permutation of mla_decode.hip (conflict-free row and transposed reads).
+#include <math.h>
+
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+constexpr int kTile = 32;       // kv tokens per tile
+constexpr int kRowsPerWave = 16;
+constexpr int kWaves = 4;
+constexpr int kBlockM = kRowsPerWave * kWaves;
+
+#define SGLK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<bf16> {
+  static __device__ __forceinline__ v4f run(const v8s& a, const v8s& b, const v4f& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ short cvt(float x) { return __builtin_bit_cast(short, (bf16)x); }
+};
+template <>
+struct Mfma<f16> {
+  static __device__ __forceinline__ v4f run(const v8s& a, const v8s& b, const v4f& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ short cvt(float x) { return __builtin_bit_cast(short, (f16)x); }
+};
+
+__device__ __forceinline__ int sw_main(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+struct AttnParams {
+  void* out;            // [total_q, Hq, D]
+  float* lse;           // [Hq, total_q]
+  float* part_o;        // [splits, total_q, Hq, D] fp32 (splits > 1)
+  float* part_lse;      // [splits, Hq, total_q]
+  const float* sinks;   // [Hq] or null
+  int64_t q_s0, q_s1;   // q strides (token, head) in elements
+  int64_t o_s0, o_s1;
+  int64_t k_s0, k_s1, k_s2;  // paged: (page, token-in-page, head); ragged: (token, head, -)
+  int64_t v_s0, v_s1, v_s2;
+  int64_t table_stride;
+  int Hq, Hk, G, D, total_q;
+  int page_shift;       // log2(page size), paged only
+  int paged;            // 1: k/v are [pages, page, Hk, D] + page_table + seqused_k; 0: ragged + cu_seqlens_k
+  int causal_right;     // window right (>= 0 active, < 0 unlimited)
+  int window_left;      // >= 0 active, < 0 unlimited
+  int splits;
+  float scale;          // softmax scale
+  float softcap;        // 0 = off
+};
+
+// DKP: head dim rounded up to 32 (k-steps of the QK product); the V/O side uses ceil(D/16) 16-wide tiles.
+template <typename T, int DKP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __restrict__ q,
+                                                       const T* __restrict__ kcache, const T* __restrict__ vcache,
+                                                       const int32_t* __restrict__ cu_q,
+                                                       const int32_t* __restrict__ seq_k,  // paged: lengths [b]; ragged: cu [b+1]
+                                                       const int32_t* __restrict__ page_table) {
+  using M = Mfma<T>;
+  constexpr int KS = DKP / 32;                 // k-steps
+  constexpr int NT = DKP / 16;                 // upper bound of 16-wide output tiles
+  constexpr int NB = (DKP * 2 + 255) / 256;    // 256-byte column blocks per row
+  constexpr int TILE_BYTES = NB * kTile * 256; // one operand, one slot
+  constexpr int SLOT = 2 * TILE_BYTES;         // K then V
+  constexpr int kSlots = DKP > 256 ? 2 : 3;    // LDS ring depth (d = 512 tiles are 64 KiB: two slots, two barriers)
+  constexpr int CPR_MAX = DKP / 8;             // 16-byte chunks per row (upper bound)
+  constexpr int LD = (kTile * CPR_MAX + 255) / 256;  // chunk loads per thread per operand per tile
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int b = blockIdx.z;
+  const int hk = blockIdx.y % p.Hk;
+  const int split = blockIdx.y / p.Hk;
+  const int D = p.D, G = p.G;
+  const int cpr = D >> 3;                      // valid 16-byte chunks per row
+  const int nt_valid = (D + 15) >> 4;
+
+  const int q_begin = cu_q[b];
+  const int seqlen_q = cu_q[b + 1] - q_begin;
+  int seqlen_k, k_begin = 0;
+  if (p.paged) {
+    seqlen_k = seq_k[b];
+  } else {
+    k_begin = seq_k[b];
+    seqlen_k = seq_k[b + 1] - k_begin;
+  }
+  const int rows_total = seqlen_q * G;
+  const int row0 = blockIdx.x * kBlockM;
+  if (row0 >= rows_total) return;
+  const int shift = seqlen_k - seqlen_q;       // bottom-right alignment
+
+  // ---- this wave's 16 packed rows; lane l15 <-> row
+  const int my_row = row0 + wave * kRowsPerWave + l15;
+  const bool row_ok = my_row < rows_total;
+  const int my_qpos = row_ok ? my_row / G : 0;
+  const int my_head = hk * G + (row_ok ? my_row % G : 0);
+  const int q_abs = my_qpos + shift;
+
+  // ---- kv range visible to this workgroup (union over its rows), then this split's share of it
+  const int last_row = (row0 + kBlockM < rows_total ? row0 + kBlockM : rows_total) - 1;
+  const int qpos_lo = row0 / G, qpos_hi = last_row / G;
+  int kv_hi = seqlen_k;
+  if (p.causal_right >= 0) {
+    const int lim = qpos_hi + shift + p.causal_right + 1;
+    kv_hi = lim < kv_hi ? lim : kv_hi;
+  }
+  int kv_lo = 0;
+  if (p.window_left >= 0) {
+    const int lim = qpos_lo + shift - p.window_left;
+    kv_lo = lim > 0 ? lim : 0;
+  }
+  if (kv_hi < 0) kv_hi = 0;
+  int t_lo = kv_lo / kTile, t_hi = (kv_hi + kTile - 1) / kTile;  // tile range [t_lo, t_hi)
+  if (t_hi < t_lo) t_hi = t_lo;
+  if (p.splits > 1) {
+    const int per = (t_hi - t_lo + p.splits - 1) / p.splits;
+    const int a = t_lo + split * per;
+    const int e = a + per;
+    t_lo = a < t_hi ? a : t_hi;
+    t_hi = e < t_hi ? e : t_hi;
+  }
+  const int n_tiles = t_hi - t_lo;
+
+  // k permutation inside a 32-deep MFMA step and token permutation inside a 16-token tile (see mla_decode.hip)
+  const int pig = (0x2130 >> (4 * g4)) & 3;
+  const int tau = (l15 & 3) | (((l15 >> 2) & 1) << 3) | (((l15 >> 3) & 1) << 2);
+
+  // ---- Q^T fragments
+  v8s qf[KS];
+  {
+    const T* qrow = q + (int64_t)(q_begin + my_qpos) * p.q_s0 + (int64_t)my_head * p.q_s1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = 32 * ks + 8 * pig;
+      v8s v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (row_ok && d0 < D) v = *reinterpret_cast<const v8s*>(qrow + d0);
+      qf[ks] = v;
+    }
+  }
+
+  // ---- staging: chunk id c = tid + 256 i  ->  (token row = c / cpr, chunk = c % cpr)
+  v4i kreg[LD], vreg[LD];
+  auto issue_loads = [&](int t) {
+    const int tok0 = t * kTile;
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / cpr, ch = c - row * cpr;
+      v4i kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+      int pos = tok0 + row;
+      if (row < kTile && pos < seqlen_k) {
+        int64_t koff, voff;
+        if (p.paged) {
+          const int page = page_table[(int64_t)b * p.table_stride + (pos >> p.page_shift)];
+          const int inp = pos & ((1 << p.page_shift) - 1);
+          koff = (int64_t)page * p.k_s0 + (int64_t)inp * p.k_s1 + (int64_t)hk * p.k_s2;
+          voff = (int64_t)page * p.v_s0 + (int64_t)inp * p.v_s1 + (int64_t)hk * p.v_s2;
+        } else {
+          koff = (int64_t)(k_begin + pos) * p.k_s0 + (int64_t)hk * p.k_s1;
+          voff = (int64_t)(k_begin + pos) * p.v_s0 + (int64_t)hk * p.v_s1;
+        }
+        kv = *reinterpret_cast<const v4i*>(kcache + koff + ch * 8);
+        vv = *reinterpret_cast<const v4i*>(vcache + voff + ch * 8);
+      }
+      kreg[i] = kv;
+      vreg[i] = vv;
+    }
+  };
+  auto write_lds = [&](int slot) {
+    char* base = smem + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / cpr, ch = c - row * cpr;
+      if (row < kTile) {
+        const int off = (ch >> 4) * (kTile * 256) + row * 256 + (((ch & 15) ^ sw_main(row)) << 4);
+        *reinterpret_cast<v4i*>(base + off) = kreg[i];
+        *reinterpret_cast<v4i*>(base + TILE_BYTES + off) = vreg[i];
+      }
+    }
+  };
+  // zero the padded head-dim chunks of every K slot once (they meet zero Q fragments, but must not be NaN)
+  if (cpr < CPR_MAX) {
+    for (int c = tid; c < kSlots * kTile * (CPR_MAX - cpr); c += 256) {
+      const int slot = c / (kTile * (CPR_MAX - cpr));
+      const int r = c - slot * (kTile * (CPR_MAX - cpr));
+      const int row = r / (CPR_MAX - cpr), ch = cpr + r % (CPR_MAX - cpr);
+      const int off = (ch >> 4) * (kTile * 256) + row * 256 + (((ch & 15) ^ sw_main(row)) << 4);
+      *reinterpret_cast<v4i*>(smem + slot * SLOT + off) = (v4i){0, 0, 0, 0};
+      *reinterpret_cast<v4i*>(smem + slot * SLOT + TILE_BYTES + off) = (v4i){0, 0, 0, 0};
+    }
+  }
+
+  // ---- per-lane LDS read bases (the second 16-token tile is +4096 bytes)
+  const int kbase = 256 * tau + 16 * (pig ^ sw_main(tau));
+  int vbase0;
+  {
+    const int qq = l15 >> 2, pp = l15 & 3;
+    const int r = 8 * (g4 & 1) + 4 * (g4 >> 1) + qq;
+    vbase0 = 256 * r + 16 * ((pp >> 1) ^ sw_main(r)) + 8 * (pp & 1);
+  }
+
+  v4f o[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float log2e = 1.4426950408889634f;
+  const float sc2 = p.scale * log2e;
+  __shared__ float xch_all[kWaves * 16];
+  float* xch = xch_all + wave * 16;
+
+  if (n_tiles > 0) {
+    issue_loads(t_lo);
+    write_lds(0);
+  }
+  __syncthreads();
+
+  for (int i = 0; i < n_tiles; ++i) {
+    const int t = t_lo + i;
+    const int slot = i % kSlots;
+    if (i + 1 < n_tiles) issue_loads(t + 1);
+
+    {
+      const char* kb = smem + slot * SLOT;
+      const char* vb = kb + TILE_BYTES;
+      v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = (ks >> 2) * (kTile * 256) + (kbase ^ ((ks & 3) << 6));
+        const v8s a0 = *reinterpret_cast<const v8s*>(kb + off);
+        const v8s a1 = *reinterpret_cast<const v8s*>(kb + off + 4096);
+        s0 = M::run(a0, qf[ks], s0);
+        s1 = M::run(a1, qf[ks], s1);
+      }
+      // logits in natural units, then masks
+      const int tb = t * kTile + 8 * (g4 & 1) + 4 * (g4 >> 1);
+      float z0[4], z1[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s0[r] * p.scale, c = s1[r] * p.scale;
+        if (p.softcap > 0.f) {
+          a = p.softcap * tanhf(a / p.softcap);
+          c = p.softcap * tanhf(c / p.softcap);
+        }
+        const int k0 = tb + r, k1 = tb + 16 + r;
+        bool m0 = !row_ok || k0 >= seqlen_k, m1 = !row_ok || k1 >= seqlen_k;
+        if (p.causal_right >= 0) { m0 |= k0 > q_abs + p.causal_right; m1 |= k1 > q_abs + p.causal_right; }
+        if (p.window_left >= 0) { m0 |= k0 < q_abs - p.window_left; m1 |= k1 < q_abs - p.window_left; }
+        z0[r] = m0 ? -INFINITY : a;
+        z1[r] = m1 ? -INFINITY : c;
+      }
+      float mt = fmaxf(fmaxf(fmaxf(z0[0], z0[1]), fmaxf(z0[2], z0[3])), fmaxf(fmaxf(z1[0], z1[1]), fmaxf(z1[2], z1[3])));
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run, mt);
+      // rows that have seen no visible key yet keep m = -inf; use 0 as the reference point to avoid inf - inf
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);  // m_run = -inf -> 0
+      float psum = 0.f;
+      v8s pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p0 = __builtin_amdgcn_exp2f((z0[r] - m_use) * log2e);
+        const float p1 = __builtin_amdgcn_exp2f((z1[r] - m_use) * log2e);
+        psum += p0 + p1;
+        pf[r] = M::cvt(p0);
+        pf[4 + r] = M::cvt(p1);
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      if (__any(alpha != 1.0f)) {
+        if (lane < 16) xch[lane] = alpha;
+        const v4f a4 = *reinterpret_cast<const v4f*>(xch + 4 * g4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          o[nt][0] *= a4[0]; o[nt][1] *= a4[1]; o[nt][2] *= a4[2]; o[nt][3] *= a4[3];
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt < nt_valid) {
+          const char* a = vb + (nt >> 3) * (kTile * 256) + (vbase0 ^ ((nt & 7) << 5));
+          const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a));
+          const v4s v1 =
+              __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a + 4096));
+          v8s vf;
+          vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+          vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+          o[nt] = M::run(pf, vf, o[nt]);
+        }
+      }
+    }
+
+    if (kSlots == 2) __syncthreads();                   // two slots: everyone must be done with the slot being refilled
+    if (i + 1 < n_tiles) write_lds((i + 1) % kSlots);  // three slots: that slot was last read two iterations ago
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const bool final_pass = p.splits == 1;
+  const float m_fin = m_run;
+  // natural-log LSE of this pass; -inf when nothing was visible
+  float lse_val = (l_tot > 0.f && m_fin != -INFINITY) ? m_fin + logf(l_tot) : -INFINITY;
+  if (final_pass && p.sinks != nullptr && row_ok) {
+    // the sink logit joins the softmax denominator (reference attention_ref: an extra score column with no value)
+    const float sk = p.sinks[my_head];
+    const float m2 = fmaxf(m_fin, sk);
+    const float l2 = l_tot * __builtin_amdgcn_exp2f((m_fin - m2) * log2e) + __builtin_amdgcn_exp2f((sk - m2) * log2e);
+    lse_val = m2 + logf(l2);
+    // O is relative to m_fin: its normaliser is l + exp(sink - m_fin) (inf -> output 0)
+    l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
+  }
+  const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
+  if (lane < 16) xch[lane] = inv_l;
+  const v4f i4 = *reinterpret_cast<const v4f*>(xch + 4 * g4);
+
+  // O tile nt: lane holds dim 16 nt + l15 of rows 4 g4 + r of this wave
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + wave * kRowsPerWave + 4 * g4 + r;
+    if (row >= rows_total) continue;
+    const int qpos = row / G, head = hk * G + row % G;
+    const int64_t tok = q_begin + qpos;
+    if (final_pass) {
+      T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)head * p.o_s1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int d = nt * 16 + l15;
+        if (d < D) orow[d] = (T)(o[nt][r] * i4[r]);
+      }
+    } else {
+      float* orow = p.part_o + (((int64_t)split * p.total_q + tok) * p.Hq + head) * D;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int d = nt * 16 + l15;
+        if (d < D) orow[d] = o[nt][r] * i4[r];
+      }
+    }
+  }
+  if (row_ok && g4 == 0) {
+    const float lse = lse_val;
+    const int64_t tok = q_begin + my_qpos;
+    if (final_pass) p.lse[(int64_t)my_head * p.total_q + tok] = lse;
+    else p.part_lse[((int64_t)split * p.Hq + my_head) * p.total_q + tok] = lse;
+  }
+}
+
+// merge split-KV partials: out = sum_s exp(lse_s - L) O_s, L = log(sum_s exp(lse_s) [+ exp(sink)])
+template <typename T>
+__global__ __launch_bounds__(128) void attn_reduce_kernel(T* __restrict__ out, float* __restrict__ lse_out,
+                                                          const float* __restrict__ part_o,
+                                                          const float* __restrict__ part_lse,
+                                                          const float* __restrict__ sinks, int splits, int total_q,
+                                                          int Hq, int D, int64_t o_s0, int64_t o_s1) {
+  const int head = blockIdx.x;
+  const int64_t tok = blockIdx.y;
+  float mx = -INFINITY;
+  for (int s = 0; s < splits; ++s) mx = fmaxf(mx, part_lse[((int64_t)s * Hq + head) * total_q + tok]);
+  const float sk = sinks ? sinks[head] : -INFINITY;
+  const float mref = fmaxf(mx, sk);
+  float denom = 0.f;
+  if (mref != -INFINITY) {
+    for (int s = 0; s < splits; ++s) denom += expf(part_lse[((int64_t)s * Hq + head) * total_q + tok] - mref);
+    if (sinks) denom += expf(sk - mref);
+  }
+  const float inv = denom > 0.f ? 1.0f / denom : 0.f;
+  for (int d = threadIdx.x; d < D; d += 128) {
+    float acc = 0.f;
+    if (mx != -INFINITY) {
+      for (int s = 0; s < splits; ++s) {
+        const float l = part_lse[((int64_t)s * Hq + head) * total_q + tok];
+        if (l != -INFINITY) acc += expf(l - mref) * part_o[(((int64_t)s * total_q + tok) * Hq + head) * D + d];
+      }
+    }
+    out[tok * o_s0 + (int64_t)head * o_s1 + d] = (T)(acc * inv);
+  }
+  if (threadIdx.x == 0) lse_out[(int64_t)head * total_q + tok] = denom > 0.f ? mref + logf(denom) : -INFINITY;
+}
+
+template <typename T, int DKP>
+static int launch(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
+                  const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
+  constexpr int NB = (DKP * 2 + 255) / 256;
+  constexpr int lds = (DKP > 256 ? 2 : 3) * 2 * NB * kTile * 256;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DKP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(SGLK_ELAUNCH, "fwd: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)cdiv(max_rows, kBlockM), (unsigned)(p.Hk * p.splits), (unsigned)batch);
+  attn_fwd_kernel<T, DKP><<<grid, 256, lds, st>>>(p, (const T*)q, (const T*)k, (const T*)v, cu_q, seq_k, table);
+  if (int rc = check_launch("fwd")) return rc;
+  if (p.splits > 1) {
+    attn_reduce_kernel<T><<<dim3(p.Hq, p.total_q), 128, 0, st>>>((T*)p.out, p.lse, p.part_o, p.part_lse, p.sinks,
+                                                                  p.splits, p.total_q, p.Hq, p.D, p.o_s0, p.o_s1);
+    return check_launch("fwd(reduce)");
+  }
+  return SGLK_OK;
+}
+
+template <typename T>
+static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
+                        const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
+  const int d = p.D;
+  if (d <= 64) return launch<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (d <= 96) return launch<T, 96>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (d <= 128) return launch<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (d <= 192) return launch<T, 192>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (d <= 256) return launch<T, 256>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  return launch<T, 512>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+}
+
+}  // namespace
+}  // namespace sglk
+
+// Split count used when the caller passes num_kv_splits == 0 ("auto"): fill the chip (~2 workgroups per CU)
+// but keep at least 8 tiles (256 tokens) per split. Prefill-sized problems never split.
+extern "C" int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
+                                         int64_t max_seqlen_k) {
+  const int64_t wgs = batch * num_heads_k * ((max_rows_per_kv_head + 63) / 64);
+  if (wgs >= 384) return 1;
+  const int64_t tiles = (max_seqlen_k + 31) / 32;
+  int64_t s = 512 / (wgs > 0 ? wgs : 1);
+  const int64_t cap = tiles / 8;
+  if (s > cap) s = cap;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const void* q, const void* k,
+                             const void* v, const int32_t* cu_seqlens_q, const int32_t* seqlens_k,
+                             const int32_t* page_table, const float* sinks, float* part_o, float* part_lse,
+                             int64_t batch, int64_t total_q, int64_t max_seqlen_q, int64_t num_heads,
+                             int64_t num_heads_k, int64_t head_dim, int64_t page_size, int64_t q_stride0,
+                             int64_t q_stride1, int64_t o_stride0, int64_t o_stride1, int64_t k_stride0,
+                             int64_t k_stride1, int64_t k_stride2, int64_t v_stride0, int64_t v_stride1,
+                             int64_t v_stride2, int64_t table_stride, float softmax_scale, int is_causal,
+                             int64_t window_left, int64_t window_right, float softcap, int64_t num_splits,
+                             int dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "mha_fwd only supports Half and BFloat16");
+  SGLK_REQUIRE(num_heads > 0 && num_heads_k > 0 && num_heads % num_heads_k == 0,
+               "Number of heads in key/value must divide number of heads in query");
+  SGLK_REQUIRE(head_dim > 0 && head_dim <= 512, "FlashAttention forward only supports head dimension at most 512");
+  SGLK_REQUIRE(head_dim % 8 == 0, "head_size should be a multiple of 8");
+  SGLK_REQUIRE(q_stride0 % 8 == 0 && q_stride1 % 8 == 0 && k_stride0 % 8 == 0 && k_stride1 % 8 == 0 &&
+                   k_stride2 % 8 == 0 && v_stride0 % 8 == 0 && v_stride1 % 8 == 0 && v_stride2 % 8 == 0 &&
+                   (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0,
+               "fwd: q, k and v rows must be 16-byte aligned");
+  const bool paged = page_table != nullptr;
+  int page_shift = 0;
+  if (paged) {
+    SGLK_REQUIRE(page_size > 0 && (page_size & (page_size - 1)) == 0, "fwd: page size must be a power of two, got %lld",
+                 (long long)page_size);
+    while ((1ll << page_shift) < page_size) ++page_shift;
+  }
+  if (batch == 0 || total_q == 0) return SGLK_OK;
+  SGLK_REQUIRE(num_splits >= 1, "fwd: num_splits must be resolved (>= 1) before the C-ABI call");
+  SGLK_REQUIRE(num_splits == 1 || (part_o != nullptr && part_lse != nullptr), "fwd: split-KV needs partial buffers");
+  AttnParams p;
+  p.out = out;
+  p.lse = lse;
+  p.part_o = part_o;
+  p.part_lse = part_lse;
+  p.sinks = sinks;
+  p.q_s0 = q_stride0; p.q_s1 = q_stride1;
+  p.o_s0 = o_stride0; p.o_s1 = o_stride1;
+  p.k_s0 = k_stride0; p.k_s1 = k_stride1; p.k_s2 = k_stride2;
+  p.v_s0 = v_stride0; p.v_s1 = v_stride1; p.v_s2 = v_stride2;
+  p.table_stride = table_stride;
+  p.Hq = (int)num_heads;
+  p.Hk = (int)num_heads_k;
+  p.G = (int)(num_heads / num_heads_k);
+  p.D = (int)head_dim;
+  p.total_q = (int)total_q;
+  p.page_shift = page_shift;
+  p.paged = paged ? 1 : 0;
+  // causal == window_right 0 (reference flash_attention.cpp:401-404); negative = unlimited
+  p.causal_right = is_causal ? 0 : (window_right >= 0 ? (int)window_right : -1);
+  p.window_left = window_left >= 0 ? (int)window_left : -1;
+  p.splits = (int)num_splits;
+  p.scale = softmax_scale;
+  p.softcap = softcap;
+  const int max_rows = (int)(max_seqlen_q * p.G);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGLK_BF16)
+    return dispatch_dim<bf16>(st, p, q, k, v, cu_seqlens_q, seqlens_k, page_table, (int)batch, max_rows);
+  return dispatch_dim<f16>(st, p, q, k, v, cu_seqlens_q, seqlens_k, page_table, (int)batch, max_rows);
+}

@@ -18,6 +18,7 @@
 #include <torch/library.h>
 
 #include <algorithm>
+#include <cmath>
 #include <optional>
 #include <tuple>
 
@@ -538,6 +539,234 @@ void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, con
                                       group_size, is_int4 ? 1 : 0, dtype_code(activations.scalar_type(), "activations")));
 }
 
+// ---- fwd / mha_fwd (reference src/sycl/flash_attention.cpp:1332-1435; the int/float narrowing the reference
+//      does with make_pytorch_shim, include/sgl_kernel_torch_shim.h:94-122, is done inline here) --------------
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
+    const Tensor& q, const Tensor& k, const Tensor& v, const std::optional<Tensor>& q_v, const Tensor& cu_seqlens_q,
+    const Tensor& cu_seqlens_k, int64_t max_seqlen_q, int64_t max_seqlen_k, const std::optional<Tensor>& page_table,
+    const std::optional<Tensor>& kv_batch_idx, const std::optional<Tensor>& leftpad_k,
+    const std::optional<Tensor>& rotary_cos, const std::optional<Tensor>& rotary_sin,
+    const std::optional<Tensor>& seqlens_rotary, const std::optional<Tensor>& q_descale,
+    const std::optional<Tensor>& k_descale, const std::optional<Tensor>& v_descale, double softmax_scale,
+    const std::optional<Tensor>& sinks, bool is_causal, int64_t window_size_left, int64_t window_size_right,
+    double softcap, bool is_rotary_interleaved, const std::optional<Tensor>& scheduler_metadata,
+    int64_t num_kv_splits, std::optional<bool> pack_gqa, int64_t sm_margin, const std::optional<Tensor>& out_) {
+  CHECK_GPU(q);
+  CHECK_GPU(k);
+  CHECK_GPU(v);
+  TORCH_CHECK(q.dim() == 3, "query must be in ragged format (total_q, h, d)");
+  const auto q_type = q.scalar_type();
+  TORCH_CHECK(q_type == at::kHalf || q_type == at::kBFloat16, "mha_fwd only supports Half and BFloat16, got", q_type);
+  TORCH_CHECK(k.scalar_type() != at::kFloat8_e4m3fn && k.scalar_type() != at::kFloat8_e5m2,
+              "fwd: the fp8 KV cache path is not built for gfx950 yet");
+  TORCH_CHECK(k.scalar_type() == q_type, "query and key must have the same dtype");
+  TORCH_CHECK(v.scalar_type() == q_type, "query and value must have the same dtype");
+  CHECK_LAST_DIM_CONTIGUOUS(q);
+  CHECK_LAST_DIM_CONTIGUOUS(k);
+  CHECK_LAST_DIM_CONTIGUOUS(v);
+  TORCH_CHECK(!q_v.has_value(), "q_v is not supported yet");  // as the reference: flash_attention.cpp:603-609
+  TORCH_CHECK(!rotary_cos.has_value() && !rotary_sin.has_value() && !seqlens_rotary.has_value(),
+              "fwd: in-kernel rotary embedding is not supported");
+  TORCH_CHECK(!kv_batch_idx.has_value(), "fwd: kv_batch_idx is not supported");
+  TORCH_CHECK(!leftpad_k.has_value(), "fwd: leftpad_k is not supported");
+  TORCH_CHECK(!q_descale.has_value() && !k_descale.has_value() && !v_descale.has_value(),
+              "fwd: descale factors only apply to the fp8 KV cache path, which is not built for gfx950 yet");
+  TORCH_CHECK(cu_seqlens_q.scalar_type() == at::kInt && cu_seqlens_q.is_contiguous() && cu_seqlens_q.is_cuda(),
+              "cu_seqlens_q must have dtype torch.int32");
+  TORCH_CHECK(cu_seqlens_k.scalar_type() == at::kInt && cu_seqlens_k.is_contiguous() && cu_seqlens_k.is_cuda(),
+              "cu_seqlens_k must have dtype torch.int32");
+  const int64_t batch = cu_seqlens_q.size(0) - 1;
+  const int64_t total_q = q.size(0), num_heads = q.size(1), head_size = q.size(2);
+  const int64_t num_heads_k = k.size(-2), head_size_v = v.size(-1);
+  TORCH_CHECK(head_size <= 512, "FlashAttention forward only supports head dimension at most ", 512);
+  TORCH_CHECK(num_heads % num_heads_k == 0, "Number of heads in key/value must divide number of heads in query");
+  TORCH_CHECK(head_size % 8 == 0, "head_size should be a multiple of 8");
+  TORCH_CHECK(head_size_v == head_size, "fwd: head_size_v must equal head_size on this build");
+  TORCH_CHECK(k.size(-1) == head_size, "key must have the head size of query");
+
+  const bool paged = page_table.has_value();
+  const int32_t* table_ptr = nullptr;
+  int64_t page_size = 0, table_stride = 0, seqlen_k_max = max_seqlen_k;
+  int64_t ks0, ks1, ks2 = 0, vs0, vs1, vs2 = 0;
+  if (paged) {
+    const Tensor& pt = *page_table;
+    CHECK_GPU(pt);
+    TORCH_CHECK(pt.scalar_type() == at::kInt, "page_table must have dtype torch.int32");
+    TORCH_CHECK(pt.dim() == 2 && pt.stride(-1) == 1, "page_table must have contiguous last dimension");
+    TORCH_CHECK(pt.size(0) == batch, "batch_size must be equal to batch_size_k");
+    TORCH_CHECK(k.dim() == 4 && v.dim() == 4, "paged key/value must be (num_pages, page_size, h_k, d)");
+    TORCH_CHECK(v.size(0) == k.size(0) && v.size(1) == k.size(1) && v.size(2) == num_heads_k,
+                "key and value cache shapes differ");
+    TORCH_CHECK(cu_seqlens_k.size(0) == batch, "with a page table cu_seqlens_k holds the per-sequence lengths [b]");
+    page_size = k.size(1);
+    TORCH_CHECK((page_size & (page_size - 1)) == 0, "Unsupported page size for attention: ", page_size);
+    table_ptr = pt.data_ptr<int32_t>();
+    table_stride = pt.stride(0);
+    ks0 = k.stride(0); ks1 = k.stride(1); ks2 = k.stride(2);
+    vs0 = v.stride(0); vs1 = v.stride(1); vs2 = v.stride(2);
+    if (seqlen_k_max <= 0) seqlen_k_max = pt.size(1) * page_size;
+  } else {
+    TORCH_CHECK(k.dim() == 3 && v.dim() == 3, "non-paged key/value must be ragged (total_k, h_k, d)");
+    TORCH_CHECK(cu_seqlens_k.size(0) == batch + 1, "cu_seqlens_k must have b + 1 entries");
+    TORCH_CHECK(v.size(0) == k.size(0) && v.size(1) == num_heads_k, "key and value shapes differ");
+    ks0 = k.stride(0); ks1 = k.stride(1);
+    vs0 = v.stride(0); vs1 = v.stride(1);
+    if (seqlen_k_max <= 0) seqlen_k_max = k.size(0);
+  }
+
+  Tensor out;
+  if (out_.has_value()) {
+    out = *out_;
+    TORCH_CHECK(out.scalar_type() == q_type, "out dtype must match q dtype");
+    TORCH_CHECK(out.dim() == 3 && out.size(0) == total_q && out.size(1) == num_heads && out.size(2) == head_size_v,
+                "out shape must be [total_q, num_heads, head_size_v]");
+    TORCH_CHECK(out.device() == q.device(), "out must be on the same device as q");
+    TORCH_CHECK(out.stride(-1) == 1, "out must have a contiguous last dimension");
+  } else {
+    out = at::empty({total_q, num_heads, head_size_v}, q.options());
+  }
+  Tensor lse = at::empty({num_heads, total_q}, q.options().dtype(at::kFloat));
+  Tensor out_accum, lse_accum;
+  const float* sinks_ptr = nullptr;
+  Tensor sinks_f;
+  if (sinks.has_value()) {
+    CHECK_GPU(*sinks);
+    TORCH_CHECK(sinks->numel() == num_heads, "sinks must have one entry per query head");
+    sinks_f = sinks->to(at::kFloat).contiguous();
+    sinks_ptr = sinks_f.data_ptr<float>();
+  }
+  if (batch <= 0 || total_q == 0) return {out, lse, out_accum, lse_accum};
+
+  // num_kv_splits (reference flash_attention.cpp:426-470): -1 or 1 = off, 0 = auto (decode only), > 1 = as given
+  int64_t splits = 1;
+  if (num_kv_splits > 1) splits = num_kv_splits;
+  else if (num_kv_splits == 0 && max_seqlen_q == 1)
+    splits = sglk_attn_auto_splits(batch, num_heads_k, max_seqlen_q * (num_heads / num_heads_k), seqlen_k_max);
+  float* po = nullptr;
+  float* pl = nullptr;
+  if (splits > 1) {
+    out_accum = at::empty({splits, total_q, num_heads, head_size_v}, q.options().dtype(at::kFloat));
+    lse_accum = at::empty({splits, num_heads, total_q}, q.options().dtype(at::kFloat));
+    po = out_accum.data_ptr<float>();
+    pl = lse_accum.data_ptr<float>();
+  }
+  const c10::OptionalDeviceGuard guard(q.device());
+  SGLK_CALL(sglk_attn_fwd(stream_of(q), out.data_ptr(), lse.data_ptr<float>(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                          cu_seqlens_q.data_ptr<int32_t>(), cu_seqlens_k.data_ptr<int32_t>(), table_ptr, sinks_ptr, po, pl,
+                          batch, total_q, max_seqlen_q, num_heads, num_heads_k, head_size, page_size, q.stride(0),
+                          q.stride(1), out.stride(0), out.stride(1), ks0, ks1, ks2, vs0, vs1, vs2, table_stride,
+                          (float)softmax_scale, is_causal ? 1 : 0, window_size_left, window_size_right, (float)softcap,
+                          splits, dtype_code(q_type, "q")));
+  return {out, lse, out_accum, lse_accum};
+}
+
+// ---- sgl_per_token_group_quant_8bit_v2 (reference src/sycl/per_token_group_quant_8bit_v2.cpp:714-842) --------
+
+void sgl_per_token_group_quant_8bit_v2(Tensor input, Tensor output_q, Tensor output_s, int64_t group_size, double eps,
+                                       double min_8bit, double max_8bit, bool scale_ue8m0, bool fuse_silu_and_mul,
+                                       const std::optional<Tensor>& masked_m) {
+  CHECK_GPU(input);
+  CHECK_GPU(output_q);
+  CHECK_GPU(output_s);
+  CHECK_CONTIGUOUS(input);
+  CHECK_CONTIGUOUS(output_q);
+  TORCH_CHECK(input.numel() > 0);
+  TORCH_CHECK(std::abs(1e-10 - eps) < 1e-13, "sgl_per_token_group_quant_8bit_v2: eps must be 1e-10");
+  TORCH_CHECK(group_size > 0 && input.numel() % group_size == 0, "input.numel() must be divisible by group_size");
+  const bool masked_layout = masked_m.has_value();
+  TORCH_CHECK(output_s.dim() == (masked_layout ? 3 : 2), "output_s must be ", masked_layout ? 3 : 2, "-D");
+  TORCH_CHECK(input.dim() == (masked_layout ? 3 : 2), "input must be ", masked_layout ? 3 : 2, "-D");
+  const auto in_t = input.scalar_type();
+  TORCH_CHECK(in_t == at::kHalf || in_t == at::kBFloat16, "sgl_per_token_group_quant_8bit_v2: input must be Half or BFloat16");
+  const auto q_t = output_q.scalar_type();
+  TORCH_CHECK(q_t == at::kChar || q_t == at::kFloat8_e4m3fn, "output_q dtype must be Int8 or Float8_e4m3fn");
+  if (q_t == at::kFloat8_e4m3fn) {
+    TORCH_CHECK(min_8bit == -448.0 && max_8bit == 448.0, "fp8 limits must be +-448");
+  } else {
+    TORCH_CHECK(min_8bit == -128.0 && max_8bit == 127.0, "int8 limits must be -128 / 127");
+  }
+  const int64_t hidden = output_q.size(-1);
+  const int64_t rows = output_q.size(-2);
+  const int64_t experts = masked_layout ? input.size(0) : 1;
+  TORCH_CHECK(hidden % group_size == 0, "the hidden dimension must be divisible by group_size");
+  TORCH_CHECK(input.size(-1) == hidden * (fuse_silu_and_mul ? 2 : 1) && input.size(-2) == rows,
+              "input / output_q shape mismatch");
+  const int64_t groups = hidden / group_size;
+  const int32_t* mm = nullptr;
+  if (masked_layout) {
+    CHECK_GPU(*masked_m);
+    TORCH_CHECK(masked_m->scalar_type() == at::kInt && masked_m->numel() == experts && masked_m->is_contiguous(),
+                "masked_m must be a contiguous int32 [num_experts] tensor");
+    mm = masked_m->data_ptr<int32_t>();
+  }
+  const bool column_major = output_s.stride(-2) < output_s.stride(-1);
+  int kind = 0;
+  int64_t s_e = masked_layout ? output_s.stride(0) : 0, s_row = output_s.stride(-2), s_col = output_s.stride(-1);
+  if (!scale_ue8m0) {
+    TORCH_CHECK(output_s.scalar_type() == at::kFloat, "output_s must be float32 unless scale_ue8m0");
+    TORCH_CHECK(output_s.size(-2) == rows && output_s.size(-1) == groups, "output_s must be [.., rows, groups]");
+  } else if (column_major) {
+    TORCH_CHECK(output_s.element_size() == 4, "column-major ue8m0 scales must be packed 4 per 32-bit element");
+    kind = 2;
+  } else {
+    TORCH_CHECK(output_s.element_size() == 1 && output_s.is_contiguous(), "row-major ue8m0 scales must be a contiguous uint8 tensor");
+    kind = 1;
+  }
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_per_token_group_quant_8bit_v2(stream_of(input), input.data_ptr(), output_q.data_ptr(), output_s.data_ptr(),
+                                               mm, experts, rows, hidden, (int)group_size, (float)eps, (float)min_8bit,
+                                               (float)max_8bit, dtype_code(in_t, "input"), dtype_code(q_t, "output_q"),
+                                               kind, s_e, s_row, s_col, fuse_silu_and_mul ? 1 : 0));
+}
+
+// ---- rotary_embedding (reference src/sycl/Rope.cpp:453-471) -------------------------------------------------
+
+std::tuple<Tensor, Tensor> rotary_embedding(Tensor& positions, Tensor& query, Tensor& key, int64_t head_size,
+                                            Tensor& cos_sin_cache, bool is_neox) {
+  CHECK_GPU(positions);
+  CHECK_GPU(query);
+  CHECK_GPU(key);
+  CHECK_GPU(cos_sin_cache);
+  const auto dim = query.dim();
+  TORCH_CHECK(dim == 2 || dim == 3,
+              " Query/Key must be 2D [num_tokens, num_heads*head_size] or 3D [num_tokens, num_heads, head_size] tensor");
+  TORCH_CHECK(key.dim() == dim, "query and key must have the same rank");
+  TORCH_CHECK(positions.scalar_type() == at::kLong, "positions must be int64");
+  TORCH_CHECK(cos_sin_cache.dim() == 2 && cos_sin_cache.is_contiguous(), "cos_sin_cache must be contiguous [max_pos, rot_dim]");
+  TORCH_CHECK(cos_sin_cache.scalar_type() == query.scalar_type() && key.scalar_type() == query.scalar_type(),
+              "query, key and cos_sin_cache must share one dtype");
+  CHECK_LAST_DIM_CONTIGUOUS(query);
+  CHECK_LAST_DIM_CONTIGUOUS(key);
+  const int64_t rot_dim = cos_sin_cache.size(1);
+  const Tensor pos = positions.reshape({-1}).contiguous();
+  const int64_t tokens = pos.size(0);
+  const c10::OptionalDeviceGuard guard(query.device());
+  if (dim == 2) {
+    TORCH_CHECK(head_size > 0 && query.size(1) % head_size == 0 && key.size(1) % head_size == 0,
+                "query/key widths must be multiples of head_size");
+    TORCH_CHECK(query.size(0) == tokens && key.size(0) == tokens, "positions and query/key disagree on the token count");
+    SGLK_CALL(sglk_rotary_embedding(stream_of(query), query.data_ptr(), key.data_ptr(), query.data_ptr(), key.data_ptr(),
+                                    pos.data_ptr<int64_t>(), cos_sin_cache.data_ptr(), tokens, query.size(1) / head_size,
+                                    key.size(1) / head_size, head_size, rot_dim, query.stride(0), head_size, key.stride(0),
+                                    head_size, query.stride(0), head_size, key.stride(0), head_size, is_neox ? 1 : 0,
+                                    dtype_code(query.scalar_type(), "query")));
+    return {query, key};
+  }
+  TORCH_CHECK(cos_sin_cache.size(1) == query.size(2), "Rotary dim doesn't match query head_size");
+  TORCH_CHECK(cos_sin_cache.size(1) == key.size(2), "Rotary dim doesn't match key head_size");
+  TORCH_CHECK(query.size(0) == tokens && key.size(0) == tokens, "positions and query/key disagree on the token count");
+  Tensor q_out = at::empty_like(query), k_out = at::empty_like(key);
+  q_out = q_out.contiguous();
+  k_out = k_out.contiguous();
+  SGLK_CALL(sglk_rotary_embedding(stream_of(query), q_out.data_ptr(), k_out.data_ptr(), query.data_ptr(), key.data_ptr(),
+                                  pos.data_ptr<int64_t>(), cos_sin_cache.data_ptr(), tokens, query.size(1), key.size(1),
+                                  query.size(2), rot_dim, query.stride(0), query.stride(1), key.stride(0), key.stride(1),
+                                  q_out.stride(0), q_out.stride(1), k_out.stride(0), k_out.stride(1), is_neox ? 1 : 0,
+                                  dtype_code(query.scalar_type(), "query")));
+  return {q_out, k_out};
+}
+
 }  // namespace
 
 TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
@@ -562,6 +791,16 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "sgl_per_token_group_quant_8bit(Tensor input, Tensor output_q, Tensor output_s, int group_size,"
       " float eps, float fp8_min, float fp8_max, bool scale_ue8m0) -> ()");
   m.impl("sgl_per_token_group_quant_8bit", c10::kCUDA, &sgl_per_token_group_quant_8bit);
+  // reference src/torch_extension_sycl.cc:399-402
+  m.def(
+      "sgl_per_token_group_quant_8bit_v2(Tensor input, Tensor output_q, Tensor output_s, int group_size,"
+      " float eps, float fp8_min, float fp8_max, bool scale_ue8m0, bool fuse_silu_and_mul, Tensor? masked_m) -> ()");
+  m.impl("sgl_per_token_group_quant_8bit_v2", c10::kCUDA, &sgl_per_token_group_quant_8bit_v2);
+  // reference src/torch_extension_sycl.cc:117-120
+  m.def(
+      "rotary_embedding(Tensor positions, Tensor query, Tensor key, int head_size, Tensor cos_sin_cache, "
+      "bool is_neox) -> (Tensor, Tensor)");
+  m.impl("rotary_embedding", c10::kCUDA, &rotary_embedding);
 
   // authored: reference include/sgl_kernel_ops.h:581-586 + python/sgl_kernel/gemm.py:24-31
   m.def(
@@ -577,6 +816,39 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "int8_scaled_mm(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype,"
       " Tensor? bias) -> Tensor");
   m.impl("int8_scaled_mm", c10::kCUDA, &int8_scaled_mm);
+
+  // reference src/torch_extension_sycl.cc:328-358
+  m.def(
+      "fwd(Tensor   q,"
+      "    Tensor   k,"
+      "    Tensor   v,"
+      "    Tensor?  q_v,"
+      "    Tensor  cu_seqlens_q,"
+      "    Tensor  cu_seqlens_k,"
+      "    int     max_seqlen_q,"
+      "    int     max_seqlen_k,"
+      "    Tensor?  page_table,"
+      "    Tensor?  kv_batch_idx,"
+      "    Tensor?  leftpad_k,"
+      "    Tensor?  rotary_cos,"
+      "    Tensor?  rotary_sin,"
+      "    Tensor?  seqlens_rotary,"
+      "    Tensor?  q_descale,"
+      "    Tensor?  k_descale,"
+      "    Tensor?  v_descale,"
+      "    float    softmax_scale,"
+      "    Tensor?  sinks,"
+      "    bool     is_causal,"
+      "    int      window_size_left,"
+      "    int      window_size_right,"
+      "    float    softcap,"
+      "    bool     is_rotary_interleaved,"
+      "    Tensor?  scheduler_metadata,"
+      "    int      num_kv_splits,"
+      "    bool?    pack_gqa,"
+      "    int      sm_margin,"
+      "    Tensor(a!)?  out=None) -> (Tensor(a!), Tensor, Tensor, Tensor)");
+  m.impl("fwd", c10::kCUDA, &mha_fwd);
 
   // reference src/torch_extension_sycl.cc:362-368
   m.def("flash_mla_get_workspace_size", &flash_mla_get_workspace_size);

@@ -26,8 +26,10 @@ from sgl_kernel.elementwise import (  # noqa: E402
     gemma_fused_add_rmsnorm,
     gemma_rmsnorm,
     rmsnorm,
+    rotary_embedding,
     silu_and_mul,
 )
+from sgl_kernel.flash_attn import flash_attn_varlen_func, flash_attn_with_kvcache, is_fa3_supported  # noqa: E402
 from sgl_kernel.gemm import (  # noqa: E402
     fp8_blockwise_scaled_mm,
     fp8_scaled_mm,

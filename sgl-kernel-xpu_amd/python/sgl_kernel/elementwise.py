@@ -93,3 +93,18 @@ def gelu_tanh_and_mul(input: torch.Tensor, out: torch.Tensor = None) -> torch.Te
 
 def gelu_and_mul(input: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     return _act_and_mul(torch.ops.sgl_kernel.gelu_and_mul, input, out)
+
+
+def rotary_embedding(
+    positions: torch.Tensor,
+    query: torch.Tensor,
+    key: torch.Tensor,
+    head_size: int,
+    cos_sin_cache: torch.Tensor,
+    is_neox: bool = True,
+):
+    """Rotary position embedding (op schema of reference src/torch_extension_sycl.cc:117-120; the reference
+    has no python wrapper, its tests call torch.ops.sgl_kernel.rotary_embedding directly). 2-D query/key
+    [tokens, heads*head_size] are rotated in place and returned; 3-D [tokens, heads, head_size] inputs give new
+    tensors (rot_dim must equal head_size there). cos_sin_cache [max_pos, rot_dim] must have query's dtype."""
+    return torch.ops.sgl_kernel.rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox)

@@ -215,7 +215,50 @@ def gen_topk_softmax():
     save("topk_softmax", cases)
 
 
+def gen_attention():
+    t = _import_ref("test_flash_attention")
+    cases = []
+    torch.manual_seed(0)
+    for dt, b, sq, sk, Hq, Hk, D, causal, window, softcap, use_sink in [
+        (torch.bfloat16, 2, 1, 130, 8, 2, 128, False, (-1, -1), 0.0, False),
+        (torch.float16, 2, 33, 97, 4, 4, 64, True, (-1, -1), 0.0, False),
+        (torch.bfloat16, 1, 64, 64, 4, 1, 64, False, (17, 5), 0.0, True),
+        (torch.float16, 2, 20, 40, 6, 2, 80, True, (-1, -1), 30.0, False),
+        (torch.bfloat16, 1, 5, 300, 16, 4, 256, True, (-1, -1), 0.0, False),
+    ]:
+        q = torch.randn(b, sq, Hq, D).to(dt)
+        k = torch.randn(b, sk, Hk, D).to(dt)
+        v = torch.randn(b, sk, Hk, D).to(dt)
+        sink = torch.randn(Hq) if use_sink else None
+        scale = D ** -0.5
+        out, _ = t.attention_ref(q, k, v, scale, sink=sink, causal=causal, window_size=window, softcap=softcap)
+        out_pt, _ = t.attention_ref(q, k, v, scale, sink=sink, causal=causal, window_size=window, softcap=softcap,
+                                    upcast=False, reorder_ops=True)
+        cases.append(dict(q=q, k=k, v=v, sink=sink, scale=scale, causal=causal, window=window, softcap=softcap,
+                          out=out, out_pt=out_pt))
+    save("attention", cases)
+
+
+def gen_rope():
+    t = _import_ref("test_rotary_embedding")
+    cases = []
+    torch.manual_seed(0)
+    for dt, tokens, hq, hk, head, rot, neox in [(torch.bfloat16, 7, 4, 2, 64, 64, True), (torch.float16, 5, 8, 8, 128, 64, False),
+                                                (torch.bfloat16, 9, 2, 1, 96, 32, True)]:
+        rope = t.RotaryEmbedding(head, rot, 256, 10000, neox, dt)
+        pos = torch.randint(0, 256, (tokens,))
+        q = torch.randn(tokens, hq * head).to(dt)
+        k = torch.randn(tokens, hk * head).to(dt)
+        rope.cos_sin_cache = rope.cos_sin_cache.to(dt)  # what the kernel is handed (forward_xpu :138-148)
+        qo, ko = rope.forward_native(pos, q.clone(), k.clone())
+        cases.append(dict(positions=pos, q=q, k=k, head_size=head, cache=rope.cos_sin_cache.clone(), is_neox=neox,
+                          q_out=qo, k_out=ko))
+    save("rope", cases)
+
+
 GENERATORS = {
+    "rope": gen_rope,
+    "attention": gen_attention,
     "moe_w4a16": gen_moe,
     "topk_softmax": gen_topk_softmax,
     "mla_decode": gen_mla_decode,

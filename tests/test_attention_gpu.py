@@ -1,0 +1,232 @@
+"""GPU parity: `fwd` (flash_attn_with_kvcache / flash_attn_varlen_func) vs the CPU oracle.
+
+Grids follow reference tests/test_flash_attention.py: paged kv-cache :626-658, decode :1173-1224, varlen
+:1908-1948, out= :2249-2300. Acceptance is the reference's rule (:1112-1121): the error against the fp32 oracle
+must not exceed twice the error of a plain torch implementation in the input dtype (+1e-5)."""
+import itertools
+
+import pytest
+import torch
+from conftest import load_golden
+
+from oracle import attention as oa
+
+pytestmark = pytest.mark.gpu
+
+
+def pt_seq(q, k, v, scale, causal, window, softcap, sinks):
+    """The same math in the input dtype (no upcast) — the reference's yardstick `out_pt`."""
+    dt = q.dtype
+    o, _ = oa.attention_seq(q, (k.float() * scale).to(dt).float() / scale if False else k, v, scale, causal=causal,
+                            window=window, softcap=softcap, sinks=sinks)
+    # low-precision emulation: scores and probabilities rounded to the input dtype
+    sq, Hq, D = q.shape
+    g = Hq // k.shape[1]
+    kf = (k * scale).repeat_interleave(g, dim=1)
+    scores = torch.einsum("thd,shd->hts", q, kf.to(dt)).float()
+    if softcap > 0:
+        scores = torch.tanh(scores / softcap) * softcap
+    sk = k.shape[0]
+    left, right = window
+    if causal:
+        right = 0
+    row = torch.arange(sq).view(-1, 1)
+    col = torch.arange(sk).view(1, -1)
+    mask = torch.zeros(sq, sk, dtype=torch.bool)
+    if right >= 0:
+        mask |= col > row + sk - sq + right
+    if left >= 0:
+        mask |= col < row + sk - sq - left
+    scores = scores.masked_fill(mask.unsqueeze(0), float("-inf"))
+    if sinks is not None:
+        scores = torch.cat([scores, sinks.float().view(Hq, 1, 1).expand(Hq, sq, 1)], dim=-1)
+    attn = torch.nan_to_num(torch.softmax(scores, dim=-1), nan=0.0).to(dt)
+    if sinks is not None:
+        attn = attn[..., :-1]
+    return torch.einsum("hts,shd->thd", attn, v.repeat_interleave(g, dim=1)).float()
+
+
+def check(out, ref, pt, what=""):
+    err = (out.float() - ref).abs().max().item()
+    err_pt = (pt - ref).abs().max().item()
+    assert err <= 2 * err_pt + 1e-5, f"{what}: max err {err:.3e} > 2 x {err_pt:.3e}"
+    m = (out.float() - ref).abs().mean().item()
+    m_pt = (pt - ref).abs().mean().item()
+    assert m <= 1.5 * m_pt + 1e-6, f"{what}: mean err {m:.3e} > 1.5 x {m_pt:.3e}"
+
+
+def run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, D, page, causal=False, window=(-1, -1), softcap=0.0,
+              use_sink=False, num_splits=0, seed=0, use_out=False):
+    g = torch.Generator().manual_seed(seed)
+    b = len(seqs_q)
+    q = torch.randn(sum(seqs_q), Hq, D, generator=g).to(dtype)
+    cu_q = torch.tensor([0] + list(itertools.accumulate(seqs_q)), dtype=torch.int32)
+    pages_per_seq = (max(seqs_k) + page - 1) // page
+    n_pages = b * pages_per_seq + 3
+    kc = torch.randn(n_pages, page, Hk, D, generator=g).to(dtype)
+    vc = torch.randn(n_pages, page, Hk, D, generator=g).to(dtype)
+    table = torch.randperm(n_pages, generator=g)[: b * pages_per_seq].view(b, pages_per_seq).to(torch.int32)
+    lens = torch.tensor(seqs_k, dtype=torch.int32)
+    sinks = torch.randn(Hq, generator=g) if use_sink else None
+    scale = D ** -0.5
+    ks = [oa.gather_paged(kc, table[i], seqs_k[i]) for i in range(b)]
+    vs = [oa.gather_paged(vc, table[i], seqs_k[i]) for i in range(b)]
+    ref, ref_lse = oa.attention_ragged(q, ks, vs, cu_q, scale, causal=causal, window=window, softcap=softcap, sinks=sinks)
+    pt = torch.zeros_like(ref)
+    for i in range(b):
+        s, e = cu_q[i], cu_q[i + 1]
+        if e > s:
+            pt[s:e] = pt_seq(q[s:e], ks[i], vs[i], scale, causal, window, softcap, sinks)
+    out_buf = torch.empty(q.shape, dtype=dtype, device=dev) if use_out else None
+    res = sglk.flash_attn_with_kvcache(
+        q.to(dev), kc.to(dev), vc.to(dev), cache_seqlens=lens.to(dev), page_table=table.to(dev),
+        cu_seqlens_q=cu_q.to(dev), max_seqlen_q=max(seqs_q), softmax_scale=scale,
+        sinks=sinks.to(dev) if use_sink else None, causal=causal, window_size=window, softcap=softcap,
+        num_splits=num_splits, return_softmax_lse=True, out=out_buf)
+    out, lse = res[0], res[1]
+    if use_out:
+        assert out.data_ptr() == out_buf.data_ptr()
+    check(out.cpu(), ref, pt, f"paged D={D} page={page}")
+    fin = torch.isfinite(ref_lse)
+    torch.testing.assert_close(lse.cpu()[fin], ref_lse[fin], rtol=1e-3, atol=1e-3)
+
+
+# ---------------------------------------------------------------------- paged kv-cache, mixed prefill/decode batches
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("heads", [(16, 16), (16, 4), (8, 1)])
+@pytest.mark.parametrize("causal,local", [(False, True), (False, False), (True, False)])
+@pytest.mark.parametrize("page", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_kvcache_paged(sglk, dev, dtype, heads, causal, local, page, D):
+    Hq, Hk = heads
+    idx = hash((str(dtype), heads, causal, local, page, D)) % 5
+    sq, sk = [(3, 1024), (64, 800), (64, 256), (3, 799), (128, 128)][idx]
+    g = torch.Generator().manual_seed(idx)
+    seqs_k = torch.randint(max(1, sk - 20), sk + 1, (3,), generator=g).tolist()
+    seqs_q = [min(sq, s) for s in seqs_k]
+    window = (torch.randint(0, sk, (2,), generator=g).tolist()) if local else (-1, -1)
+    run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, D, page, causal=causal, window=tuple(window),
+              use_sink=(D == 64), seed=idx)
+
+
+@pytest.mark.parametrize("D,sq,sk", [(512, 3, 300), (512, 40, 130), (96, 17, 200), (192, 5, 77)])
+def test_kvcache_other_head_dims(sglk, dev, D, sq, sk):
+    run_paged(sglk, dev, torch.bfloat16, [sq, 1], [sk, sk - 9], 8, 2, D, 64, causal=True, seed=D)
+
+
+# --------------------------------------------------------------------------------------------------- decode
+@pytest.mark.parametrize("heads", [(16, 16), (16, 4), (16, 1), (8, 1), (32, 8)])
+@pytest.mark.parametrize("local", [False, True])
+@pytest.mark.parametrize("page", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("batch,seqlen_k", [(1, 1), (4, 63), (1, 64), (4, 65), (1, 129), (4, 1024), (1, 4033), (4, 4097),
+                                            (2, 8192)])
+def test_decode(sglk, dev, heads, local, page, D, batch, seqlen_k):
+    Hq, Hk = heads
+    if D == 256 and seqlen_k > 4097:
+        pytest.skip("CPU oracle time")
+    g = torch.Generator().manual_seed(seqlen_k + D)
+    seqs_k = torch.randint(max(1, seqlen_k - 30), seqlen_k + 1, (batch,), generator=g).tolist()
+    seqs_k[0] = seqlen_k
+    window = (seqlen_k // 3, 0) if local else (-1, -1)
+    for splits in (0, 1, 5):
+        run_paged(sglk, dev, torch.bfloat16, [1] * batch, seqs_k, Hq, Hk, D, page, window=window,
+                  use_sink=(D == 64 and not local), num_splits=splits, seed=seqlen_k)
+
+
+def test_decode_full_size_config_sampled(sglk, dev):
+    """BASELINE configs[2] decode: b=16, Hq=32, Hk=8, d=128, seq=4096, paged (64), bf16; oracle on 3 sequences."""
+    b, Hq, Hk, D, S, page = 16, 32, 8, 128, 4096, 64
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(b, 1, Hq, D, generator=g).to(torch.bfloat16)
+    n_pages = b * S // page
+    kc = torch.randn(n_pages, page, Hk, D, generator=g).to(torch.bfloat16)
+    vc = torch.randn(n_pages, page, Hk, D, generator=g).to(torch.bfloat16)
+    table = torch.randperm(n_pages, generator=g).view(b, -1).to(torch.int32)
+    lens = torch.full((b,), S, dtype=torch.int32, device=dev)
+    out = sglk.flash_attn_with_kvcache(q.to(dev), kc.to(dev), vc.to(dev), cache_seqlens=lens, page_table=table.to(dev)).cpu()
+    assert out.shape == (b, Hq, D) and torch.isfinite(out.float()).all()
+    for i in (0, 7, 15):
+        k_i, v_i = oa.gather_paged(kc, table[i], S), oa.gather_paged(vc, table[i], S)
+        ref, _ = oa.attention_seq(q[i], k_i, v_i, D ** -0.5)
+        check(out[i:i + 1], ref, pt_seq(q[i], k_i, v_i, D ** -0.5, False, (-1, -1), 0.0, None), f"seq {i}")
+
+
+# -------------------------------------------------------------------------------------------- ragged (non-paged)
+@pytest.mark.parametrize("heads", [(16, 16), (16, 4), (16, 1)])
+@pytest.mark.parametrize("causal,local", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("D", [72, 80, 128, 192, 256])
+@pytest.mark.parametrize("sq,sk", [(1, 1), (1, 239), (3, 799), (64, 128), (113, 203), (128, 217), (256, 512),
+                                   (108, 256), (1024, 1024)])
+def test_varlen(sglk, dev, heads, causal, local, D, sq, sk):
+    Hq, Hk = heads
+    if sq * sk * Hq > 2**23 and D > 128:
+        pytest.skip("CPU oracle time")
+    dtype = torch.bfloat16 if (sq + D) % 2 else torch.float16
+    g = torch.Generator().manual_seed(sq * 7 + sk + D)
+    b = 3
+    lens_q = torch.randint(max(1, sq - 20), sq + 1, (b,), generator=g).tolist()
+    lens_k = torch.randint(max(1, sk - 20), sk + 1, (b,), generator=g).tolist()
+    cu_q = torch.tensor([0] + list(itertools.accumulate(lens_q)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(itertools.accumulate(lens_k)), dtype=torch.int32)
+    q = torch.randn(sum(lens_q), Hq, D, generator=g).to(dtype)
+    k = torch.randn(sum(lens_k), Hk, D, generator=g).to(dtype)
+    v = torch.randn(sum(lens_k), Hk, D, generator=g).to(dtype)
+    window = tuple(torch.randint(0, sk, (2,), generator=g).tolist()) if local else (-1, -1)
+    scale = D ** -0.5
+    ks = [k[cu_k[i]:cu_k[i + 1]] for i in range(b)]
+    vs = [v[cu_k[i]:cu_k[i + 1]] for i in range(b)]
+    ref, _ = oa.attention_ragged(q, ks, vs, cu_q, scale, causal=causal, window=window)
+    pt = torch.cat([pt_seq(q[cu_q[i]:cu_q[i + 1]], ks[i], vs[i], scale, causal, window, 0.0, None) for i in range(b)])
+    out = sglk.flash_attn_varlen_func(q.to(dev), k.to(dev), v.to(dev), cu_q.to(dev), cu_k.to(dev), max(lens_q),
+                                      max(lens_k), causal=causal, window_size=window)
+    check(out.cpu(), ref, pt, f"varlen D={D}")
+
+
+def test_softcap_and_out_buffer(sglk, dev):
+    run_paged(sglk, dev, torch.float16, [20, 1, 7], [40, 300, 64], 6, 2, 80, 64, causal=True, softcap=30.0, seed=1)
+    run_paged(sglk, dev, torch.bfloat16, [1, 1], [500, 77], 16, 4, 128, 128, num_splits=4, use_out=True, seed=2)
+
+
+def test_fully_masked_rows_give_zero(sglk, dev):
+    # seqlen_q > seqlen_k with a causal mask: the first rows see no key (reference docstring example)
+    q = torch.randn(5, 2, 64).to(torch.float16)
+    k = torch.randn(2, 2, 64).to(torch.float16)
+    v = torch.randn(2, 2, 64).to(torch.float16)
+    cu_q = torch.tensor([0, 5], dtype=torch.int32)
+    cu_k = torch.tensor([0, 2], dtype=torch.int32)
+    out = sglk.flash_attn_varlen_func(q.to(dev), k.to(dev), v.to(dev), cu_q.to(dev), cu_k.to(dev), 5, 2, causal=True).cpu()
+    assert torch.equal(out[:3], torch.zeros(3, 2, 64, dtype=torch.float16))
+    ref, _ = oa.attention_seq(q, k, v, 64 ** -0.5, causal=True)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_golden_vectors(sglk, dev):
+    for c in load_golden("attention"):
+        q, k, v = c["q"], c["k"], c["v"]
+        b, sq, Hq, D = q.shape
+        sk = k.shape[1]
+        cu_q = torch.arange(0, b + 1, dtype=torch.int32) * sq
+        cu_k = torch.arange(0, b + 1, dtype=torch.int32) * sk
+        out = sglk.flash_attn_varlen_func(
+            q.reshape(-1, Hq, D).to(dev), k.reshape(-1, k.shape[2], D).to(dev), v.reshape(-1, k.shape[2], D).to(dev),
+            cu_q.to(dev), cu_k.to(dev), sq, sk, softmax_scale=c["scale"],
+            sinks=c["sink"].to(dev) if c["sink"] is not None else None, causal=c["causal"], window_size=c["window"],
+            softcap=c["softcap"]).cpu().view(b, sq, Hq, D)
+        # the reference's own acceptance rule against its own fp32 and low-precision outputs
+        err = (out.float() - c["out"].float()).abs().max().item()
+        err_pt = (c["out_pt"].float() - c["out"].float()).abs().max().item()
+        assert err <= 2 * err_pt + 1e-5, (err, err_pt)
+
+
+def test_errors(sglk, dev):
+    q = torch.zeros(4, 2, 64, dtype=torch.float16, device=dev)
+    k = torch.zeros(8, 1, 64, dtype=torch.float16, device=dev)
+    cu = torch.tensor([0, 4], dtype=torch.int32, device=dev)
+    cuk = torch.tensor([0, 8], dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError, match="q_v is not supported"):
+        sglk.flash_attn_varlen_func(q, k, k, cu, cuk, 4, 8, qv=q)
+    with pytest.raises(RuntimeError, match="same dtype"):
+        sglk.flash_attn_varlen_func(q, k.to(torch.bfloat16), k, cu, cuk, 4, 8)
+    with pytest.raises(RuntimeError, match="must divide"):
+        sglk.flash_attn_varlen_func(q[:, :1].repeat(1, 3, 1), k.repeat(1, 2, 1), k.repeat(1, 2, 1), cu, cuk, 4, 8)

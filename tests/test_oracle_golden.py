@@ -129,3 +129,23 @@ def test_moe_align_and_prepare_known_answers():
     cnt, ps1, ps2, a_map, c_map = omoe.prepare_moe_input(np.array([[0, 2], [2, 1], [0, 0]]), 3, 7, 2)
     assert cnt.tolist() == [3, 1, 2] and ps1[0].tolist() == [3, 14, 2] and ps2[2].tolist() == [2, 2, 7]
     assert a_map.tolist() == [0, 2, 2, 1, 0, 1] and c_map.tolist() == [0, 4, 5, 3, 1, 2]
+
+
+def test_attention_matches_reference_vectors():
+    from oracle import attention as oa
+    for c in load_golden("attention"):
+        q, k, v = c["q"], c["k"], c["v"]
+        for b in range(q.shape[0]):
+            o, _ = oa.attention_seq(q[b], k[b], v[b], c["scale"], causal=c["causal"], window=c["window"],
+                                    softcap=c["softcap"], sinks=c["sink"])
+            ref = c["out"][b].float()
+            err = (o.to(q.dtype).float() - ref).abs().max().item()
+            err_pt = (c["out_pt"][b].float() - ref).abs().max().item()
+            assert err <= 2 * err_pt + 1e-5  # tests/test_flash_attention.py:1112-1121
+
+
+def test_rope_matches_reference_vectors():
+    from oracle import rope as orope
+    for c in load_golden("rope"):
+        qo, ko = orope.rotary_embedding(c["positions"], c["q"], c["k"], c["head_size"], c["cache"], c["is_neox"])
+        assert torch.equal(qo, c["q_out"]) and torch.equal(ko, c["k_out"])
