@@ -48,7 +48,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256, BN = 256, BK = 128;
 constexpr int kTileBytes = BM * BK;              // 32 KiB per operand per stage
-constexpr int kStageBytes = 2 * kTileBytes + 1024;  // + 256 fp32 row scales
+constexpr int kStageBytes = 2 * kTileBytes + 2048;  // + 256 fp32 row scales (+ 1 KiB spare, see pipe kernel)
 constexpr int kStages = 2;
 
 #define SGLK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
@@ -66,6 +66,17 @@ __device__ __forceinline__ v8i read_frag(const char* tile, int off) {
 enum { MODE_BLOCKWISE = 0, MODE_FP8_ROWCOL = 1, MODE_INT8_ROWCOL = 2 };
 
 // fp8 e4m3 x e4m3, K = 128, D = A*B + C
+// fragment = two 16-byte LDS reads at (addr) and (addr ^ 64); addr is a 32-bit LDS byte address
+__device__ __forceinline__ v8i read_frag_lds(uint32_t lo, uint32_t hi, int imm) {
+  typedef __attribute__((address_space(3))) const v4i* lds_v4i_ptr;
+  const v4i a = *(lds_v4i_ptr)(uintptr_t)(lo + imm);
+  const v4i b = *(lds_v4i_ptr)(uintptr_t)(hi + imm);
+  v8i r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
 template <bool HW_SCALE>
 __device__ __forceinline__ v4f mfma_k128(const v8i& a, const v8i& b, const v4f& c) {
   if constexpr (HW_SCALE) {
@@ -85,7 +96,7 @@ __device__ __forceinline__ v4i mfma_i8_k128(const v8i& a, const v8i& b, v4i c) {
   return c;
 }
 
-template <typename OutT, int MODE, bool VEC_STORE, bool HW_SCALE>
+template <typename OutT, int MODE, bool VEC_STORE, bool HW_SCALE, int VAR>
 __global__ __launch_bounds__(512) void gemm_8bit_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N,
@@ -156,6 +167,40 @@ __global__ __launch_bounds__(512) void gemm_8bit_kernel(
     }
   };
 
+  // the same DMA split in four parts (two 1-KiB pieces each; part 0 also carries the row scales) so that it can be
+  // issued between the MFMA clusters of the running block instead of in one burst behind the barrier
+  auto stage_part = [&](int kb, int s, int part) {
+    char* base = smem + s * kStageBytes;
+    const uint8_t* ag = a_tile + (int64_t)kb * BK;
+    const uint8_t* bg = b_tile + (int64_t)kb * BK;
+    // per-lane source offsets are recomputed here (a handful of VALU ops) instead of living in registers; the
+    // empty asm keeps the compiler from hoisting them out of the K loop (it then spills them: scratch reloads
+    // are vector-memory loads and would drain the LDS-DMA queue)
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ii = (part & 1) * 2 + i;
+      const int row = (wave * 4 + ii) * 8 + (lane_v >> 3);
+      const int chunk = (lane_v & 7) ^ ((row >> 1) & 7);
+      if (part < 2) {
+        const int ra = (m0 + row < M) ? row : (M - 1 - m0);
+        const uint32_t off = (uint32_t)ra * (uint32_t)lda + chunk * 16;
+        __builtin_amdgcn_global_load_lds(SGLK_GLB(ag + off), SGLK_LDS(base + (wave * 4 + ii) * 1024), 16, 0, 0);
+      } else {
+        const int rb = (n0 + row < N) ? row : (N - 1 - n0);
+        const uint32_t off = (uint32_t)rb * (uint32_t)ldb + chunk * 16;
+        __builtin_amdgcn_global_load_lds(SGLK_GLB(bg + off), SGLK_LDS(base + kTileBytes + (wave * 4 + ii) * 1024), 16, 0, 0);
+      }
+    }
+    if constexpr (MODE == MODE_BLOCKWISE) {
+      if (part == 0 && wave < 4) {
+        __builtin_amdgcn_global_load_lds(SGLK_GLB(sa_lane + (int64_t)kb * sa_sk),
+                                         SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, 0, 0);
+      }
+    }
+  };
+
   // ---- fragment addressing (see header): lane = (row j, k-group g)
   const int j = lane & 15, g = lane >> 4;
   const int frag_off = j * 128 + ((g ^ ((j >> 1) & 7)) << 4);
@@ -174,6 +219,8 @@ __global__ __launch_bounds__(512) void gemm_8bit_kernel(
       for (int r = 0; r < 4; ++r) acc[mf][nf][r] = 0;
 
   const int nkb = K / BK;
+  float sbv_next = (MODE == MODE_BLOCKWISE) ? sb_wave[0] : 0.f;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
   stage(0, 0);
 
   for (int kb = 0; kb < nkb; ++kb) {
@@ -181,16 +228,70 @@ __global__ __launch_bounds__(512) void gemm_8bit_kernel(
     // the DMA of block kb has landed for every wave, and every wave has finished reading stage s^1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kb + 1 < nkb) stage(kb + 1, s ^ 1);
+    if (VAR == 0 || VAR == 9 || MODE != MODE_BLOCKWISE) {
+      if (kb + 1 < nkb) stage(kb + 1, s ^ 1);
+    }
+    if constexpr (VAR == 9) continue;  // timing probe: DMA + barriers only (results are garbage)
 
     const char* ta = smem + s * kStageBytes;  // rows of a   -> MFMA B operand (columns = m)
     const char* tb = ta + kTileBytes;         // rows of b^T -> MFMA A operand (rows = n)
 
     v8i nfr[4];
+    if constexpr (MODE == MODE_BLOCKWISE && (VAR == 1 || VAR == 8)) {
+      int fo = frag_off;
+      asm volatile("" : "+v"(fo));
+      const uint32_t b_lo = lds_base + (uint32_t)(s * kStageBytes + kTileBytes + wn * 64 * 128) + (uint32_t)fo;
+      const uint32_t b_hi = b_lo ^ 64u;
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) nfr[nf] = read_frag(tb, (wn * 64 + nf * 16) * 128 + frag_off);
+      for (int nf = 0; nf < 4; ++nf) nfr[nf] = read_frag_lds(b_lo, b_hi, nf * 16 * 128);
+    } else {
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) nfr[nf] = read_frag(tb, (wn * 64 + nf * 16) * 128 + frag_off);
+    }
 
-    if constexpr (MODE == MODE_BLOCKWISE) {
+    if constexpr (MODE == MODE_BLOCKWISE && (VAR == 1 || VAR == 8)) {
+      // V1: m-fragments prefetched one step ahead, next block's DMA issued in four parts between the MFMA clusters.
+      // All LDS addresses of the block derive from ONE per-lane constant re-materialised here (opaque to LICM).
+      int fo = frag_off;
+      asm volatile("" : "+v"(fo));
+      const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);
+      const uint32_t a_lo = sbase + (uint32_t)(wm * 128 * 128) + (uint32_t)fo, a_hi = a_lo ^ 64u;
+      const uint32_t ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((fo >> 7) << 2);
+      typedef __attribute__((address_space(3))) const float* lds_f_ptr;
+      // this block's column-block scale was fetched (scalar load) one block ago; pin it into a VGPR here, at the
+      // top of the block, so that the lgkmcnt(0) a scalar-load consumer needs is paid before any LDS read is in flight
+      float sbv = sbv_next;
+      asm volatile("" : "+v"(sbv));
+      if (kb + 1 < nkb) sbv_next = sb_wave[(int64_t)(kb + 1) * sb_sk];
+      const v4f zero = {0.f, 0.f, 0.f, 0.f};
+      constexpr int PD = 1;  // LDS prefetch distance in m-steps (2 measured no faster)
+      constexpr int NB = PD + 1;
+      v8i mfr[NB];
+      float raw[NB];  // row scales are multiplied by sb at use, so the prefetch is not waited for early
+#pragma unroll
+      for (int p = 0; p < PD; ++p) {
+        mfr[p] = read_frag_lds(a_lo, a_hi, p * 16 * 128);
+        raw[p] = *(lds_f_ptr)(uintptr_t)(ts_addr + p * 64);
+      }
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf) {
+        if (mf + PD < 8) {
+          mfr[(mf + PD) % NB] = read_frag_lds(a_lo, a_hi, (mf + PD) * 16 * 128);
+          raw[(mf + PD) % NB] = *(lds_f_ptr)(uintptr_t)(ts_addr + (mf + PD) * 64);
+        }
+        if (VAR == 1 && mf < 4 && kb + 1 < nkb) stage_part(kb + 1, s ^ 1, mf);
+        const float sc = raw[mf % NB] * sbv;
+        v4f cur[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) cur[nf] = mfma_k128<HW_SCALE>(nfr[nf], mfr[mf % NB], zero);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mf][nf][r] = __builtin_fmaf(cur[nf][r], sc, acc[mf][nf][r]);
+        // keep the scheduler from pulling the LDS reads of later steps up here (register pressure -> spills)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (MODE == MODE_BLOCKWISE) {
       const float* ts = reinterpret_cast<const float*>(ta + 2 * kTileBytes);
       const float sbv = sb_wave[(int64_t)kb * sb_sk];
       const v4f zero = {0.f, 0.f, 0.f, 0.f};
@@ -277,6 +378,252 @@ __global__ __launch_bounds__(512) void gemm_8bit_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Blockwise kernel, pipelined across K blocks. Same tile, wave layout, LDS image and arithmetic as above; what
+// changes is WHERE the one barrier per K block sits. It is placed between m-steps 6 and 7: by then every wave
+// has read all it needs from the running stage (the last m-fragment is already in registers), and the DMA of
+// the next block, issued in pieces during m-steps 0..2 and the previous block's step 7, has had >1000 cycles
+// to land. Step 7 then overlaps its four MFMAs with the LDS reads of the NEXT block's n-fragments (each into
+// the registers of the n-fragment the MFMA just issued has consumed) and first m-fragment, so the matrix pipe
+// does not drain at the block boundary; the first DMA piece of block kb+2 goes out in the same step.
+// PROBE: 0 = real kernel, 1 = no DMA inside the loop (timing probe, garbage results).
+template <typename OutT, bool VEC_STORE, bool HW_SCALE, int PROBE>
+__global__ __launch_bounds__(512) void gemm_fp8_blockwise_pipe_kernel(
+    OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+    const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
+    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int tile;
+  {
+    const int nt = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GM = 4;
+  const int group = tile / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int in_group = tile - group * GM * tiles_n;
+  const int tm = first_m + in_group % gsz;
+  const int tn = in_group / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
+
+  // ---- LDS-DMA through buffer resources: one buffer_load_dwordx4 ... lds per 1-KiB piece (8 rows x 128 B), the
+  // per-lane part of the address is a loop-invariant VGPR, everything that changes (K block, piece) is scalar.
+  // Rows past the end of a / b are out of the resource's range and arrive as zeros.
+  const int rows_a = M - m0, rows_b = N - n0;  // > 0
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a + (int64_t)m0 * lda), 0, (int)(uint32_t)((int64_t)((rows_a < BM ? rows_a : BM) - 1) * lda + K), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(b + (int64_t)n0 * ldb), 0, (int)(uint32_t)((int64_t)((rows_b < BN ? rows_b : BN) - 1) * ldb + K), 0x00020000);
+  // piece p of a tile covers rows 8p..8p+7; lane -> (row 8p + lane/8, 16-byte chunk (lane%8) ^ ((row>>1)&7));
+  // (row>>1)&7 = (4(p&1) + lane/16) & 7, so the per-lane offset only depends on the parity of p
+  uint32_t voff_a[2], voff_b[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int chunk = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
+    voff_a[par] = (uint32_t)(lane >> 3) * (uint32_t)lda + chunk * 16;
+    voff_b[par] = (uint32_t)(lane >> 3) * (uint32_t)ldb + chunk * 16;
+  }
+  // row scales of the tile's 256 rows: waves 0..3 fetch 64 each, 4 B per lane
+  const int srows = rows_a < BM ? rows_a : BM;
+  const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(sa + (int64_t)m0 * sa_sm), 0,
+      (int)(uint32_t)(((int64_t)(srows - 1) * sa_sm + (int64_t)(K / BK - 1) * sa_sk + 1) * 4), 0x00020000);
+  const uint32_t voff_s = (uint32_t)tid * (uint32_t)sa_sm * 4u;
+
+  // a resource with no records: every lane is out of range, the DMA writes zeros and touches no memory. Selecting
+  // it (scalar selects) is how "no further K block" and "this wave fetches no scales" are expressed without
+  // branches: the loop body must stay ONE basic block or the optimiser sinks MFMAs across the hand-placed reads.
+  const __amdgpu_buffer_rsrc_t rsrc_null = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_sw = wave < 4 ? rsrc_s : rsrc_null;
+
+  // DMA part 0..3 of one K block: two pieces each (parts 0,1: rows of a; 2,3: rows of b^T); part 0 also carries
+  // the row scales (waves 4..7: zeros into the stage's spare KiB)
+  auto dma_part = [&](int kb, int s, int part, bool live) {
+    char* base = smem + s * kStageBytes;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ii = (part & 1) * 2 + i;
+      const int piece = wave * 4 + ii;
+      if (part < 2) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rsrc_a : rsrc_null, SGLK_LDS(base + piece * 1024), 16,
+                                                 voff_a[ii & 1], kb * BK + piece * 8 * (int)lda, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rsrc_b : rsrc_null, SGLK_LDS(base + kTileBytes + piece * 1024), 16,
+                                                 voff_b[ii & 1], kb * BK + piece * 8 * (int)ldb, 0, 0);
+      }
+    }
+    if (part == 0) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rsrc_sw : rsrc_null, SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4,
+                                               voff_s, kb * (int)sa_sk * 4, 0, 0);
+    }
+  };
+
+  const int j = lane & 15, g = lane >> 4;
+  const int frag_off = j * 128 + ((g ^ ((j >> 1) & 7)) << 4);
+  const int nblk_max = (N + 127) / 128 - 1;
+  int nblk = (n0 + wn * 64) >> 7;
+  nblk = nblk < nblk_max ? nblk : nblk_max;
+  const float* sb_wave = sb + (int64_t)nblk * sb_sn;
+  typedef __attribute__((address_space(3))) const float* lds_f_ptr;
+
+  v4f acc[8][4];
+#pragma unroll
+  for (int mf = 0; mf < 8; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  // LDS reads of the main loop are inline asm: their order relative to the MFMAs is the point of this kernel and
+  // the optimiser is free to hoist plain loads (it then keeps seven m-fragments live and spills). The waits are
+  // therefore counted by hand; every wait names the registers it releases so that their consumers stay below it.
+#define SGLK_RD16(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+#define SGLK_RD4(dst, addr, imm) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+#define SGLK_FRAG(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
+
+  const int nkb = K / BK;
+  v4i nlo[4], nhi[4], mlo[2], mhi[2];
+  float raw[2];
+  // ---- prologue: block 0 lands, its resident fragments are read, part 0 of block 1 goes out
+#pragma unroll
+  for (int part = 0; part < 4; ++part) dma_part(0, 0, part, true);
+  float sbv = sb_wave[0];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("" : "+v"(sbv));
+  {
+    const uint32_t b_lo = lds_base + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)frag_off, b_hi = b_lo ^ 64u;
+    const uint32_t a_lo = lds_base + (uint32_t)(wm * 128 * 128) + (uint32_t)frag_off, a_hi = a_lo ^ 64u;
+    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)(j << 2);
+    SGLK_RD16(nlo[0], b_lo, 0);     SGLK_RD16(nhi[0], b_hi, 0);
+    SGLK_RD16(mlo[0], a_lo, 0);     SGLK_RD16(mhi[0], a_hi, 0);
+    SGLK_RD4(raw[0], ts0, 0);
+    SGLK_RD16(nlo[1], b_lo, 2048);  SGLK_RD16(nhi[1], b_hi, 2048);
+    SGLK_RD16(nlo[2], b_lo, 4096);  SGLK_RD16(nhi[2], b_hi, 4096);
+    SGLK_RD16(nlo[3], b_lo, 6144);  SGLK_RD16(nhi[3], b_hi, 6144);
+  }
+  if (PROBE == 0) dma_part(1, 1, 0, nkb > 1);
+
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int s = kb & 1;
+    const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);
+    const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStageBytes);
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    const bool more = kb + 1 < nkb;
+    {
+      int fo = frag_off;
+      asm volatile("" : "+v"(fo));
+      const uint32_t a_lo = sbase + (uint32_t)(wm * 128 * 128) + (uint32_t)fo, a_hi = a_lo ^ 64u;
+      const uint32_t ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((fo >> 7) << 2);
+
+#define SGLK_STEP(mf)                                                                                          \
+  {                                                                                                            \
+    SGLK_RD16(mlo[((mf) + 1) & 1], a_lo, ((mf) + 1) * 2048);                                                   \
+    SGLK_RD16(mhi[((mf) + 1) & 1], a_hi, ((mf) + 1) * 2048);                                                   \
+    SGLK_RD4(raw[((mf) + 1) & 1], ts_addr, ((mf) + 1) * 64);                                                   \
+    if (PROBE == 0 && (mf) < 3) dma_part(kb + 1, s ^ 1, (mf) + 1, more);                                       \
+    if ((mf) == 0) {                                                                                           \
+      asm volatile("s_waitcnt lgkmcnt(3)"                                                                      \
+                   : "+v"(nlo[0]), "+v"(nhi[0]), "+v"(nlo[1]), "+v"(nhi[1]), "+v"(nlo[2]), "+v"(nhi[2]),       \
+                     "+v"(nlo[3]), "+v"(nhi[3]), "+v"(mlo[0]), "+v"(mhi[0]), "+v"(raw[0]));                    \
+    } else {                                                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(mlo[(mf) & 1]), "+v"(mhi[(mf) & 1]), "+v"(raw[(mf) & 1]));   \
+    }                                                                                                          \
+    const float sc = raw[(mf) & 1] * sbv;                                                                      \
+    const v8i mfrag = SGLK_FRAG(mlo[(mf) & 1], mhi[(mf) & 1]);                                                 \
+    v4f cur[4];                                                                                                \
+    _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
+        cur[nf] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[nf], nhi[nf]), mfrag, zero);                               \
+    _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
+            acc[mf][nf][r] = __builtin_fmaf(cur[nf][r], sc, acc[mf][nf][r]);                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+      SGLK_STEP(0) SGLK_STEP(1) SGLK_STEP(2) SGLK_STEP(3) SGLK_STEP(4) SGLK_STEP(5) SGLK_STEP(6)
+#undef SGLK_STEP
+    }
+
+    // ---- the block's barrier: next block landed everywhere, nobody reads stage s any more
+    float sbv_next = sb_wave[(int64_t)(more ? kb + 1 : kb) * sb_sk];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
+                 : "+v"(mlo[1]), "+v"(mhi[1]), "+v"(raw[1])
+                 :
+                 : "memory");
+    asm volatile("" : "+v"(sbv_next));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- m-step 7, overlapped with the next block's first LDS reads
+    {
+      const float sc = raw[1] * sbv;
+      int fo2 = frag_off;
+      asm volatile("" : "+v"(fo2));
+      const uint32_t nb_lo = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fo2, nb_hi = nb_lo ^ 64u;
+      const uint32_t na_lo = nbase + (uint32_t)(wm * 128 * 128) + (uint32_t)fo2, na_hi = na_lo ^ 64u;
+      const uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((fo2 >> 7) << 2);
+      const v8i mfrag = SGLK_FRAG(mlo[1], mhi[1]);
+      v4f cur[4];
+      cur[0] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[0], nhi[0]), mfrag, zero);
+      __builtin_amdgcn_sched_barrier(0);
+      SGLK_RD16(nlo[0], nb_lo, 0);     SGLK_RD16(nhi[0], nb_hi, 0);
+      SGLK_RD16(mlo[0], na_lo, 0);     SGLK_RD16(mhi[0], na_hi, 0);
+      SGLK_RD4(raw[0], nts, 0);
+      cur[1] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[1], nhi[1]), mfrag, zero);
+      __builtin_amdgcn_sched_barrier(0);
+      SGLK_RD16(nlo[1], nb_lo, 2048);  SGLK_RD16(nhi[1], nb_hi, 2048);
+      if (PROBE == 0) dma_part(kb + 2, s, 0, kb + 2 < nkb);
+      cur[2] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[2], nhi[2]), mfrag, zero);
+      __builtin_amdgcn_sched_barrier(0);
+      SGLK_RD16(nlo[2], nb_lo, 4096);  SGLK_RD16(nhi[2], nb_hi, 4096);
+      cur[3] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[3], nhi[3]), mfrag, zero);
+      __builtin_amdgcn_sched_barrier(0);
+      SGLK_RD16(nlo[3], nb_lo, 6144);  SGLK_RD16(nhi[3], nb_hi, 6144);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[7][nf][r] = __builtin_fmaf(cur[nf][r], sc, acc[7][nf][r]);
+      sbv = sbv_next;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // the reads issued by the last step 7 have no consumer: drain them before the registers are reused
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef SGLK_RD16
+#undef SGLK_RD4
+#undef SGLK_FRAG
+
+#pragma unroll
+  for (int mf = 0; mf < 8; ++mf) {
+    const int m = m0 + wm * 128 + mf * 16 + j;
+    if (m >= M) continue;
+    OutT* orow = out + (int64_t)m * ldc;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int n = n0 + wn * 64 + nf * 16 + g * 4;
+      if constexpr (VEC_STORE) {
+        if (n < N) {
+          Vec<OutT, 4> vv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] = (OutT)acc[mf][nf][r];
+          store_vec<OutT, 4>(orow + n, vv);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) orow[n + r] = (OutT)acc[mf][nf][r];
+      }
+    }
+  }
+}
+
+static int g_gemm_variant = 4;  // 4 = pipelined kernel (default); 0, 1 = earlier main loops; 8, 9, 14 = timing probes
+
 template <typename OutT, int MODE>
 static int launch(hipStream_t st, void* out, const void* a, const void* b, const float* sa, const float* sb,
                   const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
@@ -284,16 +631,35 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
   const unsigned grid = (unsigned)(tiles_m * tiles_n);
   const bool vec = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)out % 8 == 0);
-#define SGLK_GO(V, H)                                                                                       \
-  gemm_8bit_kernel<OutT, MODE, V, H><<<grid, 512, 0, st>>>(                                                 \
-      (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
+#define SGLK_GO_VAR(V, H, VAR)                                                                               \
+  gemm_8bit_kernel<OutT, MODE, V, H, VAR><<<grid, 512, 0, st>>>(                                             \
+      (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K,   \
       lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
+#define SGLK_GO_PIPE(V, H, P)                                                                                \
+  gemm_fp8_blockwise_pipe_kernel<OutT, V, H, P><<<grid, 512, 0, st>>>(                                       \
+      (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,       \
+      sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
+#define SGLK_GO(V, H)                                                                                        \
+  if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
+    switch (g_gemm_variant) {                                                                                \
+      case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
+      case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
+      case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
+      case 9: SGLK_GO_VAR(V, H, 9); break;                                                                   \
+      case 14: SGLK_GO_PIPE(V, H, 1); break;                                                                 \
+      default: SGLK_GO_PIPE(V, H, 0); break;                                                                 \
+    }                                                                                                        \
+  } else {                                                                                                   \
+    SGLK_GO_VAR(V, H, 0);                                                                                    \
+  }
   if (vec) {
-    if (hw_scale) SGLK_GO(true, true); else SGLK_GO(true, false);
+    if (hw_scale) { SGLK_GO(true, true) } else { SGLK_GO(true, false) }
   } else {
-    if (hw_scale) SGLK_GO(false, true); else SGLK_GO(false, false);
+    if (hw_scale) { SGLK_GO(false, true) } else { SGLK_GO(false, false) }
   }
 #undef SGLK_GO
+#undef SGLK_GO_VAR
+#undef SGLK_GO_PIPE
   return check_launch("gemm_8bit");
 }
 
@@ -317,6 +683,8 @@ static int check_common(const char* op, const void* a, const void* b, int64_t M,
 // encoding with unit scales. Both must give identical results.
 static int g_fp8_hw_scale = 1;
 extern "C" SGLK_API void sglk_debug_set_fp8_mfma_form(int hw_scale) { g_fp8_hw_scale = hw_scale; }
+// Test / tuning hook: main-loop variant of the blockwise kernel (0 = first version, 1 = default).
+extern "C" SGLK_API void sglk_debug_set_gemm_variant(int v) { sglk::g_gemm_variant = v; }
 
 extern "C" int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const void* a, const void* b,
                                             const float* sa, const float* sb, int64_t M, int64_t N,

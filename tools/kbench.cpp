@@ -1,0 +1,242 @@
+// Standalone (torch-free) timing harness for the C-ABI kernels: build with
+//   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -Lsgl-kernel-xpu_amd/python/sgl_kernel -lsglk -Wl,-rpath,... -o build/kbench
+// usage: kbench gemm M N K [variants...]   |   kbench mla B S H
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "sglk.h"
+
+extern "C" void sglk_debug_set_gemm_variant(int);
+
+#define HIP_CHECK(x)                                                                 \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) {                                                          \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));     \
+      exit(1);                                                                       \
+    }                                                                                \
+  } while (0)
+
+template <typename F>
+static double time_ms(F&& f, int warm, int iters, std::vector<float>* all = nullptr) {
+  for (int i = 0; i < warm; ++i) f();
+  HIP_CHECK(hipDeviceSynchronize());
+  std::vector<hipEvent_t> ev(iters + 1);
+  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipEventRecord(ev[0], 0));
+  for (int i = 0; i < iters; ++i) {
+    f();
+    HIP_CHECK(hipEventRecord(ev[i + 1], 0));
+  }
+  HIP_CHECK(hipDeviceSynchronize());
+  std::vector<float> ms(iters);
+  for (int i = 0; i < iters; ++i) HIP_CHECK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+  std::sort(ms.begin(), ms.end());
+  if (all) *all = ms;
+  return ms[iters / 2];
+}
+
+static void* dev_random_bytes(size_t n, unsigned seed, bool fp8_safe) {
+  std::vector<uint8_t> h(n);
+  std::mt19937 rng(seed);
+  for (size_t i = 0; i < n; i += 4) {
+    uint32_t r = rng();
+    for (int j = 0; j < 4 && i + j < n; ++j) {
+      uint8_t b = (uint8_t)(r >> (8 * j));
+      if (fp8_safe && (b & 0x7f) == 0x7f) b ^= 1;  // no e4m3 NaN
+      h[i + j] = b;
+    }
+  }
+  void* d;
+  HIP_CHECK(hipMalloc(&d, n));
+  HIP_CHECK(hipMemcpy(d, h.data(), n, hipMemcpyHostToDevice));
+  return d;
+}
+static float* dev_random_floats(size_t n, unsigned seed, float lo, float hi) {
+  std::vector<float> h(n);
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<float> d01(lo, hi);
+  for (auto& x : h) x = d01(rng);
+  float* d;
+  HIP_CHECK(hipMalloc(&d, n * 4));
+  HIP_CHECK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+  return d;
+}
+
+
+// ---- MFMA ceiling probe: no memory traffic in the loop, operands from registers --------------------------------
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ __launch_bounds__(512) void mfma_peak_kernel(const int* __restrict__ src, float* __restrict__ dst, int iters) {
+  v8i_t a[4], b[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) a[i][j] = src[(threadIdx.x * 8 + j + i * 4096) & 16383];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) b[i][j] = src[(threadIdx.x * 8 + j + i * 4096 + 777) & 16383];
+  if constexpr (MODE == 2) {
+    v16f_t acc[4] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[n], a[u + 2 * (it & 1)], acc[n], 0, 0, 0, 0, 0, 0);
+    }
+    float s = 0;
+    for (int n = 0; n < 4; ++n)
+      for (int r = 0; r < 16; ++r) s += acc[n][r];
+    dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  } else {
+    v4f_t acc[4][4] = {};
+    const v4f_t zero = {0, 0, 0, 0};
+    float sc = __int_as_float(0x3f800000 | (src[threadIdx.x] & 0xffff));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[n], a[m], acc[m][n], 0, 0, 0, 0, 0, 0);
+        } else {
+          v4f_t cur[4];
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            cur[n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[n], a[m], zero, 0, 0, 0, 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][n][r] = __builtin_fmaf(cur[n][r], sc, acc[m][n][r]);
+        }
+      }
+      asm volatile("" : "+v"(sc), "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]));
+    }
+    float s = 0;
+    for (int m = 0; m < 4; ++m)
+      for (int n = 0; n < 4; ++n)
+        for (int r = 0; r < 4; ++r) s += acc[m][n][r];
+    dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 1;
+  if (!strcmp(argv[1], "peak")) {  // kbench peak THREADS BLOCKS ITERS
+    const int threads = atoi(argv[2]), blocks = atoi(argv[3]), iters = atoi(argv[4]);
+    int* src = (int*)dev_random_bytes(16384 * 4, 9, true);
+    float* dst;
+    HIP_CHECK(hipMalloc(&dst, (size_t)blocks * threads * 4));
+    for (int mode = 0; mode < 3; ++mode) {
+      auto run = [&] {
+        if (mode == 0) mfma_peak_kernel<0><<<blocks, threads>>>(src, dst, iters);
+        if (mode == 1) mfma_peak_kernel<1><<<blocks, threads>>>(src, dst, iters);
+        if (mode == 2) mfma_peak_kernel<2><<<blocks, threads>>>(src, dst, iters);
+      };
+      std::vector<float> all;
+      const double ms = time_ms(run, 3, 10, &all);
+      const double flops = (double)blocks * (threads / 64) * iters * (mode == 2 ? 8 : 16) * (mode == 2 ? 32.0 * 32 * 64 * 2 : 16.0 * 16 * 128 * 2);
+      printf("peak mode=%d threads=%d blocks=%d iters=%d: median %.4f ms min %.4f -> %.1f TFLOP/s\n", mode, threads, blocks,
+             iters, ms, all[0], flops / ms / 1e9);
+    }
+    return 0;
+  }
+  if (!strcmp(argv[1], "gemm")) {
+    const int64_t M = atoll(argv[2]), N = atoll(argv[3]), K = atoll(argv[4]);
+    void* a = dev_random_bytes(M * K, 1, true);
+    void* b = dev_random_bytes(N * K, 2, true);
+    float* sa = dev_random_floats(M * (K / 128), 3, 1e-4f, 1e-3f);
+    float* sb = dev_random_floats((K / 128) * ((N + 127) / 128), 4, 1e-4f, 1e-3f);
+    void* out;
+    HIP_CHECK(hipMalloc(&out, M * N * 2));
+    for (int ai = 5; ai < argc || ai == 5; ++ai) {
+      const int var = ai < argc ? atoi(argv[ai]) : 1;
+      sglk_debug_set_gemm_variant(var);
+      std::vector<float> all;
+      auto run = [&] {
+        int rc = sglk_fp8_blockwise_scaled_mm(0, out, a, b, sa, sb, M, N, K, K, K, N, 1, M, 1, K / 128, SGLK_BF16);
+        if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
+      };
+      const double ms = time_ms(run, 10, 50, &all);
+      printf("gemm M=%lld N=%lld K=%lld variant=%d median %.4f ms  min %.4f  -> %.1f TFLOP/s (%.1f at min)\n", (long long)M,
+             (long long)N, (long long)K, var, ms, all[0], 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / all[0] / 1e9);
+      if (ai >= argc) break;
+    }
+    return 0;
+  }
+  if (!strcmp(argv[1], "scaledmm")) {
+    const int64_t M = atoll(argv[2]), N = atoll(argv[3]), K = atoll(argv[4]);
+    void* a = dev_random_bytes(M * K, 1, true);
+    void* b = dev_random_bytes(N * K, 2, true);
+    float* sa = dev_random_floats(M, 3, 1e-4f, 1e-3f);
+    float* sb = dev_random_floats(N, 4, 1e-4f, 1e-3f);
+    void* out;
+    HIP_CHECK(hipMalloc(&out, M * N * 2));
+    for (int dt : {SGLK_FP8_E4M3, SGLK_INT8}) {
+      std::vector<float> all;
+      auto run = [&] {
+        int rc = sglk_scaled_mm(0, out, a, b, sa, sb, nullptr, M, N, K, K, K, N, dt, SGLK_BF16);
+        if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
+      };
+      const double ms = time_ms(run, 10, 50, &all);
+      printf("scaled_mm %s M=%lld N=%lld K=%lld median %.4f ms min %.4f -> %.1f T(FL)OP/s\n", dt == SGLK_INT8 ? "int8" : "fp8",
+             (long long)M, (long long)N, (long long)K, ms, all[0], 2.0 * M * N * K / ms / 1e9);
+    }
+    return 0;
+  }
+  if (!strcmp(argv[1], "mla")) {
+    const int64_t B = atoll(argv[2]), S = atoll(argv[3]), H = atoll(argv[4]);
+    const int64_t page = 64, npages = S / page;
+    void* cache = dev_random_bytes((size_t)B * npages * page * 576 * 2, 5, false);
+    // random bf16 bit patterns can be NaN/Inf: clear the top exponent bit instead -> |x| < 2
+    {
+      const size_t n = (size_t)B * npages * page * 576;
+      std::vector<uint16_t> h(n);
+      std::mt19937 rng(7);
+      for (auto& x : h) x = (uint16_t)(rng() & 0xBFFF);
+      HIP_CHECK(hipMemcpy(cache, h.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    std::vector<uint16_t> hq((size_t)B * H * 576);
+    { std::mt19937 rng(8); for (auto& x : hq) x = (uint16_t)(rng() & 0xBFFF); }
+    void *qn, *qp, *out;
+    HIP_CHECK(hipMalloc(&qn, B * H * 512 * 2));
+    HIP_CHECK(hipMalloc(&qp, B * H * 64 * 2));
+    HIP_CHECK(hipMalloc(&out, B * H * 512 * 2));
+    HIP_CHECK(hipMemcpy(qn, hq.data(), B * H * 512 * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(qp, hq.data() + B * H * 512, B * H * 64 * 2, hipMemcpyHostToDevice));
+    std::vector<int32_t> table(B * npages), lens(B, (int32_t)S);
+    { std::mt19937 rng(9); for (auto& x : table) x = rng() % (B * npages); }
+    int32_t *dt, *dl;
+    HIP_CHECK(hipMalloc(&dt, table.size() * 4));
+    HIP_CHECK(hipMalloc(&dl, B * 4));
+    HIP_CHECK(hipMemcpy(dt, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dl, lens.data(), B * 4, hipMemcpyHostToDevice));
+    for (int ai = 5; ai < argc || ai == 5; ++ai) {
+      const int64_t splits = ai < argc ? atoll(argv[ai]) : -1;
+      const int64_t wsz = sglk_mla_decode_workspace_size(S, B, H, splits);
+      void* ws = nullptr;
+      if (wsz) HIP_CHECK(hipMalloc(&ws, wsz));
+      auto run = [&] {
+        int rc = sglk_flash_mla_decode(0, out, qn, qp, cache, dl, dt, ws, wsz, B, H, page, npages, H * 512, 512, H * 64, 64,
+                                       page * 576, npages, 0.0417f, splits, SGLK_BF16);
+        if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
+      };
+      std::vector<float> all;
+      const double ms = time_ms(run, 5, 20, &all);
+      const double bytes = (double)B * H * 576 * 2 + (double)B * S * 576 * 2 + table.size() * 4 + B * 4 + (double)B * H * 512 * 2;
+      printf("mla B=%lld S=%lld H=%lld splits=%lld median %.4f ms min %.4f -> %.1f GB/s, %.1f TFLOP/s\n", (long long)B,
+             (long long)S, (long long)H, (long long)splits, ms, all[0], bytes / ms / 1e6,
+             2.0 * B * H * S * 1088 / ms / 1e9);
+      if (ws) HIP_CHECK(hipFree(ws));
+      if (ai >= argc) break;
+    }
+    return 0;
+  }
+  return 1;
+}
