@@ -16,6 +16,7 @@ constexpr int kWave = 64;
 // ---- host-side error plumbing (defined in runtime.hip) ----------------------
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int check_launch(const char* what);
+int num_cus();
 
 #define SGLK_REQUIRE(cond, ...)                          \
   do {                                                   \

@@ -378,17 +378,55 @@ __global__ __launch_bounds__(512) void gemm_8bit_kernel(
   }
 }
 
+// buffer resource (raw, 32-bit records) from a wave-uniform pointer and byte count; the readfirstlanes are free when
+// the compiler already knows the values are uniform and keep it from building a waterfall loop when it does not
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t nrec) {
+  const uint64_t u = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// Blockwise kernel, pipelined across K blocks. Same tile, wave layout, LDS image and arithmetic as above; what
-// changes is WHERE the one barrier per K block sits. It is placed between m-steps 6 and 7: by then every wave
-// has read all it needs from the running stage (the last m-fragment is already in registers), and the DMA of
-// the next block, issued in pieces during m-steps 0..2 and the previous block's step 7, has had >1000 cycles
-// to land. Step 7 then overlaps its four MFMAs with the LDS reads of the NEXT block's n-fragments (each into
-// the registers of the n-fragment the MFMA just issued has consumed) and first m-fragment, so the matrix pipe
-// does not drain at the block boundary; the first DMA piece of block kb+2 goes out in the same step.
-// PROBE: 0 = real kernel, 1 = no DMA inside the loop (timing probe, garbage results).
-template <typename OutT, bool VEC_STORE, bool HW_SCALE, int PROBE>
-__global__ __launch_bounds__(512) void gemm_fp8_blockwise_pipe_kernel(
+// Blockwise kernel, persistent and pipelined across K blocks AND tiles. Same tile, wave layout and arithmetic as
+// above. One workgroup per CU walks its tiles (XCD-aware order); the sequence of K blocks of all its tiles is ONE
+// software pipeline:
+//  * the one barrier per K block sits between m-steps 6 and 7: by then every wave has read all it needs from the
+//    running stage (the last m-fragment is in registers) and the DMA of the next block, issued in pieces during
+//    m-steps 0..2 and the previous block's step 7, has had >1000 cycles to land;
+//  * step 7 overlaps its four MFMAs with the LDS reads of the NEXT block's n-fragments (each into the registers
+//    of the n-fragment the MFMA just issued has consumed) and first m-fragment, so the matrix pipe does not drain
+//    at the block boundary; the first DMA pieces of block +2 go out in the same step;
+//  * "next block" crosses tile boundaries: the first block of the next tile is in LDS / in registers before the
+//    running tile ends;
+//  * the epilogue of a tile is folded into the FIRST K block of the next one: m-step s of that block converts and
+//    stores accumulator rows 2s, 2s+1 of the finished tile (s = 0..3) just before it overwrites them with
+//    acc = partial * scale (no zeroing), so the 128 KiB of output per tile drain under MFMAs instead of stalling
+//    all CUs at once.
+// Output ownership: the n-fragment nf of a wave is made of LDS rows (nf>>1)*32 + (nf&1)*4 + (i>>2)*8 + (i&3),
+// i = MFMA row. A lane (m row j, group g) then owns columns g*8..g*8+7 and 32+g*8..32+g*8+7 of its wave's 64:
+// two 16-byte stores per m-fragment, 64 contiguous bytes per row per instruction. The b tile's LDS swizzle key is
+// ((row>>3)&3)<<1 | (row>>1)&1 so that those 16 rows are conflict-free for ds_read_b128.
+// LDS-DMA and the stores go through buffer resources: the per-lane address part is a loop-invariant VGPR,
+// everything that changes (tile, K block, piece) is scalar; rows past the end of a / b / out are out of the
+// resource's range (loads give zeros, stores are dropped); "nothing to do" is a resource with zero records.
+// Every K-block body is ONE basic block (selects, no branches): with branches the optimiser sinks MFMAs across
+// the hand-placed LDS reads and spills.
+// Requires K >= 256, N % 8 == 0, ldc % 8 == 0, out 16-byte aligned (the host uses the kernel above otherwise).
+// PROBE: 0 = real kernel; timing probes with garbage results: 1 = no DMA inside the loop, 2 = no DMA and no
+// stores, 3 = no stores.
+struct TileDesc {
+  const uint8_t* pa;  // a + m0 * lda
+  const uint8_t* pb;  // b + n0 * ldb
+  const float* ps;    // sa + m0 * sa_sm
+  const float* sbw;   // sb + (this wave's 128-column block) * sb_sn
+  void* po;           // out + m0 * ldc + n0
+  uint32_t nrec_a, nrec_b, nrec_s, nrec_o;  // bytes in range of the four resources (0: nothing)
+  int ncols;                                // valid columns of the tile (<= BN)
+};
+
+template <typename OutT, bool HW_SCALE, int PROBE>
+__global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
     int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n) {
@@ -397,84 +435,122 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_pipe_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  const int nkb = K / BK;  // >= 2
+  constexpr bool kDma = PROBE == 0 || PROBE == 3, kStore = PROBE == 0 || PROBE == 1;
 
-  int tile;
-  {
-    const int nt = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GM = 4;
-  const int group = tile / (GM * tiles_n);
-  const int first_m = group * GM;
-  const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-  const int in_group = tile - group * GM * tiles_n;
-  const int tm = first_m + in_group % gsz;
-  const int tn = in_group / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  // ---- this workgroup's tiles: workgroups b, b+8, ... share an XCD; each XCD owns a contiguous run of tiles,
+  // walked in groups of 4 m-tiles so that the 32 tiles in flight on an XCD share a and b panels in its L2
+  const int nt = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int q = nt >> 3, rem = nt & 7;
+  const int run_first = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int run_len = q + (xcd < rem ? 1 : 0);
+  const int nblk_max = (N + 127) / 128 - 1;
+
+  auto describe = [&](int local) -> TileDesc {  // local index inside the XCD's run; >= run_len: the null tile
+    TileDesc d;
+    const bool live = local < run_len;
+    const int tile = run_first + (live ? local : 0);
+    constexpr int GM = 4;
+    const int group = tile / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_group = tile - group * GM * tiles_n;
+    const int tm = __builtin_amdgcn_readfirstlane(first_m + in_group % gsz);
+    const int tn = __builtin_amdgcn_readfirstlane(in_group / gsz);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int rows_a = (M - m0) < BM ? (M - m0) : BM, rows_b = (N - n0) < BN ? (N - n0) : BN;
+    d.ncols = rows_b;
+    d.pa = a + (int64_t)m0 * lda;
+    d.pb = b + (int64_t)n0 * ldb;
+    d.ps = sa + (int64_t)m0 * sa_sm;
+    d.po = (void*)(out + (int64_t)m0 * ldc + n0);
+    d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * lda + K) : 0u;
+    d.nrec_b = live ? (uint32_t)((int64_t)(rows_b - 1) * ldb + K) : 0u;
+    // row scales: waves 0..3 fetch 64 rows each (4 B per lane); waves 4..7 fetch nothing (zeros into the spare KiB)
+    d.nrec_s = (live && wave < 4) ? (uint32_t)(((int64_t)(rows_a - 1) * sa_sm + (int64_t)(nkb - 1) * sa_sk + 1) * 4) : 0u;
+    d.nrec_o = (live && kStore) ? (uint32_t)(((int64_t)(rows_a - 1) * ldc + rows_b) * (int64_t)sizeof(OutT)) : 0u;
+    int nblk = (n0 + wn * 64) >> 7;
+    nblk = nblk < nblk_max ? nblk : nblk_max;
+    d.sbw = sb + (int64_t)nblk * sb_sn;
+    return d;
+  };
+  auto pick = [](bool c, const TileDesc& x, const TileDesc& y) -> TileDesc {  // scalar selects
+    TileDesc d;
+    d.pa = c ? x.pa : y.pa;  d.pb = c ? x.pb : y.pb;  d.ps = c ? x.ps : y.ps;  d.sbw = c ? x.sbw : y.sbw;
+    d.po = c ? x.po : y.po;
+    d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_s = c ? x.nrec_s : y.nrec_s;
+    d.nrec_o = c ? x.nrec_o : y.nrec_o;  d.ncols = c ? x.ncols : y.ncols;
+    return d;
+  };
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
-
-  // ---- LDS-DMA through buffer resources: one buffer_load_dwordx4 ... lds per 1-KiB piece (8 rows x 128 B), the
-  // per-lane part of the address is a loop-invariant VGPR, everything that changes (K block, piece) is scalar.
-  // Rows past the end of a / b are out of the resource's range and arrive as zeros.
-  const int rows_a = M - m0, rows_b = N - n0;  // > 0
-  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a + (int64_t)m0 * lda), 0, (int)(uint32_t)((int64_t)((rows_a < BM ? rows_a : BM) - 1) * lda + K), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(b + (int64_t)n0 * ldb), 0, (int)(uint32_t)((int64_t)((rows_b < BN ? rows_b : BN) - 1) * ldb + K), 0x00020000);
-  // piece p of a tile covers rows 8p..8p+7; lane -> (row 8p + lane/8, 16-byte chunk (lane%8) ^ ((row>>1)&7));
-  // (row>>1)&7 = (4(p&1) + lane/16) & 7, so the per-lane offset only depends on the parity of p
-  uint32_t voff_a[2], voff_b[2];
+  // piece p of a tile covers rows 8p..8p+7; lane -> row 8p + lane/8, 16-byte chunk (lane%8) ^ key(row):
+  //   a: key = (row>>1)&7            = (4(p&1) + lane/16) & 7      -> depends on the parity of p
+  //   b: key = ((row>>3)&3)<<1 | (row>>1)&1 = (p&3)<<1 | (lane/16)&1 -> depends on p&3 (p = 4*wave + ii: on ii)
+  uint32_t voff_a[2], voff_b[4];
 #pragma unroll
-  for (int par = 0; par < 2; ++par) {
-    const int chunk = (lane & 7) ^ ((par * 4 + (lane >> 4)) & 7);
-    voff_a[par] = (uint32_t)(lane >> 3) * (uint32_t)lda + chunk * 16;
-    voff_b[par] = (uint32_t)(lane >> 3) * (uint32_t)ldb + chunk * 16;
-  }
-  // row scales of the tile's 256 rows: waves 0..3 fetch 64 each, 4 B per lane
-  const int srows = rows_a < BM ? rows_a : BM;
-  const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(sa + (int64_t)m0 * sa_sm), 0,
-      (int)(uint32_t)(((int64_t)(srows - 1) * sa_sm + (int64_t)(K / BK - 1) * sa_sk + 1) * 4), 0x00020000);
+  for (int par = 0; par < 2; ++par)
+    voff_a[par] = (uint32_t)(lane >> 3) * (uint32_t)lda + (((lane & 7) ^ ((par * 4 + (lane >> 4)) & 7)) << 4);
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii)
+    voff_b[ii] = (uint32_t)(lane >> 3) * (uint32_t)ldb + (((lane & 7) ^ ((ii << 1) | ((lane >> 4) & 1))) << 4);
   const uint32_t voff_s = (uint32_t)tid * (uint32_t)sa_sm * 4u;
 
-  // a resource with no records: every lane is out of range, the DMA writes zeros and touches no memory. Selecting
-  // it (scalar selects) is how "no further K block" and "this wave fetches no scales" are expressed without
-  // branches: the loop body must stay ONE basic block or the optimiser sinks MFMAs across the hand-placed reads.
-  const __amdgpu_buffer_rsrc_t rsrc_null = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_sw = wave < 4 ? rsrc_s : rsrc_null;
-
-  // DMA part 0..3 of one K block: two pieces each (parts 0,1: rows of a; 2,3: rows of b^T); part 0 also carries
-  // the row scales (waves 4..7: zeros into the stage's spare KiB)
-  auto dma_part = [&](int kb, int s, int part, bool live) {
+  // DMA part 0..3 of K block kb of tile d into stage s: two 1-KiB pieces each (parts 0,1: rows of a; 2,3: rows of
+  // b^T); part 0 also carries the row scales
+  auto dma_part = [&](const TileDesc& d, int kb, int s, int part) {
     char* base = smem + s * kStageBytes;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ii = (part & 1) * 2 + i;
       const int piece = wave * 4 + ii;
       if (part < 2) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rsrc_a : rsrc_null, SGLK_LDS(base + piece * 1024), 16,
-                                                 voff_a[ii & 1], kb * BK + piece * 8 * (int)lda, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pa, d.nrec_a),
+                                                 SGLK_LDS(base + piece * 1024), 16, voff_a[ii & 1],
+                                                 kb * BK + piece * 8 * (int)lda, 0, 0);
       } else {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rsrc_b : rsrc_null, SGLK_LDS(base + kTileBytes + piece * 1024), 16,
-                                                 voff_b[ii & 1], kb * BK + piece * 8 * (int)ldb, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b),
+                                                 SGLK_LDS(base + kTileBytes + piece * 1024), 16, voff_b[ii],
+                                                 kb * BK + piece * 8 * (int)ldb, 0, 0);
       }
     }
     if (part == 0) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? rsrc_sw : rsrc_null, SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4,
-                                               voff_s, kb * (int)sa_sk * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s),
+                                               SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, voff_s,
+                                               kb * (int)sa_sk * 4, 0, 0);
     }
   };
 
   const int j = lane & 15, g = lane >> 4;
-  const int frag_off = j * 128 + ((g ^ ((j >> 1) & 7)) << 4);
-  const int nblk_max = (N + 127) / 128 - 1;
-  int nblk = (n0 + wn * 64) >> 7;
-  nblk = nblk < nblk_max ? nblk : nblk_max;
-  const float* sb_wave = sb + (int64_t)nblk * sb_sn;
+  const int frag_off_a = j * 128 + ((g ^ ((j >> 1) & 7)) << 4);
+  const int frag_off_b = ((j >> 2) * 8 + (j & 3)) * 128 + ((g ^ ((j >> 1) & 7)) << 4);
+  constexpr int kNfImm[4] = {0, 4 * 128, 32 * 128, 36 * 128};  // first LDS row of n-fragment nf, in bytes
   typedef __attribute__((address_space(3))) const float* lds_f_ptr;
+
+  // stores: lane (j, g) owns row wm*128 + mf*16 + j, columns wn*64 + h*32 + g*8 .. +7 (h = 0, 1) of the tile
+  const uint32_t orow_off = (uint32_t)(((int64_t)(wm * 128 + j) * ldc + wn * 64 + g * 8) * (int64_t)sizeof(OutT));
+  auto store_rows = [&](const TileDesc& d, const v4f (&accm)[4], int mf) {
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
+    const int soff = __builtin_amdgcn_readfirstlane(mf * 16 * (int)ldc * (int)sizeof(OutT));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      Vec<OutT, 8> v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = (OutT)accm[2 * h][r];
+        v[4 + r] = (OutT)accm[2 * h + 1][r];
+      }
+      // a column past the tile's valid ones would land in the next row: push those lanes out of range instead
+      const uint32_t vo = (wn * 64 + h * 32 + g * 8 < d.ncols) ? orow_off + h * 32 * (uint32_t)sizeof(OutT) : 0x80000000u;
+      const v4i data = __builtin_bit_cast(v4i, v);
+      __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, 0);
+      // gfx950 reads the 16 bytes of store data for a few cycles after issue; the compiler assumes the form with
+      // a scalar offset register has no such hazard and lets the next VALU op overwrite the registers (seen:
+      // dword 1 of lanes 12-15 of each row corrupted). Keep them alive across a short nop.
+      asm volatile("s_nop 4" ::"v"(data));
+    }
+  };
 
   v4f acc[8][4];
 #pragma unroll
@@ -483,52 +559,25 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_pipe_kernel(
     for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   // LDS reads of the main loop are inline asm: their order relative to the MFMAs is the point of this kernel and
-  // the optimiser is free to hoist plain loads (it then keeps seven m-fragments live and spills). The waits are
-  // therefore counted by hand; every wait names the registers it releases so that their consumers stay below it.
+  // the optimiser is free to hoist plain loads. The waits are therefore counted by hand; every wait names the
+  // registers it releases so that their consumers stay below it.
 #define SGLK_RD16(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define SGLK_RD4(dst, addr, imm) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define SGLK_FRAG(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
 
-  const int nkb = K / BK;
   v4i nlo[4], nhi[4], mlo[2], mhi[2];
   float raw[2];
-  // ---- prologue: block 0 lands, its resident fragments are read, part 0 of block 1 goes out
-#pragma unroll
-  for (int part = 0; part < 4; ++part) dma_part(0, 0, part, true);
-  float sbv = sb_wave[0];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  asm volatile("" : "+v"(sbv));
-  {
-    const uint32_t b_lo = lds_base + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)frag_off, b_hi = b_lo ^ 64u;
-    const uint32_t a_lo = lds_base + (uint32_t)(wm * 128 * 128) + (uint32_t)frag_off, a_hi = a_lo ^ 64u;
-    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)(j << 2);
-    SGLK_RD16(nlo[0], b_lo, 0);     SGLK_RD16(nhi[0], b_hi, 0);
-    SGLK_RD16(mlo[0], a_lo, 0);     SGLK_RD16(mhi[0], a_hi, 0);
-    SGLK_RD4(raw[0], ts0, 0);
-    SGLK_RD16(nlo[1], b_lo, 2048);  SGLK_RD16(nhi[1], b_hi, 2048);
-    SGLK_RD16(nlo[2], b_lo, 4096);  SGLK_RD16(nhi[2], b_hi, 4096);
-    SGLK_RD16(nlo[3], b_lo, 6144);  SGLK_RD16(nhi[3], b_hi, 6144);
-  }
-  if (PROBE == 0) dma_part(1, 1, 0, nkb > 1);
+  float sbv;
+  int gblk = 0;  // K blocks done so far by this workgroup: its parity is the running LDS stage
 
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int s = kb & 1;
-    const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);
-    const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStageBytes);
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    const bool more = kb + 1 < nkb;
-    {
-      int fo = frag_off;
-      asm volatile("" : "+v"(fo));
-      const uint32_t a_lo = sbase + (uint32_t)(wm * 128 * 128) + (uint32_t)fo, a_hi = a_lo ^ 64u;
-      const uint32_t ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((fo >> 7) << 2);
-
-#define SGLK_STEP(mf)                                                                                          \
+  // One K block. d1/kb1, d2/kb2: blocks +1 and +2 of the pipeline. FIRST: first block of a tile (stores tile
+  // `prv`, restarts the accumulators).
+#define SGLK_STEP(mf, FIRST)                                                                                   \
   {                                                                                                            \
     SGLK_RD16(mlo[((mf) + 1) & 1], a_lo, ((mf) + 1) * 2048);                                                   \
     SGLK_RD16(mhi[((mf) + 1) & 1], a_hi, ((mf) + 1) * 2048);                                                   \
     SGLK_RD4(raw[((mf) + 1) & 1], ts_addr, ((mf) + 1) * 64);                                                   \
-    if (PROBE == 0 && (mf) < 3) dma_part(kb + 1, s ^ 1, (mf) + 1, more);                                       \
+    if (kDma && (mf) < 3) dma_part(d1, kb1, s ^ 1, (mf) + 1);                                                  \
     if ((mf) == 0) {                                                                                           \
       asm volatile("s_waitcnt lgkmcnt(3)"                                                                      \
                    : "+v"(nlo[0]), "+v"(nhi[0]), "+v"(nlo[1]), "+v"(nhi[1]), "+v"(nlo[2]), "+v"(nhi[2]),       \
@@ -538,88 +587,118 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_pipe_kernel(
     }                                                                                                          \
     const float sc = raw[(mf) & 1] * sbv;                                                                      \
     const v8i mfrag = SGLK_FRAG(mlo[(mf) & 1], mhi[(mf) & 1]);                                                 \
-    v4f cur[4];                                                                                                \
+    v4f cur4[4];                                                                                               \
     _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
-        cur[nf] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[nf], nhi[nf]), mfrag, zero);                               \
+        cur4[nf] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[nf], nhi[nf]), mfrag, zero);                              \
+    if (FIRST && (mf) < 4) {                                                                                   \
+      store_rows(prv, acc[2 * (mf)], 2 * (mf));                                                                \
+      store_rows(prv, acc[2 * (mf) + 1], 2 * (mf) + 1);                                                        \
+    }                                                                                                          \
     _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
-            acc[mf][nf][r] = __builtin_fmaf(cur[nf][r], sc, acc[mf][nf][r]);                                   \
+            acc[mf][nf][r] = FIRST ? cur4[nf][r] * sc : __builtin_fmaf(cur4[nf][r], sc, acc[mf][nf][r]);       \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
-      SGLK_STEP(0) SGLK_STEP(1) SGLK_STEP(2) SGLK_STEP(3) SGLK_STEP(4) SGLK_STEP(5) SGLK_STEP(6)
-#undef SGLK_STEP
-    }
-
-    // ---- the block's barrier: next block landed everywhere, nobody reads stage s any more
-    float sbv_next = sb_wave[(int64_t)(more ? kb + 1 : kb) * sb_sk];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
-                 : "+v"(mlo[1]), "+v"(mhi[1]), "+v"(raw[1])
-                 :
-                 : "memory");
-    asm volatile("" : "+v"(sbv_next));
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- m-step 7, overlapped with the next block's first LDS reads
-    {
-      const float sc = raw[1] * sbv;
-      int fo2 = frag_off;
-      asm volatile("" : "+v"(fo2));
-      const uint32_t nb_lo = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fo2, nb_hi = nb_lo ^ 64u;
-      const uint32_t na_lo = nbase + (uint32_t)(wm * 128 * 128) + (uint32_t)fo2, na_hi = na_lo ^ 64u;
-      const uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((fo2 >> 7) << 2);
-      const v8i mfrag = SGLK_FRAG(mlo[1], mhi[1]);
-      v4f cur[4];
-      cur[0] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[0], nhi[0]), mfrag, zero);
-      __builtin_amdgcn_sched_barrier(0);
-      SGLK_RD16(nlo[0], nb_lo, 0);     SGLK_RD16(nhi[0], nb_hi, 0);
-      SGLK_RD16(mlo[0], na_lo, 0);     SGLK_RD16(mhi[0], na_hi, 0);
-      SGLK_RD4(raw[0], nts, 0);
-      cur[1] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[1], nhi[1]), mfrag, zero);
-      __builtin_amdgcn_sched_barrier(0);
-      SGLK_RD16(nlo[1], nb_lo, 2048);  SGLK_RD16(nhi[1], nb_hi, 2048);
-      if (PROBE == 0) dma_part(kb + 2, s, 0, kb + 2 < nkb);
-      cur[2] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[2], nhi[2]), mfrag, zero);
-      __builtin_amdgcn_sched_barrier(0);
-      SGLK_RD16(nlo[2], nb_lo, 4096);  SGLK_RD16(nhi[2], nb_hi, 4096);
-      cur[3] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[3], nhi[3]), mfrag, zero);
-      __builtin_amdgcn_sched_barrier(0);
-      SGLK_RD16(nlo[3], nb_lo, 6144);  SGLK_RD16(nhi[3], nb_hi, 6144);
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[7][nf][r] = __builtin_fmaf(cur[nf][r], sc, acc[7][nf][r]);
-      sbv = sbv_next;
-      __builtin_amdgcn_sched_barrier(0);
-    }
+#define SGLK_BLOCK(FIRST)                                                                                      \
+  {                                                                                                            \
+    const int s = gblk & 1;                                                                                    \
+    const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);                                             \
+    const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStageBytes);                                       \
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};                                                                     \
+    const bool in1 = kb + 1 < nkb, in2 = kb + 2 < nkb;                                                         \
+    const TileDesc d1 = pick(in1, cur, nxt), d2 = pick(in2, cur, nxt);                                         \
+    const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
+    {                                                                                                          \
+      int fo = frag_off_a;                                                                                     \
+      asm volatile("" : "+v"(fo));                                                                             \
+      const uint32_t a_lo = sbase + (uint32_t)(wm * 128 * 128) + (uint32_t)fo, a_hi = a_lo ^ 64u;              \
+      const uint32_t ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((fo >> 7) << 2); \
+      SGLK_STEP(0, FIRST) SGLK_STEP(1, FIRST) SGLK_STEP(2, FIRST) SGLK_STEP(3, FIRST)                          \
+      SGLK_STEP(4, FIRST) SGLK_STEP(5, FIRST) SGLK_STEP(6, FIRST)                                              \
+    }                                                                                                          \
+    /* the block's barrier: next block landed everywhere, nobody reads stage s any more */                    \
+    float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                  \
+                 : "+v"(mlo[1]), "+v"(mhi[1]), "+v"(raw[1])                                                    \
+                 :                                                                                             \
+                 : "memory");                                                                                  \
+    asm volatile("" : "+v"(sbv_next));                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    /* m-step 7, overlapped with the next block's first LDS reads */                                          \
+    {                                                                                                          \
+      const float sc = raw[1] * sbv;                                                                           \
+      int foa = frag_off_a, fob = frag_off_b;                                                                  \
+      asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
+      const uint32_t nb_lo = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fob, nb_hi = nb_lo ^ 64u; \
+      const uint32_t na_lo = nbase + (uint32_t)(wm * 128 * 128) + (uint32_t)foa, na_hi = na_lo ^ 64u;          \
+      const uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((foa >> 7) << 2);    \
+      const v8i mfrag = SGLK_FRAG(mlo[1], mhi[1]);                                                             \
+      v4f cur4[4];                                                                                             \
+      cur4[0] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[0], nhi[0]), mfrag, zero);                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      SGLK_RD16(nlo[0], nb_lo, kNfImm[0]);  SGLK_RD16(nhi[0], nb_hi, kNfImm[0]);                               \
+      SGLK_RD16(mlo[0], na_lo, 0);          SGLK_RD16(mhi[0], na_hi, 0);                                       \
+      SGLK_RD4(raw[0], nts, 0);                                                                                \
+      cur4[1] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[1], nhi[1]), mfrag, zero);                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      SGLK_RD16(nlo[1], nb_lo, kNfImm[1]);  SGLK_RD16(nhi[1], nb_hi, kNfImm[1]);                               \
+      if (kDma) dma_part(d2, kb2, s, 0);                                                                       \
+      cur4[2] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[2], nhi[2]), mfrag, zero);                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      SGLK_RD16(nlo[2], nb_lo, kNfImm[2]);  SGLK_RD16(nhi[2], nb_hi, kNfImm[2]);                               \
+      cur4[3] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[3], nhi[3]), mfrag, zero);                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      SGLK_RD16(nlo[3], nb_lo, kNfImm[3]);  SGLK_RD16(nhi[3], nb_hi, kNfImm[3]);                               \
+      _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                         \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                        \
+              acc[7][nf][r] = FIRST ? cur4[nf][r] * sc : __builtin_fmaf(cur4[nf][r], sc, acc[7][nf][r]);       \
+      sbv = sbv_next;                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+    ++gblk;                                                                                                    \
   }
-  // the reads issued by the last step 7 have no consumer: drain them before the registers are reused
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  int local = slot;
+  TileDesc cur = describe(local);
+  TileDesc prv = describe(run_len);  // the null tile: nothing to store yet
+  // ---- prologue: block 0 of the first tile lands, its resident fragments are read, part 0 of block 1 goes out
+#pragma unroll
+  for (int part = 0; part < 4; ++part) dma_part(cur, 0, 0, part);
+  sbv = cur.sbw[0];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("" : "+v"(sbv));
+  {
+    const uint32_t b_lo = lds_base + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)frag_off_b, b_hi = b_lo ^ 64u;
+    const uint32_t a_lo = lds_base + (uint32_t)(wm * 128 * 128) + (uint32_t)frag_off_a, a_hi = a_lo ^ 64u;
+    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)(j << 2);
+    SGLK_RD16(nlo[0], b_lo, kNfImm[0]);  SGLK_RD16(nhi[0], b_hi, kNfImm[0]);
+    SGLK_RD16(mlo[0], a_lo, 0);          SGLK_RD16(mhi[0], a_hi, 0);
+    SGLK_RD4(raw[0], ts0, 0);
+    SGLK_RD16(nlo[1], b_lo, kNfImm[1]);  SGLK_RD16(nhi[1], b_hi, kNfImm[1]);
+    SGLK_RD16(nlo[2], b_lo, kNfImm[2]);  SGLK_RD16(nhi[2], b_hi, kNfImm[2]);
+    SGLK_RD16(nlo[3], b_lo, kNfImm[3]);  SGLK_RD16(nhi[3], b_hi, kNfImm[3]);
+  }
+  if (kDma) dma_part(cur, 1, 1, 0);
+
+  for (; local < run_len; local += slots) {
+    const TileDesc nxt = describe(local + slots);
+    {
+      const int kb = 0;
+      SGLK_BLOCK(true)
+    }
+    for (int kb = 1; kb < nkb; ++kb) SGLK_BLOCK(false)
+    prv = cur;
+    cur = nxt;
+  }
+#undef SGLK_BLOCK
+#undef SGLK_STEP
+  // the reads and DMA issued by the last step 7 have no consumer: drain them, then store the last tile
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int mf = 0; mf < 8; ++mf) store_rows(prv, acc[mf], mf);
 #undef SGLK_RD16
 #undef SGLK_RD4
 #undef SGLK_FRAG
-
-#pragma unroll
-  for (int mf = 0; mf < 8; ++mf) {
-    const int m = m0 + wm * 128 + mf * 16 + j;
-    if (m >= M) continue;
-    OutT* orow = out + (int64_t)m * ldc;
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      const int n = n0 + wn * 64 + nf * 16 + g * 4;
-      if constexpr (VEC_STORE) {
-        if (n < N) {
-          Vec<OutT, 4> vv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) vv[r] = (OutT)acc[mf][nf][r];
-          store_vec<OutT, 4>(orow + n, vv);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < N) orow[n + r] = (OutT)acc[mf][nf][r];
-      }
-    }
-  }
 }
 
 static int g_gemm_variant = 4;  // 4 = pipelined kernel (default); 0, 1 = earlier main loops; 8, 9, 14 = timing probes
@@ -631,22 +710,28 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
   const unsigned grid = (unsigned)(tiles_m * tiles_n);
   const bool vec = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)out % 8 == 0);
+  // persistent kernel: one workgroup per CU, a multiple of 8 so that every XCD gets the same number
+  const unsigned pgrid = grid < (unsigned)num_cus() ? ((grid + 7) / 8) * 8 : (unsigned)num_cus();
+  const bool persist_ok = K / BK >= 2 && N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)out % 16 == 0 && ldc < (1ll << 22);
+  const int variant = (!persist_ok && g_gemm_variant != 0 && g_gemm_variant != 1) ? 1 : g_gemm_variant;
 #define SGLK_GO_VAR(V, H, VAR)                                                                               \
   gemm_8bit_kernel<OutT, MODE, V, H, VAR><<<grid, 512, 0, st>>>(                                             \
       (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K,   \
       lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
 #define SGLK_GO_PIPE(V, H, P)                                                                                \
-  gemm_fp8_blockwise_pipe_kernel<OutT, V, H, P><<<grid, 512, 0, st>>>(                                       \
+  gemm_fp8_blockwise_persist_kernel<OutT, H, P><<<pgrid, 512, 0, st>>>(                                   \
       (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,       \
       sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
 #define SGLK_GO(V, H)                                                                                        \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
-    switch (g_gemm_variant) {                                                                                \
+    switch (variant) {                                                                                       \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
       case 9: SGLK_GO_VAR(V, H, 9); break;                                                                   \
       case 14: SGLK_GO_PIPE(V, H, 1); break;                                                                 \
+      case 15: SGLK_GO_PIPE(V, H, 2); break;                                                                 \
+      case 16: SGLK_GO_PIPE(V, H, 3); break;                                                                 \
       default: SGLK_GO_PIPE(V, H, 0); break;                                                                 \
     }                                                                                                        \
   } else {                                                                                                   \

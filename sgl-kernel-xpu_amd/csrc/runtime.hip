@@ -22,6 +22,19 @@ int check_launch(const char* what) {
   return SGLK_OK;
 }
 
+// Compute units of the current device (cached per device id); 256 on MI355X.
+int num_cus() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 }  // namespace sglk
 
 extern "C" {

@@ -126,8 +126,44 @@ __global__ __launch_bounds__(512) void mfma_peak_kernel(const int* __restrict__ 
   }
 }
 
+// ---- does the raw-buffer range check of buffer_load ... lds include the scalar offset? (expects zeros past the end)
+__global__ void oob_probe_kernel(const uint8_t* __restrict__ src, int nrec, int soff, int use_voff, uint32_t* out) {
+  __shared__ __attribute__((aligned(256))) uint32_t lds[256];
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nrec, 0x00020000);
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256; i += 64) lds[i] = 0xdeadbeefu;
+  __syncthreads();
+  if (use_voff)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, lane * 16 + soff, 0, 0, 0);
+  else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, lane * 16, soff, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = lane; i < 256; i += 64) out[i] = lds[i];
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 1;
+  if (!strcmp(argv[1], "oob")) {
+    uint8_t* src; uint32_t* out;
+    HIP_CHECK(hipMalloc(&src, 8192)); HIP_CHECK(hipMemset(src, 0x11, 8192));
+    HIP_CHECK(hipMalloc(&out, 1024));
+    for (int use_voff = 0; use_voff < 2; ++use_voff) {
+      oob_probe_kernel<<<1, 64>>>(src, 4096, 4096 - 512, use_voff, out);
+      uint32_t h[256];
+      HIP_CHECK(hipMemcpy(h, out, 1024, hipMemcpyDeviceToHost));
+      int in_ok = 0, out_zero = 0, out_data = 0, out_other = 0;
+      for (int l = 0; l < 64; ++l)
+        for (int d = 0; d < 4; ++d) {
+          uint32_t v = h[l * 4 + d];
+          if (l < 32) in_ok += (v == 0x11111111u);
+          else { out_zero += (v == 0); out_data += (v == 0x11111111u); out_other += (v != 0 && v != 0x11111111u); }
+        }
+      printf("oob probe (%s carries the offset): in-range ok %d/128, past-the-end: zero %d data %d other %d of 128\n",
+             use_voff ? "voffset" : "soffset", in_ok, out_zero, out_data, out_other);
+    }
+    return 0;
+  }
   if (!strcmp(argv[1], "peak")) {  // kbench peak THREADS BLOCKS ITERS
     const int threads = atoi(argv[2]), blocks = atoi(argv[3]), iters = atoi(argv[4]);
     int* src = (int*)dev_random_bytes(16384 * 4, 9, true);
