@@ -45,6 +45,19 @@ def make_inputs(dev, seed):
     return x, b, sb, q, s
 
 
+def pmc_traffic_bytes():
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/gpu_profile.sh ->
+    profiles/r01/bench_fp8_gemm_v2_pmc.json): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B
+    requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section) and is doubled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "bench_fp8_gemm_v2_pmc.json")) as f:
+            pmc = json.load(f)
+        k = next(v for name, v in pmc.items() if "gemm_fp8_blockwise_persist_kernel" in name)
+        return int((2 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024)
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds_budget=20.0):
     """CPU oracle on a bounded row sample of the same workload (same N, K; fewer rows)."""
     from oracle import gemm as ogemm
@@ -214,12 +227,12 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "gemm_8bit_kernel<bf16, blockwise>",
+            "kernel": "gemm_fp8_blockwise_persist_kernel<bf16>",
             "achieved": round(achieved, 2),
             "peak": PEAK_FP8_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP8_TFLOPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic_bytes(),
             "kernel_ms_avg": round(gemm_avg_ms, 4),
             "kernel_ms_median": round(gemm_ms[len(gemm_ms) // 2], 4),
         },

@@ -414,7 +414,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 // the hand-placed LDS reads and spills.
 // Requires K >= 256, N % 8 == 0, ldc % 8 == 0, out 16-byte aligned (the host uses the kernel above otherwise).
 // PROBE: 0 = real kernel; timing probes with garbage results: 1 = no DMA inside the loop, 2 = no DMA and no
-// stores, 3 = no stores.
+// stores, 3 = no stores, 4 = no stores and every DMA re-fetches K block 0 (L2 hits).
 struct TileDesc {
   const uint8_t* pa;  // a + m0 * lda
   const uint8_t* pb;  // b + n0 * ldb
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nkb = K / BK;  // >= 2
-  constexpr bool kDma = PROBE == 0 || PROBE == 3, kStore = PROBE == 0 || PROBE == 1;
+  constexpr bool kDma = PROBE == 0 || PROBE == 3 || PROBE == 4, kStore = PROBE == 0 || PROBE == 1;
 
   // ---- this workgroup's tiles: workgroups b, b+8, ... share an XCD; each XCD owns a contiguous run of tiles,
   // walked in groups of 4 m-tiles so that the 32 tiles in flight on an XCD share a and b panels in its L2
@@ -499,7 +499,8 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
 
   // DMA part 0..3 of K block kb of tile d into stage s: two 1-KiB pieces each (parts 0,1: rows of a; 2,3: rows of
   // b^T); part 0 also carries the row scales
-  auto dma_part = [&](const TileDesc& d, int kb, int s, int part) {
+  auto dma_part = [&](const TileDesc& d, int kb_, int s, int part) {
+    const int kb = PROBE == 4 ? 0 : kb_;  // probe 4: every block re-fetches block 0 (L2 hits, no stores)
     char* base = smem + s * kStageBytes;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     SGLK_RD16(mlo[((mf) + 1) & 1], a_lo, ((mf) + 1) * 2048);                                                   \
     SGLK_RD16(mhi[((mf) + 1) & 1], a_hi, ((mf) + 1) * 2048);                                                   \
     SGLK_RD4(raw[((mf) + 1) & 1], ts_addr, ((mf) + 1) * 64);                                                   \
-    if (kDma && (mf) < 3) dma_part(d1, kb1, s ^ 1, (mf) + 1);                                                  \
+    if (kDma && (mf) < 2) dma_part(d1, kb1, s ^ 1, (mf) + 2);                                                  \
     if ((mf) == 0) {                                                                                           \
       asm volatile("s_waitcnt lgkmcnt(3)"                                                                      \
                    : "+v"(nlo[0]), "+v"(nhi[0]), "+v"(nlo[1]), "+v"(nhi[1]), "+v"(nlo[2]), "+v"(nhi[2]),       \
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
       cur4[2] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[2], nhi[2]), mfrag, zero);                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       SGLK_RD16(nlo[2], nb_lo, kNfImm[2]);  SGLK_RD16(nhi[2], nb_hi, kNfImm[2]);                               \
+      if (kDma) dma_part(d2, kb2, s, 1);                                                                       \
       cur4[3] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[3], nhi[3]), mfrag, zero);                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       SGLK_RD16(nlo[3], nb_lo, kNfImm[3]);  SGLK_RD16(nhi[3], nb_hi, kNfImm[3]);                               \
@@ -678,7 +680,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     SGLK_RD16(nlo[2], b_lo, kNfImm[2]);  SGLK_RD16(nhi[2], b_hi, kNfImm[2]);
     SGLK_RD16(nlo[3], b_lo, kNfImm[3]);  SGLK_RD16(nhi[3], b_hi, kNfImm[3]);
   }
-  if (kDma) dma_part(cur, 1, 1, 0);
+  if (kDma) {
+    dma_part(cur, 1, 1, 0);
+    dma_part(cur, 1, 1, 1);
+  }
 
   for (; local < run_len; local += slots) {
     const TileDesc nxt = describe(local + slots);
@@ -732,6 +737,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 14: SGLK_GO_PIPE(V, H, 1); break;                                                                 \
       case 15: SGLK_GO_PIPE(V, H, 2); break;                                                                 \
       case 16: SGLK_GO_PIPE(V, H, 3); break;                                                                 \
+      case 17: SGLK_GO_PIPE(V, H, 4); break;                                                                 \
       default: SGLK_GO_PIPE(V, H, 0); break;                                                                 \
     }                                                                                                        \
   } else {                                                                                                   \

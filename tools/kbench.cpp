@@ -199,7 +199,7 @@ int main(int argc, char** argv) {
         int rc = sglk_fp8_blockwise_scaled_mm(0, out, a, b, sa, sb, M, N, K, K, K, N, 1, M, 1, K / 128, SGLK_BF16);
         if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
       };
-      const double ms = time_ms(run, 10, 50, &all);
+      const double ms = time_ms(run, 300, 100, &all);  // long warm-up: clocks ramp for tens of ms
       printf("gemm M=%lld N=%lld K=%lld variant=%d median %.4f ms  min %.4f  -> %.1f TFLOP/s (%.1f at min)\n", (long long)M,
              (long long)N, (long long)K, var, ms, all[0], 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / all[0] / 1e9);
       if (ai >= argc) break;
