@@ -27,6 +27,12 @@
 //     32-lane half reads transposed are 8 rows apart.
 //   - split-KV: grid = (splits, batch); partial O (normalised, fp32) and log2-sum-exp go to the
 //     caller's workspace and a small second kernel merges them.
+//   - Fewer than 128 heads (template W = waves per 16-head group = 8, 4, 2 for H <= 16, 32, 64): the W waves of
+//     a group share the work of every tile instead of idling. Each takes every W-th 32-deep k-step of QK^T and
+//     leaves its partial S^T in LDS; after a second barrier every wave of the group adds the W partials in a
+//     fixed order (all get the same bits), runs the same softmax, and accumulates only its 512/W output columns
+//     of P.V. Per wave and tile that is 18/W + 32/W MFMA steps instead of 68, which keeps a 16-head decode on
+//     the HBM roofline instead of on one wave's issue rate. (The partials take the CU's last 16 KiB of LDS next to the 4-stage ring.)
 #include <math.h>
 
 #include "common.h"
@@ -47,10 +53,15 @@ constexpr int kTile = 32;              // kv tokens per tile
 constexpr int kMainBytes = kTile * 1024;
 constexpr int kRopeBytes = kTile * 128;
 constexpr int kStageBytes = kMainBytes + kRopeBytes;  // 36 KiB
-constexpr int kStages = 4;
-constexpr int kXchgOff = kStages * kStageBytes;       // 8 waves x 16 floats
-constexpr int kLdsBytes = kXchgOff + 8 * 16 * 4;
 constexpr int kThreads = 512;
+template <int W>
+struct Cfg {
+  static constexpr int kStages = 4;
+  static constexpr int kPartOff = kStages * kStageBytes;  // W > 1: 8 waves x [2 token tiles][64 lanes][16 B]
+  static constexpr int kLdsBytes = kPartOff + (W == 1 ? 0 : 8 * 2048);  // W > 1: exactly the CU's 160 KiB
+  static constexpr int kNT = 32 / W;                       // 16-column output tiles per wave
+  static constexpr int kKS = (18 + W - 1) / W;             // QK^T k-steps per wave
+};
 
 #define SGLK_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define SGLK_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -91,13 +102,14 @@ struct MlaParams {
   int64_t page_stride_bytes;
   int64_t table_stride;
   int H, page_shift, splits;
+  int probe;  // timing probe: 1 = stream the cache through LDS, compute nothing (garbage results)
   float scale_log2;
 };
 
 // q_nope [B,H,512] / q_pe [B,H,64] (strides in p), cache [pages, PAGE, 576], seq_lens [B], page_table
 // [B, table_stride]: read-only for the whole launch (__restrict__ lets the page lookups be scalar loads,
 // which keeps them off the vmcnt counter the LDS-DMA ring is timed with).
-template <typename T>
+template <typename T, int W>
 __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, const T* __restrict__ q_nope,
                                                                  const T* __restrict__ q_pe,
                                                                  const char* __restrict__ cache,
@@ -105,14 +117,17 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
                                                                  const int32_t* __restrict__ page_table) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   using M = Mfma<T>;
+  using C = Cfg<W>;
+  constexpr int kStages = C::kStages, kNT = C::kNT, kKS = C::kKS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hg = wave / W, ww = wave % W;  // head group, position inside the group
   const int split = blockIdx.x, b = blockIdx.y;
   const int H = p.H;
   const int ngroups = (H + 15) >> 4;
-  const bool active = wave < ngroups;
+  const bool active = hg < ngroups && p.probe != 1;
   const int l15 = lane & 15, g = lane >> 4;
 
   const int seq = seq_lens[b];
@@ -157,16 +172,16 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
 
   if (t_begin >= t_end) {
     // nothing to do for this split (or an empty sequence)
-    if (active) {
+    if (active && ww == 0) {
       for (int i = lane; i < 16 * kLatent; i += 64) {
-        const int head = wave * 16 + i / kLatent, d = i % kLatent;
+        const int head = hg * 16 + i / kLatent, d = i % kLatent;
         if (head < H) {
           if (p.splits == 1) ((T*)p.out)[((int64_t)b * H + head) * kLatent + d] = (T)0.f;
           else p.ws_o[(((int64_t)b * p.splits + split) * H + head) * kLatent + d] = 0.f;
         }
       }
-      if (p.splits > 1 && lane < 16 && wave * 16 + lane < H)
-        p.ws_lse[((int64_t)b * p.splits + split) * H + wave * 16 + lane] = -INFINITY;
+      if (p.splits > 1 && lane < 16 && hg * 16 + lane < H)
+        p.ws_lse[((int64_t)b * p.splits + split) * H + hg * 16 + lane] = -INFINITY;
     }
     return;
   }
@@ -175,22 +190,21 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
   const int pig = (0x2130 >> (4 * g)) & 3;  // pi = (0,3,1,2)
 
   // ---- Q^T fragments (MFMA B operand): lane (head l15, group g) holds q[head][32 ks + 8 pi(g) .. +7]
-  v8s qf[18];
+  // wave ww of a group takes k-steps ww, ww + W, ... (< 18; steps 16, 17 are the rope columns)
+  v8s qf[kKS];
   {
-    const int head = wave * 16 + l15;
+    const int head = hg * 16 + l15;
     const bool ok = active && head < H;
     const T* qn = q_nope + (int64_t)b * p.qn_sb + (int64_t)(ok ? head : 0) * p.qn_sh + 8 * pig;
     const T* qp = q_pe + (int64_t)b * p.qp_sb + (int64_t)(ok ? head : 0) * p.qp_sh + 8 * pig;
     const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const v8s v = *reinterpret_cast<const v8s*>(qn + 32 * ks);
-      qf[ks] = ok ? v : zero;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const v8s v = *reinterpret_cast<const v8s*>(qp + 32 * ks);
-      qf[16 + ks] = ok ? v : zero;
+    for (int jk = 0; jk < kKS; ++jk) {
+      const int ks = ww + jk * W;
+      const int kc = ks < 18 ? ks : 17;
+      const T* src = kc < 16 ? qn + 32 * kc : qp + 32 * (kc - 16);
+      const v8s v = *reinterpret_cast<const v8s*>(src);
+      qf[jk] = (ok && ks < 18) ? v : zero;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q is in registers before any LDS-DMA is counted
@@ -212,50 +226,123 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
     vbase0 = 256 * r + 16 * ((pp >> 1) ^ sw_main(r)) + 8 * (pp & 1);
   }
 
-  v4f o[32];
+  // W > 1: LDS offsets of this wave's k-steps (loop invariant) and of its first output tile
+  int koff[kKS], kdelta[kKS];
 #pragma unroll
-  for (int nt = 0; nt < 32; ++nt) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int jk = 0; jk < kKS; ++jk) {
+    const int ks = ww + jk * W;
+    const int kc = ks < 18 ? ks : 17;
+    koff[jk] = kc < 16 ? (kc >> 2) * 8192 + (kbase ^ ((kc & 3) << 6)) : (rbase ^ ((kc - 16) << 6));
+    kdelta[jk] = kc < 16 ? 4096 : 2048;  // second 16-token tile
+  }
+  const int g0 = ww * kNT;                                          // first output tile of this wave
+  const int vxor_w = vbase0 ^ ((g0 & 7) << 5), vadd_w = (g0 >> 3) * 8192;
+
+  v4f o[kNT];
+#pragma unroll
+  for (int nt = 0; nt < kNT; ++nt) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY;  // running max of the raw logits of head l15 (all four lane groups agree)
   float l_run = 0.f;        // running sum over this lane's own tokens
-  float* xch = reinterpret_cast<float*>(smem + kXchgOff) + wave * 16;
+  // value held by the lane of head 4g + r (same lane group): per-head factors for the O rows this lane owns
+  auto head_bcast = [&](float v, int r) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane & 48) | (4 * g + r)) << 2, __builtin_bit_cast(int, v)));
+  };
   const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
 
-  // ---- prologue: three tiles in flight
+  // ---- prologue: kStages - 1 tiles in flight
   const int n_my = t_end - t_begin;
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < kStages - 1; ++i)
     if (i < n_my) stage_tile(t_begin + i, i);
 
+  int st = 0;
   for (int i = 0; i < n_my; ++i) {
     const int t = t_begin + i;
-    const int st = i & 3;
-    const int rem = n_my - 1 - i;  // tiles after this one (at most two of them are already in flight)
+    const int rem = n_my - 1 - i;  // tiles after this one (at most kStages - 2 of them are already in flight)
     if (wave < 4) {
-      if (rem >= 2) wait_vmcnt<10>(); else if (rem == 1) wait_vmcnt<5>(); else wait_vmcnt<0>();
+      if (kStages == 4 && rem >= 2) wait_vmcnt<10>(); else if (rem >= 1) wait_vmcnt<5>(); else wait_vmcnt<0>();
     } else {
-      if (rem >= 2) wait_vmcnt<8>(); else if (rem == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+      if (kStages == 4 && rem >= 2) wait_vmcnt<8>(); else if (rem >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done with tile t-1
-    if (i + 3 < n_my) stage_tile(t + 3, (i + 3) & 3);
-
+    {
+      const int st_next = st == 0 ? kStages - 1 : st - 1;  // the stage tile t-1 used
+      if (i + kStages - 1 < n_my) stage_tile(t + kStages - 1, st_next);
+    }
+    const char* base = smem + st * kStageBytes;
+    v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (W == 1) {
+      if (active) {
+        // ---- S^T[token, head] = K . Q^T for the two 16-token tiles
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const v8s a0 = *reinterpret_cast<const v8s*>(base + (ks >> 2) * 8192 + (kbase ^ ((ks & 3) << 6)));
+          const v8s a1 = *reinterpret_cast<const v8s*>(base + (ks >> 2) * 8192 + 4096 + (kbase ^ ((ks & 3) << 6)));
+          s0 = M::run(a0, qf[ks], s0);
+          s1 = M::run(a1, qf[ks], s1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const v8s a0 = *reinterpret_cast<const v8s*>(base + (rbase ^ (ks << 6)));
+          const v8s a1 = *reinterpret_cast<const v8s*>(base + 2048 + (rbase ^ (ks << 6)));
+          s0 = M::run(a0, qf[16 + ks], s0);
+          s1 = M::run(a1, qf[16 + ks], s1);
+        }
+      }
+    } else {
+      // ---- this wave's share of S^T, left in LDS for the other waves of the group. The exchange uses inline asm
+      // with hand-counted waits (plain LDS accesses next to LDS-DMA make the compiler drain vmcnt).
+      const uint32_t part = lds_base + (uint32_t)C::kPartOff;
+      if (active) {
+        v4f p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jk = 0; jk < kKS; ++jk) {
+          const v8s a0 = *reinterpret_cast<const v8s*>(base + koff[jk]);
+          const v8s a1 = *reinterpret_cast<const v8s*>(base + koff[jk] + kdelta[jk]);
+          p0 = M::run(a0, qf[jk], p0);
+          p1 = M::run(a1, qf[jk], p1);
+        }
+        const uint32_t mine = part + (uint32_t)(wave * 2048 + lane * 16);
+        // p0 / p1 come straight out of the matrix pipe: the compiler does not know that this asm reads them from
+        // the LDS unit and inserts no wait states (seen: stale partials, run-to-run differences) - pad by hand
+        asm volatile("s_nop 7\n\ts_nop 7\n\tds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" ::"v"(mine), "v"(p0),
+                     "v"(p1)
+                     : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (active) {
+        const uint32_t grp = part + (uint32_t)(hg * W * 2048 + lane * 16);
+        v4f q0[W], q1[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+          asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                       : "=&v"(q0[u]), "=&v"(q1[u])
+                       : "v"(grp), "n"(u * 2048), "n"(u * 2048 + 1024)
+                       : "memory");
+        }
+        // the wait names every register it releases, so that the additions cannot be scheduled above it
+        if constexpr (W == 2) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0[0]), "+v"(q1[0]), "+v"(q0[1]), "+v"(q1[1])::"memory");
+        } else if constexpr (W == 4) {
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(q0[0]), "+v"(q1[0]), "+v"(q0[1]), "+v"(q1[1]), "+v"(q0[2]), "+v"(q1[2]), "+v"(q0[3]), "+v"(q1[3])
+                       :
+                       : "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(q0[0]), "+v"(q1[0]), "+v"(q0[1]), "+v"(q1[1]), "+v"(q0[2]), "+v"(q1[2]), "+v"(q0[3]), "+v"(q1[3]),
+                         "+v"(q0[4]), "+v"(q1[4]), "+v"(q0[5]), "+v"(q1[5]), "+v"(q0[6]), "+v"(q1[6]), "+v"(q0[7]), "+v"(q1[7])
+                       :
+                       : "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+          s0 += q0[u];
+          s1 += q1[u];
+        }
+      }
+    }
     if (active) {
-      const char* base = smem + st * kStageBytes;
-      // ---- S^T[token, head] = K . Q^T for the two 16-token tiles
-      v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const v8s a0 = *reinterpret_cast<const v8s*>(base + (ks >> 2) * 8192 + (kbase ^ ((ks & 3) << 6)));
-        const v8s a1 = *reinterpret_cast<const v8s*>(base + (ks >> 2) * 8192 + 4096 + (kbase ^ ((ks & 3) << 6)));
-        s0 = M::run(a0, qf[ks], s0);
-        s1 = M::run(a1, qf[ks], s1);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const v8s a0 = *reinterpret_cast<const v8s*>(base + (rbase ^ (ks << 6)));
-        const v8s a1 = *reinterpret_cast<const v8s*>(base + 2048 + (rbase ^ (ks << 6)));
-        s0 = M::run(a0, qf[16 + ks], s0);
-        s1 = M::run(a1, qf[16 + ks], s1);
-      }
       // ---- online softmax for head l15 over this lane's 8 tokens (+ the other three lane groups')
       if (t * kTile + kTile > seq) {
         const int tb = t * kTile + 8 * (g & 1) + 4 * (g >> 1);
@@ -285,59 +372,69 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
       m_run = m_new;
       // ---- rescale O when any head's maximum moved: O row (head) 4g + r needs alpha of head 4g + r
       if (__any(alpha != 1.0f)) {
-        if (lane < 16) xch[lane] = alpha;
-        const v4f a4 = *reinterpret_cast<const v4f*>(xch + 4 * g);
+        const v4f a4 = {head_bcast(alpha, 0), head_bcast(alpha, 1), head_bcast(alpha, 2), head_bcast(alpha, 3)};
 #pragma unroll
-        for (int nt = 0; nt < 32; ++nt) {
+        for (int nt = 0; nt < kNT; ++nt) {
           o[nt][0] *= a4[0]; o[nt][1] *= a4[1]; o[nt][2] *= a4[2]; o[nt][3] *= a4[3];
         }
       }
       // ---- O[head, dim] += P . V   (A = P from registers, B = V via transposed LDS reads).
+      // (One read per asm statement, or early-clobber outputs: with two reads in one statement and plain "=v" the
+      // compiler may give the first read's destination the address register, and the second read then races with
+      // the first one's data return - seen as rare wrong tiles.)
       // The transposed reads are issued from inline asm: behind the builtin hipcc waits vmcnt(0) (it cannot
       // tell these LDS reads from the LDS-DMA writes in flight) and that would drain the prefetch ring every
       // tile. The 2 reads of one 16-dim tile are double buffered; LDS returns in order, so lgkmcnt(2) retires
       // the older pair. No other LDS/SMEM traffic of this wave may sit inside this section.
       __builtin_amdgcn_sched_barrier(0);
       {
-        const uint32_t vbase = lds_base + (uint32_t)(st * kStageBytes);
-        v2i vb[2][2];
-#define SGLK_TR_ISSUE(G, BUF)                                                                    \
+        // this wave's kNT output tiles g0 .. g0 + kNT - 1 (W == 1: all 32); kDepth tile reads (2 instructions each)
+        // stay in flight ahead of the MFMA that consumes them: one MFMA (16 cycles) does not cover an LDS round trip
+        constexpr int kDepth = W == 1 ? 1 : 2, kNB = kDepth + 1;
+        const uint32_t vb_t = lds_base + (uint32_t)(st * kStageBytes) + (uint32_t)vadd_w;
+        v2i vb[kNB][2];
+#define SGLK_TR_ISSUE(I)                                                                         \
   do {                                                                                           \
-    const uint32_t a_ = vbase + (uint32_t)(vbase0 ^ (((G) & 7) << 5));                           \
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"    \
-                 : "=v"(vb[BUF][0]), "=v"(vb[BUF][1])                                            \
-                 : "v"(a_), "i"((((G) >> 3) * 8192)), "i"((((G) >> 3) * 8192 + 4096))            \
-                 : "memory");                                                                    \
+    const uint32_t a_ = vb_t + (uint32_t)(vxor_w ^ (((I) & 7) << 5));                            \
+    /* one instruction per asm statement: the second destination may then reuse the address register, the */ \
+    /* first one cannot (two reads in one statement with plain outputs raced: see the header)             */ \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                           \
+                 : "=v"(vb[(I) % kNB][0]) : "v"(a_), "i"((((I) >> 3) * 8192)) : "memory");       \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                           \
+                 : "=v"(vb[(I) % kNB][1]) : "v"(a_), "i"((((I) >> 3) * 8192 + 4096)) : "memory"); \
   } while (0)
-#define SGLK_TR_MMA(G, BUF)                                                                          \
-  do {                                                                                               \
-    v8s f_;                                                                                          \
-    const v4s x0_ = __builtin_bit_cast(v4s, vb[BUF][0]), x1_ = __builtin_bit_cast(v4s, vb[BUF][1]); \
-    f_[0] = x0_[0]; f_[1] = x0_[1]; f_[2] = x0_[2]; f_[3] = x0_[3];                                  \
-    f_[4] = x1_[0]; f_[5] = x1_[1]; f_[6] = x1_[2]; f_[7] = x1_[3];                                  \
-    o[G] = M::run(pf, f_, o[G]);                                                                     \
-  } while (0)
-#define SGLK_TR_WAIT(N, BUF) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(vb[BUF][0]), "+v"(vb[BUF][1])::"memory")
-#define SGLK_TR_STEP(G)                  \
-  SGLK_TR_ISSUE((G) + 1, ((G) + 1) & 1); \
-  SGLK_TR_WAIT(2, (G) & 1);              \
-  SGLK_TR_MMA(G, (G) & 1);
-        SGLK_TR_ISSUE(0, 0);
+#define SGLK_TR_WAIT(N, I) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(vb[(I) % kNB][0]), "+v"(vb[(I) % kNB][1])::"memory")
+#define SGLK_TR_STEP(G)                                                                                    \
+  if constexpr ((G) < kNT) {                                                                               \
+    if constexpr ((G) + kDepth < kNT) SGLK_TR_ISSUE((G) + kDepth);                                         \
+    constexpr int ahead_ = (G) + kDepth < kNT ? kDepth : kNT - 1 - (G);                                    \
+    if constexpr (ahead_ == 3) SGLK_TR_WAIT(6, G);                                                         \
+    if constexpr (ahead_ == 2) SGLK_TR_WAIT(4, G);                                                         \
+    if constexpr (ahead_ == 1) SGLK_TR_WAIT(2, G);                                                         \
+    if constexpr (ahead_ == 0) SGLK_TR_WAIT(0, G);                                                         \
+    v8s f_;                                                                                                \
+    const v4s x0_ = __builtin_bit_cast(v4s, vb[(G) % kNB][0]), x1_ = __builtin_bit_cast(v4s, vb[(G) % kNB][1]); \
+    f_[0] = x0_[0]; f_[1] = x0_[1]; f_[2] = x0_[2]; f_[3] = x0_[3];                                        \
+    f_[4] = x1_[0]; f_[5] = x1_[1]; f_[6] = x1_[2]; f_[7] = x1_[3];                                        \
+    o[G] = M::run(pf, f_, o[G]);                                                                           \
+  }
+        SGLK_TR_ISSUE(0);
+        if constexpr (kDepth > 1) SGLK_TR_ISSUE(1);
+        if constexpr (kDepth > 2) SGLK_TR_ISSUE(2);
         SGLK_TR_STEP(0) SGLK_TR_STEP(1) SGLK_TR_STEP(2) SGLK_TR_STEP(3) SGLK_TR_STEP(4) SGLK_TR_STEP(5)
         SGLK_TR_STEP(6) SGLK_TR_STEP(7) SGLK_TR_STEP(8) SGLK_TR_STEP(9) SGLK_TR_STEP(10) SGLK_TR_STEP(11)
         SGLK_TR_STEP(12) SGLK_TR_STEP(13) SGLK_TR_STEP(14) SGLK_TR_STEP(15) SGLK_TR_STEP(16) SGLK_TR_STEP(17)
         SGLK_TR_STEP(18) SGLK_TR_STEP(19) SGLK_TR_STEP(20) SGLK_TR_STEP(21) SGLK_TR_STEP(22) SGLK_TR_STEP(23)
         SGLK_TR_STEP(24) SGLK_TR_STEP(25) SGLK_TR_STEP(26) SGLK_TR_STEP(27) SGLK_TR_STEP(28) SGLK_TR_STEP(29)
-        SGLK_TR_STEP(30)
-        SGLK_TR_WAIT(0, 1);
-        SGLK_TR_MMA(31, 1);
+        SGLK_TR_STEP(30) SGLK_TR_STEP(31)
 #undef SGLK_TR_STEP
 #undef SGLK_TR_WAIT
-#undef SGLK_TR_MMA
 #undef SGLK_TR_ISSUE
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    st = st + 1 == kStages ? 0 : st + 1;
   }
 
   if (!active) return;
@@ -345,30 +442,29 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
   float l_tot = l_run + __shfl_xor(l_run, 16, 64);
   l_tot += __shfl_xor(l_tot, 32, 64);
   const float inv_l = 1.0f / l_tot;
-  if (lane < 16) xch[lane] = inv_l;
-  const v4f i4 = *reinterpret_cast<const v4f*>(xch + 4 * g);
+  const v4f i4 = {head_bcast(inv_l, 0), head_bcast(inv_l, 1), head_bcast(inv_l, 2), head_bcast(inv_l, 3)};
   if (p.splits == 1) {
     T* out = (T*)p.out + (int64_t)b * H * kLatent;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int head = wave * 16 + 4 * g + r;
+      const int head = hg * 16 + 4 * g + r;
       if (head < H) {
 #pragma unroll
-        for (int nt = 0; nt < 32; ++nt) out[(int64_t)head * kLatent + nt * 16 + l15] = (T)(o[nt][r] * i4[r]);
+        for (int nt = 0; nt < kNT; ++nt) out[(int64_t)head * kLatent + (g0 + nt) * 16 + l15] = (T)(o[nt][r] * i4[r]);
       }
     }
   } else {
     float* wo = p.ws_o + ((int64_t)b * p.splits + split) * H * kLatent;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int head = wave * 16 + 4 * g + r;
+      const int head = hg * 16 + 4 * g + r;
       if (head < H) {
 #pragma unroll
-        for (int nt = 0; nt < 32; ++nt) wo[(int64_t)head * kLatent + nt * 16 + l15] = o[nt][r] * i4[r];
+        for (int nt = 0; nt < kNT; ++nt) wo[(int64_t)head * kLatent + (g0 + nt) * 16 + l15] = o[nt][r] * i4[r];
       }
     }
-    if (lane < 16 && wave * 16 + lane < H)
-      p.ws_lse[((int64_t)b * p.splits + split) * H + wave * 16 + lane] = m_run * p.scale_log2 + log2f(l_tot);
+    if (ww == 0 && lane < 16 && hg * 16 + lane < H)
+      p.ws_lse[((int64_t)b * p.splits + split) * H + hg * 16 + lane] = m_run * p.scale_log2 + log2f(l_tot);
   }
 }
 
@@ -399,19 +495,41 @@ __global__ __launch_bounds__(128) void mla_reduce_kernel(T* __restrict__ out, co
   store_vec<T, 4>(out + ((int64_t)b * H + h) * kLatent + d, o);
 }
 
-template <typename T>
-static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe, const void* cache,
-                  const int32_t* seq_lens, const int32_t* page_table) {
+template <typename T, int W>
+static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe, const void* cache,
+                    const int32_t* seq_lens, const int32_t* page_table) {
   static bool attr_set = false;
+  constexpr int lds = Cfg<W>::kLdsBytes;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_decode_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e != hipSuccess) return fail(SGLK_ELAUNCH, "flash_mla_decode: cannot reserve %d B of LDS: %s", kLdsBytes,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_decode_kernel<T, W>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(SGLK_ELAUNCH, "flash_mla_decode: cannot reserve %d B of LDS: %s", lds,
                                      hipGetErrorString(e));
     attr_set = true;
   }
-  mla_decode_kernel<T><<<dim3(p.splits, B), kThreads, kLdsBytes, st>>>(p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table);
-  if (int rc = check_launch("flash_mla_decode")) return rc;
+  mla_decode_kernel<T, W><<<dim3(p.splits, B), kThreads, lds, st>>>(p, (const T*)q_nope, (const T*)q_pe,
+                                                                   (const char*)cache, seq_lens, page_table);
+  return check_launch("flash_mla_decode");
+}
+
+// Test / tuning hook: force the number of waves per 16-head group (0 = automatic).
+static int g_mla_waves_per_group = 0;
+static int g_mla_probe = 0;
+
+template <typename T>
+static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe, const void* cache,
+                  const int32_t* seq_lens, const int32_t* page_table) {
+  const int ngroups = (p.H + 15) >> 4;
+  int w = ngroups <= 1 ? 8 : ngroups <= 2 ? 4 : ngroups <= 4 ? 2 : 1;
+  if (g_mla_waves_per_group > 0 && g_mla_waves_per_group <= w) w = g_mla_waves_per_group;
+  int rc;
+  switch (w) {
+    case 8: rc = launch_w<T, 8>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
+    case 4: rc = launch_w<T, 4>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
+    case 2: rc = launch_w<T, 2>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
+    default: rc = launch_w<T, 1>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
+  }
+  if (rc) return rc;
   if (p.splits > 1) {
     mla_reduce_kernel<T><<<dim3(p.H, B), 128, 0, st>>>((T*)p.out, p.ws_o, p.ws_lse, p.H, p.splits);
     return check_launch("flash_mla_decode(reduce)");
@@ -421,6 +539,9 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
 
 }  // namespace
 }  // namespace sglk
+
+extern "C" SGLK_API void sglk_debug_set_mla_waves_per_group(int w) { sglk::g_mla_waves_per_group = w; }
+extern "C" SGLK_API void sglk_debug_set_mla_probe(int v) { sglk::g_mla_probe = v; }
 
 // Number of KV splits used when the caller passes num_kv_splits < 1: about one workgroup per CU, and at
 // least 4 tiles (128 tokens) of work per split. (The reference's set_split_kv, mla_decode.cpp:60-93, is tuned
@@ -485,6 +606,7 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   p.H = (int)num_heads;
   p.page_shift = page_size == 16 ? 4 : page_size == 32 ? 5 : page_size == 64 ? 6 : 7;
   p.splits = (int)splits;
+  p.probe = g_mla_probe;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16) return launch<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);

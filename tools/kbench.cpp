@@ -13,6 +13,8 @@
 #include "sglk.h"
 
 extern "C" void sglk_debug_set_gemm_variant(int);
+extern "C" void sglk_debug_set_mla_waves_per_group(int);
+extern "C" void sglk_debug_set_mla_probe(int);
 
 #define HIP_CHECK(x)                                                                 \
   do {                                                                               \
@@ -253,6 +255,8 @@ int main(int argc, char** argv) {
     HIP_CHECK(hipMalloc(&dl, B * 4));
     HIP_CHECK(hipMemcpy(dt, table.data(), table.size() * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dl, lens.data(), B * 4, hipMemcpyHostToDevice));
+    if (getenv("MLA_W")) sglk_debug_set_mla_waves_per_group(atoi(getenv("MLA_W")));
+    if (getenv("MLA_PROBE")) sglk_debug_set_mla_probe(atoi(getenv("MLA_PROBE")));
     for (int ai = 5; ai < argc || ai == 5; ++ai) {
       const int64_t splits = ai < argc ? atoll(argv[ai]) : -1;
       const int64_t wsz = sglk_mla_decode_workspace_size(S, B, H, splits);
@@ -264,7 +268,7 @@ int main(int argc, char** argv) {
         if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
       };
       std::vector<float> all;
-      const double ms = time_ms(run, 5, 20, &all);
+      const double ms = time_ms(run, 100, 50, &all);
       const double bytes = (double)B * H * 576 * 2 + (double)B * S * 576 * 2 + table.size() * 4 + B * 4 + (double)B * H * 512 * 2;
       printf("mla B=%lld S=%lld H=%lld splits=%lld median %.4f ms min %.4f -> %.1f GB/s, %.1f TFLOP/s\n", (long long)B,
              (long long)S, (long long)H, (long long)splits, ms, all[0], bytes / ms / 1e6,
