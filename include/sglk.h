@@ -162,6 +162,25 @@ SGLK_API int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void* 
                                    int64_t cache_page_stride, int64_t table_stride, float sm_scale,
                                    int64_t num_kv_splits, int dtype);
 
+/* ---- MLA prefill ------------------------------------------------------------
+ * flash_mla_prefill: reference src/sycl/mla_prefill.cpp (schema src/torch_extension_sycl.cc:379-383;
+ * wrapper python/sgl_kernel/attention.py:149-233; meaning tests/test_flash_mla_prefill.py:30-90).
+ * Ragged queries q_nope [total_q, H, 512] / q_pe [total_q, H, 64] (strides in elements), sequence b owns
+ * rows cu_seqlens_q[b] .. cu_seqlens_q[b+1]-1 and the first seq_lens_k[b] rows of its pages:
+ *   out[t,h,:512] = softmax(sm_scale * [q_nope[t,h], q_pe[t,h]] . C_b[:n_t]^T) . C_b[:n_t, :512]
+ * with n_t = seq_lens_k[b] - seqlen_q[b] + (t - cu_seqlens_q[b]) + 1 when causal (prefix unmasked,
+ * bottom-right aligned), else seq_lens_k[b]. out is [total_q, H, 512] contiguous; exactly total_q rows are
+ * written (no 256-row padding is needed, cf. attention.py:212-217). No workspace is used. */
+SGLK_API int64_t sglk_flash_mla_prefill_workspace_size(int64_t max_seq_len, int64_t batch, int64_t num_heads,
+                                                       int64_t page_size, int64_t num_kv_splits);
+SGLK_API int sglk_flash_mla_prefill(sglk_stream_t stream, void* out, const void* q_nope, const void* q_pe,
+                                    const void* cache, const int32_t* cu_seqlens_q, const int32_t* seq_lens_k,
+                                    const int32_t* page_table, int64_t batch, int64_t max_seqlen_q,
+                                    int64_t num_heads, int64_t page_size, int64_t pages_per_seq,
+                                    int64_t q_nope_stride_t, int64_t q_nope_stride_h, int64_t q_pe_stride_t,
+                                    int64_t q_pe_stride_h, int64_t cache_page_stride, int64_t table_stride,
+                                    float sm_scale, int causal, int dtype);
+
 /* ---- MoE routing, data movement and W4A16 grouped GEMM -----------------------
  * topk_softmax: reference src/sycl/TopKSoftMax.cpp:584-644 (schema torch_extension_sycl.cc:53).
  *   gating [tokens, experts] (F16/BF16/F32) -> topk_weights fp32 [tokens, k], topk_indices int32. */

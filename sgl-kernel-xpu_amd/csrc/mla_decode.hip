@@ -102,6 +102,9 @@ struct MlaParams {
   int64_t page_stride_bytes;
   int64_t table_stride;
   int H, page_shift, splits;
+  // prefill (cu_seqlens_q given): rows of a workgroup are (token, head) pairs, 128 / 2^hp_shift tokens x 2^hp_shift
+  // head slots; decode: hp_shift = 7 (one token, row = head)
+  int hp_shift, causal;
   int probe;  // timing probe: 1 = stream the cache through LDS, compute nothing (garbage results)
   float scale_log2;
 };
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
                                                                  const T* __restrict__ q_pe,
                                                                  const char* __restrict__ cache,
                                                                  const int32_t* __restrict__ seq_lens,
-                                                                 const int32_t* __restrict__ page_table) {
+                                                                 const int32_t* __restrict__ page_table,
+                                                                 const int32_t* __restrict__ cu_seqlens_q) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   using M = Mfma<T>;
   using C = Cfg<W>;
@@ -126,11 +130,31 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
   const int hg = wave / W, ww = wave % W;  // head group, position inside the group
   const int split = blockIdx.x, b = blockIdx.y;
   const int H = p.H;
-  const int ngroups = (H + 15) >> 4;
-  const bool active = hg < ngroups && p.probe != 1;
   const int l15 = lane & 15, g = lane >> 4;
 
-  const int seq = seq_lens[b];
+  // ---- rows of this workgroup. Decode: one token (the batch element), row = head. Prefill: tokens t0 .. t0+TPW-1
+  // of sequence b, row = (token - t0) * Hp + head; every token sees the first kv_len(token) cache rows (causal:
+  // bottom-right aligned, reference tests/test_flash_mla_prefill.py:73-81), the tile loop runs to the last one's.
+  const int hp_mask = (1 << p.hp_shift) - 1;
+  const int grp_tok = (hg * 16) >> p.hp_shift, grp_head0 = (hg * 16) & hp_mask;  // uniform per wave
+  int q_row0 = b, n_tok = 1, seq, kv_first;  // first q row, valid tokens here, kv length of the last / first token
+  if (cu_seqlens_q != nullptr) {
+    const int q0 = cu_seqlens_q[b], sq = cu_seqlens_q[b + 1] - q0, sk = seq_lens[b];
+    const int t0 = (int)blockIdx.z << (7 - p.hp_shift);
+    if (t0 >= sq) return;
+    const int tpw = 1 << (7 - p.hp_shift);
+    n_tok = (sq - t0) < tpw ? (sq - t0) : tpw;
+    q_row0 = q0 + t0;
+    kv_first = p.causal ? sk - sq + t0 + 1 : sk;
+    seq = p.causal ? sk - sq + t0 + n_tok : sk;
+  } else {
+    seq = seq_lens[b];
+    kv_first = seq;
+  }
+  const bool active = grp_tok < n_tok && grp_head0 < H && p.probe != 1;
+  // kv length of the row this lane scores (head slot l15 of the group); rows that are not stored behave like the
+  // last token's so that their softmax stays finite
+  const int kv_row = (cu_seqlens_q != nullptr && p.causal && grp_tok < n_tok) ? kv_first + grp_tok : seq;
   const int ntiles = (seq + kTile - 1) / kTile;
   const int tps = (ntiles + p.splits - 1) / p.splits;
   const int t_begin = split * tps;
@@ -193,10 +217,11 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
   // wave ww of a group takes k-steps ww, ww + W, ... (< 18; steps 16, 17 are the rope columns)
   v8s qf[kKS];
   {
-    const int head = hg * 16 + l15;
+    const int head = grp_head0 + l15;
     const bool ok = active && head < H;
-    const T* qn = q_nope + (int64_t)b * p.qn_sb + (int64_t)(ok ? head : 0) * p.qn_sh + 8 * pig;
-    const T* qp = q_pe + (int64_t)b * p.qp_sb + (int64_t)(ok ? head : 0) * p.qp_sh + 8 * pig;
+    const int64_t qrow = q_row0 + (active ? grp_tok : 0);
+    const T* qn = q_nope + qrow * p.qn_sb + (int64_t)(ok ? head : 0) * p.qn_sh + 8 * pig;
+    const T* qp = q_pe + qrow * p.qp_sb + (int64_t)(ok ? head : 0) * p.qp_sh + 8 * pig;
     const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int jk = 0; jk < kKS; ++jk) {
@@ -344,12 +369,12 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
     }
     if (active) {
       // ---- online softmax for head l15 over this lane's 8 tokens (+ the other three lane groups')
-      if (t * kTile + kTile > seq) {
+      if (t * kTile + kTile > kv_first) {
         const int tb = t * kTile + 8 * (g & 1) + 4 * (g >> 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (tb + r >= seq) s0[r] = -INFINITY;
-          if (tb + 16 + r >= seq) s1[r] = -INFINITY;
+          if (tb + r >= kv_row) s0[r] = -INFINITY;
+          if (tb + 16 + r >= kv_row) s1[r] = -INFINITY;
         }
       }
       float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
@@ -444,10 +469,10 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
   const float inv_l = 1.0f / l_tot;
   const v4f i4 = {head_bcast(inv_l, 0), head_bcast(inv_l, 1), head_bcast(inv_l, 2), head_bcast(inv_l, 3)};
   if (p.splits == 1) {
-    T* out = (T*)p.out + (int64_t)b * H * kLatent;
+    T* out = (T*)p.out + (int64_t)(q_row0 + grp_tok) * H * kLatent;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int head = hg * 16 + 4 * g + r;
+      const int head = grp_head0 + 4 * g + r;
       if (head < H) {
 #pragma unroll
         for (int nt = 0; nt < kNT; ++nt) out[(int64_t)head * kLatent + (g0 + nt) * 16 + l15] = (T)(o[nt][r] * i4[r]);
@@ -497,7 +522,8 @@ __global__ __launch_bounds__(128) void mla_reduce_kernel(T* __restrict__ out, co
 
 template <typename T, int W>
 static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe, const void* cache,
-                    const int32_t* seq_lens, const int32_t* page_table) {
+                    const int32_t* seq_lens, const int32_t* page_table, const int32_t* cu_seqlens_q = nullptr,
+                    int token_blocks = 1) {
   static bool attr_set = false;
   constexpr int lds = Cfg<W>::kLdsBytes;
   if (!attr_set) {
@@ -507,9 +533,9 @@ static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nop
                                      hipGetErrorString(e));
     attr_set = true;
   }
-  mla_decode_kernel<T, W><<<dim3(p.splits, B), kThreads, lds, st>>>(p, (const T*)q_nope, (const T*)q_pe,
-                                                                   (const char*)cache, seq_lens, page_table);
-  return check_launch("flash_mla_decode");
+  mla_decode_kernel<T, W><<<dim3(p.splits, B, token_blocks), kThreads, lds, st>>>(
+      p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
+  return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
 }
 
 // Test / tuning hook: force the number of waves per 16-head group (0 = automatic).
@@ -606,9 +632,61 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   p.H = (int)num_heads;
   p.page_shift = page_size == 16 ? 4 : page_size == 32 ? 5 : page_size == 64 ? 6 : 7;
   p.splits = (int)splits;
+  p.hp_shift = 7;
+  p.causal = 0;
   p.probe = g_mla_probe;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16) return launch<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
   return launch<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
+}
+
+// flash_mla_prefill: varlen causal MLA over the same paged latent cache (reference python/sgl_kernel/attention.py:
+// 149-233, tests/test_flash_mla_prefill.py:30-90). Same kernel as the decode: a workgroup takes 128 / Hp consecutive
+// query tokens of one sequence (Hp = H rounded up to 16, 32, 64 or 128) as its 128 MFMA rows and streams the cache
+// once for all of them; each row masks the keys past its own causal horizon.
+extern "C" int64_t sglk_flash_mla_prefill_workspace_size(int64_t, int64_t, int64_t, int64_t, int64_t) { return 0; }
+
+extern "C" int sglk_flash_mla_prefill(sglk_stream_t stream, void* out, const void* q_nope, const void* q_pe,
+                                      const void* cache, const int32_t* cu_seqlens_q, const int32_t* seq_lens_k,
+                                      const int32_t* page_table, int64_t batch, int64_t max_seqlen_q,
+                                      int64_t num_heads, int64_t page_size, int64_t pages_per_seq,
+                                      int64_t q_nope_stride_t, int64_t q_nope_stride_h, int64_t q_pe_stride_t,
+                                      int64_t q_pe_stride_h, int64_t cache_page_stride, int64_t table_stride,
+                                      float sm_scale, int causal, int dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(batch >= 0 && num_heads > 0 && num_heads <= 128, "flash_mla_prefill: H must be in [1, 128], got %lld",
+               (long long)num_heads);
+  SGLK_REQUIRE(page_size == 16 || page_size == 32 || page_size == 64 || page_size == 128,
+               "flash_mla_prefill: Unsupported page size: %lld", (long long)page_size);
+  SGLK_REQUIRE(pages_per_seq > 0, "flash_mla_prefill: block num must be greater than 0");
+  SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "flash_mla_prefill: dtype must be Half or BFloat16");
+  SGLK_REQUIRE(q_nope_stride_t % 8 == 0 && q_nope_stride_h % 8 == 0 && q_pe_stride_t % 8 == 0 &&
+                   q_pe_stride_h % 8 == 0 && (uintptr_t)q_nope % 16 == 0 && (uintptr_t)q_pe % 16 == 0 &&
+                   (uintptr_t)cache % 16 == 0 && cache_page_stride % 8 == 0,
+               "flash_mla_prefill: q and cache rows must be 16-byte aligned");
+  if (batch == 0 || max_seqlen_q <= 0) return SGLK_OK;
+  MlaParams p;
+  p.out = out;
+  p.ws_o = nullptr;
+  p.ws_lse = nullptr;
+  p.qn_sb = q_nope_stride_t;
+  p.qn_sh = q_nope_stride_h;
+  p.qp_sb = q_pe_stride_t;
+  p.qp_sh = q_pe_stride_h;
+  p.page_stride_bytes = cache_page_stride * 2;
+  p.table_stride = table_stride;
+  p.H = (int)num_heads;
+  p.page_shift = page_size == 16 ? 4 : page_size == 32 ? 5 : page_size == 64 ? 6 : 7;
+  p.splits = 1;
+  p.hp_shift = num_heads <= 16 ? 4 : num_heads <= 32 ? 5 : num_heads <= 64 ? 6 : 7;
+  p.causal = causal ? 1 : 0;
+  p.probe = 0;
+  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  const int tpw = 1 << (7 - p.hp_shift);
+  const int token_blocks = (int)((max_seqlen_q + tpw - 1) / tpw);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGLK_BF16)
+    return launch_w<bf16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+  return launch_w<f16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
 }

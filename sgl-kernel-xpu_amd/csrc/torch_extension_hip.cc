@@ -345,6 +345,59 @@ int64_t flash_mla_get_workspace_size(int64_t max_seq_len, int64_t num_batches, i
   return sglk_mla_decode_workspace_size(max_seq_len, num_batches, num_heads, num_kv_splits);
 }
 
+// ---- flash_mla_prefill (reference src/sycl/mla_prefill.cpp; schema torch_extension_sycl.cc:377-383) ----------
+
+void flash_mla_prefill(Tensor& out, Tensor& q_nope, Tensor& q_pe, Tensor& kv_c_and_k_pe_cache, Tensor& cu_seqlens_q,
+                       Tensor& seq_lens, int64_t max_seqlen_q, Tensor& page_table, Tensor& workspace, double sm_scale,
+                       bool causal, int64_t num_kv_splits) {
+  (void)workspace;
+  (void)num_kv_splits;  // reserved by the reference as well (attention.py:178-179)
+  CHECK_GPU(out);
+  CHECK_GPU(q_nope);
+  CHECK_GPU(q_pe);
+  CHECK_GPU(kv_c_and_k_pe_cache);
+  CHECK_GPU(cu_seqlens_q);
+  CHECK_GPU(seq_lens);
+  CHECK_GPU(page_table);
+  TORCH_CHECK(q_nope.dim() == 3 && q_pe.dim() == 3 && kv_c_and_k_pe_cache.dim() == 3 && out.dim() == 3,
+              "flash_mla_prefill: q_nope, q_pe, kv cache and out must be 3-D");
+  const int64_t total_q = q_nope.size(0), H = q_nope.size(1);
+  TORCH_CHECK(q_nope.size(2) == 512 && q_pe.size(2) == 64 && kv_c_and_k_pe_cache.size(2) == 576,
+              "flash_mla_prefill: expects kv_lora_rank 512 and qk_rope_head_dim 64");
+  TORCH_CHECK(q_pe.size(0) == total_q && q_pe.size(1) == H, "flash_mla_prefill: q_nope / q_pe shape mismatch");
+  TORCH_CHECK(out.size(0) >= total_q && out.size(1) == H && out.size(2) == 512 && out.is_contiguous(),
+              "flash_mla_prefill: out must be a contiguous [>= total_q, H, 512] tensor");
+  const auto dt = q_nope.scalar_type();
+  TORCH_CHECK(dt == at::kHalf || dt == at::kBFloat16, "flash_mla_prefill: dtype must be Half or BFloat16");
+  TORCH_CHECK(q_pe.scalar_type() == dt && kv_c_and_k_pe_cache.scalar_type() == dt && out.scalar_type() == dt,
+              "flash_mla_prefill: q_nope, q_pe, kv cache and out must share one dtype");
+  TORCH_CHECK(q_nope.stride(2) == 1 && q_pe.stride(2) == 1, "flash_mla_prefill: q last dimension must be contiguous");
+  TORCH_CHECK(kv_c_and_k_pe_cache.stride(2) == 1 && kv_c_and_k_pe_cache.stride(1) == 576,
+              "flash_mla_prefill: kv cache rows must be contiguous");
+  const int64_t B = seq_lens.numel();
+  TORCH_CHECK(cu_seqlens_q.scalar_type() == at::kInt && cu_seqlens_q.numel() == B + 1 && cu_seqlens_q.is_contiguous(),
+              "flash_mla_prefill: cu_seqlens_q must be a contiguous int32 [B + 1] tensor");
+  TORCH_CHECK(seq_lens.scalar_type() == at::kInt && seq_lens.is_contiguous(),
+              "flash_mla_prefill: seq_lens must be a contiguous int32 [B] tensor");
+  TORCH_CHECK(page_table.scalar_type() == at::kInt && page_table.dim() == 2 && page_table.size(0) == B &&
+                  page_table.stride(1) == 1,
+              "flash_mla_prefill: page_table must be an int32 [B, n] tensor");
+  const int64_t page = kv_c_and_k_pe_cache.size(1);
+  TORCH_CHECK(page == 16 || page == 32 || page == 64 || page == 128, "Unsupported page size: ", page);
+  const c10::OptionalDeviceGuard guard(q_nope.device());
+  SGLK_CALL(sglk_flash_mla_prefill(stream_of(q_nope), out.data_ptr(), q_nope.data_ptr(), q_pe.data_ptr(),
+                                   kv_c_and_k_pe_cache.data_ptr(), cu_seqlens_q.data_ptr<int32_t>(),
+                                   seq_lens.data_ptr<int32_t>(), page_table.data_ptr<int32_t>(), B, max_seqlen_q, H, page,
+                                   page_table.size(1), q_nope.stride(0), q_nope.stride(1), q_pe.stride(0),
+                                   q_pe.stride(1), kv_c_and_k_pe_cache.stride(0), page_table.stride(0),
+                                   (float)sm_scale, causal ? 1 : 0, dtype_code(dt, "flash_mla_prefill")));
+}
+
+int64_t flash_mla_prefill_get_workspace_size(int64_t max_seq_len, int64_t num_batches, int64_t num_heads,
+                                             int64_t page_size, int64_t num_kv_splits) {
+  return sglk_flash_mla_prefill_workspace_size(max_seq_len, num_batches, num_heads, page_size, num_kv_splits);
+}
+
 // ---- MoE (reference src/sycl/TopKSoftMax.cpp:584-644, MoEAlign.cpp:313-383, MoEPrepareInputs.cpp,
 //           GroupGemmW4A16Xe20.cpp:92-283) ----------------------------------------------------------
 
@@ -856,6 +909,12 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "flash_mla_decode(Tensor! out, Tensor! q_nope, Tensor! q_pe, Tensor! kv_c_and_k_pe_cache, Tensor! seq_lens,"
       " Tensor! page_table, Tensor! workspace, float sm_scale, int num_kv_splits) -> ()");
   m.impl("flash_mla_decode", c10::kCUDA, &flash_mla_decode);
+  m.def("flash_mla_prefill_get_workspace_size", &flash_mla_prefill_get_workspace_size);
+  m.def(
+      "flash_mla_prefill(Tensor! out, Tensor! q_nope, Tensor! q_pe, Tensor! kv_c_and_k_pe_cache, "
+      "Tensor! cu_seqlens_q, Tensor! seq_lens, int max_seqlen_q, "
+      "Tensor! page_table, Tensor! workspace, float sm_scale, bool causal, int num_kv_splits) -> ()");
+  m.impl("flash_mla_prefill", c10::kCUDA, &flash_mla_prefill);
 
   // reference src/torch_extension_sycl.cc:53, :199-203, :214-229
   m.def("topk_softmax(Tensor! topk_weights, Tensor! topk_indices, Tensor gating_output, bool renormalize) -> ()");

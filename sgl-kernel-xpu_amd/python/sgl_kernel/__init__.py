@@ -18,7 +18,12 @@ if not any(f.startswith("common_ops") and f.endswith(".so") for f in _os.listdir
     )
 
 from sgl_kernel import common_ops  # noqa: E402,F401  (TORCH_LIBRARY registration happens at dlopen)
-from sgl_kernel.attention import flash_mla_decode, flash_mla_get_workspace_size  # noqa: E402
+from sgl_kernel.attention import (  # noqa: E402
+    flash_mla_decode,
+    flash_mla_get_workspace_size,
+    flash_mla_prefill,
+    flash_mla_prefill_get_workspace_size,
+)
 from sgl_kernel.elementwise import (  # noqa: E402
     fused_add_rmsnorm,
     gelu_and_mul,

@@ -166,6 +166,37 @@ def gen_mla_decode():
     save("mla_decode", cases)
 
 
+def gen_mla_prefill():
+    import torch as _t
+    orig = _t.xpu.is_available
+    _t.xpu.is_available = lambda: True
+    try:
+        t = _import_ref("test_flash_mla_prefill")
+    finally:
+        _t.xpu.is_available = orig
+    cases = []
+    torch.manual_seed(42)
+    # shapes from the parameter list of tests/test_flash_mla_prefill.py:103-131 (small ones)
+    # (token counts cut down so that the fixture stays small: q and out are [total_q, H, 512])
+    for dt, H, page, sqs, sks in [(torch.bfloat16, 16, 64, [17], [128]), (torch.float16, 16, 16, [9, 1, 12], [64, 32, 100]),
+                                  (torch.bfloat16, 128, 32, [2, 1], [73, 40]), (torch.float16, 16, 128, [17, 5], [17, 5])]:
+        bs = len(sqs)
+        cu = torch.tensor([0] + torch.cumsum(torch.tensor(sqs), 0).tolist(), dtype=torch.int32)
+        sk = torch.tensor(sks, dtype=torch.int32)
+        block_num = (max(sks) + page - 1) // page
+        pack = 128 // page
+        block_num = (block_num + pack - 1) // pack * pack
+        qn = torch.randn(sum(sqs), H, 512, dtype=dt)
+        qp = torch.randn(sum(sqs), H, 64, dtype=dt)
+        table = torch.randint(0, bs * block_num, (bs, block_num), dtype=torch.int32)
+        cache = torch.randn(int(table.max()) + 1, page, 576, dtype=dt)
+        scale = (128 + 64) ** -0.5
+        out = t.ref_mla_prefill_varlen(qn, qp, cache, scale, table, cu, sk, causal=True)
+        cases.append(dict(q_nope=qn, q_pe=qp, cache=cache, table=table, cu_seqlens_q=cu, seq_lens_k=sk, scale=scale,
+                          out=out))
+    save("mla_prefill", cases)
+
+
 def gen_moe():
     t = _import_ref("test_moe_gemm")
     cases = {"grouped_mm": [], "fused": []}
@@ -262,6 +293,7 @@ GENERATORS = {
     "moe_w4a16": gen_moe,
     "topk_softmax": gen_topk_softmax,
     "mla_decode": gen_mla_decode,
+    "mla_prefill": gen_mla_prefill,
     "norm": gen_norm,
     "activation": gen_activation,
     "quant": gen_quant,

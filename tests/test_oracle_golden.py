@@ -149,3 +149,14 @@ def test_rope_matches_reference_vectors():
     for c in load_golden("rope"):
         qo, ko = orope.rotary_embedding(c["positions"], c["q"], c["k"], c["head_size"], c["cache"], c["is_neox"])
         assert torch.equal(qo, c["q_out"]) and torch.equal(ko, c["k_out"])
+
+
+def test_mla_prefill_oracle_matches_reference_vectors():
+    """oracle.mla.mla_prefill vs ref_mla_prefill_varlen outputs (reference tests/test_flash_mla_prefill.py:30-90)."""
+    from oracle import mla as omla
+
+    for c in load_golden("mla_prefill"):
+        out = omla.mla_prefill(c["q_nope"], c["q_pe"], c["cache"], c["scale"], c["table"], c["cu_seqlens_q"],
+                               c["seq_lens_k"], causal=True)
+        tol = 1e-2 if c["q_nope"].dtype == torch.bfloat16 else 1e-3  # reference tolerance (:235-236)
+        torch.testing.assert_close(out.float(), c["out"].float(), atol=tol, rtol=tol)
