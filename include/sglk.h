@@ -140,6 +140,24 @@ SGLK_API int sglk_scaled_mm(sglk_stream_t stream, void* out, const void* a, cons
                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                             int in_dtype, int out_dtype);
 
+/* ---- QServe W4A8 GEMMs ------------------------------------------------------
+ * Declared only in the reference (include/sgl_kernel_ops.h:1132-1148; wrappers python/sgl_kernel/gemm.py:314-356);
+ * meaning, quantisers and the 32x32 interleaved weight packing pinned by tests/test_qserve_w4a8_per_chn_gemm.py:
+ * 12-56,80-88 and tests/test_qserve_w4a8_per_group_gemm.py:12-92,134-145.
+ *   in_feats [M,K] int8 (row stride lda); kernel [N, K/2] int8 packed; out [M,N] fp16 (row stride ldc)
+ *   per_chn  : out = (in @ Wq^T) * ascales[m] * wscales[n] - a_ssums[m] * w_szs[n]       (all scale vectors fp16)
+ *   per_group: out = (in @ W8^T) * ascales[m] * wscales[n],  W8 = Wq * scales_i8[k/128, n'] + zeros[k/128, n']
+ *              (scales_i8 / zeros int8 [K/128, N] in the permuted column order of the reference packer)
+ * N % 32 == 0; K % 64 == 0 (per_chn) or K % 128 == 0 (per_group). */
+SGLK_API int sglk_qserve_w4a8_per_chn_gemm(sglk_stream_t stream, void* out, const void* in_feats,
+                                           const void* kernel, const void* wscales, const void* ascales,
+                                           const void* w_szs, const void* a_ssums, int64_t M, int64_t N,
+                                           int64_t K, int64_t lda, int64_t ldc);
+SGLK_API int sglk_qserve_w4a8_per_group_gemm(sglk_stream_t stream, void* out, const void* in_feats,
+                                             const void* kernel, const void* zeros, const void* scales_i8,
+                                             const void* wscales, const void* ascales, int64_t M, int64_t N,
+                                             int64_t K, int64_t lda, int64_t ldc);
+
 /* ---- MLA decode -------------------------------------------------------------
  * flash_mla_decode: reference src/sycl/mla_decode.cpp:135-175 (schema
  * src/torch_extension_sycl.cc:364-368; wrapper python/sgl_kernel/attention.py:54-132).

@@ -1,0 +1,171 @@
+// qserve_w4a8_per_chn_gemm / qserve_w4a8_per_group_gemm for gfx950 (QServe W4A8: int8 activations, uint4 weights).
+//
+// The reference only declares these ops (include/sgl_kernel_ops.h:1132-1148; wrappers python/sgl_kernel/gemm.py:
+// 314-356); their meaning and the weight / scale packing are pinned by tests/test_qserve_w4a8_per_chn_gemm.py:12-56,
+// 80-88 and tests/test_qserve_w4a8_per_group_gemm.py:12-92,134-145:
+//   per channel: out = fp16( (Aq @ Wq^T) * sA[m] * sW[n] - a_ssum[m] * w_szs[n] ),  w_szs = zero * sW
+//   per group  : out = fp16( (Aq @ W8^T) * sA[m] * sW[n] ),  W8[n,k] = Wq[n,k] * s8[k/128, n] + zs8[k/128, n]
+//                (int8 two-level "progressive" quantisation: s8 int8 group scale, zs8 = -zero * s8, |W8| <= 127)
+// Packing (convert_to_qserve_format): Wq [N,K] uint4 is cut in 32 x 32 blocks of 512 bytes, block (n/32, k/32) at
+// byte (n/32 * K/32 + k/32) * 512; inside a block byte ((c*4 + e)*2 + d)*2*4 + b*4 + f holds k = 16 d + 4 e + f of
+// rows 8 b + c (low nibble) and 16 + 8 b + c (high nibble). s8 / zs8 rows are permuted per 32 columns: position
+// 4 c + q holds column 8 q + c.
+//
+// Kernel: that layout IS an MFMA layout. v_mfma_i32_16x16x64_i8 wants from lane (j, kg) 16 consecutive k of row j:
+// with j = 8 b + c and kg = (k/32 odd, d) the four dwords e = 0..3 of the lane (16 bytes apart) hold k = 16 kg ..
+// 16 kg + 15 of row j in their low nibbles and of row 16 + j in their high nibbles. Two AND / shift per dword unpack
+// two A operands; the activations are the B operand (lane (m, kg): 16 bytes of row m straight from global memory,
+// the four waves of a workgroup hit the same lines in the vector L1), so a lane ends up with 4 consecutive n of
+// one m: 8-byte fp16 stores. The integer dot products are exact in int32; per group the weights are rebuilt as
+// int8 in registers (packed multiply by the small group scale, carry-free packed add of zs8) before the MFMA, so
+// both variants accumulate over all of K without rescaling.
+// No LDS, no barriers: a wave owns a 32-column block of W for all of K, 16*MF rows of A.
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// byte-wise a + b (mod 256) on four packed bytes
+__device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b) {
+  return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+
+template <bool GROUP, int MF>
+__global__ __launch_bounds__(256) void qserve_w4a8_kernel(
+    f16* __restrict__ out, const int8_t* __restrict__ a, const uint8_t* __restrict__ w,
+    const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales_i8, const f16* __restrict__ wscales,
+    const f16* __restrict__ ascales, const f16* __restrict__ w_szs, const f16* __restrict__ a_ssums, int M, int N,
+    int K, int64_t lda, int64_t ldc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n32 = blockIdx.x * 4 + wave;
+  if (n32 * 32 >= N) return;
+  const int m0 = blockIdx.y * (16 * MF);
+  const int j = lane & 15, kg = lane >> 4;
+  const int c = j & 7, b = j >> 3;
+
+  // weights: block (n32, k32) at (n32 * K/32 + k32) * 512; this lane's dword e of k step ks (64 deep): k32 = 2 ks + kg/2
+  const uint8_t* wl = w + ((int64_t)n32 * (K >> 5) + (kg >> 1)) * 512 + c * 64 + (kg & 1) * 8 + b * 4;
+  // activations: row m0 + 16 mf + j (clamped), 16 bytes at k = 64 ks + 16 kg
+  const int8_t* al[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    int m = m0 + mf * 16 + j;
+    m = m < M ? m : M - 1;
+    al[mf] = a + (int64_t)m * lda + kg * 16;
+  }
+  // group scales / zero terms of this lane's two rows (low nibble: column 8 b + c -> position 4 c + b; high: 4 c + 2 + b)
+  const int8_t* s8 = GROUP ? scales_i8 + n32 * 32 + c * 4 + b : nullptr;
+  const int8_t* z8 = GROUP ? zeros + n32 * 32 + c * 4 + b : nullptr;
+
+  v4i acc[MF][2];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) acc[mf][0] = acc[mf][1] = (v4i){0, 0, 0, 0};
+
+  const int nks = K >> 6;
+  for (int ks = 0; ks < nks; ++ks) {
+    uint32_t wd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wd[e] = *reinterpret_cast<const uint32_t*>(wl + (int64_t)ks * 1024 + e * 16);
+    v4i af[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) af[mf] = *reinterpret_cast<const v4i*>(al[mf] + ks * 64);
+    v4i wlo, whi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t lo = wd[e] & 0x0f0f0f0fu, hi = (wd[e] >> 4) & 0x0f0f0f0fu;
+      if constexpr (GROUP) {
+        const int g = ks >> 1;
+        const uint32_t slo = (uint8_t)s8[(int64_t)g * N], shi = (uint8_t)s8[(int64_t)g * N + 2];
+        const uint32_t zlo = (uint8_t)z8[(int64_t)g * N], zhi = (uint8_t)z8[(int64_t)g * N + 2];
+        // code * scale <= 15 * 17 fits a byte: one 32-bit multiply scales four codes; the add wraps per byte
+        lo = add_bytes(lo * slo, zlo * 0x01010101u);
+        hi = add_bytes(hi * shi, zhi * 0x01010101u);
+      }
+      wlo[e] = (int)lo;
+      whi[e] = (int)hi;
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      acc[mf][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wlo, af[mf], acc[mf][0], 0, 0, 0);
+      acc[mf][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(whi, af[mf], acc[mf][1], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane (column m = j of the m fragment, rows n = 4 kg + r of the n fragment)
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = m0 + mf * 16 + j;
+    if (m >= M) continue;
+    const float sa = (float)ascales[m];
+    const float asum = GROUP ? 0.f : (float)a_ssums[m];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n32 * 32 + h * 16 + kg * 4;
+      Vec<f16, 4> o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = (float)acc[mf][h][r] * sa * (float)wscales[n + r];
+        if constexpr (!GROUP) v -= asum * (float)w_szs[n + r];
+        o[r] = (f16)v;
+      }
+      store_vec<f16, 4>(out + (int64_t)m * ldc + n, o);
+    }
+  }
+}
+
+template <bool GROUP>
+static int launch(hipStream_t st, void* out, const void* a, const void* w, const void* zeros, const void* scales_i8,
+                  const void* wscales, const void* ascales, const void* w_szs, const void* a_ssums, int64_t M, int64_t N,
+                  int64_t K, int64_t lda, int64_t ldc) {
+  const unsigned gx = (unsigned)cdiv(N, 128);
+#define SGLK_GO(MF)                                                                                              \
+  qserve_w4a8_kernel<GROUP, MF><<<dim3(gx, (unsigned)cdiv(M, 16 * MF)), 256, 0, st>>>(                           \
+      (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,            \
+      (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc)
+  if (M <= 16) SGLK_GO(1);
+  else if (M <= 32) SGLK_GO(2);
+  else if (M <= 64) SGLK_GO(4);
+  else SGLK_GO(8);
+#undef SGLK_GO
+  return check_launch(GROUP ? "qserve_w4a8_per_group_gemm" : "qserve_w4a8_per_chn_gemm");
+}
+
+static int check(const char* op, const void* out, const void* a, const void* w, int64_t M, int64_t N, int64_t K,
+                 int64_t lda, int64_t ldc, int64_t kmult) {
+  SGLK_REQUIRE(M >= 0 && N > 0 && K > 0, "%s: bad shape M=%lld N=%lld K=%lld", op, (long long)M, (long long)N, (long long)K);
+  SGLK_REQUIRE(N % 32 == 0, "%s: N=%lld must be a multiple of 32 (QServe 32x32 weight blocks)", op, (long long)N);
+  SGLK_REQUIRE(K % kmult == 0, "%s: K=%lld must be a multiple of %lld", op, (long long)K, (long long)kmult);
+  SGLK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "%s: shape too large", op);
+  SGLK_REQUIRE(lda % 16 == 0 && (uintptr_t)a % 16 == 0 && (uintptr_t)w % 16 == 0,
+               "%s: activation rows and the packed weight must be 16-byte aligned", op);
+  SGLK_REQUIRE(ldc % 4 == 0 && (uintptr_t)out % 8 == 0, "%s: output rows must be 8-byte aligned", op);
+  return SGLK_OK;
+}
+
+}  // namespace
+}  // namespace sglk
+
+extern "C" int sglk_qserve_w4a8_per_chn_gemm(sglk_stream_t stream, void* out, const void* in_feats, const void* kernel,
+                                             const void* wscales, const void* ascales, const void* w_szs,
+                                             const void* a_ssums, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                             int64_t ldc) {
+  using namespace sglk;
+  if (int rc = check("qserve_w4a8_per_chn_gemm", out, in_feats, kernel, M, N, K, lda, ldc, 64)) return rc;
+  if (M == 0) return SGLK_OK;
+  return launch<false>((hipStream_t)stream, out, in_feats, kernel, nullptr, nullptr, wscales, ascales, w_szs, a_ssums, M, N,
+                       K, lda, ldc);
+}
+
+extern "C" int sglk_qserve_w4a8_per_group_gemm(sglk_stream_t stream, void* out, const void* in_feats, const void* kernel,
+                                               const void* zeros, const void* scales_i8, const void* wscales,
+                                               const void* ascales, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                               int64_t ldc) {
+  using namespace sglk;
+  if (int rc = check("qserve_w4a8_per_group_gemm", out, in_feats, kernel, M, N, K, lda, ldc, 128)) return rc;
+  if (M == 0) return SGLK_OK;
+  return launch<true>((hipStream_t)stream, out, in_feats, kernel, zeros, scales_i8, wscales, ascales, nullptr, nullptr, M, N,
+                      K, lda, ldc);
+}

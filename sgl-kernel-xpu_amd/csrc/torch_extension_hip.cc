@@ -286,6 +286,57 @@ Tensor int8_scaled_mm(const Tensor& mat_a, const Tensor& mat_b, const Tensor& sc
   return scaled_mm_impl(mat_a, mat_b, scales_a, scales_b, out_dtype, bias, true, "int8_scaled_mm");
 }
 
+// ---- QServe W4A8 (reference include/sgl_kernel_ops.h:1132-1148; python/sgl_kernel/gemm.py:314-356) ----------
+
+static void qserve_common(const char* op, const Tensor& in_feats, const Tensor& kernel, const Tensor& wscales,
+                          const Tensor& ascales, Tensor& out_feats) {
+  CHECK_GPU(in_feats);
+  CHECK_GPU(kernel);
+  CHECK_GPU(wscales);
+  CHECK_GPU(ascales);
+  CHECK_GPU(out_feats);
+  TORCH_CHECK(in_feats.dim() == 2 && kernel.dim() == 2 && out_feats.dim() == 2, op, ": in_feats, kernel, out_feats must be 2-D");
+  TORCH_CHECK(in_feats.scalar_type() == at::kChar && kernel.scalar_type() == at::kChar, op, ": in_feats and kernel must be int8");
+  TORCH_CHECK(out_feats.scalar_type() == at::kHalf, op, ": only out dtype float16 is supported");
+  TORCH_CHECK(wscales.scalar_type() == at::kHalf && ascales.scalar_type() == at::kHalf, op, ": wscales / ascales must be float16");
+  const int64_t M = in_feats.size(0), K = in_feats.size(1), N = kernel.size(0);
+  TORCH_CHECK(kernel.size(1) * 2 == K && kernel.is_contiguous(), op, ": kernel must be a contiguous [N, K/2] tensor");
+  TORCH_CHECK(in_feats.stride(1) == 1 && out_feats.stride(1) == 1, op, ": in_feats / out_feats rows must be contiguous");
+  TORCH_CHECK(out_feats.size(0) == M && out_feats.size(1) == N, op, ": out_feats must be [M, N]");
+  TORCH_CHECK(wscales.numel() == N && wscales.is_contiguous() && ascales.numel() == M && ascales.is_contiguous(), op,
+              ": wscales must hold N and ascales M contiguous values");
+}
+
+void qserve_w4a8_per_chn_gemm(const Tensor& in_feats, const Tensor& kernel, const Tensor& wscales, const Tensor& ascales,
+                              const Tensor& w_szs, const Tensor& a_ssums, Tensor& out_feats) {
+  qserve_common("qserve_w4a8_per_chn_gemm", in_feats, kernel, wscales, ascales, out_feats);
+  CHECK_GPU(w_szs);
+  CHECK_GPU(a_ssums);
+  const int64_t M = in_feats.size(0), K = in_feats.size(1), N = kernel.size(0);
+  TORCH_CHECK(w_szs.scalar_type() == at::kHalf && w_szs.numel() == N && w_szs.is_contiguous() &&
+                  a_ssums.scalar_type() == at::kHalf && a_ssums.numel() == M && a_ssums.is_contiguous(),
+              "qserve_w4a8_per_chn_gemm: w_szs [N] and a_ssums [M] must be contiguous float16");
+  const c10::OptionalDeviceGuard guard(in_feats.device());
+  SGLK_CALL(sglk_qserve_w4a8_per_chn_gemm(stream_of(in_feats), out_feats.data_ptr(), in_feats.data_ptr(), kernel.data_ptr(),
+                                          wscales.data_ptr(), ascales.data_ptr(), w_szs.data_ptr(), a_ssums.data_ptr(), M, N,
+                                          K, in_feats.stride(0), out_feats.stride(0)));
+}
+
+void qserve_w4a8_per_group_gemm(const Tensor& in_feats, const Tensor& kernel, const Tensor& zeros, const Tensor& scales_i8,
+                                const Tensor& wscales, const Tensor& ascales, Tensor& out_feats) {
+  qserve_common("qserve_w4a8_per_group_gemm", in_feats, kernel, wscales, ascales, out_feats);
+  CHECK_GPU(zeros);
+  CHECK_GPU(scales_i8);
+  const int64_t M = in_feats.size(0), K = in_feats.size(1), N = kernel.size(0);
+  TORCH_CHECK(zeros.scalar_type() == at::kChar && scales_i8.scalar_type() == at::kChar && zeros.is_contiguous() &&
+                  scales_i8.is_contiguous() && zeros.numel() == (K / 128) * N && scales_i8.numel() == (K / 128) * N,
+              "qserve_w4a8_per_group_gemm: zeros and scales_i8 must be contiguous int8 [K/128, N]");
+  const c10::OptionalDeviceGuard guard(in_feats.device());
+  SGLK_CALL(sglk_qserve_w4a8_per_group_gemm(stream_of(in_feats), out_feats.data_ptr(), in_feats.data_ptr(),
+                                            kernel.data_ptr(), zeros.data_ptr(), scales_i8.data_ptr(), wscales.data_ptr(),
+                                            ascales.data_ptr(), M, N, K, in_feats.stride(0), out_feats.stride(0)));
+}
+
 // ---- flash_mla_decode (reference src/sycl/mla_decode.cpp:135-175, :192-223) ------------------
 
 void flash_mla_decode(Tensor& out, Tensor& q_nope, Tensor& q_pe, Tensor& kv_c_and_k_pe_cache, Tensor& seq_lens,
@@ -904,6 +955,14 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
   m.impl("fwd", c10::kCUDA, &mha_fwd);
 
   // reference src/torch_extension_sycl.cc:362-368
+  m.def(
+      "qserve_w4a8_per_chn_gemm(Tensor _in_feats, Tensor _kernel, Tensor _wscales, Tensor _ascales, Tensor _w_szs, "
+      "Tensor _a_ssums, Tensor! _out_feats) -> ()");
+  m.impl("qserve_w4a8_per_chn_gemm", c10::kCUDA, &qserve_w4a8_per_chn_gemm);
+  m.def(
+      "qserve_w4a8_per_group_gemm(Tensor _in_feats, Tensor _kernel, Tensor _zeros, Tensor _scales_i8, Tensor _wscales, "
+      "Tensor _ascales, Tensor! _out_feats) -> ()");
+  m.impl("qserve_w4a8_per_group_gemm", c10::kCUDA, &qserve_w4a8_per_group_gemm);
   m.def("flash_mla_get_workspace_size", &flash_mla_get_workspace_size);
   m.def(
       "flash_mla_decode(Tensor! out, Tensor! q_nope, Tensor! q_pe, Tensor! kv_c_and_k_pe_cache, Tensor! seq_lens,"

@@ -90,3 +90,35 @@ def sgl_per_token_group_quant_8bit(
 # legacy names kept by the reference (gemm.py:124-126)
 sgl_per_token_group_quant_fp8 = sgl_per_token_group_quant_8bit
 sgl_per_token_group_quant_int8 = sgl_per_token_group_quant_8bit
+
+
+def qserve_w4a8_per_chn_gemm(
+    in_feats: torch.Tensor,
+    kernel: torch.Tensor,
+    wscales: torch.Tensor,
+    ascales: torch.Tensor,
+    w_szs: torch.Tensor,
+    a_ssums: torch.Tensor,
+    out_feats: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Reference python/sgl_kernel/gemm.py:314-333 (out dtype float16 only)."""
+    if out_feats is None:
+        out_feats = torch.empty((in_feats.shape[0], kernel.shape[0]), device=in_feats.device, dtype=torch.float16)
+    torch.ops.sgl_kernel.qserve_w4a8_per_chn_gemm.default(in_feats, kernel, wscales, ascales, w_szs, a_ssums, out_feats)
+    return out_feats
+
+
+def qserve_w4a8_per_group_gemm(
+    in_feats: torch.Tensor,
+    kernel: torch.Tensor,
+    zeros: torch.Tensor,
+    scales_i8: torch.Tensor,
+    wscales: torch.Tensor,
+    ascales: torch.Tensor,
+    out_feats: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Reference python/sgl_kernel/gemm.py:336-355 (out dtype float16 only)."""
+    if out_feats is None:
+        out_feats = torch.empty((in_feats.shape[0], kernel.shape[0]), device=in_feats.device, dtype=torch.float16)
+    torch.ops.sgl_kernel.qserve_w4a8_per_group_gemm.default(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_feats)
+    return out_feats

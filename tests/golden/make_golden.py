@@ -197,6 +197,38 @@ def gen_mla_prefill():
     save("mla_prefill", cases)
 
 
+def gen_qserve():
+    """tests/test_qserve_w4a8_per_chn_gemm.py and ..._per_group_gemm.py: quantisers, repacking and references."""
+    import types as _types
+    sys.modules.setdefault("utils", _types.SimpleNamespace(get_device=lambda: torch.device("cpu")))
+    tc = _import_ref("test_qserve_w4a8_per_chn_gemm")
+    tg = _import_ref("test_qserve_w4a8_per_group_gemm")
+    cases = {"chn": [], "group": []}
+    torch.manual_seed(0)
+    for M, N, K in [(5, 64, 128), (16, 128, 512), (33, 96, 256)]:
+        a = torch.randn(M, K) * 0.01
+        b = torch.randn(N, K) * 0.01
+        a_q, a_scale = tc.sym_quantize_tensor(a)
+        b_q, b_scale, b_zero = tc.asym_quantize_tensor(b)
+        w, ws, wsz = tc.convert_to_qserve_format(b_q, b_scale, b_zero)
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):  # the reference function prints shapes
+            ref = tc.torch_w4a8_per_chn_gemm(a_q.float(), b_q.float(), a_scale.float(), b_scale.float(), b_zero.float(), torch.float32)
+        cases["chn"].append(dict(a=a, b=b, a_q=a_q, a_scale=a_scale, b_q=b_q, b_scale=b_scale, b_zero=b_zero, packed=w,
+                                 wscales=ws, w_szs=wsz, a_ssums=a.sum(dim=-1, keepdim=True).to(torch.float16),
+                                 out=ref.to(torch.float16)))
+    for M, N, K in [(5, 64, 128), (16, 128, 512), (33, 96, 256)]:
+        a = torch.randn(M, K) * 0.01
+        b = torch.randn(N, K) * 0.01
+        a_q, a_scale = tg.sym_quantize_tensor(a)
+        b_q, chn, s8, z8 = tg.progressive_group_quantize_tensor(b, 128)
+        w, chn_f, s8_f, z8_f = tg.convert_to_qserve_format(b_q, chn, s8, z8, 128)
+        ref = tg.torch_w4a8_per_group_gemm(a_q, b_q, a_scale, chn, s8, z8, 128, torch.float16)
+        cases["group"].append(dict(a=a, b=b, a_q=a_q, a_scale=a_scale, b_q=b_q, chn_scale=chn, scale_i8=s8, zero_i8=z8,
+                                   packed=w, wscales=chn_f, scales_i8=s8_f, zeros=z8_f, out=ref))
+    save("qserve_w4a8", cases)
+
+
 def gen_moe():
     t = _import_ref("test_moe_gemm")
     cases = {"grouped_mm": [], "fused": []}
@@ -294,6 +326,7 @@ GENERATORS = {
     "topk_softmax": gen_topk_softmax,
     "mla_decode": gen_mla_decode,
     "mla_prefill": gen_mla_prefill,
+    "qserve_w4a8": gen_qserve,
     "norm": gen_norm,
     "activation": gen_activation,
     "quant": gen_quant,

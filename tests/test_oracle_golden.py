@@ -160,3 +160,29 @@ def test_mla_prefill_oracle_matches_reference_vectors():
                                c["seq_lens_k"], causal=True)
         tol = 1e-2 if c["q_nope"].dtype == torch.bfloat16 else 1e-3  # reference tolerance (:235-236)
         torch.testing.assert_close(out.float(), c["out"].float(), atol=tol, rtol=tol)
+
+
+def test_qserve_oracle_matches_reference_vectors():
+    """oracle.qserve (quantisers, 32x32 repacking, both GEMM references) vs the outputs of the reference's own test
+    functions (tests/test_qserve_w4a8_per_chn_gemm.py, tests/test_qserve_w4a8_per_group_gemm.py)."""
+    from oracle import qserve as oq
+
+    g = load_golden("qserve_w4a8")
+    for c in g["chn"]:
+        a_q, a_scale = oq.sym_quantize(c["a"])
+        b_q, b_scale, b_zero = oq.asym_quantize_u4(c["b"])
+        assert torch.equal(a_q, c["a_q"]) and torch.equal(a_scale, c["a_scale"])
+        assert torch.equal(b_q, c["b_q"]) and torch.equal(b_scale, c["b_scale"]) and torch.equal(b_zero, c["b_zero"])
+        w, ws, wsz = oq.per_chn_inputs(b_q, b_scale, b_zero)
+        assert torch.equal(w, c["packed"]) and torch.equal(ws, c["wscales"]) and torch.equal(wsz, c["w_szs"])
+        out = oq.w4a8_per_chn_gemm(a_q, b_q, a_scale, b_scale, b_zero)
+        torch.testing.assert_close(out, c["out"], rtol=1e-3, atol=1e-2)  # reference tolerance (:111)
+    for c in g["group"]:
+        b_q, chn, s8, z8 = oq.progressive_group_quantize(c["b"])
+        assert torch.equal(b_q, c["b_q"]) and torch.equal(chn, c["chn_scale"])
+        assert torch.equal(s8, c["scale_i8"]) and torch.equal(z8, c["zero_i8"])
+        w, ws, s8f, z8f = oq.per_group_inputs(b_q, chn, s8, z8)
+        assert torch.equal(w, c["packed"]) and torch.equal(ws, c["wscales"])
+        assert torch.equal(s8f, c["scales_i8"]) and torch.equal(z8f, c["zeros"])
+        out = oq.w4a8_per_group_gemm(c["a_q"], b_q, c["a_scale"], chn, s8, z8)
+        torch.testing.assert_close(out, c["out"], rtol=1e-3, atol=1e-5)  # reference tolerance (:175)
