@@ -135,6 +135,44 @@ def side_metrics(sgl_kernel, dev):
         out[f"flash_mla_decode_bs128_seq8192_h{H}_GBs"] = round(nbytes / ms / 1e6, 1)
         out[f"flash_mla_decode_bs128_seq8192_h{H}_ms"] = round(ms, 4)
         out[f"flash_mla_decode_bs128_seq8192_h{H}_TFLOPs"] = round(2.0 * bs * H * seq * (576 + 512) / ms / 1e9, 1)
+    del cache, table, seq_lens
+    # fwd (flash attention), BASELINE configs[2]: bs=16, 32 q heads / 8 kv heads, d=128, seq=4096, paged (64), bf16.
+    from sgl_kernel.flash_attn import flash_attn_with_kvcache
+
+    bs, hq, hk, d, seq, page = 16, 32, 8, 128, 4096, 64
+    n_pages = bs * seq // page
+    kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+    vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+    pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, seq // page)
+    lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+    qd = torch.randn(bs, 1, hq, d, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, page_table=pt, causal=True), iters=20)
+    out["fwd_decode_bs16_h32_kv8_d128_seq4096_GBs"] = round((kc.numel() + vc.numel() + 2 * qd.numel()) * 2 / ms / 1e6, 1)
+    out["fwd_decode_bs16_h32_kv8_d128_seq4096_ms"] = round(ms, 4)
+    qp = torch.randn(bs * seq, hq, d, device=dev, dtype=torch.bfloat16)
+    cu = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * seq
+    ms = timeit(lambda: flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                max_seqlen_q=seq, causal=True), iters=5)
+    out["fwd_prefill_causal_bs16_h32_kv8_d128_seq4096_TFLOPs"] = round(4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9, 1)
+    out["fwd_prefill_causal_bs16_h32_kv8_d128_seq4096_ms"] = round(ms, 4)
+    del kc, vc, qp, qd
+    # fused_experts int4 W4A16, BASELINE configs[4]: Mixtral-8x7B (8 experts, top-2, hidden 4096, inter 14336, group 128)
+    E, Hd, I, gs, topk = 8, 4096, 14336, 128, 2
+    w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
+    w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
+    s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01
+    s2 = torch.rand(E, Hd, I // gs, device=dev).to(torch.bfloat16) * 0.01
+    for T in (64, 2048):
+        xx = torch.randn(T, Hd, device=dev, dtype=torch.bfloat16) * 0.1
+        logits = torch.randn(T, E, device=dev, dtype=torch.bfloat16)
+        tw = torch.empty(T, topk, device=dev, dtype=torch.float32)
+        ti = torch.empty(T, topk, device=dev, dtype=torch.int32)
+        sgl_kernel.topk_softmax(tw, ti, logits, True)
+        ms = timeit(lambda: sgl_kernel.fused_experts(xx, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2),
+                    iters=5)
+        out[f"fused_experts_w4a16_mixtral_T{T}_ms"] = round(ms, 4)
+        out[f"fused_experts_w4a16_mixtral_T{T}_TFLOPs"] = round(2.0 * T * topk * 3 * Hd * I / ms / 1e9, 1)
+        out[f"fused_experts_w4a16_mixtral_T{T}_weight_GBs"] = round((w1.numel() + w2.numel()) / ms / 1e6, 1)
     return out
 
 
