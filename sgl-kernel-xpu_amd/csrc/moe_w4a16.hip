@@ -93,8 +93,20 @@ __device__ __forceinline__ void transpose4(uint32_t (&d)[4]) {
   }
 }
 
-template <typename T, int MT, int NW>
-__global__ __launch_bounds__(256) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
+template <int I>
+struct IntC {
+  static constexpr int value = I;
+};
+template <typename F>
+__device__ __forceinline__ void static_for4(F&& f) {
+  f(IntC<0>{});
+  f(IntC<1>{});
+  f(IntC<2>{});
+  f(IntC<3>{});
+}
+
+template <typename T, int MT, int NW, int PB>  // PB: scale groups per 128-deep block (4, 2, 1 for groups 32, 64, >= 128)
+__global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
                                                         const uint8_t* __restrict__ wq, const T* __restrict__ scales,
                                                         const T* __restrict__ zeros, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
@@ -123,32 +135,44 @@ __global__ __launch_bounds__(256) void moe_w4a16_kernel(T* __restrict__ out, con
   const int n_base = blockIdx.y * BN + wave * (NW * 16);
 
   const int kgroups = K >> group_shift;         // scales per row
-  const int seg_steps = group_shift >= 7 ? 4 : (1 << (group_shift - 5));  // 32-wide k steps per scale segment
   const bool has_zp = zeros != nullptr;
 
-  // ---- per-lane weight / scale rows (clamped; stores are guarded)
-  const uint8_t* wrow[NW];
-  const T* srow[NW];
-  const T* zrow[NW];
+  // ---- per-lane weight / scale rows (clamped; stores are guarded): 32-bit offsets from per-expert bases
+  const uint8_t* wexp = wq + (int64_t)e * N * (K / 2);
+  const T* sexp = scales + (int64_t)e * N * kgroups;
+  // without zero points the zero-point loads read the scales instead (values unused): an unconditional load keeps
+  // the K loop free of a branch whose other side would have to wait for every load in flight (WAW on the register)
+  const T* zexp = has_zp ? zeros + (int64_t)e * N * kgroups : sexp;
+  uint32_t woff[NW], soff[NW];
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
     int n = n_base + nt * 16 + l15;
     n = n < N ? n : N - 1;
-    wrow[nt] = wq + ((int64_t)e * N + n) * (K / 2) + 16 * g;
-    srow[nt] = scales + ((int64_t)e * N + n) * kgroups;
-    zrow[nt] = has_zp ? zeros + ((int64_t)e * N + n) * kgroups : nullptr;
+    woff[nt] = (uint32_t)n * (uint32_t)(K / 2) + 16 * g;
+    soff[nt] = (uint32_t)n * (uint32_t)kgroups;
   }
 
-  // ---- activation staging: thread handles 16-byte chunks (row, c) of the [BM][128] tile
-  auto stage_a = [&](int kb, int buf) {
-    char* base = smem + buf * (BM * 256);
+  // ---- activation staging: thread handles 16-byte chunks (row, c) of the [BM][128] tile. Split in a load (global ->
+  // registers) and a store (registers -> LDS) one iteration later: a load consumed in the iteration that issues it
+  // exposes a full memory latency per 128-deep block (that alone was 200 us of a K = 14336 decode GEMM).
+  auto load_a = [&](int kb, v4i (&r)[MT]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int idx = i * 256 + tid;
       const int row = idx >> 4, c = idx & 15;
       const int grow = m0 + (row < m_valid ? row : m_valid - 1);
-      v4i v = {0, 0, 0, 0};
-      if (kb * 128 + c * 8 < K) v = *reinterpret_cast<const v4i*>(act + (int64_t)grow * K + kb * 128 + c * 8);
+      const bool in = kb * 128 + c * 8 < K;  // past K: read k = 0 instead and zero the registers (no branch)
+      const v4i v = *reinterpret_cast<const v4i*>(act + (int64_t)grow * K + (in ? kb * 128 + c * 8 : 0));
+      r[i][0] = in ? v[0] : 0; r[i][1] = in ? v[1] : 0; r[i][2] = in ? v[2] : 0; r[i][3] = in ? v[3] : 0;
+    }
+  };
+  auto store_a = [&](int buf, const v4i (&r)[MT]) {
+    char* base = smem + buf * (BM * 256);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx >> 4, c = idx & 15;
+      const v4i v = r[i];
       // element order (a0,a4,a1,a5,a2,a6,a3,a7) to match expand_nibbles
       v4i p;
       p[0] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x05040100u);
@@ -169,32 +193,79 @@ __global__ __launch_bounds__(256) void moe_w4a16_kernel(T* __restrict__ out, con
       part[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
     }
   }
-  const v4i ones = {(int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes};
-
   const int nkb = (K + 127) >> 7;   // K is a multiple of 32; the last 128-block may hold 1..3 k steps
   const int ksteps = K >> 5;
-  uint32_t wd[NW][4], wnext[NW][4];
-#pragma unroll
-  for (int nt = 0; nt < NW; ++nt) {
-    v4i t = {0, 0, 0, 0};
-    if (32 * g < K) t = *reinterpret_cast<const v4i*>(wrow[nt]);
-    wnext[nt][0] = t[0]; wnext[nt][1] = t[1]; wnext[nt][2] = t[2]; wnext[nt][3] = t[3];
-  }
-  stage_a(0, 0);
+  const v4i ones = {(int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes};
 
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int buf = kb & 1;
-    __syncthreads();  // tile kb is staged; everyone is done reading the other buffer
-    if (kb + 1 < nkb) stage_a(kb + 1, buf ^ 1);
+  // weights run two 128-deep blocks ahead of the MFMAs, scales / zero points one block ahead: at decode sizes the
+  // kernel is a latency-bound HBM stream and a load consumed in the iteration that issued it stalls every wave
+  // All three streams (weights, scales / zero points, activations) run kD 128-deep blocks ahead of the MFMAs in
+  // register rings with static slots (the K loop is unrolled kD times): at decode sizes an iteration is ~0.15 us of
+  // MFMA work against ~2 us of memory latency, and a load consumed close to where it was issued stalls the wave.
+  constexpr int kD = 2;
+  uint32_t wd[NW][4], wq_[kD][NW][4];
+  // weights past K are never multiplied by anything but zero activations: any valid address will do (block 0)
+  auto load_w = [&](int kb, uint32_t (&dst)[NW][4]) {
+    const uint32_t koff = (kb * 128 + 32 * g < K) ? (uint32_t)kb * 64u : 0u;
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+      const v4i t = *reinterpret_cast<const v4i*>(wexp + woff[nt] - 16 * g + ((kb * 128 + 32 * g < K) ? 16 * g : 0) + koff);
+      dst[nt][0] = t[0]; dst[nt][1] = t[1]; dst[nt][2] = t[2]; dst[nt][3] = t[3];
+    }
+  };
+  T sq_[kD][NW][PB], zq_[kD][NW][PB];
+  auto load_s = [&](int kb, T (&sd)[NW][PB], T (&zd)[NW][PB]) {
+    const int kg0 = (kb * 128) >> group_shift;
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) wd[nt][t] = wnext[nt][t];
-      if (kb + 1 < nkb) {
-        v4i t = {0, 0, 0, 0};
-        if ((kb + 1) * 128 + 32 * g < K) t = *reinterpret_cast<const v4i*>(wrow[nt] + (int64_t)(kb + 1) * 64);
-        wnext[nt][0] = t[0]; wnext[nt][1] = t[1]; wnext[nt][2] = t[2]; wnext[nt][3] = t[3];
+      for (int i = 0; i < PB; ++i) {
+        int kg = kg0 + i;
+        kg = kg < kgroups ? kg : kgroups - 1;
+        sd[nt][i] = sexp[soff[nt] + kg];
+        zd[nt][i] = zexp[soff[nt] + kg];
       }
+    }
+  };
+  v4i aq_[kD][MT];
+#pragma unroll
+  for (int d = 0; d < kD; ++d) {
+    load_w(d, wq_[d]);
+    load_s(d, sq_[d], zq_[d]);
+    load_a(d, aq_[d]);
+  }
+  store_a(0, aq_[0]);
+  load_a(kD, aq_[0]);  // slot 0 now carries block kD (zeros past K)
+
+  // (blocks past K run on zero activations: the trip count is padded to a multiple of kD, the body has no exit)
+  for (int kb0 = 0; kb0 < nkb; kb0 += kD) {
+#pragma unroll
+  for (int u = 0; u < kD; ++u) {
+    const int kb = kb0 + u;
+    const int buf = kb & 1;
+    // tile kb is staged; everyone is done reading the other buffer. Not __syncthreads(): that waits vmcnt(0) and
+    // would drain the prefetch rings every iteration (measured: 3.7 us per 128-deep block instead of ~0.4)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // block kb+1 sits in slot (u+1) % kD (slot 0 after the wrap was refilled with block kb0 + kD): stage it, then
+    // refill that slot with block kb + 1 + kD
+    store_a(buf ^ 1, aq_[(u + 1) % kD]);
+    load_a(kb + 1 + kD, aq_[(u + 1) % kD]);
+    T sc[NW][PB], zc[NW][PB];
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wd[nt][t] = wq_[u][nt][t];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        sc[nt][i] = sq_[u][nt][i];
+        zc[nt][i] = zq_[u][nt][i];
+      }
+    }
+    load_w(kb + kD, wq_[u]);
+    load_s(kb + kD, sq_[u], zq_[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
       if (!has_zp) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) wd[nt][t] ^= 0x88888888u;  // two's complement -> offset binary (zp 8)
@@ -202,9 +273,9 @@ __global__ __launch_bounds__(256) void moe_w4a16_kernel(T* __restrict__ out, con
       transpose4(wd[nt]);  // now wd[nt][j] = codes of k = 128 kb + 32 j + 8 g .. + 7 of row n
     }
     const char* abase = smem + buf * (BM * 256);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (kb * 4 + j >= ksteps) break;
+    static_for4([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      // (k steps past K multiply zero activations: no tail branch)
       v4i wf[NW];
 #pragma unroll
       for (int nt = 0; nt < NW; ++nt) wf[nt] = expand_nibbles<T>(wd[nt][j]);
@@ -216,14 +287,14 @@ __global__ __launch_bounds__(256) void moe_w4a16_kernel(T* __restrict__ out, con
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
       }
-      // end of a scale segment: fold the exact integer partial sums into the fp32 accumulators
-      const int kstep = kb * 4 + j;
-      if (((kstep + 1) & (seg_steps - 1)) == 0) {
-        const int kg = (kstep * 32) >> group_shift;
+      // end of a scale segment (compile-time position: every 4 / PB steps; 256-wide groups fold their two halves
+      // separately with the same scale): fold the exact integer partial sums into the fp32 accumulators
+      if constexpr ((j + 1) % (4 / PB) == 0) {
+        constexpr int ki = j / (4 / PB);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) {
-          const float s = (float)srow[nt][kg];
-          const float z = has_zp ? 16.0f + (float)zrow[nt][kg] : 24.0f;
+          const float s = (float)sc[nt][ki];
+          const float z = has_zp ? 16.0f + (float)zc[nt][ki] : 24.0f;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -237,7 +308,10 @@ __global__ __launch_bounds__(256) void moe_w4a16_kernel(T* __restrict__ out, con
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) asum[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
       }
-    }
+      // the body is one basic block now: without fences the scheduler interleaves all steps and spills
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
   }
 
   // ---- epilogue: lane owns out[m = 16 mt + 4 g + r][n = n_base + 16 nt + l15]
@@ -257,15 +331,23 @@ __global__ __launch_bounds__(256) void moe_w4a16_kernel(T* __restrict__ out, con
   }
 }
 
-template <typename T, int MT, int NW>
-static int launch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
+template <typename T, int MT, int NW, int PB>
+static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
   constexpr int BM = 16 * MT, BN = 64 * NW;
   const int64_t max_mblocks = total_m / BM + E;  // sum_e ceil(rows_e / BM) <= total_m / BM + E
   dim3 grid((unsigned)max_mblocks, (unsigned)cdiv(N, BN));
-  moe_w4a16_kernel<T, MT, NW><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, (const T*)scales,
-                                                    (const T*)zeros, bias, rows, E, N, K, group_shift);
+  moe_w4a16_kernel<T, MT, NW, PB><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, (const T*)scales,
+                                                        (const T*)zeros, bias, rows, E, N, K, group_shift);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
+}
+
+template <typename T, int MT, int NW>
+static int launch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
+                  const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
+  if (group_shift == 5) return launch_pb<T, MT, NW, 4>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  if (group_shift == 6) return launch_pb<T, MT, NW, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  return launch_pb<T, MT, NW, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
 }
 
 template <typename T>
