@@ -423,9 +423,10 @@ struct TileDesc {
   void* po;           // out + m0 * ldc + n0
   uint32_t nrec_a, nrec_b, nrec_s, nrec_o;  // bytes in range of the four resources (0: nothing)
   int ncols;                                // valid columns of the tile (<= BN)
+  int wrows;                                // rows per wm half of the wave grid: 128 (256-row tile) or 64 (128-row half tile)
 };
 
-template <typename OutT, bool HW_SCALE, int PROBE>
+template <typename OutT, bool HW_SCALE, int PROBE, int MS>  // MS m-steps per K block: 8 = 256-row tiles, 4 = 128-row half tiles
 __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -447,10 +448,22 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   const int run_len = q + (xcd < rem ? 1 : 0);
   const int nblk_max = (N + 127) / 128 - 1;
 
-  auto describe = [&](int local) -> TileDesc {  // local index inside the XCD's run; >= run_len: the null tile
+  // Units of this workgroup. When the XCD's run of tiles does not divide by its workgroups and the remainder fits
+  // twice, the last partial round is cut into 128-row half tiles and handed to a second launch of this kernel with
+  // MS = 4 (same code, 4 m-steps per K block), so that it costs ~0.6 of a round instead of a whole one: 896 tiles on
+  // 256 CUs = 3 rounds (launch MS = 8) + 128 tiles -> 256 halves, one per workgroup (launch MS = 4).
+  const int rounds = run_len / slots, left = run_len - rounds * slots;
+  const bool split = left > 0 && 2 * left <= slots;
+  constexpr bool kHalf = MS == 4;
+  const int n_units = kHalf ? ((split && slot < 2 * left) ? 1 : 0) : (split ? rounds : rounds + (slot < left ? 1 : 0));
+  if (n_units == 0) return;
+
+  auto describe = [&](int unit) -> TileDesc {  // unit >= n_units: the null tile
     TileDesc d;
-    const bool live = local < run_len;
-    const int tile = run_first + (live ? local : 0);
+    bool live = unit < n_units;
+    constexpr bool half = kHalf;
+    const int local = !live ? 0 : half ? rounds * slots + (slot >> 1) : slot + unit * slots;
+    const int tile = run_first + local;
     constexpr int GM = 4;
     const int group = tile / (GM * tiles_n);
     const int first_m = group * GM;
@@ -458,9 +471,12 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     const int in_group = tile - group * GM * tiles_n;
     const int tm = __builtin_amdgcn_readfirstlane(first_m + in_group % gsz);
     const int tn = __builtin_amdgcn_readfirstlane(in_group / gsz);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int rows_a = (M - m0) < BM ? (M - m0) : BM, rows_b = (N - n0) < BN ? (N - n0) : BN;
+    const int trows = half ? BM / 2 : BM;
+    const int m0 = tm * BM + ((half && (slot & 1)) ? BM / 2 : 0), n0 = tn * BN;
+    const int rows_a = (M - m0) < trows ? (M - m0) : trows, rows_b = (N - n0) < BN ? (N - n0) : BN;
+    live = live && rows_a > 0;  // the lower half of an edge tile may be empty
     d.ncols = rows_b;
+    d.wrows = MS * 16;
     d.pa = a + (int64_t)m0 * lda;
     d.pb = b + (int64_t)n0 * ldb;
     d.ps = sa + (int64_t)m0 * sa_sm;
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     d.pa = c ? x.pa : y.pa;  d.pb = c ? x.pb : y.pb;  d.ps = c ? x.ps : y.ps;  d.sbw = c ? x.sbw : y.sbw;
     d.po = c ? x.po : y.po;
     d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_s = c ? x.nrec_s : y.nrec_s;
-    d.nrec_o = c ? x.nrec_o : y.nrec_o;  d.ncols = c ? x.ncols : y.ncols;
+    d.nrec_o = c ? x.nrec_o : y.nrec_o;  d.ncols = c ? x.ncols : y.ncols;  d.wrows = c ? x.wrows : y.wrows;
     return d;
   };
 
@@ -530,10 +546,12 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   typedef __attribute__((address_space(3))) const float* lds_f_ptr;
 
   // stores: lane (j, g) owns row wm*128 + mf*16 + j, columns wn*64 + h*32 + g*8 .. +7 (h = 0, 1) of the tile
-  const uint32_t orow_off = (uint32_t)(((int64_t)(wm * 128 + j) * ldc + wn * 64 + g * 8) * (int64_t)sizeof(OutT));
+  const uint32_t orow_off_full = (uint32_t)(((int64_t)(wm * 128 + j) * ldc + wn * 64 + g * 8) * (int64_t)sizeof(OutT));
+  const uint32_t orow_off_half = (uint32_t)(((int64_t)(wm * 64 + j) * ldc + wn * 64 + g * 8) * (int64_t)sizeof(OutT));
   auto store_rows = [&](const TileDesc& d, const v4f (&accm)[4], int mf) {
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
     const int soff = __builtin_amdgcn_readfirstlane(mf * 16 * (int)ldc * (int)sizeof(OutT));
+    const uint32_t orow_off = MS == 8 ? orow_off_full : orow_off_half;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       Vec<OutT, 8> v;
@@ -571,10 +589,25 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   float sbv;
   int gblk = 0;  // K blocks done so far by this workgroup: its parity is the running LDS stage
 
-  // One K block. d1/kb1, d2/kb2: blocks +1 and +2 of the pipeline. FIRST: first block of a tile (stores tile
-  // `prv`, restarts the accumulators).
-#define SGLK_STEP(mf, FIRST)                                                                                   \
-  {                                                                                                            \
+  // One K block of a tile with MS m-steps (8: 256-row tile, 4: 128-row half tile). d1/kb1, d2/kb2: blocks +1 and
+  // +2 of the pipeline (possibly in the next unit, whose format may differ: its per-wave row block comes from the
+  // descriptor). FIRST: first block of a unit (stores unit `prv`, which is always a whole tile or nothing, and
+  // restarts the accumulators).
+#define SGLK_MMA_STEP(mf, FIRST, MS_)                                                                             \
+    const float sc = raw[(mf) & 1] * sbv;                                                                      \
+    const v8i mfrag = SGLK_FRAG(mlo[(mf) & 1], mhi[(mf) & 1]);                                                 \
+    v4f cur4[4];                                                                                               \
+    _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
+        cur4[nf] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[nf], nhi[nf]), mfrag, zero);                              \
+    if (FIRST && 2 * (mf) + 1 < (MS_)) {                                                                       \
+      store_rows(prv, acc[2 * (mf)], 2 * (mf));                                                                \
+      store_rows(prv, acc[2 * (mf) + 1], 2 * (mf) + 1);                                                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
+            acc[mf][nf][r] = FIRST ? cur4[nf][r] * sc : __builtin_fmaf(cur4[nf][r], sc, acc[mf][nf][r]);
+#define SGLK_STEP(mf, FIRST, MS)                                                                               \
+  if constexpr ((mf) < (MS) - 1) {                                                                             \
     SGLK_RD16(mlo[((mf) + 1) & 1], a_lo, ((mf) + 1) * 2048);                                                   \
     SGLK_RD16(mhi[((mf) + 1) & 1], a_hi, ((mf) + 1) * 2048);                                                   \
     SGLK_RD4(raw[((mf) + 1) & 1], ts_addr, ((mf) + 1) * 64);                                                   \
@@ -586,21 +619,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     } else {                                                                                                   \
       asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(mlo[(mf) & 1]), "+v"(mhi[(mf) & 1]), "+v"(raw[(mf) & 1]));   \
     }                                                                                                          \
-    const float sc = raw[(mf) & 1] * sbv;                                                                      \
-    const v8i mfrag = SGLK_FRAG(mlo[(mf) & 1], mhi[(mf) & 1]);                                                 \
-    v4f cur4[4];                                                                                               \
-    _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
-        cur4[nf] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[nf], nhi[nf]), mfrag, zero);                              \
-    if (FIRST && (mf) < 4) {                                                                                   \
-      store_rows(prv, acc[2 * (mf)], 2 * (mf));                                                                \
-      store_rows(prv, acc[2 * (mf) + 1], 2 * (mf) + 1);                                                        \
-    }                                                                                                          \
-    _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
-            acc[mf][nf][r] = FIRST ? cur4[nf][r] * sc : __builtin_fmaf(cur4[nf][r], sc, acc[mf][nf][r]);       \
+    SGLK_MMA_STEP(mf, FIRST, MS)                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
-#define SGLK_BLOCK(FIRST)                                                                                      \
+#define SGLK_BLOCK(FIRST, MS)                                                                                  \
   {                                                                                                            \
     const int s = gblk & 1;                                                                                    \
     const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);                                             \
@@ -612,10 +634,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     {                                                                                                          \
       int fo = frag_off_a;                                                                                     \
       asm volatile("" : "+v"(fo));                                                                             \
-      const uint32_t a_lo = sbase + (uint32_t)(wm * 128 * 128) + (uint32_t)fo, a_hi = a_lo ^ 64u;              \
-      const uint32_t ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((fo >> 7) << 2); \
-      SGLK_STEP(0, FIRST) SGLK_STEP(1, FIRST) SGLK_STEP(2, FIRST) SGLK_STEP(3, FIRST)                          \
-      SGLK_STEP(4, FIRST) SGLK_STEP(5, FIRST) SGLK_STEP(6, FIRST)                                              \
+      const uint32_t a_lo = sbase + (uint32_t)(wm * ((MS) * 16) * 128) + (uint32_t)fo, a_hi = a_lo ^ 64u;       \
+      const uint32_t ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * ((MS) * 16) * 4) + (uint32_t)((fo >> 7) << 2); \
+      SGLK_STEP(0, FIRST, MS) SGLK_STEP(1, FIRST, MS) SGLK_STEP(2, FIRST, MS) SGLK_STEP(3, FIRST, MS)          \
+      SGLK_STEP(4, FIRST, MS) SGLK_STEP(5, FIRST, MS) SGLK_STEP(6, FIRST, MS)                                  \
     }                                                                                                          \
     /* the block's barrier: next block landed everywhere, nobody reads stage s any more */                    \
     float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
@@ -625,14 +647,15 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
                  : "memory");                                                                                  \
     asm volatile("" : "+v"(sbv_next));                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
-    /* m-step 7, overlapped with the next block's first LDS reads */                                          \
+    /* last m-step, overlapped with the next block's first LDS reads */                                       \
     {                                                                                                          \
+      constexpr int kLast = (MS) - 1;                                                                          \
       const float sc = raw[1] * sbv;                                                                           \
       int foa = frag_off_a, fob = frag_off_b;                                                                  \
       asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
       const uint32_t nb_lo = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fob, nb_hi = nb_lo ^ 64u; \
-      const uint32_t na_lo = nbase + (uint32_t)(wm * 128 * 128) + (uint32_t)foa, na_hi = na_lo ^ 64u;          \
-      const uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)((foa >> 7) << 2);    \
+      const uint32_t na_lo = nbase + (uint32_t)(wm * d1.wrows * 128) + (uint32_t)foa, na_hi = na_lo ^ 64u;     \
+      const uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * d1.wrows * 4) + (uint32_t)((foa >> 7) << 2); \
       const v8i mfrag = SGLK_FRAG(mlo[1], mhi[1]);                                                             \
       v4f cur4[4];                                                                                             \
       cur4[0] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[0], nhi[0]), mfrag, zero);                                   \
@@ -653,17 +676,17 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
       SGLK_RD16(nlo[3], nb_lo, kNfImm[3]);  SGLK_RD16(nhi[3], nb_hi, kNfImm[3]);                               \
       _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                         \
           _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                        \
-              acc[7][nf][r] = FIRST ? cur4[nf][r] * sc : __builtin_fmaf(cur4[nf][r], sc, acc[7][nf][r]);       \
+              acc[kLast][nf][r] = FIRST ? cur4[nf][r] * sc : __builtin_fmaf(cur4[nf][r], sc, acc[kLast][nf][r]); \
       sbv = sbv_next;                                                                                          \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
     ++gblk;                                                                                                    \
   }
 
-  int local = slot;
-  TileDesc cur = describe(local);
-  TileDesc prv = describe(run_len);  // the null tile: nothing to store yet
-  // ---- prologue: block 0 of the first tile lands, its resident fragments are read, part 0 of block 1 goes out
+  int unit = 0;
+  TileDesc cur = describe(0);
+  TileDesc prv = describe(n_units);  // the null tile: nothing to store yet
+  // ---- prologue: block 0 of the first unit lands, its resident fragments are read, parts 0, 1 of block 1 go out
 #pragma unroll
   for (int part = 0; part < 4; ++part) dma_part(cur, 0, 0, part);
   sbv = cur.sbw[0];
@@ -671,8 +694,8 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   asm volatile("" : "+v"(sbv));
   {
     const uint32_t b_lo = lds_base + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)frag_off_b, b_hi = b_lo ^ 64u;
-    const uint32_t a_lo = lds_base + (uint32_t)(wm * 128 * 128) + (uint32_t)frag_off_a, a_hi = a_lo ^ 64u;
-    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * 128 * 4) + (uint32_t)(j << 2);
+    const uint32_t a_lo = lds_base + (uint32_t)(wm * cur.wrows * 128) + (uint32_t)frag_off_a, a_hi = a_lo ^ 64u;
+    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * cur.wrows * 4) + (uint32_t)(j << 2);
     SGLK_RD16(nlo[0], b_lo, kNfImm[0]);  SGLK_RD16(nhi[0], b_hi, kNfImm[0]);
     SGLK_RD16(mlo[0], a_lo, 0);          SGLK_RD16(mhi[0], a_hi, 0);
     SGLK_RD4(raw[0], ts0, 0);
@@ -685,22 +708,23 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     dma_part(cur, 1, 1, 1);
   }
 
-  for (; local < run_len; local += slots) {
-    const TileDesc nxt = describe(local + slots);
+  for (; unit < n_units; ++unit) {
+    const TileDesc nxt = describe(unit + 1);
     {
       const int kb = 0;
-      SGLK_BLOCK(true)
+      SGLK_BLOCK(true, MS)
     }
-    for (int kb = 1; kb < nkb; ++kb) SGLK_BLOCK(false)
+    for (int kb = 1; kb < nkb; ++kb) SGLK_BLOCK(false, MS)
     prv = cur;
     cur = nxt;
   }
 #undef SGLK_BLOCK
 #undef SGLK_STEP
-  // the reads and DMA issued by the last step 7 have no consumer: drain them, then store the last tile
+#undef SGLK_MMA_STEP
+  // the reads and DMA issued by the last step have no consumer: drain them, then store the last unit
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int mf = 0; mf < 8; ++mf) store_rows(prv, acc[mf], mf);
+  for (int mf = 0; mf < MS; ++mf) store_rows(prv, acc[mf], mf);
 #undef SGLK_RD16
 #undef SGLK_RD4
 #undef SGLK_FRAG
@@ -718,15 +742,30 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   // persistent kernel: one workgroup per CU, a multiple of 8 so that every XCD gets the same number
   const unsigned pgrid = grid < (unsigned)num_cus() ? ((grid + 7) / 8) * 8 : (unsigned)num_cus();
   const bool persist_ok = K / BK >= 2 && N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)out % 16 == 0 && ldc < (1ll << 22);
+  // does any XCD cut its last partial round into half tiles (same rule as in the kernel)?
+  bool tail_halves = false;
+  {
+    const int slots = (int)pgrid >> 3, q = (int)grid >> 3, r8 = (int)grid & 7;
+    for (int len = q; len <= q + (r8 ? 1 : 0); ++len) {
+      const int left = len - (len / slots) * slots;
+      tail_halves = tail_halves || (left > 0 && 2 * left <= slots);
+    }
+  }
   const int variant = (!persist_ok && g_gemm_variant != 0 && g_gemm_variant != 1) ? 1 : g_gemm_variant;
 #define SGLK_GO_VAR(V, H, VAR)                                                                               \
   gemm_8bit_kernel<OutT, MODE, V, H, VAR><<<grid, 512, 0, st>>>(                                             \
       (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K,   \
       lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
 #define SGLK_GO_PIPE(V, H, P)                                                                                \
-  gemm_fp8_blockwise_persist_kernel<OutT, H, P><<<pgrid, 512, 0, st>>>(                                   \
-      (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,       \
-      sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
+  {                                                                                                          \
+    gemm_fp8_blockwise_persist_kernel<OutT, H, P, 8><<<pgrid, 512, 0, st>>>(                                 \
+        (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,     \
+        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n);                                                       \
+    if (tail_halves)                                                                                         \
+      gemm_fp8_blockwise_persist_kernel<OutT, H, P, 4><<<pgrid, 512, 0, st>>>(                               \
+          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,   \
+          sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n);                                                     \
+  }
 #define SGLK_GO(V, H)                                                                                        \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
     switch (variant) {                                                                                       \
