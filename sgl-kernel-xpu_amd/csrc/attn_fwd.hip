@@ -128,6 +128,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   const int my_qpos = row_ok ? my_row / G : 0;
   const int my_head = hk * G + (row_ok ? my_row % G : 0);
   const int q_abs = my_qpos + shift;
+  // bounds over the 16 rows of this wave (wave-uniform), for the interior-tile test of the main loop
+  const int wrow_first = row0 + wave * kRowsPerWave, wrow_last = wrow_first + kRowsPerWave - 1;
+  const bool wave_rows_ok = wrow_last < rows_total;
+  const int wave_qabs_lo = wrow_first / G + shift, wave_qabs_hi = (wrow_last < rows_total ? wrow_last : rows_total - 1) / G + shift;
 
   // ---- kv range visible to this workgroup (union over its rows), then this split's share of it
   const int last_row = (row0 + kBlockM < rows_total ? row0 + kBlockM : rows_total) - 1;
@@ -265,39 +269,63 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
         s0 = M::run(a0, qf[ks], s0);
         s1 = M::run(a1, qf[ks], s1);
       }
-      // logits in natural units, then masks
+      // Interior tiles (every key visible to every row of this wave, no softcap) take a short path: the softmax
+      // VALU work, not the MFMAs, bounds this kernel at head dim 128 (about 100 VALU ops per 16 x 32 logits with
+      // the masks against 16 MFMAs), so the mask arithmetic is skipped wherever a uniform test allows it.
       const int tb = t * kTile + 8 * (g4 & 1) + 4 * (g4 >> 1);
-      float z0[4], z1[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = s0[r] * p.scale, c = s1[r] * p.scale;
-        if (p.softcap > 0.f) {
-          a = p.softcap * tanhf(a / p.softcap);
-          c = p.softcap * tanhf(c / p.softcap);
-        }
-        const int k0 = tb + r, k1 = tb + 16 + r;
-        bool m0 = !row_ok || k0 >= seqlen_k, m1 = !row_ok || k1 >= seqlen_k;
-        if (p.causal_right >= 0) { m0 |= k0 > q_abs + p.causal_right; m1 |= k1 > q_abs + p.causal_right; }
-        if (p.window_left >= 0) { m0 |= k0 < q_abs - p.window_left; m1 |= k1 < q_abs - p.window_left; }
-        z0[r] = m0 ? -INFINITY : a;
-        z1[r] = m1 ? -INFINITY : c;
-      }
-      float mt = fmaxf(fmaxf(fmaxf(z0[0], z0[1]), fmaxf(z0[2], z0[3])), fmaxf(fmaxf(z1[0], z1[1]), fmaxf(z1[2], z1[3])));
-      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = fmaxf(m_run, mt);
-      // rows that have seen no visible key yet keep m = -inf; use 0 as the reference point to avoid inf - inf
-      const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);  // m_run = -inf -> 0
-      float psum = 0.f;
+      bool interior = p.softcap <= 0.f && wave_rows_ok && (t * kTile + kTile <= seqlen_k);
+      if (p.causal_right >= 0) interior = interior && (t * kTile + kTile - 1 <= wave_qabs_lo + p.causal_right);
+      if (p.window_left >= 0) interior = interior && (t * kTile >= wave_qabs_hi - p.window_left);
+      float m_new, m_use, alpha, psum = 0.f;
       v8s pf;
+      if (interior) {
+        float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        m_new = fmaxf(m_run, mt * p.scale);  // scale > 0: max commutes with it
+        m_use = m_new;
+        alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);
+        const float mneg = -m_use * log2e;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p0 = __builtin_amdgcn_exp2f((z0[r] - m_use) * log2e);
-        const float p1 = __builtin_amdgcn_exp2f((z1[r] - m_use) * log2e);
-        psum += p0 + p1;
-        pf[r] = M::cvt(p0);
-        pf[4 + r] = M::cvt(p1);
+        for (int r = 0; r < 4; ++r) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sc2, mneg));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sc2, mneg));
+          psum += p0 + p1;
+          pf[r] = M::cvt(p0);
+          pf[4 + r] = M::cvt(p1);
+        }
+      } else {
+        // logits in natural units, then masks
+        float z0[4], z1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = s0[r] * p.scale, c = s1[r] * p.scale;
+          if (p.softcap > 0.f) {
+            a = p.softcap * tanhf(a / p.softcap);
+            c = p.softcap * tanhf(c / p.softcap);
+          }
+          const int k0 = tb + r, k1 = tb + 16 + r;
+          bool m0 = !row_ok || k0 >= seqlen_k, m1 = !row_ok || k1 >= seqlen_k;
+          if (p.causal_right >= 0) { m0 |= k0 > q_abs + p.causal_right; m1 |= k1 > q_abs + p.causal_right; }
+          if (p.window_left >= 0) { m0 |= k0 < q_abs - p.window_left; m1 |= k1 < q_abs - p.window_left; }
+          z0[r] = m0 ? -INFINITY : a;
+          z1[r] = m1 ? -INFINITY : c;
+        }
+        float mt = fmaxf(fmaxf(fmaxf(z0[0], z0[1]), fmaxf(z0[2], z0[3])), fmaxf(fmaxf(z1[0], z1[1]), fmaxf(z1[2], z1[3])));
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        m_new = fmaxf(m_run, mt);
+        // rows that have seen no visible key yet keep m = -inf; use 0 as the reference point to avoid inf - inf
+        m_use = m_new == -INFINITY ? 0.f : m_new;
+        alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);  // m_run = -inf -> 0
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p0 = __builtin_amdgcn_exp2f((z0[r] - m_use) * log2e);
+          const float p1 = __builtin_amdgcn_exp2f((z1[r] - m_use) * log2e);
+          psum += p0 + p1;
+          pf[r] = M::cvt(p0);
+          pf[4 + r] = M::cvt(p1);
+        }
       }
       l_run = l_run * alpha + psum;
       m_run = m_new;
