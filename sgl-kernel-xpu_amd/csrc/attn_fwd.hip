@@ -21,6 +21,8 @@
 // swizzle / k-permutation / token-permutation of mla_decode.hip (conflict-free row and transposed reads).
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace sglk {
@@ -176,8 +178,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   }
 
   // ---- staging: chunk id c = tid + 256 i  ->  (token row = c / cpr, chunk = c % cpr)
-  v4i kreg[LD], vreg[LD];
-  auto issue_loads = [&](int t) {
+  // kSets register sets: the loads of tiles t+2 .. t+kSets are in flight while tile t is multiplied and tile t+1 waits to be written
+  // to LDS (with one set a decode-sized tile had ~0.3 us of work to hide ~2 us of latency behind)
+  struct Stage {
+    v4i k[LD], v[LD];
+  };
+  constexpr int kSets = DKP > 256 ? 1 : DKP > 128 ? 2 : 3;  // (fewer for the large head dims: registers)
+  Stage sreg[kSets];
+  // Paged KV with pages of at least one tile (32 tokens): the page of a tile is wave-uniform, so its table entry is
+  // a scalar load that the main loop issues one tile ahead (`pg`); otherwise every thread looks its own row up.
+  const bool uniform_page = p.paged && p.page_shift >= 5;
+  const int32_t* table_b = page_table + (p.paged ? (int64_t)b * p.table_stride : 0);
+  auto page_of_tile = [&](int t) -> int {
+    const int pos = t * kTile;
+    return (uniform_page && pos < seqlen_k) ? table_b[pos >> p.page_shift] : 0;
+  };
+  auto issue_loads = [&](int t, int pg, Stage& sr) {
     const int tok0 = t * kTile;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
       if (row < kTile && pos < seqlen_k) {
         int64_t koff, voff;
         if (p.paged) {
-          const int page = page_table[(int64_t)b * p.table_stride + (pos >> p.page_shift)];
+          const int page = uniform_page ? pg : table_b[pos >> p.page_shift];
           const int inp = pos & ((1 << p.page_shift) - 1);
           koff = (int64_t)page * p.k_s0 + (int64_t)inp * p.k_s1 + (int64_t)hk * p.k_s2;
           voff = (int64_t)page * p.v_s0 + (int64_t)inp * p.v_s1 + (int64_t)hk * p.v_s2;
@@ -199,11 +215,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
         kv = *reinterpret_cast<const v4i*>(kcache + koff + ch * 8);
         vv = *reinterpret_cast<const v4i*>(vcache + voff + ch * 8);
       }
-      kreg[i] = kv;
-      vreg[i] = vv;
+      sr.k[i] = kv;
+      sr.v[i] = vv;
     }
   };
-  auto write_lds = [&](int slot) {
+  auto write_lds = [&](int slot, const Stage& sr) {
     char* base = smem + slot * SLOT;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
@@ -211,8 +227,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
       const int row = c / cpr, ch = c - row * cpr;
       if (row < kTile) {
         const int off = (ch >> 4) * (kTile * 256) + row * 256 + (((ch & 15) ^ sw_main(row)) << 4);
-        *reinterpret_cast<v4i*>(base + off) = kreg[i];
-        *reinterpret_cast<v4i*>(base + TILE_BYTES + off) = vreg[i];
+        *reinterpret_cast<v4i*>(base + off) = sr.k[i];
+        *reinterpret_cast<v4i*>(base + TILE_BYTES + off) = sr.v[i];
       }
     }
   };
@@ -246,17 +262,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   __shared__ float xch_all[kWaves * 16];
   float* xch = xch_all + wave * 16;
 
+  int pg_next = 0;  // page of tile t + kSets (uniform-page case), fetched one iteration before its loads are issued
   if (n_tiles > 0) {
-    issue_loads(t_lo);
-    write_lds(0);
+    issue_loads(t_lo, page_of_tile(t_lo), sreg[0]);
+    write_lds(0, sreg[0]);
+    if (kSets >= 2 && n_tiles > 1) issue_loads(t_lo + 1, page_of_tile(t_lo + 1), sreg[1 % kSets]);
+    if (kSets >= 3 && n_tiles > 2) issue_loads(t_lo + 2, page_of_tile(t_lo + 2), sreg[2 % kSets]);
+    pg_next = page_of_tile(t_lo + kSets);
   }
   __syncthreads();
 
-  for (int i = 0; i < n_tiles; ++i) {
+  // tile i: multiply from LDS slot i % kSlots; registers sreg[i % kSets] (tile i, already in LDS) take the loads of tile
+  // i + kSets; the set of tile i + 1 goes to LDS at the end. Unrolled kSets times so that the set index is static.
+  auto body = [&](int i, auto parc) {
+    constexpr int par = decltype(parc)::value;
     const int t = t_lo + i;
     const int slot = i % kSlots;
-    if (i + 1 < n_tiles) issue_loads(t + 1);
-
+    if (i + kSets < n_tiles) issue_loads(t + kSets, pg_next, sreg[par % kSets]);
+    pg_next = (i + kSets + 1 < n_tiles) ? page_of_tile(t + kSets + 1) : 0;
     {
       const char* kb = smem + slot * SLOT;
       const char* vb = kb + TILE_BYTES;
@@ -353,8 +376,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
     }
 
     if (kSlots == 2) __syncthreads();                   // two slots: everyone must be done with the slot being refilled
-    if (i + 1 < n_tiles) write_lds((i + 1) % kSlots);  // three slots: that slot was last read two iterations ago
+    if (i + 1 < n_tiles) write_lds((i + 1) % kSlots, sreg[(par + 1) % kSets]);  // three slots: last read two iterations ago
     __syncthreads();
+  };
+  for (int i = 0; i < n_tiles; i += kSets) {
+    body(i, std::integral_constant<int, 0>{});
+    if constexpr (kSets >= 2) {
+      if (i + 1 < n_tiles) body(i + 1, std::integral_constant<int, 1>{});
+    }
+    if constexpr (kSets >= 3) {
+      if (i + 2 < n_tiles) body(i + 2, std::integral_constant<int, 2>{});
+    }
   }
 
   // ---- epilogue
