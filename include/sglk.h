@@ -256,6 +256,8 @@ SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const vo
  *   part_lse fp32 [splits,Hq,total_q]); sglk_attn_auto_splits gives the "0 = auto" choice. */
 SGLK_API int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
                                        int64_t max_seqlen_k);
+/* kv_dtype: dtype (K/V stored like q) or SGLK_FP8_E4M3 / SGLK_FP8_E5M2 for an fp8 KV cache, dequantised in the kernel
+ * with one float each for K and V (device pointers k_descale / v_descale; reference flash_attention.cpp:561-572). */
 SGLK_API int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const void* q, const void* k,
                            const void* v, const int32_t* cu_seqlens_q, const int32_t* seqlens_k,
                            const int32_t* page_table, const float* sinks, float* part_o, float* part_lse,
@@ -265,7 +267,7 @@ SGLK_API int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const vo
                            int64_t k_stride1, int64_t k_stride2, int64_t v_stride0, int64_t v_stride1,
                            int64_t v_stride2, int64_t table_stride, float softmax_scale, int is_causal,
                            int64_t window_left, int64_t window_right, float softcap, int64_t num_splits,
-                           int dtype);
+                           int dtype, int kv_dtype, const float* k_descale, const float* v_descale);
 
 /* sgl_per_token_group_quant_8bit_v2: reference src/sycl/per_token_group_quant_8bit_v2.cpp:714-842
  * (schema src/torch_extension_sycl.cc:399-402). As v1 plus: fuse_silu_and_mul (x is [.., 2*hidden], the value

@@ -63,3 +63,10 @@ def gather_paged(cache, page_table_row, seqlen):
     """cache [pages, page, Hk, D] -> the first seqlen tokens of the pages listed in page_table_row."""
     pages = cache[page_table_row.long()]
     return pages.reshape(-1, cache.shape[2], cache.shape[3])[:seqlen]
+
+
+def dequant_fp8_cache(cache, descale):
+    """fp8 (e4m3fn / e5m2) KV cache with one per-tensor descale -> fp32, as attention_ref does before its fp32 math
+    (reference tests/test_flash_attention.py:404-407, :1738-1745: cache = (ref / descale).to(fp8); the kernel and the
+    reference both multiply the stored value by descale)."""
+    return cache.float() * float(descale)

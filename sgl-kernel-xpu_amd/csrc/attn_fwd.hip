@@ -67,6 +67,8 @@ struct AttnParams {
   float* part_o;        // [splits, total_q, Hq, D] fp32 (splits > 1)
   float* part_lse;      // [splits, Hq, total_q]
   const float* sinks;   // [Hq] or null
+  const float* k_descale;  // fp8 KV cache: one float for the whole K cache (device pointer) or null
+  const float* v_descale;
   int64_t q_s0, q_s1;   // q strides (token, head) in elements
   int64_t o_s0, o_s1;
   int64_t k_s0, k_s1, k_s2;  // paged: (page, token-in-page, head); ragged: (token, head, -)
@@ -83,9 +85,12 @@ struct AttnParams {
 };
 
 // DKP: head dim rounded up to 32 (k-steps of the QK product); the V/O side uses ceil(D/16) 16-wide tiles.
-template <typename T, int DKP>
+// KV8: 0 = K/V stored like q (16-bit); 1 = fp8 e4m3fn, 2 = fp8 e5m2 cache (one byte per element, strides in bytes)
+// converted to T while it is staged into LDS, with the per-tensor descale folded into the softmax scale (K) and the
+// output normaliser (V) - reference flash_attention.cpp:561-572, tests/test_flash_attention.py:1697-1830.
+template <typename T, int DKP, int KV8>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __restrict__ q,
-                                                       const T* __restrict__ kcache, const T* __restrict__ vcache,
+                                                       const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                        const int32_t* __restrict__ cu_q,
                                                        const int32_t* __restrict__ seq_k,  // paged: lengths [b]; ragged: cu [b+1]
                                                        const int32_t* __restrict__ page_table) {
@@ -212,11 +217,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
           koff = (int64_t)(k_begin + pos) * p.k_s0 + (int64_t)hk * p.k_s1;
           voff = (int64_t)(k_begin + pos) * p.v_s0 + (int64_t)hk * p.v_s1;
         }
-        kv = *reinterpret_cast<const v4i*>(kcache + koff + ch * 8);
-        vv = *reinterpret_cast<const v4i*>(vcache + voff + ch * 8);
+        if constexpr (KV8 == 0) {
+          kv = *reinterpret_cast<const v4i*>(kcache + (koff + ch * 8) * 2);
+          vv = *reinterpret_cast<const v4i*>(vcache + (voff + ch * 8) * 2);
+        } else {  // 8 bytes = the 8 elements of this chunk
+          const uint2 k8 = *reinterpret_cast<const uint2*>(kcache + koff + ch * 8);
+          const uint2 v8 = *reinterpret_cast<const uint2*>(vcache + voff + ch * 8);
+          kv[0] = (int)k8.x; kv[1] = (int)k8.y;
+          vv[0] = (int)v8.x; vv[1] = (int)v8.y;
+        }
       }
       sr.k[i] = kv;
       sr.v[i] = vv;
+    }
+  };
+  // fp8 cache: 8 bytes -> 8 elements of T (every e4m3 / e5m2 value is exact in bf16 and fp16)
+  auto widen = [&](const v4i& x) -> v4i {
+    if constexpr (KV8 == 0) {
+      return x;
+    } else {
+      v4i r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          float f0, f1;
+          if constexpr (KV8 == 1) {
+            const auto f = w == 0 ? __builtin_amdgcn_cvt_pk_f32_fp8(x[h], false) : __builtin_amdgcn_cvt_pk_f32_fp8(x[h], true);
+            f0 = f[0]; f1 = f[1];
+          } else {
+            const auto f = w == 0 ? __builtin_amdgcn_cvt_pk_f32_bf8(x[h], false) : __builtin_amdgcn_cvt_pk_f32_bf8(x[h], true);
+            f0 = f[0]; f1 = f[1];
+          }
+          const uint32_t lo = (uint16_t)M::cvt(f0), hi = (uint16_t)M::cvt(f1);
+          r[2 * h + w] = (int)(lo | (hi << 16));
+        }
+      }
+      return r;
     }
   };
   auto write_lds = [&](int slot, const Stage& sr) {
@@ -227,8 +264,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
       const int row = c / cpr, ch = c - row * cpr;
       if (row < kTile) {
         const int off = (ch >> 4) * (kTile * 256) + row * 256 + (((ch & 15) ^ sw_main(row)) << 4);
-        *reinterpret_cast<v4i*>(base + off) = sr.k[i];
-        *reinterpret_cast<v4i*>(base + TILE_BYTES + off) = sr.v[i];
+        *reinterpret_cast<v4i*>(base + off) = widen(sr.k[i]);
+        *reinterpret_cast<v4i*>(base + TILE_BYTES + off) = widen(sr.v[i]);
       }
     }
   };
@@ -258,7 +295,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   for (int nt = 0; nt < NT; ++nt) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   const float log2e = 1.4426950408889634f;
-  const float sc2 = p.scale * log2e;
+  const float kd = (KV8 != 0 && p.k_descale) ? p.k_descale[0] : 1.f, vd = (KV8 != 0 && p.v_descale) ? p.v_descale[0] : 1.f;
+  const float scale = p.scale * kd;  // the K descale multiplies every logit
+  const float sc2 = scale * log2e;
   __shared__ float xch_all[kWaves * 16];
   float* xch = xch_all + wave * 16;
 
@@ -305,7 +344,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
         float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
         mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        m_new = fmaxf(m_run, mt * p.scale);  // scale > 0: max commutes with it
+        m_new = fmaxf(m_run, mt * scale);  // scale > 0: max commutes with it
         m_use = m_new;
         alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);
         const float mneg = -m_use * log2e;
@@ -322,7 +361,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
         float z0[4], z1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float a = s0[r] * p.scale, c = s1[r] * p.scale;
+          float a = s0[r] * scale, c = s1[r] * scale;
           if (p.softcap > 0.f) {
             a = p.softcap * tanhf(a / p.softcap);
             c = p.softcap * tanhf(c / p.softcap);
@@ -405,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
     // O is relative to m_fin: its normaliser is l + exp(sink - m_fin) (inf -> output 0)
     l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
   }
-  const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
+  const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? vd / l_tot : 0.f;  // (V descale folded in)
   if (lane < 16) xch[lane] = inv_l;
   const v4f i4 = *reinterpret_cast<const v4f*>(xch + 4 * g4);
 
@@ -472,20 +511,20 @@ __global__ __launch_bounds__(128) void attn_reduce_kernel(T* __restrict__ out, f
   if (threadIdx.x == 0) lse_out[(int64_t)head * total_q + tok] = denom > 0.f ? mref + logf(denom) : -INFINITY;
 }
 
-template <typename T, int DKP>
+template <typename T, int DKP, int KV8>
 static int launch(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                   const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
   constexpr int NB = (DKP * 2 + 255) / 256;
   constexpr int lds = (DKP > 256 ? 2 : 3) * 2 * NB * kTile * 256;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DKP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DKP, KV8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(SGLK_ELAUNCH, "fwd: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
     attr_set = true;
   }
   dim3 grid((unsigned)cdiv(max_rows, kBlockM), (unsigned)(p.Hk * p.splits), (unsigned)batch);
-  attn_fwd_kernel<T, DKP><<<grid, 256, lds, st>>>(p, (const T*)q, (const T*)k, (const T*)v, cu_q, seq_k, table);
+  attn_fwd_kernel<T, DKP, KV8><<<grid, 256, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   if (int rc = check_launch("fwd")) return rc;
   if (p.splits > 1) {
     attn_reduce_kernel<T><<<dim3(p.Hq, p.total_q), 128, 0, st>>>((T*)p.out, p.lse, p.part_o, p.part_lse, p.sinks,
@@ -497,14 +536,24 @@ static int launch(hipStream_t st, const AttnParams& p, const void* q, const void
 
 template <typename T>
 static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
-                        const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
+                        const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows, int kv8) {
   const int d = p.D;
-  if (d <= 64) return launch<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
-  if (d <= 96) return launch<T, 96>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
-  if (d <= 128) return launch<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
-  if (d <= 192) return launch<T, 192>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
-  if (d <= 256) return launch<T, 256>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
-  return launch<T, 512>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (kv8 != 0) {  // fp8 KV cache: built for the head dims the reference exercises (and 64)
+#define SGLK_FP8_GO(DKP)                                                                              \
+  return kv8 == 1 ? launch<T, DKP, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)            \
+                  : launch<T, DKP, 2>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
+    if (d <= 64) SGLK_FP8_GO(64);
+    if (d <= 128) SGLK_FP8_GO(128);
+    if (d <= 256) SGLK_FP8_GO(256);
+#undef SGLK_FP8_GO
+    return fail(SGLK_EINVAL, "fwd: the fp8 KV cache path supports head dimensions up to 256, got %d", d);
+  }
+  if (d <= 64) return launch<T, 64, 0>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (d <= 96) return launch<T, 96, 0>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (d <= 128) return launch<T, 128, 0>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (d <= 192) return launch<T, 192, 0>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (d <= 256) return launch<T, 256, 0>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  return launch<T, 512, 0>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
 }
 
 }  // namespace
@@ -533,17 +582,20 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
                              int64_t k_stride1, int64_t k_stride2, int64_t v_stride0, int64_t v_stride1,
                              int64_t v_stride2, int64_t table_stride, float softmax_scale, int is_causal,
                              int64_t window_left, int64_t window_right, float softcap, int64_t num_splits,
-                             int dtype) {
+                             int dtype, int kv_dtype, const float* k_descale, const float* v_descale) {
   using namespace sglk;
   SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "mha_fwd only supports Half and BFloat16");
   SGLK_REQUIRE(num_heads > 0 && num_heads_k > 0 && num_heads % num_heads_k == 0,
                "Number of heads in key/value must divide number of heads in query");
   SGLK_REQUIRE(head_dim > 0 && head_dim <= 512, "FlashAttention forward only supports head dimension at most 512");
   SGLK_REQUIRE(head_dim % 8 == 0, "head_size should be a multiple of 8");
+  const int kv8 = kv_dtype == SGLK_FP8_E4M3 ? 1 : kv_dtype == SGLK_FP8_E5M2 ? 2 : 0;
+  SGLK_REQUIRE(kv8 != 0 || kv_dtype == dtype, "query and key must have the same dtype (or an fp8 e4m3 / e5m2 KV cache)");
+  SGLK_REQUIRE(kv8 == 0 || (k_descale != nullptr && v_descale != nullptr), "fp8 KV cache requires k_descale and v_descale");
   SGLK_REQUIRE(q_stride0 % 8 == 0 && q_stride1 % 8 == 0 && k_stride0 % 8 == 0 && k_stride1 % 8 == 0 &&
                    k_stride2 % 8 == 0 && v_stride0 % 8 == 0 && v_stride1 % 8 == 0 && v_stride2 % 8 == 0 &&
-                   (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0,
-               "fwd: q, k and v rows must be 16-byte aligned");
+                   (uintptr_t)q % 16 == 0 && (uintptr_t)k % (kv8 ? 8 : 16) == 0 && (uintptr_t)v % (kv8 ? 8 : 16) == 0,
+               "fwd: q, k and v rows must be 16-byte aligned (8-byte for an fp8 cache)");
   const bool paged = page_table != nullptr;
   int page_shift = 0;
   if (paged) {
@@ -560,6 +612,8 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
   p.part_o = part_o;
   p.part_lse = part_lse;
   p.sinks = sinks;
+  p.k_descale = kv8 ? k_descale : nullptr;
+  p.v_descale = kv8 ? v_descale : nullptr;
   p.q_s0 = q_stride0; p.q_s1 = q_stride1;
   p.o_s0 = o_stride0; p.o_s1 = o_stride1;
   p.k_s0 = k_stride0; p.k_s1 = k_stride1; p.k_s2 = k_stride2;
@@ -581,6 +635,6 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
   const int max_rows = (int)(max_seqlen_q * p.G);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16)
-    return dispatch_dim<bf16>(st, p, q, k, v, cu_seqlens_q, seqlens_k, page_table, (int)batch, max_rows);
-  return dispatch_dim<f16>(st, p, q, k, v, cu_seqlens_q, seqlens_k, page_table, (int)batch, max_rows);
+    return dispatch_dim<bf16>(st, p, q, k, v, cu_seqlens_q, seqlens_k, page_table, (int)batch, max_rows, kv8);
+  return dispatch_dim<f16>(st, p, q, k, v, cu_seqlens_q, seqlens_k, page_table, (int)batch, max_rows, kv8);
 }

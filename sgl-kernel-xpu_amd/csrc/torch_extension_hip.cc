@@ -662,10 +662,16 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
   TORCH_CHECK(q.dim() == 3, "query must be in ragged format (total_q, h, d)");
   const auto q_type = q.scalar_type();
   TORCH_CHECK(q_type == at::kHalf || q_type == at::kBFloat16, "mha_fwd only supports Half and BFloat16, got", q_type);
-  TORCH_CHECK(k.scalar_type() != at::kFloat8_e4m3fn && k.scalar_type() != at::kFloat8_e5m2,
-              "fwd: the fp8 KV cache path is not built for gfx950 yet");
-  TORCH_CHECK(k.scalar_type() == q_type, "query and key must have the same dtype");
-  TORCH_CHECK(v.scalar_type() == q_type, "query and value must have the same dtype");
+  // fp8 KV cache (reference flash_attention.cpp:315-320, :561-572): K/V stored as e4m3fn / e5m2, one float descale each
+  const bool fp8_kv = k.scalar_type() == at::kFloat8_e4m3fn || k.scalar_type() == at::kFloat8_e5m2;
+  if (fp8_kv) {
+    TORCH_CHECK(v.scalar_type() == k.scalar_type(), "key and value must have the same dtype");
+    TORCH_CHECK(k_descale.has_value() && v_descale.has_value(), "fp8 KV cache requires k_descale and v_descale");
+    TORCH_CHECK(page_table.has_value(), "fwd: the fp8 KV cache path needs a paged cache");
+  } else {
+    TORCH_CHECK(k.scalar_type() == q_type, "query and key must have the same dtype");
+    TORCH_CHECK(v.scalar_type() == q_type, "query and value must have the same dtype");
+  }
   CHECK_LAST_DIM_CONTIGUOUS(q);
   CHECK_LAST_DIM_CONTIGUOUS(k);
   CHECK_LAST_DIM_CONTIGUOUS(v);
@@ -674,8 +680,24 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
               "fwd: in-kernel rotary embedding is not supported");
   TORCH_CHECK(!kv_batch_idx.has_value(), "fwd: kv_batch_idx is not supported");
   TORCH_CHECK(!leftpad_k.has_value(), "fwd: leftpad_k is not supported");
-  TORCH_CHECK(!q_descale.has_value() && !k_descale.has_value() && !v_descale.has_value(),
-              "fwd: descale factors only apply to the fp8 KV cache path, which is not built for gfx950 yet");
+  TORCH_CHECK(!q_descale.has_value(), "fwd: q_descale is not supported (q is never fp8 on this build)");
+  // per-tensor descale: a scalar or an expanded scalar (reference get_per_tensor_descale_ptr, flash_attention.cpp:45-70)
+  auto descale_ptr = [&](const std::optional<Tensor>& t, const char* name) -> const float* {
+    if (!fp8_kv || !t.has_value()) return nullptr;
+    TORCH_CHECK(t->scalar_type() == at::kFloat, name, " must be float32");
+    TORCH_CHECK(t->device() == k.device(), name, " must be on the same device as the tensor it descales");
+    TORCH_CHECK(t->numel() > 0, name, " must not be empty");
+    bool scalar = t->numel() == 1;
+    if (!scalar) {
+      scalar = true;
+      for (int64_t dim = 0; dim < t->dim(); ++dim)
+        if (t->size(dim) > 1 && t->stride(dim) != 0) scalar = false;
+    }
+    TORCH_CHECK(scalar, name, " uses a per-tensor descale: pass a single value (or an expanded view of one)");
+    return t->data_ptr<float>();
+  };
+  const float* k_descale_ptr = descale_ptr(k_descale, "k_descale");
+  const float* v_descale_ptr = descale_ptr(v_descale, "v_descale");
   TORCH_CHECK(cu_seqlens_q.scalar_type() == at::kInt && cu_seqlens_q.is_contiguous() && cu_seqlens_q.is_cuda(),
               "cu_seqlens_q must have dtype torch.int32");
   TORCH_CHECK(cu_seqlens_k.scalar_type() == at::kInt && cu_seqlens_k.is_contiguous() && cu_seqlens_k.is_cuda(),
@@ -761,7 +783,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
                           batch, total_q, max_seqlen_q, num_heads, num_heads_k, head_size, page_size, q.stride(0),
                           q.stride(1), out.stride(0), out.stride(1), ks0, ks1, ks2, vs0, vs1, vs2, table_stride,
                           (float)softmax_scale, is_causal ? 1 : 0, window_size_left, window_size_right, (float)softcap,
-                          splits, dtype_code(q_type, "q")));
+                          splits, dtype_code(q_type, "q"),
+                          fp8_kv ? (k.scalar_type() == at::kFloat8_e4m3fn ? SGLK_FP8_E4M3 : SGLK_FP8_E5M2)
+                                 : dtype_code(q_type, "q"),
+                          k_descale_ptr, v_descale_ptr));
   return {out, lse, out_accum, lse_accum};
 }
 

@@ -230,3 +230,53 @@ def test_errors(sglk, dev):
         sglk.flash_attn_varlen_func(q, k.to(torch.bfloat16), k, cu, cuk, 4, 8)
     with pytest.raises(RuntimeError, match="must divide"):
         sglk.flash_attn_varlen_func(q[:, :1].repeat(1, 3, 1), k.repeat(1, 2, 1), k.repeat(1, 2, 1), cu, cuk, 4, 8)
+
+
+# ---------------------------------------------------------------------- fp8 KV cache (reference :1697-1830)
+@pytest.mark.parametrize("fp8_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("heads", [(8, 8), (8, 2)])
+@pytest.mark.parametrize("D", [128, 256])
+@pytest.mark.parametrize("page", [64, 128])
+@pytest.mark.parametrize("sq", [1, 32, 64])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp8_kvcache(sglk, dev, fp8_dtype, heads, D, page, sq, causal):
+    """bf16 q against an fp8 paged KV cache with per-tensor descales (scalar and expanded-scalar layouts)."""
+    Hq, Hk = heads
+    b, sk = 3, 512
+    g = torch.Generator().manual_seed(D + page + sq)
+    fp8_max = 448.0 if fp8_dtype == torch.float8_e4m3fn else 57344.0
+    k_ref = torch.randn(b, sk, Hk, D, generator=g)
+    v_ref = torch.randn(b, sk, Hk, D, generator=g)
+    kd, vd = k_ref.abs().max().item() / fp8_max, v_ref.abs().max().item() / fp8_max
+    kc = (k_ref / kd).to(fp8_dtype).reshape(b * sk // page, page, Hk, D)
+    vc = (v_ref / vd).to(fp8_dtype).reshape(b * sk // page, page, Hk, D)
+    table = torch.arange(b * sk // page, dtype=torch.int32).view(b, sk // page)
+    lens = torch.tensor([sk, sk - 37, max(sq, 100)], dtype=torch.int32)
+    q = torch.randn(b, sq, Hq, D, generator=g).to(torch.bfloat16)
+    scale = D ** -0.5
+    kf, vf = oa.dequant_fp8_cache(kc, kd), oa.dequant_fp8_cache(vc, vd)
+    ks = [oa.gather_paged(kf, table[i], int(lens[i])) for i in range(b)]
+    vs = [oa.gather_paged(vf, table[i], int(lens[i])) for i in range(b)]
+    cu_q = torch.arange(0, b + 1, dtype=torch.int32) * sq
+    ref, _ = oa.attention_ragged(q.view(-1, Hq, D), ks, vs, cu_q, scale, causal=causal)
+    for layout in ("scalar", "expanded"):
+        kdt = torch.tensor([kd], dtype=torch.float32, device=dev)
+        vdt = torch.tensor([vd], dtype=torch.float32, device=dev)
+        if layout == "expanded":
+            kdt, vdt = kdt.expand(b, Hk), vdt.expand(b, Hk)
+        out = sglk.flash_attn_with_kvcache(q.to(dev), kc.to(dev), vc.to(dev), cache_seqlens=lens.to(dev),
+                                           page_table=table.to(dev), k_descale=kdt, v_descale=vdt, softmax_scale=scale,
+                                           causal=causal)
+        out = out.reshape(b * sq, Hq, D).float().cpu()
+        diff = (out - ref).abs()
+        # reference bounds (:1824-1830): e5m2 max 4e-1 / mean 8e-2, e4m3 max 1e-1 / mean 2e-2. The kernel converts the
+        # stored fp8 values exactly and works in fp32, so it only differs from the oracle by bf16 rounding of P and out.
+        assert diff.max().item() <= 2e-2 and diff.mean().item() <= 2e-3, (layout, diff.max().item(), diff.mean().item())
+
+
+def test_fp8_kvcache_requires_descale(sglk, dev):
+    kc = torch.zeros(2, 64, 2, 128, device=dev).to(torch.float8_e4m3fn)
+    q = torch.zeros(1, 1, 2, 128, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="k_descale and v_descale"):
+        sglk.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=torch.tensor([5], dtype=torch.int32, device=dev),
+                                     page_table=torch.zeros(1, 2, dtype=torch.int32, device=dev))
