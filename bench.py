@@ -47,13 +47,14 @@ def make_inputs(dev, seed):
 
 def pmc_traffic_bytes():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/gpu_profile.sh ->
-    profiles/r01/bench_fp8_gemm_v2_pmc.json): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B
+    profiles/r01/bench_fp8_gemm_v3_pmc.json): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B
     requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section) and is doubled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "bench_fp8_gemm_v2_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01", "bench_fp8_gemm_v3_pmc.json")) as f:
             pmc = json.load(f)
-        k = next(v for name, v in pmc.items() if "gemm_fp8_blockwise_persist_kernel" in name)
-        return int((2 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024)
+        # one GEMM = one launch of each instantiation of the persistent kernel (whole tiles, then half tiles)
+        ks = [v for name, v in pmc.items() if "gemm_fp8_blockwise_persist_kernel" in name]
+        return int(sum(2 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"] for k in ks) * 1024) if ks else None
     except Exception:
         return None
 
@@ -93,7 +94,7 @@ def side_metrics(sgl_kernel, dev):
     out = {}
 
     def timeit(fn, iters=30):
-        for _ in range(5):
+        for _ in range(max(5, iters)):  # the chip's clocks ramp for tens of milliseconds
             fn()
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record()
@@ -265,7 +266,7 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "gemm_fp8_blockwise_persist_kernel<bf16>",
+            "kernel": "gemm_fp8_blockwise_persist_kernel<bf16> (two launches: 256-row tiles, then 128-row half tiles of the last partial round)",
             "achieved": round(achieved, 2),
             "peak": PEAK_FP8_TFLOPS,
             "unit": "TFLOP/s",
