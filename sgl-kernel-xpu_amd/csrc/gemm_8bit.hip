@@ -730,6 +730,138 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
 #undef SGLK_FRAG
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Blockwise kernel for few rows (decode: M <= 64; above that the tile kernel wins). The 256 x 256 tile kernel above would put 56 workgroups on
+// 256 CUs and stream the 58.7 MB of Llama-3-8B FFN weights at ~1 TB/s. Here the work is a weight stream: one wave
+// per 16 weight rows (n), no LDS, no barriers. Per 128-deep K block a lane loads its 32 bytes of b^T (row n = lane
+// % 16, 16-byte chunks lane / 16 and lane / 16 + 4: the same k order as above) through a kD-deep register ring with
+// static slots, and the 32-byte activation fragments of up to MF = 4 m-tiles (they sit in L2 / the vector L1 for
+// all waves); one v_mfma_scale_f32_16x16x128_f8f6f4 per m-tile and K block, block scale on the VALU as above.
+// KS > 1 lets 2 / 4 waves split the K range of one n-tile and add their partial sums through LDS in a fixed order
+// (more bytes in flight; not used: it measured slower).
+// grid = (N / (16 * 4 / KS), ceil(M / (16 MF))); operands swapped as above: a lane owns 4 consecutive n of one m.
+template <typename OutT, int MF, int KS, bool HW_SCALE>  // KS waves split the K range of one 16-row n-tile
+__global__ __launch_bounds__(256) void gemm_fp8_blockwise_skinny_kernel(
+    OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+    const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
+    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn) {
+  constexpr int kD = 8;  // K blocks of weights in flight per wave
+  __shared__ float red[KS > 1 ? 4 * MF * 256 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = (blockIdx.x * (4 / KS) + wave / KS) * 16;
+  const int kpart = wave % KS;
+  const bool live = n0 < N;  // (dead waves still join the barrier below)
+  const int m0 = blockIdx.y * (16 * MF);
+  const int j = lane & 15, g = lane >> 4;
+  const int nkb_all = K / BK;
+  const int per = (nkb_all + KS - 1) / KS;
+  const int kb_lo = kpart * per;
+  const int nkb = live ? ((kb_lo + per < nkb_all ? kb_lo + per : nkb_all) - kb_lo) : 0;  // this wave's K blocks (may be <= 0)
+
+  int nrow = n0 + j;
+  nrow = nrow < N ? nrow : N - 1;
+  const uint8_t* bl = b + (int64_t)nrow * ldb + g * 16 + (int64_t)kb_lo * BK;
+  const uint8_t* al[MF];
+  const float* sl[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    int m = m0 + mf * 16 + j;
+    m = m < M ? m : M - 1;
+    al[mf] = a + (int64_t)m * lda + g * 16 + (int64_t)kb_lo * BK;
+    sl[mf] = sa + (int64_t)m * sa_sm + (int64_t)kb_lo * sa_sk;
+  }
+  const int nblk_max = (N + 127) / 128 - 1;
+  int nblk = n0 >> 7;
+  nblk = nblk < nblk_max ? nblk : nblk_max;
+  const float* sbw = sb + (int64_t)nblk * sb_sn + (int64_t)kb_lo * sb_sk;
+
+  auto load32 = [](const uint8_t* p) -> v8i {
+    const v4i lo = *reinterpret_cast<const v4i*>(p), hi = *reinterpret_cast<const v4i*>(p + 64);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  v4f acc[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) acc[mf] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const v4f zero = {0.f, 0.f, 0.f, 0.f};
+
+  if (nkb > 0) {
+    v8i wq[kD];
+#pragma unroll
+    for (int d = 0; d < kD; ++d) wq[d] = load32(bl + (int64_t)(d < nkb ? d : 0) * BK);
+    v8i af[2][MF];
+    float sv[2][MF], sbq[2];
+    auto load_a = [&](int kb, int slot) {
+      const int kc = kb < nkb ? kb : 0;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        af[slot][mf] = load32(al[mf] + (int64_t)kc * BK);
+        sv[slot][mf] = sl[mf][(int64_t)kc * sa_sk];
+      }
+      sbq[slot] = sbw[(int64_t)kc * sb_sk];
+    };
+    load_a(0, 0);
+    load_a(1, 1);
+
+    for (int kb0 = 0; kb0 < nkb; kb0 += kD) {
+#pragma unroll
+      for (int u = 0; u < kD; ++u) {
+        const int kb = kb0 + u;
+        if (kb < nkb) {
+          const v8i w = wq[u];
+          const int kn = kb + kD;
+          wq[u] = load32(bl + (int64_t)(kn < nkb ? kn : 0) * BK);
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) {
+            const v4f cur = mfma_k128<HW_SCALE>(w, af[u & 1][mf], zero);
+            const float sc = sv[u & 1][mf] * sbq[u & 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mf][r] = __builtin_fmaf(cur[r], sc, acc[mf][r]);
+          }
+          load_a(kb + 2, u & 1);
+        }
+      }
+    }
+  }
+
+  if constexpr (KS > 1) {
+    // the KS partial sums of an n-tile meet in LDS and are added in a fixed order by the first wave of the group
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) *reinterpret_cast<v4f*>(&red[((wave * MF + mf) * 64 + lane) * 4]) = acc[mf];
+    __syncthreads();
+    if (kpart != 0) return;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+      for (int u = 1; u < KS; ++u) {
+        const v4f o = *reinterpret_cast<const v4f*>(&red[(((wave + u) * MF + mf) * 64 + lane) * 4]);
+        acc[mf][0] += o[0]; acc[mf][1] += o[1]; acc[mf][2] += o[2]; acc[mf][3] += o[3];
+      }
+    }
+  }
+  if (!live) return;
+
+  // lane: column m = m0 + 16 mf + j, rows n = n0 + 4 g + r
+  const int n = n0 + g * 4;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int m = m0 + mf * 16 + j;
+    if (m >= M) continue;
+    OutT* orow = out + (int64_t)m * ldc;
+    if (n + 3 < N && (ldc % 4 == 0) && ((uintptr_t)out % 8 == 0)) {
+      Vec<OutT, 4> vv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] = (OutT)acc[mf][r];
+      store_vec<OutT, 4>(orow + n, vv);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) orow[n + r] = (OutT)acc[mf][r];
+    }
+  }
+}
+
 static int g_gemm_variant = 4;  // 4 = pipelined kernel (default); 0, 1 = earlier main loops; 8, 9, 14 = timing probes
 
 template <typename OutT, int MODE>
@@ -749,6 +881,29 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
     for (int len = q; len <= q + (r8 ? 1 : 0); ++len) {
       const int left = len - (len / slots) * slots;
       tail_halves = tail_halves || (left > 0 && 2 * left <= slots);
+    }
+  }
+  // few rows: the weight-streaming kernel (variant 5 forces it, variant 6 forbids it)
+  if constexpr (MODE == MODE_BLOCKWISE) {
+    if ((M <= 64 && g_gemm_variant == 4) || g_gemm_variant == 5) {
+#define SGLK_GO_SKINNY(MF, KS)                                                                               \
+  {                                                                                                          \
+    const dim3 sg((unsigned)cdiv(N, 16 * (4 / KS)), (unsigned)cdiv(M, 16 * MF));                             \
+    if (hw_scale)                                                                                            \
+      gemm_fp8_blockwise_skinny_kernel<OutT, MF, KS, true><<<sg, 256, 0, st>>>(                              \
+          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,   \
+          sa_sm, sa_sk, sb_sk, sb_sn);                                                                       \
+    else                                                                                                     \
+      gemm_fp8_blockwise_skinny_kernel<OutT, MF, KS, false><<<sg, 256, 0, st>>>(                             \
+          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,   \
+          sa_sm, sa_sk, sb_sk, sb_sn);                                                                       \
+  }
+      // (splitting K over 2 / 4 waves of a workgroup - template KS - measured slower: 18 -> 22 us at M = 1, N = 14336)
+      if (M <= 16) SGLK_GO_SKINNY(1, 1)
+      else if (M <= 32) SGLK_GO_SKINNY(2, 1)
+      else SGLK_GO_SKINNY(4, 1)
+#undef SGLK_GO_SKINNY
+      return check_launch("gemm_8bit(skinny)");
     }
   }
   const int variant = (!persist_ok && g_gemm_variant != 0 && g_gemm_variant != 1) ? 1 : g_gemm_variant;
