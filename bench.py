@@ -119,6 +119,17 @@ def side_metrics(sgl_kernel, dev):
                                                                    enable_v2=False))
     out["per_token_group_quant_fp8_4096x4096_GBs"] = round((x.numel() * 3 + s.numel() * 4) / ms / 1e6, 1)
     del x, x2, o2, q, s, y
+    # the M sweep of BASELINE configs[1] (decode .. prefill rows against the same N=14336, K=4096 weights)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    bw = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev).t()
+    sbw = (torch.rand(N // 128, K // 128, generator=g) * 1e-3 + 1e-4).to(dev).t()
+    for m in (1, 16, 64, 256, 1024):
+        am = ((torch.rand(m, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev)
+        sam = (torch.rand(K // 128, m, generator=g) * 1e-3 + 1e-4).to(dev).t()
+        ms = timeit(lambda: sgl_kernel.fp8_blockwise_scaled_mm(am, bw, sam, sbw, torch.bfloat16), iters=50)
+        out[f"fp8_blockwise_gemm_M{m}_us"] = round(ms * 1e3, 1)
+        out[f"fp8_blockwise_gemm_M{m}_weight_GBs"] = round(N * K / ms / 1e6, 1)
+    del bw, sbw
     # flash_mla_decode, BASELINE configs[3]: bs=128, seq=8192, kv_lora 512 + rope 64, paged (64), bf16.
     # Bytes as benchmark/bench_flash_mla_decode.py:109-115 of the reference: q + kv cache + table + seq_lens + out.
     bs, seq, page = 128, 8192, 64
