@@ -118,6 +118,13 @@ def side_metrics(sgl_kernel, dev):
     ms = timeit(lambda: sgl_kernel.sgl_per_token_group_quant_8bit(x, q, s, 128, 1e-10, -448.0, 448.0, False,
                                                                    enable_v2=False))
     out["per_token_group_quant_fp8_4096x4096_GBs"] = round((x.numel() * 3 + s.numel() * 4) / ms / 1e6, 1)
+    # per-token / per-tensor fp8 quantisation of the same activations
+    st = torch.zeros(4096, dtype=torch.float32, device=dev)
+    ms = timeit(lambda: sgl_kernel.sgl_per_token_quant_fp8(x, q, st))
+    out["per_token_quant_fp8_4096x4096_GBs"] = round((x.numel() * 3 + 4096 * 4) / ms / 1e6, 1)
+    s1 = torch.zeros(1, dtype=torch.float32, device=dev)
+    ms = timeit(lambda: sgl_kernel.sgl_per_tensor_quant_fp8(x, q, s1, False))
+    out["per_tensor_quant_fp8_dynamic_4096x4096_GBs"] = round(x.numel() * 5 / ms / 1e6, 1)  # two reads + one write
     del x, x2, o2, q, s, y
     # the M sweep of BASELINE configs[1] (decode .. prefill rows against the same N=14336, K=4096 weights)
     g = torch.Generator(device="cpu").manual_seed(3)

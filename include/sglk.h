@@ -140,6 +140,23 @@ SGLK_API int sglk_scaled_mm(sglk_stream_t stream, void* out, const void* a, cons
                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                             int in_dtype, int out_dtype);
 
+/* ---- quantisation steps around the scaled GEMMs ---------------------------------
+ * sgl_per_token_quant_fp8: reference src/sycl/per_token_quant_fp8.cpp:201 (schema torch_extension_sycl.cc:410).
+ *   input [rows, cols] F16/BF16/F32 contiguous -> output_q e4m3fn [rows, cols], output_s fp32 [rows]
+ *   scale = rowmax|x| / 448, q = e4m3(clamp(x / scale, +-448)) (all zeros for an all-zero row).
+ * sgl_per_tensor_quant_fp8: reference src/sycl/per_tensor_quant_fp8.cpp:161 (schema :407).
+ *   is_static == 0: output_s[0] (zero-initialised by the caller) is raised to max|x| / 448 first;
+ *   q = e4m3(clamp(x * 1 / (output_s[0] + 1e-8), +-448)).
+ * awq_dequantize: reference src/sycl/awq_dequantize.cpp:98-123 (schema :26).
+ *   qweight int32 [K, C], qzeros int32 [K / group, C], scales F16/BF16 [K / group, 8 C] -> out [K, 8 C] (dtype of scales),
+ *   nibble order 0,4,1,5,2,6,3,7 inside each int32. */
+SGLK_API int sglk_per_token_quant_fp8(sglk_stream_t stream, void* output_q, float* output_s, const void* input,
+                                      int64_t rows, int64_t cols, int dtype);
+SGLK_API int sglk_per_tensor_quant_fp8(sglk_stream_t stream, void* output_q, float* output_s, const void* input,
+                                       int64_t numel, int is_static, int dtype);
+SGLK_API int sglk_awq_dequantize(sglk_stream_t stream, void* out, const int32_t* qweight, const void* scales,
+                                 const int32_t* qzeros, int64_t K, int64_t C, int64_t group_size, int dtype);
+
 /* ---- QServe W4A8 GEMMs ------------------------------------------------------
  * Declared only in the reference (include/sgl_kernel_ops.h:1132-1148; wrappers python/sgl_kernel/gemm.py:314-356);
  * meaning, quantisers and the 32x32 interleaved weight packing pinned by tests/test_qserve_w4a8_per_chn_gemm.py:

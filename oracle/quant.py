@@ -75,3 +75,40 @@ def per_token_group_quant_8bit_v2(x: torch.Tensor, group_size: int, dst_dtype: t
     if masked_m is not None:
         valid = torch.arange(lead[1]).view(1, -1) < masked_m.view(-1, 1)
     return q, s, ue, valid
+
+
+# ---- per-token / per-tensor fp8 quantisation and AWQ dequantisation ---------------------------
+
+def per_token_quant_fp8(x: torch.Tensor):
+    """Reference src/sycl/per_token_quant_fp8.cpp:36, :96-125: per row scale = rowmax|x| / 448,
+    q = e4m3(clamp(x * (scale == 0 ? 0 : 1 / scale), +-448)). Returns (q e4m3fn, scale fp32 [rows])."""
+    xf = x.float().reshape(-1, x.shape[-1])
+    scale = xf.abs().amax(dim=-1) / 448.0
+    inv = torch.where(scale == 0, torch.zeros_like(scale), 1.0 / scale)
+    q = (xf * inv[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.reshape(x.shape), scale
+
+
+def per_tensor_quant_fp8(x: torch.Tensor, scale: torch.Tensor = None):
+    """Reference src/sycl/per_tensor_quant_fp8.cpp:46-47, :58-105, :121-161: dynamic scale = max|x| / 448;
+    q = e4m3(clamp(x * (1 / (scale + 1e-8)), +-448)) with fp32 arithmetic. Returns (q, scale fp32 [1])."""
+    xf = x.float()
+    if scale is None:
+        scale = (xf.abs().max() / 448.0).reshape(1)
+    inv = torch.tensor(1.0, dtype=torch.float32) / (scale.float().reshape(1) + torch.tensor(1e-8, dtype=torch.float32))
+    q = (xf * inv).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q, scale.float().reshape(1)
+
+
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> torch.Tensor:
+    """Reference src/sycl/awq_dequantize.cpp:15-51 (tests/test_awq_dequant.py:13-62): int32 words hold 8 nibbles in the
+    order 0,4,1,5,2,6,3,7; out[k, 8c+i] = (w - z) * scale in the dtype of scales."""
+    order = torch.tensor([0, 4, 1, 5, 2, 6, 3, 7])
+    shifts = (order * 4).view(1, 1, 8)
+    w = (qweight.to(torch.int64)[:, :, None] >> shifts) & 15
+    z = (qzeros.to(torch.int64)[:, :, None] >> shifts) & 15
+    group = qweight.shape[0] // scales.shape[0]
+    z = z.repeat_interleave(group, dim=0)
+    s = scales.float().repeat_interleave(group, dim=0)
+    out = (w - z).reshape(qweight.shape[0], -1).float() * s
+    return out.to(scales.dtype)

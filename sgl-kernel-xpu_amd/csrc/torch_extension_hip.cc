@@ -286,6 +286,61 @@ Tensor int8_scaled_mm(const Tensor& mat_a, const Tensor& mat_b, const Tensor& sc
   return scaled_mm_impl(mat_a, mat_b, scales_a, scales_b, out_dtype, bias, true, "int8_scaled_mm");
 }
 
+// ---- per-token / per-tensor fp8 quantisation, AWQ dequantisation (reference src/sycl/per_token_quant_fp8.cpp:201,
+//      per_tensor_quant_fp8.cpp:161, awq_dequantize.cpp:98-123) -----------------------------------------------
+
+void sgl_per_token_quant_fp8(Tensor input, Tensor output_q, Tensor output_s) {
+  CHECK_GPU(input);
+  CHECK_GPU(output_q);
+  CHECK_GPU(output_s);
+  CHECK_CONTIGUOUS(input);
+  CHECK_CONTIGUOUS(output_q);
+  CHECK_CONTIGUOUS(output_s);
+  TORCH_CHECK(input.dim() >= 1, "sgl_per_token_quant_fp8: input must have at least one dimension");
+  TORCH_CHECK(output_q.scalar_type() == at::kFloat8_e4m3fn && output_q.numel() == input.numel(),
+              "sgl_per_token_quant_fp8: output_q must be float8_e4m3fn with the shape of input");
+  const int64_t cols = input.size(-1), rows = cols ? input.numel() / cols : 0;
+  TORCH_CHECK(output_s.scalar_type() == at::kFloat && output_s.numel() == rows,
+              "sgl_per_token_quant_fp8: output_s must hold one float32 per token");
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_per_token_quant_fp8(stream_of(input), output_q.data_ptr(), output_s.data_ptr<float>(), input.data_ptr(),
+                                     rows, cols, dtype_code(input.scalar_type(), "input")));
+}
+
+void sgl_per_tensor_quant_fp8(Tensor input, Tensor output_q, Tensor output_s, bool is_static) {
+  CHECK_GPU(input);
+  CHECK_GPU(output_q);
+  CHECK_GPU(output_s);
+  CHECK_CONTIGUOUS(input);
+  CHECK_CONTIGUOUS(output_q);
+  TORCH_CHECK(output_q.scalar_type() == at::kFloat8_e4m3fn && output_q.numel() == input.numel(),
+              "sgl_per_tensor_quant_fp8: output_q must be float8_e4m3fn with the shape of input");
+  TORCH_CHECK(output_s.scalar_type() == at::kFloat && output_s.numel() == 1, "sgl_per_tensor_quant_fp8: output_s must be one float32");
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_per_tensor_quant_fp8(stream_of(input), output_q.data_ptr(), output_s.data_ptr<float>(), input.data_ptr(),
+                                      input.numel(), is_static ? 1 : 0, dtype_code(input.scalar_type(), "input")));
+}
+
+Tensor awq_dequantize(Tensor qweight, Tensor scales, Tensor qzeros) {
+  CHECK_GPU(qweight);
+  CHECK_GPU(scales);
+  CHECK_GPU(qzeros);
+  CHECK_CONTIGUOUS(qweight);
+  CHECK_CONTIGUOUS(scales);
+  CHECK_CONTIGUOUS(qzeros);
+  TORCH_CHECK(qweight.dim() == 2 && scales.dim() == 2 && qzeros.dim() == 2, "awq_dequantize: 2-D tensors expected");
+  TORCH_CHECK(qweight.scalar_type() == at::kInt && qzeros.scalar_type() == at::kInt, "awq_dequantize: qweight / qzeros must be int32");
+  const int64_t K = qweight.size(0), C = qweight.size(1);
+  TORCH_CHECK(scales.size(0) > 0 && K % scales.size(0) == 0 && scales.size(1) == C * 8 && qzeros.size(0) == scales.size(0) &&
+                  qzeros.size(1) == C,
+              "awq_dequantize: scales must be [K / group, 8 C] and qzeros [K / group, C]");
+  Tensor out = at::empty({K, C * 8}, scales.options());
+  const c10::OptionalDeviceGuard guard(qweight.device());
+  SGLK_CALL(sglk_awq_dequantize(stream_of(qweight), out.data_ptr(), qweight.data_ptr<int32_t>(), scales.data_ptr(),
+                                qzeros.data_ptr<int32_t>(), K, C, K / scales.size(0), dtype_code(scales.scalar_type(), "scales")));
+  return out;
+}
+
 // ---- QServe W4A8 (reference include/sgl_kernel_ops.h:1132-1148; python/sgl_kernel/gemm.py:314-356) ----------
 
 static void qserve_common(const char* op, const Tensor& in_feats, const Tensor& kernel, const Tensor& wscales,
@@ -980,6 +1035,12 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
   m.impl("fwd", c10::kCUDA, &mha_fwd);
 
   // reference src/torch_extension_sycl.cc:362-368
+  m.def("awq_dequantize(Tensor qweight, Tensor scales, Tensor qzeros) -> Tensor");
+  m.impl("awq_dequantize", c10::kCUDA, &awq_dequantize);
+  m.def("sgl_per_tensor_quant_fp8(Tensor input, Tensor output_q, Tensor output_s, bool is_static) -> ()");
+  m.impl("sgl_per_tensor_quant_fp8", c10::kCUDA, &sgl_per_tensor_quant_fp8);
+  m.def("sgl_per_token_quant_fp8(Tensor input, Tensor(a!) output_q, Tensor(b!) output_s) -> ()");
+  m.impl("sgl_per_token_quant_fp8", c10::kCUDA, &sgl_per_token_quant_fp8);
   m.def(
       "qserve_w4a8_per_chn_gemm(Tensor _in_feats, Tensor _kernel, Tensor _wscales, Tensor _ascales, Tensor _w_szs, "
       "Tensor _a_ssums, Tensor! _out_feats) -> ()");

@@ -36,6 +36,9 @@ from sgl_kernel.elementwise import (  # noqa: E402
 )
 from sgl_kernel.flash_attn import flash_attn_varlen_func, flash_attn_with_kvcache, is_fa3_supported  # noqa: E402
 from sgl_kernel.gemm import (  # noqa: E402
+    awq_dequantize,
+    sgl_per_tensor_quant_fp8,
+    sgl_per_token_quant_fp8,
     fp8_blockwise_scaled_mm,
     fp8_scaled_mm,
     int8_scaled_mm,
@@ -61,8 +64,8 @@ from sgl_kernel.version import __version__  # noqa: E402
 # `from sgl_kernel import X` keeps working for callers that never use X.
 _OUT_OF_SCOPE = frozenset(
     """
-    awq_dequantize bmm_fp8 cutlass_scaled_fp4_mm scaled_fp4_experts_quant scaled_fp4_quant
-    sgl_per_tensor_quant_fp8 sgl_per_token_group_quant_fp4 sgl_per_token_quant_fp8
+    bmm_fp8 cutlass_scaled_fp4_mm scaled_fp4_experts_quant scaled_fp4_quant
+    sgl_per_token_group_quant_fp4
     merge_state merge_state_v2 lightning_attention_decode flash_mla_sparse_fwd flash_mla_with_kvcache
     apply_rope_with_cos_sin_cache_inplace fused_inplace_qknorm_rope fused_k_norm_rope_flashmla
     fused_q_norm_rope fused_qk_norm_rope fused_qk_rope fused_qk_rope_with_cos_sin_cache_inplace

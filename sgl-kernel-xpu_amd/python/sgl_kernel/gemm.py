@@ -122,3 +122,18 @@ def qserve_w4a8_per_group_gemm(
         out_feats = torch.empty((in_feats.shape[0], kernel.shape[0]), device=in_feats.device, dtype=torch.float16)
     torch.ops.sgl_kernel.qserve_w4a8_per_group_gemm.default(in_feats, kernel, zeros, scales_i8, wscales, ascales, out_feats)
     return out_feats
+
+
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> torch.Tensor:
+    """Reference python/sgl_kernel/gemm.py:7-10."""
+    return torch.ops.sgl_kernel.awq_dequantize.default(qweight, scales, qzeros)
+
+
+def sgl_per_tensor_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor, is_static: bool) -> None:
+    """Reference python/sgl_kernel/gemm.py (sgl_per_tensor_quant_fp8): output_s must be zero-initialised when dynamic."""
+    torch.ops.sgl_kernel.sgl_per_tensor_quant_fp8.default(input, output_q, output_s, is_static)
+
+
+def sgl_per_token_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor) -> None:
+    """Reference python/sgl_kernel/gemm.py:236-241."""
+    torch.ops.sgl_kernel.sgl_per_token_quant_fp8.default(input, output_q, output_s)

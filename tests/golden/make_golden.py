@@ -229,6 +229,33 @@ def gen_qserve():
     save("qserve_w4a8", cases)
 
 
+def gen_quant_extra():
+    """tests/test_per_token_quant_fp8.py:18-27, test_per_tensor_quant_fp8.py:30-38, test_awq_dequant.py:13-62."""
+    import types as _types
+    sys.modules.setdefault("utils", _types.SimpleNamespace(get_device=lambda: torch.device("cpu")))
+    tt = _import_ref("test_per_token_quant_fp8")
+    tp = _import_ref("test_per_tensor_quant_fp8")
+    ta = _import_ref("test_awq_dequant")
+    cases = {"token": [], "tensor": [], "awq": []}
+    torch.manual_seed(42)
+    for dt, rows, cols in [(torch.float16, 7, 512), (torch.bfloat16, 5, 1076), (torch.bfloat16, 3, 1368)]:
+        x = torch.rand(rows, cols, dtype=dt)
+        scale = x.float().abs().amax(dim=-1) / 448.0  # the kernel's scale (per_token_quant_fp8.cpp:109)
+        cases["token"].append(dict(x=x, scale=scale, q=tt.torch_per_token_quant_fp8(x, scale).view(torch.uint8)))
+    for dt, rows, cols in [(torch.float16, 8, 512), (torch.bfloat16, 4, 2048)]:
+        x = torch.rand(rows, cols, dtype=dt)
+        scale = (x.float().abs().max() / 448.0).reshape(1)
+        # the kernel multiplies by 1 / (scale + 1e-8) (per_tensor_quant_fp8.cpp:66); the reference test compares it with
+        # x * scale.reciprocal() at rtol / atol 1e-3
+        cases["tensor"].append(dict(x=x, scale=scale, q=tp.torch_scaled_fp8_quant(x, scale).view(torch.uint8)))
+    for dt, k, c in [(torch.float16, 128, 16), (torch.bfloat16, 256, 32)]:
+        qw = torch.randint(0, torch.iinfo(torch.int32).max, (k, c), dtype=torch.int32)
+        sc = torch.rand(1, c * 8, dtype=dt)
+        qz = torch.randint(0, torch.iinfo(torch.int32).max, (1, c), dtype=torch.int32)
+        cases["awq"].append(dict(qweight=qw, scales=sc, qzeros=qz, out=ta.awq_dequantize_torch(qw, sc, qz, k)))
+    save("quant_extra", cases)
+
+
 def gen_moe():
     t = _import_ref("test_moe_gemm")
     cases = {"grouped_mm": [], "fused": []}
@@ -327,6 +354,7 @@ GENERATORS = {
     "mla_decode": gen_mla_decode,
     "mla_prefill": gen_mla_prefill,
     "qserve_w4a8": gen_qserve,
+    "quant_extra": gen_quant_extra,
     "norm": gen_norm,
     "activation": gen_activation,
     "quant": gen_quant,

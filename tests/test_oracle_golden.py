@@ -186,3 +186,23 @@ def test_qserve_oracle_matches_reference_vectors():
         assert torch.equal(s8f, c["scales_i8"]) and torch.equal(z8f, c["zeros"])
         out = oq.w4a8_per_group_gemm(c["a_q"], b_q, c["a_scale"], chn, s8, z8)
         torch.testing.assert_close(out, c["out"], rtol=1e-3, atol=1e-5)  # reference tolerance (:175)
+
+
+def test_quant_extra_oracle_matches_reference_vectors():
+    """oracle per-token / per-tensor fp8 quant and AWQ dequant vs the reference test references."""
+    g = load_golden("quant_extra")
+    for c in g["token"]:
+        q, s = oquant.per_token_quant_fp8(c["x"])
+        assert torch.equal(s, c["scale"])
+        # reference tolerance (test_per_token_quant_fp8.py:60-62): rtol = atol = 1e-3 on the dequantised codes
+        torch.testing.assert_close(q.float(), c["q"].view(torch.float8_e4m3fn).float(), rtol=1e-3, atol=1e-3)
+    for c in g["tensor"]:
+        q, s = oquant.per_tensor_quant_fp8(c["x"])
+        assert torch.equal(s, c["scale"])
+        # 1 / (scale + 1e-8) vs scale.reciprocal() may move a value across a rounding boundary: a handful of codes
+        # differ by one step, which the reference accepts through its tolerance on the few that do (:57-59)
+        a, b = q.float(), c["q"].view(torch.float8_e4m3fn).float()
+        assert ((a - b).abs() <= 0.125 * b.abs() + 1e-3).all() and (a != b).float().mean() < 0.02
+    for c in g["awq"]:
+        out = oquant.awq_dequantize(c["qweight"], c["scales"], c["qzeros"])
+        torch.testing.assert_close(out.float(), c["out"].float(), rtol=1e-3, atol=1e-5)  # reference tolerance (:119-121)
