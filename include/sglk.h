@@ -197,6 +197,14 @@ SGLK_API int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void* 
                                    int64_t cache_page_stride, int64_t table_stride, float sm_scale,
                                    int64_t num_kv_splits, int dtype);
 
+/* moe_grouped_mm_nt_xe20 (16-bit weights): reference src/sycl/GroupGemmXe20.cpp:160-275.
+ *   out[rows of expert e] = A_e @ W_e^T (+ bias_e fp32); W [E, N, K] with row stride ldb and expert stride
+ *   weight_stride_e (elements); A [total_m, K], out [total_m, N] contiguous; dtype BF16 / F16. */
+SGLK_API int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* activations, const void* weights,
+                                 const float* bias, const int32_t* rows_per_expert, int64_t total_m,
+                                 int64_t n_experts, int64_t N, int64_t K, int64_t ldb, int64_t weight_stride_e,
+                                 int dtype);
+
 /* ---- MLA prefill ------------------------------------------------------------
  * flash_mla_prefill: reference src/sycl/mla_prefill.cpp (schema src/torch_extension_sycl.cc:379-383;
  * wrapper python/sgl_kernel/attention.py:149-233; meaning tests/test_flash_mla_prefill.py:30-90).

@@ -138,3 +138,47 @@ def fused_experts_int4(x, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale, w1
     for j in range(topk):  # slot order, fp32
         acc = acc + t[:, j]
     return acc.to(T)
+
+
+def moe_grouped_mm(act, weights, bias, rows_per_expert):
+    """moe_grouped_mm_nt_xe20 without the fused epilogue (reference src/sycl/GroupGemmXe20.cpp:160-275): expert e
+    multiplies its rows by W_e^T (+ fp32 bias), fp32 accumulation, one rounding to the activation dtype."""
+    T = act.dtype
+    out = torch.empty(act.shape[0], weights.shape[1], dtype=T)
+    r0 = 0
+    for e, r in enumerate(rows_per_expert.tolist()):
+        if r:
+            o = act[r0:r0 + r].float() @ weights[e].float().t()
+            if bias is not None:
+                o = o + bias[e].float()
+            out[r0:r0 + r] = o.to(T)
+        r0 += r
+    return out
+
+
+def fused_experts_16bit(x, w1, w2, topk_weights, topk_ids, b1=None, b2=None, activation="silu", routed_scaling_factor=None):
+    """fused_experts with 16-bit weights: the op sequence of reference python/sgl_kernel/moe.py:742-866 (GEMM1, gated
+    activation in the activation dtype, GEMM2, fp32 weighted combine in slot order); same result as torch_naive_moe
+    (tests/test_moe_gemm.py:59-137) up to the rounding of the two intermediates."""
+    T = x.dtype
+    E = w1.shape[0]
+    topk = topk_ids.shape[1]
+    counts, _, _, a_map, c_map = prepare_moe_input(topk_ids.numpy(), E, x.shape[1], topk)
+    a = x[torch.from_numpy(a_map).long()]
+    rows = torch.from_numpy(counts)
+    h = moe_grouped_mm(a, w1, b1.float() if b1 is not None else None, rows)
+    if activation == "silu":
+        h = oact.silu_and_mul(h)
+    elif activation == "gelu":
+        h = oact.gelu_tanh_and_mul(h)
+    else:
+        h = torch.square(torch.relu(h))
+    o = moe_grouped_mm(h, w2, b2.float() if b2 is not None else None, rows)
+    gathered = o[torch.from_numpy(c_map).long()].view(x.shape[0], topk, -1).float()
+    t = gathered * topk_weights.float().unsqueeze(-1)
+    if routed_scaling_factor is not None and routed_scaling_factor != 1.0:
+        t = t * routed_scaling_factor
+    acc = torch.zeros(x.shape[0], o.shape[1])
+    for j in range(topk):  # slot order, fp32
+        acc = acc + t[:, j]
+    return acc.to(T)

@@ -1,0 +1,210 @@
+// moe_grouped_mm_nt_xe20: grouped GEMM over ragged expert row blocks with 16-bit weights.
+//
+// Replaces reference src/sycl/GroupGemmXe20.cpp:160-275 (host) and its CuTe kernels. Contract kept (schema
+// src/torch_extension_sycl.cc:208-212; caller python/sgl_kernel/moe.py:763-775, :812-860):
+//   for expert e with rows[e] consecutive rows of `activations` [total_m, K]:
+//     out_e = A_e @ W_e^T (+ bias_e fp32),   W [E, N, K] (row stride ld_b), out [total_m, N]
+// The fused gate/up activation of the reference op (fuse_act) is composed by the caller layer from this GEMM and
+// the activation kernels (csrc/activation.hip): one more pass over the [total_m, N] intermediate, same arithmetic up
+// to the rounding of that intermediate to the activation dtype - which is also what the reference's own unfused
+// route (moe.py:742-810) does.
+//
+// Kernel: the skeleton of moe_w4a16.hip without the dequantisation. Block = 4 waves; wave w owns NW 16-wide n tiles
+// and all MT 16-row m tiles of the block's expert rows. Weights stream HBM -> registers (lane (n, g) reads the 16
+// bytes k = 32 j + 8 g .. + 7 of its row per 32-deep MFMA step: 64 contiguous bytes per row and instruction, 256 per
+// 128-deep block), two blocks ahead in a static register ring; the activation tile [BM x 128] goes through LDS once
+// per block for all 4 waves (loaded one block ahead, written to LDS the iteration after; LDS-only barrier).
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+template <typename T>
+__device__ __forceinline__ v4f mma16(const v4i& a, const v4i& b, const v4f& c);
+template <>
+__device__ __forceinline__ v4f mma16<bf16>(const v4i& a, const v4i& b, const v4f& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ v4f mma16<f16>(const v4i& a, const v4i& b, const v4f& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+}
+
+template <typename T, int MT, int NW>
+__global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, const T* __restrict__ act,
+                                                       const T* __restrict__ w, const float* __restrict__ bias,
+                                                       const int32_t* __restrict__ rows_per_expert, int E, int N, int K,
+                                                       int64_t ldb, int64_t w_stride_e) {
+  constexpr int BM = 16 * MT;
+  constexpr int BN = 64 * NW;
+  __shared__ __attribute__((aligned(256))) char smem[2 * BM * 256];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- which expert / which block of its rows (uniform scalar walk over the row counts)
+  int e = 0, row0 = 0, rows_e = 0, blk = blockIdx.x;
+  bool found = false;
+  for (; e < E; ++e) {
+    rows_e = rows_per_expert[e];
+    const int nb = (rows_e + BM - 1) / BM;
+    if (blk < nb) { found = true; break; }
+    blk -= nb;
+    row0 += rows_e;
+  }
+  if (!found) return;
+  const int m0 = row0 + blk * BM;
+  const int m_valid = rows_e - blk * BM;
+  const int n_base = blockIdx.y * BN + wave * (NW * 16);
+
+  const T* wexp = w + (int64_t)e * w_stride_e;
+  uint32_t woff[NW];  // element offset of this lane's row and k group
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt) {
+    int n = n_base + nt * 16 + l15;
+    n = n < N ? n : N - 1;
+    woff[nt] = (uint32_t)n * (uint32_t)ldb + 8 * g;
+  }
+
+  auto load_a = [&](int kb, v4i (&r)[MT]) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx >> 4, c = idx & 15;
+      const int grow = m0 + (row < m_valid ? row : m_valid - 1);
+      const bool in = kb * 128 + c * 8 < K;  // past K: read k = 0 instead and zero the registers (no branch)
+      const v4i v = *reinterpret_cast<const v4i*>(act + (int64_t)grow * K + (in ? kb * 128 + c * 8 : 0));
+      r[i][0] = in ? v[0] : 0; r[i][1] = in ? v[1] : 0; r[i][2] = in ? v[2] : 0; r[i][3] = in ? v[3] : 0;
+    }
+  };
+  auto store_a = [&](int buf, const v4i (&r)[MT]) {
+    char* base = smem + buf * (BM * 256);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx >> 4, c = idx & 15;
+      *reinterpret_cast<v4i*>(base + row * 256 + ((c ^ (row & 15)) << 4)) = r[i];
+    }
+  };
+  // weights of k step j of block kb: 16 bytes at k = 128 kb + 32 j + 8 g (past K: any valid address, the
+  // activations there are zero)
+  auto load_w = [&](int kb, v4i (&dst)[NW][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kb * 128 + 32 * j;
+      const uint32_t koff = (k + 8 * g < K) ? (uint32_t)k : 0u;
+#pragma unroll
+      for (int nt = 0; nt < NW; ++nt) dst[nt][j] = *reinterpret_cast<const v4i*>(wexp + woff[nt] + koff);
+    }
+  };
+
+  v4f acc[MT][NW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = (K + 127) >> 7;
+  v4i wq_[2][NW][4], aq_[2][MT];
+  load_w(0, wq_[0]);
+  load_w(1, wq_[1]);
+  load_a(0, aq_[0]);
+  load_a(1, aq_[1]);
+  store_a(0, aq_[0]);
+  load_a(2, aq_[0]);
+
+  for (int kb0 = 0; kb0 < nkb; kb0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int kb = kb0 + u;
+      const int buf = kb & 1;
+      // (not __syncthreads(): that would wait vmcnt(0) and drain the prefetch rings every block)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      store_a(buf ^ 1, aq_[(u + 1) & 1]);
+      load_a(kb + 3, aq_[(u + 1) & 1]);
+      v4i wd[NW][4];
+#pragma unroll
+      for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wd[nt][j] = wq_[u][nt][j];
+      load_w(kb + 2, wq_[u]);
+      const char* abase = smem + buf * (BM * 256);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int row = mt * 16 + l15;
+          const v4i af = *reinterpret_cast<const v4i*>(abase + row * 256 + (((4 * j + g) ^ l15) << 4));
+#pragma unroll
+          for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = mma16<T>(af, wd[nt][j], acc[mt][nt]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: lane owns out[m = 16 mt + 4 g + r][n = n_base + 16 nt + l15]
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt) {
+    const int n = n_base + nt * 16 + l15;
+    if (n >= N) continue;
+    const float bv = bias ? bias[(int64_t)e * N + n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + 4 * g + r;
+        if (row < m_valid) out[(int64_t)(m0 + row) * N + n] = (T)(acc[mt][nt][r] + bv);
+      }
+    }
+  }
+}
+
+template <typename T, int MT, int NW>
+static int launch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
+                  int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e) {
+  constexpr int BM = 16 * MT, BN = 64 * NW;
+  const int64_t max_mblocks = total_m / BM + E;  // sum_e ceil(rows_e / BM) <= total_m / BM + E
+  dim3 grid((unsigned)max_mblocks, (unsigned)cdiv(N, BN));
+  moe_bf16_kernel<T, MT, NW><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E, N, K, ldb, w_stride_e);
+  return check_launch("moe_grouped_mm_nt_xe20");
+}
+
+template <typename T>
+static int dispatch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
+                    int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e) {
+  const int64_t avg = total_m / E;  // tile policy by average rows per expert, as the reference (GroupGemmXe20.cpp:226-274)
+  if (avg <= 16) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e);
+  if (avg <= 32) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e);
+  if (avg <= 128) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e);
+  return launch<T, 8, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e);
+}
+
+}  // namespace
+}  // namespace sglk
+
+extern "C" int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* activations, const void* weights,
+                                   const float* bias, const int32_t* rows_per_expert, int64_t total_m,
+                                   int64_t n_experts, int64_t N, int64_t K, int64_t ldb, int64_t weight_stride_e,
+                                   int dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "moe_grouped_mm_nt_xe20: activations and weights must be bfloat16 or half");
+  SGLK_REQUIRE(n_experts > 0 && N > 0 && K > 0, "moe_grouped_mm_nt_xe20: bad shape");
+  SGLK_REQUIRE(K % 8 == 0 && ldb % 8 == 0 && weight_stride_e % 8 == 0, "moe_grouped_mm_nt_xe20: K and the weight strides must be multiples of 8");
+  SGLK_REQUIRE((uintptr_t)activations % 16 == 0 && (uintptr_t)weights % 16 == 0,
+               "moe_grouped_mm_nt_xe20: activations and weights must be 16-byte aligned");
+  SGLK_REQUIRE(N * ldb < (1ll << 32), "moe_grouped_mm_nt_xe20: one expert's weights must stay below 4 Gi elements");
+  if (total_m == 0) return SGLK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SGLK_BF16)
+    return dispatch<bf16>(st, out, activations, weights, bias, rows_per_expert, total_m, (int)n_experts, (int)N, (int)K, ldb,
+                          weight_stride_e);
+  return dispatch<f16>(st, out, activations, weights, bias, rows_per_expert, total_m, (int)n_experts, (int)N, (int)K, ldb,
+                       weight_stride_e);
+}

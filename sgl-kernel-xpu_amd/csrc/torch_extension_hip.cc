@@ -698,6 +698,62 @@ void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, con
                                       group_size, is_int4 ? 1 : 0, dtype_code(activations.scalar_type(), "activations")));
 }
 
+// ---- moe_grouped_mm_nt_xe20 (reference src/sycl/GroupGemmXe20.cpp:160-275) ---------------------------------
+
+void moe_grouped_mm_nt_xe20(Tensor& output, const Tensor& activations, const Tensor& weights, const std::optional<Tensor>& bias,
+                            const Tensor& total_rows_for_experts, int64_t n_experts, int64_t activation_type, bool fuse_act,
+                            double gemm1_alpha, double gemm1_limit) {
+  (void)gemm1_alpha;
+  (void)gemm1_limit;
+  CHECK_GPU(output);
+  CHECK_GPU(activations);
+  CHECK_GPU(weights);
+  CHECK_GPU(total_rows_for_experts);
+  CHECK_CONTIGUOUS(activations);
+  CHECK_CONTIGUOUS(output);
+  TORCH_CHECK(activations.dim() == 2 && weights.dim() == 3, "activations must be 2D and weights 3D");
+  const int64_t total_m = activations.size(0), gemm_k = activations.size(1), gemm_n = weights.size(1);
+  TORCH_CHECK(weights.size(0) == n_experts, "weights must have n_experts as the first dimension");
+  TORCH_CHECK(weights.size(2) == gemm_k && weights.stride(2) == 1, "weights must be [n_experts, N, K] with contiguous K");
+  TORCH_CHECK(total_rows_for_experts.size(0) == n_experts && total_rows_for_experts.scalar_type() == at::kInt &&
+                  total_rows_for_experts.is_contiguous(),
+              "rows_for_experts must be an int32 tensor with one entry per expert");
+  TORCH_CHECK(output.size(0) == total_m, "output must have the same number of rows as activations");
+  TORCH_CHECK(activations.scalar_type() == weights.scalar_type() && output.scalar_type() == activations.scalar_type(),
+              "activations, weights and output must have the same data type");
+  TORCH_CHECK(activations.scalar_type() == at::kBFloat16 || activations.scalar_type() == at::kHalf,
+              "Only bfloat16 and half are supported in moe_grouped_mm_nt");
+  TORCH_CHECK(activation_type >= 0 && activation_type <= 3, "Unsupported activation_type: ", activation_type,
+              ". Supported values are 0 (silu), 1 (gelu), 2 (swiglu_gpt_oss), 3 (relu2)");
+  const float* bias_ptr = nullptr;
+  if (bias.has_value()) {
+    CHECK_GPU((*bias));
+    TORCH_CHECK(bias->scalar_type() == at::kFloat, "moe_grouped_mm_nt_xe20: bias must be float32 (at::kFloat) to match kernel expectations");
+    TORCH_CHECK(bias->dim() == 2 && bias->size(0) == n_experts && bias->size(1) == gemm_n && bias->is_contiguous(),
+                "bias must be 2D [n_experts, N]");
+    bias_ptr = bias->data_ptr<float>();
+  }
+  const c10::OptionalDeviceGuard guard(activations.device());
+  const int dt = dtype_code(activations.scalar_type(), "activations");
+  if (!fuse_act) {
+    TORCH_CHECK(output.size(1) == gemm_n, "output must have the same number of columns as the weights have rows");
+    SGLK_CALL(sglk_moe_grouped_mm(stream_of(activations), output.data_ptr(), activations.data_ptr(), weights.data_ptr(), bias_ptr,
+                                  total_rows_for_experts.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
+                                  weights.stride(1), weights.stride(0), dt));
+    return;
+  }
+  // fused gate / up epilogue: composed from the GEMM and the activation kernel (one more pass over [total_m, N])
+  TORCH_CHECK(activation_type == 0 || activation_type == 1,
+              "moe_grouped_mm_nt_xe20: fuse_act is built for silu (0) and gelu (1) on this device");
+  TORCH_CHECK(output.size(1) == gemm_n / 2, "output must have half the number of columns as activations");
+  Tensor tmp = at::empty({total_m, gemm_n}, activations.options());
+  SGLK_CALL(sglk_moe_grouped_mm(stream_of(activations), tmp.data_ptr(), activations.data_ptr(), weights.data_ptr(), bias_ptr,
+                                total_rows_for_experts.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
+                                weights.stride(1), weights.stride(0), dt));
+  SGLK_CALL(sglk_act_and_mul(stream_of(activations), output.data_ptr(), tmp.data_ptr(), total_m, gemm_n / 2, dt,
+                             activation_type == 0 ? SGLK_ACT_SILU : SGLK_ACT_GELU_TANH));
+}
+
 // ---- fwd / mha_fwd (reference src/sycl/flash_attention.cpp:1332-1435; the int/float narrowing the reference
 //      does with make_pytorch_shim, include/sgl_kernel_torch_shim.h:94-122, is done inline here) --------------
 
@@ -1069,6 +1125,11 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "experts_ids, Tensor! num_tokens_post_pad, Tensor! cumsum_buffer, bool "
       "pad_sorted_token_ids) -> ()");
   m.impl("moe_align_block_size", c10::kCUDA, &moe_align_block_size);
+  m.def(
+      "moe_grouped_mm_nt_xe20(Tensor! output, Tensor activations, Tensor weights, Tensor? bias, Tensor "
+      "total_rows_for_experts, int n_experts, int activation_type, bool fuse_act, float gemm1_alpha=1.702, float "
+      "gemm1_limit=7.0) -> ()");
+  m.impl("moe_grouped_mm_nt_xe20", c10::kCUDA, &moe_grouped_mm_nt_xe20);
   m.def(
       "moe_grouped_mm_nt_xe20_w4a16(Tensor! output, Tensor activations, Tensor packed_weights, Tensor scales, "
       "Tensor? zeros, Tensor? bias, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size) -> ()");

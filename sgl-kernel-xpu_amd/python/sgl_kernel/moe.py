@@ -160,7 +160,8 @@ def fused_experts(
     gemm1_limit: Optional[float] = None,
     swiglu_limit: Optional[float] = None,
 ) -> torch.Tensor:
-    """Routed-expert MLP: w1 [E, 2I (or I for relu2), H/2] and w2 [E, H, I/2] are int4-packed
+    """Routed-expert MLP. Default: 16-bit weights w1 [E, 2I (or I for relu2), H], w2 [E, H, I] in the activation
+    dtype. use_int4_w4a16: w1 [E, 2I (or I for relu2), H/2] and w2 [E, H, I/2] are int4-packed
     (two codes per byte, low nibble = even k) with per-group scales [E, N, K/group] in the
     activation dtype and optional raw zero-points of the same shape; topk_weights fp32 [T, k];
     biases fp32 (bf16 is up-cast, as the reference does: moe.py:574-587). Arguments and their
@@ -179,22 +180,22 @@ def fused_experts(
     assert not (use_mxfp4_w4a16 and use_int4_w4a16), "use_mxfp4_w4a16 and use_int4_w4a16 are mutually exclusive"
     if use_mxfp4_w4a16:
         raise NotImplementedError("fused_experts: the mxfp4 weight format is outside the MI355X build (int4 W4A16 only)")
-    if not use_4bit_w4a16:
-        raise NotImplementedError(
-            "fused_experts: the bf16-weight grouped GEMM (moe_grouped_mm_nt_xe20) is outside the MI355X build; "
-            "pass use_int4_w4a16=True"
-        )
-    assert w1.dtype == torch.int8 or w1.dtype == torch.uint8, "4-bit W4A16 requires w1 to be int8 or uint8 (packed [E, N, K/2])"
-    assert w2.dtype == torch.int8 or w2.dtype == torch.uint8, "4-bit W4A16 requires w2 to be int8 or uint8 (packed [E, N, K/2])"
-    assert w1_scale is not None, "w1_scale must be provided for 4-bit W4A16"
-    assert w2_scale is not None, "w2_scale must be provided for 4-bit W4A16"
-    assert (
-        w1_scale.dtype == hidden_states.dtype and w2_scale.dtype == hidden_states.dtype
-    ), "int4 scales dtype must match hidden_states dtype"
-    if w1_zp is not None:
-        assert w1_zp.dtype == w1_scale.dtype and w1_zp.shape == w1_scale.shape, "w1_zp must have the same dtype and shape as w1_scale"
-    if w2_zp is not None:
-        assert w2_zp.dtype == w2_scale.dtype and w2_zp.shape == w2_scale.shape, "w2_zp must have the same dtype and shape as w2_scale"
+    if use_4bit_w4a16:
+        assert w1.dtype == torch.int8 or w1.dtype == torch.uint8, "4-bit W4A16 requires w1 to be int8 or uint8 (packed [E, N, K/2])"
+        assert w2.dtype == torch.int8 or w2.dtype == torch.uint8, "4-bit W4A16 requires w2 to be int8 or uint8 (packed [E, N, K/2])"
+        assert w1_scale is not None, "w1_scale must be provided for 4-bit W4A16"
+        assert w2_scale is not None, "w2_scale must be provided for 4-bit W4A16"
+        assert (
+            w1_scale.dtype == hidden_states.dtype and w2_scale.dtype == hidden_states.dtype
+        ), "int4 scales dtype must match hidden_states dtype"
+        if w1_zp is not None:
+            assert w1_zp.dtype == w1_scale.dtype and w1_zp.shape == w1_scale.shape, "w1_zp must have the same dtype and shape as w1_scale"
+        if w2_zp is not None:
+            assert w2_zp.dtype == w2_scale.dtype and w2_zp.shape == w2_scale.shape, "w2_zp must have the same dtype and shape as w2_scale"
+    else:
+        # 16-bit weights: w1 [E, 2I (or I for relu2), H], w2 [E, H, I] in the activation dtype (reference moe.py:763-775)
+        assert w1.dtype == hidden_states.dtype and w2.dtype == hidden_states.dtype, "w1 / w2 must have the dtype of hidden_states"
+        assert w1_scale is None and w2_scale is None and w1_zp is None and w2_zp is None, "scales / zero points need a 4-bit format"
     if b1 is not None:
         assert b1.dtype == torch.bfloat16 or b1.dtype == torch.float32, "b1 must be bfloat16 or float32"
         if b1.dtype == torch.bfloat16:
@@ -204,8 +205,9 @@ def fused_experts(
         if b2.dtype == torch.bfloat16:
             b2 = b2.float()
 
-    _w1_inner = w1.shape[-1] * 2
-    _w2_inner = w2.shape[-1] * 2
+    _pack = 2 if use_4bit_w4a16 else 1  # codes per stored element
+    _w1_inner = w1.shape[-1] * _pack
+    _w2_inner = w2.shape[-1] * _pack
     assert hidden_states.ndim == 2, "hidden_states must be 2D"
     assert (
         hidden_states.shape[-1] == _w1_inner
@@ -220,10 +222,10 @@ def fused_experts(
     num_tokens, hidden_dims = hidden_states.shape
     E, _, K = w1.shape
     E, OutK, N = w2.shape
-    K = K * 2
-    N = N * 2
-    w1_group_size = K // w1_scale.shape[2]
-    w2_group_size = N // w2_scale.shape[2]
+    K = K * _pack
+    N = N * _pack
+    w1_group_size = K // w1_scale.shape[2] if use_4bit_w4a16 else 0
+    w2_group_size = N // w2_scale.shape[2] if use_4bit_w4a16 else 0
     if b1 is not None:
         assert b1.shape == w1.shape[:2], "b1 shape must match w1 shape[:2]"
     if b2 is not None:
@@ -273,12 +275,19 @@ def fused_experts(
 
     gate_factor = 2 if (2 * N == w1.shape[1]) else 1
 
-    # the 4-bit path always runs GEMM1 -> activation kernel -> GEMM2 (reference moe.py:735)
+    # GEMM1 -> activation kernel -> GEMM2: the reference's unfused route (moe.py:735-810), which it always takes for
+    # 4-bit weights; 16-bit weights take it here as well (its fused-epilogue route computes the same thing without
+    # rounding the GEMM1 output to the activation dtype first)
     intermediate_cache1 = _get_moe_ws("intermediate_cache1_unfused", (M * TopK, gate_factor * N), hidden_states.dtype, dev)
     intermediate_cache2 = _get_moe_ws("intermediate_cache2", (M * TopK, N), hidden_states.dtype, dev)
-    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(
-        intermediate_cache1, input_A_shuffle, w1, w1_scale, w1_zp, b1, expert_offsets, E, use_int4_w4a16, w1_group_size
-    )
+
+    def grouped_mm(out, a, w, w_scale, w_zp, bias, group_size):
+        if use_4bit_w4a16:
+            torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(out, a, w, w_scale, w_zp, bias, expert_offsets, E, use_int4_w4a16, group_size)
+        else:
+            torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, a, w, bias, expert_offsets, E, activation_type, False, 1.702, 7.0)
+
+    grouped_mm(intermediate_cache1, input_A_shuffle, w1, w1_scale, w1_zp, b1, w1_group_size)
     if activation_type == 0:
         torch.ops.sgl_kernel.silu_and_mul(intermediate_cache2, intermediate_cache1)
     elif activation_type == 1:
@@ -287,10 +296,7 @@ def fused_experts(
         intermediate_cache2 = torch.square(torch.relu(intermediate_cache1))
     if w2_g_idx_perm is not None:
         intermediate_cache2 = _apply_per_expert_channel_gather(intermediate_cache2, w2_g_idx_perm, expert_offsets, E)
-    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(
-        intermediate_cache3, intermediate_cache2.contiguous(), w2, w2_scale, w2_zp, b2, expert_offsets, E,
-        use_int4_w4a16, w2_group_size
-    )
+    grouped_mm(intermediate_cache3, intermediate_cache2.contiguous(), w2, w2_scale, w2_zp, b2, w2_group_size)
 
     rsf = 1.0
     if routed_scaling_factor is not None:

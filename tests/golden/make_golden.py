@@ -289,6 +289,22 @@ def gen_moe():
                     cases["fused"].append(dict(x=x, w1=w1.view(torch.uint8), w2=w2.view(torch.uint8), w1_scale=w1s,
                                                w2_scale=w2s, w1_zp=w1z, w2_zp=w2z, topk_ids=ids, topk_weights=tw,
                                                b1=b1, b2=b2, activation=activation, out=exp))
+    # tests/test_moe_gemm.py:140-236 (test_moe_gemm): 16-bit weights, torch_naive_moe as the reference
+    cases["fused16"] = []
+    for T, topk, E, H, I, act, with_bias in [(5, 2, 8, 128, 64, "silu", False), (7, 3, 8, 256, 128, "gelu", True),
+                                             (4, 1, 8, 128, 64, "relu2", False)]:
+        torch.manual_seed(3)
+        gate = 1 if act == "relu2" else 2
+        x = torch.randn(T, H, dtype=torch.bfloat16) * 0.1
+        w1 = torch.randn(E, gate * I, H, dtype=torch.bfloat16) * 0.1
+        w2 = torch.randn(E, H, I, dtype=torch.bfloat16) * 0.1
+        b1 = torch.randn(E, gate * I) * 0.005 if with_bias else None
+        b2 = torch.randn(E, H) * 0.005 if with_bias else None
+        score = torch.softmax(torch.randn(T, E, dtype=torch.bfloat16).float(), dim=-1)
+        tw, ids = torch.topk(score, topk)
+        exp = t.torch_naive_moe(x, w1, w2, ids, tw, topk, b1, b2, activations=act, routed_scaling_factor=2.5)
+        cases["fused16"].append(dict(x=x, w1=w1, w2=w2, topk_ids=ids, topk_weights=tw, b1=b1, b2=b2, activation=act,
+                                     routed_scaling_factor=2.5, out=exp))
     save("moe_w4a16", cases)
 
 

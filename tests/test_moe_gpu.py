@@ -6,6 +6,7 @@ import pytest
 import torch
 from conftest import load_golden
 
+from oracle import activation as oact
 from oracle import moe as omoe
 
 pytestmark = pytest.mark.gpu
@@ -210,8 +211,65 @@ def test_fused_experts_mixtral_shape_sampled(sglk, dev, T):
     torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=3e-2, atol=1e-2)
 
 
+# ---------------------------------------------------------------------- 16-bit weights
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows", [[2] * 8, [0, 17, 1, 0, 130, 3, 64, 33], [300] + [0] * 7])
+@pytest.mark.parametrize("N,K", [(128, 256), (352, 2816), (2816, 176), (1024, 1000)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_grouped_mm_16bit(sglk, dev, dt, rows, N, K, with_bias):
+    g = torch.Generator().manual_seed(N + K + sum(rows))
+    E, total = len(rows), sum(rows)
+    act = (torch.randn(total, K, generator=g) * 0.1).to(dt)
+    w = (torch.randn(E, N, K, generator=g) * 0.1).to(dt)
+    bias = torch.randn(E, N, generator=g) * 0.005 if with_bias else None
+    r = torch.tensor(rows, dtype=torch.int32)
+    out = torch.empty(total, N, dtype=dt, device=dev)
+    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, act.to(dev), w.to(dev), bias.to(dev) if with_bias else None, r.to(dev),
+                                               E, 0, False, 1.702, 7.0)
+    ref = omoe.moe_grouped_mm(act, w, bias, r)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=2e-2, atol=2e-3)
+
+
+def test_grouped_mm_16bit_fused_act(sglk, dev):
+    g = torch.Generator().manual_seed(5)
+    E, rows, N, K, dt = 8, [5, 0, 9, 1, 40, 2, 2, 7], 256, 512, torch.bfloat16
+    act = (torch.randn(sum(rows), K, generator=g) * 0.1).to(dt)
+    w = (torch.randn(E, N, K, generator=g) * 0.1).to(dt)
+    r = torch.tensor(rows, dtype=torch.int32)
+    for act_type, fn in ((0, oact.silu_and_mul), (1, oact.gelu_tanh_and_mul)):
+        out = torch.empty(sum(rows), N // 2, dtype=dt, device=dev)
+        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, act.to(dev), w.to(dev), None, r.to(dev), E, act_type, True, 1.702, 7.0)
+        ref = fn(omoe.moe_grouped_mm(act, w, None, r))
+        torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("T,topk,E,H,I", [(1, 2, 8, 1024, 512), (33, 6, 8, 1024, 1024), (222, 2, 64, 1024, 512),
+                                          (64, 1, 8, 4096, 512), (64, 8, 128, 2816, 176)])
+@pytest.mark.parametrize("activation,bias", [("silu", None), ("silu", "float32"), ("gelu", "bfloat16"), ("relu2", None)])
+def test_fused_experts_16bit(sglk, dev, T, topk, E, H, I, activation, bias):
+    """shapes / options of reference tests/test_moe_gemm.py:140-166 (bf16 weights, optional bf16 / fp32 bias,
+    routed_scaling_factor 2.5)"""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(T + H + I)
+    gate = 1 if activation == "relu2" else 2
+    x = (torch.randn(T, H, generator=g) * 0.1).to(dt)
+    w1 = (torch.randn(E, gate * I, H, generator=g) * 0.1).to(dt)
+    w2 = (torch.randn(E, H, I, generator=g) * 0.1).to(dt)
+    b1 = b2 = None
+    if bias:
+        bdt = torch.bfloat16 if bias == "bfloat16" else torch.float32
+        b1 = (torch.randn(E, gate * I, generator=g) * 0.005).to(bdt)
+        b2 = (torch.randn(E, H, generator=g) * 0.005).to(bdt)
+    score = torch.softmax(torch.randn(T, E, generator=g).to(dt).float(), dim=-1)
+    tw, ids = torch.topk(score, topk)
+    d = lambda t: t.to(dev) if t is not None else None
+    out = sglk.fused_experts(d(x), d(w1), d(w2), d(tw), d(ids), d(b1), d(b2), activation=activation, routed_scaling_factor=2.5)
+    ref = omoe.fused_experts_16bit(x, w1, w2, tw, ids, b1, b2, activation, 2.5)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=3e-2, atol=1e-2)
+
+
 def test_errors(sglk, dev):
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):
         sglk.fused_experts(torch.zeros(1, 128, device=dev), torch.zeros(1, 2, 64, device=dev),
                            torch.zeros(1, 128, 1, device=dev), torch.ones(1, 1, device=dev),
                            torch.zeros(1, 1, dtype=torch.int32, device=dev))

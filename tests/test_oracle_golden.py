@@ -206,3 +206,16 @@ def test_quant_extra_oracle_matches_reference_vectors():
     for c in g["awq"]:
         out = oquant.awq_dequantize(c["qweight"], c["scales"], c["qzeros"])
         torch.testing.assert_close(out.float(), c["out"].float(), rtol=1e-3, atol=1e-5)  # reference tolerance (:119-121)
+
+
+def test_fused_experts_16bit_oracle_matches_torch_naive_moe():
+    """oracle.moe.fused_experts_16bit vs torch_naive_moe outputs (reference tests/test_moe_gemm.py:59-137) on 16-bit
+    weights; the oracle rounds the two intermediates to bf16 as the op sequence does, the reference keeps them in its
+    working dtype, so the comparison uses the W4A16 tolerance of the same file (:471), not the 1e-4 of :236."""
+    from oracle import moe as omoe
+
+    for c in load_golden("moe_w4a16")["fused16"]:
+        out = omoe.fused_experts_16bit(c["x"], c["w1"], c["w2"], c["topk_weights"], c["topk_ids"], c["b1"], c["b2"],
+                                       c["activation"], c["routed_scaling_factor"])
+        torch.testing.assert_close(out.float(), c["out"].float(), rtol=1e-1, atol=2e-2)
+        torch.testing.assert_close(out.float(), c["out"].float(), rtol=3e-2, atol=3e-3)
