@@ -22,3 +22,21 @@ for T in (int(x) for x in (sys.argv[1:] or ["1", "16", "64", "256", "2048"])):
     for _ in range(n): f()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / n * 1e3
     print(f"fused_experts T={T}: {ms:.3f} ms  {2.0*T*topk*3*Hd*I/ms/1e9:.1f} TFLOP/s  weights {(w1.numel()+w2.numel())/ms/1e6:.0f} GB/s")
+
+# 16-bit weights (moe_grouped_mm_nt_xe20)
+del w1, w2, s1, s2
+w1b = (torch.randn(E, 2 * I, Hd, device=dev) * 0.02).to(torch.bfloat16)
+w2b = (torch.randn(E, Hd, I, device=dev) * 0.02).to(torch.bfloat16)
+for T in (64, 2048):
+    x = torch.randn(T, Hd, device=dev, dtype=torch.bfloat16) * 0.1
+    logits = torch.randn(T, E, device=dev, dtype=torch.bfloat16)
+    tw = torch.empty(T, topk, device=dev, dtype=torch.float32)
+    ti = torch.empty(T, topk, device=dev, dtype=torch.int32)
+    sgl_kernel.topk_softmax(tw, ti, logits, True)
+    f = lambda: sgl_kernel.fused_experts(x, w1b, w2b, tw, ti)
+    for _ in range(20): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 30 if T <= 256 else 10
+    for _ in range(n): f()
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / n * 1e3
+    print(f"fused_experts bf16 T={T}: {ms:.3f} ms  {2.0*T*topk*3*Hd*I/ms/1e9:.1f} TFLOP/s  weights {(w1b.numel()+w2b.numel())*2/ms/1e6:.0f} GB/s")
