@@ -430,7 +430,7 @@ template <typename OutT, bool HW_SCALE, int PROBE, int MS>  // MS m-steps per K 
 __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
-    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n) {
+    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves) {
   __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -455,14 +455,21 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   const int rounds = run_len / slots, left = run_len - rounds * slots;
   const bool split = left > 0 && 2 * left <= slots;
   constexpr bool kHalf = MS == 4;
-  const int n_units = kHalf ? ((split && slot < 2 * left) ? 1 : 0) : (split ? rounds : rounds + (slot < left ? 1 : 0));
+  // all_halves (MS = 4 only): every tile of the problem is processed as two 128-row halves, half tile h of the XCD's
+  // run = (tile h / 2, half h % 2). Up to 512 rows this gives 2x the workgroups of the 256-row tiling (a 128-row
+  // problem at N = 14336 has 56 tiles) at 0.6x the time per K block.
+  const int n_units = (kHalf && all_halves) ? (2 * run_len > slot ? (2 * run_len - slot + slots - 1) / slots : 0)
+                      : kHalf             ? ((split && slot < 2 * left) ? 1 : 0)
+                                          : (split ? rounds : rounds + (slot < left ? 1 : 0));
   if (n_units == 0) return;
 
   auto describe = [&](int unit) -> TileDesc {  // unit >= n_units: the null tile
     TileDesc d;
     bool live = unit < n_units;
     constexpr bool half = kHalf;
-    const int local = !live ? 0 : half ? rounds * slots + (slot >> 1) : slot + unit * slots;
+    const int ht = slot + unit * slots;  // half-tile index in the all_halves walk
+    const int local = !live ? 0 : (half && all_halves) ? (ht >> 1) : half ? rounds * slots + (slot >> 1) : slot + unit * slots;
+    const int lower = all_halves ? (ht & 1) : (slot & 1);
     const int tile = run_first + local;
     constexpr int GM = 4;
     const int group = tile / (GM * tiles_n);
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     const int tm = __builtin_amdgcn_readfirstlane(first_m + in_group % gsz);
     const int tn = __builtin_amdgcn_readfirstlane(in_group / gsz);
     const int trows = half ? BM / 2 : BM;
-    const int m0 = tm * BM + ((half && (slot & 1)) ? BM / 2 : 0), n0 = tn * BN;
+    const int m0 = tm * BM + ((half && lower) ? BM / 2 : 0), n0 = tn * BN;
     const int rows_a = (M - m0) < trows ? (M - m0) : trows, rows_b = (N - n0) < BN ? (N - n0) : BN;
     live = live && rows_a > 0;  // the lower half of an edge tile may be empty
     d.ncols = rows_b;
@@ -906,20 +913,27 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       return check_launch("gemm_8bit(skinny)");
     }
   }
+  // up to 512 rows the 128-row tiling (every tile as two halves) fills more CUs: see the kernel comment
+  const bool all_halves = M <= 512 && g_gemm_variant == 4;  // (M = 1024: 77 us against 64 us with 256-row tiles)
+  const unsigned hgrid = 2 * grid < (unsigned)num_cus() ? ((2 * grid + 7) / 8) * 8 : (unsigned)num_cus();
   const int variant = (!persist_ok && g_gemm_variant != 0 && g_gemm_variant != 1) ? 1 : g_gemm_variant;
 #define SGLK_GO_VAR(V, H, VAR)                                                                               \
   gemm_8bit_kernel<OutT, MODE, V, H, VAR><<<grid, 512, 0, st>>>(                                             \
       (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K,   \
       lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
 #define SGLK_GO_PIPE(V, H, P)                                                                                \
-  {                                                                                                          \
+  if (all_halves) {                                                                                          \
+    gemm_fp8_blockwise_persist_kernel<OutT, H, P, 4><<<hgrid, 512, 0, st>>>(                                 \
+        (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,     \
+        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1);                                                    \
+  } else {                                                                                                   \
     gemm_fp8_blockwise_persist_kernel<OutT, H, P, 8><<<pgrid, 512, 0, st>>>(                                 \
         (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,     \
-        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n);                                                       \
+        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0);                                                    \
     if (tail_halves)                                                                                         \
       gemm_fp8_blockwise_persist_kernel<OutT, H, P, 4><<<pgrid, 512, 0, st>>>(                               \
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,   \
-          sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n);                                                     \
+          sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0);                                                  \
   }
 #define SGLK_GO(V, H)                                                                                        \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
