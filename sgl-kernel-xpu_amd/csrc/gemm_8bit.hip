@@ -747,12 +747,17 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
 // KS > 1 lets 2 / 4 waves split the K range of one n-tile and add their partial sums through LDS in a fixed order
 // (more bytes in flight; not used: it measured slower).
 // grid = (N / (16 * 4 / KS), ceil(M / (16 MF))); operands swapped as above: a lane owns 4 consecutive n of one m.
-template <typename OutT, int MF, int KS, bool HW_SCALE>  // KS waves split the K range of one 16-row n-tile
-__global__ __launch_bounds__(256) void gemm_fp8_blockwise_skinny_kernel(
+// MODE_FP8_ROWCOL / MODE_INT8_ROWCOL (fp8_scaled_mm / int8_scaled_mm): the same stream, the MFMAs chain into the
+// accumulator and the epilogue applies sa[m] * sb[n] (+ bias) in the tile kernel's rounding order.
+template <typename OutT, int MODE, int MF, int KS, bool HW_SCALE>  // KS waves split the K range of one 16-row n-tile
+__global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-    const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
-    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn) {
+    const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
+    int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn) {
+  constexpr bool kBlockwise = MODE == MODE_BLOCKWISE;
+  using AccT = typename std::conditional<MODE == MODE_INT8_ROWCOL, v4i, v4f>::type;
   constexpr int kD = 8;  // K blocks of weights in flight per wave
+  static_assert(KS == 1 || kBlockwise, "the K split is only wired for the blockwise mode");
   __shared__ float red[KS > 1 ? 4 * MF * 256 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -776,21 +781,23 @@ __global__ __launch_bounds__(256) void gemm_fp8_blockwise_skinny_kernel(
     int m = m0 + mf * 16 + j;
     m = m < M ? m : M - 1;
     al[mf] = a + (int64_t)m * lda + g * 16 + (int64_t)kb_lo * BK;
-    sl[mf] = sa + (int64_t)m * sa_sm + (int64_t)kb_lo * sa_sk;
+    sl[mf] = kBlockwise ? sa + (int64_t)m * sa_sm + (int64_t)kb_lo * sa_sk : sa;
   }
   const int nblk_max = (N + 127) / 128 - 1;
   int nblk = n0 >> 7;
   nblk = nblk < nblk_max ? nblk : nblk_max;
-  const float* sbw = sb + (int64_t)nblk * sb_sn + (int64_t)kb_lo * sb_sk;
+  const float* sbw = kBlockwise ? sb + (int64_t)nblk * sb_sn + (int64_t)kb_lo * sb_sk : sb;
 
   auto load32 = [](const uint8_t* p) -> v8i {
     const v4i lo = *reinterpret_cast<const v4i*>(p), hi = *reinterpret_cast<const v4i*>(p + 64);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
 
-  v4f acc[MF];
+  AccT acc[MF];
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf) acc[mf] = (v4f){0.f, 0.f, 0.f, 0.f};
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[mf][r] = 0;
   const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
   if (nkb > 0) {
@@ -804,9 +811,9 @@ __global__ __launch_bounds__(256) void gemm_fp8_blockwise_skinny_kernel(
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         af[slot][mf] = load32(al[mf] + (int64_t)kc * BK);
-        sv[slot][mf] = sl[mf][(int64_t)kc * sa_sk];
+        if constexpr (kBlockwise) sv[slot][mf] = sl[mf][(int64_t)kc * sa_sk];
       }
-      sbq[slot] = sbw[(int64_t)kc * sb_sk];
+      if constexpr (kBlockwise) sbq[slot] = sbw[(int64_t)kc * sb_sk];
     };
     load_a(0, 0);
     load_a(1, 1);
@@ -821,10 +828,16 @@ __global__ __launch_bounds__(256) void gemm_fp8_blockwise_skinny_kernel(
           wq[u] = load32(bl + (int64_t)(kn < nkb ? kn : 0) * BK);
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) {
-            const v4f cur = mfma_k128<HW_SCALE>(w, af[u & 1][mf], zero);
-            const float sc = sv[u & 1][mf] * sbq[u & 1];
+            if constexpr (MODE == MODE_INT8_ROWCOL) {
+              acc[mf] = mfma_i8_k128(w, af[u & 1][mf], acc[mf]);
+            } else if constexpr (MODE == MODE_FP8_ROWCOL) {
+              acc[mf] = mfma_k128<HW_SCALE>(w, af[u & 1][mf], acc[mf]);
+            } else {
+              const v4f cur = mfma_k128<HW_SCALE>(w, af[u & 1][mf], zero);
+              const float sc = sv[u & 1][mf] * sbq[u & 1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mf][r] = __builtin_fmaf(cur[r], sc, acc[mf][r]);
+              for (int r = 0; r < 4; ++r) acc[mf][r] = __builtin_fmaf(cur[r], sc, acc[mf][r]);
+            }
           }
           load_a(kb + 2, u & 1);
         }
@@ -835,14 +848,14 @@ __global__ __launch_bounds__(256) void gemm_fp8_blockwise_skinny_kernel(
   if constexpr (KS > 1) {
     // the KS partial sums of an n-tile meet in LDS and are added in a fixed order by the first wave of the group
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) *reinterpret_cast<v4f*>(&red[((wave * MF + mf) * 64 + lane) * 4]) = acc[mf];
+    for (int mf = 0; mf < MF; ++mf) *reinterpret_cast<AccT*>(&red[((wave * MF + mf) * 64 + lane) * 4]) = acc[mf];
     __syncthreads();
     if (kpart != 0) return;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
       for (int u = 1; u < KS; ++u) {
-        const v4f o = *reinterpret_cast<const v4f*>(&red[(((wave + u) * MF + mf) * 64 + lane) * 4]);
+        const AccT o = *reinterpret_cast<const AccT*>(&red[(((wave + u) * MF + mf) * 64 + lane) * 4]);
         acc[mf][0] += o[0]; acc[mf][1] += o[1]; acc[mf][2] += o[2]; acc[mf][3] += o[3];
       }
     }
@@ -856,15 +869,31 @@ __global__ __launch_bounds__(256) void gemm_fp8_blockwise_skinny_kernel(
     const int m = m0 + mf * 16 + j;
     if (m >= M) continue;
     OutT* orow = out + (int64_t)m * ldc;
+    OutT v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (kBlockwise) {
+        v[r] = (OutT)acc[mf][r];
+      } else {
+        const int nn = (n + r < N) ? (n + r) : (N - 1);
+        const float t = ((float)acc[mf][r] * sa[m]) * sb[nn];
+        if constexpr (MODE == MODE_FP8_ROWCOL) {
+          v[r] = (OutT)t;
+          if (bias != nullptr) v[r] = (OutT)((float)v[r] + (float)bias[nn]);
+        } else {
+          v[r] = (bias != nullptr) ? (OutT)(t + (float)bias[nn]) : (OutT)t;
+        }
+      }
+    }
     if (n + 3 < N && (ldc % 4 == 0) && ((uintptr_t)out % 8 == 0)) {
       Vec<OutT, 4> vv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) vv[r] = (OutT)acc[mf][r];
+      for (int r = 0; r < 4; ++r) vv[r] = v[r];
       store_vec<OutT, 4>(orow + n, vv);
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < N) orow[n + r] = (OutT)acc[mf][r];
+        if (n + r < N) orow[n + r] = v[r];
     }
   }
 }
@@ -891,19 +920,19 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
     }
   }
   // few rows: the weight-streaming kernel (variant 5 forces it, variant 6 forbids it)
-  if constexpr (MODE == MODE_BLOCKWISE) {
+  {
     if ((M <= 64 && g_gemm_variant == 4) || g_gemm_variant == 5) {
 #define SGLK_GO_SKINNY(MF, KS)                                                                               \
   {                                                                                                          \
     const dim3 sg((unsigned)cdiv(N, 16 * (4 / KS)), (unsigned)cdiv(M, 16 * MF));                             \
     if (hw_scale)                                                                                            \
-      gemm_fp8_blockwise_skinny_kernel<OutT, MF, KS, true><<<sg, 256, 0, st>>>(                              \
-          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,   \
-          sa_sm, sa_sk, sb_sk, sb_sn);                                                                       \
+      gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, true><<<sg, 256, 0, st>>>(                                 \
+          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
+          lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn);                                                        \
     else                                                                                                     \
-      gemm_fp8_blockwise_skinny_kernel<OutT, MF, KS, false><<<sg, 256, 0, st>>>(                             \
-          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,   \
-          sa_sm, sa_sk, sb_sk, sb_sn);                                                                       \
+      gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, false><<<sg, 256, 0, st>>>(                                \
+          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
+          lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn);                                                        \
   }
       // (splitting K over 2 / 4 waves of a workgroup - template KS - measured slower: 18 -> 22 us at M = 1, N = 14336)
       if (M <= 16) SGLK_GO_SKINNY(1, 1)

@@ -216,13 +216,14 @@ int main(int argc, char** argv) {
     float* sb = dev_random_floats(N, 4, 1e-4f, 1e-3f);
     void* out;
     HIP_CHECK(hipMalloc(&out, M * N * 2));
+    if (getenv("GEMM_VARIANT")) sglk_debug_set_gemm_variant(atoi(getenv("GEMM_VARIANT")));
     for (int dt : {SGLK_FP8_E4M3, SGLK_INT8}) {
       std::vector<float> all;
       auto run = [&] {
         int rc = sglk_scaled_mm(0, out, a, b, sa, sb, nullptr, M, N, K, K, K, N, dt, SGLK_BF16);
         if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
       };
-      const double ms = time_ms(run, 10, 50, &all);
+      const double ms = time_ms(run, 100, 50, &all);
       printf("scaled_mm %s M=%lld N=%lld K=%lld median %.4f ms min %.4f -> %.1f T(FL)OP/s\n", dt == SGLK_INT8 ? "int8" : "fp8",
              (long long)M, (long long)N, (long long)K, ms, all[0], 2.0 * M * N * K / ms / 1e9);
     }
