@@ -35,6 +35,8 @@
 //     the HBM roofline instead of on one wave's issue rate. (The partials take the CU's last 16 KiB of LDS next to the 4-stage ring.)
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace sglk {
@@ -74,6 +76,15 @@ struct Mfma<bf16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ short cvt(float x) { return __builtin_bit_cast(short, (bf16)x); }
+  static __device__ __forceinline__ float back(short x) { return (float)__builtin_bit_cast(bf16, x); }
+  // inline-asm forms with the accumulator pinned to the VGPR / AGPR file (rows128 kernel)
+  static __device__ __forceinline__ void acc_v(v4f& c, const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+  template <int R>  // accumulator = the fixed registers a[R : R+3]
+  static __device__ __forceinline__ void acc_agpr(const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(R), "i"(R + 3));
+  }
 };
 template <>
 struct Mfma<f16> {
@@ -81,7 +92,50 @@ struct Mfma<f16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ short cvt(float x) { return __builtin_bit_cast(short, (f16)x); }
+  static __device__ __forceinline__ float back(short x) { return (float)__builtin_bit_cast(f16, x); }
+  static __device__ __forceinline__ void acc_v(v4f& c, const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+  template <int R>  // accumulator = the fixed registers a[R : R+3]
+  static __device__ __forceinline__ void acc_agpr(const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(R), "i"(R + 3));
+  }
 };
+
+// ---- hand-managed accumulators in fixed AGPRs (rows128 kernel): the compiler never sees these values
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <int R>
+__device__ __forceinline__ void agpr_zero4() {
+  asm volatile("v_accvgpr_write_b32 a[%0], 0\n\tv_accvgpr_write_b32 a[%1], 0\n\tv_accvgpr_write_b32 a[%2], 0\n\t"
+               "v_accvgpr_write_b32 a[%3], 0" ::"i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
+}
+template <int R>
+__device__ __forceinline__ void agpr_scale4(const v4f& f) {
+  float t0, t1, t2, t3;
+  asm volatile(
+      "v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%9]\n\tv_accvgpr_read_b32 %2, a[%10]\n\t"
+      "v_accvgpr_read_b32 %3, a[%11]\n\ts_nop 1\n\t"
+      "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %5\n\tv_mul_f32 %2, %2, %6\n\tv_mul_f32 %3, %3, %7\n\ts_nop 1\n\t"
+      "v_accvgpr_write_b32 a[%8], %0\n\tv_accvgpr_write_b32 a[%9], %1\n\tv_accvgpr_write_b32 a[%10], %2\n\t"
+      "v_accvgpr_write_b32 a[%11], %3"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
+}
+template <int R>
+__device__ __forceinline__ v4f agpr_read4() {
+  float t0, t1, t2, t3;
+  asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\t"
+               "v_accvgpr_read_b32 %3, a[%7]\n\ts_nop 1"
+               : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3)
+               : "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3));
+  return (v4f){t0, t1, t2, t3};
+}
 
 __device__ __forceinline__ int sw_main(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -91,7 +145,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
 }
 
 struct MlaParams {
@@ -493,6 +549,406 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// rows128 kernel: the same contract and LDS image as above for workgroups with more than 64 rows (decode with
+// H > 64; DeepSeek-V3 has 128 heads). In the kernel above a wave that owns 16 heads pins 72 (Q) + 128 (O) of its 256
+// registers and has no room to keep LDS reads in flight: its QK^T loop is read - wait - MFMA (seen in the ISA),
+// and every K / V fragment read from LDS feeds ONE MFMA, so the LDS pipe (2 x 1088 B per token and 16 heads)
+// bounds the kernel at ~0.4 of the HBM roofline.
+// Here a workgroup is 4 waves, one per SIMD, 512 registers each. Wave w owns rows 32w .. 32w+31 (two 16-row
+// tiles): every K fragment and every transposed V fragment is read once and feeds TWO MFMAs (LDS read traffic
+// halves), O (2 x 32 tiles x 4 = 256 registers) lives in the AGPR file and is only touched by the PV MFMAs, and
+// the 112 VGPRs left next to Q (144) hold rings of K fragments (3 k-steps ahead) and V fragments (6 tiles ahead).
+// All MFMAs and LDS reads are inline asm in program order (the waits are counted by hand; the manual wait
+// states the compiler would insert around MFMA results are padded by hand: s_nop after the last MFMA of a phase).
+// Online softmax with a lazy reference maximum: O (in AGPRs: a rescale costs 3 VALU instructions per register) is
+// rescaled only when a head's tile maximum exceeds its reference by more than 2^8; P = 2^(s - ref) stays <= 256,
+// exact in the fp32 row sums and the same relative precision in 16 bits.
+constexpr int kThreads2 = 256;
+
+// PROBE (timing experiments, garbage results): 2 = no QK^T phase, 3 = no PV phase, 4 = no softmax, 5 = QK^T MFMAs
+// without the K reads, 6 = K reads without the MFMAs, 7 = PV MFMAs without the V reads, 8 = V reads without the MFMAs
+template <typename T, int PROBE>
+__global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, const T* __restrict__ q_nope,
+                                                                   const T* __restrict__ q_pe,
+                                                                   const char* __restrict__ cache,
+                                                                   const int32_t* __restrict__ seq_lens,
+                                                                   const int32_t* __restrict__ page_table,
+                                                                   const int32_t* __restrict__ cu_seqlens_q) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using M = Mfma<T>;
+  constexpr int kStages = 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int H = p.H;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- rows (see the kernel above): row tile 2 wave + h
+  const int hp_mask = (1 << p.hp_shift) - 1;
+  int grp_tok[2], grp_head0[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    grp_tok[h] = ((wave * 2 + h) * 16) >> p.hp_shift;
+    grp_head0[h] = ((wave * 2 + h) * 16) & hp_mask;
+  }
+  int q_row0 = b, n_tok = 1, seq, kv_first;
+  if (cu_seqlens_q != nullptr) {
+    const int q0 = cu_seqlens_q[b], sq = cu_seqlens_q[b + 1] - q0, sk = seq_lens[b];
+    const int t0 = (int)blockIdx.z << (7 - p.hp_shift);
+    if (t0 >= sq) return;
+    const int tpw = 1 << (7 - p.hp_shift);
+    n_tok = (sq - t0) < tpw ? (sq - t0) : tpw;
+    q_row0 = q0 + t0;
+    kv_first = p.causal ? sk - sq + t0 + 1 : sk;
+    seq = p.causal ? sk - sq + t0 + n_tok : sk;
+  } else {
+    seq = seq_lens[b];
+    kv_first = seq;
+  }
+  bool active[2];
+  int kv_row[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    active[h] = grp_tok[h] < n_tok && grp_head0[h] < H;
+    kv_row[h] = (cu_seqlens_q != nullptr && p.causal && grp_tok[h] < n_tok) ? kv_first + grp_tok[h] : seq;
+  }
+  const bool work = (active[0] || active[1]) && p.probe != 1;  // (rows that are not stored still compute)
+  const int ntiles = (seq + kTile - 1) / kTile;
+  const int tps = (ntiles + p.splits - 1) / p.splits;
+  const int t_begin = split * tps;
+  const int t_end = (t_begin + tps < ntiles) ? (t_begin + tps) : ntiles;
+
+  const int32_t* table = page_table + (int64_t)b * p.table_stride;
+  const int page_mask = (1 << p.page_shift) - 1;
+
+  // ---- LDS-DMA of one tile (same image as above): wave w fills column block w (8 row groups) and rope rows 8w..8w+7
+  auto stage_tile = [&](int t, int st) {
+    char* base = smem + st * kStageBytes;
+    const int tok0 = t * kTile;
+    const int pg0 = table[tok0 >> p.page_shift];
+    int pg1 = pg0;
+    if (p.page_shift == 4 && tok0 + 16 < seq) pg1 = table[(tok0 + 16) >> 4];
+    const char* src0 = cache + (int64_t)pg0 * p.page_stride_bytes;
+    const char* src1 = cache + (int64_t)pg1 * p.page_stride_bytes;
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+      const int row = rg * 4 + (lane >> 4);
+      const int ch = (lane & 15) ^ sw_main(row);
+      const int in_page = (tok0 + row) & page_mask;
+      const char* src = (rg < 4 ? src0 : src1) + in_page * kRowBytes + wave * 256 + ch * 16;
+      __builtin_amdgcn_global_load_lds(SGLK_GLB(src), SGLK_LDS(base + wave * 8192 + rg * 1024), 16, 0, 0);
+    }
+    {
+      const int row = wave * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      const int in_page = (tok0 + row) & page_mask;
+      const char* src = (wave < 2 ? src0 : src1) + in_page * kRowBytes + 1024 + ch * 16;
+      __builtin_amdgcn_global_load_lds(SGLK_GLB(src), SGLK_LDS(base + kMainBytes + wave * 1024), 16, 0, 0);
+    }
+  };
+
+  if (t_begin >= t_end) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (!active[h]) continue;
+      const int row0 = (wave * 2 + h) * 16;
+      for (int i = lane; i < 16 * kLatent; i += 64) {
+        const int head = row0 + i / kLatent, d = i % kLatent;  // (decode only: splits > 1 or an empty sequence)
+        if (head < H) {
+          if (p.splits == 1) ((T*)p.out)[((int64_t)(q_row0 + grp_tok[h]) * H + grp_head0[h] + i / kLatent) * kLatent + d] = (T)0.f;
+          else p.ws_o[(((int64_t)b * p.splits + split) * H + head) * kLatent + d] = 0.f;
+        }
+      }
+      if (p.splits > 1 && lane < 16 && row0 + lane < H)
+        p.ws_lse[((int64_t)b * p.splits + split) * H + row0 + lane] = -INFINITY;
+    }
+    return;
+  }
+
+  const int pig = (0x2130 >> (4 * g)) & 3;  // pi = (0,3,1,2)
+
+  // ---- Q^T fragments of both row tiles: 2 x 18 k-steps x 4 registers
+  v8s qf[2][18];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int head = grp_head0[h] + l15;
+    const bool ok = active[h] && head < H;
+    const int64_t qrow = q_row0 + (active[h] ? grp_tok[h] : 0);
+    const T* qn = q_nope + qrow * p.qn_sb + (int64_t)(ok ? head : 0) * p.qn_sh + 8 * pig;
+    const T* qp = q_pe + qrow * p.qp_sb + (int64_t)(ok ? head : 0) * p.qp_sh + 8 * pig;
+    const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) {
+      const T* src = ks < 16 ? qn + 32 * ks : qp + 32 * (ks - 16);
+      const v8s v = *reinterpret_cast<const v8s*>(src);
+      qf[h][ks] = ok ? v : zero;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q is in registers before any LDS-DMA is counted
+
+  // ---- per-lane LDS read offsets (same image and permutations as above)
+  const int tau = (l15 & 3) | (((l15 >> 2) & 1) << 3) | (((l15 >> 3) & 1) << 2);
+  const int kbase = 256 * tau + 16 * (pig ^ sw_main(tau));
+  const int rbase = kMainBytes + 128 * tau + 16 * (pig ^ ((tau >> 1) & 7));
+  int vbase0;
+  {
+    const int q = l15 >> 2, pp = l15 & 3;
+    const int r = 8 * (g & 1) + 4 * (g >> 1) + q;
+    vbase0 = 256 * r + 16 * ((pp >> 1) ^ sw_main(r)) + 8 * (pp & 1);
+  }
+
+  // O[row tile h][16-column tile nt] = a[(32 h + nt) 4 .. +3]; the clobbers tell the compiler that the kernel
+  // owns the whole AGPR file (it must not place anything there: checked in the ISA)
+  asm volatile("" ::: "a0", "a255");
+  static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
+  float m_ref[2] = {-INFINITY, -INFINITY};  // reference maximum of head l15 of each row tile (lane groups agree)
+  float l_run[2] = {0.f, 0.f};              // sum of 2^(s - ref) over this lane's own tokens
+  auto head_bcast = [&](float v, int r) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane & 48) | (4 * g + r)) << 2, __builtin_bit_cast(int, v)));
+  };
+  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
+
+  const int n_my = t_end - t_begin;
+#pragma unroll
+  for (int i = 0; i < kStages - 1; ++i)
+    if (i < n_my) stage_tile(t_begin + i, i);
+
+  int st = 0;
+  for (int i = 0; i < n_my; ++i) {
+    const int t = t_begin + i;
+    const int rem = n_my - 1 - i;
+    if (rem >= 2) wait_vmcnt<18>(); else if (rem >= 1) wait_vmcnt<9>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done with tile t-1
+    {
+      const int st_next = st == 0 ? kStages - 1 : st - 1;
+      if (i + kStages - 1 < n_my) stage_tile(t + kStages - 1, st_next);
+    }
+    if (work) {
+      const uint32_t sb = lds_base + (uint32_t)(st * kStageBytes);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- S^T[token, head] = K . Q^T: per k-step two K fragments (token tiles 0, 1), four MFMAs
+      uint32_t ka[6];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ka[c] = sb + (uint32_t)(kbase ^ (c << 6));
+#pragma unroll
+      for (int c = 0; c < 2; ++c) ka[4 + c] = sb + (uint32_t)(rbase ^ (c << 6));
+      v4f s[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) s[h][tt] = (v4f){0.f, 0.f, 0.f, 0.f};
+      // the zeros and the addresses are in their registers BEFORE the first read goes out: left alone, the compiler
+      // rematerialises a zero accumulator right in front of its first MFMA, into the registers of the K fragment
+      // the MFMA one instruction earlier is still reading (seen; the hardware does not interlock that)
+      asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(ka[0]), "+v"(ka[1]), "+v"(ka[2]),
+                        "+v"(ka[3]), "+v"(ka[4]), "+v"(ka[5]));
+      constexpr int kKD = 3, kKB = kKD + 1;
+      v8s kr[kKB][2] = {};
+#define SGLK_K_ISSUE(KS)                                                                                     \
+  do {                                                                                                       \
+    constexpr int a_ = (KS) < 16 ? ((KS) & 3) : 4 + ((KS) - 16);                                             \
+    constexpr int o0_ = (KS) < 16 ? ((KS) >> 2) * 8192 : 0, o1_ = o0_ + ((KS) < 16 ? 4096 : 2048);           \
+    if constexpr (PROBE != 5) {                                                                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][0]) : "v"(ka[a_]), "i"(o0_) : "memory"); \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][1]) : "v"(ka[a_]), "i"(o1_) : "memory"); \
+    }                                                                                                        \
+  } while (0)
+#define SGLK_K_WAIT(N, KS) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % kKB][0]), "+v"(kr[(KS) % kKB][1])::"memory")
+#define SGLK_K_STEP(KS)                                                                                      \
+  {                                                                                                          \
+    if constexpr ((KS) + kKD < 18) SGLK_K_ISSUE((KS) + kKD);                                                 \
+    constexpr int ahead_ = (KS) + kKD < 18 ? kKD : 17 - (KS);                                                \
+    if constexpr (ahead_ == 3) SGLK_K_WAIT(6, KS);                                                           \
+    if constexpr (ahead_ == 2) SGLK_K_WAIT(4, KS);                                                           \
+    if constexpr (ahead_ == 1) SGLK_K_WAIT(2, KS);                                                           \
+    if constexpr (ahead_ == 0) SGLK_K_WAIT(0, KS);                                                           \
+    if constexpr (PROBE != 6) {                                                                              \
+    M::acc_v(s[0][0], kr[(KS) % kKB][0], qf[0][KS]);                                                         \
+    M::acc_v(s[1][0], kr[(KS) % kKB][0], qf[1][KS]);                                                         \
+    M::acc_v(s[0][1], kr[(KS) % kKB][1], qf[0][KS]);                                                         \
+    M::acc_v(s[1][1], kr[(KS) % kKB][1], qf[1][KS]);                                                         \
+    }                                                                                                        \
+  }
+      if constexpr (PROBE != 2) {
+      SGLK_K_ISSUE(0); SGLK_K_ISSUE(1); SGLK_K_ISSUE(2);
+      SGLK_K_STEP(0) SGLK_K_STEP(1) SGLK_K_STEP(2) SGLK_K_STEP(3) SGLK_K_STEP(4) SGLK_K_STEP(5)
+      SGLK_K_STEP(6) SGLK_K_STEP(7) SGLK_K_STEP(8) SGLK_K_STEP(9) SGLK_K_STEP(10) SGLK_K_STEP(11)
+      SGLK_K_STEP(12) SGLK_K_STEP(13) SGLK_K_STEP(14) SGLK_K_STEP(15) SGLK_K_STEP(16) SGLK_K_STEP(17)
+      }
+#undef SGLK_K_STEP
+#undef SGLK_K_WAIT
+#undef SGLK_K_ISSUE
+      // The compiler does not know that the asm statements above are MFMAs: (1) the S registers come straight out
+      // of the matrix pipe - pad the wait states by hand and tie the registers so that no read of them is scheduled
+      // above this point; (2) an MFMA reads its A / B operands for a few cycles after issue - the K ring registers
+      // stay reserved up to here, or the compiler hands them to the next VALU instruction (seen: an address add
+      // into a register of the last K fragment, one instruction behind its MFMA; S off by 2^-12).
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"
+                   : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1])
+                   : "v"(kr[0][0]), "v"(kr[0][1]), "v"(kr[1][0]), "v"(kr[1][1]), "v"(kr[2][0]), "v"(kr[2][1]),
+                     "v"(kr[3][0]), "v"(kr[3][1]));
+      // ---- the first V fragments go out now: their latency hides behind the softmax
+      constexpr int kVD = 6, kVB = kVD + 1;
+      uint32_t va[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) va[c] = sb + (uint32_t)(vbase0 ^ (c << 5));
+      asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7]));
+      v2i vb[kVB][2] = {};
+#define SGLK_V_ISSUE(I)                                                                                      \
+  do {                                                                                                       \
+    if constexpr (PROBE != 7) {                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                       \
+                 : "=v"(vb[(I) % kVB][0]) : "v"(va[(I) & 7]), "i"((((I) >> 3) * 8192)) : "memory");          \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                       \
+                 : "=v"(vb[(I) % kVB][1]) : "v"(va[(I) & 7]), "i"((((I) >> 3) * 8192 + 4096)) : "memory");   \
+    }                                                                                                        \
+  } while (0)
+      if constexpr (PROBE != 3) { SGLK_V_ISSUE(0); SGLK_V_ISSUE(1); SGLK_V_ISSUE(2); SGLK_V_ISSUE(3); SGLK_V_ISSUE(4); SGLK_V_ISSUE(5); }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- online softmax per row tile, lazy reference maximum
+      v8s pf[2] = {{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}};
+      float alpha[2] = {1.f, 1.f};
+      bool upd[2] = {false, false};
+      if constexpr (PROBE != 4)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v4f s0 = s[h][0], s1 = s[h][1];
+        if (t * kTile + kTile > kv_first) {
+          const int tb = t * kTile + 8 * (g & 1) + 4 * (g >> 1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (tb + r >= kv_row[h]) s0[r] = -INFINITY;
+            if (tb + 16 + r >= kv_row[h]) s1[r] = -INFINITY;
+          }
+        }
+        float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        upd[h] = (mt - m_ref[h]) * p.scale_log2 > 8.0f;  // (first tile: ref = -inf; a NaN difference keeps the ref)
+        const float m_new = upd[h] ? mt : m_ref[h];
+        alpha[h] = upd[h] ? __builtin_amdgcn_exp2f((m_ref[h] - m_new) * p.scale_log2) : 1.0f;
+        const float mneg = -m_new * p.scale_log2;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2, mneg));
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2, mneg));
+          pf[h][r] = M::cvt(p0);
+          pf[h][4 + r] = M::cvt(p1);
+          // the row sum takes the ROUNDED weights (the ones P . V uses): with a lazy reference the largest weight is
+          // no longer exactly 1, and numerator and denominator must round alike
+          psum += M::back(pf[h][r]) + M::back(pf[h][4 + r]);
+        }
+        l_run[h] = l_run[h] * alpha[h] + psum;
+        m_ref[h] = m_new;
+      }
+      // ---- rare: a reference moved, rescale O (AGPR -> VGPR -> AGPR; the last PV MFMA is a whole QK^T phase back)
+      if (__any(upd[0] || upd[1])) {
+        const v4f a0 = {head_bcast(alpha[0], 0), head_bcast(alpha[0], 1), head_bcast(alpha[0], 2), head_bcast(alpha[0], 3)};
+        const v4f a1 = {head_bcast(alpha[1], 0), head_bcast(alpha[1], 1), head_bcast(alpha[1], 2), head_bcast(alpha[1], 3)};
+        static_for<0, 32>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a0); });
+        static_for<32, 64>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a1); });
+        asm volatile("s_nop 7");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 3" : "+v"(pf[0]), "+v"(pf[1]));
+      // ---- O[head, dim] += P . V: one transposed V fragment, two MFMAs
+#define SGLK_V_WAIT(N, I) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(vb[(I) % kVB][0]), "+v"(vb[(I) % kVB][1])::"memory")
+#define SGLK_V_STEP(G)                                                                                       \
+  {                                                                                                          \
+    if constexpr ((G) + kVD < 32) SGLK_V_ISSUE((G) + kVD);                                                   \
+    constexpr int ahead_ = (G) + kVD < 32 ? kVD : 31 - (G);                                                  \
+    if constexpr (ahead_ == 6) SGLK_V_WAIT(12, G);                                                           \
+    if constexpr (ahead_ == 5) SGLK_V_WAIT(10, G);                                                           \
+    if constexpr (ahead_ == 4) SGLK_V_WAIT(8, G);                                                            \
+    if constexpr (ahead_ == 3) SGLK_V_WAIT(6, G);                                                            \
+    if constexpr (ahead_ == 2) SGLK_V_WAIT(4, G);                                                            \
+    if constexpr (ahead_ == 1) SGLK_V_WAIT(2, G);                                                            \
+    if constexpr (ahead_ == 0) SGLK_V_WAIT(0, G);                                                            \
+    v8s f_;                                                                                                  \
+    const v4s x0_ = __builtin_bit_cast(v4s, vb[(G) % kVB][0]), x1_ = __builtin_bit_cast(v4s, vb[(G) % kVB][1]); \
+    f_[0] = x0_[0]; f_[1] = x0_[1]; f_[2] = x0_[2]; f_[3] = x0_[3];                                          \
+    f_[4] = x1_[0]; f_[5] = x1_[1]; f_[6] = x1_[2]; f_[7] = x1_[3];                                          \
+    if constexpr (PROBE != 8) {                                                                              \
+    M::template acc_agpr<(G) * 4>(pf[0], f_);                                                                \
+    M::template acc_agpr<(32 + (G)) * 4>(pf[1], f_);                                                         \
+    }                                                                                                        \
+  }
+      if constexpr (PROBE != 3) {
+      SGLK_V_STEP(0) SGLK_V_STEP(1) SGLK_V_STEP(2) SGLK_V_STEP(3) SGLK_V_STEP(4) SGLK_V_STEP(5)
+      SGLK_V_STEP(6) SGLK_V_STEP(7) SGLK_V_STEP(8) SGLK_V_STEP(9) SGLK_V_STEP(10) SGLK_V_STEP(11)
+      SGLK_V_STEP(12) SGLK_V_STEP(13) SGLK_V_STEP(14) SGLK_V_STEP(15) SGLK_V_STEP(16) SGLK_V_STEP(17)
+      SGLK_V_STEP(18) SGLK_V_STEP(19) SGLK_V_STEP(20) SGLK_V_STEP(21) SGLK_V_STEP(22) SGLK_V_STEP(23)
+      SGLK_V_STEP(24) SGLK_V_STEP(25) SGLK_V_STEP(26) SGLK_V_STEP(27) SGLK_V_STEP(28) SGLK_V_STEP(29)
+      SGLK_V_STEP(30) SGLK_V_STEP(31)
+      }
+#undef SGLK_V_STEP
+#undef SGLK_V_WAIT
+#undef SGLK_V_ISSUE
+      // same for the operands of the last PV MFMAs (P and the V ring): reserved until the matrix pipe has read them
+      asm volatile("s_nop 7" ::"v"(pf[0]), "v"(pf[1]), "v"(vb[0][0]), "v"(vb[0][1]), "v"(vb[1][0]), "v"(vb[1][1]),
+                   "v"(vb[2][0]), "v"(vb[2][1]), "v"(vb[3][0]), "v"(vb[3][1]), "v"(vb[4][0]), "v"(vb[4][1]),
+                   "v"(vb[5][0]), "v"(vb[5][1]), "v"(vb[6][0]), "v"(vb[6][1]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    st = st + 1 == kStages ? 0 : st + 1;
+  }
+
+  // ---- epilogue: normalise by the row sums and write. O tile nt: lane holds dim 16 nt + l15, heads 4g + r
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");  // the last MFMA results are read from the AGPRs below
+  static_for<0, 2>([&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+    if (!active[h] || p.probe == 1) return;
+    float l_tot = l_run[h] + __shfl_xor(l_run[h], 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv_l = 1.0f / l_tot;
+    const v4f i4 = {head_bcast(inv_l, 0), head_bcast(inv_l, 1), head_bcast(inv_l, 2), head_bcast(inv_l, 3)};
+    const int row0 = (wave * 2 + h) * 16;
+    if (p.splits == 1) {
+      T* out = (T*)p.out + (int64_t)(q_row0 + grp_tok[h]) * H * kLatent;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int head = grp_head0[h] + 4 * g + r;
+        (void)head;
+      }
+      static_for<0, 32>([&](auto ic) {
+        constexpr int nt = decltype(ic)::value;
+        const v4f v = agpr_read4<(h * 32 + nt) * 4>();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int head = grp_head0[h] + 4 * g + r;
+          if (head < H) out[(int64_t)head * kLatent + nt * 16 + l15] = (T)(v[r] * i4[r]);
+        }
+      });
+    } else {
+      float* wo = p.ws_o + ((int64_t)b * p.splits + split) * H * kLatent;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int head = row0 + 4 * g + r;
+        (void)head;
+      }
+      static_for<0, 32>([&](auto ic) {
+        constexpr int nt = decltype(ic)::value;
+        const v4f v = agpr_read4<(h * 32 + nt) * 4>();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int head = row0 + 4 * g + r;
+          if (head < H) wo[(int64_t)head * kLatent + nt * 16 + l15] = v[r] * i4[r];
+        }
+      });
+      if (lane < 16 && row0 + lane < H)
+        p.ws_lse[((int64_t)b * p.splits + split) * H + row0 + lane] = m_ref[h] * p.scale_log2 + log2f(l_tot);
+    }
+  });
+}
+
 // out[b,h,:] = sum_s w_s O_s / sum_s w_s,  w_s = 2^(lse_s - max lse)
 template <typename T>
 __global__ __launch_bounds__(128) void mla_reduce_kernel(T* __restrict__ out, const float* __restrict__ ws_o,
@@ -538,7 +994,25 @@ static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nop
   return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
 }
 
-// Test / tuning hook: force the number of waves per 16-head group (0 = automatic).
+template <typename T, int PROBE = 0>
+static int launch_rows128(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
+                          const void* cache, const int32_t* seq_lens, const int32_t* page_table,
+                          const int32_t* cu_seqlens_q = nullptr, int token_blocks = 1) {
+  static bool attr_set = false;
+  constexpr int lds = 4 * kStageBytes;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_rows128_kernel<T, PROBE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(SGLK_ELAUNCH, "flash_mla_decode: cannot reserve %d B of LDS: %s", lds,
+                                     hipGetErrorString(e));
+    attr_set = true;
+  }
+  mla_rows128_kernel<T, PROBE><<<dim3(p.splits, B, token_blocks), kThreads2, lds, st>>>(
+      p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
+  return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
+}
+
+// Test / tuning hook: force the number of waves per 16-head group (0 = automatic; 9 = never the rows128 kernel).
 static int g_mla_waves_per_group = 0;
 static int g_mla_probe = 0;
 
@@ -549,6 +1023,14 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
   int w = ngroups <= 1 ? 8 : ngroups <= 2 ? 4 : ngroups <= 4 ? 2 : 1;
   if (g_mla_waves_per_group > 0 && g_mla_waves_per_group <= w) w = g_mla_waves_per_group;
   int rc;
+  if (ngroups > 4 && g_mla_waves_per_group == 0) {
+    switch (std::is_same<T, bf16>::value ? p.probe : 0) {  // (the timing probes exist for bf16 only)
+#define SGLK_PR(N) case N: rc = launch_rows128<T, N>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
+      SGLK_PR(2) SGLK_PR(3) SGLK_PR(4) SGLK_PR(5) SGLK_PR(6) SGLK_PR(7) SGLK_PR(8)
+#undef SGLK_PR
+      default: rc = launch_rows128<T>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
+    }
+  } else
   switch (w) {
     case 8: rc = launch_w<T, 8>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
     case 4: rc = launch_w<T, 4>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
