@@ -567,9 +567,7 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
 // exact in the fp32 row sums and the same relative precision in 16 bits.
 constexpr int kThreads2 = 256;
 
-// PROBE (timing experiments, garbage results): 2 = no QK^T phase, 3 = no PV phase, 4 = no softmax, 5 = QK^T MFMAs
-// without the K reads, 6 = K reads without the MFMAs, 7 = PV MFMAs without the V reads, 8 = V reads without the MFMAs
-template <typename T, int PROBE>
+template <typename T>
 __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, const T* __restrict__ q_nope,
                                                                    const T* __restrict__ q_pe,
                                                                    const char* __restrict__ cache,
@@ -626,12 +624,9 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
   const int page_mask = (1 << p.page_shift) - 1;
 
   // ---- LDS-DMA of one tile (same image as above): wave w fills column block w (8 row groups) and rope rows 8w..8w+7
-  auto stage_tile = [&](int t, int st) {
+  auto stage_tile = [&](int t, int st, int pg0, int pg1) {
     char* base = smem + st * kStageBytes;
     const int tok0 = t * kTile;
-    const int pg0 = table[tok0 >> p.page_shift];
-    int pg1 = pg0;
-    if (p.page_shift == 4 && tok0 + 16 < seq) pg1 = table[(tok0 + 16) >> 4];
     const char* src0 = cache + (int64_t)pg0 * p.page_stride_bytes;
     const char* src1 = cache + (int64_t)pg1 * p.page_stride_bytes;
 #pragma unroll
@@ -704,169 +699,172 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
   // O[row tile h][16-column tile nt] = a[(32 h + nt) 4 .. +3]; the clobbers tell the compiler that the kernel
   // owns the whole AGPR file (it must not place anything there: checked in the ISA)
   asm volatile("" ::: "a0", "a255");
-  static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
   float m_ref[2] = {-INFINITY, -INFINITY};  // reference maximum of head l15 of each row tile (lane groups agree)
   float l_run[2] = {0.f, 0.f};              // sum of 2^(s - ref) over this lane's own tokens
-  auto head_bcast = [&](float v, int r) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane & 48) | (4 * g + r)) << 2, __builtin_bit_cast(int, v)));
+  // (ln: the lane id through an opaque copy, so that the addresses are recomputed where they are used instead of
+  //  being carried through the main loop: there is no register to spare there)
+  auto head_bcast = [&](int ln, float v, int r) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((ln & 48) | (4 * (ln >> 4) + r)) << 2, __builtin_bit_cast(int, v)));
   };
   const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
 
   const int n_my = t_end - t_begin;
-#pragma unroll
-  for (int i = 0; i < kStages - 1; ++i)
-    if (i < n_my) stage_tile(t_begin + i, i);
-
-  int st = 0;
-  for (int i = 0; i < n_my; ++i) {
-    const int t = t_begin + i;
-    const int rem = n_my - 1 - i;
-    if (rem >= 2) wait_vmcnt<18>(); else if (rem >= 1) wait_vmcnt<9>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; every wave is done with tile t-1
-    {
-      const int st_next = st == 0 ? kStages - 1 : st - 1;
-      if (i + kStages - 1 < n_my) stage_tile(t + kStages - 1, st_next);
+  // page ids of local tile j, looked up one iteration before the tile is staged (the scalar-load latency would
+  // otherwise sit between the barrier and the first LDS-DMA of every tile; a single wave per SIMD cannot hide it)
+  auto load_pages = [&](int j, int& pg0, int& pg1) {
+    const int tok0 = (t_begin + (j < n_my ? j : n_my - 1)) * kTile;
+    pg0 = table[tok0 >> p.page_shift];
+    pg1 = pg0;
+    if (p.page_shift == 4 && tok0 + 16 < seq) pg1 = table[(tok0 + 16) >> 4];
+  };
+  int pgn0, pgn1;
+  {
+    int a0, a1;
+    load_pages(0, a0, a1);
+    stage_tile(t_begin, 0, a0, a1);
+    if (n_my > 1) {
+      load_pages(1, a0, a1);
+      stage_tile(t_begin + 1, 1, a0, a1);
     }
+  }
+  load_pages(2, pgn0, pgn1);
+
+  // ---- software pipeline over the tiles: iteration j runs QK^T of tile j, then P.V of tile j-1 with the softmax of
+  // tile j woven between its MFMAs (the VALU work hides behind the matrix pipe; a single wave per SIMD has no
+  // other wave to fill it). Iteration 0 accumulates P = 0 (O is zeroed after it), iteration n recomputes the last
+  // tile's scores and discards them. Ring: tiles j-1, j resident, j+1 in flight, j+2 issued after the barrier.
+  v8s pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+  for (int j = 0; j <= n_my; ++j) {
+    const bool commit = j < n_my;
+    const int jq = commit ? j : n_my - 1, jv = j > 0 ? j - 1 : 0;
+    if (j + 1 < n_my) wait_vmcnt<9>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // tile j landed for every wave; every wave is done with tile j-2
+    if (j + 2 < n_my) stage_tile(t_begin + j + 2, (j + 2) & 3, pgn0, pgn1);
+    load_pages(j + 3, pgn0, pgn1);
     if (work) {
-      const uint32_t sb = lds_base + (uint32_t)(st * kStageBytes);
+      const uint32_t sbq = lds_base + (uint32_t)((jq & 3) * kStageBytes), sbv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
+      const int t = t_begin + jq;
       __builtin_amdgcn_sched_barrier(0);
-      // ---- S^T[token, head] = K . Q^T: per k-step two K fragments (token tiles 0, 1), four MFMAs
-      uint32_t ka[6];
+      uint32_t ka[6], va[8];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) ka[c] = sb + (uint32_t)(kbase ^ (c << 6));
+      for (int c = 0; c < 4; ++c) ka[c] = sbq + (uint32_t)(kbase ^ (c << 6));
 #pragma unroll
-      for (int c = 0; c < 2; ++c) ka[4 + c] = sb + (uint32_t)(rbase ^ (c << 6));
+      for (int c = 0; c < 2; ++c) ka[4 + c] = sbq + (uint32_t)(rbase ^ (c << 6));
+#pragma unroll
+      for (int c = 0; c < 8; ++c) va[c] = sbv + (uint32_t)(vbase0 ^ (c << 5));
       v4f s[2][2];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) s[h][tt] = (v4f){0.f, 0.f, 0.f, 0.f};
-      // the zeros and the addresses are in their registers BEFORE the first read goes out: left alone, the compiler
-      // rematerialises a zero accumulator right in front of its first MFMA, into the registers of the K fragment
-      // the MFMA one instruction earlier is still reading (seen; the hardware does not interlock that)
+      // The compiler does not know that the asm statements below are MFMAs, and the hardware does not interlock a
+      // VALU write against the operands an MFMA issued just before is still reading. So: the zeros and all addresses
+      // are in their registers BEFORE the first read goes out (left alone, the compiler rematerialises a zero
+      // accumulator right in front of its first MFMA, into the registers of the K fragment of the MFMA one
+      // instruction earlier: seen, S off by 2^-12), and operand registers stay reserved past their last MFMA.
       asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(ka[0]), "+v"(ka[1]), "+v"(ka[2]),
                         "+v"(ka[3]), "+v"(ka[4]), "+v"(ka[5]));
-      constexpr int kKD = 3, kKB = kKD + 1;
-      v8s kr[kKB][2] = {};
+      asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7]));
+      constexpr int kKD = 2, kKB = kKD + 1;
+      constexpr int kVD = 4, kVB = kVD + 1;
+      v8s kr[kKB][2];
+      v2i vb[kVB][2];
 #define SGLK_K_ISSUE(KS)                                                                                     \
   do {                                                                                                       \
     constexpr int a_ = (KS) < 16 ? ((KS) & 3) : 4 + ((KS) - 16);                                             \
     constexpr int o0_ = (KS) < 16 ? ((KS) >> 2) * 8192 : 0, o1_ = o0_ + ((KS) < 16 ? 4096 : 2048);           \
-    if constexpr (PROBE != 5) {                                                                              \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][0]) : "v"(ka[a_]), "i"(o0_) : "memory"); \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][1]) : "v"(ka[a_]), "i"(o1_) : "memory"); \
-    }                                                                                                        \
   } while (0)
-#define SGLK_K_WAIT(N, KS) \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % kKB][0]), "+v"(kr[(KS) % kKB][1])::"memory")
-#define SGLK_K_STEP(KS)                                                                                      \
-  {                                                                                                          \
-    if constexpr ((KS) + kKD < 18) SGLK_K_ISSUE((KS) + kKD);                                                 \
-    constexpr int ahead_ = (KS) + kKD < 18 ? kKD : 17 - (KS);                                                \
-    if constexpr (ahead_ == 3) SGLK_K_WAIT(6, KS);                                                           \
-    if constexpr (ahead_ == 2) SGLK_K_WAIT(4, KS);                                                           \
-    if constexpr (ahead_ == 1) SGLK_K_WAIT(2, KS);                                                           \
-    if constexpr (ahead_ == 0) SGLK_K_WAIT(0, KS);                                                           \
-    if constexpr (PROBE != 6) {                                                                              \
-    M::acc_v(s[0][0], kr[(KS) % kKB][0], qf[0][KS]);                                                         \
-    M::acc_v(s[1][0], kr[(KS) % kKB][0], qf[1][KS]);                                                         \
-    M::acc_v(s[0][1], kr[(KS) % kKB][1], qf[0][KS]);                                                         \
-    M::acc_v(s[1][1], kr[(KS) % kKB][1], qf[1][KS]);                                                         \
-    }                                                                                                        \
-  }
-      if constexpr (PROBE != 2) {
-      SGLK_K_ISSUE(0); SGLK_K_ISSUE(1); SGLK_K_ISSUE(2);
-      SGLK_K_STEP(0) SGLK_K_STEP(1) SGLK_K_STEP(2) SGLK_K_STEP(3) SGLK_K_STEP(4) SGLK_K_STEP(5)
-      SGLK_K_STEP(6) SGLK_K_STEP(7) SGLK_K_STEP(8) SGLK_K_STEP(9) SGLK_K_STEP(10) SGLK_K_STEP(11)
-      SGLK_K_STEP(12) SGLK_K_STEP(13) SGLK_K_STEP(14) SGLK_K_STEP(15) SGLK_K_STEP(16) SGLK_K_STEP(17)
-      }
-#undef SGLK_K_STEP
-#undef SGLK_K_WAIT
-#undef SGLK_K_ISSUE
-      // The compiler does not know that the asm statements above are MFMAs: (1) the S registers come straight out
-      // of the matrix pipe - pad the wait states by hand and tie the registers so that no read of them is scheduled
-      // above this point; (2) an MFMA reads its A / B operands for a few cycles after issue - the K ring registers
-      // stay reserved up to here, or the compiler hands them to the next VALU instruction (seen: an address add
-      // into a register of the last K fragment, one instruction behind its MFMA; S off by 2^-12).
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"
-                   : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1])
-                   : "v"(kr[0][0]), "v"(kr[0][1]), "v"(kr[1][0]), "v"(kr[1][1]), "v"(kr[2][0]), "v"(kr[2][1]),
-                     "v"(kr[3][0]), "v"(kr[3][1]));
-      // ---- the first V fragments go out now: their latency hides behind the softmax
-      constexpr int kVD = 6, kVB = kVD + 1;
-      uint32_t va[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) va[c] = sb + (uint32_t)(vbase0 ^ (c << 5));
-      asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7]));
-      v2i vb[kVB][2] = {};
 #define SGLK_V_ISSUE(I)                                                                                      \
   do {                                                                                                       \
-    if constexpr (PROBE != 7) {                                                                              \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                       \
                  : "=v"(vb[(I) % kVB][0]) : "v"(va[(I) & 7]), "i"((((I) >> 3) * 8192)) : "memory");          \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                       \
                  : "=v"(vb[(I) % kVB][1]) : "v"(va[(I) & 7]), "i"((((I) >> 3) * 8192 + 4096)) : "memory");   \
-    }                                                                                                        \
   } while (0)
-      if constexpr (PROBE != 3) { SGLK_V_ISSUE(0); SGLK_V_ISSUE(1); SGLK_V_ISSUE(2); SGLK_V_ISSUE(3); SGLK_V_ISSUE(4); SGLK_V_ISSUE(5); }
+#define SGLK_K_WAIT(N, KS) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % kKB][0]), "+v"(kr[(KS) % kKB][1])::"memory")
+#define SGLK_K_MMA(KS)                                                                                       \
+    M::acc_v(s[0][0], kr[(KS) % kKB][0], qf[0][KS]);                                                         \
+    M::acc_v(s[1][0], kr[(KS) % kKB][0], qf[1][KS]);                                                         \
+    M::acc_v(s[0][1], kr[(KS) % kKB][1], qf[0][KS]);                                                         \
+    M::acc_v(s[1][1], kr[(KS) % kKB][1], qf[1][KS]);
+#define SGLK_K_STEP(KS)                                                                                      \
+  {                                                                                                          \
+    SGLK_K_ISSUE((KS) + kKD);                                                                                \
+    SGLK_K_WAIT(4, KS);                                                                                      \
+    SGLK_K_MMA(KS)                                                                                           \
+  }
+      // ---- S^T[token, head] = K . Q^T of tile j: per k-step two K fragments (token tiles 0, 1), four MFMAs
+      SGLK_K_ISSUE(0); SGLK_K_ISSUE(1);
+      SGLK_K_STEP(0) SGLK_K_STEP(1) SGLK_K_STEP(2) SGLK_K_STEP(3) SGLK_K_STEP(4) SGLK_K_STEP(5)
+      SGLK_K_STEP(6) SGLK_K_STEP(7) SGLK_K_STEP(8) SGLK_K_STEP(9) SGLK_K_STEP(10) SGLK_K_STEP(11)
+      SGLK_K_STEP(12) SGLK_K_STEP(13) SGLK_K_STEP(14) SGLK_K_STEP(15)
+      // the last three k-steps send out the first V fragments of tile j-1 (younger than the K reads still in flight:
+      // the counts below allow them to stay outstanding)
+      { SGLK_V_ISSUE(0); SGLK_V_ISSUE(1); SGLK_K_WAIT(6, 16); SGLK_K_MMA(16) }
+      { SGLK_V_ISSUE(2); SGLK_V_ISSUE(3); SGLK_K_WAIT(8, 17); SGLK_K_MMA(17) }
+#undef SGLK_K_STEP
+#undef SGLK_K_MMA
+#undef SGLK_K_WAIT
+#undef SGLK_K_ISSUE
+      // S is read by the VALU from PV step 2 on (two steps = 4 MFMAs behind the last QK^T MFMA: more than the wait
+      // states an MFMA result needs); the K ring registers stay reserved up to here
+      asm volatile(""
+                   : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1])
+                   : "v"(kr[0][0]), "v"(kr[0][1]), "v"(kr[1][0]), "v"(kr[1][1]), "v"(kr[2][0]), "v"(kr[2][1]));
       __builtin_amdgcn_sched_barrier(0);
 
-      // ---- online softmax per row tile, lazy reference maximum
-      v8s pf[2] = {{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}};
-      float alpha[2] = {1.f, 1.f};
-      bool upd[2] = {false, false};
-      if constexpr (PROBE != 4)
+      // ---- O += P . V of tile j-1 (one transposed V fragment, two MFMAs per step) with the softmax of tile j in
+      // pieces behind steps 2 .. 19: row tile h = 0 at steps 2..10, h = 1 at steps 11..19
+      v8s pfn[2];
+      float mt[2], alpha[2], mneg[2], psum[2];  // (mt: tile maximum, then the new reference)
+      bool upd[2];
+      auto sm_piece = [&](auto hc, auto kc) {
+        constexpr int h = decltype(hc)::value, k = decltype(kc)::value;
+        if constexpr (k == 0 || k == 1) {  // keys past this row's horizon
+          const int tb = t * kTile + 8 * (g & 1) + 4 * (g >> 1) + 16 * k;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        v4f s0 = s[h][0], s1 = s[h][1];
-        if (t * kTile + kTile > kv_first) {
-          const int tb = t * kTile + 8 * (g & 1) + 4 * (g >> 1);
+          for (int r = 0; r < 4; ++r)
+            if (tb + r >= kv_row[h]) s[h][k][r] = -INFINITY;
+        } else if constexpr (k == 2) {
+          const v4f s0 = s[h][0], s1 = s[h][1];
+          mt[h] = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+        } else if constexpr (k == 3) {  // maximum over the four lane groups of a head: VALU lane swaps, no LDS traffic
+          // (inline asm: this compiler's __builtin_amdgcn_permlane16_swap / 32_swap drop the second result - probed,
+          //  tools/permlane_probe.cpp. The s_nop covers the VALU-write -> permlane-swap wait states.)
+          float a0 = mt[h], a1 = mt[h];
+          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));  // a0 = rows 0 0 2 2, a1 = rows 1 1 3 3
+          float c0 = fmaxf(a0, a1), c1 = c0;
+          asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
+          mt[h] = fmaxf(c0, c1);
+        } else if constexpr (k == 4) {
+          upd[h] = commit && (mt[h] - m_ref[h]) * p.scale_log2 > 8.0f;  // (first tile: ref = -inf; NaN keeps the ref)
+          mt[h] = upd[h] ? mt[h] : m_ref[h];
+          alpha[h] = upd[h] ? __builtin_amdgcn_exp2f((m_ref[h] - mt[h]) * p.scale_log2) : 1.0f;
+          mneg[h] = -mt[h] * p.scale_log2;
+          m_ref[h] = mt[h];  // (the discarded last iteration never updates: upd is false there)
+          psum[h] = 0.f;
+        } else if constexpr (k >= 5 && k <= 8) {  // two weights per piece
+          constexpr int tt = (k - 5) >> 1, r0 = ((k - 5) & 1) * 2;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (tb + r >= kv_row[h]) s0[r] = -INFINITY;
-            if (tb + 16 + r >= kv_row[h]) s1[r] = -INFINITY;
+          for (int r = r0; r < r0 + 2; ++r) {
+            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[h][tt][r], p.scale_log2, mneg[h]));
+            pfn[h][tt * 4 + r] = M::cvt(pe);
+            // the row sum takes the ROUNDED weights (the ones P . V uses): with a lazy reference the largest weight
+            // is no longer exactly 1, and numerator and denominator must round alike
+            psum[h] += M::back(pfn[h][tt * 4 + r]);
           }
+          if constexpr (k == 8) l_run[h] = commit ? l_run[h] * alpha[h] + psum[h] : l_run[h];
         }
-        float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        upd[h] = (mt - m_ref[h]) * p.scale_log2 > 8.0f;  // (first tile: ref = -inf; a NaN difference keeps the ref)
-        const float m_new = upd[h] ? mt : m_ref[h];
-        alpha[h] = upd[h] ? __builtin_amdgcn_exp2f((m_ref[h] - m_new) * p.scale_log2) : 1.0f;
-        const float mneg = -m_new * p.scale_log2;
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], p.scale_log2, mneg));
-          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], p.scale_log2, mneg));
-          pf[h][r] = M::cvt(p0);
-          pf[h][4 + r] = M::cvt(p1);
-          // the row sum takes the ROUNDED weights (the ones P . V uses): with a lazy reference the largest weight is
-          // no longer exactly 1, and numerator and denominator must round alike
-          psum += M::back(pf[h][r]) + M::back(pf[h][4 + r]);
-        }
-        l_run[h] = l_run[h] * alpha[h] + psum;
-        m_ref[h] = m_new;
-      }
-      // ---- rare: a reference moved, rescale O (AGPR -> VGPR -> AGPR; the last PV MFMA is a whole QK^T phase back)
-      if (__any(upd[0] || upd[1])) {
-        const v4f a0 = {head_bcast(alpha[0], 0), head_bcast(alpha[0], 1), head_bcast(alpha[0], 2), head_bcast(alpha[0], 3)};
-        const v4f a1 = {head_bcast(alpha[1], 0), head_bcast(alpha[1], 1), head_bcast(alpha[1], 2), head_bcast(alpha[1], 3)};
-        static_for<0, 32>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a0); });
-        static_for<32, 64>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a1); });
-        asm volatile("s_nop 7");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 3" : "+v"(pf[0]), "+v"(pf[1]));
-      // ---- O[head, dim] += P . V: one transposed V fragment, two MFMAs
+      };
 #define SGLK_V_WAIT(N, I) \
   asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(vb[(I) % kVB][0]), "+v"(vb[(I) % kVB][1])::"memory")
 #define SGLK_V_STEP(G)                                                                                       \
   {                                                                                                          \
     if constexpr ((G) + kVD < 32) SGLK_V_ISSUE((G) + kVD);                                                   \
     constexpr int ahead_ = (G) + kVD < 32 ? kVD : 31 - (G);                                                  \
-    if constexpr (ahead_ == 6) SGLK_V_WAIT(12, G);                                                           \
-    if constexpr (ahead_ == 5) SGLK_V_WAIT(10, G);                                                           \
     if constexpr (ahead_ == 4) SGLK_V_WAIT(8, G);                                                            \
     if constexpr (ahead_ == 3) SGLK_V_WAIT(6, G);                                                            \
     if constexpr (ahead_ == 2) SGLK_V_WAIT(4, G);                                                            \
@@ -876,46 +874,65 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
     const v4s x0_ = __builtin_bit_cast(v4s, vb[(G) % kVB][0]), x1_ = __builtin_bit_cast(v4s, vb[(G) % kVB][1]); \
     f_[0] = x0_[0]; f_[1] = x0_[1]; f_[2] = x0_[2]; f_[3] = x0_[3];                                          \
     f_[4] = x1_[0]; f_[5] = x1_[1]; f_[6] = x1_[2]; f_[7] = x1_[3];                                          \
-    if constexpr (PROBE != 8) {                                                                              \
     M::template acc_agpr<(G) * 4>(pf[0], f_);                                                                \
     M::template acc_agpr<(32 + (G)) * 4>(pf[1], f_);                                                         \
-    }                                                                                                        \
+    if constexpr ((G) >= 2 && (G) < 20)                                                                      \
+      sm_piece(std::integral_constant<int, ((G) - 2) / 9>{}, std::integral_constant<int, ((G) - 2) % 9>{});  \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
   }
-      if constexpr (PROBE != 3) {
       SGLK_V_STEP(0) SGLK_V_STEP(1) SGLK_V_STEP(2) SGLK_V_STEP(3) SGLK_V_STEP(4) SGLK_V_STEP(5)
       SGLK_V_STEP(6) SGLK_V_STEP(7) SGLK_V_STEP(8) SGLK_V_STEP(9) SGLK_V_STEP(10) SGLK_V_STEP(11)
       SGLK_V_STEP(12) SGLK_V_STEP(13) SGLK_V_STEP(14) SGLK_V_STEP(15) SGLK_V_STEP(16) SGLK_V_STEP(17)
       SGLK_V_STEP(18) SGLK_V_STEP(19) SGLK_V_STEP(20) SGLK_V_STEP(21) SGLK_V_STEP(22) SGLK_V_STEP(23)
       SGLK_V_STEP(24) SGLK_V_STEP(25) SGLK_V_STEP(26) SGLK_V_STEP(27) SGLK_V_STEP(28) SGLK_V_STEP(29)
       SGLK_V_STEP(30) SGLK_V_STEP(31)
-      }
 #undef SGLK_V_STEP
 #undef SGLK_V_WAIT
 #undef SGLK_V_ISSUE
-      // same for the operands of the last PV MFMAs (P and the V ring): reserved until the matrix pipe has read them
-      asm volatile("s_nop 7" ::"v"(pf[0]), "v"(pf[1]), "v"(vb[0][0]), "v"(vb[0][1]), "v"(vb[1][0]), "v"(vb[1][1]),
-                   "v"(vb[2][0]), "v"(vb[2][1]), "v"(vb[3][0]), "v"(vb[3][1]), "v"(vb[4][0]), "v"(vb[4][1]),
-                   "v"(vb[5][0]), "v"(vb[5][1]), "v"(vb[6][0]), "v"(vb[6][1]));
+      // the operands of the last PV MFMAs (P and the V ring) stay reserved until the matrix pipe has read them; the
+      // nops also cover the MFMA -> v_accvgpr_read wait states of the two blocks below
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::"v"(pf[0]), "v"(pf[1]), "v"(vb[0][0]), "v"(vb[0][1]), "v"(vb[1][0]),
+                   "v"(vb[1][1]), "v"(vb[2][0]), "v"(vb[2][1]), "v"(vb[3][0]), "v"(vb[3][1]), "v"(vb[4][0]), "v"(vb[4][1]));
+      __builtin_amdgcn_sched_barrier(0);
+      if (j == 0) {
+        // O[row tile h][16-column tile nt] = a[(32 h + nt) 4 .. +3]: start from zero (iteration 0 added 0 . V)
+        static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
+      } else if (__any(upd[0] || upd[1])) {
+        // rare: a reference moved, rescale O (AGPR -> VGPR -> AGPR) before the next tile's P . V is added
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const v4f a0 = {head_bcast(ln, alpha[0], 0), head_bcast(ln, alpha[0], 1), head_bcast(ln, alpha[0], 2), head_bcast(ln, alpha[0], 3)};
+        const v4f a1 = {head_bcast(ln, alpha[1], 0), head_bcast(ln, alpha[1], 1), head_bcast(ln, alpha[1], 2), head_bcast(ln, alpha[1], 3)};
+        static_for<0, 32>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a0); });
+        static_for<32, 64>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a1); });
+        asm volatile("s_nop 7");
+      }
+      if (commit) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) pf[h] = pfn[h];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    st = st + 1 == kStages ? 0 : st + 1;
   }
 
   // ---- epilogue: normalise by the row sums and write. O tile nt: lane holds dim 16 nt + l15, heads 4g + r
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");  // the last MFMA results are read from the AGPRs below
+  int le = threadIdx.x & 63;
+  asm volatile("" : "+v"(le));  // (everything the stores need is derived here, after the loop)
+  const int l15e = le & 15, ge = le >> 4;
   static_for<0, 2>([&](auto hc) {
     constexpr int h = decltype(hc)::value;
     if (!active[h] || p.probe == 1) return;
     float l_tot = l_run[h] + __shfl_xor(l_run[h], 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
     const float inv_l = 1.0f / l_tot;
-    const v4f i4 = {head_bcast(inv_l, 0), head_bcast(inv_l, 1), head_bcast(inv_l, 2), head_bcast(inv_l, 3)};
+    const v4f i4 = {head_bcast(le, inv_l, 0), head_bcast(le, inv_l, 1), head_bcast(le, inv_l, 2), head_bcast(le, inv_l, 3)};
     const int row0 = (wave * 2 + h) * 16;
     if (p.splits == 1) {
       T* out = (T*)p.out + (int64_t)(q_row0 + grp_tok[h]) * H * kLatent;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int head = grp_head0[h] + 4 * g + r;
+        const int head = grp_head0[h] + 4 * ge + r;
         (void)head;
       }
       static_for<0, 32>([&](auto ic) {
@@ -923,15 +940,15 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
         const v4f v = agpr_read4<(h * 32 + nt) * 4>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int head = grp_head0[h] + 4 * g + r;
-          if (head < H) out[(int64_t)head * kLatent + nt * 16 + l15] = (T)(v[r] * i4[r]);
+          const int head = grp_head0[h] + 4 * ge + r;
+          if (head < H) out[(int64_t)head * kLatent + nt * 16 + l15e] = (T)(v[r] * i4[r]);
         }
       });
     } else {
       float* wo = p.ws_o + ((int64_t)b * p.splits + split) * H * kLatent;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int head = row0 + 4 * g + r;
+        const int head = row0 + 4 * ge + r;
         (void)head;
       }
       static_for<0, 32>([&](auto ic) {
@@ -939,12 +956,12 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
         const v4f v = agpr_read4<(h * 32 + nt) * 4>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int head = row0 + 4 * g + r;
-          if (head < H) wo[(int64_t)head * kLatent + nt * 16 + l15] = v[r] * i4[r];
+          const int head = row0 + 4 * ge + r;
+          if (head < H) wo[(int64_t)head * kLatent + nt * 16 + l15e] = v[r] * i4[r];
         }
       });
-      if (lane < 16 && row0 + lane < H)
-        p.ws_lse[((int64_t)b * p.splits + split) * H + row0 + lane] = m_ref[h] * p.scale_log2 + log2f(l_tot);
+      if (le < 16 && row0 + le < H)
+        p.ws_lse[((int64_t)b * p.splits + split) * H + row0 + le] = m_ref[h] * p.scale_log2 + log2f(l_tot);
     }
   });
 }
@@ -994,20 +1011,20 @@ static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nop
   return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
 }
 
-template <typename T, int PROBE = 0>
+template <typename T>
 static int launch_rows128(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
                           const void* cache, const int32_t* seq_lens, const int32_t* page_table,
                           const int32_t* cu_seqlens_q = nullptr, int token_blocks = 1) {
   static bool attr_set = false;
   constexpr int lds = 4 * kStageBytes;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_rows128_kernel<T, PROBE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_rows128_kernel<T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(SGLK_ELAUNCH, "flash_mla_decode: cannot reserve %d B of LDS: %s", lds,
                                      hipGetErrorString(e));
     attr_set = true;
   }
-  mla_rows128_kernel<T, PROBE><<<dim3(p.splits, B, token_blocks), kThreads2, lds, st>>>(
+  mla_rows128_kernel<T><<<dim3(p.splits, B, token_blocks), kThreads2, lds, st>>>(
       p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
   return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
 }
@@ -1024,12 +1041,7 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
   if (g_mla_waves_per_group > 0 && g_mla_waves_per_group <= w) w = g_mla_waves_per_group;
   int rc;
   if (ngroups > 4 && g_mla_waves_per_group == 0) {
-    switch (std::is_same<T, bf16>::value ? p.probe : 0) {  // (the timing probes exist for bf16 only)
-#define SGLK_PR(N) case N: rc = launch_rows128<T, N>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
-      SGLK_PR(2) SGLK_PR(3) SGLK_PR(4) SGLK_PR(5) SGLK_PR(6) SGLK_PR(7) SGLK_PR(8)
-#undef SGLK_PR
-      default: rc = launch_rows128<T>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
-    }
+    rc = launch_rows128<T>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table);
   } else
   switch (w) {
     case 8: rc = launch_w<T, 8>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
