@@ -624,24 +624,26 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
   const int page_mask = (1 << p.page_shift) - 1;
 
   // ---- LDS-DMA of one tile (same image as above): wave w fills column block w (8 row groups) and rope rows 8w..8w+7
+  // Addresses: a scalar base per half tile (rows 0..15 / 16..31: the second half is another page when PAGE == 16)
+  // plus two loop-invariant per-lane offsets (the row-group dependence of the swizzle is an XOR on bits 4, 5), so
+  // that a tile costs a handful of scalar instructions instead of ~90 vector ones (64-bit adds, multiplies) on the
+  // critical path behind the barrier.
+  const uint32_t dma_lo0 = (uint32_t)((lane >> 4) * kRowBytes + wave * 256 + 16 * ((lane & 15) ^ ((lane >> 4) << 2)));
+  const uint32_t dma_ro = (uint32_t)((((wave & 1) * 8 + (lane >> 3)) * kRowBytes) + 1024 +
+                                     16 * ((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)));
   auto stage_tile = [&](int t, int st, int pg0, int pg1) {
     char* base = smem + st * kStageBytes;
     const int tok0 = t * kTile;
-    const char* src0 = cache + (int64_t)pg0 * p.page_stride_bytes;
-    const char* src1 = cache + (int64_t)pg1 * p.page_stride_bytes;
+    const char* sA = cache + (int64_t)pg0 * p.page_stride_bytes + (int64_t)(tok0 & page_mask) * kRowBytes;
+    const char* sB = p.page_shift == 4 ? cache + (int64_t)pg1 * p.page_stride_bytes : sA + 16 * kRowBytes;
 #pragma unroll
     for (int rg = 0; rg < 8; ++rg) {
-      const int row = rg * 4 + (lane >> 4);
-      const int ch = (lane & 15) ^ sw_main(row);
-      const int in_page = (tok0 + row) & page_mask;
-      const char* src = (rg < 4 ? src0 : src1) + in_page * kRowBytes + wave * 256 + ch * 16;
+      const char* sbase = (rg < 4 ? sA : sB) + (rg & 3) * 4 * kRowBytes;
+      const char* src = sbase + (dma_lo0 ^ (uint32_t)((rg & 3) << 4));
       __builtin_amdgcn_global_load_lds(SGLK_GLB(src), SGLK_LDS(base + wave * 8192 + rg * 1024), 16, 0, 0);
     }
     {
-      const int row = wave * 8 + (lane >> 3);
-      const int ch = (lane & 7) ^ ((row >> 1) & 7);
-      const int in_page = (tok0 + row) & page_mask;
-      const char* src = (wave < 2 ? src0 : src1) + in_page * kRowBytes + 1024 + ch * 16;
+      const char* src = (wave < 2 ? sA : sB) + dma_ro;
       __builtin_amdgcn_global_load_lds(SGLK_GLB(src), SGLK_LDS(base + kMainBytes + wave * 1024), 16, 0, 0);
     }
   };
@@ -816,47 +818,57 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
                    : "v"(kr[0][0]), "v"(kr[0][1]), "v"(kr[1][0]), "v"(kr[1][1]), "v"(kr[2][0]), "v"(kr[2][1]));
       __builtin_amdgcn_sched_barrier(0);
 
-      // ---- O += P . V of tile j-1 (one transposed V fragment, two MFMAs per step) with the softmax of tile j in
-      // pieces behind steps 2 .. 19: row tile h = 0 at steps 2..10, h = 1 at steps 11..19
+      // ---- O += P . V of tile j-1 (one transposed V fragment, two MFMAs per step) with the softmax of tile j
+      // behind the MFMAs of steps 2 .. 29
       v8s pfn[2];
       float mt[2], alpha[2], mneg[2], psum[2];  // (mt: tile maximum, then the new reference)
       bool upd[2];
-      auto sm_piece = [&](auto hc, auto kc) {
-        constexpr int h = decltype(hc)::value, k = decltype(kc)::value;
-        if constexpr (k == 0 || k == 1) {  // keys past this row's horizon
-          const int tb = t * kTile + 8 * (g & 1) + 4 * (g >> 1) + 16 * k;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (tb + r >= kv_row[h]) s[h][k][r] = -INFINITY;
-        } else if constexpr (k == 2) {
-          const v4f s0 = s[h][0], s1 = s[h][1];
-          mt[h] = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-        } else if constexpr (k == 3) {  // maximum over the four lane groups of a head: VALU lane swaps, no LDS traffic
-          // (inline asm: this compiler's __builtin_amdgcn_permlane16_swap / 32_swap drop the second result - probed,
-          //  tools/permlane_probe.cpp. The s_nop covers the VALU-write -> permlane-swap wait states.)
+      // one micro-op (a few dependent VALU instructions of one row tile) per MFMA slot, the two row tiles
+      // alternating, so that consecutive slots are independent and a dependent pair is >= 2 MFMAs apart: a single
+      // wave issues in order, and a dependent VALU chain between two MFMAs would leave the matrix pipe idle
+      auto sm_op = [&](auto nc) {
+        constexpr int n = decltype(nc)::value, h = n & 1, k = n >> 1;
+        if constexpr (k < 8) {  // keys past this row's horizon
+          constexpr int tt = k >> 2, r = k & 3;
+          if (t * kTile + 8 * (g & 1) + 4 * (g >> 1) + 16 * tt + r >= kv_row[h]) s[h][tt][r] = -INFINITY;
+        } else if constexpr (k == 8) {
+          mt[h] = fmaxf(fmaxf(s[h][0][0], s[h][0][1]), fmaxf(s[h][0][2], s[h][0][3]));
+        } else if constexpr (k == 9) {
+          mt[h] = fmaxf(mt[h], fmaxf(fmaxf(s[h][1][0], s[h][1][1]), fmaxf(s[h][1][2], s[h][1][3])));
+        } else if constexpr (k == 10) {
+          // maximum over the four lane groups of a head: VALU lane swaps, no LDS traffic. (inline asm: this
+          // compiler's __builtin_amdgcn_permlane16_swap / 32_swap drop the second result - probed,
+          // tools/permlane_probe.cpp. The s_nop covers the VALU-write -> permlane-swap wait states.)
           float a0 = mt[h], a1 = mt[h];
           asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));  // a0 = rows 0 0 2 2, a1 = rows 1 1 3 3
-          float c0 = fmaxf(a0, a1), c1 = c0;
+          mt[h] = fmaxf(a0, a1);
+        } else if constexpr (k == 11) {
+          float c0 = mt[h], c1 = mt[h];
           asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
           mt[h] = fmaxf(c0, c1);
-        } else if constexpr (k == 4) {
+        } else if constexpr (k == 12) {
           upd[h] = commit && (mt[h] - m_ref[h]) * p.scale_log2 > 8.0f;  // (first tile: ref = -inf; NaN keeps the ref)
           mt[h] = upd[h] ? mt[h] : m_ref[h];
+        } else if constexpr (k == 13) {
           alpha[h] = upd[h] ? __builtin_amdgcn_exp2f((m_ref[h] - mt[h]) * p.scale_log2) : 1.0f;
+        } else if constexpr (k == 14) {
           mneg[h] = -mt[h] * p.scale_log2;
           m_ref[h] = mt[h];  // (the discarded last iteration never updates: upd is false there)
           psum[h] = 0.f;
-        } else if constexpr (k >= 5 && k <= 8) {  // two weights per piece
-          constexpr int tt = (k - 5) >> 1, r0 = ((k - 5) & 1) * 2;
+        } else if constexpr (k < 23) {  // the weights overwrite the scores
+          constexpr int e = k - 15, tt = e >> 2, r = e & 3;
+          s[h][tt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[h][tt][r], p.scale_log2, mneg[h]));
+        } else if constexpr (k < 27) {
+          constexpr int pr = k - 23, tt = pr >> 1, r0 = (pr & 1) * 2;
 #pragma unroll
           for (int r = r0; r < r0 + 2; ++r) {
-            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[h][tt][r], p.scale_log2, mneg[h]));
-            pfn[h][tt * 4 + r] = M::cvt(pe);
+            pfn[h][tt * 4 + r] = M::cvt(s[h][tt][r]);
             // the row sum takes the ROUNDED weights (the ones P . V uses): with a lazy reference the largest weight
             // is no longer exactly 1, and numerator and denominator must round alike
             psum[h] += M::back(pfn[h][tt * 4 + r]);
           }
-          if constexpr (k == 8) l_run[h] = commit ? l_run[h] * alpha[h] + psum[h] : l_run[h];
+        } else if constexpr (k == 27) {
+          l_run[h] = commit ? l_run[h] * alpha[h] + psum[h] : l_run[h];
         }
       };
 #define SGLK_V_WAIT(N, I) \
@@ -875,9 +887,19 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
     f_[0] = x0_[0]; f_[1] = x0_[1]; f_[2] = x0_[2]; f_[3] = x0_[3];                                          \
     f_[4] = x1_[0]; f_[5] = x1_[1]; f_[6] = x1_[2]; f_[7] = x1_[3];                                          \
     M::template acc_agpr<(G) * 4>(pf[0], f_);                                                                \
+    if constexpr ((G) >= 2 && (G) < 30) {                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      sm_op(std::integral_constant<int, ((G) - 2) * 2>{});                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
     M::template acc_agpr<(32 + (G)) * 4>(pf[1], f_);                                                         \
-    if constexpr ((G) >= 2 && (G) < 20)                                                                      \
-      sm_piece(std::integral_constant<int, ((G) - 2) / 9>{}, std::integral_constant<int, ((G) - 2) % 9>{});  \
+    if constexpr ((G) >= 2 && (G) < 30) {                                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      sm_op(std::integral_constant<int, ((G) - 2) * 2 + 1>{});                                               \
+    }                                                                                                        \
+    /* the V fragment's registers stay reserved past the micro-op (the compiler would hand them to it: a VALU */ \
+    /* write into an operand of the MFMA issued just before)                                               */ \
+    asm volatile("" ::"v"(vb[(G) % kVB][0]), "v"(vb[(G) % kVB][1]));                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
   }
       SGLK_V_STEP(0) SGLK_V_STEP(1) SGLK_V_STEP(2) SGLK_V_STEP(3) SGLK_V_STEP(4) SGLK_V_STEP(5)
@@ -1180,7 +1202,13 @@ extern "C" int sglk_flash_mla_prefill(sglk_stream_t stream, void* out, const voi
   const int tpw = 1 << (7 - p.hp_shift);
   const int token_blocks = (int)((max_seqlen_q + tpw - 1) / tpw);
   hipStream_t st = (hipStream_t)stream;
+  // 128 rows per workgroup either way: the rows128 kernel (the hook value 1 selects the 8-wave kernel instead)
+  if (g_mla_waves_per_group == 1) {
+    if (dtype == SGLK_BF16)
+      return launch_w<bf16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+    return launch_w<f16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+  }
   if (dtype == SGLK_BF16)
-    return launch_w<bf16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
-  return launch_w<f16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+    return launch_rows128<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+  return launch_rows128<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
 }
