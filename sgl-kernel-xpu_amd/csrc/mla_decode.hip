@@ -551,20 +551,26 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
 
 
 // ---------------------------------------------------------------------------------------------------------
-// rows128 kernel: the same contract and LDS image as above for workgroups with more than 64 rows (decode with
-// H > 64; DeepSeek-V3 has 128 heads). In the kernel above a wave that owns 16 heads pins 72 (Q) + 128 (O) of its 256
-// registers and has no room to keep LDS reads in flight: its QK^T loop is read - wait - MFMA (seen in the ISA),
-// and every K / V fragment read from LDS feeds ONE MFMA, so the LDS pipe (2 x 1088 B per token and 16 heads)
-// bounds the kernel at ~0.4 of the HBM roofline.
+// rows128 kernel: the same contract and LDS image as above for workgroups with 128 rows (decode with H > 64 -
+// DeepSeek-V3 has 128 heads - and every flash_mla_prefill). In the kernel above a wave that owns 16 rows pins
+// 72 (Q) + 128 (O) of its 256 registers and has no room to keep LDS reads in flight: its QK^T loop is read - wait -
+// MFMA (seen in the ISA), and every K / V fragment read from LDS feeds ONE MFMA, so the LDS pipe (2 x 1088 B per
+// token and 16 rows) bounds it at ~0.4 of the HBM roofline.
 // Here a workgroup is 4 waves, one per SIMD, 512 registers each. Wave w owns rows 32w .. 32w+31 (two 16-row
 // tiles): every K fragment and every transposed V fragment is read once and feeds TWO MFMAs (LDS read traffic
-// halves), O (2 x 32 tiles x 4 = 256 registers) lives in the AGPR file and is only touched by the PV MFMAs, and
-// the 112 VGPRs left next to Q (144) hold rings of K fragments (3 k-steps ahead) and V fragments (6 tiles ahead).
-// All MFMAs and LDS reads are inline asm in program order (the waits are counted by hand; the manual wait
-// states the compiler would insert around MFMA results are padded by hand: s_nop after the last MFMA of a phase).
+// halves). O (2 x 32 tiles x 4 = 256 registers) lives in the FIXED registers a0..a255, named in the asm text; the
+// compiler never sees those values (tools/check_isa.py verifies that it does not touch the AGPR file itself in this
+// kernel: under VGPR pressure it would park values there). Next to Q (144 VGPRs) the rings hold K fragments 2
+// k-steps ahead and V fragments 4 tiles ahead - all the registers there are (252 of 256 used).
+// One wave per SIMD has no other wave to overlap with, so the overlap is written out: iteration j runs QK^T of tile
+// j, then P.V of tile j-1 with the softmax of tile j as ~56 micro-ops between its MFMAs; page ids are looked up one
+// tile ahead; the max across lane groups uses v_permlane16/32_swap (VALU) instead of LDS shuffles.
+// All MFMAs and LDS reads are inline asm in program order with hand-counted waits. What the compiler would do for
+// real MFMA instructions is done by hand: s_nop after the last MFMA of a phase before its results are read, operand
+// registers kept reserved past the issue of their last MFMA, zeros and addresses materialised before the first read.
 // Online softmax with a lazy reference maximum: O (in AGPRs: a rescale costs 3 VALU instructions per register) is
-// rescaled only when a head's tile maximum exceeds its reference by more than 2^8; P = 2^(s - ref) stays <= 256,
-// exact in the fp32 row sums and the same relative precision in 16 bits.
+// rescaled only when a head's tile maximum exceeds its reference by more than 2^8; P = 2^(s - ref) stays <= 256 and
+// the row sums add the ROUNDED weights, so numerator and denominator round alike.
 constexpr int kThreads2 = 256;
 
 template <typename T>
