@@ -136,6 +136,11 @@ def side_metrics(sgl_kernel, dev):
         ms = timeit(lambda: sgl_kernel.fp8_blockwise_scaled_mm(am, bw, sam, sbw, torch.bfloat16), iters=50)
         out[f"fp8_blockwise_gemm_M{m}_us"] = round(ms * 1e3, 1)
         out[f"fp8_blockwise_gemm_M{m}_weight_GBs"] = round(N * K / ms / 1e6, 1)
+        if m <= 64:  # fp8_scaled_mm (per-row / per-column scales) on the same weights
+            sa1 = torch.rand(m, 1, device=dev) * 1e-3 + 1e-4
+            sb1 = torch.rand(N, 1, device=dev) * 1e-3 + 1e-4
+            ms = timeit(lambda: sgl_kernel.fp8_scaled_mm(am, bw, sa1, sb1, torch.bfloat16), iters=50)
+            out[f"fp8_scaled_mm_M{m}_us"] = round(ms * 1e3, 1)
     del bw, sbw
     # flash_mla_decode, BASELINE configs[3]: bs=128, seq=8192, kv_lora 512 + rope 64, paged (64), bf16.
     # Bytes as benchmark/bench_flash_mla_decode.py:109-115 of the reference: q + kv cache + table + seq_lens + out.
@@ -149,12 +154,27 @@ def side_metrics(sgl_kernel, dev):
         q_nope, q_pe = qq[..., :512], qq[..., 512:].contiguous()
         ws = torch.empty(sgl_kernel.flash_mla_get_workspace_size(seq, bs, H, page, -1), device=dev, dtype=torch.uint8)
         ms = timeit(lambda: sgl_kernel.flash_mla_decode(q_nope, q_pe, cache, seq_lens, table, ws, 576 ** -0.5, -1),
-                    iters=10)
+                    iters=50)
         nbytes = qq.numel() * 2 + cache.numel() * 2 + table.numel() * 4 + seq_lens.numel() * 4 + bs * H * 512 * 2
         out[f"flash_mla_decode_bs128_seq8192_h{H}_GBs"] = round(nbytes / ms / 1e6, 1)
         out[f"flash_mla_decode_bs128_seq8192_h{H}_ms"] = round(ms, 4)
         out[f"flash_mla_decode_bs128_seq8192_h{H}_TFLOPs"] = round(2.0 * bs * H * seq * (576 + 512) / ms / 1e9, 1)
     del cache, table, seq_lens
+    # flash_mla_prefill (same latent cache layout): 16 sequences, 512 new tokens each over 4096 cached keys, causal
+    pb, psq, psk = 16, 512, 4096
+    pcache = torch.randn(pb * psk // page, page, 576, device=dev, dtype=torch.bfloat16)
+    ptable = torch.arange(pb * psk // page, device=dev, dtype=torch.int32).view(pb, psk // page)
+    pq = torch.randn(pb * psq, 128, 576, device=dev, dtype=torch.bfloat16)
+    pqn, pqp = pq[..., :512], pq[..., 512:].contiguous()
+    pcu = torch.arange(pb + 1, device=dev, dtype=torch.int32) * psq
+    psl = torch.full((pb,), psk, device=dev, dtype=torch.int32)
+    pws = torch.empty(1, device=dev, dtype=torch.uint8)
+    ms = timeit(lambda: sgl_kernel.flash_mla_prefill(pqn, pqp, pcache, pcu, psl, psq, ptable, pws, 576 ** -0.5, True),
+                iters=5)
+    out["flash_mla_prefill_h128_16x512_over_4096_ms"] = round(ms, 4)
+    out["flash_mla_prefill_h128_16x512_over_4096_TFLOPs"] = round(
+        2.0 * pb * 128 * (576 + 512) * (psq * (psk - psq) + psq * (psq + 1) / 2) / ms / 1e9, 1)
+    del pcache, ptable, pq, pqn, pqp
     # fwd (flash attention), BASELINE configs[2]: bs=16, 32 q heads / 8 kv heads, d=128, seq=4096, paged (64), bf16.
     from sgl_kernel.flash_attn import flash_attn_with_kvcache
 

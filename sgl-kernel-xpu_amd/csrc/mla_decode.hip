@@ -753,13 +753,9 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
       const uint32_t sbq = lds_base + (uint32_t)((jq & 3) * kStageBytes), sbv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
       const int t = t_begin + jq;
       __builtin_amdgcn_sched_barrier(0);
-      uint32_t ka[6], va[8];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) ka[c] = sbq + (uint32_t)(kbase ^ (c << 6));
-#pragma unroll
-      for (int c = 0; c < 2; ++c) ka[4 + c] = sbq + (uint32_t)(rbase ^ (c << 6));
-#pragma unroll
-      for (int c = 0; c < 8; ++c) va[c] = sbv + (uint32_t)(vbase0 ^ (c << 5));
+      // one base address per read kind; the chunk step of a read is an XOR on bits 5..7 (stage bases are multiples
+      // of 4 KiB, so the XOR commutes with the add) done right before the read goes out: 3 registers instead of 14
+      uint32_t ksum = sbq + (uint32_t)kbase, rsum = sbq + (uint32_t)rbase, vsum = sbv + (uint32_t)vbase0;
       v4f s[2][2];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -770,26 +766,28 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
       // are in their registers BEFORE the first read goes out (left alone, the compiler rematerialises a zero
       // accumulator right in front of its first MFMA, into the registers of the K fragment of the MFMA one
       // instruction earlier: seen, S off by 2^-12), and operand registers stay reserved past their last MFMA.
-      asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(ka[0]), "+v"(ka[1]), "+v"(ka[2]),
-                        "+v"(ka[3]), "+v"(ka[4]), "+v"(ka[5]));
-      asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7]));
+      asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(ksum), "+v"(rsum), "+v"(vsum));
       constexpr int kKD = 2, kKB = kKD + 1;
-      constexpr int kVD = 4, kVB = kVD + 1;
+      constexpr int kVD = 6, kVB = kVD + 1;
       v8s kr[kKB][2];
       v2i vb[kVB][2];
 #define SGLK_K_ISSUE(KS)                                                                                     \
   do {                                                                                                       \
-    constexpr int a_ = (KS) < 16 ? ((KS) & 3) : 4 + ((KS) - 16);                                             \
     constexpr int o0_ = (KS) < 16 ? ((KS) >> 2) * 8192 : 0, o1_ = o0_ + ((KS) < 16 ? 4096 : 2048);           \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][0]) : "v"(ka[a_]), "i"(o0_) : "memory"); \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][1]) : "v"(ka[a_]), "i"(o1_) : "memory"); \
+    const uint32_t a_ = (KS) < 16 ? (ksum ^ (uint32_t)(((KS) & 3) << 6)) : (rsum ^ (uint32_t)(((KS) - 16) << 6)); \
+    /* the address is computed while the slot this read will overwrite is still reserved: its last MFMAs were */ \
+    /* issued just before, and the compiler would otherwise be free to put the address into those registers   */ \
+    if constexpr ((KS) >= kKB) asm volatile("" ::"v"(kr[(KS) % kKB][0]), "v"(kr[(KS) % kKB][1]), "v"(a_));   \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][0]) : "v"(a_), "i"(o0_) : "memory");  \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][1]) : "v"(a_), "i"(o1_) : "memory");  \
   } while (0)
 #define SGLK_V_ISSUE(I)                                                                                      \
   do {                                                                                                       \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                       \
-                 : "=v"(vb[(I) % kVB][0]) : "v"(va[(I) & 7]), "i"((((I) >> 3) * 8192)) : "memory");          \
+                 : "=v"(vb[(I) % kVB][0]) : "v"(vnext), "i"((((I) >> 3) * 8192)) : "memory");                \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                       \
-                 : "=v"(vb[(I) % kVB][1]) : "v"(va[(I) & 7]), "i"((((I) >> 3) * 8192 + 4096)) : "memory");   \
+                 : "=v"(vb[(I) % kVB][1]) : "v"(vnext), "i"((((I) >> 3) * 8192 + 4096)) : "memory");         \
+    vnext = vsum ^ (uint32_t)((((I) + 1) & 7) << 5); /* address of the next fragment (the reads go out in order) */ \
   } while (0)
 #define SGLK_K_WAIT(N, KS) \
   asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % kKB][0]), "+v"(kr[(KS) % kKB][1])::"memory")
@@ -805,14 +803,16 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
     SGLK_K_MMA(KS)                                                                                           \
   }
       // ---- S^T[token, head] = K . Q^T of tile j: per k-step two K fragments (token tiles 0, 1), four MFMAs
+      uint32_t vnext = vsum;
       SGLK_K_ISSUE(0); SGLK_K_ISSUE(1);
       SGLK_K_STEP(0) SGLK_K_STEP(1) SGLK_K_STEP(2) SGLK_K_STEP(3) SGLK_K_STEP(4) SGLK_K_STEP(5)
       SGLK_K_STEP(6) SGLK_K_STEP(7) SGLK_K_STEP(8) SGLK_K_STEP(9) SGLK_K_STEP(10) SGLK_K_STEP(11)
-      SGLK_K_STEP(12) SGLK_K_STEP(13) SGLK_K_STEP(14) SGLK_K_STEP(15)
+      SGLK_K_STEP(12) SGLK_K_STEP(13) SGLK_K_STEP(14)
       // the last three k-steps send out the first V fragments of tile j-1 (younger than the K reads still in flight:
       // the counts below allow them to stay outstanding)
-      { SGLK_V_ISSUE(0); SGLK_V_ISSUE(1); SGLK_K_WAIT(6, 16); SGLK_K_MMA(16) }
-      { SGLK_V_ISSUE(2); SGLK_V_ISSUE(3); SGLK_K_WAIT(8, 17); SGLK_K_MMA(17) }
+      { SGLK_K_ISSUE(17); SGLK_V_ISSUE(0); SGLK_V_ISSUE(1); SGLK_K_WAIT(8, 15); SGLK_K_MMA(15) }
+      { SGLK_V_ISSUE(2); SGLK_V_ISSUE(3); SGLK_K_WAIT(10, 16); SGLK_K_MMA(16) }
+      { SGLK_V_ISSUE(4); SGLK_V_ISSUE(5); SGLK_K_WAIT(12, 17); SGLK_K_MMA(17) }
 #undef SGLK_K_STEP
 #undef SGLK_K_MMA
 #undef SGLK_K_WAIT
@@ -883,6 +883,8 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
   {                                                                                                          \
     if constexpr ((G) + kVD < 32) SGLK_V_ISSUE((G) + kVD);                                                   \
     constexpr int ahead_ = (G) + kVD < 32 ? kVD : 31 - (G);                                                  \
+    if constexpr (ahead_ == 6) SGLK_V_WAIT(12, G);                                                           \
+    if constexpr (ahead_ == 5) SGLK_V_WAIT(10, G);                                                           \
     if constexpr (ahead_ == 4) SGLK_V_WAIT(8, G);                                                            \
     if constexpr (ahead_ == 3) SGLK_V_WAIT(6, G);                                                            \
     if constexpr (ahead_ == 2) SGLK_V_WAIT(4, G);                                                            \
@@ -920,7 +922,8 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
       // the operands of the last PV MFMAs (P and the V ring) stay reserved until the matrix pipe has read them; the
       // nops also cover the MFMA -> v_accvgpr_read wait states of the two blocks below
       asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::"v"(pf[0]), "v"(pf[1]), "v"(vb[0][0]), "v"(vb[0][1]), "v"(vb[1][0]),
-                   "v"(vb[1][1]), "v"(vb[2][0]), "v"(vb[2][1]), "v"(vb[3][0]), "v"(vb[3][1]), "v"(vb[4][0]), "v"(vb[4][1]));
+                   "v"(vb[1][1]), "v"(vb[2][0]), "v"(vb[2][1]), "v"(vb[3][0]), "v"(vb[3][1]), "v"(vb[4][0]), "v"(vb[4][1]),
+                   "v"(vb[5][0]), "v"(vb[5][1]), "v"(vb[6][0]), "v"(vb[6][1]));
       __builtin_amdgcn_sched_barrier(0);
       if (j == 0) {
         // O[row tile h][16-column tile nt] = a[(32 h + nt) 4 .. +3]: start from zero (iteration 0 added 0 . V)

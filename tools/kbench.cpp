@@ -83,7 +83,26 @@ __global__ __launch_bounds__(512) void mfma_peak_kernel(const int* __restrict__ 
     for (int j = 0; j < 8; ++j) a[i][j] = src[(threadIdx.x * 8 + j + i * 4096) & 16383];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 8; ++j) b[i][j] = src[(threadIdx.x * 8 + j + i * 4096 + 777) & 16383];
-  if constexpr (MODE == 2) {
+  if constexpr (MODE == 3) {  // bf16 16x16x32, 16 independent accumulators
+    typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    v4f_t acc[4][4] = {};
+    v4i_t ah[4], bh[4];
+    for (int i = 0; i < 4; ++i) { ah[i] = (v4i_t){a[i][0], a[i][1], a[i][2], a[i][3]}; bh[i] = (v4i_t){b[i][0], b[i][1], b[i][2], b[i][3]}; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf_t, bh[n]), __builtin_bit_cast(v8bf_t, ah[m]), acc[m][n], 0, 0, 0);
+      asm volatile("" : "+v"(ah[0][0]), "+v"(ah[1][0]), "+v"(ah[2][0]), "+v"(ah[3][0]));
+    }
+    float s = 0;
+    for (int m = 0; m < 4; ++m)
+      for (int n = 0; n < 4; ++n)
+        for (int r = 0; r < 4; ++r) s += acc[m][n][r];
+    dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  } else if constexpr (MODE == 2) {
     v16f_t acc[4] = {};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -171,15 +190,16 @@ int main(int argc, char** argv) {
     int* src = (int*)dev_random_bytes(16384 * 4, 9, true);
     float* dst;
     HIP_CHECK(hipMalloc(&dst, (size_t)blocks * threads * 4));
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
       auto run = [&] {
         if (mode == 0) mfma_peak_kernel<0><<<blocks, threads>>>(src, dst, iters);
         if (mode == 1) mfma_peak_kernel<1><<<blocks, threads>>>(src, dst, iters);
         if (mode == 2) mfma_peak_kernel<2><<<blocks, threads>>>(src, dst, iters);
+        if (mode == 3) mfma_peak_kernel<3><<<blocks, threads>>>(src, dst, iters);
       };
       std::vector<float> all;
       const double ms = time_ms(run, 3, 10, &all);
-      const double flops = (double)blocks * (threads / 64) * iters * (mode == 2 ? 8 : 16) * (mode == 2 ? 32.0 * 32 * 64 * 2 : 16.0 * 16 * 128 * 2);
+      const double flops = (double)blocks * (threads / 64) * iters * (mode == 2 ? 8 : 16) * (mode == 2 ? 32.0 * 32 * 64 * 2 : mode == 3 ? 16.0 * 16 * 32 * 2 : 16.0 * 16 * 128 * 2);
       printf("peak mode=%d threads=%d blocks=%d iters=%d: median %.4f ms min %.4f -> %.1f TFLOP/s\n", mode, threads, blocks,
              iters, ms, all[0], flops / ms / 1e9);
     }
