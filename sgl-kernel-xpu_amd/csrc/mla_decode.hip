@@ -569,8 +569,11 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
 // real MFMA instructions is done by hand: s_nop after the last MFMA of a phase before its results are read, operand
 // registers kept reserved past the issue of their last MFMA, zeros and addresses materialised before the first read.
 // Online softmax with a lazy reference maximum: O (in AGPRs: a rescale costs 3 VALU instructions per register) is
-// rescaled only when a head's tile maximum exceeds its reference by more than 2^8; P = 2^(s - ref) stays <= 256 and
-// the row sums add the ROUNDED weights, so numerator and denominator round alike.
+// rescaled only when a weight would pass 2^50 (bf16: the weights have fp32's exponent range and the reference is
+// set 2^50 above the tile maximum when it moves) or 2^8 (f16); the row sums add the ROUNDED weights, so numerator
+// and denominator round alike.
+// (The reference benchmark's q x 100 logits move a head's maximum by tens of binades at a time: with an exact
+// reference 76 of a split's 128 tiles would rescale, each costing about a tile's time.)
 constexpr int kThreads2 = 256;
 
 template <typename T>
@@ -742,6 +745,9 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
   // other wave to fill it). Iteration 0 accumulates P = 0 (O is zeroed after it), iteration n recomputes the last
   // tile's scores and discards them. Ring: tiles j-1, j resident, j+1 in flight, j+2 issued after the barrier.
   v8s pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+  constexpr bool kWide = std::is_same<T, bf16>::value;  // weights with fp32's exponent range
+  constexpr float kLazy = kWide ? 50.0f : 8.0f;
+  const float head_raw = (kWide && p.scale_log2 > 0.f) ? 50.0f / p.scale_log2 : 0.f;  // 2^50 in units of the raw logits
   for (int j = 0; j <= n_my; ++j) {
     const bool commit = j < n_my;
     const int jq = commit ? j : n_my - 1, jv = j > 0 ? j - 1 : 0;
@@ -853,8 +859,20 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
           asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
           mt[h] = fmaxf(c0, c1);
         } else if constexpr (k == 12) {
-          upd[h] = commit && (mt[h] - m_ref[h]) * p.scale_log2 > 8.0f;  // (first tile: ref = -inf; NaN keeps the ref)
-          mt[h] = upd[h] ? mt[h] : m_ref[h];
+          // bf16 has fp32's exponent range, so the reference need not be the maximum: when it moves it is set 2^50
+          // ABOVE the tile maximum (weights start at 2^-50: normal numbers with the same relative precision) and it
+          // moves again only when a weight would pass 2^50: a window of 100 binades per move. The rescale factor
+          // 2^-(move) flushes to zero below 2^-126, i.e. for moves past 126 binades: by then every old weight is
+          // below 2^-26 of the new largest one. (With 90 + 60 the flush dropped weights that mattered: caught by the
+          // parity tests.) O and the row sums are
+          // fp32: 2^60 x 1M keys x |V| stays far below 2^127. f16 weights must stay in [2^-14, 2^16): no headroom,
+          // threshold 2^8. (first tile: ref = -inf; a NaN difference keeps the ref)
+          // A rescale touches the whole row tile's registers whichever head asked for it, so when one head's
+          // reference has to move every head of the row tile takes fresh headroom with it (never downwards): the
+          // number of rescales per row tile is set by its fastest-growing head, not by the sum over its 16 heads.
+          upd[h] = __any(commit && (mt[h] - m_ref[h]) * p.scale_log2 > kLazy);
+          const float cand = mt[h] + head_raw;
+          mt[h] = (upd[h] && cand > m_ref[h]) ? cand : m_ref[h];
         } else if constexpr (k == 13) {
           alpha[h] = upd[h] ? __builtin_amdgcn_exp2f((m_ref[h] - mt[h]) * p.scale_log2) : 1.0f;
         } else if constexpr (k == 14) {
@@ -928,15 +946,22 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
       if (j == 0) {
         // O[row tile h][16-column tile nt] = a[(32 h + nt) 4 .. +3]: start from zero (iteration 0 added 0 . V)
         static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
-      } else if (__any(upd[0] || upd[1])) {
-        // rare: a reference moved, rescale O (AGPR -> VGPR -> AGPR) before the next tile's P . V is added
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const v4f a0 = {head_bcast(ln, alpha[0], 0), head_bcast(ln, alpha[0], 1), head_bcast(ln, alpha[0], 2), head_bcast(ln, alpha[0], 3)};
-        const v4f a1 = {head_bcast(ln, alpha[1], 0), head_bcast(ln, alpha[1], 1), head_bcast(ln, alpha[1], 2), head_bcast(ln, alpha[1], 3)};
-        static_for<0, 32>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a0); });
-        static_for<32, 64>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a1); });
-        asm volatile("s_nop 7");
+      } else {
+        // rare: a reference moved, rescale that row tile's O (AGPR -> VGPR -> AGPR) before the next tile's P . V
+        if (upd[0]) {
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          const v4f a0 = {head_bcast(ln, alpha[0], 0), head_bcast(ln, alpha[0], 1), head_bcast(ln, alpha[0], 2), head_bcast(ln, alpha[0], 3)};
+          static_for<0, 32>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a0); });
+          asm volatile("s_nop 7");
+        }
+        if (upd[1]) {
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          const v4f a1 = {head_bcast(ln, alpha[1], 0), head_bcast(ln, alpha[1], 1), head_bcast(ln, alpha[1], 2), head_bcast(ln, alpha[1], 3)};
+          static_for<32, 64>([&](auto ic) { agpr_scale4<decltype(ic)::value * 4>(a1); });
+          asm volatile("s_nop 7");
+        }
       }
       if (commit) {
 #pragma unroll

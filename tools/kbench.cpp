@@ -263,6 +263,17 @@ int main(int argc, char** argv) {
     }
     std::vector<uint16_t> hq((size_t)B * H * 576);
     { std::mt19937 rng(8); for (auto& x : hq) x = (uint16_t)(rng() & 0xBFFF); }
+    if (getenv("MLA_GAUSS")) {  // the reference benchmark's distribution: q = N(0,1) * MLA_GAUSS (100 there), cache = N(0,1)
+      const float qs = (float)atof(getenv("MLA_GAUSS"));
+      auto to_bf16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); };
+      std::mt19937 rng(11);
+      std::normal_distribution<float> nd(0.f, 1.f);
+      for (auto& x : hq) x = to_bf16(nd(rng) * qs);
+      const size_t n = (size_t)B * npages * page * 576;
+      std::vector<uint16_t> h(n);
+      for (auto& x : h) x = to_bf16(nd(rng));
+      HIP_CHECK(hipMemcpy(cache, h.data(), n * 2, hipMemcpyHostToDevice));
+    }
     void *qn, *qp, *out;
     HIP_CHECK(hipMalloc(&qn, B * H * 512 * 2));
     HIP_CHECK(hipMalloc(&qp, B * H * 64 * 2));
