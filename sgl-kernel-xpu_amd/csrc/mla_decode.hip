@@ -754,7 +754,6 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
     if (j + 1 < n_my) wait_vmcnt<9>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // tile j landed for every wave; every wave is done with tile j-2
     if (j + 2 < n_my) stage_tile(t_begin + j + 2, (j + 2) & 3, pgn0, pgn1);
-    load_pages(j + 3, pgn0, pgn1);
     if (work) {
       const uint32_t sbq = lds_base + (uint32_t)((jq & 3) * kStageBytes), sbv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
       const int t = t_begin + jq;
@@ -969,6 +968,9 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    // next tile's page ids: the scalar loads go out at the END of the iteration, so that they are not outstanding
+    // (on the same counter) while the hand-counted LDS waits of the phases above run
+    load_pages(j + 3, pgn0, pgn1);
   }
 
   // ---- epilogue: normalise by the row sums and write. O tile nt: lane holds dim 16 nt + l15, heads 4g + r
