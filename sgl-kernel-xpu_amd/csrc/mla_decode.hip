@@ -27,6 +27,8 @@
 //     32-lane half reads transposed are 8 rows apart.
 //   - split-KV: grid = (splits, batch); partial O (normalised, fp32) and log2-sum-exp go to the
 //     caller's workspace and a small second kernel merges them.
+//   - More than 64 heads, and every prefill: mla_rows128_kernel further down (4 waves x 512 registers, two row tiles
+//     per LDS fragment, O in fixed AGPRs); this kernel serves H <= 64 (and H > 64 through the W = 1 test hook).
 //   - Fewer than 128 heads (template W = waves per 16-head group = 8, 4, 2 for H <= 16, 32, 64): the W waves of
 //     a group share the work of every tile instead of idling. Each takes every W-th 32-deep k-step of QK^T and
 //     leaves its partial S^T in LDS; after a second barrier every wave of the group adds the W partials in a
