@@ -8,7 +8,8 @@ One "step" = one pass of the hot path over one synthetic batch already resident 
 quantise x[M,K] bf16 -> (e4m3, column-major 1x128 scales), then out = fp8_blockwise_scaled_mm(...)
 in bf16. value = whole-job GEMM TFLOP/s (2*M*N*K per step per GPU; the quant pass is inside the timed
 region). N > 1: the path does not shard (per-GPU leaf kernels, SURVEY.md section 8e: "replicas only"),
-so every rank runs an independent replica; rank 0 prints ONE JSON line.
+so every rank runs an independent replica; rank 0 prints ONE JSON line. Without a launcher (WORLD_SIZE unset)
+`--gpus N` starts the N rank processes itself; under torch.distributed.run it uses the launcher's ranks.
 
 roofline.achieved is measured live with HIP events recorded on the launch stream around each GEMM
 launch of the timed region. cpu_baseline times the CPU oracle (torch eager, all host cores) on a row
@@ -32,6 +33,9 @@ GROUP = 128
 FP8 = torch.float8_e4m3fn
 PEAK_FP8_TFLOPS = 5000.0  # MI355X_MICROARCH.md: dense FP8 MFMA peak (MX K=128 form), 2:1 sparsity excluded
 PEAK_HBM_GBS = 8000.0
+GEMM_KERNEL = ("gemm_fp8_blockwise_persist_kernel<bf16> (two launches: 256-row tiles, then 128-row half tiles of "
+               "the last partial round)")
+PMC_FILE = os.path.join("profiles", "r01", "bench_fp8_gemm_v3_pmc.json")
 
 
 def make_inputs(dev, seed):
@@ -50,7 +54,7 @@ def pmc_traffic_bytes():
     profiles/r01/bench_fp8_gemm_v3_pmc.json): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B
     requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section) and is doubled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "bench_fp8_gemm_v3_pmc.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             pmc = json.load(f)
         # one GEMM = one launch of each instantiation of the persistent kernel (whole tiles, then half tiles)
         ks = [v for name, v in pmc.items() if "gemm_fp8_blockwise_persist_kernel" in name]
@@ -215,29 +219,149 @@ def side_metrics(sgl_kernel, dev):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true")
-    args = ap.parse_args()
+def spawn_replicas(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and pass rank 0's
+    JSON line through. The parent never touches the GPU (no torch.cuda call), the children are ordinary
+    subprocesses (no exec from a process that has initialised the GPU)."""
+    import socket
+    import subprocess
 
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.exit("bench.py: rank(s) failed: %s" % bad)
+
+
+def init_ranks(args):
+    """(rank, local_rank, world, dist or None) from the launcher's environment; --gpus must agree with it."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}")
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.plumbing_only:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    return rank, local_rank, world, dist
+
+
+def timed_steps(step, steps, sync, dist, dev):
+    """EXACTLY `steps` steps between barrier + sync on both sides; returns the MAX elapsed seconds over ranks."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def mla_roofline(sgl_kernel, dev, heads=128):
+    """Second half of BASELINE's metric: flash_mla_decode at configs[3] (bs=128, seq=8192, kv_lora 512 + rope 64,
+    paged 64, bf16, q x 100 as the reference benchmark), HIP events on the launch stream around every call.
+    Bytes = reference formula benchmark/bench_flash_mla_decode.py:109-115 (q + cache + table + seq_lens + out)."""
+    bs, seq, page = 128, 8192, 64
+    n_pages = seq // page
+    g = torch.Generator(device=dev).manual_seed(0x561)
+    cache = torch.randn(bs * n_pages, page, 576, device=dev, dtype=torch.bfloat16, generator=g)
+    table = torch.randint(0, bs * n_pages, (bs, n_pages), device=dev, dtype=torch.int32, generator=g)
+    seq_lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+    qq = torch.randn(bs, heads, 576, device=dev, dtype=torch.bfloat16, generator=g) * 100
+    q_nope, q_pe = qq[..., :512], qq[..., 512:].contiguous()
+    ws = torch.empty(sgl_kernel.flash_mla_get_workspace_size(seq, bs, heads, page, -1), device=dev, dtype=torch.uint8)
+
+    def run():
+        return sgl_kernel.flash_mla_decode(q_nope, q_pe, cache, seq_lens, table, ws, 576 ** -0.5, -1)
+
+    for _ in range(30):
+        run()
+    iters = 50
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b_ in ev:
+        a.record()
+        run()
+        b_.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
+    avg = sum(ms) / len(ms)
+    nbytes = qq.numel() * 2 + cache.numel() * 2 + table.numel() * 4 + seq_lens.numel() * 4 + bs * heads * 512 * 2
+    return {
+        "bound": "hbm",
+        "kernel": "mla_rows128_kernel<bf16> (+ split merge)" if heads > 64 else "mla_decode_kernel<bf16> (+ split merge)",
+        "workload": f"flash_mla_decode bs={bs} seq={seq} heads={heads} kv_lora=512 rope=64 page={page} bf16",
+        "achieved": round(nbytes / avg / 1e6, 1),
+        "peak": PEAK_HBM_GBS,
+        "unit": "GB/s",
+        "frac": round(nbytes / avg / 1e6 / PEAK_HBM_GBS, 4),
+        "bytes": nbytes,
+        "traffic": None,
+        "kernel_ms_avg": round(avg, 4),
+        "kernel_ms_median": round(ms[len(ms) // 2], 4),
+        "tflops": round(2.0 * bs * heads * seq * (576 + 512) / avg / 1e9, 1),
+    }
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    # test hook (tests/test_bench_plumbing.py, CPU, gloo): rank / barrier / max-over-ranks / JSON plumbing with an
+    # empty step; measures nothing and says so in the line it prints
+    ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_replicas(args, argv)
+    rank, local_rank, world, dist = init_ranks(args)
+
+    if args.plumbing_only:
+        dev = torch.device("cpu")
+        elapsed = timed_steps(lambda i: None, args.steps, lambda: None, dist, dev)
+        if rank == 0:
+            print(json.dumps({"metric": "plumbing-only (no kernels ran)", "value": None, "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "elapsed_max_s": elapsed}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
     import sgl_kernel
 
@@ -253,29 +377,15 @@ def main():
         quant()
         gemm()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
+
+    def step(i):
         quant()
         ev[i][0].record()  # current stream == the stream the ops launch on
         gemm()
         ev[i][1].record()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = timed_steps(step, args.steps, torch.cuda.synchronize, dist, dev)
     gemm_ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
     gemm_avg_ms = sum(gemm_ms) / len(gemm_ms)
 
@@ -304,7 +414,7 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "gemm_fp8_blockwise_persist_kernel<bf16> (two launches: 256-row tiles, then 128-row half tiles of the last partial round)",
+            "kernel": GEMM_KERNEL,
             "achieved": round(achieved, 2),
             "peak": PEAK_FP8_TFLOPS,
             "unit": "TFLOP/s",
@@ -315,6 +425,10 @@ def main():
         },
     }
     if rank == 0:
+        if world == 1:
+            del x, b, sb, q, s
+            # the "GB/s (flash decode)" half of the metric: its own roofline entry, measured in the same run
+            result["roofline_flash_decode"] = mla_roofline(sgl_kernel, dev)
         if world == 1 and not args.no_extra:
             result["extra"] = side_metrics(sgl_kernel, dev)
         if world == 1 and not args.no_cpu_baseline:

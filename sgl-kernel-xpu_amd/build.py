@@ -9,7 +9,18 @@ Replaces the reference's cmake/SYCL.cmake + src/BuildOnLinux.cmake (icpx, one
 
 Both outputs are in-tree (git-ignored) so that they travel to the GPU box.
 Incremental: a source is recompiled when it, a header or this script is newer
-than its object. Usage: python build.py [--jobs N] [--force] [--no-torch]
+than its object.
+
+After compiling, the ISA of the kernels that manage registers or wait counters by hand
+(mla_decode.hip, gemm_8bit.hip) is checked (check_isa below): a compiler that spills or parks
+values in the accumulator registers those kernels own would give silently wrong results, so a
+failed check fails the build. Validated with ROCm 7.2.0 (AMD clang 20, /opt/rocm/bin/hipcc).
+
+--probes additionally builds the DIAGNOSTIC library build/libsglk_probes.so (-DSGLK_PROBES: main-loop
+variants and timing probes with garbage results behind sglk_debug_* switches) and tools/kbench against
+it. The release libsglk.so contains neither the switches nor the probe code.
+
+Usage: python build.py [--jobs N] [--force] [--no-torch] [--probes] [--check]
 """
 import argparse
 import concurrent.futures as cf
@@ -31,7 +42,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function",
-    "-Wno-implicit-fallthrough", "-Wno-unused-variable",
+    "-Wno-implicit-fallthrough", "-Wno-unused-variable", "-Wno-shift-negative-value",
+    "-Wno-unused-local-typedef",
 ]
 
 
@@ -50,37 +62,171 @@ def run(cmd):
     return time.time() - t0, p.stdout
 
 
-def build(jobs=None, force=False, with_torch=True, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
-    headers.append(os.path.abspath(__file__))
-    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
-    jobs = jobs or min(8, os.cpu_count() or 1)
+# sources whose device assembly is kept next to the object (-save-temps=obj) for check_isa
+ISA_CHECKED = ("mla_decode.hip", "gemm_8bit.hip")
 
-    todo = []
-    objs = []
+
+def _asm_path(src_name, obj_dir=None):
+    return os.path.join(obj_dir or OBJ, src_name[:-4] + "-hip-amdgcn-amd-amdhsa-%s.s" % ARCH)
+
+
+def _functions(asm_text, pattern):
+    """yield (mangled name, body lines) of every function whose label matches pattern"""
+    import re
+    lines = asm_text.splitlines()
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(_Z\w+):", lines[i])
+        if m and re.search(pattern, m.group(1)):
+            j = i
+            while j < len(lines) and "s_endpgm" not in lines[j]:
+                j += 1
+            yield m.group(1), lines[i:j + 1]
+            i = j
+        i += 1
+
+
+def check_isa(verbose=True):
+    """Guards for hand-managed registers, run on the assembly the build just produced.
+
+    * mla_rows128_kernel keeps O in the fixed registers a0..a255 named only in inline asm: the compiler must not
+      touch the AGPR file itself in that kernel (no AGPR operand outside ;;#ASMSTART..;;#ASMEND), must not spill,
+      and the kernel descriptor must allocate 256 AGPRs.
+    * gemm_fp8_blockwise_persist_kernel counts its LDS waits by hand: a VGPR spill (scratch access = vector-memory
+      traffic inside the counted vmcnt window) breaks the counts.
+    Returns the list of problems (empty = good)."""
+    import re
+    problems = []
+    agpr = re.compile(r"(?<![\w.])a(\d+|\[\d+:\d+\])(?![\w])|accvgpr")
+    path = _asm_path("mla_decode.hip")
+    if not os.path.exists(path):
+        return ["%s missing (build with this script first)" % path]
+    text = open(path).read()
+    found = 0
+    for name, body in _functions(text, r"mla_rows128_kernelI"):
+        found += 1
+        in_asm = False
+        for ln in body:
+            if "#ASMSTART" in ln:
+                in_asm = True
+                continue
+            if "#ASMEND" in ln:
+                in_asm = False
+                continue
+            code = ln.split(";")[0]
+            if not code.strip() or code.lstrip().startswith("."):
+                continue
+            if not in_asm and agpr.search(code):
+                problems.append("%s: compiler-generated AGPR use: %s" % (name, code.strip()))
+            if "scratch_" in code:
+                problems.append("%s: spill: %s" % (name, code.strip()))
+        meta = re.search(r"\.amdhsa_kernel %s\b(.*?)\.end_amdhsa_kernel" % re.escape(name), text, re.S)
+        if meta:
+            nv = re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta.group(1))
+            ao = re.search(r"\.amdhsa_accum_offset (\d+)", meta.group(1))
+            if not (nv and ao and int(nv.group(1)) - int(ao.group(1)) >= 256):
+                problems.append("%s: fewer than 256 AGPRs allocated (next_free_vgpr %s, accum_offset %s)"
+                                % (name, nv and nv.group(1), ao and ao.group(1)))
+        else:
+            problems.append("%s: no kernel descriptor found" % name)
+    if found == 0:
+        problems.append("no mla_rows128_kernel instantiation found")
+    path = _asm_path("gemm_8bit.hip")
+    if not os.path.exists(path):
+        problems.append("%s missing" % path)
+    else:
+        text = open(path).read()
+        n = 0
+        for name, body in _functions(text, r"gemm_fp8_blockwise_persist_kernelI"):
+            n += 1
+            for ln in body:
+                code = ln.split(";")[0]
+                if "scratch_" in code:
+                    problems.append("%s: spill: %s" % (name, code.strip()))
+                    break
+        found += n
+        if n == 0:
+            problems.append("no gemm_fp8_blockwise_persist_kernel instantiation found")
+    if verbose:
+        print("[build] check_isa: %d kernels checked, %d problems" % (found, len(problems)), flush=True)
+        for pr in problems[:20]:
+            print("  " + pr)
+    return problems
+
+
+def _compile_all(obj_dir, extra_flags, jobs, force, verbose, headers):
+    os.makedirs(obj_dir, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    todo, objs = [], []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s[:-4] + ".o")
+        obj = os.path.join(obj_dir, s[:-4] + ".o")
         objs.append(obj)
-        if force or newer(obj, [src] + headers):
-            todo.append((src, obj))
+        if force or newer(obj, [src] + headers) or (s in ISA_CHECKED and not os.path.exists(_asm_path(s, obj_dir))):
+            todo.append((s, src, obj))
     if todo:
         with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-            futs = {ex.submit(run, [HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj]): src for src, obj in todo}
+            futs = {}
+            for s, src, obj in todo:
+                flags = HIP_FLAGS + extra_flags + (["-save-temps=obj"] if s in ISA_CHECKED else [])
+                futs[ex.submit(run, [HIPCC] + flags + ["-c", src, "-o", obj])] = src
             for f in cf.as_completed(futs):
                 dt, out = f.result()
                 if verbose:
                     print("[build] hipcc %-32s %5.1fs" % (os.path.basename(futs[f]), dt), flush=True)
                     if out.strip():
                         print(out)
+        # -save-temps=obj leaves large intermediates next to the objects: keep only the device assembly
+        for f in os.listdir(obj_dir):
+            if f.endswith((".bc", ".hipi", ".out", ".resolution.txt", ".hipfb")) or (f.endswith(".s") and "-host-" in f) or \
+               (f.endswith(".o") and "-hip-amdgcn" in f) or (f.endswith(".o") and "-host-" in f):
+                os.remove(os.path.join(obj_dir, f))
+    return objs, bool(todo)
+
+
+def build_probes(jobs=None, force=False, verbose=True):
+    """Diagnostic library + kbench (not shipped, not loaded by the Python package)."""
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    headers.append(os.path.abspath(__file__))
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    bdir = os.path.join(HERE, "build")
+    objs, changed = _compile_all(os.path.join(bdir, "obj_probes"), ["-DSGLK_PROBES"], jobs, force, verbose, headers)
+    lib = os.path.join(bdir, "libsglk_probes.so")
+    if force or changed or newer(lib, objs):
+        run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs)
+    kb_src = os.path.join(ROOT, "tools", "kbench.cpp")
+    kb = os.path.join(bdir, "kbench")
+    if force or newer(kb, [kb_src, lib]):
+        dt, out = run([HIPCC, f"--offload-arch={ARCH}", "-O2", "-std=c++17", kb_src, f"-I{INCLUDE}", f"-L{bdir}",
+                       "-lsglk_probes", "-Wl,-rpath,$ORIGIN", "-o", kb])
+        if verbose:
+            print("[build] kbench %5.1fs" % dt, flush=True)
+    return lib
+
+
+def build(jobs=None, force=False, with_torch=True, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    headers.append(os.path.abspath(__file__))
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    # objects of sources that no longer exist must not ship to the GPU box
+    live = {f[:-4] + ".o" for f in os.listdir(CSRC) if f.endswith(".hip")}
+    for f in os.listdir(OBJ):
+        if f.endswith(".o") and f not in live:
+            os.remove(os.path.join(OBJ, f))
+    objs, todo = _compile_all(OBJ, [], jobs, force, verbose, headers)
 
     lib = os.path.join(PKG, "libsglk.so")
     if force or todo or newer(lib, objs):
         dt, out = run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs)
         if verbose:
             print("[build] link  %-32s %5.1fs" % ("libsglk.so", dt), flush=True)
+    problems = check_isa(verbose)
+    if problems:
+        raise RuntimeError("ISA check failed (hand-managed registers are not safe with this compiler output):\n  "
+                           + "\n  ".join(problems))
 
     if with_torch:
         import torch  # noqa: F401  (paths only; no GPU needed)
@@ -115,6 +261,12 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--no-torch", action="store_true")
+    ap.add_argument("--probes", action="store_true", help="also build build/libsglk_probes.so and build/kbench")
+    ap.add_argument("--check", action="store_true", help="only run the ISA check on the last build's assembly")
     a = ap.parse_args()
+    if a.check:
+        sys.exit(1 if check_isa() else 0)
     build(a.jobs, a.force, not a.no_torch)
+    if a.probes:
+        build_probes(a.jobs, a.force)
     print("[build] ok")

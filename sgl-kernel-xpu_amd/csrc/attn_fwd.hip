@@ -516,12 +516,9 @@ static int launch(hipStream_t st, const AttnParams& p, const void* q, const void
                   const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
   constexpr int NB = (DKP * 2 + 255) / 256;
   constexpr int lds = (DKP > 256 ? 2 : 3) * 2 * NB * kTile * 256;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DKP, KV8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return fail(SGLK_ELAUNCH, "fwd: cannot reserve %d B of LDS: %s", lds, hipGetErrorString(e));
-    attr_set = true;
+  static unsigned long long attr_done = 0;
+  if (lds > 64 * 1024) {
+    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_fwd_kernel<T, DKP, KV8>), lds, &attr_done, "fwd")) return rc;
   }
   dim3 grid((unsigned)cdiv(max_rows, kBlockM), (unsigned)(p.Hk * p.splits), (unsigned)batch);
   attn_fwd_kernel<T, DKP, KV8><<<grid, 256, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);

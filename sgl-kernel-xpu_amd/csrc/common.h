@@ -17,6 +17,9 @@ constexpr int kWave = 64;
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int check_launch(const char* what);
 int num_cus();
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function object of the CURRENT device: set it once per
+// device (bit d of *done_mask = done on device d; devices >= 64 set it on every launch). Thread-safe.
+int set_max_dyn_lds(const void* fn, int bytes, unsigned long long* done_mask, const char* what);
 
 #define SGLK_REQUIRE(cond, ...)                          \
   do {                                                   \

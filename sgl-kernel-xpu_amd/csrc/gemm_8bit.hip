@@ -430,14 +430,18 @@ template <typename OutT, bool HW_SCALE, int PROBE, int MS>  // MS m-steps per K 
 __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
-    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves) {
+    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves,
+    uint32_t* __restrict__ stamps) {
   __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nkb = K / BK;  // >= 2
-  constexpr bool kDma = PROBE == 0 || PROBE == 3 || PROBE == 4, kStore = PROBE == 0 || PROBE == 1;
+  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || PROBE == 5;
+  // PROBE 5 (diagnostic build only): three s_memtime stamps per K block (compute done / own DMA landed / barrier
+  // released) for K blocks 40..60 of the workgroup, kept in the lanes of one VGPR and written out at the end
+  uint32_t stampv = 0;
 
   // ---- this workgroup's tiles: workgroups b, b+8, ... share an XCD; each XCD owns a contiguous run of tiles,
   // walked in groups of 4 m-tiles so that the 32 tiles in flight on an XCD share a and b panels in its L2
@@ -648,10 +652,23 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     }                                                                                                          \
     /* the block's barrier: next block landed everywhere, nobody reads stage s any more */                    \
     float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                  \
-                 : "+v"(mlo[1]), "+v"(mhi[1]), "+v"(raw[1])                                                    \
-                 :                                                                                             \
-                 : "memory");                                                                                  \
+    if constexpr (PROBE == 5) {                                                                                \
+      const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memtime();                                              \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(mlo[1]), "+v"(mhi[1]), "+v"(raw[1]) : : "memory");   \
+      const uint32_t t1 = (uint32_t)__builtin_amdgcn_s_memtime();                                              \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                          \
+      const uint32_t t2 = (uint32_t)__builtin_amdgcn_s_memtime();                                              \
+      const int w_ = gblk - 40;                                                                                \
+      const int sl_ = (w_ >= 0 && w_ < 20) ? w_ * 3 : 61;                                                      \
+      stampv = (lane == sl_) ? t0 : stampv;                                                    \
+      stampv = (lane == sl_ + 1) ? t1 : stampv;                                                \
+      stampv = (lane == sl_ + 2) ? t2 : stampv;                                                \
+    } else {                                                                                                   \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                \
+                   : "+v"(mlo[1]), "+v"(mhi[1]), "+v"(raw[1])                                                  \
+                   :                                                                                           \
+                   : "memory");                                                                                \
+    }                                                                                                          \
     asm volatile("" : "+v"(sbv_next));                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     /* last m-step, overlapped with the next block's first LDS reads */                                       \
@@ -732,6 +749,9 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int mf = 0; mf < MS; ++mf) store_rows(prv, acc[mf], mf);
+  if constexpr (PROBE == 5) {
+    if (stamps != nullptr) stamps[((int64_t)blockIdx.x * 8 + wave) * 64 + lane] = stampv;
+  }
 #undef SGLK_RD16
 #undef SGLK_RD4
 #undef SGLK_FRAG
@@ -898,7 +918,21 @@ __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
   }
 }
 
-static int g_gemm_variant = 4;  // 4 = pipelined kernel (default); 0, 1 = earlier main loops; 8, 9, 14 = timing probes
+// Main-loop variant: 4 = the pipelined persistent kernel. Everything else exists only in the diagnostic build
+// (-DSGLK_PROBES: build.py --probes -> libsglk_probes.so, used by tools/kbench): 0, 1 = earlier main loops; 8, 9,
+// 14..18 = timing probes whose RESULTS ARE GARBAGE by design. The release library has no switch and no probe code.
+#ifdef SGLK_PROBES
+#define SGLK_HW(hw, T, F) if (hw) { T; } else { F; }
+#else
+#define SGLK_HW(hw, T, F) { T; }
+#endif
+#ifdef SGLK_PROBES
+static int g_gemm_variant = 4;
+static uint32_t* g_gemm_stamps = nullptr;
+#else
+constexpr int g_gemm_variant = 4;
+constexpr uint32_t* g_gemm_stamps = nullptr;
+#endif
 
 template <typename OutT, int MODE>
 static int launch(hipStream_t st, void* out, const void* a, const void* b, const float* sa, const float* sb,
@@ -909,7 +943,9 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   const bool vec = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)out % 8 == 0);
   // persistent kernel: one workgroup per CU, a multiple of 8 so that every XCD gets the same number
   const unsigned pgrid = grid < (unsigned)num_cus() ? ((grid + 7) / 8) * 8 : (unsigned)num_cus();
-  const bool persist_ok = K / BK >= 2 && N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)out % 16 == 0 && ldc < (1ll << 22);
+  // (the row-scale DMA addresses its K blocks and rows with 32-bit byte offsets inside one buffer resource)
+  const bool persist_ok = K / BK >= 2 && N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)out % 16 == 0 && ldc < (1ll << 22) &&
+                          ((K / BK - 1) * sa_sk + 256 * sa_sm) * 4 < (1ll << 31);
   // does any XCD cut its last partial round into half tiles (same rule as in the kernel)?
   bool tail_halves = false;
   {
@@ -925,14 +961,13 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
 #define SGLK_GO_SKINNY(MF, KS)                                                                               \
   {                                                                                                          \
     const dim3 sg((unsigned)cdiv(N, 16 * (4 / KS)), (unsigned)cdiv(M, 16 * MF));                             \
-    if (hw_scale)                                                                                            \
-      gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, true><<<sg, 256, 0, st>>>(                                 \
+    SGLK_HW(hw_scale,                                                                                        \
+      (gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, true><<<sg, 256, 0, st>>>(                                \
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
-          lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn);                                                        \
-    else                                                                                                     \
-      gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, false><<<sg, 256, 0, st>>>(                                \
+          lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn)),                                                       \
+      (gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, false><<<sg, 256, 0, st>>>(                               \
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
-          lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn);                                                        \
+          lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn)))                                                       \
   }
       // (splitting K over 2 / 4 waves of a workgroup - template KS - measured slower: 18 -> 22 us at M = 1, N = 14336)
       if (M <= 16) SGLK_GO_SKINNY(1, 1)
@@ -954,16 +989,17 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   if (all_halves) {                                                                                          \
     gemm_fp8_blockwise_persist_kernel<OutT, H, P, 4><<<hgrid, 512, 0, st>>>(                                 \
         (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,     \
-        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1);                                                    \
+        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_gemm_stamps);                                     \
   } else {                                                                                                   \
     gemm_fp8_blockwise_persist_kernel<OutT, H, P, 8><<<pgrid, 512, 0, st>>>(                                 \
         (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,     \
-        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0);                                                    \
+        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps);                                     \
     if (tail_halves)                                                                                         \
       gemm_fp8_blockwise_persist_kernel<OutT, H, P, 4><<<pgrid, 512, 0, st>>>(                               \
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,   \
-          sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0);                                                  \
+          sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps);                                   \
   }
+#ifdef SGLK_PROBES
 #define SGLK_GO(V, H)                                                                                        \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
     switch (variant) {                                                                                       \
@@ -975,15 +1011,24 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 15: SGLK_GO_PIPE(V, H, 2); break;                                                                 \
       case 16: SGLK_GO_PIPE(V, H, 3); break;                                                                 \
       case 17: SGLK_GO_PIPE(V, H, 4); break;                                                                 \
+      case 18: SGLK_GO_PIPE(V, H, 5); break;                                                                 \
       default: SGLK_GO_PIPE(V, H, 0); break;                                                                 \
     }                                                                                                        \
   } else {                                                                                                   \
     SGLK_GO_VAR(V, H, 0);                                                                                    \
   }
+#else
+#define SGLK_GO(V, H)                                                                                        \
+  if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
+    if (variant == 1) { SGLK_GO_VAR(V, H, 1); } else { SGLK_GO_PIPE(V, H, 0) }                               \
+  } else {                                                                                                   \
+    SGLK_GO_VAR(V, H, 0);                                                                                    \
+  }
+#endif
   if (vec) {
-    if (hw_scale) { SGLK_GO(true, true) } else { SGLK_GO(true, false) }
+    SGLK_HW(hw_scale, SGLK_GO(true, true), SGLK_GO(true, false))
   } else {
-    if (hw_scale) { SGLK_GO(false, true) } else { SGLK_GO(false, false) }
+    SGLK_HW(hw_scale, SGLK_GO(false, true), SGLK_GO(false, false))
   }
 #undef SGLK_GO
 #undef SGLK_GO_VAR
@@ -1007,12 +1052,16 @@ static int check_common(const char* op, const void* a, const void* b, int64_t M,
 }  // namespace
 }  // namespace sglk
 
-// Test hook: 0 selects the plain (non-MX) encoding of the K=128 fp8 MFMA, 1 (default) the MX
-// encoding with unit scales. Both must give identical results.
+// The K=128 fp8 MFMA is issued in its MX encoding with unit E8M0 scales (twice the rate of the plain encoding, the
+// same results: tests/test_gemm_gpu.py compares the two through the diagnostic build's hook).
+#ifdef SGLK_PROBES
 static int g_fp8_hw_scale = 1;
 extern "C" SGLK_API void sglk_debug_set_fp8_mfma_form(int hw_scale) { g_fp8_hw_scale = hw_scale; }
-// Test / tuning hook: main-loop variant of the blockwise kernel (0 = first version, 1 = default).
 extern "C" SGLK_API void sglk_debug_set_gemm_variant(int v) { sglk::g_gemm_variant = v; }
+extern "C" SGLK_API void sglk_debug_set_gemm_stamps(uint32_t* p) { sglk::g_gemm_stamps = p; }
+#else
+constexpr int g_fp8_hw_scale = 1;
+#endif
 
 extern "C" int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const void* a, const void* b,
                                             const float* sa, const float* sb, int64_t M, int64_t N,

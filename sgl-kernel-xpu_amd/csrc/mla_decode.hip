@@ -1077,15 +1077,10 @@ template <typename T, int W>
 static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe, const void* cache,
                     const int32_t* seq_lens, const int32_t* page_table, const int32_t* cu_seqlens_q = nullptr,
                     int token_blocks = 1) {
-  static bool attr_set = false;
+  static unsigned long long attr_done = 0;
   constexpr int lds = Cfg<W>::kLdsBytes;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_decode_kernel<T, W>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return fail(SGLK_ELAUNCH, "flash_mla_decode: cannot reserve %d B of LDS: %s", lds,
-                                     hipGetErrorString(e));
-    attr_set = true;
-  }
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_decode_kernel<T, W>), lds, &attr_done, "flash_mla_decode"))
+    return rc;
   mla_decode_kernel<T, W><<<dim3(p.splits, B, token_blocks), kThreads, lds, st>>>(
       p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
   return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
@@ -1095,23 +1090,25 @@ template <typename T>
 static int launch_rows128(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
                           const void* cache, const int32_t* seq_lens, const int32_t* page_table,
                           const int32_t* cu_seqlens_q = nullptr, int token_blocks = 1) {
-  static bool attr_set = false;
+  static unsigned long long attr_done = 0;
   constexpr int lds = 4 * kStageBytes;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mla_rows128_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return fail(SGLK_ELAUNCH, "flash_mla_decode: cannot reserve %d B of LDS: %s", lds,
-                                     hipGetErrorString(e));
-    attr_set = true;
-  }
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128_kernel<T>), lds, &attr_done, "flash_mla_decode"))
+    return rc;
   mla_rows128_kernel<T><<<dim3(p.splits, B, token_blocks), kThreads2, lds, st>>>(
       p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
   return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
 }
 
-// Test / tuning hook: force the number of waves per 16-head group (0 = automatic; 9 = never the rows128 kernel).
+// Diagnostic build only (-DSGLK_PROBES, tools/kbench): force the number of waves per 16-head group (0 = automatic;
+// 9 = never the rows128 kernel) and the streaming-only timing probe (garbage results). The release library has
+// neither switch.
+#ifdef SGLK_PROBES
 static int g_mla_waves_per_group = 0;
 static int g_mla_probe = 0;
+#else
+constexpr int g_mla_waves_per_group = 0;
+constexpr int g_mla_probe = 0;
+#endif
 
 template <typename T>
 static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe, const void* cache,
@@ -1140,8 +1137,10 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
 }  // namespace
 }  // namespace sglk
 
+#ifdef SGLK_PROBES
 extern "C" SGLK_API void sglk_debug_set_mla_waves_per_group(int w) { sglk::g_mla_waves_per_group = w; }
 extern "C" SGLK_API void sglk_debug_set_mla_probe(int v) { sglk::g_mla_probe = v; }
+#endif
 
 // Number of KV splits used when the caller passes num_kv_splits < 1: about one workgroup per CU, and at
 // least 4 tiles (128 tokens) of work per split. (The reference's set_split_kv, mla_decode.cpp:60-93, is tuned

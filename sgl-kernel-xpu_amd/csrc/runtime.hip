@@ -35,6 +35,17 @@ int num_cus() {
   return cached[dev];
 }
 
+int set_max_dyn_lds(const void* fn, int bytes, unsigned long long* done_mask, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && ((__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return SGLK_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return fail(SGLK_ELAUNCH, "%s: cannot reserve %d B of LDS: %s", what, bytes, hipGetErrorString(e));
+  if (tracked) __atomic_fetch_or(done_mask, 1ull << dev, __ATOMIC_RELEASE);
+  return SGLK_OK;
+}
+
 }  // namespace sglk
 
 extern "C" {

@@ -53,3 +53,10 @@ def test_code_objects_are_gfx950_only():
     data = open(LIB, "rb").read()
     archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", data))
     assert archs == {b"gfx950"}, archs
+
+
+def test_release_library_has_no_debug_switches():
+    # main-loop variants and garbage-result timing probes live only in the diagnostic build (build.py --probes ->
+    # build/libsglk_probes.so); a serving process must not be one dlsym away from wrong answers
+    data = open(LIB, "rb").read()
+    assert b"sglk_debug_" not in data, "the release libsglk.so exports sglk_debug_* switches"

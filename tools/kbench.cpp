@@ -1,6 +1,8 @@
-// Standalone (torch-free) timing harness for the C-ABI kernels: build with
-//   hipcc -O2 -std=c++17 tools/kbench.cpp -Iinclude -Lsgl-kernel-xpu_amd/python/sgl_kernel -lsglk -Wl,-rpath,... -o build/kbench
-// usage: kbench gemm M N K [variants...]   |   kbench mla B S H
+// Standalone (torch-free) timing harness for the C-ABI kernels, linked against the DIAGNOSTIC library
+// (build/libsglk_probes.so, -DSGLK_PROBES: main-loop variants and garbage-result timing probes behind sglk_debug_*):
+//   python sgl-kernel-xpu_amd/build.py --probes   ->  sgl-kernel-xpu_amd/build/kbench
+// usage: kbench gemm M N K [variants...] | kbench stamps M N K | kbench scaledmm M N K | kbench mla B S H [splits...]
+//        kbench peak THREADS BLOCKS ITERS | kbench oob
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -15,6 +17,7 @@
 extern "C" void sglk_debug_set_gemm_variant(int);
 extern "C" void sglk_debug_set_mla_waves_per_group(int);
 extern "C" void sglk_debug_set_mla_probe(int);
+extern "C" void sglk_debug_set_gemm_stamps(uint32_t*);
 
 #define HIP_CHECK(x)                                                                 \
   do {                                                                               \
@@ -225,6 +228,53 @@ int main(int argc, char** argv) {
       printf("gemm M=%lld N=%lld K=%lld variant=%d median %.4f ms  min %.4f  -> %.1f TFLOP/s (%.1f at min)\n", (long long)M,
              (long long)N, (long long)K, var, ms, all[0], 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / all[0] / 1e9);
       if (ai >= argc) break;
+    }
+    return 0;
+  }
+  if (!strcmp(argv[1], "stamps")) {
+    // in-kernel timeline of the persistent blockwise kernel (variant 18): per wave and K block the s_memtime
+    // stamps t0 = compute of the block done, t1 = own LDS-DMA landed + LDS reads returned, t2 = barrier released
+    const int64_t M = atoll(argv[2]), N = atoll(argv[3]), K = atoll(argv[4]);
+    void* a = dev_random_bytes(M * K, 1, true);
+    void* b = dev_random_bytes(N * K, 2, true);
+    float* sa = dev_random_floats(M * (K / 128), 3, 1e-4f, 1e-3f);
+    float* sb = dev_random_floats((K / 128) * ((N + 127) / 128), 4, 1e-4f, 1e-3f);
+    void* out;
+    HIP_CHECK(hipMalloc(&out, M * N * 2));
+    const int nwg = 256, nw = nwg * 8;
+    uint32_t* st;
+    HIP_CHECK(hipMalloc(&st, (size_t)nw * 64 * 4));
+    HIP_CHECK(hipMemset(st, 0, (size_t)nw * 64 * 4));
+    sglk_debug_set_gemm_variant(18);
+    sglk_debug_set_gemm_stamps(st);
+    for (int i = 0; i < 300; ++i)
+      sglk_fp8_blockwise_scaled_mm(0, out, a, b, sa, sb, M, N, K, K, K, N, 1, M, 1, K / 128, SGLK_BF16);
+    HIP_CHECK(hipDeviceSynchronize());
+    std::vector<uint32_t> h((size_t)nw * 64);
+    HIP_CHECK(hipMemcpy(h.data(), st, h.size() * 4, hipMemcpyDeviceToHost));
+    // s_memtime counts shader cycles (MI355X_MICROARCH.md, cycle constants)
+    double sum_c = 0, sum_d = 0, sum_b = 0; long n = 0;
+    for (int w = 0; w < nw; ++w) {
+      const uint32_t* s = &h[(size_t)w * 64];
+      if (s[0] == 0 && s[1] == 0) continue;
+      for (int k = 1; k < 20; ++k) {
+        sum_c += (double)(uint32_t)(s[3 * k] - s[3 * (k - 1) + 2]);
+        sum_d += (double)(uint32_t)(s[3 * k + 1] - s[3 * k]);
+        sum_b += (double)(uint32_t)(s[3 * k + 2] - s[3 * k + 1]);
+        ++n;
+      }
+    }
+    printf("stamps over %ld (wave, K block) samples, shader cycles: compute %.1f  own-wait %.1f  barrier %.1f  (block total %.1f)\n",
+           n, sum_c / n, sum_d / n, sum_b / n, (sum_c + sum_d + sum_b) / n);
+    for (int wg : {0, 1, 100}) {
+      for (int w = 0; w < 8; ++w) {
+        const uint32_t* s = &h[((size_t)wg * 8 + w) * 64];
+        printf("wg %3d wave %d:", wg, w);
+        for (int k = 1; k < 9; ++k)
+          printf(" [c%u w%u b%u]", (uint32_t)(s[3 * k] - s[3 * (k - 1) + 2]), (uint32_t)(s[3 * k + 1] - s[3 * k]),
+                 (uint32_t)(s[3 * k + 2] - s[3 * k + 1]));
+        printf("\n");
+      }
     }
     return 0;
   }
