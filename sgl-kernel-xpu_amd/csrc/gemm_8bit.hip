@@ -750,7 +750,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
 #pragma unroll
   for (int mf = 0; mf < MS; ++mf) store_rows(prv, acc[mf], mf);
   if constexpr (PROBE == 5) {
-    if (stamps != nullptr) stamps[((int64_t)blockIdx.x * 8 + wave) * 64 + lane] = stampv;
+    if (stamps != nullptr && gblk >= 60) stamps[((int64_t)blockIdx.x * 8 + wave) * 64 + lane] = stampv;  // (window complete)
   }
 #undef SGLK_RD16
 #undef SGLK_RD4

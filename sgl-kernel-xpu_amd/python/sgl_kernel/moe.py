@@ -1,305 +1,267 @@
-"""MoE wrappers and the fused_experts orchestration for the W4A16 (int4) path.
+"""Mixture-of-experts host layer: thin op wrappers and the `fused_experts` routed-expert MLP.
 
-Mirrors reference python/sgl_kernel/moe.py: moe_align_block_size :48-67, topk_softmax :70-78,
-prepare_moe_input :278-301, apply_shuffle_mul_sum :304-318, scatter_tokens_to_experts :321-322,
-the grow-only workspace cache :372-400 and fused_experts :403-870 (same arguments, asserts and op
-sequence: prepare_moe_input -> scatter_tokens_to_experts -> grouped GEMM1 -> activation ->
-grouped GEMM2 -> apply_shuffle_mul_sum). Built for gfx950: the 4-bit int4 path named by the
-north star; the mxfp4 format and the bf16-weight grouped GEMM (`moe_grouped_mm_nt_xe20`) are
-outside this build and raise NotImplementedError.
+Contract (reference python/sgl_kernel/moe.py): public names and parameters of `moe_align_block_size` (:48-67),
+`topk_softmax` (:70-78), `prepare_moe_input` (:278-301), `apply_shuffle_mul_sum` (:304-318),
+`scatter_tokens_to_experts` (:321-322) and `fused_experts` (:403-432); the op sequence
+prepare_moe_input -> scatter_tokens_to_experts -> grouped GEMM 1 -> gate/up activation -> grouped GEMM 2 ->
+apply_shuffle_mul_sum (:655-868); the grow-only scratch buffers keyed by (name, device) with 10 % headroom
+(:372-400); gate/up detection from the UNPACKED inner size of w2 (:723); bf16 biases up-cast to fp32 (:574-587);
+`rows_per_expert` (the tensor the reference calls expert_offsets) holds COUNTS.
+
+This build's own structure: one `_Plan` derives every size and route from the arguments, `_Scratch` owns the
+buffers, the activation routes are a table. 4-bit weights (int4 / mxfp4 W4A16) take GEMM -> activation kernel ->
+GEMM; 16-bit weights take the grouped GEMM's fused gate/up epilogue when the activation has one.
 """
+from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
 import torch
 
 from .utils import is_xe2_arch
 
-
-def _apply_per_expert_channel_gather(
-    x: torch.Tensor,
-    perm: torch.Tensor,
-    rows_per_expert: torch.Tensor,
-    num_experts: int,
-) -> torch.Tensor:
-    """GPTQ desc_act/g_idx support (reference moe.py:18-45): out[:, c'] = x[:, perm[e, c']] for the
-    row block of expert e; rows_per_expert holds counts, rows are already grouped by expert."""
-    expert_ids = torch.repeat_interleave(
-        torch.arange(num_experts, device=x.device),
-        rows_per_expert.to(torch.int64),
-        output_size=x.size(0),
-    )
-    return x.gather(1, perm.index_select(0, expert_ids))
+_ops = torch.ops.sgl_kernel  # (patched by the host-logic tests)
 
 
-def moe_align_block_size(
-    topk_ids,
-    num_experts,
-    block_size,
-    sorted_token_ids,
-    experts_ids,
-    num_tokens_post_pad,
-    cumsum_buffer,
-    pad_sorted_token_ids=False,
-):
-    torch.ops.sgl_kernel.moe_align_block_size.default(
-        topk_ids,
-        num_experts,
-        block_size,
-        sorted_token_ids,
-        experts_ids,
-        num_tokens_post_pad,
-        cumsum_buffer,
-        pad_sorted_token_ids,
-    )
+# ------------------------------------------------------------------------------------------------ op wrappers
+
+def moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, experts_ids, num_tokens_post_pad,
+                         cumsum_buffer, pad_sorted_token_ids=False):
+    _ops.moe_align_block_size.default(topk_ids, num_experts, block_size, sorted_token_ids, experts_ids,
+                                      num_tokens_post_pad, cumsum_buffer, pad_sorted_token_ids)
 
 
-def topk_softmax(
-    topk_weights: torch.Tensor,
-    topk_ids: torch.Tensor,
-    gating_output: float,
-    renormalize: bool = False,
-) -> None:
-    torch.ops.sgl_kernel.topk_softmax.default(topk_weights, topk_ids, gating_output, renormalize)
+def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor, gating_output: float, renormalize: bool = False) -> None:
+    _ops.topk_softmax.default(topk_weights, topk_ids, gating_output, renormalize)
 
 
-def prepare_moe_input(
-    topk_ids,
-    expert_offsets,
-    problem_sizes1,
-    problem_sizes2,
-    input_permutation,
-    output_permutation,
-    num_experts,
-    n,
-    k,
-    blockscale_offsets: Optional[torch.Tensor] = None,
-):
-    torch.ops.sgl_kernel.prepare_moe_input.default(
-        topk_ids,
-        expert_offsets,
-        blockscale_offsets,
-        problem_sizes1,
-        problem_sizes2,
-        input_permutation,
-        output_permutation,
-        num_experts,
-        n,
-        k,
-    )
+def prepare_moe_input(topk_ids, expert_offsets, problem_sizes1, problem_sizes2, input_permutation, output_permutation,
+                      num_experts, n, k, blockscale_offsets: Optional[torch.Tensor] = None):
+    _ops.prepare_moe_input.default(topk_ids, expert_offsets, blockscale_offsets, problem_sizes1, problem_sizes2,
+                                   input_permutation, output_permutation, num_experts, n, k)
 
 
-def apply_shuffle_mul_sum(
-    input,
-    output,
-    permutation,
-    factors,
-    routed_scaling_factor: Optional[float] = None,
-):
-    rsf = 1.0
-
-    if routed_scaling_factor is not None:
-        rsf = routed_scaling_factor
-
-    torch.ops.sgl_kernel.apply_shuffle_mul_sum.default(input, output, permutation, rsf, factors)
+def apply_shuffle_mul_sum(input, output, permutation, factors, routed_scaling_factor: Optional[float] = None):
+    _ops.apply_shuffle_mul_sum.default(input, output, permutation,
+                                       1.0 if routed_scaling_factor is None else routed_scaling_factor, factors)
 
 
 def scatter_tokens_to_experts(input, src2dst_map, output):
-    torch.ops.sgl_kernel.scatter_tokens_to_experts.default(input, src2dst_map, output)
+    _ops.scatter_tokens_to_experts.default(input, src2dst_map, output)
 
 
-_MOE_WS_HEADROOM = 1.1
-_moe_ws_cache: Dict[Tuple[str, torch.device], torch.Tensor] = {}
+# ------------------------------------------------------------------------------------------------ scratch
+
+class _Scratch:
+    """Process-wide grow-only flat buffers, one per (name, device). A request is a view of the first `numel`
+    elements; a buffer is replaced (10 % larger than asked) only when it is too small or of another dtype, so the
+    same storage serves every MoE layer and every call and the caching allocator does not collect differently
+    sized blocks. Replacing a buffer is safe without a sync: the allocator orders the free on the stream."""
+
+    HEADROOM = 1.1
+
+    def __init__(self):
+        self._buffers: Dict[Tuple[str, torch.device], torch.Tensor] = {}
+
+    def get(self, name: str, shape: tuple, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+        numel = 1
+        for extent in shape:
+            numel *= int(extent)
+        key = (name, device)
+        flat = self._buffers.get(key)
+        if flat is None or flat.dtype != dtype or flat.numel() < numel:
+            flat = torch.empty(max(numel, int(numel * self.HEADROOM)), dtype=dtype, device=device)
+            self._buffers[key] = flat
+        return flat[:numel].view(shape)
 
 
-def _get_moe_ws(
-    name: str,
-    shape: tuple,
-    dtype: torch.dtype,
-    device: torch.device,
-) -> torch.Tensor:
-    """A tensor of `shape`/`dtype` backed by a process-wide grow-only flat scratch buffer
-    (reference moe.py:376-400): stable buffers across calls and MoE layers keep the caching
-    allocator from piling up differently-shaped blocks. Dropping the old buffer is stream-ordered."""
-    numel = 1
-    for d in shape:
-        numel *= d
-    key = (name, device)
-    cur = _moe_ws_cache.get(key)
-    if cur is None or cur.numel() < numel or cur.dtype != dtype:
-        new_numel = max(numel, int(numel * _MOE_WS_HEADROOM))
-        cur = torch.empty(new_numel, dtype=dtype, device=device)
-        _moe_ws_cache[key] = cur
-    return cur.narrow(0, 0, numel).view(shape)
+_scratch = _Scratch()
 
 
-def fused_experts(
-    hidden_states: torch.Tensor,
-    w1: torch.Tensor,
-    w2: torch.Tensor,
-    topk_weights: torch.Tensor,
-    topk_ids: torch.Tensor,
-    b1: Optional[torch.Tensor] = None,
-    b2: Optional[torch.Tensor] = None,
-    inplace: bool = False,
-    activation: str = "silu",
-    use_fp8_w8a8: bool = False,
-    use_mxfp4_w4a16: bool = False,
-    use_int4_w4a16: bool = False,
-    w1_scale: Optional[torch.Tensor] = None,
-    w2_scale: Optional[torch.Tensor] = None,
-    w1_zp: Optional[torch.Tensor] = None,
-    w2_zp: Optional[torch.Tensor] = None,
-    w1_g_idx_perm: Optional[torch.Tensor] = None,
-    w2_g_idx_perm: Optional[torch.Tensor] = None,
-    a1_scale: Optional[torch.Tensor] = None,
-    a2_scale: Optional[torch.Tensor] = None,
-    block_shape: Optional[list] = None,
-    no_combine: bool = False,
-    routed_scaling_factor: Optional[float] = None,
-    gemm1_alpha: Optional[float] = None,
-    gemm1_limit: Optional[float] = None,
-    swiglu_limit: Optional[float] = None,
-) -> torch.Tensor:
-    """Routed-expert MLP. Default: 16-bit weights w1 [E, 2I (or I for relu2), H], w2 [E, H, I] in the activation
-    dtype. use_int4_w4a16: w1 [E, 2I (or I for relu2), H/2] and w2 [E, H, I/2] are int4-packed
-    (two codes per byte, low nibble = even k) with per-group scales [E, N, K/group] in the
-    activation dtype and optional raw zero-points of the same shape; topk_weights fp32 [T, k];
-    biases fp32 (bf16 is up-cast, as the reference does: moe.py:574-587). Arguments and their
-    meaning are the reference's (moe.py:403-508)."""
-    assert use_fp8_w8a8 is False, "current MoE does not support use_fp8_w8a8"
-    assert a1_scale is None, "current MoE does not support a1_scale"
-    assert a2_scale is None, "current MoE does not support a2_scale"
-    assert block_shape is None, "current MoE does not support block_shape"
-    assert activation in (
-        "silu",
-        "gelu",
-        "relu2",
-    ), f"Only silu, gelu and relu2 are supported but got {activation}"
+def _get_moe_ws(name: str, shape: tuple, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """The reference's name for a scratch request (moe.py:376)."""
+    return _scratch.get(name, shape, dtype, device)
 
-    use_4bit_w4a16 = use_mxfp4_w4a16 or use_int4_w4a16
-    assert not (use_mxfp4_w4a16 and use_int4_w4a16), "use_mxfp4_w4a16 and use_int4_w4a16 are mutually exclusive"
-    if use_mxfp4_w4a16:
-        raise NotImplementedError("fused_experts: the mxfp4 weight format is outside the MI355X build (int4 W4A16 only)")
-    if use_4bit_w4a16:
-        assert w1.dtype == torch.int8 or w1.dtype == torch.uint8, "4-bit W4A16 requires w1 to be int8 or uint8 (packed [E, N, K/2])"
-        assert w2.dtype == torch.int8 or w2.dtype == torch.uint8, "4-bit W4A16 requires w2 to be int8 or uint8 (packed [E, N, K/2])"
-        assert w1_scale is not None, "w1_scale must be provided for 4-bit W4A16"
-        assert w2_scale is not None, "w2_scale must be provided for 4-bit W4A16"
-        assert (
-            w1_scale.dtype == hidden_states.dtype and w2_scale.dtype == hidden_states.dtype
-        ), "int4 scales dtype must match hidden_states dtype"
-        if w1_zp is not None:
-            assert w1_zp.dtype == w1_scale.dtype and w1_zp.shape == w1_scale.shape, "w1_zp must have the same dtype and shape as w1_scale"
-        if w2_zp is not None:
-            assert w2_zp.dtype == w2_scale.dtype and w2_zp.shape == w2_scale.shape, "w2_zp must have the same dtype and shape as w2_scale"
-    else:
-        # 16-bit weights: w1 [E, 2I (or I for relu2), H], w2 [E, H, I] in the activation dtype (reference moe.py:763-775)
-        assert w1.dtype == hidden_states.dtype and w2.dtype == hidden_states.dtype, "w1 / w2 must have the dtype of hidden_states"
-        assert w1_scale is None and w2_scale is None and w1_zp is None and w2_zp is None, "scales / zero points need a 4-bit format"
-    if b1 is not None:
-        assert b1.dtype == torch.bfloat16 or b1.dtype == torch.float32, "b1 must be bfloat16 or float32"
-        if b1.dtype == torch.bfloat16:
-            b1 = b1.float()  # bias is accumulated in float32 in the kernel
-    if b2 is not None:
-        assert b2.dtype == torch.bfloat16 or b2.dtype == torch.float32, "b2 must be bfloat16 or float32"
-        if b2.dtype == torch.bfloat16:
-            b2 = b2.float()
 
-    _pack = 2 if use_4bit_w4a16 else 1  # codes per stored element
-    _w1_inner = w1.shape[-1] * _pack
-    _w2_inner = w2.shape[-1] * _pack
+# ------------------------------------------------------------------------------------------------ plan
+
+# activation name -> (activation_type of the grouped GEMM op, gated?, elementwise op used on the unfused route)
+_ACTIVATIONS = {
+    "silu": (0, True, "silu_and_mul"),
+    "gelu": (1, True, "gelu_tanh_and_mul"),
+    "relu2": (3, False, None),
+}
+
+
+@dataclass(frozen=True)
+class _Plan:
+    tokens: int
+    hidden: int        # H: GEMM 1 contracts over it, GEMM 2 produces it
+    inter: int         # I: GEMM 2 contracts over it (unpacked)
+    experts: int
+    topk: int
+    gate_factor: int   # 2: w1 holds gate and up halves; 1: no gate (relu2)
+    four_bit: bool
+    int4: bool
+    group1: int        # quantisation group along H (GEMM 1) / along I (GEMM 2); 0 for 16-bit weights
+    group2: int
+    act_type: int
+    act_op: Optional[str]
+
+    @property
+    def rows(self) -> int:
+        return self.tokens * self.topk
+
+
+def _plan(hidden_states, w1, w2, topk_weights, topk_ids, activation, use_mxfp4_w4a16, use_int4_w4a16,
+          w1_scale, w2_scale) -> _Plan:
+    assert activation in _ACTIVATIONS, f"Only silu, gelu and relu2 are supported but got {activation}"
+    act_type, _, act_op = _ACTIVATIONS[activation]
+    four_bit = use_mxfp4_w4a16 or use_int4_w4a16
+    unpack = 2 if four_bit else 1  # codes per stored byte
     assert hidden_states.ndim == 2, "hidden_states must be 2D"
-    assert (
-        hidden_states.shape[-1] == _w1_inner
-    ), f"hidden_states shape[-1] {hidden_states.shape} must equal w1 inner dim {_w1_inner} (w1.shape={w1.shape})"
-    assert (2 * _w2_inner == w1.shape[1]) or (
-        (_w2_inner == w1.shape[1]) and (activation == "relu2")
-    ), f"w2 inner dim {_w2_inner} must be half of w1 shape[1] {w1.shape[1]} except non-gate"
-    assert (topk_ids.shape == topk_weights.shape) and (
-        topk_ids.shape[0] == hidden_states.shape[0]
-    ), f"topk_ids shape {topk_ids.shape} and topk_weights shape {topk_weights.shape} must be equal and match hidden_states shape[0] {hidden_states.shape[0]}"
+    tokens, hidden = hidden_states.shape
+    experts, w1_rows, w1_inner = w1.shape
+    experts2, w2_rows, w2_inner = w2.shape
+    w1_inner *= unpack
+    w2_inner *= unpack
+    assert experts == experts2, f"w1 and w2 disagree on the number of experts ({experts} vs {experts2})"
+    assert hidden == w1_inner, (
+        f"hidden_states shape[-1] {tuple(hidden_states.shape)} must equal w1 inner dim {w1_inner} (w1.shape={tuple(w1.shape)})")
+    gated = w1_rows == 2 * w2_inner
+    assert gated or (w1_rows == w2_inner and activation == "relu2"), (
+        f"w2 inner dim {w2_inner} must be half of w1 shape[1] {w1_rows} except non-gate")
+    assert topk_ids.shape == topk_weights.shape and topk_ids.shape[0] == tokens, (
+        f"topk_ids shape {tuple(topk_ids.shape)} and topk_weights shape {tuple(topk_weights.shape)} must be equal "
+        f"and match hidden_states shape[0] {tokens}")
+    return _Plan(tokens=tokens, hidden=hidden, inter=w2_inner, experts=experts, topk=topk_ids.shape[1],
+                 gate_factor=2 if gated else 1, four_bit=four_bit, int4=bool(use_int4_w4a16),
+                 group1=(hidden // w1_scale.shape[2]) if four_bit else 0,
+                 group2=(w2_inner // w2_scale.shape[2]) if four_bit else 0,
+                 act_type=act_type, act_op=act_op)
 
-    num_tokens, hidden_dims = hidden_states.shape
-    E, _, K = w1.shape
-    E, OutK, N = w2.shape
-    K = K * _pack
-    N = N * _pack
-    w1_group_size = K // w1_scale.shape[2] if use_4bit_w4a16 else 0
-    w2_group_size = N // w2_scale.shape[2] if use_4bit_w4a16 else 0
-    if b1 is not None:
-        assert b1.shape == w1.shape[:2], "b1 shape must match w1 shape[:2]"
-    if b2 is not None:
-        assert b2.shape == w2.shape[:2], "b2 shape must match w2 shape[:2]"
 
-    M = num_tokens
-    TopK = topk_ids.shape[1]
-    dev = hidden_states.device
-
-    if no_combine:
-        assert not inplace
-        out_hidden_states = torch.empty((num_tokens, OutK), device=dev, dtype=hidden_states.dtype)
-    elif inplace:
-        out_hidden_states = hidden_states
+def _check_weight_format(hidden_states, w1, w2, use_mxfp4_w4a16, use_int4_w4a16, w1_scale, w2_scale, w1_zp, w2_zp):
+    assert not (use_mxfp4_w4a16 and use_int4_w4a16), "use_mxfp4_w4a16 and use_int4_w4a16 are mutually exclusive"
+    act_dtype = hidden_states.dtype
+    if not (use_mxfp4_w4a16 or use_int4_w4a16):
+        assert w1.dtype == act_dtype and w2.dtype == act_dtype, "w1 / w2 must have the dtype of hidden_states"
+        assert w1_scale is None and w2_scale is None, "w1_scale / w2_scale are only supported for 4-bit W4A16 MoE"
+        assert w1_zp is None and w2_zp is None, "w1_zp/w2_zp are only supported for 4-bit W4A16 MoE"
+        return
+    for name, w, s in (("w1", w1, w1_scale), ("w2", w2, w2_scale)):
+        assert w.dtype in (torch.int8, torch.uint8), f"4-bit W4A16 requires {name} to be int8 or uint8 (packed [E, N, K/2])"
+        assert s is not None, f"{name}_scale must be provided for 4-bit W4A16"
+    if use_int4_w4a16:
+        assert w1_scale.dtype == act_dtype and w2_scale.dtype == act_dtype, "int4 scales dtype must match hidden_states dtype"
+        for name, zp, s in (("w1_zp", w1_zp, w1_scale), ("w2_zp", w2_zp, w2_scale)):
+            if zp is not None:
+                assert zp.dtype == s.dtype and zp.shape == s.shape, f"{name} must have the same dtype and shape as its scale"
     else:
-        out_hidden_states = torch.empty_like(hidden_states)
+        e8m0 = getattr(torch, "float8_e8m0fnu", torch.uint8)
+        assert w1_scale.dtype in (torch.uint8, e8m0) and w2_scale.dtype in (torch.uint8, e8m0), (
+            "mxfp4 scales must be E8M0 bytes (uint8 or float8_e8m0fnu)")
+        assert w1_zp is None and w2_zp is None, "mxfp4 weights have no zero points"
 
-    topk_ids = topk_ids.int() if topk_ids.dtype == torch.long else topk_ids
-    topk_ids = topk_ids.contiguous()
-    expert_offsets = _get_moe_ws("expert_offsets", (E,), torch.int32, dev)
-    problem_sizes1 = _get_moe_ws("problem_sizes1", (E, 3), torch.int32, dev)
-    problem_sizes2 = _get_moe_ws("problem_sizes2", (E, 3), torch.int32, dev)
-    a_map = _get_moe_ws("a_map", (topk_ids.numel(),), torch.int32, dev)
-    c_map = _get_moe_ws("c_map", (topk_ids.numel(),), torch.int32, dev)
-    torch.ops.sgl_kernel.prepare_moe_input.default(
-        topk_ids, expert_offsets, None, problem_sizes1, problem_sizes2, a_map, c_map, E, hidden_dims, TopK
-    )
-    input_A_shuffle = _get_moe_ws("input_A_shuffle", (num_tokens * TopK, K), hidden_states.dtype, dev)
-    torch.ops.sgl_kernel.scatter_tokens_to_experts.default(hidden_states.contiguous(), c_map, input_A_shuffle)
-    if w1_g_idx_perm is not None:
-        input_A_shuffle = _apply_per_expert_channel_gather(input_A_shuffle, w1_g_idx_perm, expert_offsets, E)
 
-    intermediate_cache3 = _get_moe_ws("intermediate_cache3", (M * TopK, OutK), hidden_states.dtype, dev)
+def _bias_fp32(bias, name, expect):
+    """The kernels add the bias in fp32 and take it as fp32: bf16 biases are widened once here."""
+    if bias is None:
+        return None
+    assert bias.dtype in (torch.bfloat16, torch.float32), f"{name} must be bfloat16 or float32"
+    assert tuple(bias.shape) == tuple(expect), f"{name} shape must match w{name[1]} shape[:2]"
+    return bias.float() if bias.dtype != torch.float32 else bias
 
-    # 0=silu, 1=gelu, 3=relu2 (the gpt-oss / deepseek-v4 clamped swiglus of the reference, types 2 and 4,
-    # need activation kernels that are outside this build)
-    if activation == "silu":
-        if gemm1_alpha is not None or swiglu_limit is not None:
-            raise NotImplementedError("fused_experts: clamped swiglu variants are outside the MI355X build")
-        activation_type = 0
-    elif activation == "gelu":
-        activation_type = 1
-    else:
-        activation_type = 3
 
+def _gather_channels_per_expert(x, perm, rows_per_expert, num_experts):
+    """GPTQ act-order support: row r of expert e becomes x[r, perm[e, :]] (rows are grouped by expert, counts given)."""
+    owner = torch.repeat_interleave(torch.arange(num_experts, device=x.device), rows_per_expert.to(torch.int64),
+                                    output_size=x.size(0))
+    return torch.gather(x, 1, perm[owner])
+
+
+# ------------------------------------------------------------------------------------------------ fused_experts
+
+def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, topk_weights: torch.Tensor,
+                  topk_ids: torch.Tensor, b1: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None,
+                  inplace: bool = False, activation: str = "silu", use_fp8_w8a8: bool = False,
+                  use_mxfp4_w4a16: bool = False, use_int4_w4a16: bool = False,
+                  w1_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None,
+                  w1_zp: Optional[torch.Tensor] = None, w2_zp: Optional[torch.Tensor] = None,
+                  w1_g_idx_perm: Optional[torch.Tensor] = None, w2_g_idx_perm: Optional[torch.Tensor] = None,
+                  a1_scale: Optional[torch.Tensor] = None, a2_scale: Optional[torch.Tensor] = None,
+                  block_shape: Optional[list] = None, no_combine: bool = False,
+                  routed_scaling_factor: Optional[float] = None, gemm1_alpha: Optional[float] = None,
+                  gemm1_limit: Optional[float] = None, swiglu_limit: Optional[float] = None) -> torch.Tensor:
+    """out[t] = sum_j topk_weights[t, j] * MLP_{topk_ids[t, j]}(hidden_states[t]) (times routed_scaling_factor).
+
+    Weights: 16-bit w1 [E, 2I, H] (gate rows first, then up; [E, I, H] for relu2) and w2 [E, H, I] in the
+    activation dtype, or 4-bit W4A16: the same matrices packed two codes per byte along the last axis (low nibble
+    = even index), int4 with scales [E, rows, cols/group] in the activation dtype (+ optional raw zero points of
+    the same shape; without them the codes are two's-complement), mxfp4 (e2m1) with E8M0 scale bytes, group 32.
+    Biases b1 [E, 2I] / b2 [E, H] are added in fp32. `inplace` writes the result over hidden_states."""
+    assert not use_fp8_w8a8, "current MoE does not support use_fp8_w8a8"
+    assert a1_scale is None and a2_scale is None, "current MoE does not support a1_scale / a2_scale"
+    assert block_shape is None, "current MoE does not support block_shape"
+    if gemm1_alpha is not None or swiglu_limit is not None:
+        raise NotImplementedError("fused_experts: the clamped swiglu variants (gpt-oss, DeepSeek-V4) are outside this build")
     assert is_xe2_arch(), "this MoE path is built for gfx950 (MI355X) only"
+    if w1_g_idx_perm is not None or w2_g_idx_perm is not None:
+        assert use_int4_w4a16, "w1_g_idx_perm/w2_g_idx_perm only apply to use_int4_w4a16"
 
-    gate_factor = 2 if (2 * N == w1.shape[1]) else 1
+    _check_weight_format(hidden_states, w1, w2, use_mxfp4_w4a16, use_int4_w4a16, w1_scale, w2_scale, w1_zp, w2_zp)
+    p = _plan(hidden_states, w1, w2, topk_weights, topk_ids, activation, use_mxfp4_w4a16, use_int4_w4a16, w1_scale, w2_scale)
+    b1 = _bias_fp32(b1, "b1", w1.shape[:2])
+    b2 = _bias_fp32(b2, "b2", w2.shape[:2])
 
-    # GEMM1 -> activation kernel -> GEMM2: the reference's unfused route (moe.py:735-810), which it always takes for
-    # 4-bit weights; 16-bit weights take it here as well (its fused-epilogue route computes the same thing without
-    # rounding the GEMM1 output to the activation dtype first)
-    intermediate_cache1 = _get_moe_ws("intermediate_cache1_unfused", (M * TopK, gate_factor * N), hidden_states.dtype, dev)
-    intermediate_cache2 = _get_moe_ws("intermediate_cache2", (M * TopK, N), hidden_states.dtype, dev)
-
-    def grouped_mm(out, a, w, w_scale, w_zp, bias, group_size):
-        if use_4bit_w4a16:
-            torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(out, a, w, w_scale, w_zp, bias, expert_offsets, E, use_int4_w4a16, group_size)
-        else:
-            torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, a, w, bias, expert_offsets, E, activation_type, False, 1.702, 7.0)
-
-    grouped_mm(intermediate_cache1, input_A_shuffle, w1, w1_scale, w1_zp, b1, w1_group_size)
-    if activation_type == 0:
-        torch.ops.sgl_kernel.silu_and_mul(intermediate_cache2, intermediate_cache1)
-    elif activation_type == 1:
-        torch.ops.sgl_kernel.gelu_tanh_and_mul(intermediate_cache2, intermediate_cache1)
+    dev, dt = hidden_states.device, hidden_states.dtype
+    if no_combine:
+        assert not inplace, "no_combine and inplace exclude each other"
+        result = torch.empty((p.tokens, p.hidden), device=dev, dtype=dt)
     else:
-        intermediate_cache2 = torch.square(torch.relu(intermediate_cache1))
-    if w2_g_idx_perm is not None:
-        intermediate_cache2 = _apply_per_expert_channel_gather(intermediate_cache2, w2_g_idx_perm, expert_offsets, E)
-    grouped_mm(intermediate_cache3, intermediate_cache2.contiguous(), w2, w2_scale, w2_zp, b2, w2_group_size)
+        result = hidden_states if inplace else torch.empty_like(hidden_states)
 
-    rsf = 1.0
-    if routed_scaling_factor is not None:
-        rsf = routed_scaling_factor
-    torch.ops.sgl_kernel.apply_shuffle_mul_sum.default(intermediate_cache3, out_hidden_states, c_map, rsf, topk_weights)
-    return out_hidden_states
+    def scratch(name, shape, dtype=dt):
+        return _scratch.get(name, shape, dtype, dev)
+
+    # ---- routing: expert row counts and the token -> expert-contiguous row map
+    ids = (topk_ids.int() if topk_ids.dtype == torch.long else topk_ids).contiguous()
+    rows_per_expert = scratch("expert_offsets", (p.experts,), torch.int32)
+    src_rows = scratch("a_map", (p.rows,), torch.int32)
+    dst_rows = scratch("c_map", (p.rows,), torch.int32)
+    _ops.prepare_moe_input.default(ids, rows_per_expert, None,
+                                   scratch("problem_sizes1", (p.experts, 3), torch.int32),
+                                   scratch("problem_sizes2", (p.experts, 3), torch.int32),
+                                   src_rows, dst_rows, p.experts, p.hidden, p.topk)
+    x = scratch("input_A_shuffle", (p.rows, p.hidden))
+    _ops.scatter_tokens_to_experts.default(hidden_states.contiguous(), dst_rows, x)
+    if w1_g_idx_perm is not None:
+        x = _gather_channels_per_expert(x, w1_g_idx_perm, rows_per_expert, p.experts)
+
+    def grouped_mm(out, a, w, scale, zp, bias, group, fuse_act=False):
+        if p.four_bit:
+            _ops.moe_grouped_mm_nt_xe20_w4a16(out, a, w, scale, zp, bias, rows_per_expert, p.experts, p.int4, group)
+        else:
+            _ops.moe_grouped_mm_nt_xe20(out, a, w, bias, rows_per_expert, p.experts, p.act_type, fuse_act, 1.702, 7.0)
+
+    # ---- GEMM 1 (+ gate/up activation)
+    fused_epilogue = (not p.four_bit) and p.gate_factor == 2 and p.act_op is not None
+    if fused_epilogue:
+        h = scratch("intermediate_cache1_fused", (p.rows, p.inter))
+        grouped_mm(h, x, w1, None, None, b1, 0, fuse_act=True)
+    else:
+        gu = scratch("intermediate_cache1_unfused", (p.rows, p.gate_factor * p.inter))
+        grouped_mm(gu, x, w1, w1_scale, w1_zp, b1, p.group1)
+        if p.act_op is not None:
+            h = scratch("intermediate_cache2", (p.rows, p.inter))
+            getattr(_ops, p.act_op)(h, gu)
+        else:
+            h = torch.square(torch.relu(gu))
+    if w2_g_idx_perm is not None:
+        h = _gather_channels_per_expert(h, w2_g_idx_perm, rows_per_expert, p.experts)
+
+    # ---- GEMM 2 and the weighted combine over the top-k slots
+    y = scratch("intermediate_cache3", (p.rows, p.hidden))
+    grouped_mm(y, h.contiguous(), w2, w2_scale, w2_zp, b2, p.group2)
+    _ops.apply_shuffle_mul_sum.default(y, result, dst_rows, 1.0 if routed_scaling_factor is None else routed_scaling_factor,
+                                       topk_weights)
+    return result

@@ -43,3 +43,201 @@ def test_out_of_scope_names_raise_on_call_only(sglk):
         f()
     with pytest.raises(AttributeError):
         sglk.definitely_not_an_op
+
+
+# ---- wrapper contract: argument normalisation pinned with the op call intercepted ----------
+
+class _Recorder:
+    """Stands in for torch.ops.sgl_kernel: records (op name, args) and returns what a caller needs to go on."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __getattr__(self, name):
+        rec = self
+
+        class _Op:
+            def __call__(self, *a, **k):
+                rec.calls.append((name, a, k))
+                return 0
+
+            default = property(lambda self_: self_)
+
+        return _Op()
+
+    def names(self):
+        return [c[0] for c in self.calls]
+
+
+def test_fwd_slot_table_matches_schema(sglk):
+    from sgl_kernel import flash_attn as fa
+
+    schema = torch.ops.sgl_kernel.fwd.default._schema
+    assert [a.name for a in schema.arguments] == [n for n, _ in fa._FWD_SLOTS]
+    assert len(fa._FWD_SLOTS) == 29
+
+
+def test_flash_attn_with_kvcache_normalisation(sglk, monkeypatch):
+    from sgl_kernel import flash_attn as fa
+
+    seen = {}
+
+    def fake(*pos):
+        seen["args"] = pos
+        return (torch.zeros(1), torch.zeros(1), None, None)
+
+    monkeypatch.setattr(fa, "_fwd", fake)
+    b, s, h, d = 3, 5, 4, 64
+    q = torch.randn(b, s, h, d)
+    kc = torch.randn(7, 64, 2, d)
+    vc = torch.randn(7, 64, 2, d)
+    lens = torch.tensor([5, 9, 64], dtype=torch.int32)
+    table = torch.zeros(b, 1, dtype=torch.int32)
+    out = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, page_table=table, causal=True, window_size=(7, 0))
+    assert isinstance(out, torch.Tensor)  # no LSE unless asked
+    a = dict(zip([n for n, _ in fa._FWD_SLOTS], seen["args"]))
+    # padded 4-D q -> ragged 3-D rows with an arange cu_seqlens_q and max_seqlen_q = s (reference flash_attn.py:258-263)
+    assert a["q"].shape == (b * s, h, d) and a["q"].is_contiguous()
+    assert a["cu_seqlens_q"].dtype == torch.int32 and a["cu_seqlens_q"].tolist() == [0, 5, 10, 15]
+    assert a["max_seqlen_q"] == s
+    # cache_seqlens (lengths) rides in the cu_seqlens_k slot, same object (reference :264-266)
+    assert a["cu_seqlens_k"] is lens
+    # default scale = headdim^-0.5 (reference :233-236)
+    assert a["softmax_scale"] == d ** -0.5
+    assert a["is_causal"] is True and a["window_size_left"] == 7 and a["window_size_right"] == 0
+    assert a["page_table"] is table and a["out"] is None and a["q_v"] is None
+    # an int cache_seqlens becomes one int32 per cache row (reference :238-242); return_softmax_lse passes all through
+    res = fa.flash_attn_with_kvcache(q[:, :1], kc[:b], vc[:b], cache_seqlens=11, return_softmax_lse=True, softmax_scale=0.25)
+    assert isinstance(res, tuple) and len(res) == 4
+    a = dict(zip([n for n, _ in fa._FWD_SLOTS], seen["args"]))
+    assert a["cu_seqlens_k"].dtype == torch.int32 and a["cu_seqlens_k"].tolist() == [11] * b
+    assert a["softmax_scale"] == 0.25 and a["max_seqlen_q"] == 1
+    # ragged q given: passed through untouched
+    cu = torch.tensor([0, 2, 6, 15], dtype=torch.int32)
+    qr = torch.randn(15, h, d)
+    fa.flash_attn_with_kvcache(qr, kc, vc, cache_seqlens=lens, page_table=table, cu_seqlens_q=cu, max_seqlen_q=9)
+    a = dict(zip([n for n, _ in fa._FWD_SLOTS], seen["args"]))
+    assert a["q"] is qr and a["cu_seqlens_q"] is cu and a["max_seqlen_q"] == 9
+    with pytest.raises(AssertionError, match="cache_seqlens"):
+        fa.flash_attn_with_kvcache(q, kc, vc)
+    with pytest.raises(AssertionError, match="appending"):
+        fa.flash_attn_with_kvcache(q, kc, vc, k=kc, v=vc, cache_seqlens=lens)
+
+
+def test_flash_mla_wrappers(sglk, monkeypatch):
+    from sgl_kernel import attention as at
+
+    rec = _Recorder()
+    monkeypatch.setattr(at, "_ops", rec)
+    B, H = 2, 16
+    qn = torch.randn(B, H, 512, dtype=torch.bfloat16)
+    qp = torch.randn(B, H, 64, dtype=torch.bfloat16)
+    cache = torch.randn(8, 64, 576, dtype=torch.bfloat16)
+    lens = torch.tensor([100, 128], dtype=torch.int32)
+    table = torch.zeros(B, 2, dtype=torch.int32)
+    ws = torch.empty(16, dtype=torch.uint8)
+    out = at.flash_mla_decode(qn, qp, cache, lens, table, ws, 0.1, -1)
+    assert out.shape == (B, H, 512) and out.dtype == torch.bfloat16 and out.is_contiguous()
+    name, args, _ = rec.calls[-1]
+    assert name == "flash_mla_decode" and args[0] is out and args[1] is qn and args[6] is ws and args[7:] == (0.1, -1)
+    # a transposed q_nope view keeps its strides (only the innermost stride must be 1)
+    qn_t = torch.randn(H, B, 512, dtype=torch.bfloat16).transpose(0, 1)
+    at.flash_mla_decode(qn_t, qp, cache, lens, table, ws, 0.1)
+    assert rec.calls[-1][1][1] is qn_t and rec.calls[-1][1][8] == 1  # default num_kv_splits = 1
+    with pytest.raises(AssertionError, match="128-token"):
+        at.flash_mla_decode(qn, qp, cache, lens, torch.zeros(B, 1, dtype=torch.int32), ws, 0.1)
+    with pytest.raises(AssertionError, match="int32"):
+        at.flash_mla_decode(qn, qp, cache, lens.long(), table, ws, 0.1)
+    with pytest.raises(AssertionError, match="<= 128"):
+        at.flash_mla_decode(torch.randn(B, 129, 512, dtype=torch.bfloat16), torch.randn(B, 129, 64, dtype=torch.bfloat16),
+                            cache, lens, table, ws, 0.1)
+    with pytest.raises(AssertionError, match="greater than 0"):
+        at.flash_mla_get_workspace_size(0, 4)
+    # prefill: exactly total_q rows, nothing launched for an empty batch
+    cu = torch.tensor([0, 3, 7], dtype=torch.int32)
+    n = len(rec.calls)
+    o = at.flash_mla_prefill(torch.randn(7, H, 512, dtype=torch.bfloat16), torch.randn(7, H, 64, dtype=torch.bfloat16),
+                             cache, cu, lens, 4, table, ws, 0.1)
+    assert o.shape == (7, H, 512) and rec.calls[-1][0] == "flash_mla_prefill" and rec.calls[-1][1][10:] == (True, -1)
+    o = at.flash_mla_prefill(torch.randn(0, H, 512, dtype=torch.bfloat16), torch.randn(0, H, 64, dtype=torch.bfloat16),
+                             cache, torch.zeros(3, dtype=torch.int32), lens, 0, table, ws, 0.1)
+    assert o.shape == (0, H, 512) and len(rec.calls) == n + 1
+
+
+def _moe_case(dtype=torch.bfloat16, T=5, H=128, I=64, E=4, k=2, four_bit=True, gated=True):
+    x = torch.randn(T, H, dtype=dtype)
+    rows1 = 2 * I if gated else I
+    if four_bit:
+        w1 = torch.zeros(E, rows1, H // 2, dtype=torch.uint8)
+        w2 = torch.zeros(E, H, I // 2, dtype=torch.uint8)
+        s1 = torch.ones(E, rows1, H // 32, dtype=dtype)
+        s2 = torch.ones(E, H, I // 32, dtype=dtype)
+    else:
+        w1, w2, s1, s2 = torch.zeros(E, rows1, H, dtype=dtype), torch.zeros(E, H, I, dtype=dtype), None, None
+    tw = torch.rand(T, k)
+    ti = torch.randint(0, E, (T, k), dtype=torch.int64)
+    return x, w1, w2, tw, ti, s1, s2
+
+
+def test_fused_experts_plan_and_op_sequence(sglk, monkeypatch):
+    from sgl_kernel import moe
+
+    rec = _Recorder()
+    monkeypatch.setattr(moe, "_ops", rec)
+    monkeypatch.setattr(moe, "is_xe2_arch", lambda: True)
+    x, w1, w2, tw, ti, s1, s2 = _moe_case()
+    b1 = torch.randn(4, 128, dtype=torch.bfloat16)
+    out = moe.fused_experts(x, w1, w2, tw, ti, b1=b1, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, routed_scaling_factor=2.5)
+    assert out.shape == x.shape and out is not x
+    assert rec.names() == ["prepare_moe_input", "scatter_tokens_to_experts", "moe_grouped_mm_nt_xe20_w4a16", "silu_and_mul",
+                           "moe_grouped_mm_nt_xe20_w4a16", "apply_shuffle_mul_sum"]
+    prep = rec.calls[0][1]
+    assert prep[0].dtype == torch.int32 and prep[2] is None and prep[7:] == (4, 128, 2)  # ids int32, E, hidden, topk
+    g1, g2 = rec.calls[2][1], rec.calls[4][1]
+    assert g1[0].shape == (10, 128) and g1[1].shape == (10, 128)  # gate_factor 2: [T*k, 2I] from [T*k, H]
+    assert g1[5].dtype == torch.float32 and torch.equal(g1[5], b1.float())  # bf16 bias widened to fp32
+    assert g1[7:] == (4, True, 32) and g2[9] == 32  # E, is_int4, group sizes recovered from the scale shapes
+    assert g2[0].shape == (10, 128) and g2[1].shape == (10, 64) and g2[5] is None
+    comb = rec.calls[5][1]
+    assert comb[1] is out and comb[3] == 2.5 and comb[4] is tw
+    # relu2: no gate (gate_factor 1), no activation op; inplace writes over the input
+    rec.calls.clear()
+    x, w1, w2, tw, ti, s1, s2 = _moe_case(gated=False)
+    out = moe.fused_experts(x, w1, w2, tw, ti, activation="relu2", inplace=True, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2)
+    assert out is x and rec.calls[2][1][0].shape == (10, 64) and "silu_and_mul" not in rec.names()
+    assert rec.calls[-1][1][3] == 1.0
+    # 16-bit weights: the grouped GEMM's fused gate/up epilogue, GEMM 2 without it
+    rec.calls.clear()
+    x, w1, w2, tw, ti, _, _ = _moe_case(four_bit=False)
+    moe.fused_experts(x, w1, w2, tw, ti, activation="gelu")
+    assert rec.names() == ["prepare_moe_input", "scatter_tokens_to_experts", "moe_grouped_mm_nt_xe20", "moe_grouped_mm_nt_xe20",
+                           "apply_shuffle_mul_sum"]
+    assert rec.calls[2][1][0].shape == (10, 64) and rec.calls[2][1][6:8] == (1, True) and rec.calls[3][1][7] is False
+    # argument errors
+    with pytest.raises(AssertionError, match="mutually exclusive"):
+        moe.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, use_mxfp4_w4a16=True)
+    with pytest.raises(AssertionError, match="w1_scale"):
+        x4, w14, w24, tw4, ti4, s14, s24 = _moe_case()
+        moe.fused_experts(x4, w14, w24, tw4, ti4, use_int4_w4a16=True)
+    with pytest.raises(AssertionError, match="Only silu"):
+        moe.fused_experts(x, w1, w2, tw, ti, activation="tanh")
+    with pytest.raises(AssertionError, match="use_fp8_w8a8"):
+        moe.fused_experts(x, w1, w2, tw, ti, use_fp8_w8a8=True)
+
+
+def test_moe_scratch_is_grow_only_and_stable(sglk):
+    from sgl_kernel import moe
+
+    dev = torch.device("cpu")
+    a = moe._get_moe_ws("t_probe", (10, 8), torch.float32, dev)
+    b = moe._get_moe_ws("t_probe", (5, 8), torch.float32, dev)
+    assert b.data_ptr() == a.data_ptr() and b.shape == (5, 8)  # a smaller request re-uses the same storage
+    c = moe._get_moe_ws("t_probe", (10, 8), torch.float32, dev)
+    assert c.data_ptr() == a.data_ptr()
+    big = moe._get_moe_ws("t_probe", (100, 8), torch.float32, dev)
+    assert big.untyped_storage().nbytes() >= int(800 * 1.1) * 4  # grown with 10 % headroom
+    again = moe._get_moe_ws("t_probe", (100, 8), torch.float32, dev)
+    assert again.data_ptr() == big.data_ptr()
+    other = moe._get_moe_ws("t_probe", (4,), torch.int32, dev)  # another dtype replaces the buffer
+    assert other.dtype == torch.int32
+    assert moe._get_moe_ws("t_other", (4,), torch.int32, dev).data_ptr() != other.data_ptr()
