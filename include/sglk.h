@@ -319,6 +319,45 @@ SGLK_API int sglk_rotary_embedding(sglk_stream_t stream, void* q_out, void* k_ou
                                    int64_t qo_tok_stride, int64_t qo_head_stride, int64_t ko_tok_stride,
                                    int64_t ko_head_stride, int is_neox, int dtype);
 
+/* ---- attention prologue / epilogue ------------------------------------------------------
+ * merge_state / merge_state_v2: reference src/sycl/merge_states.cpp:138-361 (schemas
+ * src/torch_extension_sycl.cc:232-234). v_* [tokens, heads, head_size] contiguous, s_* [tokens, heads] fp32.
+ *   m = max(s_a, s_b) (non-finite s counts as -inf); w_x = B^(s_x - m); z = max(w_a + w_b, FLT_MIN)
+ *   v_merged = T(v_a w_a / z + v_b w_b / z);  s_merged = log_B(z) + m   (B = 2 when base2 != 0, else e)
+ * s_merged may be NULL. dtype in {F32, F16, BF16}; head_size a multiple of 16 bytes of T. */
+SGLK_API int sglk_merge_state(sglk_stream_t stream, void* v_merged, float* s_merged, const void* v_a,
+                              const float* s_a, const void* v_b, const float* s_b, int64_t tokens, int64_t heads,
+                              int64_t head_size, int dtype, int base2);
+
+/* store_cache: reference src/sycl/KVCache.cpp:75-160 (schema src/torch_extension_sycl.cc:122-125).
+ * Row t of k / v (row strides in BYTES; rows themselves contiguous) is copied to row indices[t] of the dense
+ * k_cache / v_cache [cache_size, row_bytes]; indices[t] < 0 skips the token. Any element type (byte copy). */
+SGLK_API int sglk_store_cache(sglk_stream_t stream, void* k_cache, void* v_cache, const void* k, const void* v,
+                              const int64_t* indices, int64_t tokens, int64_t row_bytes, int64_t k_row_stride_bytes,
+                              int64_t v_row_stride_bytes);
+
+/* fused_inplace_qknorm_rope: reference src/sycl/FusedQKNormRope.cpp:1723-1861 (schema
+ * src/torch_extension_sycl.cc:421-424). In place on q [tokens, Hq, D] / k [tokens, Hk, D] (strides in elements,
+ * last dim contiguous): per head y = x * rsqrt(mean x^2 + eps) * w, then the first rope_dim elements are rotated
+ * (neox or interleaved pairs) by the fp32 cos_sin_cache row of the token's position ([max_pos, rope_dim]: cos
+ * first half, sin second half). D in {64, 128, 256}; positions int32 or int64; dtype in {F32, F16, BF16}. */
+SGLK_API int sglk_fused_qknorm_rope_cache(sglk_stream_t stream, void* q, void* k, const void* q_weight,
+                                          const void* k_weight, const float* cos_sin_cache, const void* positions,
+                                          int positions_are_int64, int64_t tokens, int64_t num_q_heads,
+                                          int64_t num_k_heads, int64_t head_dim, int64_t rope_dim,
+                                          int64_t q_token_stride, int64_t q_head_stride, int64_t k_token_stride,
+                                          int64_t k_head_stride, int is_neox, float eps, int dtype);
+
+/* fused_qk_norm_rope: reference src/sycl/FusedQKNormRope.cpp:507-615 (schema src/torch_extension_sycl.cc:416-420).
+ * Same arithmetic on a packed qkv [tokens, (Hq + Hk + Hv) * D] (V untouched), angles computed on the fly:
+ * theta = position * freq(j), freq(j) = base^(-2j / rotary_dim) blended YaRN-style when factor != 1
+ * (computeFreqYarn :42-67); the rotated elements are multiplied by attention_factor. positions int32. */
+SGLK_API int sglk_fused_qknorm_rope_yarn(sglk_stream_t stream, void* qkv, const void* q_weight, const void* k_weight,
+                                         const int32_t* position_ids, int64_t tokens, int64_t num_q_heads,
+                                         int64_t num_k_heads, int64_t num_v_heads, int64_t head_dim,
+                                         int64_t rotary_dim, float eps, float base, int is_neox, float factor,
+                                         float low, float high, float attention_factor, int dtype);
+
 #ifdef __cplusplus
 }
 #endif

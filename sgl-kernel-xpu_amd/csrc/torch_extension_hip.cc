@@ -960,6 +960,166 @@ void sgl_per_token_group_quant_8bit_v2(Tensor input, Tensor output_q, Tensor out
                                                kind, s_e, s_row, s_col, fuse_silu_and_mul ? 1 : 0));
 }
 
+// ---- merge_state / merge_state_v2 (reference src/sycl/merge_states.cpp:303-361) ------------------------------
+
+void merge_state_impl(const Tensor& v_a, const Tensor& s_a, const Tensor& v_b, const Tensor& s_b, Tensor& v_merged,
+                      Tensor& s_merged, bool base2, const char* name) {
+  for (const Tensor* t : {&v_a, &s_a, &v_b, &s_b, (const Tensor*)&v_merged, (const Tensor*)&s_merged}) {
+    TORCH_CHECK(t->is_cuda(), name, ": all tensors must be GPU (cuda/hip) tensors");
+    TORCH_CHECK(t->is_contiguous(), name, ": all tensors must be contiguous");
+  }
+  TORCH_CHECK(v_a.dim() == 3 && v_b.dim() == 3, name, ": v_a / v_b must be 3D [tokens, heads, head_size]");
+  TORCH_CHECK(s_a.dim() == 2 && s_b.dim() == 2, name, ": s_a / s_b must be 2D [tokens, heads]");
+  TORCH_CHECK(v_a.sizes() == v_b.sizes() && s_a.sizes() == s_b.sizes(), name, ": the two states must have the same shape");
+  TORCH_CHECK(v_a.size(0) == s_a.size(0) && v_a.size(1) == s_b.size(1), name, ": v and s disagree on tokens / heads");
+  TORCH_CHECK(v_merged.sizes() == v_a.sizes() && s_merged.sizes() == s_a.sizes(), name, ": outputs must have the input shapes");
+  TORCH_CHECK(s_a.scalar_type() == at::kFloat && s_b.scalar_type() == at::kFloat && s_merged.scalar_type() == at::kFloat,
+              name, ": s tensors must be float32");
+  TORCH_CHECK(v_a.scalar_type() == v_merged.scalar_type() && v_b.scalar_type() == v_merged.scalar_type(), name,
+              ": v tensors must share one dtype");
+  const at::ScalarType dt = v_merged.scalar_type();
+  TORCH_CHECK(dt == at::kFloat || dt == at::kHalf || dt == at::kBFloat16, "Unsupported dtype for ", name, ": ", dt);
+  const c10::OptionalDeviceGuard guard(v_a.device());
+  SGLK_CALL(sglk_merge_state(stream_of(v_a), v_merged.data_ptr(), s_merged.data_ptr<float>(), v_a.data_ptr(),
+                             s_a.data_ptr<float>(), v_b.data_ptr(), s_b.data_ptr<float>(), v_merged.size(0),
+                             v_merged.size(1), v_merged.size(2), dtype_code(dt, name), base2 ? 1 : 0));
+}
+void merge_state(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor v_merged, Tensor s_merged) {
+  merge_state_impl(v_a, s_a, v_b, s_b, v_merged, s_merged, true, "merge_state");
+}
+void merge_state_v2(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor v_merged, Tensor s_merged) {
+  merge_state_impl(v_a, s_a, v_b, s_b, v_merged, s_merged, false, "merge_state_v2");
+}
+
+// ---- store_cache (reference src/sycl/KVCache.cpp:75-160) ------------------------------------------------------
+
+void store_cache(Tensor& k, Tensor& v, Tensor& k_cache, Tensor& v_cache, Tensor& indices) {
+  CHECK_GPU(k);
+  CHECK_GPU(v);
+  CHECK_GPU(k_cache);
+  CHECK_GPU(v_cache);
+  CHECK_GPU(indices);
+  CHECK_CONTIGUOUS(k_cache);
+  CHECK_CONTIGUOUS(v_cache);
+  CHECK_CONTIGUOUS(indices);
+  TORCH_CHECK(k.dim() == 2, "k must be 2D [num_tokens, row_dim]");
+  TORCH_CHECK(v.dim() == 2, "v must be 2D [num_tokens, row_dim]");
+  TORCH_CHECK(k_cache.dim() == 2, "k_cache must be 2D [cache_size, row_dim]");
+  TORCH_CHECK(v_cache.dim() == 2, "v_cache must be 2D [cache_size, row_dim]");
+  TORCH_CHECK(indices.dim() == 1, "indices must be 1D [num_tokens]");
+  TORCH_CHECK(k.size(0) == 0 || k.stride(1) == 1, "k rows must be contiguous (k.stride(1) == 1)");
+  TORCH_CHECK(v.size(0) == 0 || v.stride(1) == 1, "v rows must be contiguous (v.stride(1) == 1)");
+  TORCH_CHECK(v.sizes() == k.sizes(), "v shape must match k shape");
+  TORCH_CHECK(v_cache.sizes() == k_cache.sizes(), "v_cache shape must match k_cache shape");
+  TORCH_CHECK(k.size(1) == k_cache.size(1), "k row_dim must match k_cache row_dim");
+  TORCH_CHECK(indices.size(0) == k.size(0), "indices length must match num_tokens");
+  TORCH_CHECK(indices.scalar_type() == at::kLong, "indices must be int64");
+  TORCH_CHECK(k.dtype() == v.dtype(), "k and v must have the same dtype");
+  TORCH_CHECK(k.dtype() == k_cache.dtype(), "k and k_cache must have the same dtype");
+  TORCH_CHECK(k.dtype() == v_cache.dtype(), "k and v_cache must have the same dtype");
+  if (k.size(0) == 0) return;
+  const int64_t esz = k.element_size();
+  const c10::OptionalDeviceGuard guard(k.device());
+  SGLK_CALL(sglk_store_cache(stream_of(k), k_cache.data_ptr(), v_cache.data_ptr(), k.data_ptr(), v.data_ptr(),
+                             indices.data_ptr<int64_t>(), k.size(0), k.size(1) * esz, k.stride(0) * esz, v.stride(0) * esz));
+}
+
+// ---- fused_qk_norm_rope / fused_inplace_qknorm_rope (reference src/sycl/FusedQKNormRope.cpp:507-615, :1723-1861) ----
+
+void fused_qk_norm_rope(Tensor& qkv, int64_t num_heads_q, int64_t num_heads_k, int64_t num_heads_v, int64_t head_dim,
+                        double eps, Tensor& q_weight, Tensor& k_weight, double base, bool is_neox, Tensor& position_ids,
+                        double factor, double low, double high, double attention_factor, int64_t rotary_dim) {
+  TORCH_CHECK(qkv.dim() == 2, "QKV tensor must be 2D: [num_tokens, (num_heads_q+num_heads_k+num_heads_v)*head_dim]");
+  TORCH_CHECK(position_ids.dim() == 1, "Position IDs must be 1D: [num_tokens]");
+  TORCH_CHECK(q_weight.dim() == 1, "Query weights must be 1D: [head_dim]");
+  TORCH_CHECK(k_weight.dim() == 1, "Key weights must be 1D: [head_dim]");
+  TORCH_CHECK(q_weight.size(0) == head_dim, "Query weights size must match head dimension");
+  TORCH_CHECK(k_weight.size(0) == head_dim, "Key weights size must match head dimension");
+  CHECK_GPU(qkv);
+  CHECK_CONTIGUOUS(qkv);
+  CHECK_GPU(position_ids);
+  CHECK_CONTIGUOUS(position_ids);
+  TORCH_CHECK(position_ids.scalar_type() == at::kInt, "position_ids must have dtype int32 (at::kInt); got ",
+              position_ids.scalar_type());
+  CHECK_GPU(q_weight);
+  CHECK_CONTIGUOUS(q_weight);
+  CHECK_GPU(k_weight);
+  CHECK_CONTIGUOUS(k_weight);
+  TORCH_CHECK(q_weight.scalar_type() == qkv.scalar_type() && k_weight.scalar_type() == qkv.scalar_type(),
+              "q_weight / k_weight must have the dtype of qkv");
+  const int64_t num_tokens = qkv.size(0);
+  TORCH_CHECK(position_ids.size(0) == num_tokens, "Number of tokens in position_ids must match QKV");
+  TORCH_CHECK(qkv.size(1) == (num_heads_q + num_heads_k + num_heads_v) * head_dim,
+              "QKV tensor size must match total number of heads and head dimension");
+  const at::ScalarType dt = qkv.scalar_type();
+  TORCH_CHECK(dt == at::kFloat || dt == at::kHalf || dt == at::kBFloat16, "Unsupported dtype for fused_qk_norm_rope: ", dt);
+  const c10::OptionalDeviceGuard guard(qkv.device());
+  SGLK_CALL(sglk_fused_qknorm_rope_yarn(stream_of(qkv), qkv.data_ptr(), q_weight.data_ptr(), k_weight.data_ptr(),
+                                        position_ids.data_ptr<int32_t>(), num_tokens, num_heads_q, num_heads_k, num_heads_v,
+                                        head_dim, rotary_dim, (float)eps, (float)base, is_neox ? 1 : 0, (float)factor,
+                                        (float)low, (float)high, (float)attention_factor, dtype_code(dt, "fused_qk_norm_rope")));
+}
+
+void fused_inplace_qknorm_rope(Tensor& q, Tensor& k, Tensor& q_weight, Tensor& k_weight, Tensor& cos_sin_cache,
+                               Tensor& positions, bool is_neox, double eps, int64_t head_dim, int64_t rope_dim) {
+  TORCH_CHECK(q.dim() == k.dim(), "q and k must have the same rank, got q:", q.dim(), " k:", k.dim());
+  TORCH_CHECK(q.dim() == 3 || q.dim() == 4, "q/k must be 3D or 4D tensors, got q:", q.dim());
+  TORCH_CHECK(q.scalar_type() == k.scalar_type(), "q and k must have the same dtype");
+  TORCH_CHECK(q_weight.scalar_type() == q.scalar_type(), "q_weight dtype must match q dtype");
+  TORCH_CHECK(k_weight.scalar_type() == k.scalar_type(), "k_weight dtype must match k dtype");
+  TORCH_CHECK(cos_sin_cache.scalar_type() == at::kFloat, "cos_sin_cache must be float32");
+  CHECK_GPU(q);
+  TORCH_CHECK(q.stride(-1) == 1, "q must be contiguous in its last dimension (head_dim)");
+  CHECK_GPU(k);
+  TORCH_CHECK(k.stride(-1) == 1, "k must be contiguous in its last dimension (head_dim)");
+  CHECK_GPU(q_weight);
+  CHECK_CONTIGUOUS(q_weight);
+  CHECK_GPU(k_weight);
+  CHECK_CONTIGUOUS(k_weight);
+  CHECK_GPU(cos_sin_cache);
+  CHECK_CONTIGUOUS(cos_sin_cache);
+  CHECK_GPU(positions);
+  CHECK_CONTIGUOUS(positions);
+  // a 4-D [batch, seq, heads, D] input is addressed as [batch * seq, heads, D]: batch and seq must merge
+  auto flat = [](const Tensor& t, const char* name, int64_t& tokens, int64_t& heads, int64_t& ts, int64_t& hs) {
+    if (t.dim() == 4) {
+      TORCH_CHECK(t.stride(0) == t.size(1) * t.stride(1), name,
+                  " batch and sequence dimensions must be mergeable (i.e. contiguous with each other) for 4D input");
+      tokens = t.size(0) * t.size(1); heads = t.size(2); ts = t.stride(1); hs = t.stride(2);
+    } else {
+      tokens = t.size(0); heads = t.size(1); ts = t.stride(0); hs = t.stride(1);
+    }
+  };
+  int64_t tq, hq, q_ts, q_hs, tk, hk, k_ts, k_hs;
+  flat(q, "q", tq, hq, q_ts, q_hs);
+  flat(k, "k", tk, hk, k_ts, k_hs);
+  TORCH_CHECK(tq == tk, "q and k must have the same token count after flattening");
+  TORCH_CHECK(q.size(-1) == k.size(-1), "q and k must have the same head_dim");
+  const int64_t inferred_head_dim = q.size(-1);
+  TORCH_CHECK(q_weight.dim() == 1, "q_weight must be 1D [head_dim]");
+  TORCH_CHECK(k_weight.dim() == 1, "k_weight must be 1D [head_dim]");
+  TORCH_CHECK(q_weight.size(0) == inferred_head_dim, "q_weight size must match head_dim");
+  TORCH_CHECK(k_weight.size(0) == inferred_head_dim, "k_weight size must match head_dim");
+  TORCH_CHECK(cos_sin_cache.dim() == 2, "cos_sin_cache must be 2D [max_position, rope_dim]");
+  const int64_t inferred_rope_dim = cos_sin_cache.size(1);
+  if (head_dim != 0) TORCH_CHECK(head_dim == inferred_head_dim, "head_dim must match q/k hidden size, got ", head_dim, " vs ", inferred_head_dim);
+  if (rope_dim != 0) TORCH_CHECK(rope_dim == inferred_rope_dim, "rope_dim must match cos_sin_cache width, got ", rope_dim, " vs ", inferred_rope_dim);
+  TORCH_CHECK(inferred_rope_dim % 2 == 0, "rope_dim must be even");
+  TORCH_CHECK(inferred_rope_dim <= inferred_head_dim, "rope_dim must be <= head_dim");
+  TORCH_CHECK(positions.dim() == 1, "positions must be 1D [num_tokens]");
+  TORCH_CHECK(positions.size(0) == tq, "positions size must match flattened q/k tokens");
+  TORCH_CHECK(positions.scalar_type() == at::kInt || positions.scalar_type() == at::kLong,
+              "Unsupported dtype for fused_inplace_qknorm_rope positions: ", positions.scalar_type());
+  const at::ScalarType dt = q.scalar_type();
+  TORCH_CHECK(dt == at::kFloat || dt == at::kHalf || dt == at::kBFloat16, "Unsupported dtype for fused_inplace_qknorm_rope: ", dt);
+  const c10::OptionalDeviceGuard guard(q.device());
+  SGLK_CALL(sglk_fused_qknorm_rope_cache(stream_of(q), q.data_ptr(), k.data_ptr(), q_weight.data_ptr(), k_weight.data_ptr(),
+                                         cos_sin_cache.data_ptr<float>(), positions.data_ptr(),
+                                         positions.scalar_type() == at::kLong ? 1 : 0, tq, hq, hk, inferred_head_dim,
+                                         inferred_rope_dim, q_ts, q_hs, k_ts, k_hs, is_neox ? 1 : 0, (float)eps,
+                                         dtype_code(dt, "fused_inplace_qknorm_rope")));
+}
+
 // ---- rotary_embedding (reference src/sycl/Rope.cpp:453-471) -------------------------------------------------
 
 std::tuple<Tensor, Tensor> rotary_embedding(Tensor& positions, Tensor& query, Tensor& key, int64_t head_size,
@@ -1041,6 +1201,27 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "rotary_embedding(Tensor positions, Tensor query, Tensor key, int head_size, Tensor cos_sin_cache, "
       "bool is_neox) -> (Tensor, Tensor)");
   m.impl("rotary_embedding", c10::kCUDA, &rotary_embedding);
+
+  // reference src/torch_extension_sycl.cc:122-125
+  m.def(
+      "store_cache(Tensor k, Tensor v, Tensor(a!) k_cache, Tensor(b!) v_cache, "
+      "Tensor indices) -> ()");
+  m.impl("store_cache", c10::kCUDA, &store_cache);
+  // reference src/torch_extension_sycl.cc:232-235
+  m.def("merge_state_v2(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor! v_merged, Tensor! s_merged) -> ()");
+  m.impl("merge_state_v2", c10::kCUDA, &merge_state_v2);
+  m.def("merge_state(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor! v_merged, Tensor! s_merged) -> ()");
+  m.impl("merge_state", c10::kCUDA, &merge_state);
+  // reference src/torch_extension_sycl.cc:416-424
+  m.def(
+      "fused_qk_norm_rope(Tensor! qkv, int num_heads_q, int num_heads_k, int num_heads_v, int head_dim, "
+      "float eps, Tensor! q_weight, Tensor! k_weight, float base, bool is_neox, Tensor! position_ids, "
+      "float factor, float low, float high, float attention_factor, int rotary_dim) -> ()");
+  m.impl("fused_qk_norm_rope", c10::kCUDA, &fused_qk_norm_rope);
+  m.def(
+      "fused_inplace_qknorm_rope(Tensor! q, Tensor! k, Tensor q_weight, Tensor k_weight, "
+      "Tensor cos_sin_cache, Tensor positions, bool is_neox, float eps, int head_dim=0, int rope_dim=0) -> ()");
+  m.impl("fused_inplace_qknorm_rope", c10::kCUDA, &fused_inplace_qknorm_rope);
 
   // authored: reference include/sgl_kernel_ops.h:581-586 + python/sgl_kernel/gemm.py:24-31
   m.def(
