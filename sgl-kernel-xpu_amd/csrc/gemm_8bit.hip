@@ -524,29 +524,25 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     voff_b[ii] = (uint32_t)(lane >> 3) * (uint32_t)ldb + (((lane & 7) ^ ((ii << 1) | ((lane >> 4) & 1))) << 4);
   const uint32_t voff_s = (uint32_t)tid * (uint32_t)sa_sm * 4u;
 
-  // DMA part 0..3 of K block kb of tile d into stage s: two 1-KiB pieces each (parts 0,1: rows of a; 2,3: rows of
-  // b^T); part 0 also carries the row scales
-  auto dma_part = [&](const TileDesc& d, int kb_, int s, int part) {
+  // LDS-DMA of K block kb of tile d into stage s, one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = rows
+  // of b^T, two pieces (sub 0, 1) each; (part 0, sub 2) = the block's row scales
+  auto dma_piece = [&](const TileDesc& d, int kb_, int s, int part, int sub) {
     const int kb = PROBE == 4 ? 0 : kb_;  // probe 4: every block re-fetches block 0 (L2 hits, no stores)
     char* base = smem + s * kStageBytes;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ii = (part & 1) * 2 + i;
-      const int piece = wave * 4 + ii;
-      if (part < 2) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pa, d.nrec_a),
-                                                 SGLK_LDS(base + piece * 1024), 16, voff_a[ii & 1],
-                                                 kb * BK + piece * 8 * (int)lda, 0, 0);
-      } else {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b),
-                                                 SGLK_LDS(base + kTileBytes + piece * 1024), 16, voff_b[ii],
-                                                 kb * BK + piece * 8 * (int)ldb, 0, 0);
-      }
-    }
-    if (part == 0) {
+    if (sub == 2) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s),
                                                SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, voff_s,
                                                kb * (int)sa_sk * 4, 0, 0);
+      return;
+    }
+    const int ii = (part & 1) * 2 + sub;
+    const int piece = wave * 4 + ii;
+    if (part < 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pa, d.nrec_a), SGLK_LDS(base + piece * 1024), 16,
+                                               voff_a[ii & 1], kb * BK + piece * 8 * (int)lda, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b), SGLK_LDS(base + kTileBytes + piece * 1024),
+                                               16, voff_b[ii], kb * BK + piece * 8 * (int)ldb, 0, 0);
     }
   };
 
@@ -559,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   // stores: lane (j, g) owns row wm*128 + mf*16 + j, columns wn*64 + h*32 + g*8 .. +7 (h = 0, 1) of the tile
   const uint32_t orow_off_full = (uint32_t)(((int64_t)(wm * 128 + j) * ldc + wn * 64 + g * 8) * (int64_t)sizeof(OutT));
   const uint32_t orow_off_half = (uint32_t)(((int64_t)(wm * 64 + j) * ldc + wn * 64 + g * 8) * (int64_t)sizeof(OutT));
-  auto store_rows = [&](const TileDesc& d, const v4f (&accm)[4], int mf) {
+  auto store_rows = [&](const TileDesc& d, const float (&accm)[4][4], int mf) {
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
     const int soff = __builtin_amdgcn_readfirstlane(mf * 16 * (int)ldc * (int)sizeof(OutT));
     const uint32_t orow_off = MS == 8 ? orow_off_full : orow_off_half;
@@ -582,73 +578,113 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     }
   };
 
-  v4f acc[8][4];
+  // Accumulators as scalars: the promotion FMAs below are inline asm on single registers.
+  float acc[8][4][4];
 #pragma unroll
   for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mf][nf][r] = 0.f;
 
-  // LDS reads of the main loop are inline asm: their order relative to the MFMAs is the point of this kernel and
-  // the optimiser is free to hoist plain loads. The waits are therefore counted by hand; every wait names the
-  // registers it releases so that their consumers stay below it.
+  // The main loop is written as a fixed instruction stream: LDS reads, MFMAs and the block-scale FMAs are inline asm
+  // (asm volatile statements keep their order; the compiler only allocates registers), the waits are counted by hand
+  // and every wait names the registers it releases so that their consumers stay below it.
+  //  * an m-step is four slots "MFMA; 4 x v_fma (promotion of the PREVIOUS m-step's partial of the same n-fragment);
+  //    one LDS read or LDS-DMA piece": no FMA waits on an MFMA issued less than an m-step (>= 4 MFMAs) earlier, so an
+  //    in-order wave never idles on MFMA latency and the compiler's MFMA -> VALU hazard nops have nothing to cover.
+  //    (The first version issued 4 MFMAs and then their 16 dependent FMAs: both waves of a SIMD stalled on their own
+  //    results at the same time and the matrix pipe was busy 53 % of the block; measured per wave with s_memtime:
+  //    2700 / 3450 cycles per K block for the older / younger wave of a SIMD against 2048 of MFMA time.)
+  //  * the promotion runs one m-step behind across K blocks and tiles: step 0 of a block promotes the last m-step of the
+  //    block before (cur[] and scp carry it), the kernel's tail promotes the very last one.
+  //  * the first K block of a tile stores the finished tile's rows 2s, 2s+1 in m-step s and zeroes them; row MS-1 of
+  //    the finished tile is completed by that block's step 0 and stored in step (MS-1)/2.
 #define SGLK_RD16(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define SGLK_RD4(dst, addr, imm) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define SGLK_FRAG(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
+// cur[cb][nf] = n-fragment nf x m-fragment buffer mb (zero C: the partial of ONE 128-deep block)
+#define SGLK_MFMA(cb, nf, mb)                                                                                  \
+  if constexpr (HW_SCALE)                                                                                      \
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"                   \
+                 : "=&v"(cur[cb][nf])                                                                          \
+                 : "v"(SGLK_FRAG(nlo[nf], nhi[nf])), "v"(SGLK_FRAG(mlo[mb], mhi[mb])), "v"(one_e8m0));         \
+  else                                                                                                         \
+    asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, 0"                                                   \
+                 : "=&v"(cur[cb][nf])                                                                          \
+                 : "v"(SGLK_FRAG(nlo[nf], nhi[nf])), "v"(SGLK_FRAG(mlo[mb], mhi[mb])));
+// acc[row][nf][:] += cur[cb][nf][:] * scp
+#define SGLK_PROMOTE(row, cb, nf)                                                                              \
+  _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                             \
+      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[row][nf][r_]) : "v"(cur[cb][nf][r_]), "v"(scp));
 
   v4i nlo[4], nhi[4], mlo[2], mhi[2];
   float raw[2];
   float sbv;
+  v4f cur[2][4];    // partials of the running (mf & 1) and the previous m-step
+  float scp = 0.f;  // row scale x column-block scale of the previous m-step
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) cur[1][nf] = (v4f){0.f, 0.f, 0.f, 0.f};  // (the first step 0 promotes nothing)
+  int one_e8m0 = 127;  // E8M0 2^0 for both operands of the MX-encoded MFMA
+  asm volatile("" : "+v"(one_e8m0), "+v"(scp), "+v"(cur[1][0]), "+v"(cur[1][1]), "+v"(cur[1][2]), "+v"(cur[1][3]));
   int gblk = 0;  // K blocks done so far by this workgroup: its parity is the running LDS stage
 
-  // One K block of a tile with MS m-steps (8: 256-row tile, 4: 128-row half tile). d1/kb1, d2/kb2: blocks +1 and
-  // +2 of the pipeline (possibly in the next unit, whose format may differ: its per-wave row block comes from the
-  // descriptor). FIRST: first block of a unit (stores unit `prv`, which is always a whole tile or nothing, and
-  // restarts the accumulators).
-#define SGLK_MMA_STEP(mf, FIRST, MS_)                                                                             \
-    const float sc = raw[(mf) & 1] * sbv;                                                                      \
-    const v8i mfrag = SGLK_FRAG(mlo[(mf) & 1], mhi[(mf) & 1]);                                                 \
-    v4f cur4[4];                                                                                               \
-    _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
-        cur4[nf] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[nf], nhi[nf]), mfrag, zero);                              \
-    if (FIRST && 2 * (mf) + 1 < (MS_)) {                                                                       \
-      store_rows(prv, acc[2 * (mf)], 2 * (mf));                                                                \
-      store_rows(prv, acc[2 * (mf) + 1], 2 * (mf) + 1);                                                        \
-    }                                                                                                          \
-    _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                           \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                          \
-            acc[mf][nf][r] = FIRST ? cur4[nf][r] * sc : __builtin_fmaf(cur4[nf][r], sc, acc[mf][nf][r]);
-#define SGLK_STEP(mf, FIRST, MS)                                                                               \
+  // m-step mf < MS - 1 of a K block (see above). Reads for m-fragment mf + 1 go out first (the buffer they land in was
+  // last read by the MFMAs of step mf - 1, all issued), then fragment mf is waited for.
+#define SGLK_STEP(mf, STORE, MS)                                                                               \
   if constexpr ((mf) < (MS) - 1) {                                                                             \
-    SGLK_RD16(mlo[((mf) + 1) & 1], a_lo, ((mf) + 1) * 2048);                                                   \
-    SGLK_RD16(mhi[((mf) + 1) & 1], a_hi, ((mf) + 1) * 2048);                                                   \
-    SGLK_RD4(raw[((mf) + 1) & 1], ts_addr, ((mf) + 1) * 64);                                                   \
-    if (kDma && (mf) < 2) dma_part(d1, kb1, s ^ 1, (mf) + 2);                                                  \
+    constexpr int cb_ = (mf) & 1, pb_ = cb_ ^ 1, prow_ = ((mf) + (MS) - 1) % (MS);                             \
+    SGLK_RD16(mlo[pb_], a_lo, ((mf) + 1) * 2048);                                                              \
+    SGLK_RD16(mhi[pb_], a_hi, ((mf) + 1) * 2048);                                                              \
+    SGLK_RD4(raw[pb_], ts_addr, ((mf) + 1) * 64);                                                              \
     if ((mf) == 0) {                                                                                           \
-      asm volatile("s_waitcnt lgkmcnt(3)"                                                                      \
-                   : "+v"(nlo[0]), "+v"(nhi[0]), "+v"(nlo[1]), "+v"(nhi[1]), "+v"(nlo[2]), "+v"(nhi[2]),       \
-                     "+v"(nlo[3]), "+v"(nhi[3]), "+v"(mlo[0]), "+v"(mhi[0]), "+v"(raw[0]));                    \
+      asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(nlo[0]), "+v"(nhi[0]), "+v"(mlo[0]), "+v"(mhi[0]), "+v"(raw[0])); \
     } else {                                                                                                   \
-      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(mlo[(mf) & 1]), "+v"(mhi[(mf) & 1]), "+v"(raw[(mf) & 1]));   \
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(mlo[cb_]), "+v"(mhi[cb_]), "+v"(raw[cb_]));                   \
     }                                                                                                          \
-    SGLK_MMA_STEP(mf, FIRST, MS)                                                                               \
+    const float sc_ = raw[cb_] * sbv;                                                                          \
+    if constexpr (STORE && 2 * (mf) + 1 < (MS)) {                                                              \
+      constexpr int r0_ = 2 * (mf) + 1 < (MS) ? 2 * (mf) : 0, r1_ = r0_ + 1; /* (in range also when discarded) */ \
+      store_rows(prv, acc[r0_], r0_);                                                                          \
+      store_rows(prv, acc[r1_], r1_);                                                                          \
+      _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) _Pragma("unroll") for (int r = 0; r < 4; ++r) {         \
+        acc[r0_][nf][r] = 0.f;                                                                                 \
+        acc[r1_][nf][r] = 0.f;                                                                                 \
+      }                                                                                                        \
+      asm volatile("" : "+v"(acc[r0_][0][0]), "+v"(acc[r1_][0][0]));                                           \
+    }                                                                                                          \
+    SGLK_MFMA(cb_, 0, cb_)                                                                                     \
+    SGLK_PROMOTE(prow_, pb_, 0)                                                                                \
+    if ((mf) == 0) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(nlo[1]), "+v"(nhi[1]));                          \
+    SGLK_MFMA(cb_, 1, cb_)                                                                                     \
+    SGLK_PROMOTE(prow_, pb_, 1)                                                                                \
+    if (kDma && (mf) < 3) dma_piece(d1, kb1, s ^ 1, (mf) + 1, 0);                                              \
+    if ((mf) == 0) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(nlo[2]), "+v"(nhi[2]));                          \
+    SGLK_MFMA(cb_, 2, cb_)                                                                                     \
+    SGLK_PROMOTE(prow_, pb_, 2)                                                                                \
+    if ((mf) == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(nlo[3]), "+v"(nhi[3]));                          \
+    SGLK_MFMA(cb_, 3, cb_)                                                                                     \
+    SGLK_PROMOTE(prow_, pb_, 3)                                                                                \
+    if (kDma && (mf) < 3) dma_piece(d1, kb1, s ^ 1, (mf) + 1, 1);                                              \
+    scp = sc_;                                                                                                 \
+    asm volatile("" : "+v"(scp));                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
-#define SGLK_BLOCK(FIRST, MS)                                                                                  \
+#define SGLK_BLOCK(STORE, MS)                                                                                  \
   {                                                                                                            \
     const int s = gblk & 1;                                                                                    \
     const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);                                             \
     const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStageBytes);                                       \
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};                                                                     \
     const bool in1 = kb + 1 < nkb, in2 = kb + 2 < nkb;                                                         \
-    const TileDesc d1 = pick(in1, cur, nxt), d2 = pick(in2, cur, nxt);                                         \
+    const TileDesc d1 = pick(in1, cur_t, nxt), d2 = pick(in2, cur_t, nxt);                                     \
     const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
     {                                                                                                          \
       int fo = frag_off_a;                                                                                     \
       asm volatile("" : "+v"(fo));                                                                             \
       const uint32_t a_lo = sbase + (uint32_t)(wm * ((MS) * 16) * 128) + (uint32_t)fo, a_hi = a_lo ^ 64u;       \
       const uint32_t ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * ((MS) * 16) * 4) + (uint32_t)((fo >> 7) << 2); \
-      SGLK_STEP(0, FIRST, MS) SGLK_STEP(1, FIRST, MS) SGLK_STEP(2, FIRST, MS) SGLK_STEP(3, FIRST, MS)          \
-      SGLK_STEP(4, FIRST, MS) SGLK_STEP(5, FIRST, MS) SGLK_STEP(6, FIRST, MS)                                  \
+      SGLK_STEP(0, STORE, MS) SGLK_STEP(1, STORE, MS) SGLK_STEP(2, STORE, MS) SGLK_STEP(3, STORE, MS)          \
+      SGLK_STEP(4, STORE, MS) SGLK_STEP(5, STORE, MS) SGLK_STEP(6, STORE, MS)                                  \
     }                                                                                                          \
     /* the block's barrier: next block landed everywhere, nobody reads stage s any more */                    \
     float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
@@ -660,9 +696,9 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
       const uint32_t t2 = (uint32_t)__builtin_amdgcn_s_memtime();                                              \
       const int w_ = gblk - 40;                                                                                \
       const int sl_ = (w_ >= 0 && w_ < 20) ? w_ * 3 : 61;                                                      \
-      stampv = (lane == sl_) ? t0 : stampv;                                                    \
-      stampv = (lane == sl_ + 1) ? t1 : stampv;                                                \
-      stampv = (lane == sl_ + 2) ? t2 : stampv;                                                \
+      stampv = (lane == sl_) ? t0 : stampv;                                                                    \
+      stampv = (lane == sl_ + 1) ? t1 : stampv;                                                                \
+      stampv = (lane == sl_ + 2) ? t2 : stampv;                                                                \
     } else {                                                                                                   \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                \
                    : "+v"(mlo[1]), "+v"(mhi[1]), "+v"(raw[1])                                                  \
@@ -671,55 +707,59 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     }                                                                                                          \
     asm volatile("" : "+v"(sbv_next));                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
-    /* last m-step, overlapped with the next block's first LDS reads */                                       \
+    /* last m-step: its slots carry the first LDS reads of the next block (each n-fragment into the registers */ \
+    /* the MFMA just issued has consumed) and the first DMA pieces of the block after it                      */ \
     {                                                                                                          \
       constexpr int kLast = (MS) - 1;                                                                          \
-      const float sc = raw[1] * sbv;                                                                           \
+      const float sc_ = raw[1] * sbv;                                                                          \
       int foa = frag_off_a, fob = frag_off_b;                                                                  \
       asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
-      const uint32_t nb_lo = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fob, nb_hi = nb_lo ^ 64u; \
-      const uint32_t na_lo = nbase + (uint32_t)(wm * d1.wrows * 128) + (uint32_t)foa, na_hi = na_lo ^ 64u;     \
-      const uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * d1.wrows * 4) + (uint32_t)((foa >> 7) << 2); \
-      const v8i mfrag = SGLK_FRAG(mlo[1], mhi[1]);                                                             \
-      v4f cur4[4];                                                                                             \
-      cur4[0] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[0], nhi[0]), mfrag, zero);                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      uint32_t nb_lo = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fob, nb_hi = nb_lo ^ 64u;   \
+      uint32_t na_lo = nbase + (uint32_t)(wm * d1.wrows * 128) + (uint32_t)foa, na_hi = na_lo ^ 64u;           \
+      uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * d1.wrows * 4) + (uint32_t)((foa >> 7) << 2);    \
+      asm volatile("" : "+v"(nb_lo), "+v"(nb_hi), "+v"(na_lo), "+v"(na_hi), "+v"(nts));                        \
+      SGLK_MFMA(1, 0, 1)                                                                                       \
+      SGLK_PROMOTE(kLast - 1, 0, 0)                                                                            \
       SGLK_RD16(nlo[0], nb_lo, kNfImm[0]);  SGLK_RD16(nhi[0], nb_hi, kNfImm[0]);                               \
       SGLK_RD16(mlo[0], na_lo, 0);          SGLK_RD16(mhi[0], na_hi, 0);                                       \
       SGLK_RD4(raw[0], nts, 0);                                                                                \
-      cur4[1] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[1], nhi[1]), mfrag, zero);                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      SGLK_MFMA(1, 1, 1)                                                                                       \
+      SGLK_PROMOTE(kLast - 1, 0, 1)                                                                            \
       SGLK_RD16(nlo[1], nb_lo, kNfImm[1]);  SGLK_RD16(nhi[1], nb_hi, kNfImm[1]);                               \
-      if (kDma) dma_part(d2, kb2, s, 0);                                                                       \
-      cur4[2] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[2], nhi[2]), mfrag, zero);                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if (kDma) dma_piece(d2, kb2, s, 0, 0);                                                                   \
+      SGLK_MFMA(1, 2, 1)                                                                                       \
+      SGLK_PROMOTE(kLast - 1, 0, 2)                                                                            \
       SGLK_RD16(nlo[2], nb_lo, kNfImm[2]);  SGLK_RD16(nhi[2], nb_hi, kNfImm[2]);                               \
-      if (kDma) dma_part(d2, kb2, s, 1);                                                                       \
-      cur4[3] = mfma_k128<HW_SCALE>(SGLK_FRAG(nlo[3], nhi[3]), mfrag, zero);                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      if (kDma) dma_piece(d2, kb2, s, 0, 1);                                                                   \
+      SGLK_MFMA(1, 3, 1)                                                                                       \
+      SGLK_PROMOTE(kLast - 1, 0, 3)                                                                            \
       SGLK_RD16(nlo[3], nb_lo, kNfImm[3]);  SGLK_RD16(nhi[3], nb_hi, kNfImm[3]);                               \
-      _Pragma("unroll") for (int nf = 0; nf < 4; ++nf)                                                         \
-          _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                        \
-              acc[kLast][nf][r] = FIRST ? cur4[nf][r] * sc : __builtin_fmaf(cur4[nf][r], sc, acc[kLast][nf][r]); \
+      if (kDma) dma_piece(d2, kb2, s, 0, 2);                                                                   \
+      scp = sc_;                                                                                               \
       sbv = sbv_next;                                                                                          \
+      asm volatile("" : "+v"(scp));                                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
     ++gblk;                                                                                                    \
   }
 
   int unit = 0;
-  TileDesc cur = describe(0);
+  TileDesc cur_t = describe(0);
   TileDesc prv = describe(n_units);  // the null tile: nothing to store yet
-  // ---- prologue: block 0 of the first unit lands, its resident fragments are read, parts 0, 1 of block 1 go out
+  // ---- prologue: block 0 of the first unit lands, its resident fragments are read, part 0 of block 1 goes out
 #pragma unroll
-  for (int part = 0; part < 4; ++part) dma_part(cur, 0, 0, part);
-  sbv = cur.sbw[0];
+  for (int part = 0; part < 4; ++part) {
+    dma_piece(cur_t, 0, 0, part, 0);
+    dma_piece(cur_t, 0, 0, part, 1);
+  }
+  dma_piece(cur_t, 0, 0, 0, 2);
+  sbv = cur_t.sbw[0];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   asm volatile("" : "+v"(sbv));
   {
     const uint32_t b_lo = lds_base + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)frag_off_b, b_hi = b_lo ^ 64u;
-    const uint32_t a_lo = lds_base + (uint32_t)(wm * cur.wrows * 128) + (uint32_t)frag_off_a, a_hi = a_lo ^ 64u;
-    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * cur.wrows * 4) + (uint32_t)(j << 2);
+    const uint32_t a_lo = lds_base + (uint32_t)(wm * cur_t.wrows * 128) + (uint32_t)frag_off_a, a_hi = a_lo ^ 64u;
+    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * cur_t.wrows * 4) + (uint32_t)(j << 2);
     SGLK_RD16(nlo[0], b_lo, kNfImm[0]);  SGLK_RD16(nhi[0], b_hi, kNfImm[0]);
     SGLK_RD16(mlo[0], a_lo, 0);          SGLK_RD16(mhi[0], a_hi, 0);
     SGLK_RD4(raw[0], ts0, 0);
@@ -728,8 +768,9 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     SGLK_RD16(nlo[3], b_lo, kNfImm[3]);  SGLK_RD16(nhi[3], b_hi, kNfImm[3]);
   }
   if (kDma) {
-    dma_part(cur, 1, 1, 0);
-    dma_part(cur, 1, 1, 1);
+    dma_piece(cur_t, 1, 1, 0, 0);
+    dma_piece(cur_t, 1, 1, 0, 1);
+    dma_piece(cur_t, 1, 1, 0, 2);
   }
 
   for (; unit < n_units; ++unit) {
@@ -739,19 +780,22 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
       SGLK_BLOCK(true, MS)
     }
     for (int kb = 1; kb < nkb; ++kb) SGLK_BLOCK(false, MS)
-    prv = cur;
-    cur = nxt;
+    prv = cur_t;
+    cur_t = nxt;
   }
 #undef SGLK_BLOCK
 #undef SGLK_STEP
-#undef SGLK_MMA_STEP
-  // the reads and DMA issued by the last step have no consumer: drain them, then store the last unit
+  // the reads and DMA issued by the last step have no consumer: drain them; promote the last m-step; store the last unit
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(cur[1][0]), "+v"(cur[1][1]), "+v"(cur[1][2]), "+v"(cur[1][3]));  // (MFMA -> VALU)
+  SGLK_PROMOTE(MS - 1, 1, 0) SGLK_PROMOTE(MS - 1, 1, 1) SGLK_PROMOTE(MS - 1, 1, 2) SGLK_PROMOTE(MS - 1, 1, 3)
 #pragma unroll
   for (int mf = 0; mf < MS; ++mf) store_rows(prv, acc[mf], mf);
   if constexpr (PROBE == 5) {
     if (stamps != nullptr && gblk >= 60) stamps[((int64_t)blockIdx.x * 8 + wave) * 64 + lane] = stampv;  // (window complete)
   }
+#undef SGLK_PROMOTE
+#undef SGLK_MFMA
 #undef SGLK_RD16
 #undef SGLK_RD4
 #undef SGLK_FRAG

@@ -23,9 +23,13 @@ from sgl_kernel.attention import (  # noqa: E402
     flash_mla_get_workspace_size,
     flash_mla_prefill,
     flash_mla_prefill_get_workspace_size,
+    merge_state,
+    merge_state_v2,
 )
 from sgl_kernel.elementwise import (  # noqa: E402
     fused_add_rmsnorm,
+    fused_inplace_qknorm_rope,
+    fused_qk_norm_rope,
     gelu_and_mul,
     gelu_tanh_and_mul,
     gemma_fused_add_rmsnorm,
@@ -33,6 +37,8 @@ from sgl_kernel.elementwise import (  # noqa: E402
     rmsnorm,
     rotary_embedding,
     silu_and_mul,
+    store_cache,
+    store_cache_xpu,
 )
 from sgl_kernel.flash_attn import flash_attn_varlen_func, flash_attn_with_kvcache, is_fa3_supported  # noqa: E402
 from sgl_kernel.gemm import (  # noqa: E402
@@ -66,10 +72,10 @@ _OUT_OF_SCOPE = frozenset(
     """
     bmm_fp8 cutlass_scaled_fp4_mm scaled_fp4_experts_quant scaled_fp4_quant
     sgl_per_token_group_quant_fp4
-    merge_state merge_state_v2 lightning_attention_decode flash_mla_sparse_fwd flash_mla_with_kvcache
-    apply_rope_with_cos_sin_cache_inplace fused_inplace_qknorm_rope fused_k_norm_rope_flashmla
-    fused_q_norm_rope fused_qk_norm_rope fused_qk_rope fused_qk_rope_with_cos_sin_cache_inplace
-    multimodal_rotary_embedding silu_and_mul_clamp store_cache_xpu
+    lightning_attention_decode flash_mla_sparse_fwd flash_mla_with_kvcache
+    apply_rope_with_cos_sin_cache_inplace fused_k_norm_rope_flashmla
+    fused_q_norm_rope fused_qk_rope fused_qk_rope_with_cos_sin_cache_inplace
+    multimodal_rotary_embedding silu_and_mul_clamp
     biased_topk cutlass_fp4_group_mm fp8_blockwise_scaled_grouped_mm hash_topk moe_fused_gate moe_sum
     moe_sum_reduce swiglu_gpt_oss_sigmoid_alpha topk_sigmoid
     min_p_sampling_from_probs top_k_renorm_prob top_k_top_p_sampling_from_probs top_p_renorm_prob

@@ -12,6 +12,7 @@ stride is copied), the reference's pad-to-128-heads CUDA branch (:86-93) and its
 prefill (:212-217: its epilogue writes whole tiles, this one writes exactly total_q rows) do not exist here.
 """
 from dataclasses import dataclass
+from typing import Optional, Tuple
 
 import torch
 
@@ -54,6 +55,30 @@ def _check_int32(who, **tensors):
 def _check_positive(who, **values):
     for name, v in values.items():
         assert v > 0, f"{who}: {name} must be greater than 0, got {v}"
+
+
+def _merge(op_name, v_a, s_a, v_b, s_b, v_merged, s_merged):
+    s_a, s_b = s_a.to(torch.float32), s_b.to(torch.float32)
+    v_merged = torch.empty_like(v_a) if v_merged is None else v_merged
+    s_merged = torch.empty_like(s_a) if s_merged is None else s_merged
+    getattr(_ops, op_name).default(v_a, s_a, v_b, s_b, v_merged, s_merged)
+    return v_merged, s_merged
+
+
+def merge_state(v_a: torch.Tensor, s_a: torch.Tensor, v_b: torch.Tensor, s_b: torch.Tensor,
+                v_merged: Optional[torch.Tensor] = None,
+                s_merged: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge two partial attention states over disjoint key sets: v [tokens, heads, d] normalised outputs, s
+    [tokens, heads] log-sum-exp in BASE 2 (the flashinfer convention; reference attention.py:12-28). Outputs are
+    allocated unless given."""
+    return _merge("merge_state", v_a, s_a, v_b, s_b, v_merged, s_merged)
+
+
+def merge_state_v2(v_a: torch.Tensor, s_a: torch.Tensor, v_b: torch.Tensor, s_b: torch.Tensor,
+                   v_merged: Optional[torch.Tensor] = None,
+                   s_merged: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The same merge with natural-log s (what `fwd` returns as softmax_lse; reference attention.py:31-51)."""
+    return _merge("merge_state_v2", v_a, s_a, v_b, s_b, v_merged, s_merged)
 
 
 def _inner_unit_stride(t):

@@ -108,3 +108,38 @@ def rotary_embedding(
     [tokens, heads*head_size] are rotated in place and returned; 3-D [tokens, heads, head_size] inputs give new
     tensors (rot_dim must equal head_size there). cos_sin_cache [max_pos, rot_dim] must have query's dtype."""
     return torch.ops.sgl_kernel.rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox)
+
+
+# ---- attention prologue ops (SURVEY 8f rank 3): reference elementwise.py:143-200, :288-317, :372-462 ----------
+
+def fused_inplace_qknorm_rope(q: torch.Tensor, k: torch.Tensor, q_weight: torch.Tensor, k_weight: torch.Tensor,
+                              cos_sin_cache: torch.Tensor, positions: torch.Tensor, is_neox: bool, eps: float = 1e-6,
+                              head_dim: int = 0, rope_dim: int = 0) -> None:
+    """In place on q [tokens, Hq, D] / k [tokens, Hk, D] (or 4-D [batch, seq, heads, D]; last dim contiguous):
+    per-head RMSNorm with q_weight / k_weight [D], then rotation of the first rope_dim elements by the fp32
+    cos_sin_cache row [max_pos, rope_dim] of each token's position. head_dim / rope_dim = 0: taken from the tensors."""
+    torch.ops.sgl_kernel.fused_inplace_qknorm_rope(q, k, q_weight, k_weight, cos_sin_cache, positions, is_neox, eps,
+                                                   head_dim, rope_dim)
+
+
+def fused_qk_norm_rope(qkv: torch.Tensor, num_heads_q: int, num_heads_k: int, num_heads_v: int, head_dim: int, eps: float,
+                       q_weight: torch.Tensor, k_weight: torch.Tensor, base: float, is_neox: bool,
+                       position_ids: torch.Tensor, factor: float = 1.0, low: float = 1.0, high: float = 1.0,
+                       attention_factor: float = 1.0, rotary_dim: int = None) -> None:
+    """In place on the packed qkv [tokens, (Hq + Hk + Hv) * head_dim]: per-head RMSNorm of the q and k heads, then
+    rotary embedding with angles position * base^(-2j / rotary_dim) (YaRN-blended when factor != 1, scaled by
+    attention_factor). V is untouched. rotary_dim defaults to head_dim; position_ids int32."""
+    torch.ops.sgl_kernel.fused_qk_norm_rope(qkv, num_heads_q, num_heads_k, num_heads_v, head_dim, eps, q_weight, k_weight,
+                                            base, is_neox, position_ids, factor, low, high, attention_factor,
+                                            head_dim if rotary_dim is None else rotary_dim)
+
+
+def store_cache_xpu(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                    indices: torch.Tensor) -> None:
+    """k_cache[indices[t]] = k[t], v_cache[indices[t]] = v[t] in one launch; k / v [tokens, row_dim] may be row-strided
+    views (rows contiguous), the caches are dense [cache_size, row_dim], indices[t] = -1 skips token t. (The name is the
+    reference's; `store_cache` is the same function.)"""
+    torch.ops.sgl_kernel.store_cache(k, v, k_cache, v_cache, indices.long())
+
+
+store_cache = store_cache_xpu

@@ -33,8 +33,25 @@ class _Stub(types.ModuleType):
         return _missing
 
 
+class _TritonStub(types.ModuleType):
+    """`import triton, triton.language as tl` of the reference tests: @triton.jit leaves the function alone (it is
+    never called here), tl.constexpr etc. are placeholders."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        if name == "jit":
+            return lambda fn=None, **kw: fn if fn is not None else (lambda f: f)
+        return object
+
+
 def _import_ref(name):
     sys.modules.setdefault("sgl_kernel", _Stub("sgl_kernel"))
+    if "triton" not in sys.modules:
+        tr = _TritonStub("triton")
+        tr.language = _TritonStub("triton.language")
+        sys.modules["triton"] = tr
+        sys.modules["triton.language"] = tr.language
     if REF_TESTS not in sys.path:
         sys.path.insert(0, REF_TESTS)
     return importlib.import_module(name)
@@ -65,17 +82,38 @@ def gen_norm():
 
 
 def gen_activation():
-    # tests/test_activation.py:18,28,38 are inline expressions; evaluate those expressions here
-    import torch.nn.functional as F
+    """The reference's expected values are inline expressions inside its test functions (tests/test_activation.py:18,
+    28, 38), so the TEST FUNCTIONS THEMSELVES are run here: the stub op returns a marker, and the test's own
+    torch.testing.assert_close call is intercepted to capture (input, expected)."""
+    t = _import_ref("test_activation")
+    stub = sys.modules["sgl_kernel"]
     cases = []
-    g = torch.Generator().manual_seed(1)
-    for shape, dt in [((2, 4, 256), torch.float16), ((3, 1, 1024), torch.float16), ((5, 2, 4096), torch.bfloat16)]:
-        x = torch.randn(*shape, generator=g).to(dt)
-        d = shape[-1] // 2
-        cases.append(dict(x=x,
-                          silu=x[..., d:] * F.silu(x[..., :d]),
-                          gelu_tanh=x[..., d:] * F.gelu(x[..., :d], approximate="tanh"),
-                          gelu=x[..., d:] * F.gelu(x[..., :d], approximate="none")))
+    for dim, batch, seq in [(128, 2, 4), (512, 3, 1), (2048, 1, 8), (11008, 2, 2)]:
+        case = {}
+        for key, test_fn, op in (("silu", t.test_fused_silu_mul, "silu_and_mul"),
+                                 ("gelu_tanh", t.test_fused_gelu_tanh_mul, "gelu_tanh_and_mul"),
+                                 ("gelu", t.test_fused_gelu_mul, "gelu_and_mul")):
+            seen = {}
+
+            def fake_op(x, _seen=seen):
+                _seen["x"] = x.clone()
+                return "marker"
+
+            def fake_close(expected, actual, **kw):
+                assert actual == "marker"
+                seen["expected"], seen["tol"] = expected.clone(), kw
+
+            setattr(stub, op, fake_op)
+            real = torch.testing.assert_close
+            torch.testing.assert_close = fake_close
+            try:
+                torch.manual_seed(dim + batch)
+                test_fn(dim, batch, seq)
+            finally:
+                torch.testing.assert_close = real
+                delattr(stub, op)
+            case[key] = dict(x=seen["x"].cpu(), out=seen["expected"].cpu(), rtol=seen["tol"]["rtol"], atol=seen["tol"]["atol"])
+        cases.append(case)
     save("activation", cases)
 
 
@@ -93,6 +131,81 @@ def gen_quant():
         cases.append(dict(x=x, group_size=gs, fp8_q=q8.view(torch.uint8), fp8_s=s8,
                           fp8_ue8m0_q=qu.view(torch.uint8), fp8_ue8m0_s=su, int8_q=qi, int8_s=si))
     save("quant", cases)
+
+
+def gen_quant_v2():
+    """tests/test_per_token_group_quant_8bit_v2.py:408-480: the v2 op's own torch references (fused silu * mul, UE8M0)."""
+    t = _import_ref("test_per_token_group_quant_8bit_v2")
+    cases = []
+    g = torch.Generator().manual_seed(7)
+    for rows, hidden, gs, ue, fuse in [(5, 512, 128, False, False), (9, 1024, 128, True, False), (6, 512, 64, False, True),
+                                       (4, 2048, 128, True, True), (3, 256, 32, False, False), (7, 128, 16, False, False)]:
+        width = hidden * (2 if fuse else 1)
+        x = torch.randn(rows, width, generator=g).to(torch.bfloat16)
+        q, s = t.per_token_group_quant_fp8_ref(x, gs, 1e-10, ue, fuse)
+        qi, si = t.per_token_group_quant_int8_ref(x[:, :hidden].contiguous(), gs, 1e-10)
+        cases.append(dict(x=x, group_size=gs, scale_ue8m0=ue, fuse_silu_and_mul=fuse, fp8_q=q.view(torch.uint8), fp8_s=s,
+                          int8_q=qi, int8_s=si))
+    save("quant_v2", cases)
+
+
+def gen_merge_state():
+    """tests/test_merge_state_v2.py:101-137 (merge_state_torch, natural log) on the test's own input recipe (:198-224:
+    randn lse with ~10 % of either side set to +inf, never both)."""
+    t = _import_ref("test_merge_state_v2")
+    cases = []
+    for tokens, heads, d, dt in [(64, 8, 32, torch.half), (37, 16, 48, torch.bfloat16), (33, 8, 128, torch.bfloat16),
+                                 (7, 8, 256, torch.half), (5, 4, 64, torch.float32)]:
+        torch.manual_seed(tokens + d)
+        s_a = torch.randn(tokens, heads)
+        s_b = torch.randn(tokens, heads)
+        ma, mb = torch.rand(tokens, heads) < 0.1, torch.rand(tokens, heads) < 0.1
+        both = ma & mb
+        s_a[ma & ~both] = float("inf")
+        s_b[mb & ~both] = float("inf")
+        v_a = torch.randn(tokens, heads, d).to(dt)
+        v_b = torch.randn(tokens, heads, d).to(dt)
+        out, lse = t.merge_state_torch(v_a.float(), s_a.clone(), v_b.float(), s_b.clone(), torch.empty_like(v_a, dtype=torch.float32),
+                                       torch.empty_like(s_a))
+        cases.append(dict(v_a=v_a, s_a=s_a, v_b=v_b, s_b=s_b, v_merged=out, s_merged=lse))
+    save("merge_state", cases)
+
+
+def gen_qknorm_rope():
+    """tests/test_fused_qk_norm_rope.py:104-218: fused_qk_norm_rope_reference (analytic / YaRN angles) and
+    fused_qk_norm_rope_with_cache_reference (cos_sin_cache from tests/test_rope_utils.py:create_cos_sin_cache)."""
+    t = _import_ref("test_fused_qk_norm_rope")
+    cases = {"yarn": [], "cache": []}
+    for tokens, hq, hk, hv, d, neox, dt, factor, low, high, af, rot in [
+            (7, 8, 8, 8, 64, True, torch.bfloat16, 1.0, 1.0, 1.0, 1.0, 64),
+            (9, 6, 2, 2, 128, False, torch.float16, 1.0, 1.0, 1.0, 1.0, 128),
+            (12, 4, 2, 2, 128, True, torch.bfloat16, 4.0, 1.0, 32.0, 1.2, 128),      # YaRN (:302-377)
+            (6, 4, 2, 2, 256, False, torch.bfloat16, 4.0, 1.0, 32.0, 1.2, 256),
+            (10, 4, 4, 2, 128, True, torch.bfloat16, 1.0, 1.0, 1.0, 1.0, 32),        # partial rotary (:380-455)
+            (10, 4, 4, 2, 128, False, torch.bfloat16, 1.0, 1.0, 1.0, 1.0, 64)]:
+        torch.manual_seed(42)
+        qkv = torch.randn(tokens, (hq + hk + hv) * d).to(dt)
+        qw, kw = torch.randn(d).to(dt), torch.randn(d).to(dt)
+        pos = torch.arange(tokens, dtype=torch.int32) * 3
+        out = t.fused_qk_norm_rope_reference(qkv.float(), hq, hk, hv, d, 1e-6, qw.float(), kw.float(), 10000.0, neox, pos,
+                                             factor, low, high, af, rot)
+        cases["yarn"].append(dict(qkv=qkv, Hq=hq, Hk=hk, Hv=hv, head_dim=d, eps=1e-6, q_weight=qw, k_weight=kw, base=10000.0,
+                                  is_neox=neox, position_ids=pos, factor=factor, low=low, high=high, attention_factor=af,
+                                  rotary_dim=rot, out=out))
+    for tokens, hq, hk, d, rope, neox, dt, pdt in [(3, 4, 2, 64, 32, False, torch.bfloat16, torch.int32),
+                                                   (5, 8, 4, 128, 64, True, torch.float16, torch.int64),
+                                                   (8, 6, 2, 128, 128, False, torch.bfloat16, torch.int32),
+                                                   (4, 8, 2, 256, 128, True, torch.float16, torch.int64),
+                                                   (6, 4, 4, 64, 8, True, torch.bfloat16, torch.int32)]:
+        torch.manual_seed(42)
+        q, k = torch.randn(tokens, hq, d).to(dt), torch.randn(tokens, hk, d).to(dt)
+        qw, kw = torch.randn(d).to(dt), torch.randn(d).to(dt)
+        pos = torch.randperm(tokens + 1)[:tokens].to(pdt)
+        cache = t.create_cos_sin_cache(rope, max_position=tokens + 1)
+        q_ref, k_ref = t.fused_qk_norm_rope_with_cache_reference(q.float(), k.float(), qw.float(), kw.float(), cache, pos, neox)
+        cases["cache"].append(dict(q=q, k=k, q_weight=qw, k_weight=kw, cos_sin_cache=cache, positions=pos, is_neox=neox,
+                                   q_out=q_ref, k_out=k_ref))
+    save("qknorm_rope", cases)
 
 
 def gen_fp8_blockwise():
@@ -305,6 +418,19 @@ def gen_moe():
         exp = t.torch_naive_moe(x, w1, w2, ids, tw, topk, b1, b2, activations=act, routed_scaling_factor=2.5)
         cases["fused16"].append(dict(x=x, w1=w1, w2=w2, topk_ids=ids, topk_weights=tw, b1=b1, b2=b2, activation=act,
                                      routed_scaling_factor=2.5, out=exp))
+    # Mixtral-shaped small-T case (E=8, top-2, group 128, routing through a softmax top-k as SGLang does; the hidden and
+    # intermediate widths are cut to keep the fixture small): torch_naive_moe on the dequantised weights
+    torch.manual_seed(11)
+    T, topk, E, H, I, gs = 3, 2, 8, 512, 256, 128
+    x = torch.randn(T, H, dtype=torch.bfloat16) * 0.1
+    w1, w1s, w1z, w1ref = t._make_int4_weight(E, 2 * I, H, gs, torch.bfloat16, False)
+    w2, w2s, w2z, w2ref = t._make_int4_weight(E, H, I, gs, torch.bfloat16, False)
+    score = torch.softmax(torch.randn(T, E, dtype=torch.bfloat16).float(), dim=-1)
+    tw, ids = torch.topk(score, topk)
+    tw = tw / tw.sum(dim=-1, keepdim=True)
+    exp = t.torch_naive_moe(x, w1ref, w2ref, ids, tw, topk, None, None, activations="silu")
+    cases["fused"].append(dict(x=x, w1=w1.view(torch.uint8), w2=w2.view(torch.uint8), w1_scale=w1s, w2_scale=w2s, w1_zp=None,
+                               w2_zp=None, topk_ids=ids, topk_weights=tw, b1=None, b2=None, activation="silu", out=exp))
     save("moe_w4a16", cases)
 
 
@@ -373,6 +499,9 @@ GENERATORS = {
     "quant_extra": gen_quant_extra,
     "norm": gen_norm,
     "activation": gen_activation,
+    "quant_v2": gen_quant_v2,
+    "merge_state": gen_merge_state,
+    "qknorm_rope": gen_qknorm_rope,
     "quant": gen_quant,
     "fp8_blockwise_gemm": gen_fp8_blockwise,
     "scaled_mm": gen_scaled_mm,

@@ -38,7 +38,7 @@ def test_activation_row_rule(sglk):
 
 
 def test_out_of_scope_names_raise_on_call_only(sglk):
-    f = sglk.merge_state
+    f = sglk.lightning_attention_decode
     with pytest.raises(NotImplementedError):
         f()
     with pytest.raises(AttributeError):

@@ -1,10 +1,14 @@
 """CPU: the oracle restatements against golden vectors produced by the reference's own
 torch-eager test references (tests/golden/make_golden.py). Tolerances are the
 reference tests' (cited per test)."""
+import math
+
 import torch
 from conftest import load_golden
 
 from oracle import activation as oact
+from oracle import attn_aux as oaux
+from oracle import qknorm_rope as oqk
 from oracle import gemm as ogemm
 from oracle import norm as onorm
 from oracle import quant as oquant
@@ -33,12 +37,12 @@ def test_norm_family_matches_reference_vectors():
 
 
 def test_activation_matches_reference_vectors():
+    # fixtures captured by RUNNING the reference's test functions (tests/test_activation.py:16-40): each entry holds the
+    # input the test built, the expected value it computed and the tolerance it asserted with
     for c in load_golden("activation"):
-        x = c["x"]
-        tol = dict(rtol=1e-3, atol=1e-3) if x.dtype == torch.float16 else dict(rtol=1e-2, atol=1e-2)
-        torch.testing.assert_close(oact.silu_and_mul(x), c["silu"], **tol)  # tests/test_activation.py:20
-        torch.testing.assert_close(oact.gelu_tanh_and_mul(x), c["gelu_tanh"], **tol)
-        torch.testing.assert_close(oact.gelu_and_mul(x), c["gelu"], **tol)
+        for key, fn in (("silu", oact.silu_and_mul), ("gelu_tanh", oact.gelu_tanh_and_mul), ("gelu", oact.gelu_and_mul)):
+            e = c[key]
+            torch.testing.assert_close(fn(e["x"]), e["out"], rtol=e["rtol"], atol=e["atol"])
 
 
 def test_quant_matches_reference_vectors():
@@ -219,3 +223,60 @@ def test_fused_experts_16bit_oracle_matches_torch_naive_moe():
                                        c["activation"], c["routed_scaling_factor"])
         torch.testing.assert_close(out.float(), c["out"].float(), rtol=1e-1, atol=2e-2)
         torch.testing.assert_close(out.float(), c["out"].float(), rtol=3e-2, atol=3e-3)
+
+
+def test_quant_v2_matches_reference_vectors():
+    """oracle.quant.per_token_group_quant_8bit_v2 vs the v2 test's own references
+    (reference tests/test_per_token_group_quant_8bit_v2.py:408-480), incl. the fused silu * mul input and UE8M0 scales."""
+    for c in load_golden("quant_v2"):
+        x, gs = c["x"], c["group_size"]
+        q, s, ue, _ = oquant.per_token_group_quant_8bit_v2(x, gs, torch.float8_e4m3fn, scale_ue8m0=c["scale_ue8m0"],
+                                                           fuse_silu_and_mul=c["fuse_silu_and_mul"])
+        ref_q = c["fp8_q"].view(torch.float8_e4m3fn).float()
+        if c["scale_ue8m0"]:
+            assert torch.equal(ue.to(torch.int32), c["fp8_s"].to(torch.int32))  # exponent bytes, exact
+            scale = torch.pow(2.0, c["fp8_s"].float() - 127.0)
+        else:
+            torch.testing.assert_close(s, c["fp8_s"], rtol=1e-6, atol=0)
+            scale = c["fp8_s"]
+        # same acceptance as the reference (dequantised values, :599-629): a code may differ by one fp8 step where the
+        # fused silu is rounded differently
+        deq = q.float() * s.repeat_interleave(gs, dim=-1)
+        ref = ref_q * scale.repeat_interleave(gs, dim=-1)
+        torch.testing.assert_close(deq, ref, rtol=0.13, atol=1e-2 if c["fuse_silu_and_mul"] else 1e-6)
+        if not c["fuse_silu_and_mul"]:
+            # the two only differ where x*(1/s) and x/s round to different fp8 codes (1 ulp), as for v1 above
+            assert (q.view(torch.uint8) != c["fp8_q"]).float().mean() < 0.02
+            qi, si, _, _ = oquant.per_token_group_quant_8bit_v2(x, gs, torch.int8)
+            torch.testing.assert_close(si, c["int8_s"], rtol=1e-6, atol=0)
+            assert (qi.int() - c["int8_q"].int()).abs().max() <= 1
+
+
+def test_merge_state_matches_reference_vectors():
+    ln2 = math.log(2.0)
+    for c in load_golden("merge_state"):
+        v, s = oaux.merge_state(c["v_a"], c["s_a"], c["v_b"], c["s_b"], base2=False)
+        tol = dict(rtol=1e-5, atol=1e-5) if c["v_a"].dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(v.float(), c["v_merged"].to(v.dtype).float(), **tol)
+        torch.testing.assert_close(s, c["s_merged"], rtol=1e-5, atol=1e-5)
+        # the base-2 op: same merge in other units (its only reference in the reference's tests is a Triton kernel)
+        v2, s2 = oaux.merge_state(c["v_a"], c["s_a"] / ln2, c["v_b"], c["s_b"] / ln2, base2=True)
+        torch.testing.assert_close(v2.float(), v.float(), **tol)
+        torch.testing.assert_close(s2 * ln2, s, rtol=1e-5, atol=1e-5)
+
+
+def test_qknorm_rope_matches_reference_vectors():
+    prec = {torch.bfloat16: 1e-2, torch.float16: 1e-3}
+    g = load_golden("qknorm_rope")
+    for c in g["cache"]:
+        q, k = oqk.fused_inplace_qknorm_rope(c["q"], c["k"], c["q_weight"], c["k_weight"], c["cos_sin_cache"], c["positions"],
+                                             c["is_neox"])
+        p = prec[c["q"].dtype]
+        torch.testing.assert_close(q, c["q_out"].to(q.dtype), rtol=p, atol=p)  # tests/test_fused_qk_norm_rope.py:622-627
+        torch.testing.assert_close(k, c["k_out"].to(k.dtype), rtol=p, atol=p)
+    for c in g["yarn"]:
+        out = oqk.fused_qk_norm_rope(c["qkv"], c["Hq"], c["Hk"], c["Hv"], c["head_dim"], c["eps"], c["q_weight"], c["k_weight"],
+                                     c["base"], c["is_neox"], c["position_ids"], c["factor"], c["low"], c["high"],
+                                     c["attention_factor"], c["rotary_dim"])
+        p = prec[c["qkv"].dtype] * (2 if c["factor"] != 1.0 else 1)  # :375-377
+        torch.testing.assert_close(out, c["out"].to(out.dtype), rtol=p, atol=p)
