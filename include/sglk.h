@@ -198,12 +198,17 @@ SGLK_API int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void* 
                                    int64_t num_kv_splits, int dtype);
 
 /* moe_grouped_mm_nt_xe20 (16-bit weights): reference src/sycl/GroupGemmXe20.cpp:160-275.
- *   out[rows of expert e] = A_e @ W_e^T (+ bias_e fp32); W [E, N, K] with row stride ldb and expert stride
- *   weight_stride_e (elements); A [total_m, K], out [total_m, N] contiguous; dtype BF16 / F16. */
+ *   x = A_e @ W_e^T (+ bias_e fp32) for the rows of expert e; W [E, N, K] with row stride ldb and expert stride
+ *   weight_stride_e (elements); A [total_m, K] contiguous; dtype BF16 / F16.
+ *   fused_act 0: out [total_m, N] = T(x)
+ *             1 / 2 (silu / tanh-gelu, gated: W = gate rows [0, N/2) then up rows): out [total_m, N/2] =
+ *                   T(act(x[:, n]) * x[:, N/2 + n]) computed on the fp32 accumulators
+ *             3 (relu2): out [total_m, N] = T(max(x, 0)^2)
+ *   (reference kernels/moe/xe20/bf16/moe_mainloop.hpp:232-247, :375-390; common/activation.hpp:31-50) */
 SGLK_API int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* activations, const void* weights,
                                  const float* bias, const int32_t* rows_per_expert, int64_t total_m,
                                  int64_t n_experts, int64_t N, int64_t K, int64_t ldb, int64_t weight_stride_e,
-                                 int dtype);
+                                 int dtype, int fused_act);
 
 /* ---- MLA prefill ------------------------------------------------------------
  * flash_mla_prefill: reference src/sycl/mla_prefill.cpp (schema src/torch_extension_sycl.cc:379-383;

@@ -156,7 +156,34 @@ def moe_grouped_mm(act, weights, bias, rows_per_expert):
     return out
 
 
-def fused_experts_16bit(x, w1, w2, topk_weights, topk_ids, b1=None, b2=None, activation="silu", routed_scaling_factor=None):
+def moe_grouped_mm_fused(act, weights, bias, rows_per_expert, activation):
+    """moe_grouped_mm_nt_xe20 with fuse_act (reference kernels/moe/xe20/bf16/moe_mainloop.hpp:232-247, :375-390,
+    common/activation.hpp:31-50): the activation works on the fp32 accumulators (+ bias), one rounding to T.
+    silu / gelu: weights hold gate rows then up rows, out [rows, N/2]; relu2: out [rows, N] = max(x, 0)^2."""
+    T = act.dtype
+    n = weights.shape[1]
+    out = torch.empty(act.shape[0], n if activation == "relu2" else n // 2, dtype=T)
+    r0 = 0
+    for e, r in enumerate(rows_per_expert.tolist()):
+        if r:
+            o = act[r0:r0 + r].float() @ weights[e].float().t()
+            if bias is not None:
+                o = o + bias[e].float()
+            if activation == "relu2":
+                o = torch.square(torch.relu(o))
+            else:
+                g, u = o[:, : n // 2], o[:, n // 2:]
+                if activation == "silu":
+                    o = g * torch.sigmoid(g) * u
+                else:
+                    o = g * (0.5 * (1.0 + torch.tanh(0.7978845608028654 * (g + 0.044715 * g * g * g)))) * u
+            out[r0:r0 + r] = o.to(T)
+        r0 += r
+    return out
+
+
+def fused_experts_16bit(x, w1, w2, topk_weights, topk_ids, b1=None, b2=None, activation="silu", routed_scaling_factor=None,
+                        fused_epilogue=False):
     """fused_experts with 16-bit weights: the op sequence of reference python/sgl_kernel/moe.py:742-866 (GEMM1, gated
     activation in the activation dtype, GEMM2, fp32 weighted combine in slot order); same result as torch_naive_moe
     (tests/test_moe_gemm.py:59-137) up to the rounding of the two intermediates."""
@@ -166,13 +193,16 @@ def fused_experts_16bit(x, w1, w2, topk_weights, topk_ids, b1=None, b2=None, act
     counts, _, _, a_map, c_map = prepare_moe_input(topk_ids.numpy(), E, x.shape[1], topk)
     a = x[torch.from_numpy(a_map).long()]
     rows = torch.from_numpy(counts)
-    h = moe_grouped_mm(a, w1, b1.float() if b1 is not None else None, rows)
-    if activation == "silu":
-        h = oact.silu_and_mul(h)
-    elif activation == "gelu":
-        h = oact.gelu_tanh_and_mul(h)
+    if fused_epilogue:  # the reference's fuse_act route (moe.py:812-860): no rounding between GEMM 1 and the activation
+        h = moe_grouped_mm_fused(a, w1, b1.float() if b1 is not None else None, rows, activation)
     else:
-        h = torch.square(torch.relu(h))
+        h = moe_grouped_mm(a, w1, b1.float() if b1 is not None else None, rows)
+        if activation == "silu":
+            h = oact.silu_and_mul(h)
+        elif activation == "gelu":
+            h = oact.gelu_tanh_and_mul(h)
+        else:
+            h = torch.square(torch.relu(h))
     o = moe_grouped_mm(h, w2, b2.float() if b2 is not None else None, rows)
     gathered = o[torch.from_numpy(c_map).long()].view(x.shape[0], topk, -1).float()
     t = gathered * topk_weights.float().unsqueeze(-1)

@@ -438,7 +438,14 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nkb = K / BK;  // >= 2
-  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || PROBE == 5;
+  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || PROBE >= 5;
+  // schedule experiments with correct results (diagnostic build): 6 = all LDS-DMA issued by waves 0..3 (the older wave of
+  // each SIMD, which wins the issue arbitration and otherwise waits ~900 cycles per K block at the barrier for the
+  // younger one), 7 = 6 + static priority 1 for waves 4..7
+  constexpr bool kLeadDma = PROBE == 6 || PROBE == 7;
+  if constexpr (PROBE == 7) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
   // PROBE 5 (diagnostic build only): three s_memtime stamps per K block (compute done / own DMA landed / barrier
   // released) for K blocks 40..60 of the workgroup, kept in the lanes of one VGPR and written out at the end
   uint32_t stampv = 0;
@@ -530,19 +537,29 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     const int kb = PROBE == 4 ? 0 : kb_;  // probe 4: every block re-fetches block 0 (L2 hits, no stores)
     char* base = smem + s * kStageBytes;
     if (sub == 2) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s),
-                                               SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, voff_s,
-                                               kb * (int)sa_sk * 4, 0, 0);
+      if (!kLeadDma || wave < 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s),
+                                                 SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, voff_s,
+                                                 kb * (int)sa_sk * 4, 0, 0);
       return;
     }
     const int ii = (part & 1) * 2 + sub;
-    const int piece = wave * 4 + ii;
-    if (part < 2) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pa, d.nrec_a), SGLK_LDS(base + piece * 1024), 16,
-                                               voff_a[ii & 1], kb * BK + piece * 8 * (int)lda, 0, 0);
+    auto one = [&](int piece) {
+      if (part < 2) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pa, d.nrec_a), SGLK_LDS(base + piece * 1024), 16,
+                                                 voff_a[ii & 1], kb * BK + piece * 8 * (int)lda, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b), SGLK_LDS(base + kTileBytes + piece * 1024),
+                                                 16, voff_b[ii], kb * BK + piece * 8 * (int)ldb, 0, 0);
+      }
+    };
+    if constexpr (kLeadDma) {
+      if (wave < 4) {
+        one(wave * 4 + ii);
+        one((wave + 4) * 4 + ii);
+      }
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b), SGLK_LDS(base + kTileBytes + piece * 1024),
-                                               16, voff_b[ii], kb * BK + piece * 8 * (int)ldb, 0, 0);
+      one(wave * 4 + ii);
     }
   };
 
@@ -1056,6 +1073,8 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 16: SGLK_GO_PIPE(V, H, 3); break;                                                                 \
       case 17: SGLK_GO_PIPE(V, H, 4); break;                                                                 \
       case 18: SGLK_GO_PIPE(V, H, 5); break;                                                                 \
+      case 20: SGLK_GO_PIPE(V, H, 6); break;                                                                 \
+      case 21: SGLK_GO_PIPE(V, H, 7); break;                                                                 \
       default: SGLK_GO_PIPE(V, H, 0); break;                                                                 \
     }                                                                                                        \
   } else {                                                                                                   \

@@ -4,10 +4,12 @@
 // src/torch_extension_sycl.cc:208-212; caller python/sgl_kernel/moe.py:763-775, :812-860):
 //   for expert e with rows[e] consecutive rows of `activations` [total_m, K]:
 //     out_e = A_e @ W_e^T (+ bias_e fp32),   W [E, N, K] (row stride ld_b), out [total_m, N]
-// The fused gate/up activation of the reference op (fuse_act) is composed by the caller layer from this GEMM and
-// the activation kernels (csrc/activation.hip): one more pass over the [total_m, N] intermediate, same arithmetic up
-// to the rounding of that intermediate to the activation dtype - which is also what the reference's own unfused
-// route (moe.py:742-810) does.
+// fuse_act (reference kernels/moe/xe20/bf16/moe_mainloop.hpp:232-247, :375-390; common/activation.hpp:31-50): the
+// activation is applied to the fp32 accumulators (+ bias) in the epilogue, one rounding to T:
+//   silu / gelu (gated): W holds gate rows [0, N/2) then up rows [N/2, N); out[m, n] = T(act(gate) * up), out is
+//                        [total_m, N/2]. A wave's two n tiles are gate tile n and up tile n + N/2: the product never
+//                        leaves the registers (the unfused route writes and re-reads a [total_m, N] intermediate).
+//   relu2 (not gated):   out[m, n] = T(max(x, 0)^2), out is [total_m, N].
 //
 // Kernel: the skeleton of moe_w4a16.hip without the dequantisation. Block = 4 waves; wave w owns NW 16-wide n tiles
 // and all MT 16-row m tiles of the block's expert rows. Weights stream HBM -> registers (lane (n, g) reads the 16
@@ -35,7 +37,19 @@ __device__ __forceinline__ v4f mma16<f16>(const v4i& a, const v4i& b, const v4f&
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
 }
 
-template <typename T, int MT, int NW>
+enum { FUSE_NONE = 0, FUSE_SILU = 1, FUSE_GELU = 2, FUSE_RELU2 = 3 };
+
+template <int FUSE>
+__device__ __forceinline__ float gated_act(float x, float y) {
+  if constexpr (FUSE == FUSE_SILU) {
+    return (x / (1.0f + expf(-x))) * y;
+  } else {
+    const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return (x * (0.5f * (1.0f + tanhf(inner)))) * y;
+  }
+}
+
+template <typename T, int MT, int NW, int FUSE>
 __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, const T* __restrict__ act,
                                                        const T* __restrict__ w, const float* __restrict__ bias,
                                                        const int32_t* __restrict__ rows_per_expert, int E, int N, int K,
@@ -61,14 +75,18 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
   if (!found) return;
   const int m0 = row0 + blk * BM;
   const int m_valid = rows_e - blk * BM;
-  const int n_base = blockIdx.y * BN + wave * (NW * 16);
+  constexpr bool kGated = FUSE == FUSE_SILU || FUSE == FUSE_GELU;
+  static_assert(!kGated || NW == 2, "the gated epilogue pairs the two n tiles of a wave");
+  const int Nh = N >> 1;  // gated: output width; gate rows [0, Nh), up rows [Nh, N)
+  const int n_base = kGated ? blockIdx.y * (BN / 2) + wave * 16 : blockIdx.y * BN + wave * (NW * 16);
 
   const T* wexp = w + (int64_t)e * w_stride_e;
   uint32_t woff[NW];  // element offset of this lane's row and k group
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
-    int n = n_base + nt * 16 + l15;
-    n = n < N ? n : N - 1;
+    int n = kGated ? n_base + l15 + nt * Nh : n_base + nt * 16 + l15;
+    const int lim = kGated ? (nt + 1) * Nh : N;
+    n = n < lim ? n : lim - 1;
     woff[nt] = (uint32_t)n * (uint32_t)ldb + 8 * g;
   }
 
@@ -150,17 +168,37 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
   }
 
   // ---- epilogue: lane owns out[m = 16 mt + 4 g + r][n = n_base + 16 nt + l15]
+  if constexpr (kGated) {
+    const int n = n_base + l15;
+    if (n < Nh) {
+      const float bg = bias ? bias[(int64_t)e * N + n] : 0.f, bu = bias ? bias[(int64_t)e * N + Nh + n] : 0.f;
 #pragma unroll
-  for (int nt = 0; nt < NW; ++nt) {
-    const int n = n_base + nt * 16 + l15;
-    if (n >= N) continue;
-    const float bv = bias ? bias[(int64_t)e * N + n] : 0.f;
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + 4 * g + r;
+          if (row < m_valid) out[(int64_t)(m0 + row) * Nh + n] = (T)gated_act<FUSE>(acc[mt][0][r] + bg, acc[mt][1][r] + bu);
+        }
+      }
+    }
+  } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + 4 * g + r;
-        if (row < m_valid) out[(int64_t)(m0 + row) * N + n] = (T)(acc[mt][nt][r] + bv);
+    for (int nt = 0; nt < NW; ++nt) {
+      const int n = n_base + nt * 16 + l15;
+      if (n >= N) continue;
+      const float bv = bias ? bias[(int64_t)e * N + n] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + 4 * g + r;
+          float v = acc[mt][nt][r] + bv;
+          if constexpr (FUSE == FUSE_RELU2) {
+            v = fmaxf(v, 0.f);
+            v = v * v;
+          }
+          if (row < m_valid) out[(int64_t)(m0 + row) * N + n] = (T)v;
+        }
       }
     }
   }
@@ -168,22 +206,31 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
 
 template <typename T, int MT, int NW>
 static int launch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
-                  int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e) {
+                  int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
   constexpr int BM = 16 * MT, BN = 64 * NW;
   const int64_t max_mblocks = total_m / BM + E;  // sum_e ceil(rows_e / BM) <= total_m / BM + E
-  dim3 grid((unsigned)max_mblocks, (unsigned)cdiv(N, BN));
-  moe_bf16_kernel<T, MT, NW><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E, N, K, ldb, w_stride_e);
+  const bool gated = fuse == FUSE_SILU || fuse == FUSE_GELU;
+  dim3 grid((unsigned)max_mblocks, (unsigned)(gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN)));
+#define SGLK_GO(F) \
+  moe_bf16_kernel<T, MT, NW, F><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E, N, K, ldb, w_stride_e)
+  switch (fuse) {
+    case FUSE_SILU: SGLK_GO(FUSE_SILU); break;
+    case FUSE_GELU: SGLK_GO(FUSE_GELU); break;
+    case FUSE_RELU2: SGLK_GO(FUSE_RELU2); break;
+    default: SGLK_GO(FUSE_NONE); break;
+  }
+#undef SGLK_GO
   return check_launch("moe_grouped_mm_nt_xe20");
 }
 
 template <typename T>
 static int dispatch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
-                    int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e) {
+                    int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
   const int64_t avg = total_m / E;  // tile policy by average rows per expert, as the reference (GroupGemmXe20.cpp:226-274)
-  if (avg <= 16) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e);
-  if (avg <= 32) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e);
-  if (avg <= 128) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e);
-  return launch<T, 8, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e);
+  if (avg <= 16) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  if (avg <= 32) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  if (avg <= 128) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  return launch<T, 8, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
 }
 
 }  // namespace
@@ -192,7 +239,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* w, c
 extern "C" int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* activations, const void* weights,
                                    const float* bias, const int32_t* rows_per_expert, int64_t total_m,
                                    int64_t n_experts, int64_t N, int64_t K, int64_t ldb, int64_t weight_stride_e,
-                                   int dtype) {
+                                   int dtype, int fused_act) {
   using namespace sglk;
   SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "moe_grouped_mm_nt_xe20: activations and weights must be bfloat16 or half");
   SGLK_REQUIRE(n_experts > 0 && N > 0 && K > 0, "moe_grouped_mm_nt_xe20: bad shape");
@@ -200,11 +247,13 @@ extern "C" int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* 
   SGLK_REQUIRE((uintptr_t)activations % 16 == 0 && (uintptr_t)weights % 16 == 0,
                "moe_grouped_mm_nt_xe20: activations and weights must be 16-byte aligned");
   SGLK_REQUIRE(N * ldb < (1ll << 32), "moe_grouped_mm_nt_xe20: one expert's weights must stay below 4 Gi elements");
+  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 3, "moe_grouped_mm_nt_xe20: fused_act must be 0 (none), 1 (silu), 2 (gelu) or 3 (relu2)");
+  SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2) || N % 2 == 0, "moe_grouped_mm_nt_xe20: a gated epilogue needs an even N");
   if (total_m == 0) return SGLK_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16)
     return dispatch<bf16>(st, out, activations, weights, bias, rows_per_expert, total_m, (int)n_experts, (int)N, (int)K, ldb,
-                          weight_stride_e);
+                          weight_stride_e, fused_act);
   return dispatch<f16>(st, out, activations, weights, bias, rows_per_expert, total_m, (int)n_experts, (int)N, (int)K, ldb,
-                       weight_stride_e);
+                       weight_stride_e, fused_act);
 }

@@ -735,23 +735,20 @@ void moe_grouped_mm_nt_xe20(Tensor& output, const Tensor& activations, const Ten
   }
   const c10::OptionalDeviceGuard guard(activations.device());
   const int dt = dtype_code(activations.scalar_type(), "activations");
-  if (!fuse_act) {
-    TORCH_CHECK(output.size(1) == gemm_n, "output must have the same number of columns as the weights have rows");
-    SGLK_CALL(sglk_moe_grouped_mm(stream_of(activations), output.data_ptr(), activations.data_ptr(), weights.data_ptr(), bias_ptr,
-                                  total_rows_for_experts.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
-                                  weights.stride(1), weights.stride(0), dt));
-    return;
+  // fused epilogue codes of the C-ABI: 0 none, 1 silu (gated), 2 gelu (gated), 3 relu2
+  int fused = 0;
+  if (fuse_act) {
+    TORCH_CHECK(activation_type != 2, "moe_grouped_mm_nt_xe20: the gpt-oss clamped swiglu epilogue (activation_type 2) is outside this build");
+    fused = activation_type == 0 ? 1 : activation_type == 1 ? 2 : 3;
   }
-  // fused gate / up epilogue: composed from the GEMM and the activation kernel (one more pass over [total_m, N])
-  TORCH_CHECK(activation_type == 0 || activation_type == 1,
-              "moe_grouped_mm_nt_xe20: fuse_act is built for silu (0) and gelu (1) on this device");
-  TORCH_CHECK(output.size(1) == gemm_n / 2, "output must have half the number of columns as activations");
-  Tensor tmp = at::empty({total_m, gemm_n}, activations.options());
-  SGLK_CALL(sglk_moe_grouped_mm(stream_of(activations), tmp.data_ptr(), activations.data_ptr(), weights.data_ptr(), bias_ptr,
+  if (fused == 1 || fused == 2) {
+    TORCH_CHECK(gemm_n % 2 == 0 && output.size(1) == gemm_n / 2, "output must have half the number of columns as activations");
+  } else {
+    TORCH_CHECK(output.size(1) == gemm_n, "output must have the same number of columns as the weights have rows");
+  }
+  SGLK_CALL(sglk_moe_grouped_mm(stream_of(activations), output.data_ptr(), activations.data_ptr(), weights.data_ptr(), bias_ptr,
                                 total_rows_for_experts.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
-                                weights.stride(1), weights.stride(0), dt));
-  SGLK_CALL(sglk_act_and_mul(stream_of(activations), output.data_ptr(), tmp.data_ptr(), total_m, gemm_n / 2, dt,
-                             activation_type == 0 ? SGLK_ACT_SILU : SGLK_ACT_GELU_TANH));
+                                weights.stride(1), weights.stride(0), dt, fused));
 }
 
 // ---- fwd / mha_fwd (reference src/sycl/flash_attention.cpp:1332-1435; the int/float narrowing the reference

@@ -10,7 +10,7 @@ apply_shuffle_mul_sum (:655-868); the grow-only scratch buffers keyed by (name, 
 
 This build's own structure: one `_Plan` derives every size and route from the arguments, `_Scratch` owns the
 buffers, the activation routes are a table. 4-bit weights (int4 / mxfp4 W4A16) take GEMM -> activation kernel ->
-GEMM; 16-bit weights take the grouped GEMM's fused gate/up epilogue when the activation has one.
+GEMM; 16-bit weights take the grouped GEMM's fused activation epilogue (gate/up product or relu2).
 """
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -244,8 +244,7 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
             _ops.moe_grouped_mm_nt_xe20(out, a, w, bias, rows_per_expert, p.experts, p.act_type, fuse_act, 1.702, 7.0)
 
     # ---- GEMM 1 (+ gate/up activation)
-    fused_epilogue = (not p.four_bit) and p.gate_factor == 2 and p.act_op is not None
-    if fused_epilogue:
+    if not p.four_bit:  # gate/up activation (or relu2) on the fp32 accumulators in the GEMM's epilogue
         h = scratch("intermediate_cache1_fused", (p.rows, p.inter))
         grouped_mm(h, x, w1, None, None, b1, 0, fuse_act=True)
     else:

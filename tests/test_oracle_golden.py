@@ -219,10 +219,11 @@ def test_fused_experts_16bit_oracle_matches_torch_naive_moe():
     from oracle import moe as omoe
 
     for c in load_golden("moe_w4a16")["fused16"]:
-        out = omoe.fused_experts_16bit(c["x"], c["w1"], c["w2"], c["topk_weights"], c["topk_ids"], c["b1"], c["b2"],
-                                       c["activation"], c["routed_scaling_factor"])
-        torch.testing.assert_close(out.float(), c["out"].float(), rtol=1e-1, atol=2e-2)
-        torch.testing.assert_close(out.float(), c["out"].float(), rtol=3e-2, atol=3e-3)
+        for fused in (False, True):  # both routes of the op sequence (activation kernel / GEMM epilogue)
+            out = omoe.fused_experts_16bit(c["x"], c["w1"], c["w2"], c["topk_weights"], c["topk_ids"], c["b1"], c["b2"],
+                                           c["activation"], c["routed_scaling_factor"], fused_epilogue=fused)
+            torch.testing.assert_close(out.float(), c["out"].float(), rtol=1e-1, atol=2e-2)
+            torch.testing.assert_close(out.float(), c["out"].float(), rtol=3e-2, atol=3e-3)
 
 
 def test_quant_v2_matches_reference_vectors():

@@ -150,6 +150,94 @@ __global__ __launch_bounds__(512) void mfma_peak_kernel(const int* __restrict__ 
   }
 }
 
+// ---- issue-cost probe: the GEMM main loop's instruction mix without memory (operands in registers): zero-C MFMA of one
+// 128-deep block per 16x16 (or 32x32) tile and the block-scale promotion of the PREVIOUS tile's partial between MFMAs
+//   0: 16x16x128 + 4 v_fma_f32    1: 16x16x128 + 2 v_pk_fma_f32    2: 2 x 32x32x64 + 16 v_fma_f32
+//   3: 2 x 32x32x64 + 8 v_pk_fma_f32    4: 16x16x128 alone    5: 2 x 32x32x64 alone
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(512) void issue_probe_kernel(const int* __restrict__ src, float* __restrict__ dst, int iters) {
+  v8i_t a[4], b[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) {
+      a[i][j] = src[(threadIdx.x * 8 + j + i * 4096) & 16383];
+      b[i][j] = src[(threadIdx.x * 8 + j + i * 4096 + 777) & 16383];
+    }
+  int one = 127;
+  float sc = __int_as_float(0x3f800000 | (src[threadIdx.x] & 0xffff));
+  v2f_t sc2 = {sc, sc};
+  asm volatile("" : "+v"(one), "+v"(sc), "+v"(sc2));
+  float s = 0;
+  if constexpr (MODE == 0 || MODE == 1 || MODE == 4) {
+    float acc[16][4] = {};
+    v2f_t acc2[16][2] = {};
+    v4f_t cur[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
+                     : "=&v"(cur[t & 1]) : "v"(b[t & 3]), "v"(a[t >> 2]), "v"(one));
+        constexpr int dummy = 0; (void)dummy;
+        const int p = (t + 15) & 15;
+        if constexpr (MODE == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[p][r]) : "v"(cur[(t & 1) ^ 1][r]), "v"(sc));
+        } else if constexpr (MODE == 1) {
+          const v2f_t lo = {cur[(t & 1) ^ 1][0], cur[(t & 1) ^ 1][1]}, hi = {cur[(t & 1) ^ 1][2], cur[(t & 1) ^ 1][3]};
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[p][0]) : "v"(lo), "v"(sc2));
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[p][1]) : "v"(hi), "v"(sc2));
+        }
+      }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(cur[0]), "+v"(cur[1]));
+    for (int t = 0; t < 16; ++t)
+      for (int r = 0; r < 4; ++r) s += acc[t][r] + acc2[t][r >> 1][r & 1];
+    s += cur[0][0] + cur[1][0];
+  } else {
+    float acc[4][16] = {};
+    v2f_t acc2[4][8] = {};
+    v16f_t cur[2];
+    for (int i = 0; i < 16; ++i) { cur[0][i] = 0; cur[1][i] = 0; }
+    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
+                     : "=&v"(cur[t & 1]) : "v"(b[t & 3]), "v"(a[t >> 1]), "v"(one));
+        const int p = (t + 3) & 3;
+        if constexpr (MODE == 2) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[p][r]) : "v"(cur[(t & 1) ^ 1][r]), "v"(sc));
+        } else if constexpr (MODE == 3) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const v2f_t x = {cur[(t & 1) ^ 1][2 * r], cur[(t & 1) ^ 1][2 * r + 1]};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[p][r]) : "v"(x), "v"(sc2));
+          }
+        }
+        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                     : "+v"(cur[t & 1]) : "v"(a[t & 3]), "v"(b[t >> 1]), "v"(one));
+        if constexpr (MODE == 2) {
+#pragma unroll
+          for (int r = 8; r < 16; ++r) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[p][r]) : "v"(cur[(t & 1) ^ 1][r]), "v"(sc));
+        } else if constexpr (MODE == 3) {
+#pragma unroll
+          for (int r = 4; r < 8; ++r) {
+            const v2f_t x = {cur[(t & 1) ^ 1][2 * r], cur[(t & 1) ^ 1][2 * r + 1]};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc2[p][r]) : "v"(x), "v"(sc2));
+          }
+        }
+      }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(cur[0]), "+v"(cur[1]));
+    for (int t = 0; t < 4; ++t)
+      for (int r = 0; r < 16; ++r) s += acc[t][r] + acc2[t][r >> 1][r & 1];
+    s += cur[0][0] + cur[1][0];
+  }
+  dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // ---- does the raw-buffer range check of buffer_load ... lds include the scalar offset? (expects zeros past the end)
 __global__ void oob_probe_kernel(const uint8_t* __restrict__ src, int nrec, int soff, int use_voff, uint32_t* out) {
   __shared__ __attribute__((aligned(256))) uint32_t lds[256];
@@ -205,6 +293,29 @@ int main(int argc, char** argv) {
       const double flops = (double)blocks * (threads / 64) * iters * (mode == 2 ? 8 : 16) * (mode == 2 ? 32.0 * 32 * 64 * 2 : mode == 3 ? 16.0 * 16 * 32 * 2 : 16.0 * 16 * 128 * 2);
       printf("peak mode=%d threads=%d blocks=%d iters=%d: median %.4f ms min %.4f -> %.1f TFLOP/s\n", mode, threads, blocks,
              iters, ms, all[0], flops / ms / 1e9);
+    }
+    return 0;
+  }
+  if (!strcmp(argv[1], "issue")) {  // kbench issue THREADS BLOCKS ITERS
+    const int threads = atoi(argv[2]), blocks = atoi(argv[3]), iters = atoi(argv[4]);
+    int* src = (int*)dev_random_bytes(16384 * 4, 9, true);
+    float* dst;
+    HIP_CHECK(hipMalloc(&dst, (size_t)blocks * threads * 4));
+    const char* names[6] = {"16x16x128 + 4 v_fma", "16x16x128 + 2 v_pk_fma", "2x 32x32x64 + 16 v_fma", "2x 32x32x64 + 8 v_pk_fma",
+                            "16x16x128 alone", "2x 32x32x64 alone"};
+    for (int mode = 0; mode < 6; ++mode) {
+      auto run = [&] {
+        if (mode == 0) issue_probe_kernel<0><<<blocks, threads>>>(src, dst, iters);
+        if (mode == 1) issue_probe_kernel<1><<<blocks, threads>>>(src, dst, iters);
+        if (mode == 2) issue_probe_kernel<2><<<blocks, threads>>>(src, dst, iters);
+        if (mode == 3) issue_probe_kernel<3><<<blocks, threads>>>(src, dst, iters);
+        if (mode == 4) issue_probe_kernel<4><<<blocks, threads>>>(src, dst, iters);
+        if (mode == 5) issue_probe_kernel<5><<<blocks, threads>>>(src, dst, iters);
+      };
+      std::vector<float> all;
+      const double ms = time_ms(run, 3, 10, &all);
+      const double flops = (double)blocks * (threads / 64) * iters * 16 * 16.0 * 16 * 128 * 2;  // both shapes: 16 x 65536 per iteration
+      printf("issue mode=%d (%s) threads=%d: median %.4f ms -> %.1f TFLOP/s\n", mode, names[mode], threads, ms, flops / ms / 1e9);
     }
     return 0;
   }
