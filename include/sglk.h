@@ -363,6 +363,30 @@ SGLK_API int sglk_fused_qknorm_rope_yarn(sglk_stream_t stream, void* qkv, const 
                                          int64_t rotary_dim, float eps, float base, int is_neox, float factor,
                                          float low, float high, float attention_factor, int dtype);
 
+/* ---- DeepSeek-style MoE routers -------------------------------------------------------
+ * Experts are picked by iterative arg-max of choice = score (+ bias), ties -> the lower expert index; the weights
+ * are the UNBIASED scores. gating / input [tokens, E] in {F32, F16, BF16}, E <= 512, topk <= 32; outputs fp32 /
+ * int32 [tokens, topk]; fused shared-expert slot i gets id E + i.
+ * topk_sigmoid: reference src/sycl/TopKSigMoid.cpp (schema src/torch_extension_sycl.cc:55-58). */
+SGLK_API int sglk_topk_sigmoid(sglk_stream_t stream, float* topk_weights, int32_t* topk_ids, const void* gating,
+                               const float* correction_bias, int64_t tokens, int64_t num_experts, int64_t topk,
+                               int renormalize, float routed_scaling_factor, int64_t num_fused_shared_experts,
+                               int dtype);
+/* biased_topk: reference src/sycl/BiasedTopK.cpp (schema src/torch_extension_sycl.cc:111-115);
+ * scoring_func 0 = sigmoid, 1 = sqrt(softplus). */
+SGLK_API int sglk_biased_topk(sglk_stream_t stream, float* output, int32_t* indices, const void* input,
+                              const float* bias, int64_t tokens, int64_t num_experts, int64_t topk, int scoring_func,
+                              int64_t num_fused_shared_experts, int renormalize, float routed_scaling_factor,
+                              int apply_routed_scaling_factor_on_output, int dtype);
+/* moe_fused_gate: reference src/sycl/MoE_fused_gate.cpp (schema src/torch_extension_sycl.cc:191-196); grouped
+ * top-k (groups ranked by the sum of their two largest choices; softmax scoring: by the largest);
+ * scoring_func 0 = sigmoid, 1 = softmax; bias (may be NULL) in the dtype of input. */
+SGLK_API int sglk_moe_fused_gate(sglk_stream_t stream, float* output, int32_t* indices, const void* input,
+                                 const void* bias, int64_t tokens, int64_t num_experts, int64_t num_expert_group,
+                                 int64_t topk_group, int64_t topk, int64_t num_fused_shared_experts, int scoring_func,
+                                 int renormalize, float routed_scaling_factor,
+                                 int apply_routed_scaling_factor_on_output, int dtype);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <optional>
 #include <tuple>
+#include <vector>
 
 #include "sglk.h"
 
@@ -957,6 +958,96 @@ void sgl_per_token_group_quant_8bit_v2(Tensor input, Tensor output_q, Tensor out
                                                kind, s_e, s_row, s_col, fuse_silu_and_mul ? 1 : 0));
 }
 
+// ---- DeepSeek-style routers (reference src/sycl/TopKSigMoid.cpp, BiasedTopK.cpp:457-520, MoE_fused_gate.cpp:486-600) ----
+
+void topk_sigmoid(Tensor& topk_weights, Tensor& topk_indices, const Tensor& gating_output, bool renormalize,
+                  const std::optional<Tensor>& correction_bias, double routed_scaling_factor, int64_t num_fused_shared_experts) {
+  CHECK_GPU(topk_weights);
+  CHECK_GPU(topk_indices);
+  CHECK_GPU(gating_output);
+  CHECK_CONTIGUOUS(topk_weights);
+  CHECK_CONTIGUOUS(topk_indices);
+  CHECK_CONTIGUOUS(gating_output);
+  TORCH_CHECK(gating_output.dim() == 2, "gating_output must be 2D [tokens, experts]");
+  TORCH_CHECK(topk_weights.scalar_type() == at::kFloat && topk_indices.scalar_type() == at::kInt,
+              "topk_weights must be float32 and topk_indices int32");
+  TORCH_CHECK(topk_weights.dim() == 2 && topk_weights.sizes() == topk_indices.sizes() && topk_weights.size(0) == gating_output.size(0),
+              "topk_weights / topk_indices must be [tokens, topk]");
+  const float* bias = nullptr;
+  if (correction_bias.has_value()) {
+    CHECK_GPU((*correction_bias));
+    TORCH_CHECK(correction_bias->scalar_type() == at::kFloat && correction_bias->is_contiguous() &&
+                    correction_bias->numel() == gating_output.size(1),
+                "correction_bias must be a contiguous float32 tensor with one entry per expert");
+    bias = correction_bias->data_ptr<float>();
+  }
+  const c10::OptionalDeviceGuard guard(gating_output.device());
+  SGLK_CALL(sglk_topk_sigmoid(stream_of(gating_output), topk_weights.data_ptr<float>(), topk_indices.data_ptr<int32_t>(),
+                              gating_output.data_ptr(), bias, gating_output.size(0), gating_output.size(1), topk_weights.size(1),
+                              renormalize ? 1 : 0, (float)routed_scaling_factor, num_fused_shared_experts,
+                              dtype_code(gating_output.scalar_type(), "topk_sigmoid")));
+}
+
+void biased_topk(const Tensor& input, const Tensor& bias, Tensor& output, Tensor& indices, int64_t topk, int64_t scoring_func,
+                 int64_t num_fused_shared_experts, bool renormalize, double routed_scaling_factor,
+                 bool apply_routed_scaling_factor_on_output) {
+  CHECK_GPU(input);
+  CHECK_GPU(bias);
+  CHECK_GPU(output);
+  CHECK_GPU(indices);
+  CHECK_CONTIGUOUS(input);
+  CHECK_CONTIGUOUS(bias);
+  CHECK_CONTIGUOUS(output);
+  CHECK_CONTIGUOUS(indices);
+  TORCH_CHECK(input.dim() == 2, "input must be 2D, got ", input.dim(), "D");
+  TORCH_CHECK(bias.dim() == 1, "bias must be 1D, got ", bias.dim(), "D");
+  TORCH_CHECK(input.size(1) == bias.size(0), "input.size(1) must match bias.size(0)");
+  TORCH_CHECK(input.scalar_type() == at::kFloat || input.scalar_type() == at::kHalf || input.scalar_type() == at::kBFloat16,
+              "input must be float32, float16, or bfloat16");
+  TORCH_CHECK(bias.scalar_type() == at::kFloat, "bias must be float32");
+  TORCH_CHECK(topk > num_fused_shared_experts, "topk must be greater than num_fused_shared_experts");
+  TORCH_CHECK(scoring_func == 0 || scoring_func == 1, "scoring_func must be 0 (sigmoid) or 1 (sqrtsoftplus)");
+  TORCH_CHECK(output.scalar_type() == at::kFloat, "output must be float32");
+  TORCH_CHECK(indices.scalar_type() == at::kInt, "indices must be int32");
+  TORCH_CHECK(output.dim() == 2 && output.size(0) == input.size(0) && output.size(1) == topk, "output shape mismatch");
+  TORCH_CHECK(indices.dim() == 2 && indices.size(0) == input.size(0) && indices.size(1) == topk, "indices shape mismatch");
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_biased_topk(stream_of(input), output.data_ptr<float>(), indices.data_ptr<int32_t>(), input.data_ptr(),
+                             bias.data_ptr<float>(), input.size(0), input.size(1), topk, (int)scoring_func,
+                             num_fused_shared_experts, renormalize ? 1 : 0, (float)routed_scaling_factor,
+                             apply_routed_scaling_factor_on_output ? 1 : 0, dtype_code(input.scalar_type(), "biased_topk")));
+}
+
+std::vector<Tensor> moe_fused_gate(const Tensor& input, const std::optional<Tensor>& bias, int64_t num_expert_group,
+                                   int64_t topk_group, int64_t topk, int64_t num_fused_shared_experts, int64_t scoring_func,
+                                   bool renormalize, double routed_scaling_factor, bool apply_routed_scaling_factor_on_output) {
+  CHECK_GPU(input);
+  CHECK_CONTIGUOUS(input);
+  TORCH_CHECK(input.dim() == 2, "input must be 2D [tokens, experts]");
+  const void* bias_ptr = nullptr;
+  if (bias.has_value()) {
+    CHECK_GPU((*bias));
+    TORCH_CHECK(input.dtype() == bias->dtype(), "input and bias should have the same dtype");
+    TORCH_CHECK(bias->dim() == 1, "bias must be a 1D tensor when provided");
+    TORCH_CHECK(bias->size(0) == input.size(1), "bias size must match the number of experts, but got ", bias->size(0), " vs ",
+                input.size(1));
+    TORCH_CHECK(bias->is_contiguous(), "bias must be contiguous");
+    bias_ptr = bias->data_ptr();
+  }
+  TORCH_CHECK(scoring_func == 0 || scoring_func == 1, "scoring_func must be 0 (sigmoid) or 1 (softmax), but got ", scoring_func);
+  const int64_t num_experts = input.size(1);
+  TORCH_CHECK(num_experts % num_expert_group == 0, "num_experts must be divisible by num_expert_group, but got ", num_experts,
+              " / ", num_expert_group);
+  const c10::OptionalDeviceGuard guard(input.device());
+  Tensor output = at::empty({input.size(0), topk}, input.options().dtype(at::kFloat));
+  Tensor indices = at::empty({input.size(0), topk}, input.options().dtype(at::kInt));
+  SGLK_CALL(sglk_moe_fused_gate(stream_of(input), output.data_ptr<float>(), indices.data_ptr<int32_t>(), input.data_ptr(), bias_ptr,
+                                input.size(0), num_experts, num_expert_group, topk_group, topk, num_fused_shared_experts,
+                                (int)scoring_func, renormalize ? 1 : 0, (float)routed_scaling_factor,
+                                apply_routed_scaling_factor_on_output ? 1 : 0, dtype_code(input.scalar_type(), "moe_fused_gate")));
+  return {output, indices};
+}
+
 // ---- merge_state / merge_state_v2 (reference src/sycl/merge_states.cpp:303-361) ------------------------------
 
 void merge_state_impl(const Tensor& v_a, const Tensor& s_a, const Tensor& v_b, const Tensor& s_b, Tensor& v_merged,
@@ -1204,6 +1295,22 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "store_cache(Tensor k, Tensor v, Tensor(a!) k_cache, Tensor(b!) v_cache, "
       "Tensor indices) -> ()");
   m.impl("store_cache", c10::kCUDA, &store_cache);
+  // reference src/torch_extension_sycl.cc:55-58, :111-115, :191-196
+  m.def(
+      "topk_sigmoid(Tensor! topk_weights, Tensor! topk_indices, Tensor gating_output, bool renormalize, Tensor? "
+      "correction_bias, float routed_scaling_factor=1.0, int num_fused_shared_experts=0) -> ()");
+  m.impl("topk_sigmoid", c10::kCUDA, &topk_sigmoid);
+  m.def(
+      "biased_topk(Tensor input, Tensor bias, Tensor! output, Tensor! indices, int topk, int scoring_func, int "
+      "num_fused_shared_experts, bool renormalize, float routed_scaling_factor, bool "
+      "apply_routed_scaling_factor_on_output) -> ()");
+  m.impl("biased_topk", c10::kCUDA, &biased_topk);
+  m.def(
+      "moe_fused_gate(Tensor input, Tensor? bias, int num_expert_group, int topk_group, int topk, int "
+      "num_fused_shared_experts, int scoring_func, bool renormalize, float routed_scaling_factor, bool "
+      "apply_routed_scaling_factor_on_output) -> "
+      "(Tensor[])");
+  m.impl("moe_fused_gate", c10::kCUDA, &moe_fused_gate);
   // reference src/torch_extension_sycl.cc:232-235
   m.def("merge_state_v2(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor! v_merged, Tensor! s_merged) -> ()");
   m.impl("merge_state_v2", c10::kCUDA, &merge_state_v2);

@@ -56,10 +56,13 @@ from sgl_kernel.gemm import (  # noqa: E402
 )
 from sgl_kernel.moe import (  # noqa: E402
     apply_shuffle_mul_sum,
+    biased_topk,
     fused_experts,
     moe_align_block_size,
+    moe_fused_gate,
     prepare_moe_input,
     scatter_tokens_to_experts,
+    topk_sigmoid,
     topk_softmax,
 )
 from sgl_kernel.utils import get_device_capability, is_gfx950_arch, is_xe2_arch  # noqa: E402
@@ -76,8 +79,8 @@ _OUT_OF_SCOPE = frozenset(
     apply_rope_with_cos_sin_cache_inplace fused_k_norm_rope_flashmla
     fused_q_norm_rope fused_qk_rope fused_qk_rope_with_cos_sin_cache_inplace
     multimodal_rotary_embedding silu_and_mul_clamp
-    biased_topk cutlass_fp4_group_mm fp8_blockwise_scaled_grouped_mm hash_topk moe_fused_gate moe_sum
-    moe_sum_reduce swiglu_gpt_oss_sigmoid_alpha topk_sigmoid
+    cutlass_fp4_group_mm fp8_blockwise_scaled_grouped_mm hash_topk moe_sum
+    moe_sum_reduce swiglu_gpt_oss_sigmoid_alpha
     min_p_sampling_from_probs top_k_renorm_prob top_k_top_p_sampling_from_probs top_p_renorm_prob
     top_p_sampling_from_probs weak_ref_tensor
     """.split()

@@ -1,7 +1,7 @@
 """Mixture-of-experts host layer: thin op wrappers and the `fused_experts` routed-expert MLP.
 
 Contract (reference python/sgl_kernel/moe.py): public names and parameters of `moe_align_block_size` (:48-67),
-`topk_softmax` (:70-78), `prepare_moe_input` (:278-301), `apply_shuffle_mul_sum` (:304-318),
+`topk_softmax` (:70-78), `topk_sigmoid` (:81-98), `moe_fused_gate` (:159-201), `biased_topk` (:204-233), `prepare_moe_input` (:278-301), `apply_shuffle_mul_sum` (:304-318),
 `scatter_tokens_to_experts` (:321-322) and `fused_experts` (:403-432); the op sequence
 prepare_moe_input -> scatter_tokens_to_experts -> grouped GEMM 1 -> gate/up activation -> grouped GEMM 2 ->
 apply_shuffle_mul_sum (:655-868); the grow-only scratch buffers keyed by (name, device) with 10 % headroom
@@ -32,6 +32,43 @@ def moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, ex
 
 def topk_softmax(topk_weights: torch.Tensor, topk_ids: torch.Tensor, gating_output: float, renormalize: bool = False) -> None:
     _ops.topk_softmax.default(topk_weights, topk_ids, gating_output, renormalize)
+
+
+_GATE_SCORING = {"sigmoid": 0, "softmax": 1}          # moe_fused_gate
+_BIASED_TOPK_SCORING = {"sigmoid": 0, "sqrtsoftplus": 1}
+
+
+def _scoring_code(table, scoring_func):
+    code = table.get(scoring_func.lower())
+    if code is None:
+        raise ValueError(f"Unknown scoring_func '{scoring_func}', must be one of {list(table.keys())}")
+    return code
+
+
+def topk_sigmoid(topk_weights: torch.Tensor, topk_ids: torch.Tensor, gating_output: torch.Tensor, renormalize: bool = False,
+                 correction_bias: Optional[torch.Tensor] = None, routed_scaling_factor: float = 1.0,
+                 num_fused_shared_experts: int = 0) -> None:
+    """Top-k of sigmoid(gating) (+ correction_bias for the choice only); weights / ids are written in place
+    ([tokens, topk] fp32 / int32). The last num_fused_shared_experts slots name the fused shared expert."""
+    _ops.topk_sigmoid.default(topk_weights, topk_ids, gating_output, renormalize, correction_bias, routed_scaling_factor,
+                              num_fused_shared_experts)
+
+
+def moe_fused_gate(input_tensor, bias: Optional[torch.Tensor], num_expert_group, topk_group, topk, renormalize=True,
+                   scoring_func="sigmoid", num_fused_shared_experts=0, routed_scaling_factor=0,
+                   apply_routed_scaling_factor_on_output=False):
+    """DeepSeek-V3 grouped top-k: expert groups are ranked by the sum of their two best (biased) scores, the topk_group
+    best groups stay eligible, then top-k over their experts. Returns [weights fp32 [tokens, topk], ids int32]."""
+    return _ops.moe_fused_gate.default(input_tensor, bias, num_expert_group, topk_group, topk, num_fused_shared_experts,
+                                       _scoring_code(_GATE_SCORING, scoring_func), renormalize, routed_scaling_factor,
+                                       apply_routed_scaling_factor_on_output)
+
+
+def biased_topk(input_tensor, bias, output, indices, topk, scoring_func, num_fused_shared_experts=0, renormalize=False,
+                routed_scaling_factor=1.0, apply_routed_scaling_factor_on_output=False):
+    """Top-k of score(input) + bias with score = sigmoid or sqrt(softplus); weights are the unbiased scores."""
+    _ops.biased_topk.default(input_tensor, bias, output, indices, topk, _scoring_code(_BIASED_TOPK_SCORING, scoring_func),
+                             num_fused_shared_experts, renormalize, routed_scaling_factor, apply_routed_scaling_factor_on_output)
 
 
 def prepare_moe_input(topk_ids, expert_offsets, problem_sizes1, problem_sizes2, input_permutation, output_permutation,

@@ -208,6 +208,42 @@ def gen_qknorm_rope():
     save("qknorm_rope", cases)
 
 
+def gen_moe_gates():
+    """tests/test_topk_sigmoid.py:41-92, tests/test_biased_topk.py:13-66, tests/test_moe_fused_gate.py:68-139: the three
+    routers' torch references on small seeded inputs (indices + weights)."""
+    cases = {"topk_sigmoid": [], "biased_topk": [], "moe_fused_gate": []}
+    t = _import_ref("test_topk_sigmoid")
+    for T, E, k, shared, renorm, with_bias, rsf in [(7, 8, 2, 0, False, False, 1.0), (32, 32, 4, 1, True, True, 2.5),
+                                                    (19, 256, 4, 0, True, True, 2.5), (5, 256, 2, 1, False, False, 2.5)]:
+        torch.manual_seed(1024 + E)
+        x = torch.randn(T, E)
+        bias = torch.randn(E) if with_bias else None
+        w, ids = t.fused_topk_sigmoid_torch_native(torch.randn(T, 100), x, k, renorm, bias, routed_scaling_factor=rsf,
+                                                   num_fused_shared_experts=shared)
+        cases["topk_sigmoid"].append(dict(x=x, bias=bias, topk=k, shared=shared, renormalize=renorm, rsf=rsf, weights=w, ids=ids))
+    t = _import_ref("test_biased_topk")
+    for T, E, k, scoring, shared, renorm, apply in [(9, 128, 4, "sigmoid", 0, True, False), (64, 384, 6, "sqrtsoftplus", 1, True, True),
+                                                    (5, 512, 8, "sigmoid", 1, False, True), (3, 128, 8, "sqrtsoftplus", 0, False, False)]:
+        torch.manual_seed(E * 100 + k)
+        x = torch.randn(T, E) * 2.0
+        bias = torch.randn(E) * 0.5
+        w, ids = t.biased_topk_torch_native(torch.randn(T, 100), x, bias, k, renorm, scoring, shared, 2.5, apply)
+        cases["biased_topk"].append(dict(x=x, bias=bias, topk=k, scoring=scoring, shared=shared, renormalize=renorm, rsf=2.5,
+                                         apply=apply, weights=w, ids=ids))
+    t = _import_ref("test_moe_fused_gate")
+    for T, (E, G, tg, k), scoring, renorm, apply in [(9, (128, 4, 2, 4), "sigmoid", True, False), (33, (256, 8, 4, 8), "sigmoid", True, True),
+                                                     (7, (512, 16, 8, 16), "softmax", False, False), (16, (256, 8, 4, 8), "softmax", True, True)]:
+        torch.manual_seed(T)
+        x = torch.rand(T, E)
+        bias = None if scoring == "softmax" else torch.rand(E)
+        w, ids = t.biased_grouped_topk_native(x, x, bias, topk=k, renormalize=renorm, num_expert_group=G, topk_group=tg,
+                                              num_fused_shared_experts=0, routed_scaling_factor=2.5,
+                                              apply_routed_scaling_factor_on_output=apply, scoring_func=scoring)
+        cases["moe_fused_gate"].append(dict(x=x, bias=bias, G=G, topk_group=tg, topk=k, scoring=scoring, renormalize=renorm, rsf=2.5,
+                                            apply=apply, weights=w, ids=ids))
+    save("moe_gates", cases)
+
+
 def gen_fp8_blockwise():
     t = _import_ref("test_fp8_blockwise_gemm")
     cases = []
@@ -499,6 +535,7 @@ GENERATORS = {
     "quant_extra": gen_quant_extra,
     "norm": gen_norm,
     "activation": gen_activation,
+    "moe_gates": gen_moe_gates,
     "quant_v2": gen_quant_v2,
     "merge_state": gen_merge_state,
     "qknorm_rope": gen_qknorm_rope,

@@ -281,3 +281,28 @@ def test_qknorm_rope_matches_reference_vectors():
                                      c["attention_factor"], c["rotary_dim"])
         p = prec[c["qkv"].dtype] * (2 if c["factor"] != 1.0 else 1)  # :375-377
         torch.testing.assert_close(out, c["out"].to(out.dtype), rtol=p, atol=p)
+
+
+def _same_routing(w, ids, ref_w, ref_ids, n_cols, rtol=1e-4, atol=1e-5):
+    """Order inside a row is not part of the contract (the reference's torch.topk(sorted=False)): compare the weights
+    scattered by expert id, as reference tests/test_biased_topk.py:77-86 does; the id SETS must be equal."""
+    dense = torch.zeros(w.shape[0], n_cols).scatter_(1, ids.long(), w.float())
+    ref = torch.zeros(w.shape[0], n_cols).scatter_(1, ref_ids.long(), ref_w.float())
+    assert torch.equal(ids.long().sort(dim=1).values, ref_ids.long().sort(dim=1).values)
+    torch.testing.assert_close(dense, ref, rtol=rtol, atol=atol)
+
+
+def test_moe_gates_match_reference_vectors():
+    from oracle import moe_gates as og
+
+    gold = load_golden("moe_gates")
+    for c in gold["topk_sigmoid"]:
+        w, ids = og.topk_sigmoid(c["x"], c["topk"], c["renormalize"], c["bias"], c["rsf"], c["shared"])
+        _same_routing(w, ids, c["weights"], c["ids"], c["x"].shape[1] + 1)
+    for c in gold["biased_topk"]:
+        w, ids = og.biased_topk(c["x"], c["bias"], c["topk"], c["scoring"], c["shared"], c["renormalize"], c["rsf"], c["apply"])
+        _same_routing(w, ids, c["weights"], c["ids"], c["x"].shape[1] + 1)
+    for c in gold["moe_fused_gate"]:
+        w, ids = og.moe_fused_gate(c["x"], c["bias"], c["G"], c["topk_group"], c["topk"], 0, c["scoring"], c["renormalize"],
+                                   c["rsf"], c["apply"])
+        _same_routing(w, ids, c["weights"], c["ids"], c["x"].shape[1], rtol=1e-2, atol=1e-3)  # test_moe_fused_gate.py:22-23
