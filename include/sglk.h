@@ -387,6 +387,28 @@ SGLK_API int sglk_moe_fused_gate(sglk_stream_t stream, float* output, int32_t* i
                                  int renormalize, float routed_scaling_factor,
                                  int apply_routed_scaling_factor_on_output, int dtype);
 
+/* ---- top-k / top-p / min-p filtering and sampling -------------------------------------------
+ * reference src/sycl/TopKRenormProbs.cpp, TopPRenormProbs.cpp, TopKTopPSamplingFromProbs.cpp,
+ * MinPSamplingFromProbs.cpp (schemas src/torch_extension_sycl.cc:66-80). probs fp32 [rows, vocab] contiguous.
+ *   kept(top-k): x >= k-th largest value; kept(top-p): x >= t_p, t_p the largest t with mass{x >= t} >= p;
+ *   kept(min-p): x >= min_p * max(x). Pivots are exact (radix select on the float bits, fixed-point masses).
+ *   renorm: out = kept ? x / sum(kept) : 0.  sampling: index drawn ~ x over the kept set by inverse CDF of one
+ *   Philox4x32-10(seed; offset, row) 64-bit draw: reproducible from (seed, offset). Per-row parameter arrays are
+ *   optional (NULL: the scalar); indices (optional) maps output row b to probs row indices[b]. */
+SGLK_API int sglk_top_k_renorm_probs(sglk_stream_t stream, float* renorm_probs, const float* probs,
+                                     const int64_t* top_k_arr, int64_t top_k_val, int64_t batch, int64_t vocab);
+SGLK_API int sglk_top_p_renorm_probs(sglk_stream_t stream, float* renorm_probs, const float* probs,
+                                     const float* top_p_arr, float top_p_val, int64_t batch, int64_t vocab);
+SGLK_API int sglk_top_k_top_p_sampling_from_probs(sglk_stream_t stream, int32_t* output, const float* probs,
+                                                  const int64_t* indices, const int32_t* top_k_arr, int64_t top_k_val,
+                                                  const float* top_p_arr, float top_p_val, int use_top_k,
+                                                  int64_t batch, int64_t vocab, uint64_t philox_seed,
+                                                  uint64_t philox_offset);
+SGLK_API int sglk_min_p_sampling_from_probs(sglk_stream_t stream, int32_t* output, const float* probs,
+                                            const int64_t* indices, const float* min_p_arr, float min_p_val,
+                                            int64_t batch, int64_t vocab, uint64_t philox_seed,
+                                            uint64_t philox_offset);
+
 #ifdef __cplusplus
 }
 #endif

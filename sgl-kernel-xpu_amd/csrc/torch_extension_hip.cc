@@ -13,12 +13,14 @@
 // module name python/sgl_kernel/__init__.py:14 of the reference imports.
 #include <Python.h>
 #include <ATen/ATen.h>
+#include <ATen/hip/HIPGeneratorImpl.h>
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <optional>
 #include <tuple>
 #include <vector>
@@ -958,6 +960,116 @@ void sgl_per_token_group_quant_8bit_v2(Tensor input, Tensor output_q, Tensor out
                                                kind, s_e, s_row, s_col, fuse_silu_and_mul ? 1 : 0));
 }
 
+// ---- sampling (reference src/sycl/TopKRenormProbs.cpp:300-330, TopPRenormProbs.cpp, TopKTopPSamplingFromProbs.cpp:265-347,
+//      MinPSamplingFromProbs.cpp) ---------------------------------------------------------------------------------
+
+void check_probs(const Tensor& probs, const char* op) {
+  CHECK_GPU(probs);
+  TORCH_CHECK(probs.is_contiguous(), op, ": probs must be contiguous");
+  TORCH_CHECK(probs.dim() == 2, "probs must be a 2D tensor [batch_size, vocab_size]");
+  TORCH_CHECK(probs.scalar_type() == at::kFloat, "probs must be float32");
+}
+
+template <typename T>
+const T* optional_row_array(const std::optional<Tensor>& t, at::ScalarType dt, int64_t batch, const char* name) {
+  if (!t.has_value()) return nullptr;
+  TORCH_CHECK(t->is_cuda() && t->is_contiguous(), name, " must be a contiguous GPU tensor");
+  TORCH_CHECK(t->dim() == 1, name, " must be a 1D tensor");
+  TORCH_CHECK(t->scalar_type() == dt, name, " must be ", dt);
+  TORCH_CHECK(t->size(0) == batch, name, " size must match batch_size");
+  return t->data_ptr<T>();
+}
+
+// (seed, offset) of the generator's Philox stream; the kernel consumes one 128-bit block per row
+std::pair<uint64_t, uint64_t> philox_inputs(const std::optional<at::Generator>& gen) {
+  auto* impl = at::get_generator_or_default<at::CUDAGeneratorImpl>(gen, at::cuda::detail::getDefaultCUDAGenerator());
+  std::lock_guard<std::mutex> lock(impl->mutex_);
+  return impl->philox_engine_inputs(4);
+}
+
+void top_k_renorm_probs(const Tensor& probs, Tensor& renorm_probs, const std::optional<Tensor>& maybe_top_k_arr, int64_t top_k_val) {
+  check_probs(probs, "top_k_renorm_probs");
+  CHECK_GPU(renorm_probs);
+  CHECK_CONTIGUOUS(renorm_probs);
+  TORCH_CHECK(probs.sizes() == renorm_probs.sizes(), "Input tensors must have the same shape");
+  TORCH_CHECK(probs.scalar_type() == renorm_probs.scalar_type(), "Input tensors must have the same dtype");
+  const int64_t* k = optional_row_array<int64_t>(maybe_top_k_arr, at::kLong, probs.size(0), "maybe_top_k_arr");
+  if (!k) TORCH_CHECK(top_k_val > 0, "top_k_val must be positive");
+  const c10::OptionalDeviceGuard guard(probs.device());
+  SGLK_CALL(sglk_top_k_renorm_probs(stream_of(probs), renorm_probs.data_ptr<float>(), probs.data_ptr<float>(), k, top_k_val,
+                                    probs.size(0), probs.size(1)));
+}
+
+void top_p_renorm_probs(const Tensor& probs, Tensor& renorm_probs, const std::optional<Tensor>& maybe_top_p_arr, double top_p_val) {
+  check_probs(probs, "top_p_renorm_probs");
+  CHECK_GPU(renorm_probs);
+  CHECK_CONTIGUOUS(renorm_probs);
+  TORCH_CHECK(probs.sizes() == renorm_probs.sizes(), "Input tensors must have the same shape");
+  TORCH_CHECK(probs.scalar_type() == renorm_probs.scalar_type(), "Input tensors must have the same dtype");
+  const float* pa = optional_row_array<float>(maybe_top_p_arr, at::kFloat, probs.size(0), "maybe_top_p_arr");
+  if (!pa) TORCH_CHECK(top_p_val > 0.0 && top_p_val <= 1.0, "top_p_val must be within (0, 1]");
+  const c10::OptionalDeviceGuard guard(probs.device());
+  SGLK_CALL(sglk_top_p_renorm_probs(stream_of(probs), renorm_probs.data_ptr<float>(), probs.data_ptr<float>(), pa, (float)top_p_val,
+                                    probs.size(0), probs.size(1)));
+}
+
+void sampling_common(const char* op, const Tensor& probs, Tensor& output, const std::optional<Tensor>& maybe_indices,
+                     int64_t& batch, const int64_t*& indices) {
+  check_probs(probs, op);
+  CHECK_GPU(output);
+  CHECK_CONTIGUOUS(output);
+  TORCH_CHECK(output.dim() == 1, "output must be a 1D tensor [batch_size]");
+  TORCH_CHECK(output.scalar_type() == at::kInt, "output must be int32");
+  batch = output.size(0);
+  indices = optional_row_array<int64_t>(maybe_indices, at::kLong, batch, "maybe_indices");
+  if (!indices) TORCH_CHECK(probs.size(0) == batch, "probs.size(0) must match output.size(0) when maybe_indices is not provided");
+}
+
+void top_k_top_p_sampling_from_probs(Tensor probs, Tensor output, std::optional<Tensor> maybe_indices,
+                                     std::optional<Tensor> maybe_top_k_arr, int64_t top_k_val, std::optional<Tensor> maybe_top_p_arr,
+                                     double top_p_val, bool deterministic, std::optional<at::Generator> gen) {
+  (void)deterministic;  // the kernel is reproducible from (seed, offset) either way
+  int64_t batch;
+  const int64_t* indices;
+  sampling_common("top_k_top_p_sampling_from_probs", probs, output, maybe_indices, batch, indices);
+  const int32_t* k = optional_row_array<int32_t>(maybe_top_k_arr, at::kInt, batch, "maybe_top_k_arr");
+  if (!k) TORCH_CHECK(top_k_val > 0 && top_k_val <= probs.size(1), "top_k_val must be within (0, vocab_size]");
+  const float* pa = optional_row_array<float>(maybe_top_p_arr, at::kFloat, batch, "maybe_top_p_arr");
+  if (!pa) TORCH_CHECK(top_p_val > 0.0 && top_p_val <= 1.0, "top_p_val must be within (0, 1]");
+  const auto ph = philox_inputs(gen);
+  const c10::OptionalDeviceGuard guard(probs.device());
+  SGLK_CALL(sglk_top_k_top_p_sampling_from_probs(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices, k,
+                                                 top_k_val, pa, (float)top_p_val, 1, batch, probs.size(1), ph.first, ph.second));
+}
+
+void top_p_sampling_from_probs(Tensor probs, Tensor output, std::optional<Tensor> maybe_indices, std::optional<Tensor> maybe_top_p_arr,
+                               double top_p_val, bool deterministic, std::optional<at::Generator> gen) {
+  (void)deterministic;
+  int64_t batch;
+  const int64_t* indices;
+  sampling_common("top_p_sampling_from_probs", probs, output, maybe_indices, batch, indices);
+  const float* pa = optional_row_array<float>(maybe_top_p_arr, at::kFloat, batch, "maybe_top_p_arr");
+  if (!pa) TORCH_CHECK(top_p_val > 0.0 && top_p_val <= 1.0, "top_p_val must be within (0, 1]");
+  const auto ph = philox_inputs(gen);
+  const c10::OptionalDeviceGuard guard(probs.device());
+  SGLK_CALL(sglk_top_k_top_p_sampling_from_probs(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices,
+                                                 nullptr, 0, pa, (float)top_p_val, 0, batch, probs.size(1), ph.first, ph.second));
+}
+
+void min_p_sampling_from_probs(const Tensor& probs, Tensor& output, const std::optional<Tensor>& maybe_indices,
+                               const std::optional<Tensor>& maybe_min_p_arr, double min_p_val, bool deterministic,
+                               const std::optional<at::Generator>& gen) {
+  (void)deterministic;
+  int64_t batch;
+  const int64_t* indices;
+  sampling_common("min_p_sampling_from_probs", probs, output, maybe_indices, batch, indices);
+  const float* pa = optional_row_array<float>(maybe_min_p_arr, at::kFloat, batch, "maybe_min_p_arr");
+  const auto ph = philox_inputs(gen);
+  const c10::OptionalDeviceGuard guard(probs.device());
+  SGLK_CALL(sglk_min_p_sampling_from_probs(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices, pa,
+                                           (float)min_p_val, batch, probs.size(1), ph.first, ph.second));
+}
+
 // ---- DeepSeek-style routers (reference src/sycl/TopKSigMoid.cpp, BiasedTopK.cpp:457-520, MoE_fused_gate.cpp:486-600) ----
 
 void topk_sigmoid(Tensor& topk_weights, Tensor& topk_indices, const Tensor& gating_output, bool renormalize,
@@ -1295,6 +1407,25 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "store_cache(Tensor k, Tensor v, Tensor(a!) k_cache, Tensor(b!) v_cache, "
       "Tensor indices) -> ()");
   m.impl("store_cache", c10::kCUDA, &store_cache);
+  // reference src/torch_extension_sycl.cc:66-80 (top_p_sampling_from_probs: declared at include/sgl_kernel_ops.h:938-945 and
+  // called by python/sgl_kernel/sampling.py:119, never registered there; schema authored from the declaration)
+  m.def("top_k_renorm_probs(Tensor probs, Tensor! renorm_probs, Tensor? maybe_top_k_arr, int top_k_val) -> ()");
+  m.impl("top_k_renorm_probs", c10::kCUDA, &top_k_renorm_probs);
+  m.def("top_p_renorm_probs(Tensor probs, Tensor! renorm_probs, Tensor? maybe_top_p_arr, float top_p_val) -> ()");
+  m.impl("top_p_renorm_probs", c10::kCUDA, &top_p_renorm_probs);
+  m.def(
+      "top_k_top_p_sampling_from_probs(Tensor probs, Tensor! output, Tensor? maybe_indices, Tensor? "
+      "maybe_top_k_arr, int top_k_val, Tensor? maybe_top_p_arr, float top_p_val, bool deterministic, Generator? "
+      "gen) -> ()");
+  m.impl("top_k_top_p_sampling_from_probs", c10::kCUDA, &top_k_top_p_sampling_from_probs);
+  m.def(
+      "top_p_sampling_from_probs(Tensor probs, Tensor! output, Tensor? maybe_indices, Tensor? "
+      "maybe_top_p_arr, float top_p_val, bool deterministic, Generator? gen) -> ()");
+  m.impl("top_p_sampling_from_probs", c10::kCUDA, &top_p_sampling_from_probs);
+  m.def(
+      "min_p_sampling_from_probs(Tensor probs, Tensor! output, Tensor? maybe_indices, Tensor? "
+      "maybe_min_p_arr, float min_p_val, bool deterministic, Generator? gen) -> ()");
+  m.impl("min_p_sampling_from_probs", c10::kCUDA, &min_p_sampling_from_probs);
   // reference src/torch_extension_sycl.cc:55-58, :111-115, :191-196
   m.def(
       "topk_sigmoid(Tensor! topk_weights, Tensor! topk_indices, Tensor gating_output, bool renormalize, Tensor? "

@@ -65,6 +65,15 @@ from sgl_kernel.moe import (  # noqa: E402
     topk_sigmoid,
     topk_softmax,
 )
+from sgl_kernel.sampling import (  # noqa: E402
+    min_p_sampling_from_probs,
+    top_k_renorm_prob,
+    top_k_renorm_probs,
+    top_k_top_p_sampling_from_probs,
+    top_p_renorm_prob,
+    top_p_renorm_probs,
+    top_p_sampling_from_probs,
+)
 from sgl_kernel.utils import get_device_capability, is_gfx950_arch, is_xe2_arch  # noqa: E402
 from sgl_kernel.version import __version__  # noqa: E402
 
@@ -81,8 +90,7 @@ _OUT_OF_SCOPE = frozenset(
     multimodal_rotary_embedding silu_and_mul_clamp
     cutlass_fp4_group_mm fp8_blockwise_scaled_grouped_mm hash_topk moe_sum
     moe_sum_reduce swiglu_gpt_oss_sigmoid_alpha
-    min_p_sampling_from_probs top_k_renorm_prob top_k_top_p_sampling_from_probs top_p_renorm_prob
-    top_p_sampling_from_probs weak_ref_tensor
+    weak_ref_tensor
     """.split()
 )
 

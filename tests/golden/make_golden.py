@@ -244,6 +244,47 @@ def gen_moe_gates():
     save("moe_gates", cases)
 
 
+def gen_sampling():
+    """tests/test_sampling.py: torch_top_k_renorm_probs (:176-204), torch_top_p_renorm_probs (:104-126; it regenerates its
+    input from seed 42, so the same recipe is used here), torch_top_k_top_p_joint_mask (:13-34), torch_min_p_sampling
+    (:262-274)."""
+    t = _import_ref("test_sampling")
+    t.device = "cpu"
+    cases = {"top_k_renorm": [], "top_p_renorm": [], "joint_mask": [], "min_p_mask": []}
+    for B, V, k in [(3, 111, 10), (5, 3000, 100), (4, 3000, torch.tensor([10, 33, 49, 17]))]:
+        torch.manual_seed(42)
+        pre = torch.rand(B, V)
+        pr = pre / pre.sum(dim=-1, keepdim=True)
+        cases["top_k_renorm"].append(dict(probs=pr, k=k, out=t.torch_top_k_renorm_probs(pr, k)))
+    for B, V, pp in [(3, 111, 0.1), (5, 3000, 1.0), (4, 3000, torch.tensor([0.2, 0.5, 0.75, 0.9]))]:
+        torch.manual_seed(42)
+        pre = torch.rand(B, V)
+        pr = pre / pre.sum(dim=-1, keepdim=True)
+        cases["top_p_renorm"].append(dict(probs=pr, p=pp, out=t.torch_top_p_renorm_probs(pr, pp)))
+    for B, V, k, pp in [(3, 111, 55, 0.1), (5, 3000, 300, 0.5), (4, 3000, torch.tensor([10, 49, 150, 70]), torch.tensor([0.1, 0.3, 0.7, 0.5]))]:
+        torch.manual_seed(42)
+        pre = torch.rand(B, V)
+        pr = pre / pre.sum(dim=-1, keepdim=True)
+        cases["joint_mask"].append(dict(probs=pr, k=k, p=pp, mask=t.torch_top_k_top_p_joint_mask(B, V, k, pp, pr)))
+    for B, V, pp in [(3, 111, 0.05), (5, 3000, 0.7), (4, 3000, torch.tensor([0.05, 0.1, 0.2, 0.6]))]:
+        torch.manual_seed(42)
+        pre = torch.rand(B, V)
+        pr = pre / pre.sum(dim=-1, keepdim=True)
+        real = torch.zeros
+        cases["min_p_mask"].append(dict(probs=pr, p=pp, mask=_min_p_mask_ref(t, B, V, pp, pr)))
+    save("sampling", cases)
+
+
+def _min_p_mask_ref(t, B, V, pp, pr):
+    # torch_min_p_sampling builds its mask with device=f"{device}:0": run it with torch.zeros redirected to the CPU
+    real = torch.zeros
+    torch.zeros = lambda *a, **k: real(*a, **{**k, "device": "cpu"})
+    try:
+        return t.torch_min_p_sampling(B, V, pp, pr)
+    finally:
+        torch.zeros = real
+
+
 def gen_fp8_blockwise():
     t = _import_ref("test_fp8_blockwise_gemm")
     cases = []
@@ -536,6 +577,7 @@ GENERATORS = {
     "norm": gen_norm,
     "activation": gen_activation,
     "moe_gates": gen_moe_gates,
+    "sampling": gen_sampling,
     "quant_v2": gen_quant_v2,
     "merge_state": gen_merge_state,
     "qknorm_rope": gen_qknorm_rope,

@@ -306,3 +306,19 @@ def test_moe_gates_match_reference_vectors():
         w, ids = og.moe_fused_gate(c["x"], c["bias"], c["G"], c["topk_group"], c["topk"], 0, c["scoring"], c["renormalize"],
                                    c["rsf"], c["apply"])
         _same_routing(w, ids, c["weights"], c["ids"], c["x"].shape[1], rtol=1e-2, atol=1e-3)  # test_moe_fused_gate.py:22-23
+
+
+def test_sampling_filters_match_reference_vectors():
+    from oracle import sampling as osamp
+
+    gold = load_golden("sampling")
+    for c in gold["top_k_renorm"]:
+        torch.testing.assert_close(osamp.renorm(c["probs"], osamp.top_k_mask(c["probs"], c["k"])), c["out"], rtol=1e-3, atol=1e-3)
+    for c in gold["top_p_renorm"]:
+        torch.testing.assert_close(osamp.renorm(c["probs"], osamp.top_p_mask(c["probs"], c["p"])), c["out"], rtol=1e-3, atol=1e-3)
+    for c in gold["joint_mask"]:
+        mine = osamp.top_k_mask(c["probs"], c["k"]) & osamp.top_p_mask(c["probs"], c["p"])
+        assert torch.all(c["mask"][mine] == 1)  # the reference's mask has an eps of slack on the top-p side: a superset
+        assert (c["mask"].bool() & ~mine).sum() <= mine.shape[0] * 2
+    for c in gold["min_p_mask"]:
+        assert torch.equal(osamp.min_p_mask(c["probs"], c["p"]), c["mask"].bool())

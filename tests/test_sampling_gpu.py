@@ -1,0 +1,147 @@
+"""GPU parity: top_k_renorm_probs, top_p_renorm_probs, top_k_top_p_sampling_from_probs, top_p_sampling_from_probs,
+min_p_sampling_from_probs vs the CPU oracle's filters.
+
+Grids follow reference tests/test_sampling.py (batch {1, 99, 989}, vocab {111, 32000, 128256, 151936}, scalar and
+per-row thresholds); draws are checked the way the reference does (every sample lies inside the filter mask, :56-61),
+plus what an exact-pivot implementation can promise on top: the mask of renormalised rows EQUALS the oracle's,
+draws are reproducible from the generator state, and the empirical distribution matches."""
+import pytest
+import torch
+from conftest import load_golden
+
+from oracle import sampling as osamp
+
+pytestmark = pytest.mark.gpu
+
+
+def make_probs(B, V, seed=42):
+    g = torch.Generator().manual_seed(seed)
+    pre = torch.rand(B, V, generator=g)
+    return pre / pre.sum(dim=-1, keepdim=True)
+
+
+@pytest.mark.parametrize("B", [1, 99, 989])
+@pytest.mark.parametrize("V", [111, 32000, 128256])
+@pytest.mark.parametrize("k", [10, 100, 500, "array"])
+def test_top_k_renorm(sglk, dev, B, V, k):
+    if k != "array" and k > V:
+        pytest.skip("k > vocab")
+    if B == 989 and V > 32000:
+        B = 123  # (CPU oracle time)
+    pr = make_probs(B, V)
+    kk = torch.randint(10, min(200, V), (B,), generator=torch.Generator().manual_seed(1)) if k == "array" else k
+    out = sglk.top_k_renorm_prob(pr.to(dev), kk.to(dev) if k == "array" else kk).cpu()
+    mask = osamp.top_k_mask(pr, kk)
+    assert torch.equal(out > 0, mask & (pr > 0))  # exact pivot: the kept set is the oracle's
+    torch.testing.assert_close(out, osamp.renorm(pr, mask), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.sum(dim=-1), torch.ones(B), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B", [1, 99, 989])
+@pytest.mark.parametrize("V", [111, 32000, 151936])
+@pytest.mark.parametrize("p", [0.1, 0.5, 1.0, "array"])
+def test_top_p_renorm(sglk, dev, B, V, p):
+    if B == 989 and V > 32000:
+        B = 123
+    pr = make_probs(B, V)
+    pp = torch.rand(B, generator=torch.Generator().manual_seed(2)) * 0.8 + 0.1 if p == "array" else p
+    out = sglk.top_p_renorm_prob(pr.to(dev), pp.to(dev) if p == "array" else pp).cpu()
+    mask = osamp.top_p_mask(pr, pp)
+    got = out > 0
+    # the nucleus boundary is decided on sums of ~V terms: the oracle sums in float64, the kernel in 2^-40 fixed point;
+    # at most the boundary element of a row may differ
+    assert ((got != (mask & (pr > 0))).sum(dim=1) <= 1).all()
+    torch.testing.assert_close(out, osamp.renorm(pr, got), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("B", [1, 99, 989])
+@pytest.mark.parametrize("V", [111, 32000, 128256])
+@pytest.mark.parametrize("p,kfrac", [(0.1, 0.5), (0.5, 0.1), ("array", None)])
+def test_joint_sampling_membership(sglk, dev, B, V, p, kfrac):
+    if B == 989 and V > 32000:
+        B = 123
+    pr = make_probs(B, V)
+    if p == "array":
+        g = torch.Generator().manual_seed(3)
+        kk = torch.randint(10, min(200, V), (B,), generator=g)
+        pp = torch.rand(B, generator=g) * 0.6 + 0.1
+        k_dev, p_dev = kk.to(dev), pp.to(dev)
+    else:
+        kk, pp = int(V * kfrac), p
+        k_dev, p_dev = kk, pp
+    mask = osamp.top_k_mask(pr, kk) & osamp.top_p_mask(pr, pp)
+    # one element of slack at the nucleus boundary (see test_top_p_renorm): allow the kernel's own renorm mask as well
+    mask |= sglk.top_p_renorm_prob(pr.to(dev), p_dev).cpu() > 0 if p == "array" else mask
+    mask &= osamp.top_k_mask(pr, kk)
+    prd = pr.to(dev)
+    rows = torch.arange(B)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    for _ in range(50):
+        s = sglk.top_k_top_p_sampling_from_probs(prd, k_dev, p_dev, filter_apply_order="joint", generator=gen).cpu().long()
+        assert s.dtype == torch.int64 and torch.all((s >= 0) & (s < V))
+        assert torch.all(mask[rows, s]), pr[rows, s][~mask[rows, s]]
+
+
+@pytest.mark.parametrize("B", [1, 99])
+@pytest.mark.parametrize("V", [111, 32000, 128256])
+@pytest.mark.parametrize("p", [0.05, 0.2, 0.7, 1.0, "array"])
+def test_min_p_sampling_membership(sglk, dev, B, V, p):
+    pr = make_probs(B, V)
+    pp = torch.rand(B, generator=torch.Generator().manual_seed(4)) * 0.6 + 0.05 if p == "array" else p
+    mask = osamp.min_p_mask(pr, pp)
+    prd, p_dev = pr.to(dev), (pp.to(dev) if p == "array" else pp)
+    rows = torch.arange(B)
+    for _ in range(50):
+        s = sglk.min_p_sampling_from_probs(prd, p_dev).cpu().long()
+        assert torch.all(mask[rows, s])
+
+
+def test_draws_are_reproducible_and_distributed_like_the_filtered_probs(sglk, dev):
+    # 20000 rows of ONE small distribution: the sample histogram must follow the renormalised kept probabilities
+    V, B = 16, 20000
+    base = torch.tensor([0.30, 0.02, 0.18, 0.01, 0.09, 0.05, 0.11, 0.004, 0.07, 0.03, 0.06, 0.016, 0.02, 0.02, 0.01, 0.01])
+    base = base / base.sum()
+    pr = base.unsqueeze(0).repeat(B, 1).contiguous().to(dev)
+    g1 = torch.Generator(device=dev).manual_seed(123)
+    g2 = torch.Generator(device=dev).manual_seed(123)
+    a = sglk.top_k_top_p_sampling_from_probs(pr, 8, 0.85, filter_apply_order="joint", generator=g1)
+    b = sglk.top_k_top_p_sampling_from_probs(pr, 8, 0.85, filter_apply_order="joint", generator=g2)
+    assert torch.equal(a, b)  # same generator state, same draws
+    c = sglk.top_k_top_p_sampling_from_probs(pr, 8, 0.85, filter_apply_order="joint", generator=g1)
+    assert not torch.equal(a, c)  # the generator advanced
+    mask = (osamp.top_k_mask(base[None], 8) & osamp.top_p_mask(base[None], 0.85))[0]
+    want = osamp.renorm(base[None], mask[None])[0]
+    freq = torch.bincount(a.cpu().long(), minlength=V).float() / B
+    assert torch.all(freq[~mask] == 0)
+    assert (freq - want).abs().max() < 4 * (want * (1 - want) / B).sqrt().max() + 1e-3  # 4 sigma
+    # indices: output row b samples probs row indices[b]
+    two = torch.stack([base, torch.eye(V)[5]]).to(dev)
+    idx = torch.tensor([1, 1, 0, 1], device=dev)
+    s = sglk.top_p_sampling_from_probs(two, 1.0, indices=idx).cpu()
+    assert s[0] == 5 and s[1] == 5 and s[3] == 5
+    # top_k_first order = renorm then top-p sampling
+    s = sglk.top_k_top_p_sampling_from_probs(pr, 1, 0.99)
+    assert torch.all(s.cpu() == 0)
+    with pytest.raises(ValueError, match="NaN"):
+        sglk.min_p_sampling_from_probs(torch.full((1, 8), float("nan"), device=dev), 0.1, check_nan=True)
+    with pytest.raises(ValueError, match="Invalid filter_apply_order"):
+        sglk.top_k_top_p_sampling_from_probs(pr, 1, 0.5, filter_apply_order="p_first")
+
+
+def test_sampling_golden(sglk, dev):
+    gold = load_golden("sampling")
+    mv = lambda v: v.to(dev) if isinstance(v, torch.Tensor) else v
+    for c in gold["top_k_renorm"]:
+        torch.testing.assert_close(sglk.top_k_renorm_prob(c["probs"].to(dev), mv(c["k"])).cpu(), c["out"], rtol=1e-3, atol=1e-3)
+    for c in gold["top_p_renorm"]:
+        torch.testing.assert_close(sglk.top_p_renorm_prob(c["probs"].to(dev), mv(c["p"])).cpu(), c["out"], rtol=1e-3, atol=1e-3)
+    for c in gold["joint_mask"]:
+        B = c["probs"].shape[0]
+        for _ in range(20):
+            s = sglk.top_k_top_p_sampling_from_probs(c["probs"].to(dev), mv(c["k"]), mv(c["p"]), filter_apply_order="joint").cpu().long()
+            assert torch.all(c["mask"][torch.arange(B), s] == 1)
+    for c in gold["min_p_mask"]:
+        B = c["probs"].shape[0]
+        for _ in range(20):
+            s = sglk.min_p_sampling_from_probs(c["probs"].to(dev), mv(c["p"])).cpu().long()
+            assert torch.all(c["mask"][torch.arange(B), s] == 1)
