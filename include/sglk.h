@@ -286,6 +286,12 @@ SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const vo
  *   part_lse fp32 [splits,Hq,total_q]); sglk_attn_auto_splits gives the "0 = auto" choice. */
 SGLK_API int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
                                        int64_t max_seqlen_k);
+/* kv_layout 0: ragged k / v [total_k, Hk, D] (strides token, head), seqlens_k = cumulative offsets [b + 1];
+ *           1: paged [pages, page, Hk, D] + page_table; 2: one cache row per slot [slots, seqlen_cache, Hk, D]
+ *              (strides slot, token, head; reference decode::mha_fwd_nopage, flash_attention.cpp:83-270).
+ * Layouts 1 and 2: seqlens_k[b] is the END cache position of sequence b, its keys are the cache positions
+ * [leftpad_k[b], seqlens_k[b]) (leftpad_k NULL: 0) of cache row kv_batch_idx[b] (NULL: b) - the page-table row or
+ * the slot (reference flash_attention.cpp:383, :408-412, :649-653). */
 /* kv_dtype: dtype (K/V stored like q) or SGLK_FP8_E4M3 / SGLK_FP8_E5M2 for an fp8 KV cache, dequantised in the kernel
  * with one float each for K and V (device pointers k_descale / v_descale; reference flash_attention.cpp:561-572). */
 SGLK_API int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const void* q, const void* k,
@@ -297,7 +303,8 @@ SGLK_API int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const vo
                            int64_t k_stride1, int64_t k_stride2, int64_t v_stride0, int64_t v_stride1,
                            int64_t v_stride2, int64_t table_stride, float softmax_scale, int is_causal,
                            int64_t window_left, int64_t window_right, float softcap, int64_t num_splits,
-                           int dtype, int kv_dtype, const float* k_descale, const float* v_descale);
+                           int dtype, int kv_dtype, const float* k_descale, const float* v_descale, int kv_layout,
+                           const int32_t* kv_batch_idx, const int32_t* leftpad_k);
 
 /* sgl_per_token_group_quant_8bit_v2: reference src/sycl/per_token_group_quant_8bit_v2.cpp:714-842
  * (schema src/torch_extension_sycl.cc:399-402). As v1 plus: fuse_silu_and_mul (x is [.., 2*hidden], the value

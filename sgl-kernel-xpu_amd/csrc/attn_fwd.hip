@@ -76,7 +76,10 @@ struct AttnParams {
   int64_t table_stride;
   int Hq, Hk, G, D, total_q;
   int page_shift;       // log2(page size), paged only
-  int paged;            // 1: k/v are [pages, page, Hk, D] + page_table + seqused_k; 0: ragged + cu_seqlens_k
+  int paged;            // 0: ragged k/v [total_k, Hk, D] + cu_seqlens_k; 1: paged [pages, page, Hk, D] + page_table + key END
+                        // positions; 2: one cache row per slot [slots, seqlen_cache, Hk, D] + key END positions
+  const int32_t* kv_batch_idx;  // [b] cache row (page-table row / slot) of sequence b, or null: b itself (layouts 1, 2)
+  const int32_t* leftpad_k;     // [b] first valid cache position of sequence b, or null: 0 (layouts 1, 2)
   int causal_right;     // window right (>= 0 active, < 0 unlimited)
   int window_left;      // >= 0 active, < 0 unlimited
   int splits;
@@ -117,9 +120,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 
   const int q_begin = cu_q[b];
   const int seqlen_q = cu_q[b + 1] - q_begin;
-  int seqlen_k, k_begin = 0;
+  // Cache layouts (reference flash_attention.cpp:383, :408-412, :649-653; tests/test_flash_attention.py:855-893): sequence
+  // b lives in cache row kv_batch_idx[b] (default b) at cache positions [leftpad_k[b], seq_k[b]): key index i of the
+  // attention problem is cache position i + leftpad.
+  int seqlen_k, k_begin = 0, cache_row = b, leftpad = 0;
   if (p.paged) {
-    seqlen_k = seq_k[b];
+    if (p.kv_batch_idx != nullptr) cache_row = p.kv_batch_idx[b];
+    if (p.leftpad_k != nullptr) leftpad = p.leftpad_k[b];
+    seqlen_k = seq_k[b] - leftpad;
+    seqlen_k = seqlen_k > 0 ? seqlen_k : 0;
   } else {
     k_begin = seq_k[b];
     seqlen_k = seq_k[b + 1] - k_begin;
@@ -192,11 +201,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   Stage sreg[kSets];
   // Paged KV with pages of at least one tile (32 tokens): the page of a tile is wave-uniform, so its table entry is
   // a scalar load that the main loop issues one tile ahead (`pg`); otherwise every thread looks its own row up.
-  const bool uniform_page = p.paged && p.page_shift >= 5;
-  const int32_t* table_b = page_table + (p.paged ? (int64_t)b * p.table_stride : 0);
+  const bool uniform_page = p.paged == 1 && p.page_shift >= 5 && (leftpad & (kTile - 1)) == 0;
+  const int32_t* table_b = page_table + (p.paged == 1 ? (int64_t)cache_row * p.table_stride : 0);
   auto page_of_tile = [&](int t) -> int {
     const int pos = t * kTile;
-    return (uniform_page && pos < seqlen_k) ? table_b[pos >> p.page_shift] : 0;
+    return (uniform_page && pos < seqlen_k) ? table_b[(pos + leftpad) >> p.page_shift] : 0;
   };
   auto issue_loads = [&](int t, int pg, Stage& sr) {
     const int tok0 = t * kTile;
@@ -209,8 +218,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
       if (row < kTile && pos < seqlen_k) {
         int64_t koff, voff;
         if (p.paged) {
-          const int page = uniform_page ? pg : table_b[pos >> p.page_shift];
-          const int inp = pos & ((1 << p.page_shift) - 1);
+          const int cp = pos + leftpad;  // cache position
+          const int page = p.paged == 2 ? cache_row : uniform_page ? pg : table_b[cp >> p.page_shift];
+          const int inp = p.paged == 2 ? cp : cp & ((1 << p.page_shift) - 1);
           koff = (int64_t)page * p.k_s0 + (int64_t)inp * p.k_s1 + (int64_t)hk * p.k_s2;
           voff = (int64_t)page * p.v_s0 + (int64_t)inp * p.v_s1 + (int64_t)hk * p.v_s2;
         } else {
@@ -579,7 +589,8 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
                              int64_t k_stride1, int64_t k_stride2, int64_t v_stride0, int64_t v_stride1,
                              int64_t v_stride2, int64_t table_stride, float softmax_scale, int is_causal,
                              int64_t window_left, int64_t window_right, float softcap, int64_t num_splits,
-                             int dtype, int kv_dtype, const float* k_descale, const float* v_descale) {
+                             int dtype, int kv_dtype, const float* k_descale, const float* v_descale, int kv_layout,
+                             const int32_t* kv_batch_idx, const int32_t* leftpad_k) {
   using namespace sglk;
   SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "mha_fwd only supports Half and BFloat16");
   SGLK_REQUIRE(num_heads > 0 && num_heads_k > 0 && num_heads % num_heads_k == 0,
@@ -593,7 +604,11 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
                    k_stride2 % 8 == 0 && v_stride0 % 8 == 0 && v_stride1 % 8 == 0 && v_stride2 % 8 == 0 &&
                    (uintptr_t)q % 16 == 0 && (uintptr_t)k % (kv8 ? 8 : 16) == 0 && (uintptr_t)v % (kv8 ? 8 : 16) == 0,
                "fwd: q, k and v rows must be 16-byte aligned (8-byte for an fp8 cache)");
-  const bool paged = page_table != nullptr;
+  SGLK_REQUIRE(kv_layout >= 0 && kv_layout <= 2, "fwd: kv_layout must be 0 (ragged), 1 (paged) or 2 (cache rows)");
+  SGLK_REQUIRE((kv_layout == 1) == (page_table != nullptr), "fwd: a page table goes with the paged layout and only with it");
+  SGLK_REQUIRE(kv_layout != 0 || (kv_batch_idx == nullptr && leftpad_k == nullptr),
+               "fwd: kv_batch_idx / leftpad_k need a KV cache (paged or cache-row layout)");
+  const bool paged = kv_layout == 1;
   int page_shift = 0;
   if (paged) {
     SGLK_REQUIRE(page_size > 0 && (page_size & (page_size - 1)) == 0, "fwd: page size must be a power of two, got %lld",
@@ -622,7 +637,9 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
   p.D = (int)head_dim;
   p.total_q = (int)total_q;
   p.page_shift = page_shift;
-  p.paged = paged ? 1 : 0;
+  p.paged = kv_layout;
+  p.kv_batch_idx = kv_batch_idx;
+  p.leftpad_k = leftpad_k;
   // causal == window_right 0 (reference flash_attention.cpp:401-404); negative = unlimited
   p.causal_right = is_causal ? 0 : (window_right >= 0 ? (int)window_right : -1);
   p.window_left = window_left >= 0 ? (int)window_left : -1;

@@ -778,7 +778,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
   if (fp8_kv) {
     TORCH_CHECK(v.scalar_type() == k.scalar_type(), "key and value must have the same dtype");
     TORCH_CHECK(k_descale.has_value() && v_descale.has_value(), "fp8 KV cache requires k_descale and v_descale");
-    TORCH_CHECK(page_table.has_value(), "fwd: the fp8 KV cache path needs a paged cache");
+    TORCH_CHECK(k.dim() == 4, "fwd: the fp8 KV cache path needs a KV cache (paged or one row per slot)");
   } else {
     TORCH_CHECK(k.scalar_type() == q_type, "query and key must have the same dtype");
     TORCH_CHECK(v.scalar_type() == q_type, "query and value must have the same dtype");
@@ -789,8 +789,6 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
   TORCH_CHECK(!q_v.has_value(), "q_v is not supported yet");  // as the reference: flash_attention.cpp:603-609
   TORCH_CHECK(!rotary_cos.has_value() && !rotary_sin.has_value() && !seqlens_rotary.has_value(),
               "fwd: in-kernel rotary embedding is not supported");
-  TORCH_CHECK(!kv_batch_idx.has_value(), "fwd: kv_batch_idx is not supported");
-  TORCH_CHECK(!leftpad_k.has_value(), "fwd: leftpad_k is not supported");
   TORCH_CHECK(!q_descale.has_value(), "fwd: q_descale is not supported (q is never fp8 on this build)");
   // per-tensor descale: a scalar or an expanded scalar (reference get_per_tensor_descale_ptr, flash_attention.cpp:45-70)
   auto descale_ptr = [&](const std::optional<Tensor>& t, const char* name) -> const float* {
@@ -823,6 +821,18 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
   TORCH_CHECK(k.size(-1) == head_size, "key must have the head size of query");
 
   const bool paged = page_table.has_value();
+  const bool cache_rows = !paged && k.dim() == 4;  // [slots, seqlen_cache, h_k, d] (reference mha_fwd_nopage)
+  const int kv_layout = paged ? 1 : cache_rows ? 2 : 0;
+  auto batch_array = [&](const std::optional<Tensor>& t, const char* name) -> const int32_t* {
+    if (!t.has_value()) return nullptr;
+    TORCH_CHECK(kv_layout != 0, name, " needs a KV cache (a page table or a 4-D cache)");
+    TORCH_CHECK(t->is_cuda() && t->is_contiguous(), name, " must be a contiguous GPU tensor");
+    TORCH_CHECK(t->scalar_type() == at::kInt, name, " must have dtype int32");
+    TORCH_CHECK(t->dim() == 1 && t->size(0) == batch, name, " must have one entry per sequence");
+    return t->data_ptr<int32_t>();
+  };
+  const int32_t* batch_idx_ptr = batch_array(kv_batch_idx, "kv_batch_idx");
+  const int32_t* leftpad_ptr = batch_array(leftpad_k, "leftpad_k");
   const int32_t* table_ptr = nullptr;
   int64_t page_size = 0, table_stride = 0, seqlen_k_max = max_seqlen_k;
   int64_t ks0, ks1, ks2 = 0, vs0, vs1, vs2 = 0;
@@ -831,7 +841,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
     CHECK_GPU(pt);
     TORCH_CHECK(pt.scalar_type() == at::kInt, "page_table must have dtype torch.int32");
     TORCH_CHECK(pt.dim() == 2 && pt.stride(-1) == 1, "page_table must have contiguous last dimension");
-    TORCH_CHECK(pt.size(0) == batch, "batch_size must be equal to batch_size_k");
+    TORCH_CHECK(batch_idx_ptr != nullptr || pt.size(0) == batch, "batch_size must be equal to batch_size_k");
     TORCH_CHECK(k.dim() == 4 && v.dim() == 4, "paged key/value must be (num_pages, page_size, h_k, d)");
     TORCH_CHECK(v.size(0) == k.size(0) && v.size(1) == k.size(1) && v.size(2) == num_heads_k,
                 "key and value cache shapes differ");
@@ -843,8 +853,16 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
     ks0 = k.stride(0); ks1 = k.stride(1); ks2 = k.stride(2);
     vs0 = v.stride(0); vs1 = v.stride(1); vs2 = v.stride(2);
     if (seqlen_k_max <= 0) seqlen_k_max = pt.size(1) * page_size;
+  } else if (cache_rows) {
+    TORCH_CHECK(v.dim() == 4 && v.size(0) == k.size(0) && v.size(1) == k.size(1) && v.size(2) == num_heads_k,
+                "key and value cache shapes differ");
+    TORCH_CHECK(batch_idx_ptr != nullptr || k.size(0) >= batch, "the KV cache must have one row per sequence");
+    TORCH_CHECK(cu_seqlens_k.size(0) == batch, "with a KV cache cu_seqlens_k holds the per-sequence lengths [b]");
+    ks0 = k.stride(0); ks1 = k.stride(1); ks2 = k.stride(2);
+    vs0 = v.stride(0); vs1 = v.stride(1); vs2 = v.stride(2);
+    if (seqlen_k_max <= 0) seqlen_k_max = k.size(1);
   } else {
-    TORCH_CHECK(k.dim() == 3 && v.dim() == 3, "non-paged key/value must be ragged (total_k, h_k, d)");
+    TORCH_CHECK(k.dim() == 3 && v.dim() == 3, "non-paged key/value must be ragged (total_k, h_k, d) or a 4-D cache");
     TORCH_CHECK(cu_seqlens_k.size(0) == batch + 1, "cu_seqlens_k must have b + 1 entries");
     TORCH_CHECK(v.size(0) == k.size(0) && v.size(1) == num_heads_k, "key and value shapes differ");
     ks0 = k.stride(0); ks1 = k.stride(1);
@@ -897,7 +915,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
                           splits, dtype_code(q_type, "q"),
                           fp8_kv ? (k.scalar_type() == at::kFloat8_e4m3fn ? SGLK_FP8_E4M3 : SGLK_FP8_E5M2)
                                  : dtype_code(q_type, "q"),
-                          k_descale_ptr, v_descale_ptr));
+                          k_descale_ptr, v_descale_ptr, kv_layout, batch_idx_ptr, leftpad_ptr));
   return {out, lse, out_accum, lse_accum};
 }
 

@@ -546,6 +546,27 @@ def gen_attention():
         cases.append(dict(q=q, k=k, v=v, sink=sink, scale=scale, causal=causal, window=window, softcap=softcap,
                           out=out, out_pt=out_pt))
     save("attention", cases)
+    # KV-cache addressing of flash_attn_with_kvcache (reference tests/test_flash_attention.py:855-893, :938-990): a cache
+    # with more rows than sequences, cache_batch_idx picks the row, keys are the cache positions [leftpad, cache_seqlens)
+    kvc = []
+    torch.manual_seed(1)
+    for dt, b, rows, sq, cache_len, Hq, Hk, D, causal in [(torch.bfloat16, 3, 5, 1, 200, 8, 2, 128, False),
+                                                           (torch.float16, 2, 4, 17, 96, 4, 4, 64, True)]:
+        q = torch.randn(b, sq, Hq, D).to(dt)
+        k_cache = torch.randn(rows, cache_len, Hk, D).to(dt)
+        v_cache = torch.randn(rows, cache_len, Hk, D).to(dt)
+        batch_idx = torch.randperm(rows)[:b].to(torch.int32)
+        seqlens = torch.randint(cache_len // 2, cache_len + 1, (b,), dtype=torch.int32)
+        leftpad = torch.tensor([int(torch.randint(0, max(1, int(s) - sq), (1,))) for s in seqlens], dtype=torch.int32)
+        ar = torch.arange(cache_len).unsqueeze(0)
+        key_mask = (ar < seqlens.unsqueeze(1)) & (ar >= leftpad.unsqueeze(1))
+        out, _ = t.attention_ref(q, k_cache[batch_idx.long()], v_cache[batch_idx.long()], D ** -0.5, key_padding_mask=key_mask,
+                                 causal=causal, key_leftpad=leftpad)
+        out_pt, _ = t.attention_ref(q, k_cache[batch_idx.long()], v_cache[batch_idx.long()], D ** -0.5, key_padding_mask=key_mask,
+                                    causal=causal, key_leftpad=leftpad, upcast=False, reorder_ops=True)
+        kvc.append(dict(q=q, k_cache=k_cache, v_cache=v_cache, cache_batch_idx=batch_idx, cache_seqlens=seqlens,
+                        cache_leftpad=leftpad, causal=causal, out=out, out_pt=out_pt))
+    save("attention_kvcache", kvc)
 
 
 def gen_rope():

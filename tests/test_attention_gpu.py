@@ -280,3 +280,73 @@ def test_fp8_kvcache_requires_descale(sglk, dev):
     with pytest.raises(RuntimeError, match="k_descale and v_descale"):
         sglk.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=torch.tensor([5], dtype=torch.int32, device=dev),
                                      page_table=torch.zeros(1, 2, dtype=torch.int32, device=dev))
+
+
+# ------------------------------------------- KV-cache addressing: 4-D cache rows, cache_batch_idx, cache_leftpad
+@pytest.mark.parametrize("layout", ["rows", "paged"])
+@pytest.mark.parametrize("use_batch_idx", [False, True])
+@pytest.mark.parametrize("use_leftpad", [False, True])
+@pytest.mark.parametrize("sq,D,heads", [(1, 128, (16, 4)), (40, 64, (8, 8)), (1, 256, (8, 1)), (130, 128, (4, 2))])
+def test_kvcache_rows_batch_idx_leftpad(sglk, dev, layout, use_batch_idx, use_leftpad, sq, D, heads):
+    """reference decode::mha_fwd_nopage (flash_attention.cpp:83-270), kv_batch_idx (:383, :649-653), leftpad_k (:408-412)"""
+    Hq, Hk = heads
+    g = torch.Generator().manual_seed(sq + D + Hq)
+    b, rows, cache_len, page = 3, 5, 448, 64
+    q = torch.randn(b, sq, Hq, D, generator=g).to(torch.bfloat16)
+    k_rows = torch.randn(rows, cache_len, Hk, D, generator=g).to(torch.bfloat16)
+    v_rows = torch.randn(rows, cache_len, Hk, D, generator=g).to(torch.bfloat16)
+    batch_idx = torch.randperm(rows, generator=g)[:b].to(torch.int32) if use_batch_idx else None
+    ends = torch.randint(cache_len // 2, cache_len + 1, (b,), generator=g, dtype=torch.int32)
+    ends[0] = cache_len
+    leftpad = None
+    if use_leftpad:
+        leftpad = torch.tensor([int(torch.randint(0, int(e) - sq + 1, (1,), generator=g)) for e in ends], dtype=torch.int32)
+        leftpad[1] = 37  # (not a multiple of the 32-token tile)
+    if layout == "rows":
+        kc, vc, table = k_rows, v_rows, None
+    else:  # the same cache rows cut into shuffled pages; page_table row r describes cache row r
+        pages_per = cache_len // page
+        perm = torch.randperm(rows * pages_per, generator=g)
+        kc = torch.empty(rows * pages_per, page, Hk, D, dtype=torch.bfloat16)
+        vc = torch.empty_like(kc)
+        kc[perm] = k_rows.view(rows * pages_per, page, Hk, D)
+        vc[perm] = v_rows.view(rows * pages_per, page, Hk, D)
+        table = perm.view(rows, pages_per).to(torch.int32)
+    if not use_batch_idx:  # one cache row per sequence
+        kc_use, vc_use = (kc[:b], vc[:b]) if layout == "rows" else (kc, vc)
+        table_use = table[:b] if table is not None else None
+    else:
+        kc_use, vc_use, table_use = kc, vc, table
+    d = lambda t: t.to(dev) if t is not None else None
+    for causal in (False, True):
+        out, lse, *_ = sglk.flash_attn_with_kvcache(d(q), d(kc_use), d(vc_use), cache_seqlens=d(ends), cache_batch_idx=d(batch_idx),
+                                                    cache_leftpad=d(leftpad), page_table=d(table_use), causal=causal,
+                                                    return_softmax_lse=True)
+        out = out.cpu().view(b, sq, Hq, D)
+        for i in range(b):
+            row = int(batch_idx[i]) if use_batch_idx else i
+            lo, hi = (int(leftpad[i]) if use_leftpad else 0), int(ends[i])
+            ki, vi = k_rows[row, lo:hi], v_rows[row, lo:hi]
+            ref, ref_lse = oa.attention_seq(q[i], ki, vi, D ** -0.5, causal=causal)
+            check(out[i], ref, pt_seq(q[i], ki, vi, D ** -0.5, causal, (-1, -1), 0.0, None), f"seq {i}")
+            torch.testing.assert_close(lse.cpu()[:, i * sq:(i + 1) * sq], ref_lse, rtol=1e-3, atol=1e-3)
+
+
+def test_kvcache_golden(sglk, dev):
+    for c in load_golden("attention_kvcache"):
+        out = sglk.flash_attn_with_kvcache(c["q"].to(dev), c["k_cache"].to(dev), c["v_cache"].to(dev),
+                                           cache_seqlens=c["cache_seqlens"].to(dev), cache_batch_idx=c["cache_batch_idx"].to(dev),
+                                           cache_leftpad=c["cache_leftpad"].to(dev), causal=c["causal"]).cpu().view(c["q"].shape)
+        err = (out.float() - c["out"].float()).abs().max().item()
+        err_pt = (c["out_pt"].float() - c["out"].float()).abs().max().item()
+        assert err <= 2 * err_pt + 1e-5, (err, err_pt)
+
+
+def test_kvcache_addressing_errors(sglk, dev):
+    q = torch.zeros(2, 1, 4, 64, dtype=torch.float16, device=dev)
+    kc = torch.zeros(2, 128, 4, 64, dtype=torch.float16, device=dev)
+    lens = torch.tensor([5, 6], dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError, match="int32"):
+        sglk.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=lens, cache_leftpad=torch.zeros(2, dtype=torch.int64, device=dev))
+    with pytest.raises(RuntimeError, match="one entry per sequence"):
+        sglk.flash_attn_with_kvcache(q, kc, kc, cache_seqlens=lens, cache_batch_idx=torch.zeros(3, dtype=torch.int32, device=dev))

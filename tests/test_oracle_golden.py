@@ -322,3 +322,19 @@ def test_sampling_filters_match_reference_vectors():
         assert (c["mask"].bool() & ~mine).sum() <= mine.shape[0] * 2
     for c in gold["min_p_mask"]:
         assert torch.equal(osamp.min_p_mask(c["probs"], c["p"]), c["mask"].bool())
+
+
+def test_attention_kvcache_addressing_matches_reference_vectors():
+    """cache_batch_idx / cache_leftpad semantics (keys = cache positions [leftpad, cache_seqlens) of row batch_idx[b]) as
+    attention_ref computes them from key_padding_mask + key_leftpad (reference tests/test_flash_attention.py:855-990)."""
+    from oracle import attention as oa
+
+    for c in load_golden("attention_kvcache"):
+        q = c["q"]
+        b, sq, Hq, D = q.shape
+        for i in range(b):
+            row, lo, hi = int(c["cache_batch_idx"][i]), int(c["cache_leftpad"][i]), int(c["cache_seqlens"][i])
+            out, _ = oa.attention_seq(q[i], c["k_cache"][row, lo:hi], c["v_cache"][row, lo:hi], D ** -0.5, causal=c["causal"])
+            err = (out - c["out"][i].float()).abs().max().item()
+            err_pt = (c["out_pt"][i].float() - c["out"][i].float()).abs().max().item()
+            assert err <= 2 * err_pt + 1e-5, (err, err_pt)
