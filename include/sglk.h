@@ -265,7 +265,9 @@ SGLK_API int sglk_apply_shuffle_mul_sum(sglk_stream_t stream, const void* input,
 /* moe_grouped_mm_nt_xe20_w4a16: reference src/sycl/GroupGemmW4A16Xe20.cpp:92-283 (schema
  * torch_extension_sycl.cc:214-217). out [total_m, N]; activations [total_m, K]; packed_weights
  * [E, N, K/2] (low nibble = even k); scales / zeros [E, N, K/group] (activation dtype; zeros may be
- * NULL = signed codes); bias fp32 [E, N] or NULL; rows_per_expert int32 [E] (counts). */
+ * NULL = signed codes); bias fp32 [E, N] or NULL; rows_per_expert int32 [E] (counts).
+ * is_int4 == 0: mxfp4 weights (OCP e2m1 nibbles), scales = E8M0 bytes [E, N, K/32], group_size 32, zeros NULL
+ * (reference GroupGemmW4A16Xe20.cpp:140-168, kernels/moe/xe20/w4a16/gemm_xe2.hpp:238-448). */
 SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const void* activations,
                                        const void* packed_weights, const void* scales,
                                        const void* zeros, const float* bias,

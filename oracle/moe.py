@@ -97,9 +97,24 @@ def dequant_w4(packed, scales, zeros, group_size):
     return (v * s).to(T)
 
 
-def moe_grouped_mm_w4a16(act, packed, scales, zeros, bias, rows_per_expert, group_size):
+_E2M1 = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)  # OCP MX e2m1 magnitudes by the low three code bits
+
+
+def dequant_mxfp4(packed, scales, dtype):
+    """T(T(e2m1 value) * 2^(scale byte - 127)) with one E8M0 byte per 32 weights: the dequantisation the reference's
+    tests pair with the mxfp4 op (tests/test_per_token_group_quant_mxfp4.py:175-288, used by tests/test_moe_gemm.py:
+    273-290); the kernel side is src/sycl/GroupGemmW4A16Xe20.cpp:140-168."""
+    codes = unpack_int4(packed, signed=False).long()
+    mag = torch.tensor(_E2M1, dtype=torch.float32)[codes & 7]
+    v = torch.where((codes & 8) != 0, -mag, mag).to(dtype).float()
+    exp = scales.view(torch.uint8).to(torch.int32) - 127
+    s = torch.pow(2.0, exp.float()).repeat_interleave(32, dim=-1)
+    return (v * s).to(dtype)
+
+
+def moe_grouped_mm_w4a16(act, packed, scales, zeros, bias, rows_per_expert, group_size, mxfp4=False):
     T = act.dtype
-    w = dequant_w4(packed, scales, zeros, group_size)  # [E, N, K]
+    w = dequant_mxfp4(packed, scales, T) if mxfp4 else dequant_w4(packed, scales, zeros, group_size)  # [E, N, K]
     out = torch.empty(act.shape[0], w.shape[1], dtype=T)
     r0 = 0
     for e, r in enumerate(rows_per_expert.tolist()):
@@ -113,7 +128,7 @@ def moe_grouped_mm_w4a16(act, packed, scales, zeros, bias, rows_per_expert, grou
 
 
 def fused_experts_int4(x, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale, w1_zp=None, w2_zp=None, b1=None,
-                       b2=None, activation="silu", routed_scaling_factor=None):
+                       b2=None, activation="silu", routed_scaling_factor=None, mxfp4=False):
     T = x.dtype
     E = w1.shape[0]
     K = w1.shape[2] * 2
@@ -122,14 +137,16 @@ def fused_experts_int4(x, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale, w1
     counts, _, _, a_map, c_map = prepare_moe_input(topk_ids.numpy(), E, x.shape[1], topk)
     a = x[torch.from_numpy(a_map).long()]
     rows = torch.from_numpy(counts)
-    h = moe_grouped_mm_w4a16(a, w1, w1_scale, w1_zp, b1.float() if b1 is not None else None, rows, K // w1_scale.shape[2])
+    h = moe_grouped_mm_w4a16(a, w1, w1_scale, w1_zp, b1.float() if b1 is not None else None, rows, K // w1_scale.shape[2],
+                             mxfp4)
     if activation == "silu":
         h = oact.silu_and_mul(h)
     elif activation == "gelu":
         h = oact.gelu_tanh_and_mul(h)
     else:
         h = torch.square(torch.relu(h))
-    o = moe_grouped_mm_w4a16(h, w2, w2_scale, w2_zp, b2.float() if b2 is not None else None, rows, I // w2_scale.shape[2])
+    o = moe_grouped_mm_w4a16(h, w2, w2_scale, w2_zp, b2.float() if b2 is not None else None, rows, I // w2_scale.shape[2],
+                             mxfp4)
     gathered = o[torch.from_numpy(c_map).long()].view(x.shape[0], topk, -1).float()
     t = gathered * topk_weights.float().unsqueeze(-1)
     if routed_scaling_factor is not None and routed_scaling_factor != 1.0:

@@ -29,6 +29,7 @@ namespace sglk {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef short v8s __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -489,6 +490,287 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Prefill kernel (head dim 128, 16-bit KV, no softcap; everything else of the contract above): the kernel above gives a
+// wave 16 packed rows and 32-token tiles, so every K / V fragment it reads from LDS feeds one MFMA and every tile costs
+// a barrier per 16 MFMAs of a wave: 267 TFLOP/s on the causal 16 x 4096 Llama-3-8B prefill (0.11 of the bf16 MFMA
+// peak), LDS-read bound. Here a workgroup is 8 waves x 32 packed rows = 256 rows and a tile is 64 tokens:
+//   * S^T = K . Q^T and O^T = V^T . P^T with v_mfma_f32_32x32x16: lane l owns query row l % 32 in BOTH products
+//     (score and output columns), so the running max / sum / rescale factors are per-lane scalars and P never moves
+//     between lanes: a lane's 16 scores of a 32-token block, taken 8 at a time, ARE its P operand for the k-slot
+//     order tau(s, u, e) = 32 (s / 2) + 16 (s % 2) + 8 (e / 4) + 4 u + e % 4 (u = lane / 32), and V^T is read in that
+//     token order with the hardware transpose read (4 tokens x 16 dims per 16 lanes);
+//   * per wave and tile 16 + 16 MFMAs of 32 cycles against 24 KiB of LDS reads (the 16-row kernel: 32 KiB for half the
+//     work); the row maximum costs one cross-lane exchange (lane ^ 32);
+//   * K / V tiles go global -> registers -> LDS (loads issued before the tile's MFMAs, written after them), two LDS
+//     buffers, one barrier per 64 tokens; LDS images are 256-byte rows with 16-byte chunk c of row r at c ^ (r & 15)
+//     for K (ds_read_b128 of 16 different rows is conflict-free) and c ^ ((r & 3) << 2) for V (the 4-row x 64-byte
+//     footprint of a transpose read covers all banks once);
+//   * causal / window masks only on tiles that are not fully visible to the wave's 32 rows; workgroups of later (longer)
+//     row blocks are dispatched first.
+constexpr int kPBlockM = 256, kPTile = 64;
+
+template <typename T>
+struct Mfma32;
+template <>
+struct Mfma32<bf16> {
+  static __device__ __forceinline__ v16f run(const v8s& a, const v8s& b, const v16f& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mfma32<f16> {
+  static __device__ __forceinline__ v16f run(const v8s& a, const v8s& b, const v16f& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
+                                                           const char* __restrict__ kcache, const char* __restrict__ vcache,
+                                                           const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
+                                                           const int32_t* __restrict__ page_table) {
+  using M = Mfma<T>;
+  using M32 = Mfma32<T>;
+  constexpr int D = 128, KS = D / 16, DB = D / 32, ROWB = D * 2, TILE_BYTES = kPTile * ROWB;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][K tile, V tile]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, u = lane >> 5;
+  const int b = blockIdx.z, hk = blockIdx.y, G = p.G;
+
+  const int q_begin = cu_q[b];
+  const int seqlen_q = cu_q[b + 1] - q_begin;
+  int seqlen_k, k_begin = 0, cache_row = b, leftpad = 0;
+  if (p.paged) {
+    if (p.kv_batch_idx != nullptr) cache_row = p.kv_batch_idx[b];
+    if (p.leftpad_k != nullptr) leftpad = p.leftpad_k[b];
+    seqlen_k = seq_k[b] - leftpad;
+    seqlen_k = seqlen_k > 0 ? seqlen_k : 0;
+  } else {
+    k_begin = seq_k[b];
+    seqlen_k = seq_k[b + 1] - k_begin;
+  }
+  const int rows_total = seqlen_q * G;
+  const int nblk = (rows_total + kPBlockM - 1) / kPBlockM;
+  if ((int)blockIdx.x >= nblk) return;
+  const int row0 = (nblk - 1 - (int)blockIdx.x) * kPBlockM;  // longest rows first
+  const int shift = seqlen_k - seqlen_q;
+
+  const int my_row = row0 + wave * 32 + l31;
+  const bool row_ok = my_row < rows_total;
+  const int my_qpos = row_ok ? my_row / G : 0;
+  const int my_head = hk * G + (row_ok ? my_row % G : 0);
+  const int q_abs = my_qpos + shift;
+  const int wrow_first = row0 + wave * 32, wrow_last = wrow_first + 31;
+  const bool wave_rows_ok = wrow_last < rows_total;
+  const int wave_qabs_lo = wrow_first / G + shift, wave_qabs_hi = (wrow_last < rows_total ? wrow_last : rows_total - 1) / G + shift;
+
+  const int last_row = (row0 + kPBlockM < rows_total ? row0 + kPBlockM : rows_total) - 1;
+  const int qpos_lo = row0 / G, qpos_hi = last_row / G;
+  int kv_hi = seqlen_k;
+  if (p.causal_right >= 0) {
+    const int lim = qpos_hi + shift + p.causal_right + 1;
+    kv_hi = lim < kv_hi ? lim : kv_hi;
+  }
+  int kv_lo = 0;
+  if (p.window_left >= 0) {
+    const int lim = qpos_lo + shift - p.window_left;
+    kv_lo = lim > 0 ? lim : 0;
+  }
+  if (kv_hi < 0) kv_hi = 0;
+  int t_lo = kv_lo / kPTile, t_hi = (kv_hi + kPTile - 1) / kPTile;
+  if (t_hi < t_lo) t_hi = t_lo;
+  const int n_tiles = t_hi - t_lo;
+
+  // ---- Q^T fragments (B operand of K . Q^T): lane supplies q[row l31][16 ks + 8 u .. + 8)
+  v8s qf[KS];
+  {
+    const T* qrow = q + (int64_t)(q_begin + my_qpos) * p.q_s0 + (int64_t)my_head * p.q_s1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      v8s v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (row_ok) v = *reinterpret_cast<const v8s*>(qrow + 16 * ks + 8 * u);
+      qf[ks] = v;
+    }
+  }
+
+  // ---- staging: 16-byte chunk c = tid + 512 i (i = 0, 1) of a tile <-> (token row c / 16, chunk c % 16)
+  const int32_t* table_b = page_table + (p.paged == 1 ? (int64_t)cache_row * p.table_stride : 0);
+  struct Stage { v4i k[2], v[2]; };
+  auto issue_loads = [&](int t, Stage& sr) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 512 * i;
+      const int row = c >> 4, ch = c & 15;
+      const int pos = t * kPTile + row;
+      v4i kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+      if (pos < seqlen_k) {
+        int64_t koff, voff;
+        if (p.paged) {
+          const int cp = pos + leftpad;
+          const int page = p.paged == 2 ? cache_row : table_b[cp >> p.page_shift];
+          const int inp = p.paged == 2 ? cp : cp & ((1 << p.page_shift) - 1);
+          koff = (int64_t)page * p.k_s0 + (int64_t)inp * p.k_s1 + (int64_t)hk * p.k_s2;
+          voff = (int64_t)page * p.v_s0 + (int64_t)inp * p.v_s1 + (int64_t)hk * p.v_s2;
+        } else {
+          koff = (int64_t)(k_begin + pos) * p.k_s0 + (int64_t)hk * p.k_s1;
+          voff = (int64_t)(k_begin + pos) * p.v_s0 + (int64_t)hk * p.v_s1;
+        }
+        kv = *reinterpret_cast<const v4i*>(kcache + (koff + ch * 8) * 2);
+        vv = *reinterpret_cast<const v4i*>(vcache + (voff + ch * 8) * 2);
+      }
+      sr.k[i] = kv;
+      sr.v[i] = vv;
+    }
+  };
+  auto write_lds = [&](int buf, const Stage& sr) {
+    char* base = smem + buf * (2 * TILE_BYTES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 512 * i;
+      const int row = c >> 4, ch = c & 15;
+      *reinterpret_cast<v4i*>(base + row * ROWB + ((ch ^ (row & 15)) << 4)) = sr.k[i];
+      *reinterpret_cast<v4i*>(base + TILE_BYTES + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4)) = sr.v[i];
+    }
+  };
+
+  // ---- per-lane LDS read offsets
+  // K (A operand of K . Q^T): token row 32 beta + l31, chunk 2 ks + u at position chunk ^ (row & 15)
+  const int krow_off = l31 * ROWB, kkey = l31 & 15;  // (32 beta does not change row & 15)
+  // V^T (A operand of V^T . P^T) by transpose reads: 16 lanes fetch 4 tokens x 16 dims; lane -> (token qq, 4-dim quad pp)
+  const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, hh = (lane >> 4) & 1;
+  const int vlane_off = (4 * u + qq) * ROWB + 8 * (pp & 1);  // + token group offsets below; row & 3 == qq
+  const int vchunk_lo = 2 * hh + (pp >> 1);                  // chunk = 4 db + vchunk_lo, swizzled with qq << 2
+
+  v16f o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o[db][v] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float log2e = 1.4426950408889634f;
+  const float scale = p.scale, sc2 = scale * log2e;
+
+  Stage sreg;
+  if (n_tiles > 0) {
+    issue_loads(t_lo, sreg);
+    write_lds(0, sreg);
+  }
+  __syncthreads();
+
+  for (int i = 0; i < n_tiles; ++i) {
+    const int t = t_lo + i, buf = i & 1;
+    if (i + 1 < n_tiles) issue_loads(t + 1, sreg);
+    const char* kb = smem + buf * (2 * TILE_BYTES);
+    const char* vb = kb + TILE_BYTES;
+
+    // ---- S^T[token, row] = K . Q^T: two 32-token blocks
+    v16f s0, s1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int off = krow_off + (((2 * ks + u) ^ kkey) << 4);
+      const v8s a0 = *reinterpret_cast<const v8s*>(kb + off);
+      const v8s a1 = *reinterpret_cast<const v8s*>(kb + off + 32 * ROWB);
+      s0 = M32::run(a0, qf[ks], s0);
+      s1 = M32::run(a1, qf[ks], s1);
+    }
+
+    // ---- online softmax for row l31 (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each block)
+    bool interior = wave_rows_ok && (t * kPTile + kPTile <= seqlen_k);
+    if (p.causal_right >= 0) interior = interior && (t * kPTile + kPTile - 1 <= wave_qabs_lo + p.causal_right);
+    if (p.window_left >= 0) interior = interior && (t * kPTile >= wave_qabs_hi - p.window_left);
+    float m_new, m_use, alpha, psum = 0.f;
+    if (!interior) {
+      const int tb = t * kPTile + 4 * u;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int k0 = tb + 8 * (v >> 2) + (v & 3), k1 = k0 + 32;
+        bool m0 = !row_ok || k0 >= seqlen_k, m1 = !row_ok || k1 >= seqlen_k;
+        if (p.causal_right >= 0) { m0 |= k0 > q_abs + p.causal_right; m1 |= k1 > q_abs + p.causal_right; }
+        if (p.window_left >= 0) { m0 |= k0 < q_abs - p.window_left; m1 |= k1 < q_abs - p.window_left; }
+        s0[v] = m0 ? -INFINITY : s0[v];
+        s1[v] = m1 ? -INFINITY : s1[v];
+      }
+    }
+    float mt = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int v = 1; v < 16; ++v) mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    m_new = fmaxf(m_run, mt * scale);  // scale > 0; -inf stays -inf
+    m_use = m_new == -INFINITY ? 0.f : m_new;
+    alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);
+    const float mneg = -m_use * log2e;
+    v8s pf[4];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[v], sc2, mneg));
+      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[v], sc2, mneg));
+      psum += p0 + p1;
+      pf[v >> 3][v & 7] = M::cvt(p0);
+      pf[2 + (v >> 3)][v & 7] = M::cvt(p1);
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[db][v] *= alpha;
+    }
+
+    // ---- O^T[dim, row] += V^T . P^T: k-slot order tau (see above): MFMA s4 takes tokens 32 (s4 / 2) + 16 (s4 % 2) + ...
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int chunk = ((4 * db + vchunk_lo) ^ (qq << 2)) << 4;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const char* a = vb + (32 * (s4 >> 1) + 16 * (s4 & 1)) * ROWB + vlane_off + chunk;
+        const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a));
+        const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a + 8 * ROWB));
+        v8s vf;
+        vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+        vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+        o[db] = M32::run(vf, pf[s4], o[db]);
+      }
+    }
+
+    if (i + 1 < n_tiles) write_lds(buf ^ 1, sreg);  // (last read of that buffer: the tile before this one, a barrier ago)
+    __syncthreads();
+  }
+
+  // ---- epilogue (as the kernel above; the two lanes of a row hold partial sums)
+  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float m_fin = m_run;
+  float lse_val = (l_tot > 0.f && m_fin != -INFINITY) ? m_fin + logf(l_tot) : -INFINITY;
+  if (p.sinks != nullptr && row_ok) {
+    const float sk = p.sinks[my_head];
+    const float m2 = fmaxf(m_fin, sk);
+    const float l2 = l_tot * __builtin_amdgcn_exp2f((m_fin - m2) * log2e) + __builtin_amdgcn_exp2f((sk - m2) * log2e);
+    lse_val = m2 + logf(l2);
+    l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
+  }
+  const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
+  if (row_ok) {
+    const int64_t tok = q_begin + my_qpos;
+    T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)my_head * p.o_s1;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // dims 32 db + 8 g + 4 u .. + 3
+        Vec<T, 4> ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (T)(o[db][4 * g + r] * inv_l);
+        store_vec<T, 4>(orow + 32 * db + 8 * g + 4 * u, ov);
+      }
+    }
+    if (u == 0) p.lse[(int64_t)my_head * p.total_q + tok] = lse_val;
+  }
+}
+
 // merge split-KV partials: out = sum_s exp(lse_s - L) O_s, L = log(sum_s exp(lse_s) [+ exp(sink)])
 template <typename T>
 __global__ __launch_bounds__(128) void attn_reduce_kernel(T* __restrict__ out, float* __restrict__ lse_out,
@@ -542,9 +824,25 @@ static int launch(hipStream_t st, const AttnParams& p, const void* q, const void
 }
 
 template <typename T>
+static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
+                          const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
+  constexpr int lds = 2 * 2 * kPTile * 256;  // 64 KiB
+  static unsigned long long attr_done = 0;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T>), lds, &attr_done, "fwd")) return rc;
+  dim3 grid((unsigned)cdiv(max_rows, kPBlockM), (unsigned)p.Hk, (unsigned)batch);
+  attn_prefill_kernel<T><<<grid, 512, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  return check_launch("fwd(prefill)");
+}
+
+template <typename T>
 static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                         const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows, int kv8) {
   const int d = p.D;
+  // prefill-sized problems at head dim 128 (Llama-3 / BASELINE configs[2]): the 256-row kernel. A row block must be worth
+  // filling: at least 128 packed rows per (sequence, kv head) at the longest sequence.
+  if (kv8 == 0 && d == 128 && p.splits == 1 && p.softcap <= 0.f && max_rows >= 128 && p.q_s0 % 8 == 0 && p.o_s0 % 4 == 0 &&
+      p.o_s1 % 4 == 0)
+    return launch_prefill<T>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
   if (kv8 != 0) {  // fp8 KV cache: built for the head dims the reference exercises (and 64)
 #define SGLK_FP8_GO(DKP)                                                                              \
   return kv8 == 1 ? launch<T, DKP, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)            \

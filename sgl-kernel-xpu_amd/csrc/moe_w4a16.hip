@@ -19,6 +19,12 @@
 // which is what keeps the decode regime on the HBM roofline, and it is at least as accurate as the
 // reference (no per-weight rounding); results agree within the reference test tolerance.
 //
+// mxfp4 weights (FMT = 1; reference GroupGemmW4A16Xe20.cpp:140-168, gemm_xe2.hpp:238-448): the nibbles are OCP e2m1
+// codes (sign, 2 exponent bits, 1 mantissa bit: 0, 0.5, 1, 1.5, 2, 3, 4, 6), one E8M0 scale byte per 32 weights.
+// Every e2m1 value is exact in bf16 / fp16: the codes are widened by two byte-table lookups (v_perm_b32 on the 3-bit
+// magnitudes of a nibble pair) plus the sign bits, keeping the nibble-pair order of the int4 path; the group scale
+// 2^(byte - 127) is applied in fp32 per 32-deep k step (no zero point, no row-sum MFMA).
+//
 // Data movement. Weights are streamed once from HBM straight into registers (16 B per lane; they are not
 // shared between waves, so an LDS round trip would be pure overhead), then a 4x4 dword transpose across
 // the four 16-lane groups (2 x v_permlane32_swap + 2 x v_permlane16_swap) gives every MFMA k-step a
@@ -28,6 +34,8 @@
 // Block = 4 waves; wave w owns NW 16-wide n tiles and all MT 16-row m tiles of the block's expert rows.
 // Experts are ragged: the grid is sized for the worst case and each block finds its (expert, row block)
 // from rows_per_expert on the device (no host sync).
+#include <type_traits>
+
 #include "common.h"
 
 namespace sglk {
@@ -46,6 +54,8 @@ struct W4<bf16> {
   static constexpr int kShift = 3;                 // nibble position inside a 16-bit half: 16 + u = 0x4180 | u << 3
   static constexpr uint32_t kMagic = 0x41804180u;
   static constexpr uint32_t kOnes = 0x3F803F80u;   // (1.0, 1.0)
+  // e2m1 magnitudes 0, .5, 1, 1.5 | 2, 3, 4, 6 as bf16: high bytes 00 3F 3F 3F | 40 40 40 40, low bytes 00 00 80 C0 | 00 40 80 C0
+  static constexpr uint32_t kHiLo = 0x3F3F3F00u, kHiHi = 0x40404040u, kLoLo = 0xC0800000u, kLoHi = 0xC0804000u;
   static __device__ __forceinline__ v4f mma(const v4i& a, const v4i& b, const v4f& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
   }
@@ -55,6 +65,8 @@ struct W4<f16> {
   static constexpr int kShift = 6;                 // 16 + u = 0x4C00 | u << 6
   static constexpr uint32_t kMagic = 0x4C004C00u;
   static constexpr uint32_t kOnes = 0x3C003C00u;
+  // as fp16: 0000 3800 3C00 3E00 | 4000 4200 4400 4600
+  static constexpr uint32_t kHiLo = 0x3E3C3800u, kHiHi = 0x46444240u, kLoLo = 0u, kLoHi = 0u;
   static __device__ __forceinline__ v4f mma(const v4i& a, const v4i& b, const v4f& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
   }
@@ -72,6 +84,26 @@ __device__ __forceinline__ v4i expand_nibbles(uint32_t w) {
     const int sh = S - 4 * p;
     const uint32_t t = sh >= 0 ? (w << sh) : (w >> (-sh));
     r[p] = (int)((t & mask) | W4<T>::kMagic);
+  }
+  return r;
+}
+
+// mxfp4: 8 e2m1 nibbles -> 4 dwords of two 16-bit floats in the same order (dword p = k offsets p, p + 4)
+template <typename T>
+__device__ __forceinline__ v4i expand_mxfp4(uint32_t w) {
+  v4i r;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint32_t uu = w >> (4 * p);
+    const uint32_t mag = uu & 0x00070007u;      // magnitudes of nibbles p (byte 0) and p + 4 (byte 2)
+    const uint32_t sel = mag | (mag << 8);      // same index in bytes (0, 1) and (2, 3)
+    const uint32_t hi = __builtin_amdgcn_perm(W4<T>::kHiHi, W4<T>::kHiLo, sel);
+    uint32_t v = hi & 0xFF00FF00u;
+    if constexpr (W4<T>::kLoLo != 0u || W4<T>::kLoHi != 0u) {
+      const uint32_t lo = __builtin_amdgcn_perm(W4<T>::kLoHi, W4<T>::kLoLo, sel);
+      v |= lo & 0x00FF00FFu;
+    }
+    r[p] = (int)(v | ((uu & 0x00080008u) << 12));  // sign bits 3 / 19 -> 15 / 31
   }
   return r;
 }
@@ -105,10 +137,12 @@ __device__ __forceinline__ void static_for4(F&& f) {
   f(IntC<3>{});
 }
 
-template <typename T, int MT, int NW, int PB>  // PB: scale groups per 128-deep block (4, 2, 1 for groups 32, 64, >= 128)
+// PB: scale groups per 128-deep block (4, 2, 1 for groups 32, 64, >= 128); FMT: 0 = int4 (scales / zeros of type T),
+// 1 = mxfp4 (scales = E8M0 bytes, group 32, no zeros)
+template <typename T, int MT, int NW, int PB, int FMT>
 __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
-                                                        const uint8_t* __restrict__ wq, const T* __restrict__ scales,
-                                                        const T* __restrict__ zeros, const float* __restrict__ bias,
+                                                        const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
+                                                        const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
                                                         int K, int group_shift) {
   constexpr int BM = 16 * MT;
@@ -134,15 +168,18 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   const int m_valid = rows_e - blk * BM;        // rows of this block that exist (>= 1)
   const int n_base = blockIdx.y * BN + wave * (NW * 16);
 
+  using S = typename std::conditional<FMT == 1, uint8_t, T>::type;  // stored scale type
+  const S* scales = reinterpret_cast<const S*>(scales_);
+  const S* zeros = reinterpret_cast<const S*>(zeros_);
   const int kgroups = K >> group_shift;         // scales per row
-  const bool has_zp = zeros != nullptr;
+  const bool has_zp = FMT == 0 && zeros != nullptr;
 
   // ---- per-lane weight / scale rows (clamped; stores are guarded): 32-bit offsets from per-expert bases
   const uint8_t* wexp = wq + (int64_t)e * N * (K / 2);
-  const T* sexp = scales + (int64_t)e * N * kgroups;
+  const S* sexp = scales + (int64_t)e * N * kgroups;
   // without zero points the zero-point loads read the scales instead (values unused): an unconditional load keeps
   // the K loop free of a branch whose other side would have to wait for every load in flight (WAW on the register)
-  const T* zexp = has_zp ? zeros + (int64_t)e * N * kgroups : sexp;
+  const S* zexp = has_zp ? zeros + (int64_t)e * N * kgroups : sexp;
   uint32_t woff[NW], soff[NW];
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
@@ -213,8 +250,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
       dst[nt][0] = t[0]; dst[nt][1] = t[1]; dst[nt][2] = t[2]; dst[nt][3] = t[3];
     }
   };
-  T sq_[kD][NW][PB], zq_[kD][NW][PB];
-  auto load_s = [&](int kb, T (&sd)[NW][PB], T (&zd)[NW][PB]) {
+  S sq_[kD][NW][PB], zq_[kD][NW][PB];
+  auto load_s = [&](int kb, S (&sd)[NW][PB], S (&zd)[NW][PB]) {
     const int kg0 = (kb * 128) >> group_shift;
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
@@ -223,7 +260,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
         int kg = kg0 + i;
         kg = kg < kgroups ? kg : kgroups - 1;
         sd[nt][i] = sexp[soff[nt] + kg];
-        zd[nt][i] = zexp[soff[nt] + kg];
+        if constexpr (FMT == 0) zd[nt][i] = zexp[soff[nt] + kg];
       }
     }
   };
@@ -250,7 +287,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
     // refill that slot with block kb + 1 + kD
     store_a(buf ^ 1, aq_[(u + 1) % kD]);
     load_a(kb + 1 + kD, aq_[(u + 1) % kD]);
-    T sc[NW][PB], zc[NW][PB];
+    S sc[NW][PB], zc[NW][PB];
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
 #pragma unroll
@@ -258,7 +295,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         sc[nt][i] = sq_[u][nt][i];
-        zc[nt][i] = zq_[u][nt][i];
+        if constexpr (FMT == 0) zc[nt][i] = zq_[u][nt][i];
       }
     }
     load_w(kb + kD, wq_[u]);
@@ -266,7 +303,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
-      if (!has_zp) {
+      if (FMT == 0 && !has_zp) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) wd[nt][t] ^= 0x88888888u;  // two's complement -> offset binary (zp 8)
       }
@@ -278,12 +315,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
       // (k steps past K multiply zero activations: no tail branch)
       v4i wf[NW];
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) wf[nt] = expand_nibbles<T>(wd[nt][j]);
+      for (int nt = 0; nt < NW; ++nt) wf[nt] = FMT == 1 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
         const v4i af = *reinterpret_cast<const v4i*>(abase + row * 256 + (((4 * j + g) ^ l15) << 4));
-        asum[mt] = W4<T>::mma(af, ones, asum[mt]);
+        if constexpr (FMT == 0) asum[mt] = W4<T>::mma(af, ones, asum[mt]);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
       }
@@ -293,13 +330,19 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
         constexpr int ki = j / (4 / PB);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) {
-          const float s = (float)sc[nt][ki];
-          const float z = has_zp ? 16.0f + (float)zc[nt][ki] : 24.0f;
+          float s, z = 0.f;
+          if constexpr (FMT == 1) {
+            const uint32_t e = sc[nt][ki];  // E8M0: 2^(byte - 127); byte 0 is the subnormal 2^-127
+            s = __uint_as_float(e ? e << 23 : 0x00400000u);
+          } else {
+            s = (float)sc[nt][ki];
+            z = has_zp ? 16.0f + (float)zc[nt][ki] : 24.0f;
+          }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float t = __builtin_fmaf(-z, asum[mt][r], part[mt][nt][r]);
+              const float t = FMT == 1 ? part[mt][nt][r] : __builtin_fmaf(-z, asum[mt][r], part[mt][nt][r]);
               acc[mt][nt][r] = __builtin_fmaf(s, t, acc[mt][nt][r]);
             }
             part[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -331,20 +374,22 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   }
 }
 
-template <typename T, int MT, int NW, int PB>
+template <typename T, int MT, int NW, int PB, int FMT = 0>
 static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
   constexpr int BM = 16 * MT, BN = 64 * NW;
   const int64_t max_mblocks = total_m / BM + E;  // sum_e ceil(rows_e / BM) <= total_m / BM + E
   dim3 grid((unsigned)max_mblocks, (unsigned)cdiv(N, BN));
-  moe_w4a16_kernel<T, MT, NW, PB><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, (const T*)scales,
-                                                        (const T*)zeros, bias, rows, E, N, K, group_shift);
+  moe_w4a16_kernel<T, MT, NW, PB, FMT><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
+                                                             rows, E, N, K, group_shift);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
 }
 
 template <typename T, int MT, int NW>
 static int launch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
+  if (group_shift < 0)  // mxfp4: E8M0 scales per 32
+    return launch_pb<T, MT, NW, 4, 1>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 5);
   if (group_shift == 5) return launch_pb<T, MT, NW, 4>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   if (group_shift == 6) return launch_pb<T, MT, NW, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   return launch_pb<T, MT, NW, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
@@ -371,9 +416,10 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
                                          int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
                                          int dtype) {
   using namespace sglk;
-  SGLK_REQUIRE(is_int4, "moe_grouped_mm_nt_xe20_w4a16: only the int4 weight format is built for gfx950 (mxfp4 is not)");
   SGLK_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256,
                "group_size must be 32, 64, 128 or 256; got %lld", (long long)group_size);
+  SGLK_REQUIRE(is_int4 || (group_size == 32 && zeros == nullptr),
+               "moe_grouped_mm_nt_xe20_w4a16: mxfp4 weights use E8M0 scales per 32 elements and no zero points");
   SGLK_REQUIRE(K > 0 && K % group_size == 0, "K must be a multiple of group_size");
   SGLK_REQUIRE(N > 0 && N % 8 == 0, "N must be divisible by 8");
   SGLK_REQUIRE(n_experts > 0, "n_experts must be positive");
@@ -381,7 +427,7 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
   SGLK_REQUIRE((uintptr_t)activations % 16 == 0 && (uintptr_t)packed_weights % 16 == 0,
                "moe_grouped_mm_nt_xe20_w4a16: activations and packed_weights must be 16-byte aligned");
   if (total_m == 0) return SGLK_OK;
-  const int gs = group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : 8;
+  const int gs = !is_int4 ? -1 : group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : 8;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16)
     return dispatch<bf16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,

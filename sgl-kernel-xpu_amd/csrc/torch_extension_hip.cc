@@ -667,8 +667,14 @@ void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, con
   TORCH_CHECK(scales.size(0) == n_experts, "scales.size(0) must equal n_experts");
   TORCH_CHECK(scales.size(1) == gemm_n, "scales.size(1) must equal N");
   TORCH_CHECK(scales.size(2) == gemm_k / group_size, "scales.size(2) must equal K/group_size");
-  TORCH_CHECK(is_int4, "moe_grouped_mm_nt_xe20_w4a16: mxfp4 weights are not built for gfx950 yet; int4 only");
-  TORCH_CHECK(scales.scalar_type() == activations.scalar_type(), "int4 scales dtype must match activations dtype");
+  if (is_int4) {
+    TORCH_CHECK(scales.scalar_type() == activations.scalar_type(), "int4 scales dtype must match activations dtype");
+  } else {  // mxfp4 (reference GroupGemmW4A16Xe20.cpp:140-168): E8M0 scale bytes, one per 32 weights, no zero points
+    TORCH_CHECK(scales.scalar_type() == at::kByte || scales.scalar_type() == at::kFloat8_e8m0fnu,
+                "mxfp4 scales must be uint8 or float8_e8m0fnu (E8M0 bytes)");
+    TORCH_CHECK(group_size == 32, "mxfp4 weights use group_size 32, got ", group_size);
+    TORCH_CHECK(!zeros.has_value(), "mxfp4 weights have no zero points");
+  }
   TORCH_CHECK(n_experts > 0, "n_experts must be positive");
   TORCH_CHECK(n_experts == rows_per_expert.size(0), "rows_per_expert must have n_experts elements");
   TORCH_CHECK(rows_per_expert.scalar_type() == at::kInt, "rows_per_expert must be int32");

@@ -508,6 +508,34 @@ def gen_moe():
     exp = t.torch_naive_moe(x, w1ref, w2ref, ids, tw, topk, None, None, activations="silu")
     cases["fused"].append(dict(x=x, w1=w1.view(torch.uint8), w2=w2.view(torch.uint8), w1_scale=w1s, w2_scale=w2s, w1_zp=None,
                                w2_zp=None, topk_ids=ids, topk_weights=tw, b1=None, b2=None, activation="silu", out=exp))
+    # mxfp4 (tests/test_moe_gemm.py:245-290 quantise / dequantise helpers; :767-846 op-level check; :555-640 fused check)
+    cases["mxfp4_dequant"], cases["mxfp4_grouped_mm"], cases["mxfp4_fused"] = [], [], []
+    for dt in (torch.bfloat16, torch.float16):
+        torch.manual_seed(0)
+        E, rpe, n, k = 8, 3, 64, 256
+        act = t.create_random_cpu_tensor((E * rpe, k), dt)
+        w = t.create_random_cpu_tensor((E, n, k), dt)
+        w[0, 0, :32] = 0           # an all-zero block (scale byte from the zero guard)
+        w[1, 1, 32:64] *= 2.0 ** -20  # small / large block exponents
+        w[2, 2, 64:96] *= 2.0 ** 9
+        packed, scales = t._quantize_weights_mxfp4(w)
+        dq = t._dequantize_weights_mxfp4(packed, scales, dtype=dt)
+        cases["mxfp4_dequant"].append(dict(packed=packed, scales=scales, out=dq))
+        expected = torch.cat([act[e * rpe:(e + 1) * rpe].float() @ dq[e].float().t() for e in range(E)]).to(dt)
+        cases["mxfp4_grouped_mm"].append(dict(act=act, packed=packed, scales=scales, rows_per_expert=rpe, out=expected))
+    for T, topk, E, H, I in [(1, 1, 8, 128, 128), (9, 2, 8, 256, 128)]:
+        torch.manual_seed(0)
+        a = t.create_random_cpu_tensor((T, H), torch.bfloat16)
+        w1 = t.create_random_cpu_tensor((E, 2 * I, H), torch.bfloat16)
+        w2 = t.create_random_cpu_tensor((E, H, I), torch.bfloat16)
+        score = torch.softmax(torch.randn([T, E], dtype=torch.bfloat16), dim=-1, dtype=torch.float32)
+        tw, ids = torch.topk(score, topk)
+        w1p, w1s = t._quantize_weights_mxfp4(w1)
+        w2p, w2s = t._quantize_weights_mxfp4(w2)
+        exp = t.torch_naive_moe(a, t._dequantize_weights_mxfp4(w1p, w1s), t._dequantize_weights_mxfp4(w2p, w2s), ids, tw,
+                                topk, None, None, activations="silu")
+        cases["mxfp4_fused"].append(dict(x=a, w1=w1p, w2=w2p, w1_scale=w1s, w2_scale=w2s, topk_ids=ids, topk_weights=tw,
+                                         out=exp))
     save("moe_w4a16", cases)
 
 

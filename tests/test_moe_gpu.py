@@ -191,6 +191,100 @@ def test_fused_experts_golden(sglk, dev):
         torch.testing.assert_close(out.cpu(), c["out"], rtol=1e-1, atol=2e-2)  # tests/test_moe_gemm.py:471
 
 
+# ------------------------------------------------------------------------------- mxfp4 weights (e2m1 + E8M0 / 32)
+def make_mxfp4(E, N, K, g, exp_lo=110, exp_hi=135):
+    """Random e2m1 nibbles and E8M0 scale bytes: every bit pattern is a valid weight, so no quantiser is needed."""
+    packed = torch.randint(0, 256, (E, N, K // 2), generator=g, dtype=torch.int16).to(torch.uint8)
+    scales = torch.randint(exp_lo, exp_hi, (E, N, K // 32), generator=g, dtype=torch.int16).to(torch.uint8)
+    return packed, scales
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,N,K", [([2] * 8, 1024, 1024), ([6] * 8, 1024, 1024), ([33] * 8, 1024, 1024),
+                                      ([129] * 8, 1024, 1024), ([0, 5, 17, 0, 1, 33, 0, 129], 200, 512),
+                                      ([300, 0, 40, 7], 1024, 1280), ([1] * 8, 4096, 1024)])
+def test_moe_grouped_mm_w4a16_mxfp4(sglk, dev, dtype, rows, N, K):
+    """reference tests/test_moe_gemm.py:805-885 (rows per expert {2, 6, 33, 129}, E=8, K=1024, N=2*512) + ragged rows"""
+    g = torch.Generator().manual_seed(len(rows) * 17 + N + K)
+    E, total = len(rows), sum(rows)
+    act = (torch.randn(total, K, generator=g) * 0.1).to(dtype)
+    packed, scales = make_mxfp4(E, N, K, g, 113, 124)  # |w| <= 6 * 2^-4: products stay far inside fp16
+    bias = torch.randn(E, N, generator=g) * 0.01 if (N % 256 == 0) else None
+    rows_t = torch.tensor(rows, dtype=torch.int32)
+    out = torch.full((total, N), float("nan"), dtype=dtype, device=dev)
+    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(
+        out, act.to(dev), packed.to(dev), scales.to(dev), None, bias.to(dev) if bias is not None else None,
+        rows_t.to(dev), E, False, 32)
+    ref = omoe.moe_grouped_mm_w4a16(act, packed, scales, None, bias, rows_t, 32, mxfp4=True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-1, atol=1e-2)  # reference tolerance (test_moe_gemm.py:846)
+    # the dequantised weights are exact in T, so only the fp32 summation order differs from the oracle
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=1e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("wdt", [torch.int8, torch.uint8])
+@pytest.mark.parametrize("sdt", ["uint8", "float8_e8m0fnu"])
+def test_mxfp4_input_dtypes_and_scale_range(sglk, dev, wdt, sdt):
+    """reference tests/test_moe_gemm.py:888-904: int8 / uint8 codes and uint8 / float8_e8m0fnu scales carry the same
+    bits. The scale bytes here span 2^-127 (byte 0) .. 2^20 so the E8M0 decode is checked at its ends (bf16 only: the
+    products leave fp16's range)."""
+    if not hasattr(torch, sdt):
+        pytest.skip(f"torch has no {sdt}")
+    g = torch.Generator().manual_seed(5)
+    E, N, K, rows = 4, 256, 512, [3, 0, 65, 9]
+    act = (torch.randn(sum(rows), K, generator=g) * 0.1).to(torch.bfloat16)
+    packed, scales = make_mxfp4(E, N, K, g, 0, 148)
+    scales[0, 0, :4] = torch.tensor([0, 1, 2, 147], dtype=torch.uint8)
+    rows_t = torch.tensor(rows, dtype=torch.int32)
+    out = torch.empty(sum(rows), N, dtype=torch.bfloat16, device=dev)
+    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(
+        out, act.to(dev), packed.view(wdt).to(dev), scales.to(dev).view(getattr(torch, sdt)), None, None, rows_t.to(dev),
+        E, False, 32)
+    ref = omoe.moe_grouped_mm_w4a16(act, packed, scales, None, None, rows_t, 32, mxfp4=True)
+    o, r = out.cpu().float(), ref.float()
+    assert torch.isfinite(o).all()
+    # outputs span ~40 binades: bound the error by each row's largest term instead of an absolute floor
+    assert ((o - r).abs() <= 1e-2 * r.abs() + 1e-3 * r.abs().amax(dim=1, keepdim=True)).all()
+
+
+def test_mxfp4_golden(sglk, dev):
+    g = load_golden("moe_w4a16")
+    for c in g["mxfp4_grouped_mm"]:
+        E = c["packed"].shape[0]
+        rows = torch.full((E,), c["rows_per_expert"], dtype=torch.int32, device=dev)
+        out = torch.empty_like(c["out"], device=dev)
+        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(out, c["act"].to(dev), c["packed"].to(dev), c["scales"].to(dev),
+                                                          None, None, rows, E, False, 32)
+        torch.testing.assert_close(out.cpu(), c["out"], rtol=1e-1, atol=1e-2)
+    for c in g["mxfp4_fused"]:
+        out = sglk.fused_experts(c["x"].to(dev), c["w1"].to(dev), c["w2"].to(dev), c["topk_weights"].to(dev),
+                                 c["topk_ids"].to(dev), use_mxfp4_w4a16=True, w1_scale=c["w1_scale"].to(dev),
+                                 w2_scale=c["w2_scale"].to(dev))
+        torch.testing.assert_close(out.cpu(), c["out"], rtol=1e-1, atol=1e-2)  # tests/test_moe_gemm.py:580
+
+
+@pytest.mark.parametrize("T,topk,E,H,I", [(1, 1, 8, 128, 128), (33, 2, 8, 1024, 512), (222, 6, 64, 128, 512),
+                                          (33, 6, 64, 1024, 128)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_fused_experts_mxfp4(sglk, dev, T, topk, E, H, I, bias):
+    """reference tests/test_moe_gemm.py:555-640: fused_experts(use_mxfp4_w4a16=True) against the MLP on the
+    dequantised weights (grid sampled from its [1,33,222] x [1,2,6] x [8,64] x [128,1024] x [128,512])"""
+    g = torch.Generator().manual_seed(T + topk + E + H + I)
+    dt = torch.bfloat16
+    x = (torch.randn(T, H, generator=g) * 0.1).to(dt)
+    w1, s1 = make_mxfp4(E, 2 * I, H, g, 119, 123)
+    w2, s2 = make_mxfp4(E, H, I, g, 119, 123)
+    b1 = torch.randn(E, 2 * I, generator=g) * 0.005 if bias else None
+    b2 = torch.randn(E, H, generator=g) * 0.005 if bias else None
+    score = torch.softmax(torch.randn(T, E, generator=g), dim=-1)
+    tw, ids = torch.topk(score, topk)
+    d = lambda t: t.to(dev) if t is not None else None
+    out = sglk.fused_experts(d(x), d(w1.view(torch.int8)), d(w2), d(tw), d(ids), d(b1), d(b2), use_mxfp4_w4a16=True,
+                             w1_scale=d(s1), w2_scale=d(s2))
+    ref = omoe.fused_experts_int4(x, w1, w2, tw, ids, s1, s2, None, None, b1, b2, mxfp4=True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-1, atol=1e-2)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=3e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("T", [1, 32, 512])
 def test_fused_experts_mixtral_shape_sampled(sglk, dev, T):
     """BASELINE configs[4] shape class (E=8, top-2, H=4096, int4 g=128) at a reduced intermediate size so the CPU

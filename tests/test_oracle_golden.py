@@ -109,6 +109,18 @@ def test_moe_w4a16_matches_reference_vectors():
         o = omoe.fused_experts_int4(c["x"], c["w1"], c["w2"], c["topk_weights"], c["topk_ids"], c["w1_scale"],
                                     c["w2_scale"], c["w1_zp"], c["w2_zp"], c["b1"], c["b2"], c["activation"])
         torch.testing.assert_close(o, c["out"], rtol=1e-1, atol=2e-2)  # tests/test_moe_gemm.py:471
+    # mxfp4: the dequantisation is exact arithmetic on both sides, so the weights must agree bit for bit
+    for c in g["mxfp4_dequant"]:
+        assert torch.equal(omoe.dequant_mxfp4(c["packed"], c["scales"], c["out"].dtype), c["out"])
+    for c in g["mxfp4_grouped_mm"]:
+        E = c["packed"].shape[0]
+        rows = torch.full((E,), c["rows_per_expert"], dtype=torch.int32)
+        o = omoe.moe_grouped_mm_w4a16(c["act"], c["packed"], c["scales"], None, None, rows, 32, mxfp4=True)
+        assert torch.equal(o, c["out"])
+    for c in g["mxfp4_fused"]:
+        o = omoe.fused_experts_int4(c["x"], c["w1"], c["w2"], c["topk_weights"], c["topk_ids"], c["w1_scale"],
+                                    c["w2_scale"], mxfp4=True)
+        torch.testing.assert_close(o, c["out"], rtol=1e-1, atol=1e-2)  # tests/test_moe_gemm.py:580
 
 
 def test_topk_softmax_matches_reference_vectors():
