@@ -63,7 +63,7 @@ def run(cmd):
 
 
 # sources whose device assembly is kept next to the object (-save-temps=obj) for check_isa
-ISA_CHECKED = ("mla_decode.hip", "gemm_8bit.hip")
+ISA_CHECKED = ("mla_decode.hip", "gemm_8bit.hip", "attn_fwd.hip")
 
 
 def _asm_path(src_name, obj_dir=None):
@@ -94,6 +94,7 @@ def check_isa(verbose=True):
       and the kernel descriptor must allocate 256 AGPRs.
     * gemm_fp8_blockwise_persist_kernel counts its LDS waits by hand: a VGPR spill (scratch access = vector-memory
       traffic inside the counted vmcnt window) breaks the counts.
+    * attn_prefill_kernel is sized for two 256-register waves per SIMD: a spill means the tile shape no longer fits.
     Returns the list of problems (empty = good)."""
     import re
     problems = []
@@ -147,6 +148,22 @@ def check_isa(verbose=True):
         found += n
         if n == 0:
             problems.append("no gemm_fp8_blockwise_persist_kernel instantiation found")
+    for src_name, pat in (("attn_fwd.hip", r"attn_prefill_kernelI"),):
+        path = _asm_path(src_name)
+        if not os.path.exists(path):
+            problems.append("%s missing" % path)
+            continue
+        n = 0
+        for name, body in _functions(open(path).read(), pat):
+            n += 1
+            for ln in body:
+                code = ln.split(";")[0]
+                if "scratch_" in code:
+                    problems.append("%s: spill: %s" % (name, code.strip()))
+                    break
+        found += n
+        if n == 0:
+            problems.append("no %s instantiation found" % pat)
     if verbose:
         print("[build] check_isa: %d kernels checked, %d problems" % (found, len(problems)), flush=True)
         for pr in problems[:20]:

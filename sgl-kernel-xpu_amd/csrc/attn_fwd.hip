@@ -60,6 +60,10 @@ struct Mfma<f16> {
   static __device__ __forceinline__ short cvt(float x) { return __builtin_bit_cast(short, (f16)x); }
 };
 
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight (__syncthreads() also
+// drains vmcnt, which would end the prefetch of the next tiles at every barrier)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int sw_main(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 struct AttnParams {
@@ -186,9 +190,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int d0 = 32 * ks + 8 * pig;
-      v8s v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (row_ok && d0 < D) v = *reinterpret_cast<const v8s*>(qrow + d0);
-      qf[ks] = v;
+      const v8s v = *reinterpret_cast<const v8s*>(qrow + (d0 < D ? d0 : 0));  // (unconditional load, then select)
+      const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = (row_ok && d0 < D) ? v : zero;
     }
   }
 
@@ -200,46 +204,60 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   };
   constexpr int kSets = DKP > 256 ? 1 : DKP > 128 ? 2 : 3;  // (fewer for the large head dims: registers)
   Stage sreg[kSets];
-  // Paged KV with pages of at least one tile (32 tokens): the page of a tile is wave-uniform, so its table entry is
-  // a scalar load that the main loop issues one tile ahead (`pg`); otherwise every thread looks its own row up.
-  const bool uniform_page = p.paged == 1 && p.page_shift >= 5 && (leftpad & (kTile - 1)) == 0;
-  const int32_t* table_b = page_table + (p.paged == 1 ? (int64_t)cache_row * p.table_stride : 0);
-  auto page_of_tile = [&](int t) -> int {
-    const int pos = t * kTile;
-    return (uniform_page && pos < seqlen_k) ? table_b[(pos + leftpad) >> p.page_shift] : 0;
+  // One address formula for the three layouts: page * s0 + position-in-page * s1 + base, with the page term switched off
+  // (stride 0, ids read from a dummy word) when there is no table. Positions past the end are clamped to the last key -
+  // their scores are masked and a real V row times weight 0 is 0 - so a tile's loads are unconditional, and the page ids
+  // of a tile are fetched kSets tiles before its loads: vmcnt retires in order, so waiting for a fetch issued one tile
+  // ahead would also wait for every K / V load in front of it and empty the ring; at distance kSets those have landed.
+  const bool use_table = p.paged == 1;
+  const int32_t* pg_src = use_table ? page_table + (int64_t)cache_row * p.table_stride : cu_q + b;
+  const int pos_mask = use_table ? (1 << p.page_shift) - 1 : -1;
+  const int pos_shift = use_table ? p.page_shift : 31;  // (position >> 31 = 0)
+  const int pos_base = p.paged ? leftpad : k_begin;
+  const int64_t kpg = use_table ? p.k_s0 : 0, vpg = use_table ? p.v_s0 : 0;        // page stride
+  const int64_t kst = p.paged ? p.k_s1 : p.k_s0, vst = p.paged ? p.v_s1 : p.v_s0;  // token stride
+  const int64_t kbase_off = p.paged == 2 ? (int64_t)cache_row * p.k_s0 + (int64_t)hk * p.k_s2
+                                         : (int64_t)hk * (p.paged ? p.k_s2 : p.k_s1);
+  const int64_t vbase_off = p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
+                                         : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1);
+  const int last_key = seqlen_k - 1;
+  int srow[LD], sch[LD];  // this thread's (token row, chunk) of a tile; rows >= kTile (odd head dims) load row kTile-1, unused
+#pragma unroll
+  for (int i = 0; i < LD; ++i) {
+    const int c = tid + 256 * i;
+    srow[i] = c / cpr;
+    sch[i] = c - srow[i] * cpr;
+  }
+  struct Pages {
+    int pg[LD];
   };
-  auto issue_loads = [&](int t, int pg, Stage& sr) {
-    const int tok0 = t * kTile;
+  auto fetch_pages = [&](int t) -> Pages {
+    Pages r;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c / cpr, ch = c - row * cpr;
-      v4i kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-      int pos = tok0 + row;
-      if (row < kTile && pos < seqlen_k) {
-        int64_t koff, voff;
-        if (p.paged) {
-          const int cp = pos + leftpad;  // cache position
-          const int page = p.paged == 2 ? cache_row : uniform_page ? pg : table_b[cp >> p.page_shift];
-          const int inp = p.paged == 2 ? cp : cp & ((1 << p.page_shift) - 1);
-          koff = (int64_t)page * p.k_s0 + (int64_t)inp * p.k_s1 + (int64_t)hk * p.k_s2;
-          voff = (int64_t)page * p.v_s0 + (int64_t)inp * p.v_s1 + (int64_t)hk * p.v_s2;
-        } else {
-          koff = (int64_t)(k_begin + pos) * p.k_s0 + (int64_t)hk * p.k_s1;
-          voff = (int64_t)(k_begin + pos) * p.v_s0 + (int64_t)hk * p.v_s1;
-        }
-        if constexpr (KV8 == 0) {
-          kv = *reinterpret_cast<const v4i*>(kcache + (koff + ch * 8) * 2);
-          vv = *reinterpret_cast<const v4i*>(vcache + (voff + ch * 8) * 2);
-        } else {  // 8 bytes = the 8 elements of this chunk
-          const uint2 k8 = *reinterpret_cast<const uint2*>(kcache + koff + ch * 8);
-          const uint2 v8 = *reinterpret_cast<const uint2*>(vcache + voff + ch * 8);
-          kv[0] = (int)k8.x; kv[1] = (int)k8.y;
-          vv[0] = (int)v8.x; vv[1] = (int)v8.y;
-        }
+      int pos = t * kTile + (srow[i] < kTile ? srow[i] : kTile - 1);
+      pos = pos < last_key ? pos : last_key;
+      r.pg[i] = pg_src[(pos + pos_base) >> pos_shift];
+    }
+    return r;
+  };
+  auto issue_loads = [&](int t, const Pages& pages, Stage& sr) {
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      int pos = t * kTile + (srow[i] < kTile ? srow[i] : kTile - 1);
+      pos = pos < last_key ? pos : last_key;
+      const int cp = (pos + pos_base) & pos_mask;
+      const int64_t koff = (int64_t)pages.pg[i] * kpg + (int64_t)cp * kst + kbase_off + sch[i] * 8;
+      const int64_t voff = (int64_t)pages.pg[i] * vpg + (int64_t)cp * vst + vbase_off + sch[i] * 8;
+      if constexpr (KV8 == 0) {
+        sr.k[i] = *reinterpret_cast<const v4i*>(kcache + koff * 2);
+        sr.v[i] = *reinterpret_cast<const v4i*>(vcache + voff * 2);
+      } else {  // 8 bytes = the 8 elements of this chunk
+        const uint2 k8 = *reinterpret_cast<const uint2*>(kcache + koff);
+        const uint2 v8 = *reinterpret_cast<const uint2*>(vcache + voff);
+        sr.k[i] = (v4i){(int)k8.x, (int)k8.y, 0, 0};
+        sr.v[i] = (v4i){(int)v8.x, (int)v8.y, 0, 0};
       }
-      sr.k[i] = kv;
-      sr.v[i] = vv;
     }
   };
   // fp8 cache: 8 bytes -> 8 elements of T (every e4m3 / e5m2 value is exact in bf16 and fp16)
@@ -271,8 +289,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
     char* base = smem + slot * SLOT;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c / cpr, ch = c - row * cpr;
+      const int row = srow[i], ch = sch[i];
       if (row < kTile) {
         const int off = (ch >> 4) * (kTile * 256) + row * 256 + (((ch & 15) ^ sw_main(row)) << 4);
         *reinterpret_cast<v4i*>(base + off) = widen(sr.k[i]);
@@ -312,13 +329,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   __shared__ float xch_all[kWaves * 16];
   float* xch = xch_all + wave * 16;
 
-  int pg_next = 0;  // page of tile t + kSets (uniform-page case), fetched one iteration before its loads are issued
+  Pages pgring[kSets];  // page ids of tiles t + kSets .. t + 2 kSets - 1
   if (n_tiles > 0) {
-    issue_loads(t_lo, page_of_tile(t_lo), sreg[0]);
+    Pages first[kSets];
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) first[j] = fetch_pages(t_lo + j < t_hi ? t_lo + j : t_hi - 1);
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) pgring[j] = fetch_pages(t_lo + kSets + j < t_hi ? t_lo + kSets + j : t_hi - 1);
+#pragma unroll
+    for (int j = 0; j < kSets; ++j) issue_loads(t_lo + j < t_hi ? t_lo + j : t_hi - 1, first[j], sreg[j]);
     write_lds(0, sreg[0]);
-    if (kSets >= 2 && n_tiles > 1) issue_loads(t_lo + 1, page_of_tile(t_lo + 1), sreg[1 % kSets]);
-    if (kSets >= 3 && n_tiles > 2) issue_loads(t_lo + 2, page_of_tile(t_lo + 2), sreg[2 % kSets]);
-    pg_next = page_of_tile(t_lo + kSets);
   }
   __syncthreads();
 
@@ -328,8 +348,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
     constexpr int par = decltype(parc)::value;
     const int t = t_lo + i;
     const int slot = i % kSlots;
-    if (i + kSets < n_tiles) issue_loads(t + kSets, pg_next, sreg[par % kSets]);
-    pg_next = (i + kSets + 1 < n_tiles) ? page_of_tile(t + kSets + 1) : 0;
+    {  // no branch around these (past this workgroup's range they re-read its last tile: cache hits, never used): a
+       // conditional load is merged with the old registers through copies that wait for it on the spot
+      const int tl = t_hi - 1;
+      issue_loads(t + kSets < tl ? t + kSets : tl, pgring[par % kSets], sreg[par % kSets]);
+      // (after the last use of the old ids, so that both can live in the same registers: no copy at the loop end)
+      pgring[par % kSets] = fetch_pages(t + 2 * kSets < tl ? t + 2 * kSets : tl);
+    }
     {
       const char* kb = smem + slot * SLOT;
       const char* vb = kb + TILE_BYTES;
@@ -425,18 +450,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
       }
     }
 
-    if (kSlots == 2) __syncthreads();                   // two slots: everyone must be done with the slot being refilled
+    // (barriers that order LDS only: __syncthreads() would also wait for the K / V loads in flight)
+    if (kSlots == 2) lds_barrier();                     // two slots: everyone must be done with the slot being refilled
     if (i + 1 < n_tiles) write_lds((i + 1) % kSlots, sreg[(par + 1) % kSets]);  // three slots: last read two iterations ago
-    __syncthreads();
+    lds_barrier();
   };
-  for (int i = 0; i < n_tiles; i += kSets) {
-    body(i, std::integral_constant<int, 0>{});
-    if constexpr (kSets >= 2) {
-      if (i + 1 < n_tiles) body(i + 1, std::integral_constant<int, 1>{});
-    }
-    if constexpr (kSets >= 3) {
-      if (i + 2 < n_tiles) body(i + 2, std::integral_constant<int, 2>{});
-    }
+  // whole groups of kSets tiles in a branch-free loop body (a conditional iteration merges the register sets of its two
+  // paths through copies, and a copy of a register waits for the load into it - with vmcnt in order that is a wait for
+  // every load in flight), then the remaining tiles
+  int i_main = 0;
+  for (; i_main + kSets <= n_tiles; i_main += kSets) {
+    body(i_main, std::integral_constant<int, 0>{});
+    if constexpr (kSets >= 2) body(i_main + 1, std::integral_constant<int, 1>{});
+    if constexpr (kSets >= 3) body(i_main + 2, std::integral_constant<int, 2>{});
+  }
+  if constexpr (kSets >= 2) {
+    if (i_main < n_tiles) body(i_main, std::integral_constant<int, 0>{});
+  }
+  if constexpr (kSets >= 3) {
+    if (i_main + 1 < n_tiles) body(i_main + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue
@@ -509,6 +541,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 //   * causal / window masks only on tiles that are not fully visible to the wave's 32 rows; workgroups of later (longer)
 //     row blocks are dispatched first.
 constexpr int kPBlockM = 256, kPTile = 64;
+
 
 template <typename T>
 struct Mfma32;
@@ -596,43 +629,61 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
     }
   }
 
-  // ---- staging: 16-byte chunk c = tid + 512 i (i = 0, 1) of a tile <-> (token row c / 16, chunk c % 16)
+  // ---- staging: 16-byte chunk c = tid + 512 i (i = 0, 1) of a tile <-> (token row c / 16, chunk c % 16).
+  // One address formula for the three layouts (page * s0 + position-in-page * s1 + base), positions past the end clamped
+  // to the last key (their scores are masked, and a real V row times weight 0 is 0), so that a tile's loads are four
+  // unconditional instructions; the page ids of a tile are fetched one tile before its loads are issued.
   const int32_t* table_b = page_table + (p.paged == 1 ? (int64_t)cache_row * p.table_stride : 0);
-  struct Stage { v4i k[2], v[2]; };
-  auto issue_loads = [&](int t, Stage& sr) {
+  const bool use_table = p.paged == 1;
+  const int pos_mask = use_table ? (1 << p.page_shift) - 1 : -1;
+  const int pos_shift = use_table ? p.page_shift : 31;           // (position >> 31 = 0)
+  const int64_t kpg = use_table ? p.k_s0 : 0, vpg = use_table ? p.v_s0 : 0;  // page stride
+  const int pos_base = p.paged ? leftpad : k_begin;
+  const int64_t kst = p.paged ? p.k_s1 : p.k_s0, vst = p.paged ? p.v_s1 : p.v_s0;  // token stride
+  const int64_t kbase = p.paged == 2 ? (int64_t)cache_row * p.k_s0 + (int64_t)hk * p.k_s2
+                                     : (int64_t)hk * (p.paged ? p.k_s2 : p.k_s1);
+  const int64_t vbase = p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
+                                     : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1);
+  const int srow = tid >> 4, sch = (tid & 15) * 8;  // this thread's token rows srow, srow + 32 and chunk of a tile
+  const int last_key = seqlen_k - 1;
+  struct Pages { int pg[2]; };
+  // (without a page table the fetch reads cu_q[b], a valid word, and the page stride below is 0: no branch, so that the
+  // loaded registers are not merged with constants behind a wait)
+  const int32_t* pg_src = use_table ? table_b : cu_q + b;
+  auto fetch_pages = [&](int t) -> Pages {
+    Pages r;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + 512 * i;
-      const int row = c >> 4, ch = c & 15;
-      const int pos = t * kPTile + row;
-      v4i kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-      if (pos < seqlen_k) {
-        int64_t koff, voff;
-        if (p.paged) {
-          const int cp = pos + leftpad;
-          const int page = p.paged == 2 ? cache_row : table_b[cp >> p.page_shift];
-          const int inp = p.paged == 2 ? cp : cp & ((1 << p.page_shift) - 1);
-          koff = (int64_t)page * p.k_s0 + (int64_t)inp * p.k_s1 + (int64_t)hk * p.k_s2;
-          voff = (int64_t)page * p.v_s0 + (int64_t)inp * p.v_s1 + (int64_t)hk * p.v_s2;
-        } else {
-          koff = (int64_t)(k_begin + pos) * p.k_s0 + (int64_t)hk * p.k_s1;
-          voff = (int64_t)(k_begin + pos) * p.v_s0 + (int64_t)hk * p.v_s1;
-        }
-        kv = *reinterpret_cast<const v4i*>(kcache + (koff + ch * 8) * 2);
-        vv = *reinterpret_cast<const v4i*>(vcache + (voff + ch * 8) * 2);
-      }
-      sr.k[i] = kv;
-      sr.v[i] = vv;
+      int pos = t * kPTile + srow + 32 * i;
+      pos = pos < last_key ? pos : last_key;
+      r.pg[i] = pg_src[(pos + pos_base) >> pos_shift];
+    }
+    return r;
+  };
+  auto issue_load = [&](int t, const Pages& pages, const char* cache, int64_t s0, int64_t st, int64_t base, v4i (&dst)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int pos = t * kPTile + srow + 32 * i;
+      pos = pos < last_key ? pos : last_key;
+      const int cp = (pos + pos_base) & pos_mask;
+      const int64_t off = (int64_t)pages.pg[i] * s0 + (int64_t)cp * st + base + sch;
+      dst[i] = *reinterpret_cast<const v4i*>(cache + off * 2);
     }
   };
-  auto write_lds = [&](int buf, const Stage& sr) {
-    char* base = smem + buf * (2 * TILE_BYTES);
+  auto write_k = [&](int buf, const v4i (&src)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + 512 * i;
       const int row = c >> 4, ch = c & 15;
-      *reinterpret_cast<v4i*>(base + row * ROWB + ((ch ^ (row & 15)) << 4)) = sr.k[i];
-      *reinterpret_cast<v4i*>(base + TILE_BYTES + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4)) = sr.v[i];
+      *reinterpret_cast<v4i*>(smem + buf * TILE_BYTES + row * ROWB + ((ch ^ (row & 15)) << 4)) = src[i];
+    }
+  };
+  auto write_v = [&](int buf, const v4i (&src)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 512 * i;
+      const int row = c >> 4, ch = c & 15;
+      *reinterpret_cast<v4i*>(smem + (2 + buf) * TILE_BYTES + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4)) = src[i];
     }
   };
 
@@ -649,41 +700,82 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int v = 0; v < 16; ++v) o[db][v] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  // Softmax reference m_ref (log2 units, per row): moved only when a tile's maximum passes it by more than kSlack
+  // binades, so that the 64-register rescale of O^T is rare; weights are then at most 2^kSlack (exact arithmetic gives
+  // the same result for any reference, the final normalisation divides it out).
+  constexpr float kSlack = 8.0f;
+  float m_ref = -INFINITY, l_run = 0.f;
   const float log2e = 1.4426950408889634f;
   const float scale = p.scale, sc2 = scale * log2e;
 
-  Stage sreg;
+  // Schedule. Per wave and tile j: QK(j) (MFMA), softmax(j) (VALU), PV(j) (MFMA). The two waves of a SIMD (w, w + 4)
+  // take the workgroup's one barrier per tile at different places - waves 0..3 between softmax and PV, waves 4..7
+  // between QK and softmax - so that after every barrier one of them starts a matrix phase (PV(j), QK(j+1)) while the
+  // other starts its softmax: the matrix pipe and the VALU are shared by phase instead of both waves queueing for
+  // the same unit. Barrier j+1 is passed by everybody after QK(j) and before PV(j); K(j+1) and V(j) are written into
+  // their double buffers at the top of iteration j (between barriers j and j+1: K(j-1) and V(j-2) are dead by then,
+  // and the first readers come after barrier j+1); their global loads were issued one iteration earlier.
+  const bool late_barrier = wave < 4;
+  v4i sk[2], sv[2];
+  Pages pg_v = {{0, 0}}, pg_k = {{0, 0}}, pg_pre = {{0, 0}};  // page ids of tiles t + 1, t + 2 and (in flight) t + 3
   if (n_tiles > 0) {
-    issue_loads(t_lo, sreg);
-    write_lds(0, sreg);
+    pg_v = fetch_pages(t_lo);
+    pg_k = fetch_pages(t_lo + 1);
+    pg_pre = fetch_pages(t_lo + 2);
+    issue_load(t_lo, pg_v, kcache, kpg, kst, kbase, sk);
+    write_k(0, sk);
+    issue_load(t_lo + 1, pg_k, kcache, kpg, kst, kbase, sk);
+    issue_load(t_lo, pg_v, vcache, vpg, vst, vbase, sv);
+    pg_v = pg_k;
+    pg_k = pg_pre;
   }
   __syncthreads();
 
   for (int i = 0; i < n_tiles; ++i) {
     const int t = t_lo + i, buf = i & 1;
-    if (i + 1 < n_tiles) issue_loads(t + 1, sreg);
-    const char* kb = smem + buf * (2 * TILE_BYTES);
-    const char* vb = kb + TILE_BYTES;
+    write_k(buf ^ 1, sk);
+    write_v(buf, sv);
+    issue_load(t + 2, pg_k, kcache, kpg, kst, kbase, sk);  // (past the end: clamped to the last key, never used)
+    issue_load(t + 1, pg_v, vcache, vpg, vst, vbase, sv);
+    pg_v = pg_k;
+    pg_k = fetch_pages(t + 3);
+    const char* kb = smem + buf * TILE_BYTES;
+    const char* vb = smem + (2 + buf) * TILE_BYTES;
 
-    // ---- S^T[token, row] = K . Q^T: two 32-token blocks
+    // ---- S^T[token, row] = K . Q^T: two 32-token blocks; K fragments two k-steps ahead of their MFMAs
     v16f s0, s1;
 #pragma unroll
     for (int v = 0; v < 16; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    {
+      v8s ka[2][2];
+      auto read_k = [&](int ks, v8s (&dst)[2]) {
+        const int off = krow_off + (((2 * ks + u) ^ kkey) << 4);
+        dst[0] = *reinterpret_cast<const v8s*>(kb + off);
+        dst[1] = *reinterpret_cast<const v8s*>(kb + off + 32 * ROWB);
+      };
+      read_k(0, ka[0]);
+      read_k(1, ka[1]);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int off = krow_off + (((2 * ks + u) ^ kkey) << 4);
-      const v8s a0 = *reinterpret_cast<const v8s*>(kb + off);
-      const v8s a1 = *reinterpret_cast<const v8s*>(kb + off + 32 * ROWB);
-      s0 = M32::run(a0, qf[ks], s0);
-      s1 = M32::run(a1, qf[ks], s1);
+      for (int ks = 0; ks < KS; ++ks) {
+        s0 = M32::run(ka[ks & 1][0], qf[ks], s0);
+        s1 = M32::run(ka[ks & 1][1], qf[ks], s1);
+        if (ks + 2 < KS) read_k(ks + 2, ka[ks & 1]);
+      }
+      // keep that order: the scheduler otherwise sinks every read below the MFMAs in front of it
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS - 2; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
+    if (!late_barrier) lds_barrier();
 
     // ---- online softmax for row l31 (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each block)
     bool interior = wave_rows_ok && (t * kPTile + kPTile <= seqlen_k);
     if (p.causal_right >= 0) interior = interior && (t * kPTile + kPTile - 1 <= wave_qabs_lo + p.causal_right);
     if (p.window_left >= 0) interior = interior && (t * kPTile >= wave_qabs_hi - p.window_left);
-    float m_new, m_use, alpha, psum = 0.f;
     if (!interior) {
       const int tb = t * kPTile + 4 * u;
 #pragma unroll
@@ -700,10 +792,19 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
 #pragma unroll
     for (int v = 1; v < 16; ++v) mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    m_new = fmaxf(m_run, mt * scale);  // scale > 0; -inf stays -inf
-    m_use = m_new == -INFINITY ? 0.f : m_new;
-    alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);
-    const float mneg = -m_use * log2e;
+    mt *= sc2;  // scale > 0; -inf stays -inf
+    if (__any(mt > m_ref + kSlack)) {  // (m_ref = -inf: any finite maximum moves it)
+      const float m_new = mt > m_ref + kSlack ? mt : m_ref;
+      const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
+      m_ref = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[db][v] *= alpha;
+    }
+    const float mneg = m_ref == -INFINITY ? 0.f : -m_ref;
+    float psum = 0.f;
     v8s pf[4];
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
@@ -713,34 +814,39 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
       pf[v >> 3][v & 7] = M::cvt(p0);
       pf[2 + (v >> 3)][v & 7] = M::cvt(p1);
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    if (__any(alpha != 1.0f)) {
-#pragma unroll
-      for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) o[db][v] *= alpha;
-    }
+    l_run += psum;
+    if (late_barrier) lds_barrier();
 
     // ---- O^T[dim, row] += V^T . P^T: k-slot order tau (see above): MFMA s4 takes tokens 32 (s4 / 2) + 16 (s4 % 2) + ...
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const int chunk = ((4 * db + vchunk_lo) ^ (qq << 2)) << 4;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
+    // MFMA m = 4 s4 + db (the four accumulators in turn); V^T fragments four MFMAs ahead
+    {
+      v8s vf[4];
+      auto read_v = [&](int m, v8s& dst) {
+        const int s4 = m >> 2, db = m & 3;
+        const int chunk = ((4 * db + vchunk_lo) ^ (qq << 2)) << 4;
         const char* a = vb + (32 * (s4 >> 1) + 16 * (s4 & 1)) * ROWB + vlane_off + chunk;
         const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a));
         const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a + 8 * ROWB));
-        v8s vf;
-        vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-        vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-        o[db] = M32::run(vf, pf[s4], o[db]);
+        dst[0] = v0[0]; dst[1] = v0[1]; dst[2] = v0[2]; dst[3] = v0[3];
+        dst[4] = v1[0]; dst[5] = v1[1]; dst[6] = v1[2]; dst[7] = v1[3];
+      };
+#pragma unroll
+      for (int m = 0; m < 4; ++m) read_v(m, vf[m]);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        o[m & 3] = M32::run(vf[m & 3], pf[m >> 2], o[m & 3]);
+        if (m + 4 < 16) read_v(m + 4, vf[m & 3]);
       }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
-
-    if (i + 1 < n_tiles) write_lds(buf ^ 1, sreg);  // (last read of that buffer: the tile before this one, a barrier ago)
-    __syncthreads();
   }
+  const float m_run = m_ref == -INFINITY ? -INFINITY : m_ref * 0.6931471805599453f;  // the reference in natural-log units
 
   // ---- epilogue (as the kernel above; the two lanes of a row hold partial sums)
   float l_tot = l_run + __shfl_xor(l_run, 32, 64);

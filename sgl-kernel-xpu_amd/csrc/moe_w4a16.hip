@@ -26,9 +26,10 @@
 // 2^(byte - 127) is applied in fp32 per 32-deep k step (no zero point, no row-sum MFMA).
 //
 // Data movement. Weights are streamed once from HBM straight into registers (16 B per lane; they are not
-// shared between waves, so an LDS round trip would be pure overhead), then a 4x4 dword transpose across
-// the four 16-lane groups (2 x v_permlane32_swap + 2 x v_permlane16_swap) gives every MFMA k-step a
-// contiguous 32-wide k range, i.e. exactly one quantisation group for group sizes >= 32. The
+// shared between waves, so an LDS round trip would be pure overhead). For quantisation groups of 32 / 64 a 4x4
+// dword transpose across the four 16-lane groups (2 x v_permlane32_swap + 2 x v_permlane16_swap) gives every MFMA
+// k-step a contiguous 32-wide k range, i.e. exactly one group; groups of 128 / 256 cover the whole 128-deep block,
+// so the k order inside it is permuted instead (k-step j = dword j of each lane) and nothing moves between lanes. The
 // activation tile [BM rows x 128 k] is staged through LDS once per 128-deep block for all 4 waves
 // (element order permuted to match the nibble-pair order of the weight fragments; rows XOR-swizzled).
 // Block = 4 waves; wave w owns NW 16-wide n tiles and all MT 16-row m tiles of the block's expert rows.
@@ -74,8 +75,10 @@ struct W4<f16> {
 
 // 8 nibbles (k offsets 0..7, nibble i at bits 4i) -> 4 dwords of two 16-bit floats (16 + u):
 // dword p = (k offset p, k offset p + 4).  The activation fragments use the same element order.
+// Two instructions per dword: a shift and v_and_or_b32 (the compiler emits and + or with literal operands instead: a
+// VOP3 cannot take literals on gfx9 and may read only one SGPR, so the mask is passed in an SGPR and the magic in a VGPR)
 template <typename T>
-__device__ __forceinline__ v4i expand_nibbles(uint32_t w) {
+__device__ __forceinline__ v4i expand_nibbles(uint32_t w, uint32_t magic_vgpr) {
   constexpr int S = W4<T>::kShift;
   constexpr uint32_t mask = (0xFu << S) | (0xFu << (S + 16));
   v4i r;
@@ -83,7 +86,9 @@ __device__ __forceinline__ v4i expand_nibbles(uint32_t w) {
   for (int p = 0; p < 4; ++p) {
     const int sh = S - 4 * p;
     const uint32_t t = sh >= 0 ? (w << sh) : (w >> (-sh));
-    r[p] = (int)((t & mask) | W4<T>::kMagic);
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(t), "s"(mask), "v"(magic_vgpr));
+    r[p] = (int)d;
   }
   return r;
 }
@@ -233,6 +238,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   const int nkb = (K + 127) >> 7;   // K is a multiple of 32; the last 128-block may hold 1..3 k steps
   const int ksteps = K >> 5;
   const v4i ones = {(int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes};
+  uint32_t magic = W4<T>::kMagic;
+  asm volatile("" : "+v"(magic));  // (a VGPR, once, not a re-materialised literal per use)
+  // One scale group per 128-deep block (groups of 128 / 256): the order of k inside the block is free, so MFMA k-step j
+  // takes dword j of every lane's own 16 weight bytes (k = 32 g + 8 j ..) and the activation fragment is read from
+  // that k range; smaller groups need each k-step to be one contiguous 32-wide range: 4x4 transpose across lane groups.
+  constexpr bool kTranspose = PB > 1;
 
   // weights run two 128-deep blocks ahead of the MFMAs, scales / zero points one block ahead: at decode sizes the
   // kernel is a latency-bound HBM stream and a load consumed in the iteration that issued it stalls every wave
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
 #pragma unroll
         for (int t = 0; t < 4; ++t) wd[nt][t] ^= 0x88888888u;  // two's complement -> offset binary (zp 8)
       }
-      transpose4(wd[nt]);  // now wd[nt][j] = codes of k = 128 kb + 32 j + 8 g .. + 7 of row n
+      if constexpr (kTranspose) transpose4(wd[nt]);  // now wd[nt][j] = codes of k = 128 kb + 32 j + 8 g .. + 7 of row n
     }
     const char* abase = smem + buf * (BM * 256);
     static_for4([&](auto jc) {
@@ -315,11 +326,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
       // (k steps past K multiply zero activations: no tail branch)
       v4i wf[NW];
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) wf[nt] = FMT == 1 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j]);
+      for (int nt = 0; nt < NW; ++nt) wf[nt] = FMT == 1 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], magic);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
-        const v4i af = *reinterpret_cast<const v4i*>(abase + row * 256 + (((4 * j + g) ^ l15) << 4));
+        const int chunk = kTranspose ? 4 * j + g : 4 * g + j;
+        const v4i af = *reinterpret_cast<const v4i*>(abase + row * 256 + ((chunk ^ l15) << 4));
         if constexpr (FMT == 0) asum[mt] = W4<T>::mma(af, ones, asum[mt]);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
