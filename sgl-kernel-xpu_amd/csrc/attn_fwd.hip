@@ -20,6 +20,7 @@
 // with the hardware transpose read. LDS images are [256-byte column block][32 rows][256 B] with the chunk
 // swizzle / k-permutation / token-permutation of mla_decode.hip (conflict-free row and transposed reads).
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -60,6 +61,8 @@ struct Mfma<f16> {
   static __device__ __forceinline__ short cvt(float x) { return __builtin_bit_cast(short, (f16)x); }
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight (__syncthreads() also
 // drains vmcnt, which would end the prefetch of the next tiles at every barrier)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -90,6 +93,7 @@ struct AttnParams {
   int splits;
   float scale;          // softmax scale
   float softcap;        // 0 = off
+  int probe;            // TEMPORARY experiment switch (env SGLK_ATTN_PROBE)
 };
 
 // DKP: head dim rounded up to 32 (k-steps of the QK product); the V/O side uses ceil(D/16) 16-wide tiles.
@@ -116,9 +120,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g4 = lane >> 4;
-  const int b = blockIdx.z;
-  const int hk = blockIdx.y % p.Hk;
-  const int split = blockIdx.y / p.Hk;
+  // (kv head, split, sequence) of this workgroup. Workgroups are handed to the 8 XCDs round-robin in launch order; the
+  // kv heads of one token range read neighbouring 256-byte pieces of the same cache rows, and consecutive splits of a
+  // sequence neighbouring rows: the launch index is re-ordered so that those run on the same XCD (one L2, and DRAM pages
+  // opened once instead of once per XCD).
+  int wg = blockIdx.y + gridDim.y * blockIdx.z;
+  {
+    const int total = gridDim.y * gridDim.z;
+    if ((total & 7) == 0) wg = (wg & 7) * (total >> 3) + (wg >> 3);
+  }
+  const int hk = wg % p.Hk;
+  const int split = (wg / p.Hk) % p.splits;
+  const int b = wg / (p.Hk * p.splits);
   const int D = p.D, G = p.G;
   const int cpr = D >> 3;                      // valid 16-byte chunks per row
   const int nt_valid = (D + 15) >> 4;
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   // bounds over the 16 rows of this wave (wave-uniform), for the interior-tile test of the main loop
   const int wrow_first = row0 + wave * kRowsPerWave, wrow_last = wrow_first + kRowsPerWave - 1;
   const bool wave_rows_ok = wrow_last < rows_total;
+  const bool wave_active = wrow_first < rows_total;
   const int wave_qabs_lo = wrow_first / G + shift, wave_qabs_hi = (wrow_last < rows_total ? wrow_last : rows_total - 1) / G + shift;
 
   // ---- kv range visible to this workgroup (union over its rows), then this split's share of it
@@ -214,8 +228,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   const int pos_mask = use_table ? (1 << p.page_shift) - 1 : -1;
   const int pos_shift = use_table ? p.page_shift : 31;  // (position >> 31 = 0)
   const int pos_base = p.paged ? leftpad : k_begin;
-  const int64_t kpg = use_table ? p.k_s0 : 0, vpg = use_table ? p.v_s0 : 0;        // page stride
-  const int64_t kst = p.paged ? p.k_s1 : p.k_s0, vst = p.paged ? p.v_s1 : p.v_s0;  // token stride
+  // (strides are below 2^31 elements - checked on the host - so each product is one v_mad_u64_u32)
+  const uint32_t kpg = use_table ? (uint32_t)p.k_s0 : 0u, vpg = use_table ? (uint32_t)p.v_s0 : 0u;          // page stride
+  const uint32_t kst = (uint32_t)(p.paged ? p.k_s1 : p.k_s0), vst = (uint32_t)(p.paged ? p.v_s1 : p.v_s0);  // token stride
   const int64_t kbase_off = p.paged == 2 ? (int64_t)cache_row * p.k_s0 + (int64_t)hk * p.k_s2
                                          : (int64_t)hk * (p.paged ? p.k_s2 : p.k_s1);
   const int64_t vbase_off = p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
@@ -246,9 +261,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
     for (int i = 0; i < LD; ++i) {
       int pos = t * kTile + (srow[i] < kTile ? srow[i] : kTile - 1);
       pos = pos < last_key ? pos : last_key;
-      const int cp = (pos + pos_base) & pos_mask;
-      const int64_t koff = (int64_t)pages.pg[i] * kpg + (int64_t)cp * kst + kbase_off + sch[i] * 8;
-      const int64_t voff = (int64_t)pages.pg[i] * vpg + (int64_t)cp * vst + vbase_off + sch[i] * 8;
+      const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask), pg = (uint32_t)pages.pg[i];
+      const int64_t koff = (int64_t)((uint64_t)pg * kpg + ((uint64_t)cp * kst + (uint64_t)(kbase_off + sch[i] * 8)));
+      const int64_t voff = (int64_t)((uint64_t)pg * vpg + ((uint64_t)cp * vst + (uint64_t)(vbase_off + sch[i] * 8)));
       if constexpr (KV8 == 0) {
         sr.k[i] = *reinterpret_cast<const v4i*>(kcache + koff * 2);
         sr.v[i] = *reinterpret_cast<const v4i*>(vcache + voff * 2);
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
       // (after the last use of the old ids, so that both can live in the same registers: no copy at the loop end)
       pgring[par % kSets] = fetch_pages(t + 2 * kSets < tl ? t + 2 * kSets : tl);
     }
-    {
+    if (wave_active) {  // (decode: the rows of a kv head fill one wave; the others only stage tiles)
       const char* kb = smem + slot * SLOT;
       const char* vb = kb + TILE_BYTES;
       v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -571,7 +586,15 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, u = lane >> 5;
-  const int b = blockIdx.z, hk = blockIdx.y, G = p.G;
+  // launch index -> (row block, kv head, sequence), re-ordered so that the row blocks of one (sequence, kv head) - which
+  // stream the same K / V - run on the same XCD (workgroups go to the 8 XCDs round-robin in launch order)
+  int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  {
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 7) == 0) wg = (wg & 7) * (total >> 3) + (wg >> 3);
+  }
+  const int bx = wg % gridDim.x;
+  const int hk = (wg / gridDim.x) % gridDim.y, b = wg / (gridDim.x * gridDim.y), G = p.G;
 
   const int q_begin = cu_q[b];
   const int seqlen_q = cu_q[b + 1] - q_begin;
@@ -587,8 +610,8 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   }
   const int rows_total = seqlen_q * G;
   const int nblk = (rows_total + kPBlockM - 1) / kPBlockM;
-  if ((int)blockIdx.x >= nblk) return;
-  const int row0 = (nblk - 1 - (int)blockIdx.x) * kPBlockM;  // longest rows first
+  if (bx >= nblk) return;
+  const int row0 = (nblk - 1 - bx) * kPBlockM;  // longest rows first
   const int shift = seqlen_k - seqlen_q;
 
   const int my_row = row0 + wave * 32 + l31;
@@ -637,9 +660,10 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   const bool use_table = p.paged == 1;
   const int pos_mask = use_table ? (1 << p.page_shift) - 1 : -1;
   const int pos_shift = use_table ? p.page_shift : 31;           // (position >> 31 = 0)
-  const int64_t kpg = use_table ? p.k_s0 : 0, vpg = use_table ? p.v_s0 : 0;  // page stride
+  // (strides are below 2^31 elements - checked on the host - so each product is one v_mad_u64_u32)
+  const uint32_t kpg = use_table ? (uint32_t)p.k_s0 : 0u, vpg = use_table ? (uint32_t)p.v_s0 : 0u;  // page stride
   const int pos_base = p.paged ? leftpad : k_begin;
-  const int64_t kst = p.paged ? p.k_s1 : p.k_s0, vst = p.paged ? p.v_s1 : p.v_s0;  // token stride
+  const uint32_t kst = (uint32_t)(p.paged ? p.k_s1 : p.k_s0), vst = (uint32_t)(p.paged ? p.v_s1 : p.v_s0);  // token stride
   const int64_t kbase = p.paged == 2 ? (int64_t)cache_row * p.k_s0 + (int64_t)hk * p.k_s2
                                      : (int64_t)hk * (p.paged ? p.k_s2 : p.k_s1);
   const int64_t vbase = p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
@@ -660,13 +684,13 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
     }
     return r;
   };
-  auto issue_load = [&](int t, const Pages& pages, const char* cache, int64_t s0, int64_t st, int64_t base, v4i (&dst)[2]) {
+  auto issue_load = [&](int t, const Pages& pages, const char* cache, uint32_t s0, uint32_t st, int64_t base, v4i (&dst)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int pos = t * kPTile + srow + 32 * i;
       pos = pos < last_key ? pos : last_key;
-      const int cp = (pos + pos_base) & pos_mask;
-      const int64_t off = (int64_t)pages.pg[i] * s0 + (int64_t)cp * st + base + sch;
+      const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
+      const int64_t off = (int64_t)((uint64_t)(uint32_t)pages.pg[i] * s0 + ((uint64_t)cp * st + (uint64_t)(base + sch)));
       dst[i] = *reinterpret_cast<const v4i*>(cache + off * 2);
     }
   };
@@ -715,7 +739,10 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   // the same unit. Barrier j+1 is passed by everybody after QK(j) and before PV(j); K(j+1) and V(j) are written into
   // their double buffers at the top of iteration j (between barriers j and j+1: K(j-1) and V(j-2) are dead by then,
   // and the first readers come after barrier j+1); their global loads were issued one iteration earlier.
-  const bool late_barrier = wave < 4;
+  bool late_barrier = wave < 4;
+  if (p.probe == 1) late_barrier = (wave & 1) == 0;
+  if (p.probe == 2) late_barrier = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) == 0;  // HW_ID.wave_id parity
+  if (p.probe == 3) late_barrier = true;
   v4i sk[2], sv[2];
   Pages pg_v = {{0, 0}}, pg_k = {{0, 0}}, pg_pre = {{0, 0}};  // page ids of tiles t + 1, t + 2 and (in flight) t + 3
   if (n_tiles > 0) {
@@ -788,11 +815,27 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
         s1[v] = m1 ? -INFINITY : s1[v];
       }
     }
-    float mt = fmaxf(s0[0], s1[0]);
+    // (the VALU is this kernel's second bottleneck after the matrix pipe. Scores are scaled first, as packed fp32
+    // products: the maxima of products need no NaN canonicalisation (raw MFMA results get one v_max x, x each) and pair
+    // up into v_max3_f32; then packed adds for x - m and for the row sums. No inline-asm VALU here: the hazard recogniser
+    // cannot see an asm read of a register an MFMA is still writing.)
+    const v2f sc2v = {sc2, sc2};
+    v2f x0[8], x1[8];
 #pragma unroll
-    for (int v = 1; v < 16; ++v) mt = fmaxf(mt, fmaxf(s0[v], s1[v]));
+    for (int v = 0; v < 8; ++v) {
+      x0[v] = (v2f){s0[2 * v], s0[2 * v + 1]} * sc2v;  // -inf stays -inf (scale > 0)
+      x1[v] = (v2f){s1[2 * v], s1[2 * v + 1]} * sc2v;
+    }
+    float mt = fmaxf(fmaxf(x0[0][0], x0[0][1]), x1[0][0]);
+    mt = fmaxf(fmaxf(mt, x1[0][1]), x0[1][0]);
+    mt = fmaxf(fmaxf(mt, x0[1][1]), x1[1][0]);
+    mt = fmaxf(mt, x1[1][1]);
+#pragma unroll
+    for (int v = 2; v < 8; ++v) {
+      mt = fmaxf(fmaxf(mt, x0[v][0]), x0[v][1]);
+      mt = fmaxf(fmaxf(mt, x1[v][0]), x1[v][1]);
+    }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    mt *= sc2;  // scale > 0; -inf stays -inf
     if (__any(mt > m_ref + kSlack)) {  // (m_ref = -inf: any finite maximum moves it)
       const float m_new = mt > m_ref + kSlack ? mt : m_ref;
       const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
@@ -804,16 +847,23 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
         for (int v = 0; v < 16; ++v) o[db][v] *= alpha;
     }
     const float mneg = m_ref == -INFINITY ? 0.f : -m_ref;
-    float psum = 0.f;
+    const v2f mnegv = {mneg, mneg};
+    v2f psum0 = {0.f, 0.f}, psum1 = {0.f, 0.f};
     v8s pf[4];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[v], sc2, mneg));
-      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[v], sc2, mneg));
-      psum += p0 + p1;
-      pf[v >> 3][v & 7] = M::cvt(p0);
-      pf[2 + (v >> 3)][v & 7] = M::cvt(p1);
+    for (int v = 0; v < 8; ++v) {
+      const v2f y0 = x0[v] + mnegv, y1 = x1[v] + mnegv;
+      const v2f p0 = {__builtin_amdgcn_exp2f(y0[0]), __builtin_amdgcn_exp2f(y0[1])};
+      const v2f p1 = {__builtin_amdgcn_exp2f(y1[0]), __builtin_amdgcn_exp2f(y1[1])};
+      psum0 += p0;
+      psum1 += p1;
+      pf[v >> 2][2 * (v & 3)] = M::cvt(p0[0]);
+      pf[v >> 2][2 * (v & 3) + 1] = M::cvt(p0[1]);
+      pf[2 + (v >> 2)][2 * (v & 3)] = M::cvt(p1[0]);
+      pf[2 + (v >> 2)][2 * (v & 3) + 1] = M::cvt(p1[1]);
     }
+    psum0 += psum1;
+    const float psum = psum0[0] + psum0[1];
     l_run += psum;
     if (late_barrier) lds_barrier();
 
@@ -1009,6 +1059,13 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
                    (uintptr_t)q % 16 == 0 && (uintptr_t)k % (kv8 ? 8 : 16) == 0 && (uintptr_t)v % (kv8 ? 8 : 16) == 0,
                "fwd: q, k and v rows must be 16-byte aligned (8-byte for an fp8 cache)");
   SGLK_REQUIRE(kv_layout >= 0 && kv_layout <= 2, "fwd: kv_layout must be 0 (ragged), 1 (paged) or 2 (cache rows)");
+  {
+    const int64_t lim = (int64_t)1 << 31;
+    SGLK_REQUIRE(k_stride0 >= 0 && k_stride1 >= 0 && k_stride2 >= 0 && v_stride0 >= 0 && v_stride1 >= 0 && v_stride2 >= 0 &&
+                     k_stride0 < lim && k_stride1 < lim && k_stride2 < lim && v_stride0 < lim && v_stride1 < lim &&
+                     v_stride2 < lim,
+                 "fwd: k / v strides must be non-negative and below 2^31 elements");
+  }
   SGLK_REQUIRE((kv_layout == 1) == (page_table != nullptr), "fwd: a page table goes with the paged layout and only with it");
   SGLK_REQUIRE(kv_layout != 0 || (kv_batch_idx == nullptr && leftpad_k == nullptr),
                "fwd: kv_batch_idx / leftpad_k need a KV cache (paged or cache-row layout)");
@@ -1050,6 +1107,10 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
   p.splits = (int)num_splits;
   p.scale = softmax_scale;
   p.softcap = softcap;
+  {
+    static const int probe_env = getenv("SGLK_ATTN_PROBE") ? atoi(getenv("SGLK_ATTN_PROBE")) : 0;
+    p.probe = probe_env;
+  }
   const int max_rows = (int)(max_seqlen_q * p.G);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16)

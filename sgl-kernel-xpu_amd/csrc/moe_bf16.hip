@@ -17,6 +17,7 @@
 // 128-deep block), two blocks ahead in a static register ring; the activation tile [BM x 128] goes through LDS once
 // per block for all 4 waves (loaded one block ahead, written to LDS the iteration after; LDS-only barrier).
 #include "common.h"
+#include "moe_tiles.h"
 
 namespace sglk {
 namespace {
@@ -62,23 +63,14 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
 
-  // ---- which expert / which block of its rows (uniform scalar walk over the row counts)
-  int e = 0, row0 = 0, rows_e = 0, blk = blockIdx.x;
-  bool found = false;
-  for (; e < E; ++e) {
-    rows_e = rows_per_expert[e];
-    const int nb = (rows_e + BM - 1) / BM;
-    if (blk < nb) { found = true; break; }
-    blk -= nb;
-    row0 += rows_e;
-  }
-  if (!found) return;
-  const int m0 = row0 + blk * BM;
-  const int m_valid = rows_e - blk * BM;
+  // ---- which (expert, block of its rows, column block): see moe_tiles.h
   constexpr bool kGated = FUSE == FUSE_SILU || FUSE == FUSE_GELU;
   static_assert(!kGated || NW == 2, "the gated epilogue pairs the two n tiles of a wave");
   const int Nh = N >> 1;  // gated: output width; gate rows [0, Nh), up rows [Nh, N)
-  const int n_base = kGated ? blockIdx.y * (BN / 2) + wave * 16 : blockIdx.y * BN + wave * (NW * 16);
+  const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, kGated ? (Nh + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN);
+  if (tile.expert < 0) return;
+  const int e = tile.expert, m0 = tile.m0, m_valid = tile.m_valid;
+  const int n_base = kGated ? tile.col_block * (BN / 2) + wave * 16 : tile.col_block * BN + wave * (NW * 16);
 
   const T* wexp = w + (int64_t)e * w_stride_e;
   uint32_t woff[NW];  // element offset of this lane's row and k group
@@ -208,9 +200,10 @@ template <typename T, int MT, int NW>
 static int launch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
                   int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
   constexpr int BM = 16 * MT, BN = 64 * NW;
-  const int64_t max_mblocks = total_m / BM + E;  // sum_e ceil(rows_e / BM) <= total_m / BM + E
   const bool gated = fuse == FUSE_SILU || fuse == FUSE_GELU;
-  dim3 grid((unsigned)max_mblocks, (unsigned)(gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN)));
+  const int64_t wgs = moe_tile_launch_size(total_m, E, BM, gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN));
+  if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20: problem too large for one launch");
+  dim3 grid((unsigned)wgs);
 #define SGLK_GO(F) \
   moe_bf16_kernel<T, MT, NW, F><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E, N, K, ldb, w_stride_e)
   switch (fuse) {

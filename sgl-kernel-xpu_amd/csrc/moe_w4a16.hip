@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "moe_tiles.h"
 
 namespace sglk {
 namespace {
@@ -75,20 +76,19 @@ struct W4<f16> {
 
 // 8 nibbles (k offsets 0..7, nibble i at bits 4i) -> 4 dwords of two 16-bit floats (16 + u):
 // dword p = (k offset p, k offset p + 4).  The activation fragments use the same element order.
-// Two instructions per dword: a shift and v_and_or_b32 (the compiler emits and + or with literal operands instead: a
-// VOP3 cannot take literals on gfx9 and may read only one SGPR, so the mask is passed in an SGPR and the magic in a VGPR)
+// Two instructions per dword: a shift and v_and_or_b32. The mask and the magic are passed as opaque register values:
+// with literal operands the compiler emits and + or (a VOP3 takes no literal on gfx9). Not inline asm: the hazard
+// recogniser does not see through an asm statement, and a VALU write it cannot see may land on the source registers of
+// an MFMA still in the queue (that broke the fp16 / 32-row / group-64 instantiation).
 template <typename T>
-__device__ __forceinline__ v4i expand_nibbles(uint32_t w, uint32_t magic_vgpr) {
+__device__ __forceinline__ v4i expand_nibbles(uint32_t w, uint32_t mask_reg, uint32_t magic_reg) {
   constexpr int S = W4<T>::kShift;
-  constexpr uint32_t mask = (0xFu << S) | (0xFu << (S + 16));
   v4i r;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int sh = S - 4 * p;
     const uint32_t t = sh >= 0 ? (w << sh) : (w >> (-sh));
-    uint32_t d;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(t), "s"(mask), "v"(magic_vgpr));
-    r[p] = (int)d;
+    r[p] = (int)((t & mask_reg) | magic_reg);
   }
   return r;
 }
@@ -149,7 +149,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
                                                         const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
                                                         const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
-                                                        int K, int group_shift) {
+                                                        int K, int group_shift, int probe) {
+  // probe (libsglk_probes.so only; 0 in the release library): timing experiments with garbage results -
+  // 1: one activation row for all 16 m rows, 2: no output stores, 4: non-temporal weight loads, 8: scales read once,
+  // 16: no weight expansion / MFMAs (stream only)
+#ifndef SGLK_PROBES
+  probe = 0;
+#endif
   constexpr int BM = 16 * MT;
   constexpr int BN = 64 * NW;
   __shared__ __attribute__((aligned(256))) char smem[2 * BM * 256];
@@ -158,20 +164,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, g = lane >> 4;
 
-  // ---- which expert / which block of its rows (uniform scalar walk over the row counts)
-  int e = 0, row0 = 0, rows_e = 0, blk = blockIdx.x;
-  bool found = false;
-  for (; e < E; ++e) {
-    rows_e = rows_per_expert[e];
-    const int nb = (rows_e + BM - 1) / BM;
-    if (blk < nb) { found = true; break; }
-    blk -= nb;
-    row0 += rows_e;
-  }
-  if (!found) return;
-  const int m0 = row0 + blk * BM;               // first global row of this block
-  const int m_valid = rows_e - blk * BM;        // rows of this block that exist (>= 1)
-  const int n_base = blockIdx.y * BN + wave * (NW * 16);
+  // ---- which (expert, block of its rows, column block): see moe_tiles.h
+  const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, (N + BN - 1) / BN);
+  if (tile.expert < 0) return;
+  const int e = tile.expert, m0 = tile.m0, m_valid = tile.m_valid;
+  const int n_base = tile.col_block * BN + wave * (NW * 16);
 
   using S = typename std::conditional<FMT == 1, uint8_t, T>::type;  // stored scale type
   const S* scales = reinterpret_cast<const S*>(scales_);
@@ -202,7 +199,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
     for (int i = 0; i < MT; ++i) {
       const int idx = i * 256 + tid;
       const int row = idx >> 4, c = idx & 15;
-      const int grow = m0 + (row < m_valid ? row : m_valid - 1);
+      const int grow = m0 + ((probe & 1) ? 0 : row < m_valid ? row : m_valid - 1);
       const bool in = kb * 128 + c * 8 < K;  // past K: read k = 0 instead and zero the registers (no branch)
       const v4i v = *reinterpret_cast<const v4i*>(act + (int64_t)grow * K + (in ? kb * 128 + c * 8 : 0));
       r[i][0] = in ? v[0] : 0; r[i][1] = in ? v[1] : 0; r[i][2] = in ? v[2] : 0; r[i][3] = in ? v[3] : 0;
@@ -238,8 +235,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   const int nkb = (K + 127) >> 7;   // K is a multiple of 32; the last 128-block may hold 1..3 k steps
   const int ksteps = K >> 5;
   const v4i ones = {(int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes};
-  uint32_t magic = W4<T>::kMagic;
-  asm volatile("" : "+v"(magic));  // (a VGPR, once, not a re-materialised literal per use)
+  uint32_t magic = W4<T>::kMagic, nib_mask = (0xFu << W4<T>::kShift) | (0xFu << (W4<T>::kShift + 16));
+  asm volatile("" : "+v"(magic), "+s"(nib_mask));  // (opaque register values: see expand_nibbles)
   // One scale group per 128-deep block (groups of 128 / 256): the order of k inside the block is free, so MFMA k-step j
   // takes dword j of every lane's own 16 weight bytes (k = 32 g + 8 j ..) and the activation fragment is read from
   // that k range; smaller groups need each k-step to be one contiguous 32-wide range: 4x4 transpose across lane groups.
@@ -250,14 +247,15 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   // All three streams (weights, scales / zero points, activations) run kD 128-deep blocks ahead of the MFMAs in
   // register rings with static slots (the K loop is unrolled kD times): at decode sizes an iteration is ~0.15 us of
   // MFMA work against ~2 us of memory latency, and a load consumed close to where it was issued stalls the wave.
-  constexpr int kD = 2;
+  constexpr int kD = MT <= 2 ? 4 : 2;  // (decode tiles: 8 KiB of weights in flight per wave; the large tiles: registers)
   uint32_t wd[NW][4], wq_[kD][NW][4];
   // weights past K are never multiplied by anything but zero activations: any valid address will do (block 0)
   auto load_w = [&](int kb, uint32_t (&dst)[NW][4]) {
     const uint32_t koff = (kb * 128 + 32 * g < K) ? (uint32_t)kb * 64u : 0u;
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
-      const v4i t = *reinterpret_cast<const v4i*>(wexp + woff[nt] - 16 * g + ((kb * 128 + 32 * g < K) ? 16 * g : 0) + koff);
+      const v4i* wp = reinterpret_cast<const v4i*>(wexp + woff[nt] - 16 * g + ((kb * 128 + 32 * g < K) ? 16 * g : 0) + koff);
+      const v4i t = (probe & 4) ? __builtin_nontemporal_load(wp) : *wp;
       dst[nt][0] = t[0]; dst[nt][1] = t[1]; dst[nt][2] = t[2]; dst[nt][3] = t[3];
     }
   };
@@ -268,7 +266,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
     for (int nt = 0; nt < NW; ++nt) {
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
-        int kg = kg0 + i;
+        int kg = (probe & 8) ? 0 : kg0 + i;
         kg = kg < kgroups ? kg : kgroups - 1;
         sd[nt][i] = sexp[soff[nt] + kg];
         if constexpr (FMT == 0) zd[nt][i] = zexp[soff[nt] + kg];
@@ -321,12 +319,17 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
       if constexpr (kTranspose) transpose4(wd[nt]);  // now wd[nt][j] = codes of k = 128 kb + 32 j + 8 g .. + 7 of row n
     }
     const char* abase = smem + buf * (BM * 256);
+    if (probe & 16) {
+#pragma unroll
+      for (int nt = 0; nt < NW; ++nt) acc[0][nt][0] += __uint_as_float(wd[nt][0] ^ wd[nt][1] ^ wd[nt][2] ^ wd[nt][3]) + (float)sc[nt][0];
+      continue;
+    }
     static_for4([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // (k steps past K multiply zero activations: no tail branch)
       v4i wf[NW];
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) wf[nt] = FMT == 1 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], magic);
+      for (int nt = 0; nt < NW; ++nt) wf[nt] = FMT == 1 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
@@ -380,20 +383,27 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = mt * 16 + 4 * g + r;
-        if (row < m_valid) out[(int64_t)(m0 + row) * N + n] = (T)(acc[mt][nt][r] + bv);
+        if (row < m_valid && !((probe & 2) && acc[mt][nt][r] != 12345.f)) out[(int64_t)(m0 + row) * N + n] = (T)(acc[mt][nt][r] + bv);
       }
     }
   }
 }
 
+#ifdef SGLK_PROBES
+static int g_w4_probe = 0, g_w4_mt = 0;
+#else
+constexpr int g_w4_probe = 0, g_w4_mt = 0;
+#endif
+
 template <typename T, int MT, int NW, int PB, int FMT = 0>
 static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
   constexpr int BM = 16 * MT, BN = 64 * NW;
-  const int64_t max_mblocks = total_m / BM + E;  // sum_e ceil(rows_e / BM) <= total_m / BM + E
-  dim3 grid((unsigned)max_mblocks, (unsigned)cdiv(N, BN));
+  const int64_t wgs = moe_tile_launch_size(total_m, E, BM, cdiv(N, BN));
+  if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20_w4a16: problem too large for one launch");
+  dim3 grid((unsigned)wgs);
   moe_w4a16_kernel<T, MT, NW, PB, FMT><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
-                                                             rows, E, N, K, group_shift);
+                                                             rows, E, N, K, group_shift, g_w4_probe);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
 }
 
@@ -412,7 +422,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
                     const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
   // tile policy by average rows per expert (the reference switches policies the same way,
   // GroupGemmW4A16Xe20.cpp:266-277): decode streams weights with one 16-row tile per block
-  const int64_t avg = total_m / E;
+  const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 16 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 128 : 1000) : total_m / E;
   if (avg <= 16) return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   if (avg <= 32) return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   if (avg <= 128) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
@@ -447,3 +457,10 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
   return dispatch<f16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
                        (int)n_experts, (int)N, (int)K, gs);
 }
+
+#ifdef SGLK_PROBES
+extern "C" SGLK_API void sglk_debug_set_w4a16_probe(int probe, int force_mt) {
+  sglk::g_w4_probe = probe;
+  sglk::g_w4_mt = force_mt;
+}
+#endif

@@ -2,7 +2,7 @@
 // (build/libsglk_probes.so, -DSGLK_PROBES: main-loop variants and garbage-result timing probes behind sglk_debug_*):
 //   python sgl-kernel-xpu_amd/build.py --probes   ->  sgl-kernel-xpu_amd/build/kbench
 // usage: kbench gemm M N K [variants...] | kbench stamps M N K | kbench scaledmm M N K | kbench mla B S H [splits...]
-//        kbench peak THREADS BLOCKS ITERS | kbench oob
+//        kbench peak THREADS BLOCKS ITERS | kbench oob | kbench w4a16 N K ROWS_PER_EXPERT [probe:mt ...]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -18,6 +18,7 @@ extern "C" void sglk_debug_set_gemm_variant(int);
 extern "C" void sglk_debug_set_mla_waves_per_group(int);
 extern "C" void sglk_debug_set_mla_probe(int);
 extern "C" void sglk_debug_set_gemm_stamps(uint32_t*);
+extern "C" void sglk_debug_set_w4a16_probe(int probe, int force_mt);
 
 #define HIP_CHECK(x)                                                                 \
   do {                                                                               \
@@ -239,6 +240,48 @@ __global__ __launch_bounds__(512) void issue_probe_kernel(const int* __restrict_
 }
 
 // ---- does the raw-buffer range check of buffer_load ... lds include the scalar offset? (expects zeros past the end)
+// Weight-streaming access patterns of a [rows x row_bytes] matrix (the int4 expert weights): every workgroup streams 128
+// rows end to end, 4 waves x 32 rows, 16 bytes per lane and load, DEPTH loads in flight per lane.
+//   pattern 0: one load = 16 rows x 64 contiguous bytes (lane = (row l15, chunk g)): the MFMA-fragment order
+//   pattern 1: one load = 4 rows x 256 contiguous bytes (lane = (row lane / 16, chunk lane % 16))
+//   pattern 2: one load = 1 row x 1024 contiguous bytes
+template <int PATTERN, int DEPTH>
+__global__ __launch_bounds__(256) void stream_probe_kernel(const uint8_t* __restrict__ w, uint32_t* __restrict__ out, int row_bytes) {
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  v4i_ acc = {0, 0, 0, 0};
+  // one "round" moves 32 rows x 256 bytes per wave = 8 loads per lane
+  const int rounds = row_bytes / 256;
+  for (int r0 = 0; r0 < rounds; r0 += DEPTH) {
+    v4i_ v[DEPTH][8];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int r = r0 + d;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int64_t row, off;
+        if (PATTERN == 0) {  // i = (n tile nt = i / 4, 64-byte block q = i % 4)
+          row = row0 + (i >> 2) * 16 + (lane & 15);
+          off = (int64_t)r * 256 + (i & 3) * 64 + (lane >> 4) * 16;
+        } else if (PATTERN == 1) {  // i = 4-row group
+          row = row0 + i * 4 + (lane >> 4);
+          off = (int64_t)r * 256 + (lane & 15) * 16;
+        } else {  // 8 loads = 8 rows x 1 KB; a round pair covers the 32 rows
+          row = row0 + (r & 3) * 8 + i;
+          off = (int64_t)(r >> 2) * 1024 + lane * 16;
+        }
+        v[d][i] = *reinterpret_cast<const v4i_*>(w + row * row_bytes + off);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc ^= v[d][i];
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678) out[0] = 1;
+}
+
 __global__ void oob_probe_kernel(const uint8_t* __restrict__ src, int nrec, int soff, int use_voff, uint32_t* out) {
   __shared__ __attribute__((aligned(256))) uint32_t lds[256];
   __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nrec, 0x00020000);
@@ -407,6 +450,66 @@ int main(int argc, char** argv) {
       const double ms = time_ms(run, 100, 50, &all);
       printf("scaled_mm %s M=%lld N=%lld K=%lld median %.4f ms min %.4f -> %.1f T(FL)OP/s\n", dt == SGLK_INT8 ? "int8" : "fp8",
              (long long)M, (long long)N, (long long)K, ms, all[0], 2.0 * M * N * K / ms / 1e9);
+    }
+    return 0;
+  }
+  if (!strcmp(argv[1], "stream")) {  // kbench stream ROWS ROW_BYTES: DRAM access-pattern probe (see stream_probe_kernel)
+    const int64_t rows = atoll(argv[2]), row_bytes = atoll(argv[3]);
+    uint8_t* w;
+    HIP_CHECK(hipMalloc(&w, rows * row_bytes));
+    HIP_CHECK(hipMemset(w, 1, rows * row_bytes));
+    uint32_t* out;
+    HIP_CHECK(hipMalloc(&out, 64));
+    const int blocks = (int)(rows / 128);
+    for (int pat = 0; pat < 3; ++pat)
+      for (int depth : {1, 2, 4}) {
+        auto run = [&] {
+#define GO(P, D) if (pat == P && depth == D) stream_probe_kernel<P, D><<<blocks, 256>>>(w, out, (int)row_bytes);
+          GO(0, 1) GO(0, 2) GO(0, 4) GO(1, 1) GO(1, 2) GO(1, 4) GO(2, 1) GO(2, 2) GO(2, 4)
+#undef GO
+        };
+        std::vector<float> all;
+        const double ms = time_ms(run, 5, 20, &all);
+        printf("stream rows=%lld row_bytes=%lld pattern=%d depth=%d: median %.1f us min %.1f -> %.0f GB/s\n", (long long)rows,
+               (long long)row_bytes, pat, depth, ms * 1e3, all[0] * 1e3, rows * row_bytes / ms / 1e6);
+      }
+    return 0;
+  }
+  if (!strcmp(argv[1], "w4a16")) {  // kbench w4a16 N K ROWS [probe:mt ...]: int4 group-128 grouped GEMM, 8 experts, uniform rows
+    const int64_t E = 8, N = atoll(argv[2]), K = atoll(argv[3]), rows = atoll(argv[4]), total = E * rows;
+    void* w = dev_random_bytes(E * N * K / 2, 1, false);
+    std::vector<uint16_t> hs(E * N * (K / 128), 0x3c00 >> 3);  // bf16 ~0.0078
+    for (auto& x : hs) x = 0x3c00;                               // bf16 2^-7
+    void *sc, *act, *out;
+    HIP_CHECK(hipMalloc(&sc, hs.size() * 2));
+    HIP_CHECK(hipMemcpy(sc, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
+    std::vector<uint16_t> ha(total * K);
+    std::mt19937 rng(5);
+    for (auto& x : ha) x = (uint16_t)(0x3c00 | (rng() & 0x80ff));  // bf16 +-(2^-7 .. 2^-6)
+    HIP_CHECK(hipMalloc(&act, ha.size() * 2));
+    HIP_CHECK(hipMemcpy(act, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&out, total * N * 2));
+    std::vector<int32_t> hr(E, (int32_t)rows);
+    int32_t* dr;
+    HIP_CHECK(hipMalloc(&dr, E * 4));
+    HIP_CHECK(hipMemcpy(dr, hr.data(), E * 4, hipMemcpyHostToDevice));
+    std::vector<std::pair<int, int>> vars;
+    for (int i = 5; i < argc; ++i) {
+      int pr = 0, mt = 0;
+      sscanf(argv[i], "%d:%d", &pr, &mt);
+      vars.push_back({pr, mt});
+    }
+    if (vars.empty()) vars.push_back({0, 0});
+    for (auto [pr, mt] : vars) {
+      sglk_debug_set_w4a16_probe(pr, mt);
+      auto run = [&] {
+        int rc = sglk_moe_grouped_mm_w4a16(0, out, act, w, sc, nullptr, nullptr, dr, total, E, N, K, 128, 1, SGLK_BF16);
+        if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
+      };
+      std::vector<float> all;
+      const double ms = time_ms(run, 30, 50, &all);
+      printf("w4a16 N=%lld K=%lld rows=%lld probe=%d mt=%d: median %.1f us min %.1f -> weights %.0f GB/s\n", (long long)N,
+             (long long)K, (long long)rows, pr, mt, ms * 1e3, all[0] * 1e3, E * N * K / 2 / ms / 1e6);
     }
     return 0;
   }
