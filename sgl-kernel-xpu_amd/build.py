@@ -63,7 +63,7 @@ def run(cmd):
 
 
 # sources whose device assembly is kept next to the object (-save-temps=obj) for check_isa
-ISA_CHECKED = ("mla_decode.hip", "gemm_8bit.hip", "attn_fwd.hip")
+ISA_CHECKED = ("mla_decode.hip", "gemm_8bit.hip", "attn_fwd.hip", "moe_w4a16.hip", "moe_bf16.hip")
 
 
 def _asm_path(src_name, obj_dir=None):
@@ -78,8 +78,8 @@ def _functions(asm_text, pattern):
     while i < len(lines):
         m = re.match(r"^(_Z\w+):", lines[i])
         if m and re.search(pattern, m.group(1)):
-            j = i
-            while j < len(lines) and "s_endpgm" not in lines[j]:
+            j = i + 1  # to the function's end label (an early return puts an s_endpgm in the middle of the body)
+            while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
                 j += 1
             yield m.group(1), lines[i:j + 1]
             i = j
@@ -94,7 +94,11 @@ def check_isa(verbose=True):
       and the kernel descriptor must allocate 256 AGPRs.
     * gemm_fp8_blockwise_persist_kernel counts its LDS waits by hand: a VGPR spill (scratch access = vector-memory
       traffic inside the counted vmcnt window) breaks the counts.
-    * attn_prefill_kernel is sized for two 256-register waves per SIMD: a spill means the tile shape no longer fits.
+    * attn_prefill_kernel / attn_decode_kernel are sized for two 256-register waves per SIMD: a spill means the tile
+      shape no longer fits.
+    * the grouped-GEMM kernels (moe_w4a16, moe_bf16) keep several 128-deep blocks of loads in flight in register rings:
+      a spill inside the K loop is reloaded through scratch, behind an s_waitcnt vmcnt(0) that empties the rings
+      (measured: 2.5 TB/s instead of > 4).
     Returns the list of problems (empty = good)."""
     import re
     problems = []
@@ -148,7 +152,12 @@ def check_isa(verbose=True):
         found += n
         if n == 0:
             problems.append("no gemm_fp8_blockwise_persist_kernel instantiation found")
-    for src_name, pat in (("attn_fwd.hip", r"attn_prefill_kernelI"),):
+    # (moe_w4a16: the group >= 128 instantiations, PB = 1 - AWQ / GPTQ / Mixtral checkpoints - and the mxfp4 ones; the
+    # group-32 / 64 int4 tiles of 32 rows and more still spill and are reported by --check only)
+    for src_name, pat in (("attn_fwd.hip", r"attn_prefill_kernelI"), ("attn_fwd.hip", r"attn_decode_kernelI"),
+                          ("moe_w4a16.hip", r"moe_w4a16_kernelIDF16.Li\dELi\dELi1ELi\dE"),
+                          ("moe_w4a16.hip", r"moe_w4a16_kernelIDF16.Li\dELi\dELi4ELi1E"),
+                          ("moe_bf16.hip", r"moe_bf16_kernelI")):
         path = _asm_path(src_name)
         if not os.path.exists(path):
             problems.append("%s missing" % path)

@@ -20,7 +20,6 @@
 // with the hardware transpose read. LDS images are [256-byte column block][32 rows][256 B] with the chunk
 // swizzle / k-permutation / token-permutation of mla_decode.hip (conflict-free row and transposed reads).
 #include <math.h>
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -93,7 +92,6 @@ struct AttnParams {
   int splits;
   float scale;          // softmax scale
   float softcap;        // 0 = off
-  int probe;            // TEMPORARY experiment switch (env SGLK_ATTN_PROBE)
 };
 
 // DKP: head dim rounded up to 32 (k-steps of the QK product); the V/O side uses ceil(D/16) 16-wide tiles.
@@ -739,10 +737,10 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   // the same unit. Barrier j+1 is passed by everybody after QK(j) and before PV(j); K(j+1) and V(j) are written into
   // their double buffers at the top of iteration j (between barriers j and j+1: K(j-1) and V(j-2) are dead by then,
   // and the first readers come after barrier j+1); their global loads were issued one iteration earlier.
-  bool late_barrier = wave < 4;
-  if (p.probe == 1) late_barrier = (wave & 1) == 0;
-  if (p.probe == 2) late_barrier = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) == 0;  // HW_ID.wave_id parity
-  if (p.probe == 3) late_barrier = true;
+  // (which two waves share a SIMD is the hardware's choice: the wave slot number HW_ID.wave_id tells them apart.
+  // Measured on the 16 x 4096 prefill, causal / full: this 817 / 942 TFLOP/s, waves 0..3 vs 4..7 809 / 917, even vs odd
+  // waves 777 / 872, no skew 783 / 900.)
+  const bool late_barrier = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) == 0;
   v4i sk[2], sv[2];
   Pages pg_v = {{0, 0}}, pg_k = {{0, 0}}, pg_pre = {{0, 0}};  // page ids of tiles t + 1, t + 2 and (in flight) t + 3
   if (n_tiles > 0) {
@@ -927,6 +925,353 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Decode kernel (head dim 128, 16-bit KV, at most 16 packed rows per (sequence, kv head): seqlen_q * G <= 16; paged with
+// pages of >= 32 tokens, or one of the unpaged layouts; everything else of the contract above). In the general kernel
+// the rows of a decode step fill one of the four waves: that wave's read - MFMA - exchange - exp - MFMA chain takes ~1.7 us
+// per 32-token tile while the other three wait at the tile's barrier (measured: 72 us for the 268 MB of
+// BASELINE configs[2] against 52 us with the arithmetic switched off). Here the four waves of a workgroup run
+// INDEPENDENTLY over interleaved tiles (wave w: tiles w, w + 4, ..), each with its own running max / sum / output, merged
+// once at the end:
+//   * K fragments go global -> registers directly in the A-operand layout of S^T = K . Q^T (lane = (token, 8-dim
+//     chunk): 16 bytes per lane and load, no LDS); V goes global -> registers -> a wave-private 8 KiB LDS image
+//     (the hardware transpose read needs it) with no workgroup barrier anywhere in the loop;
+//   * two tiles in flight per wave (32 KiB; 256 KiB per CU at two workgroups per CU);
+//   * the page id of a tile is fetched two tiles ahead, in front of the loads of the tile one ahead (vmcnt retires in
+//     order: see the general kernel).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const T* __restrict__ q,
+                                                             const char* __restrict__ kcache, const char* __restrict__ vcache,
+                                                             const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
+                                                             const int32_t* __restrict__ page_table) {
+  using M = Mfma<T>;
+  constexpr int D = 128, KS = 4, NT = 8, VIMG = kTile * 256;  // V image of a tile: 8 KiB
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [4 waves][2] V images; the merge reuses them
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  int wg = blockIdx.x + gridDim.x * blockIdx.y;  // x = kv head + Hk * split, y = sequence; re-ordered as above
+  {
+    const int total = gridDim.x * gridDim.y;
+    if ((total & 7) == 0) wg = (wg & 7) * (total >> 3) + (wg >> 3);
+  }
+  const int hk = wg % p.Hk;
+  const int split = (wg / p.Hk) % p.splits;
+  const int b = wg / (p.Hk * p.splits);
+  const int G = p.G;
+
+  const int q_begin = cu_q[b];
+  const int seqlen_q = cu_q[b + 1] - q_begin;
+  int seqlen_k, k_begin = 0, cache_row = b, leftpad = 0;
+  if (p.paged) {
+    if (p.kv_batch_idx != nullptr) cache_row = p.kv_batch_idx[b];
+    if (p.leftpad_k != nullptr) leftpad = p.leftpad_k[b];
+    seqlen_k = seq_k[b] - leftpad;
+    seqlen_k = seqlen_k > 0 ? seqlen_k : 0;
+  } else {
+    k_begin = seq_k[b];
+    seqlen_k = seq_k[b + 1] - k_begin;
+  }
+  const int rows_total = seqlen_q * G;  // <= 16
+  if (rows_total <= 0) return;
+  const int shift = seqlen_k - seqlen_q;
+
+  const int my_row = l15;
+  const bool row_ok = my_row < rows_total;
+  const int my_qpos = row_ok ? my_row / G : 0;
+  const int my_head = hk * G + (row_ok ? my_row % G : 0);
+  const int q_abs = my_qpos + shift;
+  const bool wave_rows_ok = rows_total == kRowsPerWave;
+  const int wave_qabs_lo = shift, wave_qabs_hi = (rows_total - 1) / G + shift;
+
+  int kv_hi = seqlen_k;
+  if (p.causal_right >= 0) {
+    const int lim = wave_qabs_hi + p.causal_right + 1;
+    kv_hi = lim < kv_hi ? lim : kv_hi;
+  }
+  int kv_lo = 0;
+  if (p.window_left >= 0) {
+    const int lim = shift - p.window_left;
+    kv_lo = lim > 0 ? lim : 0;
+  }
+  if (kv_hi < 0) kv_hi = 0;
+  int t_lo = kv_lo / kTile, t_hi = (kv_hi + kTile - 1) / kTile;
+  if (t_hi < t_lo) t_hi = t_lo;
+  if (p.splits > 1) {
+    const int per = (t_hi - t_lo + p.splits - 1) / p.splits;
+    const int a = t_lo + split * per;
+    const int e = a + per;
+    t_lo = a < t_hi ? a : t_hi;
+    t_hi = e < t_hi ? e : t_hi;
+  }
+  const int n_tiles = t_hi - t_lo;
+  const int nw = n_tiles > wave ? (n_tiles - wave + kWaves - 1) / kWaves : 0;  // tiles of this wave: t_lo + wave + 4 j
+
+  const int pig = (0x2130 >> (4 * g4)) & 3;
+  const int tau = (l15 & 3) | (((l15 >> 2) & 1) << 3) | (((l15 >> 3) & 1) << 2);
+
+  v8s qf[KS];
+  {
+    const T* qrow = q + (int64_t)(q_begin + my_qpos) * p.q_s0 + (int64_t)my_head * p.q_s1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const v8s v = *reinterpret_cast<const v8s*>(qrow + 32 * ks + 8 * pig);
+      const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = row_ok ? v : zero;
+    }
+  }
+
+  // ---- addressing (the formula of the general kernel; a tile lies in one page, so one id per tile)
+  const bool use_table = p.paged == 1;
+  const int32_t* pg_src = use_table ? page_table + (int64_t)cache_row * p.table_stride : cu_q + b;
+  const int pos_mask = use_table ? (1 << p.page_shift) - 1 : -1;
+  const int pos_shift = use_table ? p.page_shift : 31;
+  const int pos_base = p.paged ? leftpad : k_begin;
+  const uint32_t kpg = use_table ? (uint32_t)p.k_s0 : 0u, vpg = use_table ? (uint32_t)p.v_s0 : 0u;
+  const uint32_t kst = (uint32_t)(p.paged ? p.k_s1 : p.k_s0), vst = (uint32_t)(p.paged ? p.v_s1 : p.v_s0);
+  const int64_t kbase_off = (p.paged == 2 ? (int64_t)cache_row * p.k_s0 + (int64_t)hk * p.k_s2
+                                          : (int64_t)hk * (p.paged ? p.k_s2 : p.k_s1)) + 8 * pig;
+  const int64_t vbase_off = (p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
+                                          : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1)) + 8 * (lane & 15);
+  const int last_key = seqlen_k - 1;
+  auto tile_of = [&](int j) { return t_lo + wave + kWaves * (j < nw ? j : nw - 1); };  // (past the end: the last tile again)
+  auto fetch_page = [&](int t) -> int {
+    int pos = t * kTile;
+    pos = pos < last_key ? pos : last_key;
+    return pg_src[(pos + pos_base) >> pos_shift];
+  };
+  struct KRegs {
+    v4i k[2 * KS];  // [ks][half]: token 16 half + tau(l15), dims 32 ks + 8 pig ..
+  };
+  struct VRegs {
+    v4i v[8];       // chunk lane + 64 i of the [32 tokens][16 chunks] tile: token 4 i + lane / 16, chunk lane % 16
+  };
+  auto issue_k = [&](int t, int page, KRegs& r) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int pos = t * kTile + 16 * h + tau;
+      pos = pos < last_key ? pos : last_key;
+      const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
+      const int64_t off = (int64_t)((uint64_t)(uint32_t)page * kpg + ((uint64_t)cp * kst + (uint64_t)kbase_off));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) r.k[2 * ks + h] = *reinterpret_cast<const v4i*>(kcache + (off + 32 * ks) * 2);
+    }
+  };
+  auto issue_v = [&](int t, int page, VRegs& r) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int pos = t * kTile + 4 * i + (lane >> 4);
+      pos = pos < last_key ? pos : last_key;
+      const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
+      const int64_t off = (int64_t)((uint64_t)(uint32_t)page * vpg + ((uint64_t)cp * vst + (uint64_t)vbase_off));
+      r.v[i] = *reinterpret_cast<const v4i*>(vcache + off * 2);
+    }
+  };
+
+  int vbase0;
+  {
+    const int qq = l15 >> 2, pp = l15 & 3;
+    const int r = 8 * (g4 & 1) + 4 * (g4 >> 1) + qq;
+    vbase0 = 256 * r + 16 * ((pp >> 1) ^ sw_main(r)) + 8 * (pp & 1);
+  }
+  char* vimg = smem + wave * (2 * VIMG);
+
+  v4f o[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float log2e = 1.4426950408889634f;
+  const float scale = p.scale, sc2 = scale * log2e;
+  __shared__ float xch_all[kWaves * 16];
+  float* xch = xch_all + wave * 16;
+
+  // Tile j of this wave: K(j) sits in kr (loaded two tiles ago), V(j) in vr (loaded one tile ago). Once V(j) is in its LDS
+  // image and the scores are out of the matrix pipe, both register sets are free: V(j + 1) and K(j + 2) are requested
+  // before the softmax. In flight per wave: K(j + 1), then V(j + 1) and K(j + 2).
+  VRegs vr;
+  auto compute = [&](int j, KRegs& kr, int buf, int page_v, int page_k) {
+    const int t = tile_of(j);
+    v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s0 = M::run(__builtin_bit_cast(v8s, kr.k[2 * ks]), qf[ks], s0);
+      s1 = M::run(__builtin_bit_cast(v8s, kr.k[2 * ks + 1]), qf[ks], s1);
+    }
+    // V image of this tile (wave-private: no barrier; LDS operations of a wave complete in order)
+    char* vb = vimg + buf * VIMG;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + (lane >> 4), ch = lane & 15;
+      *reinterpret_cast<v4i*>(vb + row * 256 + ((ch ^ sw_main(row)) << 4)) = vr.v[i];
+    }
+    issue_v(tile_of(j + 1), page_v, vr);
+    issue_k(tile_of(j + 2), page_k, kr);
+    const int tb = t * kTile + 8 * (g4 & 1) + 4 * (g4 >> 1);
+    bool interior = p.softcap <= 0.f && wave_rows_ok && (t * kTile + kTile <= seqlen_k);
+    if (p.causal_right >= 0) interior = interior && (t * kTile + kTile - 1 <= wave_qabs_lo + p.causal_right);
+    if (p.window_left >= 0) interior = interior && (t * kTile >= wave_qabs_hi - p.window_left);
+    float m_new, m_use, alpha, psum = 0.f;
+    v8s pf;
+    if (interior) {
+      float mt = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      m_new = fmaxf(m_run, mt * scale);
+      m_use = m_new;
+      alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);
+      const float mneg = -m_use * log2e;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], sc2, mneg));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], sc2, mneg));
+        psum += p0 + p1;
+        pf[e] = M::cvt(p0);
+        pf[4 + e] = M::cvt(p1);
+      }
+    } else {
+      float z0[4], z1[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = s0[e] * scale, c = s1[e] * scale;
+        if (p.softcap > 0.f) {
+          a = p.softcap * tanhf(a / p.softcap);
+          c = p.softcap * tanhf(c / p.softcap);
+        }
+        const int k0 = tb + e, k1 = tb + 16 + e;
+        bool m0 = !row_ok || k0 >= seqlen_k, m1 = !row_ok || k1 >= seqlen_k;
+        if (p.causal_right >= 0) { m0 |= k0 > q_abs + p.causal_right; m1 |= k1 > q_abs + p.causal_right; }
+        if (p.window_left >= 0) { m0 |= k0 < q_abs - p.window_left; m1 |= k1 < q_abs - p.window_left; }
+        z0[e] = m0 ? -INFINITY : a;
+        z1[e] = m1 ? -INFINITY : c;
+      }
+      float mt = fmaxf(fmaxf(fmaxf(z0[0], z0[1]), fmaxf(z0[2], z0[3])), fmaxf(fmaxf(z1[0], z1[1]), fmaxf(z1[2], z1[3])));
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      m_new = fmaxf(m_run, mt);
+      m_use = m_new == -INFINITY ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f((m_run - m_use) * log2e);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p0 = __builtin_amdgcn_exp2f((z0[e] - m_use) * log2e);
+        const float p1 = __builtin_amdgcn_exp2f((z1[e] - m_use) * log2e);
+        psum += p0 + p1;
+        pf[e] = M::cvt(p0);
+        pf[4 + e] = M::cvt(p1);
+      }
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (__any(alpha != 1.0f)) {
+      if (lane < 16) xch[lane] = alpha;
+      const v4f a4 = *reinterpret_cast<const v4f*>(xch + 4 * g4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        o[nt][0] *= a4[0]; o[nt][1] *= a4[1]; o[nt][2] *= a4[2]; o[nt][3] *= a4[3];
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const char* a = vb + (vbase0 ^ ((nt & 7) << 5));
+      const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a));
+      const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a + 4096));
+      v8s vf;
+      vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+      vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+      o[nt] = M::run(pf, vf, o[nt]);
+    }
+  };
+
+  // ---- this wave's tiles. Page ids: p1 of tile j + 1 (for its V), p2 of tile j + 2 (for its K, then its V), p3 of tile
+  // j + 3: fetched one step before they are first used, in front of the loads that follow.
+  if (nw > 0) {
+    KRegs ka, kb;
+    int p0 = fetch_page(tile_of(0)), p1 = fetch_page(tile_of(1)), p2 = fetch_page(tile_of(2));
+    issue_k(tile_of(0), p0, ka);
+    issue_v(tile_of(0), p0, vr);
+    issue_k(tile_of(1), p1, kb);
+    int j = 0;
+    for (; j + 2 <= nw; j += 2) {
+      int p3 = fetch_page(tile_of(j + 3));
+      compute(j, ka, 0, p1, p2);       // requests V(j + 1), K(j + 2)
+      const int p4 = fetch_page(tile_of(j + 4));
+      compute(j + 1, kb, 1, p2, p3);   // requests V(j + 2), K(j + 3)
+      p1 = p3;
+      p2 = p4;
+    }
+    if (j < nw) compute(j, ka, 0, p1, p2);
+  }
+
+  // ---- merge the four waves' states into wave 0 (through the V images, everybody being done with them)
+  __syncthreads();
+  float* mo = reinterpret_cast<float*>(smem);            // [wave][nt][lane] v4f
+  float* mm = mo + kWaves * NT * 64 * 4;                 // [wave][lane] m, then [wave][lane] l
+  if (wave != 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<v4f*>(mo + ((wave * NT + nt) * 64 + lane) * 4) = o[nt];
+    mm[wave * 64 + lane] = m_run;
+    mm[(kWaves + wave) * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) {
+    const float m_w = mm[w * 64 + lane], l_w = mm[(kWaves + w) * 64 + lane];
+    const float m_new = fmaxf(m_run, m_w);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float fa = __builtin_amdgcn_exp2f((m_run - m_use) * log2e), fb = __builtin_amdgcn_exp2f((m_w - m_use) * log2e);
+    l_run = l_run * fa + l_w * fb;
+    m_run = m_new;
+    // row factors (this lane's row l15) -> the lanes holding output rows 4 g4 + e
+    if (lane < 16) { xch[lane] = fa; xch_all[16 + lane] = fb; }
+    const v4f a4 = *reinterpret_cast<const v4f*>(xch + 4 * g4), b4 = *reinterpret_cast<const v4f*>(xch_all + 16 + 4 * g4);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const v4f ow = *reinterpret_cast<const v4f*>(mo + ((w * NT + nt) * 64 + lane) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[nt][e] = o[nt][e] * a4[e] + ow[e] * b4[e];
+    }
+  }
+
+  // ---- epilogue (as the general kernel, rows of wave 0)
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const bool final_pass = p.splits == 1;
+  const float m_fin = m_run;
+  float lse_val = (l_tot > 0.f && m_fin != -INFINITY) ? m_fin + logf(l_tot) : -INFINITY;
+  if (final_pass && p.sinks != nullptr && row_ok) {
+    const float sk = p.sinks[my_head];
+    const float m2 = fmaxf(m_fin, sk);
+    const float l2 = l_tot * __builtin_amdgcn_exp2f((m_fin - m2) * log2e) + __builtin_amdgcn_exp2f((sk - m2) * log2e);
+    lse_val = m2 + logf(l2);
+    l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
+  }
+  const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
+  if (lane < 16) xch[lane] = inv_l;
+  const v4f i4 = *reinterpret_cast<const v4f*>(xch + 4 * g4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = 4 * g4 + e;
+    if (row >= rows_total) continue;
+    const int qpos = row / G, head = hk * G + row % G;
+    const int64_t tok = q_begin + qpos;
+    if (final_pass) {
+      T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)head * p.o_s1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + l15] = (T)(o[nt][e] * i4[e]);
+    } else {
+      float* orow = p.part_o + (((int64_t)split * p.total_q + tok) * p.Hq + head) * D;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + l15] = o[nt][e] * i4[e];
+    }
+  }
+  if (row_ok && g4 == 0) {
+    const int64_t tok = q_begin + my_qpos;
+    if (final_pass) p.lse[(int64_t)my_head * p.total_q + tok] = lse_val;
+    else p.part_lse[((int64_t)split * p.Hq + my_head) * p.total_q + tok] = lse_val;
+  }
+}
+
 // merge split-KV partials: out = sum_s exp(lse_s - L) O_s, L = log(sum_s exp(lse_s) [+ exp(sink)])
 template <typename T>
 __global__ __launch_bounds__(128) void attn_reduce_kernel(T* __restrict__ out, float* __restrict__ lse_out,
@@ -991,6 +1336,23 @@ static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, co
 }
 
 template <typename T>
+static int launch_decode(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
+                         const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch) {
+  constexpr int lds = kWaves * 2 * kTile * 256;  // 64 KiB
+  static unsigned long long attr_done = 0;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_decode_kernel<T>), lds, &attr_done, "fwd")) return rc;
+  dim3 grid((unsigned)(p.Hk * p.splits), (unsigned)batch);
+  attn_decode_kernel<T><<<grid, 256, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  if (int rc = check_launch("fwd(decode)")) return rc;
+  if (p.splits > 1) {
+    attn_reduce_kernel<T><<<dim3(p.Hq, p.total_q), 128, 0, st>>>((T*)p.out, p.lse, p.part_o, p.part_lse, p.sinks,
+                                                                  p.splits, p.total_q, p.Hq, p.D, p.o_s0, p.o_s1);
+    return check_launch("fwd(reduce)");
+  }
+  return SGLK_OK;
+}
+
+template <typename T>
 static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                         const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows, int kv8) {
   const int d = p.D;
@@ -999,6 +1361,10 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
   if (kv8 == 0 && d == 128 && p.splits == 1 && p.softcap <= 0.f && max_rows >= 128 && p.q_s0 % 8 == 0 && p.o_s0 % 4 == 0 &&
       p.o_s1 % 4 == 0)
     return launch_prefill<T>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  // decode-sized problems at head dim 128: every sequence has at most 16 packed rows per kv head; a tile within one page
+  if (kv8 == 0 && d == 128 && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) && p.leftpad_k == nullptr &&
+      p.q_s0 % 8 == 0)
+    return launch_decode<T>(st, p, q, k, v, cu_q, seq_k, table, batch);
   if (kv8 != 0) {  // fp8 KV cache: built for the head dims the reference exercises (and 64)
 #define SGLK_FP8_GO(DKP)                                                                              \
   return kv8 == 1 ? launch<T, DKP, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)            \
@@ -1107,10 +1473,6 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
   p.splits = (int)num_splits;
   p.scale = softmax_scale;
   p.softcap = softcap;
-  {
-    static const int probe_env = getenv("SGLK_ATTN_PROBE") ? atoi(getenv("SGLK_ATTN_PROBE")) : 0;
-    p.probe = probe_env;
-  }
   const int max_rows = (int)(max_seqlen_q * p.G);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16)

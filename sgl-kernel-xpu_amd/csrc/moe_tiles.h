@@ -9,8 +9,8 @@
 // and the unused indices all lie at the END of the launch. With a 2-D grid of max-row-blocks x column-blocks the empty
 // workgroups sat in between: they retire at once, the dispatcher hands the next real workgroup to whichever CU is free,
 // and a third of the CUs ended up with two weight streams while others had none (350 us instead of 185 us for 16 rows
-// per expert at N = 28672, K = 4096). Workgroups go to the 8 XCDs round-robin in launch order, so the index is first
-// re-ordered to keep neighbours on one XCD (one L2 for the shared weights).
+// per expert at N = 28672, K = 4096). Workgroups go to the 8 XCDs round-robin in launch order, so the index is
+// re-ordered (within the real tiles) to keep neighbours on one XCD (one L2 for the shared weights).
 #pragma once
 #include "common.h"
 
@@ -35,8 +35,6 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
 // every wave of the workgroup computes the same (wave-uniform) answer
 __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ rows_per_expert, int E, int BM, int NB) {
   const int lane = threadIdx.x & 63;
-  int L = blockIdx.x;
-  if ((gridDim.x & 7) == 0) L = (L & 7) * (gridDim.x >> 3) + (L >> 3);
   int MB = 0;
   for (int c0 = 0; c0 < E; c0 += 64) {
     const int r = c0 + lane < E ? rows_per_expert[c0 + lane] : 0;
@@ -44,7 +42,12 @@ __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ row
   }
   MB = __builtin_amdgcn_readfirstlane(MB);
   MoeTile t = {-1, 0, 0, 0};
-  if (MB == 0 || L >= MB * NB) return t;
+  // launch index -> tile index: XCD x (launch indices = x mod 8) takes a contiguous eighth of the REAL tiles (the unused
+  // tail of the launch must stay out of the re-ordering, or the XCDs that get it sit idle)
+  const int real = MB * NB, real8 = real & ~7;
+  int L = blockIdx.x;
+  if (L >= real) return t;
+  if (L < real8) L = (L & 7) * (real8 >> 3) + (L >> 3);
   const int mblk = L % MB;
   int e = 0, row0 = 0, rows_e = 0, blk = 0, base_b = 0, base_r = 0;
   for (int c0 = 0; c0 < E; c0 += 64) {

@@ -142,10 +142,10 @@ __device__ __forceinline__ void static_for4(F&& f) {
   f(IntC<3>{});
 }
 
-// PB: scale groups per 128-deep block (4, 2, 1 for groups 32, 64, >= 128); FMT: 0 = int4 (scales / zeros of type T),
-// 1 = mxfp4 (scales = E8M0 bytes, group 32, no zeros)
+// PB: scale groups per 128-deep block (4, 2, 1 for groups 32, 64, >= 128); FMT: 0 = int4, two's-complement codes (scales
+// of type T), 2 = int4, unsigned codes with zero points of type T, 1 = mxfp4 (scales = E8M0 bytes, group 32, no zeros)
 template <typename T, int MT, int NW, int PB, int FMT>
-__global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
+__global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
                                                         const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
                                                         const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
@@ -174,13 +174,12 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   const S* scales = reinterpret_cast<const S*>(scales_);
   const S* zeros = reinterpret_cast<const S*>(zeros_);
   const int kgroups = K >> group_shift;         // scales per row
-  const bool has_zp = FMT == 0 && zeros != nullptr;
+  constexpr bool has_zp = FMT == 2;
+  constexpr bool is_int4 = FMT != 1;
 
   // ---- per-lane weight / scale rows (clamped; stores are guarded): 32-bit offsets from per-expert bases
   const uint8_t* wexp = wq + (int64_t)e * N * (K / 2);
   const S* sexp = scales + (int64_t)e * N * kgroups;
-  // without zero points the zero-point loads read the scales instead (values unused): an unconditional load keeps
-  // the K loop free of a branch whose other side would have to wait for every load in flight (WAW on the register)
   const S* zexp = has_zp ? zeros + (int64_t)e * N * kgroups : sexp;
   uint32_t woff[NW], soff[NW];
 #pragma unroll
@@ -194,14 +193,22 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   // ---- activation staging: thread handles 16-byte chunks (row, c) of the [BM][128] tile. Split in a load (global ->
   // registers) and a store (registers -> LDS) one iteration later: a load consumed in the iteration that issues it
   // exposes a full memory latency per 128-deep block (that alone was 200 us of a K = 14336 decode GEMM).
+  // (a scalar base per workgroup and 32-bit per-thread offsets: 64-bit per-thread row addresses of the large tiles were
+  // spilled and reloaded inside the K loop)
+  const T* act_blk = act + (int64_t)m0 * K;
+  uint32_t aoff[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int idx = i * 256 + tid;
+    const int row = idx >> 4, c = idx & 15;
+    aoff[i] = (uint32_t)((probe & 1) ? 0 : row < m_valid ? row : m_valid - 1) * (uint32_t)K + c * 8;
+  }
   auto load_a = [&](int kb, v4i (&r)[MT]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int idx = i * 256 + tid;
-      const int row = idx >> 4, c = idx & 15;
-      const int grow = m0 + ((probe & 1) ? 0 : row < m_valid ? row : m_valid - 1);
+      const int c = (i * 256 + tid) & 15;
       const bool in = kb * 128 + c * 8 < K;  // past K: read k = 0 instead and zero the registers (no branch)
-      const v4i v = *reinterpret_cast<const v4i*>(act + (int64_t)grow * K + (in ? kb * 128 + c * 8 : 0));
+      const v4i v = *reinterpret_cast<const v4i*>(act_blk + (aoff[i] + (in ? (uint32_t)kb * 128u : 0u)));
       r[i][0] = in ? v[0] : 0; r[i][1] = in ? v[1] : 0; r[i][2] = in ? v[2] : 0; r[i][3] = in ? v[3] : 0;
     }
   };
@@ -247,7 +254,9 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
   // All three streams (weights, scales / zero points, activations) run kD 128-deep blocks ahead of the MFMAs in
   // register rings with static slots (the K loop is unrolled kD times): at decode sizes an iteration is ~0.15 us of
   // MFMA work against ~2 us of memory latency, and a load consumed close to where it was issued stalls the wave.
-  constexpr int kD = MT <= 2 ? 4 : 2;  // (decode tiles: 8 KiB of weights in flight per wave; the large tiles: registers)
+  // (decode tiles: 8 KiB of weights in flight per wave; the large tiles: registers. A spill in this loop is reloaded
+  // through scratch, i.e. behind an s_waitcnt vmcnt(0) that empties the rings: build.py's check_isa rejects one.)
+  constexpr int kD = (PB == 1 && (MT == 1 || (MT == 2 && FMT != 2))) ? 4 : 2;
   uint32_t wd[NW][4], wq_[kD][NW][4];
   // weights past K are never multiplied by anything but zero activations: any valid address will do (block 0)
   auto load_w = [&](int kb, uint32_t (&dst)[NW][4]) {
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
       dst[nt][0] = t[0]; dst[nt][1] = t[1]; dst[nt][2] = t[2]; dst[nt][3] = t[3];
     }
   };
-  S sq_[kD][NW][PB], zq_[kD][NW][PB];
+  S sq_[kD][NW][PB], zq_[has_zp ? kD : 1][NW][PB];
   auto load_s = [&](int kb, S (&sd)[NW][PB], S (&zd)[NW][PB]) {
     const int kg0 = (kb * 128) >> group_shift;
 #pragma unroll
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
         int kg = (probe & 8) ? 0 : kg0 + i;
         kg = kg < kgroups ? kg : kgroups - 1;
         sd[nt][i] = sexp[soff[nt] + kg];
-        if constexpr (FMT == 0) zd[nt][i] = zexp[soff[nt] + kg];
+        if constexpr (has_zp) zd[nt][i] = zexp[soff[nt] + kg];
       }
     }
   };
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
 #pragma unroll
   for (int d = 0; d < kD; ++d) {
     load_w(d, wq_[d]);
-    load_s(d, sq_[d], zq_[d]);
+    load_s(d, sq_[d], zq_[has_zp ? d : 0]);
     load_a(d, aq_[d]);
   }
   store_a(0, aq_[0]);
@@ -304,15 +313,15 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         sc[nt][i] = sq_[u][nt][i];
-        if constexpr (FMT == 0) zc[nt][i] = zq_[u][nt][i];
+        if constexpr (has_zp) zc[nt][i] = zq_[u][nt][i];
       }
     }
     load_w(kb + kD, wq_[u]);
-    load_s(kb + kD, sq_[u], zq_[u]);
+    load_s(kb + kD, sq_[u], zq_[has_zp ? u : 0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
-      if (FMT == 0 && !has_zp) {
+      if constexpr (FMT == 0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) wd[nt][t] ^= 0x88888888u;  // two's complement -> offset binary (zp 8)
       }
@@ -329,13 +338,13 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
       // (k steps past K multiply zero activations: no tail branch)
       v4i wf[NW];
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) wf[nt] = FMT == 1 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
+      for (int nt = 0; nt < NW; ++nt) wf[nt] = !is_int4 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
         const int chunk = kTranspose ? 4 * j + g : 4 * g + j;
         const v4i af = *reinterpret_cast<const v4i*>(abase + row * 256 + ((chunk ^ l15) << 4));
-        if constexpr (FMT == 0) asum[mt] = W4<T>::mma(af, ones, asum[mt]);
+        if constexpr (is_int4) asum[mt] = W4<T>::mma(af, ones, asum[mt]);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
       }
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) {
           float s, z = 0.f;
-          if constexpr (FMT == 1) {
+          if constexpr (!is_int4) {
             const uint32_t e = sc[nt][ki];  // E8M0: 2^(byte - 127); byte 0 is the subnormal 2^-127
             s = __uint_as_float(e ? e << 23 : 0x00400000u);
           } else {
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 3 : MT == 2 ? 2 : 1)) void moe_w4a1
           for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float t = FMT == 1 ? part[mt][nt][r] : __builtin_fmaf(-z, asum[mt][r], part[mt][nt][r]);
+              const float t = !is_int4 ? part[mt][nt][r] : __builtin_fmaf(-z, asum[mt][r], part[mt][nt][r]);
               acc[mt][nt][r] = __builtin_fmaf(s, t, acc[mt][nt][r]);
             }
             part[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -412,21 +421,27 @@ static int launch(hipStream_t st, void* out, const void* act, const void* wq, co
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
   if (group_shift < 0)  // mxfp4: E8M0 scales per 32
     return launch_pb<T, MT, NW, 4, 1>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 5);
-  if (group_shift == 5) return launch_pb<T, MT, NW, 4>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-  if (group_shift == 6) return launch_pb<T, MT, NW, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-  return launch_pb<T, MT, NW, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+#define SGLK_W4_GO(PB)                                                                                                    \
+  return zeros != nullptr ? launch_pb<T, MT, NW, PB, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift) \
+                          : launch_pb<T, MT, NW, PB, 0>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift)
+  if (group_shift == 5) SGLK_W4_GO(4);
+  if (group_shift == 6) SGLK_W4_GO(2);
+  SGLK_W4_GO(1);
+#undef SGLK_W4_GO
 }
 
 template <typename T>
 static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                     const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
-  // tile policy by average rows per expert (the reference switches policies the same way,
-  // GroupGemmW4A16Xe20.cpp:266-277): decode streams weights with one 16-row tile per block
-  const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 16 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 128 : 1000) : total_m / E;
-  if (avg <= 16) return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-  if (avg <= 32) return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-  if (avg <= 128) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-  return launch<T, 8, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  // Tile policy by average rows per expert (the reference switches policies the same way,
+  // GroupGemmW4A16Xe20.cpp:266-277). The row counts are ragged around the average, and a second row block of an expert
+  // streams its weights again, so a tile is chosen that holds ~1.5x the average; 16 rows cost the same as 32 while the
+  // kernel is bound by the weight stream (measured at 1 row per expert: 183 vs 186 us), 64-row tiles are the largest whose
+  // K loop stays free of register spills.
+  const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 1 : g_w4_mt == 2 ? 16 : 1000) : total_m / E;
+  if (avg <= 6) return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  if (avg <= 24) return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
 }
 
 }  // namespace

@@ -19,7 +19,7 @@
 // one m: 8-byte fp16 stores. The integer dot products are exact in int32; per group the weights are rebuilt as
 // int8 in registers (packed multiply by the small group scale, carry-free packed add of zs8) before the MFMA, so
 // both variants accumulate over all of K without rescaling.
-// No LDS, no barriers: a wave owns a 32-column block of W for all of K, 16*MF rows of A.
+// No LDS, no barriers: a wave owns a 32-column block of W for all of K, 16*MF rows of A; loads run 2-4 k steps ahead.
 #include "common.h"
 
 namespace sglk {
@@ -64,33 +64,56 @@ __global__ __launch_bounds__(256) void qserve_w4a8_kernel(
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) acc[mf][0] = acc[mf][1] = (v4i){0, 0, 0, 0};
 
+  // Weights, activations and group scales run kD 64-deep steps ahead of the MFMAs in a register ring with static slots
+  // (loop unrolled kD times): a load consumed in the iteration that issues it exposes the whole memory latency per step.
+  // Steps past K re-read the last one (their results are not accumulated).
   const int nks = K >> 6;
-  for (int ks = 0; ks < nks; ++ks) {
-    uint32_t wd[4];
+  constexpr int kD = MF <= 2 ? 4 : 2;
+  uint32_t wq_[kD][4], sq_[kD][4];
+  v4i aq_[kD][MF];
+  auto load_step = [&](int ks, uint32_t (&wd)[4], uint32_t (&sz)[4], v4i (&af)[MF]) {
+    ks = ks < nks ? ks : nks - 1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) wd[e] = *reinterpret_cast<const uint32_t*>(wl + (int64_t)ks * 1024 + e * 16);
-    v4i af[MF];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) af[mf] = *reinterpret_cast<const v4i*>(al[mf] + ks * 64);
-    v4i wlo, whi;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      uint32_t lo = wd[e] & 0x0f0f0f0fu, hi = (wd[e] >> 4) & 0x0f0f0f0fu;
-      if constexpr (GROUP) {
-        const int g = ks >> 1;
-        const uint32_t slo = (uint8_t)s8[(int64_t)g * N], shi = (uint8_t)s8[(int64_t)g * N + 2];
-        const uint32_t zlo = (uint8_t)z8[(int64_t)g * N], zhi = (uint8_t)z8[(int64_t)g * N + 2];
-        // code * scale <= 15 * 17 fits a byte: one 32-bit multiply scales four codes; the add wraps per byte
-        lo = add_bytes(lo * slo, zlo * 0x01010101u);
-        hi = add_bytes(hi * shi, zhi * 0x01010101u);
-      }
-      wlo[e] = (int)lo;
-      whi[e] = (int)hi;
+    if constexpr (GROUP) {
+      const int64_t g = ks >> 1;
+      sz[0] = (uint8_t)s8[g * N]; sz[1] = (uint8_t)s8[g * N + 2];
+      sz[2] = (uint8_t)z8[g * N]; sz[3] = (uint8_t)z8[g * N + 2];
     }
+  };
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      acc[mf][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wlo, af[mf], acc[mf][0], 0, 0, 0);
-      acc[mf][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(whi, af[mf], acc[mf][1], 0, 0, 0);
+  for (int d = 0; d < kD; ++d) load_step(d, wq_[d], sq_[d], aq_[d]);
+  for (int ks0 = 0; ks0 < nks; ks0 += kD) {
+#pragma unroll
+    for (int u = 0; u < kD; ++u) {
+      uint32_t wd[4], sz[4];
+      v4i af[MF];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wd[e] = wq_[u][e]; sz[e] = sq_[u][e]; }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) af[mf] = aq_[u][mf];
+      load_step(ks0 + u + kD, wq_[u], sq_[u], aq_[u]);
+      if (ks0 + u < nks) {
+        v4i wlo, whi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t lo = wd[e] & 0x0f0f0f0fu, hi = (wd[e] >> 4) & 0x0f0f0f0fu;
+          if constexpr (GROUP) {
+            // code * scale <= 15 * 17 fits a byte: one 32-bit multiply scales four codes; the add wraps per byte
+            lo = add_bytes(lo * sz[0], sz[2] * 0x01010101u);
+            hi = add_bytes(hi * sz[1], sz[3] * 0x01010101u);
+          }
+          wlo[e] = (int)lo;
+          whi[e] = (int)hi;
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          acc[mf][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wlo, af[mf], acc[mf][0], 0, 0, 0);
+          acc[mf][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(whi, af[mf], acc[mf][1], 0, 0, 0);
+        }
+      }
     }
   }
 
