@@ -82,24 +82,33 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
     woff[nt] = (uint32_t)n * (uint32_t)ldb + 8 * g;
   }
 
+  // (a scalar base per workgroup and 32-bit per-thread offsets; the zeroing of chunks past K happens on the way to LDS and
+  // not behind the load: a select right after a load waits for it on the spot, with every younger load in flight)
+  const T* act_blk = act + (int64_t)m0 * K;
+  uint32_t aoff[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int idx = i * 256 + tid;
+    const int row = idx >> 4, c = idx & 15;
+    aoff[i] = (uint32_t)(row < m_valid ? row : m_valid - 1) * (uint32_t)K + c * 8;
+  }
   auto load_a = [&](int kb, v4i (&r)[MT]) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int idx = i * 256 + tid;
-      const int row = idx >> 4, c = idx & 15;
-      const int grow = m0 + (row < m_valid ? row : m_valid - 1);
-      const bool in = kb * 128 + c * 8 < K;  // past K: read k = 0 instead and zero the registers (no branch)
-      const v4i v = *reinterpret_cast<const v4i*>(act + (int64_t)grow * K + (in ? kb * 128 + c * 8 : 0));
-      r[i][0] = in ? v[0] : 0; r[i][1] = in ? v[1] : 0; r[i][2] = in ? v[2] : 0; r[i][3] = in ? v[3] : 0;
+      const int c = (i * 256 + tid) & 15;
+      const bool in = kb * 128 + c * 8 < K;  // past K: read k = 0 instead (zeroed in store_a; no branch)
+      r[i] = *reinterpret_cast<const v4i*>(act_blk + (aoff[i] + (in ? (uint32_t)kb * 128u : 0u)));
     }
   };
-  auto store_a = [&](int buf, const v4i (&r)[MT]) {
+  auto store_a = [&](int buf, int kb, const v4i (&r)[MT]) {
     char* base = smem + buf * (BM * 256);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int idx = i * 256 + tid;
       const int row = idx >> 4, c = idx & 15;
-      *reinterpret_cast<v4i*>(base + row * 256 + ((c ^ (row & 15)) << 4)) = r[i];
+      const bool in = kb * 128 + c * 8 < K;
+      const v4i zero = {0, 0, 0, 0};
+      *reinterpret_cast<v4i*>(base + row * 256 + ((c ^ (row & 15)) << 4)) = in ? r[i] : zero;
     }
   };
   // weights of k step j of block kb: 16 bytes at k = 128 kb + 32 j + 8 g (past K: any valid address, the
@@ -122,12 +131,18 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
 
   const int nkb = (K + 127) >> 7;
   v4i wq_[2][NW][4], aq_[2][MT];
-  load_w(0, wq_[0]);
-  load_w(1, wq_[1]);
+  // (activation requests in front of the weight ring's, as in the steady state: the waits the compiler counts for the loop
+  // are the worse of the two ways into it)
+  // (and fenced: the scheduler otherwise interleaves the two slots' requests, slot 0 then looks as young as slot 1)
   load_a(0, aq_[0]);
   load_a(1, aq_[1]);
-  store_a(0, aq_[0]);
+  store_a(0, 0, aq_[0]);
   load_a(2, aq_[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w(0, wq_[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w(1, wq_[1]);
+  __builtin_amdgcn_sched_barrier(0);
 
   for (int kb0 = 0; kb0 < nkb; kb0 += 2) {
 #pragma unroll
@@ -136,14 +151,8 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
       const int buf = kb & 1;
       // (not __syncthreads(): that would wait vmcnt(0) and drain the prefetch rings every block)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      store_a(buf ^ 1, aq_[(u + 1) & 1]);
+      store_a(buf ^ 1, kb + 1, aq_[(u + 1) & 1]);
       load_a(kb + 3, aq_[(u + 1) & 1]);
-      v4i wd[NW][4];
-#pragma unroll
-      for (int nt = 0; nt < NW; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wd[nt][j] = wq_[u][nt][j];
-      load_w(kb + 2, wq_[u]);
       const char* abase = smem + buf * (BM * 256);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -152,9 +161,13 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
           const int row = mt * 16 + l15;
           const v4i af = *reinterpret_cast<const v4i*>(abase + row * 256 + (((4 * j + g) ^ l15) << 4));
 #pragma unroll
-          for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = mma16<T>(af, wd[nt][j], acc[mt][nt]);
+          for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = mma16<T>(af, wq_[u][nt][j], acc[mt][nt]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      // refill slot u AFTER its last use: requested earlier, the new block has to live in other registers and the loop end
+      // moves the ring back into place with copies, each of which waits for the load into its source (the whole ring)
+      load_w(kb + 2, wq_[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }

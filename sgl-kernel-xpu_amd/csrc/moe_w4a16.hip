@@ -44,6 +44,7 @@ namespace sglk {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef short v8s __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
@@ -152,13 +153,26 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
                                                         int K, int group_shift, int probe) {
   // probe (libsglk_probes.so only; 0 in the release library): timing experiments with garbage results -
   // 1: one activation row for all 16 m rows, 2: no output stores, 4: non-temporal weight loads, 8: scales read once,
-  // 16: no weight expansion / MFMAs (stream only)
+  // 16: no weight expansion / MFMAs (stream only), 32: no barrier, 64: no activation staging
 #ifndef SGLK_PROBES
   probe = 0;
 #endif
   constexpr int BM = 16 * MT;
   constexpr int BN = 64 * NW;
-  __shared__ __attribute__((aligned(256))) char smem[2 * BM * 256];
+  // kD: 128-deep blocks of weights / scales in flight per wave (register ring, the K loop is unrolled kD times).
+  // (decode tiles: 8 KiB of weights in flight per wave; the large tiles: registers. A spill in this loop is reloaded
+  // through scratch, i.e. behind an s_waitcnt vmcnt(0) that empties the rings: build.py's check_isa rejects one.)
+  constexpr int kD = (PB == 1 && (MT == 1 || (MT == 2 && FMT != 2))) ? 4 : 2;
+  // AS: 128-deep blocks per activation stage. The decode tiles stage 512 / 256 k at a time: one workgroup barrier per
+  // four / two blocks instead of one per block (with one workgroup per CU - the Mixtral down projection at decode - barrier and
+  // staging cost 40 of 96 us).
+  constexpr int AS = kD >= 4 ? (MT == 1 ? 4 : 2) : 1;  // (32-row tiles: 256 k per stage, four more would spill)
+  constexpr int AROW = 256 * AS;  // bytes of a staged activation row
+  // SV: the scales (zero points) of the kD = 4 blocks of one trip of the K loop are ONE 8-byte load per row, requested a
+  // trip ahead (groups of 128, K a multiple of 512: the host sends other shapes to the 64-row tile). A quarter of the scale
+  // requests, and the one loop-carried register set is rotated at the top of the trip, where its load is the oldest in flight.
+  constexpr bool SV = PB == 1 && kD == 4 && FMT != 1;
+  __shared__ __attribute__((aligned(256))) char smem[2 * BM * AROW];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -196,36 +210,41 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
   // (a scalar base per workgroup and 32-bit per-thread offsets: 64-bit per-thread row addresses of the large tiles were
   // spilled and reloaded inside the K loop)
   const T* act_blk = act + (int64_t)m0 * K;
-  uint32_t aoff[MT];
+  constexpr int AL = MT * AS;        // 16-byte chunks per thread and stage: chunk q = i * 256 + tid of [BM][16 AS]
+  uint32_t aoff[AL];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int idx = i * 256 + tid;
-    const int row = idx >> 4, c = idx & 15;
+  for (int i = 0; i < AL; ++i) {
+    const int q = i * 256 + tid;
+    const int row = q / (16 * AS), c = q % (16 * AS);
     aoff[i] = (uint32_t)((probe & 1) ? 0 : row < m_valid ? row : m_valid - 1) * (uint32_t)K + c * 8;
   }
-  auto load_a = [&](int kb, v4i (&r)[MT]) {
+  auto load_a = [&](int st, v4i (&r)[AL]) {  // stage st = blocks st * AS .. + AS - 1
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int c = (i * 256 + tid) & 15;
-      const bool in = kb * 128 + c * 8 < K;  // past K: read k = 0 instead and zero the registers (no branch)
-      const v4i v = *reinterpret_cast<const v4i*>(act_blk + (aoff[i] + (in ? (uint32_t)kb * 128u : 0u)));
-      r[i][0] = in ? v[0] : 0; r[i][1] = in ? v[1] : 0; r[i][2] = in ? v[2] : 0; r[i][3] = in ? v[3] : 0;
+    for (int i = 0; i < AL; ++i) {
+      const int c = (i * 256 + tid) % (16 * AS);
+      const bool in = st * (128 * AS) + c * 8 < K;  // past K: read k = 0 instead (zeroed on the way to LDS; no branch)
+      r[i] = *reinterpret_cast<const v4i*>(act_blk + (aoff[i] + (in ? (uint32_t)st * (128u * AS) : 0u)));
     }
   };
-  auto store_a = [&](int buf, const v4i (&r)[MT]) {
-    char* base = smem + buf * (BM * 256);
+  // (the zeroing of chunks past K belongs here and not behind the load: a select right after the load waits for it on the
+  // spot, with every younger load in flight)
+  auto store_a = [&](int buf, int st, const v4i (&r)[AL]) {
+    char* base = smem + buf * (BM * AROW);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int idx = i * 256 + tid;
-      const int row = idx >> 4, c = idx & 15;
-      const v4i v = r[i];
+    for (int i = 0; i < AL; ++i) {
+      const int q = i * 256 + tid;
+      const int row = q / (16 * AS), c = q % (16 * AS);
+      const bool in = st * (128 * AS) + c * 8 < K;
+      const v4i zero = {0, 0, 0, 0};
+      const v4i v = in ? r[i] : zero;
       // element order (a0,a4,a1,a5,a2,a6,a3,a7) to match expand_nibbles
       v4i p;
       p[0] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x05040100u);
       p[1] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x07060302u);
       p[2] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x05040100u);
       p[3] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x07060302u);
-      *reinterpret_cast<v4i*>(base + row * 256 + ((c ^ (row & 15)) << 4)) = p;
+      // (the swizzle permutes the 16 chunks of a 128-deep block among themselves)
+      *reinterpret_cast<v4i*>(base + row * AROW + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4)) = p;
     }
   };
 
@@ -254,9 +273,6 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
   // All three streams (weights, scales / zero points, activations) run kD 128-deep blocks ahead of the MFMAs in
   // register rings with static slots (the K loop is unrolled kD times): at decode sizes an iteration is ~0.15 us of
   // MFMA work against ~2 us of memory latency, and a load consumed close to where it was issued stalls the wave.
-  // (decode tiles: 8 KiB of weights in flight per wave; the large tiles: registers. A spill in this loop is reloaded
-  // through scratch, i.e. behind an s_waitcnt vmcnt(0) that empties the rings: build.py's check_isa rejects one.)
-  constexpr int kD = (PB == 1 && (MT == 1 || (MT == 2 && FMT != 2))) ? 4 : 2;
   uint32_t wd[NW][4], wq_[kD][NW][4];
   // weights past K are never multiplied by anything but zero activations: any valid address will do (block 0)
   auto load_w = [&](int kb, uint32_t (&dst)[NW][4]) {
@@ -282,42 +298,84 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
       }
     }
   };
-  v4i aq_[kD][MT];
+  uint2 sv_cur[NW], sv_nxt[NW], zv_cur[NW], zv_nxt[NW];
+  auto load_sv = [&](int kb0, uint2 (&sd)[NW], uint2 (&zd)[NW]) {
+    int kg0 = (probe & 8) ? 0 : kb0;
+    kg0 = kg0 + 4 <= kgroups ? kg0 : kgroups - 4;
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+      sd[nt] = *reinterpret_cast<const uint2*>(sexp + soff[nt] + kg0);
+      if constexpr (has_zp) zd[nt] = *reinterpret_cast<const uint2*>(zexp + soff[nt] + kg0);
+    }
+  };
+  auto sv_get = [&](const uint2& v, int u) -> float {  // element u (0..3) of four packed 16-bit floats, widened
+    const uint32_t d = u < 2 ? v.x : v.y;
+    const uint16_t h = (u & 1) ? (uint16_t)(d >> 16) : (uint16_t)d;
+    return (float)__builtin_bit_cast(T, h);
+  };
+  // activations: with AS = 1 a ring of kD blocks like the weights; with AS = 4 one register set, a stage is requested
+  // when the one before it goes to LDS (four blocks of lead)
+  constexpr int kA = AS == 1 ? kD : 1;
+  v4i aq_[kA][AL];
+  // (activation requests in front of the ring's, as in the steady state: the waits the compiler counts for the loop are the
+  // worse of the two ways into it)
+#pragma unroll
+  for (int d = 0; d < kA; ++d) load_a(d, aq_[d]);
+  store_a(0, 0, aq_[0]);
+  load_a(kA, aq_[0]);  // slot 0 now carries block / stage kA (zeros past K)
+  if constexpr (SV) {
+    load_sv(0, sv_cur, zv_cur);
+    load_sv(kD, sv_nxt, zv_nxt);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // (fenced: interleaved by the scheduler, slot 0 looks as young as the last slot)
 #pragma unroll
   for (int d = 0; d < kD; ++d) {
     load_w(d, wq_[d]);
-    load_s(d, sq_[d], zq_[has_zp ? d : 0]);
-    load_a(d, aq_[d]);
+    if constexpr (!SV) load_s(d, sq_[d], zq_[has_zp ? d : 0]);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  store_a(0, aq_[0]);
-  load_a(kD, aq_[0]);  // slot 0 now carries block kD (zeros past K)
 
   // (blocks past K run on zero activations: the trip count is padded to a multiple of kD, the body has no exit)
   for (int kb0 = 0; kb0 < nkb; kb0 += kD) {
 #pragma unroll
   for (int u = 0; u < kD; ++u) {
     const int kb = kb0 + u;
-    const int buf = kb & 1;
-    // tile kb is staged; everyone is done reading the other buffer. Not __syncthreads(): that waits vmcnt(0) and
-    // would drain the prefetch rings every iteration (measured: 3.7 us per 128-deep block instead of ~0.4)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // block kb+1 sits in slot (u+1) % kD (slot 0 after the wrap was refilled with block kb0 + kD): stage it, then
-    // refill that slot with block kb + 1 + kD
-    store_a(buf ^ 1, aq_[(u + 1) % kD]);
-    load_a(kb + 1 + kD, aq_[(u + 1) % kD]);
+    const int st = kb / AS;  // activation stage of this block
+    const int buf = st & 1;
+    if constexpr (SV) {
+      if (u == 0 && kb0 > 0) {
+#pragma unroll
+        for (int nt = 0; nt < NW; ++nt) {
+          sv_cur[nt] = sv_nxt[nt];
+          if constexpr (has_zp) zv_cur[nt] = zv_nxt[nt];
+        }
+        load_sv(kb0 + kD, sv_nxt, zv_nxt);
+      }
+    }
+    if (u % AS == 0) {
+      // stage st is in LDS; everyone is done reading the other buffer. Not __syncthreads(): that waits vmcnt(0) and
+      // would drain the prefetch rings every iteration (measured: 3.7 us per 128-deep block instead of ~0.4)
+      if (!(probe & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // AS = 1: block kb+1 sits in slot (u+1) % kD (slot 0 after the wrap was refilled with block kb0 + kD): stage it,
+      // then refill that slot with block kb + 1 + kD. AS = 4: the one set holds stage st + 1; then request st + 2.
+      if (!(probe & 64)) {
+        store_a(buf ^ 1, st + 1, aq_[AS == 1 ? (u + 1) % kD : 0]);
+        load_a(st + 1 + kA, aq_[AS == 1 ? (u + 1) % kD : 0]);
+      }
+    }
     S sc[NW][PB], zc[NW][PB];
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) wd[nt][t] = wq_[u][nt][t];
+      if constexpr (!SV) {
 #pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        sc[nt][i] = sq_[u][nt][i];
-        if constexpr (has_zp) zc[nt][i] = zq_[u][nt][i];
+        for (int i = 0; i < PB; ++i) {
+          sc[nt][i] = sq_[u][nt][i];
+          if constexpr (has_zp) zc[nt][i] = zq_[u][nt][i];
+        }
       }
     }
-    load_w(kb + kD, wq_[u]);
-    load_s(kb + kD, sq_[u], zq_[has_zp ? u : 0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
@@ -327,10 +385,10 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
       }
       if constexpr (kTranspose) transpose4(wd[nt]);  // now wd[nt][j] = codes of k = 128 kb + 32 j + 8 g .. + 7 of row n
     }
-    const char* abase = smem + buf * (BM * 256);
+    const char* abase = smem + buf * (BM * AROW) + (kb % AS) * 256;
     if (probe & 16) {
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) acc[0][nt][0] += __uint_as_float(wd[nt][0] ^ wd[nt][1] ^ wd[nt][2] ^ wd[nt][3]) + (float)sc[nt][0];
+      for (int nt = 0; nt < NW; ++nt) acc[0][nt][0] += __uint_as_float(wd[nt][0] ^ wd[nt][1] ^ wd[nt][2] ^ wd[nt][3]) + (SV ? sv_get(sv_cur[nt], u) : (float)sc[nt][0]);
       continue;
     }
     static_for4([&](auto jc) {
@@ -343,7 +401,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
         const int chunk = kTranspose ? 4 * j + g : 4 * g + j;
-        const v4i af = *reinterpret_cast<const v4i*>(abase + row * 256 + ((chunk ^ l15) << 4));
+        const v4i af = *reinterpret_cast<const v4i*>(abase + row * AROW + ((chunk ^ l15) << 4));
         if constexpr (is_int4) asum[mt] = W4<T>::mma(af, ones, asum[mt]);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
@@ -358,16 +416,26 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
           if constexpr (!is_int4) {
             const uint32_t e = sc[nt][ki];  // E8M0: 2^(byte - 127); byte 0 is the subnormal 2^-127
             s = __uint_as_float(e ? e << 23 : 0x00400000u);
+          } else if constexpr (SV) {
+            s = sv_get(sv_cur[nt], u);
+            z = has_zp ? 16.0f + sv_get(zv_cur[nt], u) : 24.0f;
           } else {
             s = (float)sc[nt][ki];
             z = has_zp ? 16.0f + (float)zc[nt][ki] : 24.0f;
           }
+          // (explicit pairs {s, s}: left to itself the compiler forms v_pk_fma_f32 with the scalar broadcast from the low
+          // half of a register PAIR whose high half it is free to use as the destination of a ring load - the FMA then
+          // waits for a load it does not need, with the whole ring in flight behind it)
+          const v2f sv = {s, s}, zv = {-z, -z};
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float t = !is_int4 ? part[mt][nt][r] : __builtin_fmaf(-z, asum[mt][r], part[mt][nt][r]);
-              acc[mt][nt][r] = __builtin_fmaf(s, t, acc[mt][nt][r]);
+            for (int h = 0; h < 2; ++h) {
+              v2f t = {part[mt][nt][2 * h], part[mt][nt][2 * h + 1]};
+              if constexpr (is_int4) t = __builtin_elementwise_fma(zv, (v2f){asum[mt][2 * h], asum[mt][2 * h + 1]}, t);
+              const v2f a = __builtin_elementwise_fma(sv, t, (v2f){acc[mt][nt][2 * h], acc[mt][nt][2 * h + 1]});
+              acc[mt][nt][2 * h] = a[0];
+              acc[mt][nt][2 * h + 1] = a[1];
             }
             part[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
           }
@@ -378,6 +446,13 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
       // the body is one basic block now: without fences the scheduler interleaves all steps and spills
       __builtin_amdgcn_sched_barrier(0);
     });
+    // Refill ring slot u with block kb + kD AFTER the last use of what it held: requested before (at the top of the
+    // block) the new value had to live in other registers while the old one was still being expanded, and the loop end
+    // moved all kD slots back into place with copies - each copy waits for the load into its source, so the whole ring was
+    // drained once per trip of the loop (vmcnt(0) in front of 40 v_mov).
+    load_w(kb + kD, wq_[u]);
+    if constexpr (!SV) load_s(kb + kD, sq_[u], zq_[has_zp ? u : 0]);
+    __builtin_amdgcn_sched_barrier(0);
   }
   }
 
@@ -439,6 +514,11 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // kernel is bound by the weight stream (measured at 1 row per expert: 183 vs 186 us), 64-row tiles are the largest whose
   // K loop stays free of register spills.
   const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 1 : g_w4_mt == 2 ? 16 : 1000) : total_m / E;
+  // (16-column tiles per wave - 64 columns per workgroup, twice the workgroups - were slower at every decode shape: the
+  // activation staging and the barrier are per workgroup, 155 vs 145 us at N = 28672, K = 4096)
+  // (the 16 / 32-row tiles fetch the scales of four 128-deep blocks with one 8-byte load: groups of 128, K % 512 == 0)
+  const bool small_ok = group_shift != 7 && group_shift != 8 ? true : (group_shift == 7 && K % 512 == 0);
+  if (!small_ok) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   if (avg <= 6) return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   if (avg <= 24) return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);

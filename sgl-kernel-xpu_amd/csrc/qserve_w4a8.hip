@@ -32,16 +32,21 @@ __device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b) {
   return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
 }
 
-template <bool GROUP, int MF>
-__global__ __launch_bounds__(256) void qserve_w4a8_kernel(
+// SPLIT = 1: workgroup = 4 waves on 4 neighbouring 32-column blocks, each over all of K.
+// SPLIT = 16 / 8 (few rows, M <= 16 / 64: the weight stream of a decode step): workgroup = SPLIT waves on ONE 32-column
+// block, wave w takes the 64-deep k steps w, w + SPLIT, ..; the int32 partial sums are added through LDS (exact) and wave
+// 0 finishes (8 waves above 16 rows: 16 would leave 128 registers per lane and spill).
+// With one wave per 32 columns over all of K a 4096 x 4096 layer is 128 waves of 64 dependent steps each: 19 us.
+template <bool GROUP, int MF, int SPLIT>
+__global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void qserve_w4a8_kernel(
     f16* __restrict__ out, const int8_t* __restrict__ a, const uint8_t* __restrict__ w,
     const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales_i8, const f16* __restrict__ wscales,
     const f16* __restrict__ ascales, const f16* __restrict__ w_szs, const f16* __restrict__ a_ssums, int M, int N,
     int K, int64_t lda, int64_t ldc) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n32 = blockIdx.x * 4 + wave;
-  if (n32 * 32 >= N) return;
+  const int n32 = SPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  if (SPLIT == 1 && n32 * 32 >= N) return;
   const int m0 = blockIdx.y * (16 * MF);
   const int j = lane & 15, kg = lane >> 4;
   const int c = j & 7, b = j >> 3;
@@ -67,12 +72,17 @@ __global__ __launch_bounds__(256) void qserve_w4a8_kernel(
   // Weights, activations and group scales run kD 64-deep steps ahead of the MFMAs in a register ring with static slots
   // (loop unrolled kD times): a load consumed in the iteration that issues it exposes the whole memory latency per step.
   // Steps past K re-read the last one (their results are not accumulated).
-  const int nks = K >> 6;
+  const int nks_all = K >> 6;
+  // this wave's steps: ks = kfirst + kstride * i, i < nks
+  const int kfirst = SPLIT == 1 ? 0 : wave, kstride = SPLIT;
+  const int nks = SPLIT == 1 ? nks_all : (nks_all > wave ? (nks_all - wave + SPLIT - 1) / SPLIT : 0);
   constexpr int kD = MF <= 2 ? 4 : 2;
   uint32_t wq_[kD][4], sq_[kD][4];
   v4i aq_[kD][MF];
-  auto load_step = [&](int ks, uint32_t (&wd)[4], uint32_t (&sz)[4], v4i (&af)[MF]) {
-    ks = ks < nks ? ks : nks - 1;
+  auto load_step = [&](int i, uint32_t (&wd)[4], uint32_t (&sz)[4], v4i (&af)[MF]) {
+    i = i < nks ? i : nks - 1;
+    int ks = kfirst + kstride * (i > 0 ? i : 0);
+    ks = ks < nks_all ? ks : nks_all - 1;  // (a wave without steps loads the last one; nothing is accumulated)
 #pragma unroll
     for (int e = 0; e < 4; ++e) wd[e] = *reinterpret_cast<const uint32_t*>(wl + (int64_t)ks * 1024 + e * 16);
 #pragma unroll
@@ -117,6 +127,28 @@ __global__ __launch_bounds__(256) void qserve_w4a8_kernel(
     }
   }
 
+  if constexpr (SPLIT > 1) {
+    extern __shared__ int red[];  // [SPLIT - 1][MF][2][64 lanes][4]
+    if (wave > 0) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          *reinterpret_cast<v4i*>(red + ((((wave - 1) * MF + mf) * 2 + h) * 64 + lane) * 4) = acc[mf][h];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 0; w < SPLIT - 1; ++w) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const v4i t = *reinterpret_cast<const v4i*>(red + (((w * MF + mf) * 2 + h) * 64 + lane) * 4);
+          acc[mf][h][0] += t[0]; acc[mf][h][1] += t[1]; acc[mf][h][2] += t[2]; acc[mf][h][3] += t[3];
+        }
+    }
+  }
+
   // ---- epilogue: lane (column m = j of the m fragment, rows n = 4 kg + r of the n fragment)
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
@@ -145,14 +177,27 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
                   int64_t K, int64_t lda, int64_t ldc) {
   const unsigned gx = (unsigned)cdiv(N, 128);
 #define SGLK_GO(MF)                                                                                              \
-  qserve_w4a8_kernel<GROUP, MF><<<dim3(gx, (unsigned)cdiv(M, 16 * MF)), 256, 0, st>>>(                           \
+  qserve_w4a8_kernel<GROUP, MF, 1><<<dim3(gx, (unsigned)cdiv(M, 16 * MF)), 256, 0, st>>>(                        \
       (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,            \
       (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc)
-  if (M <= 16) SGLK_GO(1);
-  else if (M <= 32) SGLK_GO(2);
-  else if (M <= 64) SGLK_GO(4);
+#define SGLK_GO_SPLIT(MF, SPLIT)                                                                                 \
+  {                                                                                                              \
+    constexpr int lds = (SPLIT - 1) * MF * 2 * 64 * 16;                                                          \
+    static unsigned long long attr_done = 0;                                                                     \
+    if (lds > 64 * 1024)                                                                                         \
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&qserve_w4a8_kernel<GROUP, MF, SPLIT>), lds, &attr_done, \
+                                   "qserve_w4a8"))                                                               \
+        return rc;                                                                                               \
+    qserve_w4a8_kernel<GROUP, MF, SPLIT><<<dim3((unsigned)(N / 32), (unsigned)cdiv(M, 16 * MF)), 64 * SPLIT, lds, st>>>( \
+        (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,          \
+        (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc); \
+  }
+  if (M <= 16) SGLK_GO_SPLIT(1, 16)
+  else if (M <= 32) SGLK_GO_SPLIT(2, 8)
+  else if (M <= 64) SGLK_GO_SPLIT(4, 8)
   else SGLK_GO(8);
 #undef SGLK_GO
+#undef SGLK_GO_SPLIT
   return check_launch(GROUP ? "qserve_w4a8_per_group_gemm" : "qserve_w4a8_per_chn_gemm");
 }
 

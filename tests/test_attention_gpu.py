@@ -134,6 +134,21 @@ def test_decode(sglk, dev, heads, local, page, D, batch, seqlen_k):
                   use_sink=(D == 64 and not local), num_splits=splits, seed=seqlen_k)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("heads,sq", [((16, 16), 1), ((16, 16), 5), ((16, 4), 4), ((16, 2), 2), ((32, 2), 1), ((8, 1), 2)])
+@pytest.mark.parametrize("feature", ["plain", "causal", "local", "softcap", "sinks", "causal+sinks"])
+def test_decode_kernel_features(sglk, dev, dtype, heads, sq, feature):
+    """the independent-wave decode kernel (d = 128, at most 16 packed rows per kv head, pages >= 32 tokens): every mask /
+    softcap / sink combination of the contract, 1..16 rows, ragged lengths around tile and page edges, all split counts"""
+    Hq, Hk = heads
+    seqs_k = [1, 31, 32, 33, 640, 1000 + sq]
+    seqs_q = [min(sq, k) for k in seqs_k]
+    kw = dict(causal="causal" in feature, window=(100, 0) if feature == "local" else (-1, -1),
+              softcap=20.0 if feature == "softcap" else 0.0, use_sink="sinks" in feature)
+    for page, splits in ((32, 0), (64, 1), (256, 3), (64, 16)):
+        run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, 128, page, num_splits=splits, seed=sq + Hq, **kw)
+
+
 def test_decode_full_size_config_sampled(sglk, dev):
     """BASELINE configs[2] decode: b=16, Hq=32, Hk=8, d=128, seq=4096, paged (64), bf16; oracle on 3 sequences."""
     b, Hq, Hk, D, S, page = 16, 32, 8, 128, 4096, 64

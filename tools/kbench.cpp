@@ -245,6 +245,36 @@ __global__ __launch_bounds__(512) void issue_probe_kernel(const int* __restrict_
 //   pattern 0: one load = 16 rows x 64 contiguous bytes (lane = (row l15, chunk g)): the MFMA-fragment order
 //   pattern 1: one load = 4 rows x 256 contiguous bytes (lane = (row lane / 16, chunk lane % 16))
 //   pattern 2: one load = 1 row x 1024 contiguous bytes
+// pattern 3: the W4A16 kernel's order - a round is ONE 64-byte piece of each of the wave's 32 rows (2 loads per lane),
+// DEPTH rounds in flight, consecutive rounds advance along the rows (the next 64 bytes of a row come a round later)
+template <int DEPTH, int WGS_PER_CU>
+__global__ __launch_bounds__(256, WGS_PER_CU) void stream_probe3_kernel(const uint8_t* __restrict__ w, uint32_t* __restrict__ out,
+                                                                       int row_bytes) {
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  v4i_ acc = {0, 0, 0, 0};
+  const int rounds = row_bytes / 64;
+  const uint8_t* p0 = w + (row0 + (lane & 15)) * row_bytes + (lane >> 4) * 16;
+  const uint8_t* p1 = p0 + (int64_t)16 * row_bytes;
+  v4i_ ring[DEPTH][2];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    ring[d][0] = *reinterpret_cast<const v4i_*>(p0 + d * 64);
+    ring[d][1] = *reinterpret_cast<const v4i_*>(p1 + d * 64);
+  }
+  for (int r0 = 0; r0 < rounds; r0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      acc ^= ring[d][0] ^ ring[d][1];
+      const int rn = r0 + d + DEPTH < rounds ? r0 + d + DEPTH : rounds - 1;
+      ring[d][0] = *reinterpret_cast<const v4i_*>(p0 + rn * 64);
+      ring[d][1] = *reinterpret_cast<const v4i_*>(p1 + rn * 64);
+    }
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678) out[0] = 1;
+}
+
 template <int PATTERN, int DEPTH>
 __global__ __launch_bounds__(256) void stream_probe_kernel(const uint8_t* __restrict__ w, uint32_t* __restrict__ out, int row_bytes) {
   typedef int v4i_ __attribute__((ext_vector_type(4)));
@@ -473,6 +503,21 @@ int main(int argc, char** argv) {
         printf("stream rows=%lld row_bytes=%lld pattern=%d depth=%d: median %.1f us min %.1f -> %.0f GB/s\n", (long long)rows,
                (long long)row_bytes, pat, depth, ms * 1e3, all[0] * 1e3, rows * row_bytes / ms / 1e6);
       }
+    for (int v = 0; v < 6; ++v) {
+      auto run = [&] {
+        if (v == 0) stream_probe3_kernel<4, 1><<<blocks, 256>>>(w, out, (int)row_bytes);
+        if (v == 1) stream_probe3_kernel<4, 2><<<blocks, 256>>>(w, out, (int)row_bytes);
+        if (v == 2) stream_probe3_kernel<4, 3><<<blocks, 256>>>(w, out, (int)row_bytes);
+        if (v == 3) stream_probe3_kernel<8, 2><<<blocks, 256>>>(w, out, (int)row_bytes);
+        if (v == 4) stream_probe3_kernel<16, 2><<<blocks, 256>>>(w, out, (int)row_bytes);
+        if (v == 5) stream_probe3_kernel<4, 8><<<blocks, 256>>>(w, out, (int)row_bytes);
+      };
+      std::vector<float> all;
+      const double ms = time_ms(run, 5, 20, &all);
+      const char* names[] = {"depth 4, 1 WG/CU", "depth 4, 2 WG/CU", "depth 4, 3 WG/CU", "depth 8, 2 WG/CU", "depth 16, 2 WG/CU", "depth 4, 8 WG/CU"};
+      printf("stream rows=%lld row_bytes=%lld pattern=3 (%s): median %.1f us min %.1f -> %.0f GB/s\n", (long long)rows,
+             (long long)row_bytes, names[v], ms * 1e3, all[0] * 1e3, rows * row_bytes / ms / 1e6);
+    }
     return 0;
   }
   if (!strcmp(argv[1], "w4a16")) {  // kbench w4a16 N K ROWS [probe:mt ...]: int4 group-128 grouped GEMM, 8 experts, uniform rows

@@ -1,0 +1,32 @@
+"""qserve_w4a8_per_chn_gemm / per_group_gemm timing (random codes): M sweep at N = K = 4096 and at N = 14336, K = 4096."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "python"))
+import sgl_kernel
+dev = "cuda"
+
+
+def timeit(f, it=30):
+    for _ in range(10): f()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(it): f()
+    en.record(); torch.cuda.synchronize()
+    return st.elapsed_time(en) / it
+
+
+for N, K in ((4096, 4096), (14336, 4096)):
+    w = torch.randint(-128, 128, (N, K // 2), device=dev, dtype=torch.int8)
+    ws = (torch.rand(N, device=dev) * 0.01).half()
+    wz = (torch.rand(N, device=dev) * 0.01).half()
+    z8 = torch.randint(-8, 8, (K // 128, N), device=dev, dtype=torch.int8)
+    s8 = torch.randint(1, 8, (K // 128, N), device=dev, dtype=torch.int8)
+    for M in ([int(a) for a in sys.argv[1:]] or [1, 16, 64, 256, 4096]):
+        a = torch.randint(-127, 128, (M, K), device=dev, dtype=torch.int8)
+        sa = (torch.rand(M, device=dev) * 0.01).half()
+        ssum = torch.rand(M, device=dev).half()
+        out = torch.empty(M, N, device=dev, dtype=torch.float16)
+        ms = timeit(lambda: sgl_kernel.qserve_w4a8_per_chn_gemm(a, w, ws, sa, wz, ssum, out))
+        ms2 = timeit(lambda: sgl_kernel.qserve_w4a8_per_group_gemm(a, w, z8, s8, ws, sa, out))
+        print(f"N={N} K={K} M={M}: per_chn {ms*1e3:.1f} us {2.0*M*N*K/ms/1e9:.1f} TOP/s weights {N*K/2/ms/1e6:.0f} GB/s | "
+              f"per_group {ms2*1e3:.1f} us {2.0*M*N*K/ms2/1e9:.1f} TOP/s")
