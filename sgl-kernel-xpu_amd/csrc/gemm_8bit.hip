@@ -899,31 +899,39 @@ __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
     load_a(0, 0);
     load_a(1, 1);
 
-    for (int kb0 = 0; kb0 < nkb; kb0 += kD) {
+    // One K block: multiply from ring slot u, THEN refill it (requested before its last use the new block has to live in
+    // other registers and the loop end moves the ring back into place with copies, each waiting for the load into its
+    // source - i.e. for the whole ring).
+    auto step = [&](int u, int kb) {
 #pragma unroll
-      for (int u = 0; u < kD; ++u) {
-        const int kb = kb0 + u;
-        if (kb < nkb) {
-          const v8i w = wq[u];
-          const int kn = kb + kD;
-          wq[u] = load32(bl + (int64_t)(kn < nkb ? kn : 0) * BK);
+      for (int mf = 0; mf < MF; ++mf) {
+        if constexpr (MODE == MODE_INT8_ROWCOL) {
+          acc[mf] = mfma_i8_k128(wq[u], af[u & 1][mf], acc[mf]);
+        } else if constexpr (MODE == MODE_FP8_ROWCOL) {
+          acc[mf] = mfma_k128<HW_SCALE>(wq[u], af[u & 1][mf], acc[mf]);
+        } else {
+          const v4f cur = mfma_k128<HW_SCALE>(wq[u], af[u & 1][mf], zero);
+          const float sc = sv[u & 1][mf] * sbq[u & 1];
 #pragma unroll
-          for (int mf = 0; mf < MF; ++mf) {
-            if constexpr (MODE == MODE_INT8_ROWCOL) {
-              acc[mf] = mfma_i8_k128(w, af[u & 1][mf], acc[mf]);
-            } else if constexpr (MODE == MODE_FP8_ROWCOL) {
-              acc[mf] = mfma_k128<HW_SCALE>(w, af[u & 1][mf], acc[mf]);
-            } else {
-              const v4f cur = mfma_k128<HW_SCALE>(w, af[u & 1][mf], zero);
-              const float sc = sv[u & 1][mf] * sbq[u & 1];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[mf][r] = __builtin_fmaf(cur[r], sc, acc[mf][r]);
-            }
-          }
-          load_a(kb + 2, u & 1);
+          for (int r = 0; r < 4; ++r) acc[mf][r] = __builtin_fmaf(cur[r], sc, acc[mf][r]);
         }
       }
+      // (activations first: vmcnt retires in order, so the wait for the 2-deep activation ring two steps from now also waits
+      // for every weight request in front of it - this way the two youngest weight blocks stay in flight behind it)
+      load_a(kb + 2, u & 1);
+      const int kn = kb + kD;
+      wq[u] = load32(bl + (int64_t)(kn < nkb ? kn : 0) * BK);
+    };
+    // whole groups of kD blocks without a branch (a conditional step merges its loads with the old registers through
+    // copies), then the rest
+    int kb0 = 0;
+    for (; kb0 + kD <= nkb; kb0 += kD) {
+#pragma unroll
+      for (int u = 0; u < kD; ++u) step(u, kb0 + u);
     }
+#pragma unroll
+    for (int u = 0; u < kD; ++u)
+      if (kb0 + u < nkb) step(u, kb0 + u);
   }
 
   if constexpr (KS > 1) {

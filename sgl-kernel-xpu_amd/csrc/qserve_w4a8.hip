@@ -98,32 +98,30 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void qserve_w4a8_ker
   for (int ks0 = 0; ks0 < nks; ks0 += kD) {
 #pragma unroll
     for (int u = 0; u < kD; ++u) {
-      uint32_t wd[4], sz[4];
-      v4i af[MF];
+      // (steps past this wave's range multiply zero weights: no branch; the slot is refilled AFTER its last use, else the
+      // new step lives in other registers and the loop end moves the ring back with copies that wait for every load)
+      const uint32_t keep = ks0 + u < nks ? 0xffffffffu : 0u;
+      v4i wlo, whi;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { wd[e] = wq_[u][e]; sz[e] = sq_[u][e]; }
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) af[mf] = aq_[u][mf];
-      load_step(ks0 + u + kD, wq_[u], sq_[u], aq_[u]);
-      if (ks0 + u < nks) {
-        v4i wlo, whi;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t lo = wd[e] & 0x0f0f0f0fu, hi = (wd[e] >> 4) & 0x0f0f0f0fu;
-          if constexpr (GROUP) {
-            // code * scale <= 15 * 17 fits a byte: one 32-bit multiply scales four codes; the add wraps per byte
-            lo = add_bytes(lo * sz[0], sz[2] * 0x01010101u);
-            hi = add_bytes(hi * sz[1], sz[3] * 0x01010101u);
-          }
-          wlo[e] = (int)lo;
-          whi[e] = (int)hi;
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t wd = wq_[u][e] & keep;
+        uint32_t lo = wd & 0x0f0f0f0fu, hi = (wd >> 4) & 0x0f0f0f0fu;
+        if constexpr (GROUP) {
+          // code * scale <= 15 * 17 fits a byte: one 32-bit multiply scales four codes; the add wraps per byte
+          lo = add_bytes(lo * sq_[u][0], (sq_[u][2] * 0x01010101u) & keep);
+          hi = add_bytes(hi * sq_[u][1], (sq_[u][3] * 0x01010101u) & keep);
         }
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          acc[mf][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wlo, af[mf], acc[mf][0], 0, 0, 0);
-          acc[mf][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(whi, af[mf], acc[mf][1], 0, 0, 0);
-        }
+        wlo[e] = (int)lo;
+        whi[e] = (int)hi;
       }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        acc[mf][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wlo, aq_[u][mf], acc[mf][0], 0, 0, 0);
+        acc[mf][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(whi, aq_[u][mf], acc[mf][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(ks0 + u + kD, wq_[u], sq_[u], aq_[u]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

@@ -521,7 +521,16 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (!strcmp(argv[1], "w4a16")) {  // kbench w4a16 N K ROWS [probe:mt ...]: int4 group-128 grouped GEMM, 8 experts, uniform rows
-    const int64_t E = 8, N = atoll(argv[2]), K = atoll(argv[3]), rows = atoll(argv[4]), total = E * rows;
+    const int64_t E = 8, N = atoll(argv[2]), K = atoll(argv[3]);
+    std::vector<int32_t> hr(E, (int32_t)atoll(argv[4]));  // ROWS: one number (uniform) or 8 comma-separated counts
+    if (strchr(argv[4], ',')) {
+      char* sp = strdup(argv[4]);
+      int i = 0;
+      for (char* tok = strtok(sp, ","); tok && i < E; tok = strtok(nullptr, ",")) hr[i++] = atoi(tok);
+    }
+    int64_t total = 0;
+    for (int32_t r : hr) total += r;
+    const int64_t rows = total / E;
     void* w = dev_random_bytes(E * N * K / 2, 1, false);
     std::vector<uint16_t> hs(E * N * (K / 128), 0x3c00 >> 3);  // bf16 ~0.0078
     for (auto& x : hs) x = 0x3c00;                               // bf16 2^-7
@@ -534,7 +543,6 @@ int main(int argc, char** argv) {
     HIP_CHECK(hipMalloc(&act, ha.size() * 2));
     HIP_CHECK(hipMemcpy(act, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&out, total * N * 2));
-    std::vector<int32_t> hr(E, (int32_t)rows);
     int32_t* dr;
     HIP_CHECK(hipMalloc(&dr, E * 4));
     HIP_CHECK(hipMemcpy(dr, hr.data(), E * 4, hipMemcpyHostToDevice));
