@@ -233,9 +233,10 @@ template <typename T>
 static int dispatch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
                     int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
   const int64_t avg = total_m / E;  // tile policy by average rows per expert, as the reference (GroupGemmXe20.cpp:226-274)
-  if (avg <= 16) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
-  if (avg <= 32) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
-  if (avg <= 128) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  // (ragged counts: a tile that holds ~1.5x the average rows, a second row block of an expert streams its weights again)
+  if (avg <= 10) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  if (avg <= 24) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  if (avg <= 96) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   return launch<T, 8, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
 }
 

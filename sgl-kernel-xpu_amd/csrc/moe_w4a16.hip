@@ -510,17 +510,18 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
                     const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
   // Tile policy by average rows per expert (the reference switches policies the same way,
   // GroupGemmW4A16Xe20.cpp:266-277). The row counts are ragged around the average, and a second row block of an expert
-  // streams its weights again, so a tile is chosen that holds ~1.5x the average; 16 rows cost the same as 32 while the
-  // kernel is bound by the weight stream (measured at 1 row per expert: 183 vs 186 us), 64-row tiles are the largest whose
-  // K loop stays free of register spills.
-  const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 1 : g_w4_mt == 2 ? 16 : 1000) : total_m / E;
+  // streams its weights again, so a tile is chosen that holds ~1.5x the average; 64-row tiles are the largest whose K loop
+  // stays free of register spills.
+  const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 1 : g_w4_mt == 2 ? 32 : 1000) : total_m / E;
   // (16-column tiles per wave - 64 columns per workgroup, twice the workgroups - were slower at every decode shape: the
   // activation staging and the barrier are per workgroup, 155 vs 145 us at N = 28672, K = 4096)
   // (the 16 / 32-row tiles fetch the scales of four 128-deep blocks with one 8-byte load: groups of 128, K % 512 == 0)
   const bool small_ok = group_shift != 7 && group_shift != 8 ? true : (group_shift == 7 && K % 512 == 0);
   if (!small_ok) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-  if (avg <= 6) return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-  if (avg <= 24) return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  // measured on ragged counts around the average (gate/up + down projection of Mixtral, us): avg 8: 16-row tile 124 + 75,
+  // 32-row 140 + 98; avg 16: 151 + 97 vs 145 + 99; avg 32: 226 + 130 vs 191 + 141 vs 64-row 251 + 175
+  if (avg <= 10) return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  if (avg <= 40) return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
 }
 
