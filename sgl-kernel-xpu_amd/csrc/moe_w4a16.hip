@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
   // staging cost 40 of 96 us).
   constexpr int AS = kD >= 4 ? (MT == 1 ? 4 : 2) : 1;  // (32-row tiles: 256 k per stage, four more would spill)
   constexpr int AROW = 256 * AS;  // bytes of a staged activation row
+  constexpr bool kTranspose = PB > 1;  // (groups of 32 / 64: see below, where the weights are expanded)
   // SV: the scales (zero points) of the kD = 4 blocks of one trip of the K loop are ONE 8-byte load per row, requested a
   // trip ahead (groups of 128, K a multiple of 512: the host sends other shapes to the 64-row tile). A quarter of the scale
   // requests, and the one loop-carried register set is rotated at the top of the trip, where its load is the oldest in flight.
@@ -244,7 +245,15 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
       p[2] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x05040100u);
       p[3] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x07060302u);
       // (the swizzle permutes the 16 chunks of a 128-deep block among themselves)
-      *reinterpret_cast<v4i*>(base + row * AROW + (((c & ~15) | ((c & 15) ^ (row & 15))) << 4)) = p;
+      // position of chunk cb = c % 16 of a 128-deep block inside its 256-byte row piece: slot(cb) ^ (row & 15); slot is the
+      // identity when the k-steps read chunks 4 j + g, and {0, 12, 4, 8}[cb / 4] + cb % 4 when they read chunks 4 g + j
+      // (groups >= 128): a ds_read_b128 serves lanes {0-3, 12-15, 20-27} together (MI355X_MICROARCH.md, LDS), i.e. rows
+      // {0-3, 12-15} of lane group 0 with rows 4-11 of lane group 1 - their slots must differ by a value with equal bits 2
+      // and 3 (here 12) or every read is a 2-way conflict (3 conflict cycles per LDS instruction in the r02 profile of
+      // the first version); the eight chunks a ds_write_b128 group stores stay distinct mod 8.
+      const int cb = c & 15;
+      const int slot = kTranspose ? cb : (((0x84C0 >> (cb & 12)) & 15) + (cb & 3));
+      *reinterpret_cast<v4i*>(base + row * AROW + (((c & ~15) | (slot ^ (row & 15))) << 4)) = p;
     }
   };
 
@@ -266,7 +275,6 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
   // One scale group per 128-deep block (groups of 128 / 256): the order of k inside the block is free, so MFMA k-step j
   // takes dword j of every lane's own 16 weight bytes (k = 32 g + 8 j ..) and the activation fragment is read from
   // that k range; smaller groups need each k-step to be one contiguous 32-wide range: 4x4 transpose across lane groups.
-  constexpr bool kTranspose = PB > 1;
 
   // weights run two 128-deep blocks ahead of the MFMAs, scales / zero points one block ahead: at decode sizes the
   // kernel is a latency-bound HBM stream and a load consumed in the iteration that issued it stalls every wave
@@ -400,8 +408,8 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
-        const int chunk = kTranspose ? 4 * j + g : 4 * g + j;
-        const v4i af = *reinterpret_cast<const v4i*>(abase + row * AROW + ((chunk ^ l15) << 4));
+        const int slot = kTranspose ? 4 * j + g : ((0x84C0 >> (4 * g)) & 15) + j;  // (see store_a)
+        const v4i af = *reinterpret_cast<const v4i*>(abase + row * AROW + ((slot ^ l15) << 4));
         if constexpr (is_int4) asum[mt] = W4<T>::mma(af, ones, asum[mt]);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
