@@ -47,6 +47,18 @@ HIP_FLAGS = [
 ]
 
 
+# Per-file flags. -fno-slp-vectorize: a plain -O3 build packs adjacent scalar f32 adds / multiplies into v_pk_*_f32, which
+# issue SLOWER next to MFMAs than the two scalar instructions they replace (MI355X_MICROARCH.md, "price of one filler
+# beside MFMAs"; kbench issue: 4 v_fma_f32 per MFMA 2.88 PFLOP/s, 2 v_pk_fma_f32 2.40), and whose register pairs create
+# false dependencies on ring loads.
+FILE_FLAGS = {
+    "attn_fwd.hip": ["-fno-slp-vectorize"],
+    "moe_w4a16.hip": ["-fno-slp-vectorize"],
+    "moe_bf16.hip": ["-fno-slp-vectorize"],
+    "mla_decode.hip": ["-fno-slp-vectorize"],
+}
+
+
 def newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -194,7 +206,7 @@ def _compile_all(obj_dir, extra_flags, jobs, force, verbose, headers):
         with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
             futs = {}
             for s, src, obj in todo:
-                flags = HIP_FLAGS + extra_flags + (["-save-temps=obj"] if s in ISA_CHECKED else [])
+                flags = HIP_FLAGS + FILE_FLAGS.get(s, []) + extra_flags + (["-save-temps=obj"] if s in ISA_CHECKED else [])
                 futs[ex.submit(run, [HIPCC] + flags + ["-c", src, "-o", obj])] = src
             for f in cf.as_completed(futs):
                 dt, out = f.result()

@@ -813,25 +813,23 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
         s1[v] = m1 ? -INFINITY : s1[v];
       }
     }
-    // (the VALU is this kernel's second bottleneck after the matrix pipe. Scores are scaled first, as packed fp32
-    // products: the maxima of products need no NaN canonicalisation (raw MFMA results get one v_max x, x each) and pair
-    // up into v_max3_f32; then packed adds for x - m and for the row sums. No inline-asm VALU here: the hazard recogniser
-    // cannot see an asm read of a register an MFMA is still writing.)
-    const v2f sc2v = {sc2, sc2};
-    v2f x0[8], x1[8];
+    // (the VALU is this kernel's second bottleneck after the matrix pipe. Scores are scaled first: the maxima of products
+    // need no NaN canonicalisation (raw MFMA results get one v_max x, x each) and pair up into v_max3_f32. Scalar f32
+    // instructions on purpose - the file is built with -fno-slp-vectorize: next to MFMAs a v_pk_*_f32 costs more issue
+    // time than the two scalar instructions it replaces. No inline-asm VALU here: the hazard recogniser cannot see an
+    // asm read of a register an MFMA is still writing.)
+    float x0[16], x1[16];
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      x0[v] = (v2f){s0[2 * v], s0[2 * v + 1]} * sc2v;  // -inf stays -inf (scale > 0)
-      x1[v] = (v2f){s1[2 * v], s1[2 * v + 1]} * sc2v;
+    for (int v = 0; v < 16; ++v) {
+      x0[v] = s0[v] * sc2;  // -inf stays -inf (scale > 0)
+      x1[v] = s1[v] * sc2;
     }
-    float mt = fmaxf(fmaxf(x0[0][0], x0[0][1]), x1[0][0]);
-    mt = fmaxf(fmaxf(mt, x1[0][1]), x0[1][0]);
-    mt = fmaxf(fmaxf(mt, x0[1][1]), x1[1][0]);
-    mt = fmaxf(mt, x1[1][1]);
+    float mt = fmaxf(fmaxf(x0[0], x0[1]), x1[0]);
+    mt = fmaxf(mt, x1[1]);
 #pragma unroll
-    for (int v = 2; v < 8; ++v) {
-      mt = fmaxf(fmaxf(mt, x0[v][0]), x0[v][1]);
-      mt = fmaxf(fmaxf(mt, x1[v][0]), x1[v][1]);
+    for (int v = 2; v < 16; v += 2) {
+      mt = fmaxf(fmaxf(mt, x0[v]), x0[v + 1]);
+      mt = fmaxf(fmaxf(mt, x1[v]), x1[v + 1]);
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     if (__any(mt > m_ref + kSlack)) {  // (m_ref = -inf: any finite maximum moves it)
@@ -845,23 +843,18 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
         for (int v = 0; v < 16; ++v) o[db][v] *= alpha;
     }
     const float mneg = m_ref == -INFINITY ? 0.f : -m_ref;
-    const v2f mnegv = {mneg, mneg};
-    v2f psum0 = {0.f, 0.f}, psum1 = {0.f, 0.f};
+    float psum_a = 0.f, psum_b = 0.f;
     v8s pf[4];
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const v2f y0 = x0[v] + mnegv, y1 = x1[v] + mnegv;
-      const v2f p0 = {__builtin_amdgcn_exp2f(y0[0]), __builtin_amdgcn_exp2f(y0[1])};
-      const v2f p1 = {__builtin_amdgcn_exp2f(y1[0]), __builtin_amdgcn_exp2f(y1[1])};
-      psum0 += p0;
-      psum1 += p1;
-      pf[v >> 2][2 * (v & 3)] = M::cvt(p0[0]);
-      pf[v >> 2][2 * (v & 3) + 1] = M::cvt(p0[1]);
-      pf[2 + (v >> 2)][2 * (v & 3)] = M::cvt(p1[0]);
-      pf[2 + (v >> 2)][2 * (v & 3) + 1] = M::cvt(p1[1]);
+    for (int v = 0; v < 16; ++v) {
+      const float p0 = __builtin_amdgcn_exp2f(x0[v] + mneg);
+      const float p1 = __builtin_amdgcn_exp2f(x1[v] + mneg);
+      psum_a += p0;
+      psum_b += p1;
+      pf[v >> 3][v & 7] = M::cvt(p0);
+      pf[2 + (v >> 3)][v & 7] = M::cvt(p1);
     }
-    psum0 += psum1;
-    const float psum = psum0[0] + psum0[1];
+    const float psum = psum_a + psum_b;
     l_run += psum;
     if (late_barrier) lds_barrier();
 

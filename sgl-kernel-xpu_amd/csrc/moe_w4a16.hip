@@ -162,17 +162,17 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
   // kD: 128-deep blocks of weights / scales in flight per wave (register ring, the K loop is unrolled kD times).
   // (decode tiles: 8 KiB of weights in flight per wave; the large tiles: registers. A spill in this loop is reloaded
   // through scratch, i.e. behind an s_waitcnt vmcnt(0) that empties the rings: build.py's check_isa rejects one.)
-  constexpr int kD = (PB == 1 && (MT == 1 || (MT == 2 && FMT != 2))) ? 4 : 2;
+  constexpr int kD = (PB == 1 && (MT == 1 || (MT == 2 && FMT != 2))) ? (NW == 1 ? 8 : 4) : 2;
   // AS: 128-deep blocks per activation stage. The decode tiles stage 512 / 256 k at a time: one workgroup barrier per
   // four / two blocks instead of one per block (with one workgroup per CU - the Mixtral down projection at decode - barrier and
   // staging cost 40 of 96 us).
   constexpr int AS = kD >= 4 ? (MT == 1 ? 4 : 2) : 1;  // (32-row tiles: 256 k per stage, four more would spill)
   constexpr int AROW = 256 * AS;  // bytes of a staged activation row
   constexpr bool kTranspose = PB > 1;  // (groups of 32 / 64: see below, where the weights are expanded)
-  // SV: the scales (zero points) of the kD = 4 blocks of one trip of the K loop are ONE 8-byte load per row, requested a
-  // trip ahead (groups of 128, K a multiple of 512: the host sends other shapes to the 64-row tile). A quarter of the scale
+  // SV: the scales (zero points) of the kD = 4 / 8 blocks of one trip of the K loop are ONE 8- / 16-byte load per row,
+  // requested a trip ahead (groups of 128, K a multiple of 512 / 1024: the host sends other shapes elsewhere). A quarter of the scale
   // requests, and the one loop-carried register set is rotated at the top of the trip, where its load is the oldest in flight.
-  constexpr bool SV = PB == 1 && kD == 4 && FMT != 1;
+  constexpr bool SV = PB == 1 && kD >= 4 && FMT != 1;
   __shared__ __attribute__((aligned(256))) char smem[2 * BM * AROW];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -306,18 +306,20 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
       }
     }
   };
-  uint2 sv_cur[NW], sv_nxt[NW], zv_cur[NW], zv_nxt[NW];
-  auto load_sv = [&](int kb0, uint2 (&sd)[NW], uint2 (&zd)[NW]) {
+  // (kD 16-bit scales of a row = kD / 2 dwords: one 8- or 16-byte load)
+  typedef uint32_t SVec __attribute__((ext_vector_type(kD >= 4 ? kD / 2 : 2)));
+  SVec sv_cur[NW], sv_nxt[NW], zv_cur[NW], zv_nxt[NW];
+  auto load_sv = [&](int kb0, SVec (&sd)[NW], SVec (&zd)[NW]) {
     int kg0 = (probe & 8) ? 0 : kb0;
-    kg0 = kg0 + 4 <= kgroups ? kg0 : kgroups - 4;
+    kg0 = kg0 + kD <= kgroups ? kg0 : kgroups - kD;
 #pragma unroll
     for (int nt = 0; nt < NW; ++nt) {
-      sd[nt] = *reinterpret_cast<const uint2*>(sexp + soff[nt] + kg0);
-      if constexpr (has_zp) zd[nt] = *reinterpret_cast<const uint2*>(zexp + soff[nt] + kg0);
+      sd[nt] = *reinterpret_cast<const SVec*>(sexp + soff[nt] + kg0);
+      if constexpr (has_zp) zd[nt] = *reinterpret_cast<const SVec*>(zexp + soff[nt] + kg0);
     }
   };
-  auto sv_get = [&](const uint2& v, int u) -> float {  // element u (0..3) of four packed 16-bit floats, widened
-    const uint32_t d = u < 2 ? v.x : v.y;
+  auto sv_get = [&](const SVec& v, int u) -> float {  // element u of the packed 16-bit floats, widened
+    const uint32_t d = v[u >> 1];
     const uint16_t h = (u & 1) ? (uint16_t)(d >> 16) : (uint16_t)d;
     return (float)__builtin_bit_cast(T, h);
   };
@@ -431,19 +433,16 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
             s = (float)sc[nt][ki];
             z = has_zp ? 16.0f + (float)zc[nt][ki] : 24.0f;
           }
-          // (explicit pairs {s, s}: left to itself the compiler forms v_pk_fma_f32 with the scalar broadcast from the low
-          // half of a register PAIR whose high half it is free to use as the destination of a ring load - the FMA then
-          // waits for a load it does not need, with the whole ring in flight behind it)
-          const v2f sv = {s, s}, zv = {-z, -z};
+          // (scalar FMAs; the file is built with -fno-slp-vectorize: left to itself the compiler forms v_pk_fma_f32 with
+          // the scalar broadcast from the low half of a register PAIR whose high half it is free to use as the destination
+          // of a ring load - the FMA then waits for a load it does not need, with the whole ring in flight behind it - and
+          // packed f32 instructions issue slower next to MFMAs than the scalar ones they replace)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              v2f t = {part[mt][nt][2 * h], part[mt][nt][2 * h + 1]};
-              if constexpr (is_int4) t = __builtin_elementwise_fma(zv, (v2f){asum[mt][2 * h], asum[mt][2 * h + 1]}, t);
-              const v2f a = __builtin_elementwise_fma(sv, t, (v2f){acc[mt][nt][2 * h], acc[mt][nt][2 * h + 1]});
-              acc[mt][nt][2 * h] = a[0];
-              acc[mt][nt][2 * h + 1] = a[1];
+            for (int r = 0; r < 4; ++r) {
+              const float t = !is_int4 ? part[mt][nt][r] : __builtin_fmaf(-z, asum[mt][r], part[mt][nt][r]);
+              acc[mt][nt][r] = __builtin_fmaf(s, t, acc[mt][nt][r]);
             }
             part[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
           }
@@ -528,8 +527,17 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   if (!small_ok) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   // measured on ragged counts around the average (gate/up + down projection of Mixtral, us): avg 8: 16-row tile 124 + 75,
   // 32-row 140 + 98; avg 16: 151 + 97 vs 145 + 99; avg 32: 226 + 130 vs 191 + 141 vs 64-row 251 + 175
-  if (avg <= 10) return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-  if (avg <= 40) return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  // few column blocks (the Mixtral down projection: 32 of 128 columns x 8 experts = one workgroup per CU): 64-column
+  // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
+  const bool narrow = group_shift == 7 && K % 1024 == 0 && (int64_t)(total_m < E ? total_m : E) * cdiv(N, 128) <= 384;
+  if (avg <= 10) {
+    if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+    return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  }
+  if (avg <= 40) {
+    if (narrow) return launch<T, 2, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+    return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  }
   return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
 }
 

@@ -169,6 +169,154 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void qserve_w4a8_ker
   }
 }
 
+// Many rows (M > 64): a 128 x 128 tile per workgroup, 4 waves as 2 (m) x 2 (n), a wave owns 64 rows x two 32-column
+// weight blocks = 4 x 4 MFMA tiles. The activation tile [128 rows][64 B] of a k step is staged ONCE per workgroup in LDS
+// (global -> registers two steps ahead -> LDS one step ahead, two buffers, one LDS-only barrier per step) instead of being
+// pulled through the vector L1 by every wave: per 16 MFMAs a wave now reads 4 KiB of activations from LDS and 2 KiB of
+// weights from global memory, against 8 KiB + 1 KiB through the L1 before. LDS image: row r at 64 r, its four 16-byte
+// parts at (part ^ swz[(r >> 2) & 3]) with swz = {0, 3, 2, 1}: a ds_read_b128 serves lanes {0-3, 12-15, 20-27} together
+// (MI355X_MICROARCH.md, LDS), i.e. rows r, r + 12 of lane group kg with rows r + 4, r + 8 of group kg + 1 - four rows
+// on the same 16 banks that this swizzle spreads over the four parts.
+template <bool GROUP>
+__global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
+    f16* __restrict__ out, const int8_t* __restrict__ a, const uint8_t* __restrict__ w,
+    const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales_i8, const f16* __restrict__ wscales,
+    const f16* __restrict__ ascales, const f16* __restrict__ w_szs, const f16* __restrict__ a_ssums, int M, int N,
+    int K, int64_t lda, int64_t ldc) {
+  __shared__ __attribute__((aligned(1024))) char as[2][128 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128;
+  const int j = lane & 15, kg = lane >> 4;
+  const int c = j & 7, b = j >> 3;
+
+  // weights: the wave's two 32-column blocks (clamped: a block past N reads block 0 and is not stored)
+  const uint8_t* wl[2];
+  const int8_t *s8[2], *z8[2];
+  int n32[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    n32[q] = blockIdx.x * 4 + wn * 2 + q;
+    const int nc = n32[q] * 32 < N ? n32[q] : 0;
+    wl[q] = w + ((int64_t)nc * (K >> 5) + (kg >> 1)) * 512 + c * 64 + (kg & 1) * 8 + b * 4;
+    s8[q] = GROUP ? scales_i8 + nc * 32 + c * 4 + b : nullptr;
+    z8[q] = GROUP ? zeros + nc * 32 + c * 4 + b : nullptr;
+  }
+  // activation staging: 16-byte chunk ch = tid + 256 i of the [128][4] tile: row ch / 4, part ch % 4
+  const int8_t* ap[2];
+  int aoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = tid + 256 * i, row = ch >> 2, part = ch & 3;
+    int m = m0 + row;
+    m = m < M ? m : M - 1;
+    ap[i] = a + (int64_t)m * lda + part * 16;
+    aoff[i] = row * 64 + ((part ^ ((4 - ((row >> 2) & 3)) & 3)) << 4);
+  }
+  // fragment reads: row wm * 64 + 16 mf + j, part kg
+  const int rd = (wm * 64 + j) * 64 + ((kg ^ ((4 - ((j >> 2) & 3)) & 3)) << 4);  // (+ 1024 mf: (16 mf) >> 2 is a multiple of 4)
+
+  v4i acc[4][4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = (v4i){0, 0, 0, 0};
+
+  const int nks = K >> 6;
+  auto load_w = [&](int ks, uint32_t (&wd)[2][4], uint32_t (&sz)[2][4]) {
+    ks = ks < nks ? ks : nks - 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wd[q][e] = *reinterpret_cast<const uint32_t*>(wl[q] + (int64_t)ks * 1024 + e * 16);
+      if constexpr (GROUP) {
+        const int64_t g = ks >> 1;
+        sz[q][0] = (uint8_t)s8[q][g * N]; sz[q][1] = (uint8_t)s8[q][g * N + 2];
+        sz[q][2] = (uint8_t)z8[q][g * N]; sz[q][3] = (uint8_t)z8[q][g * N + 2];
+      }
+    }
+  };
+  auto load_a = [&](int ks, v4i (&r)[2]) {
+    ks = ks < nks ? ks : nks - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const v4i*>(ap[i] + ks * 64);
+  };
+  auto store_a = [&](int buf, const v4i (&r)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<v4i*>(&as[buf][aoff[i]]) = r[i];
+  };
+
+  uint32_t wq_[2][2][4], sq_[2][2][4];
+  v4i aq_[2];
+  load_a(0, aq_);
+  store_a(0, aq_);
+  load_a(1, aq_);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w(0, wq_[0], sq_[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  load_w(1, wq_[1], sq_[1]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int ks0 = 0; ks0 < nks; ks0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ks = ks0 + u;
+      // step ks is in LDS, everyone is done reading the other buffer (LDS-only barrier: the loads in flight stay there)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      store_a(u ^ 1, aq_);
+      load_a(ks + 2, aq_);
+      const uint32_t keep = ks < nks ? 0xffffffffu : 0u;  // (a step past K multiplies zero weights: no branch)
+      v4i wop[4];                                          // [2 q + half]
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t wd = wq_[u][q][e] & keep;
+          uint32_t lo = wd & 0x0f0f0f0fu, hi = (wd >> 4) & 0x0f0f0f0fu;
+          if constexpr (GROUP) {
+            lo = add_bytes(lo * sq_[u][q][0], (sq_[u][q][2] * 0x01010101u) & keep);
+            hi = add_bytes(hi * sq_[u][q][1], (sq_[u][q][3] * 0x01010101u) & keep);
+          }
+          wop[2 * q][e] = (int)lo;
+          wop[2 * q + 1][e] = (int)hi;
+        }
+      }
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        const v4i af = *reinterpret_cast<const v4i*>(&as[u][rd + mf * 1024]);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop[nf], af, acc[mf][nf], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(ks + 2, wq_[u], sq_[u]);  // (after the slot's last use: see the kernel above)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: lane (column m = j of the m fragment, rows n = 4 kg + r of the n fragment)
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    const int m = m0 + wm * 64 + mf * 16 + j;
+    if (m >= M) continue;
+    const float sa = (float)ascales[m];
+    const float asum = GROUP ? 0.f : (float)a_ssums[m];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int n = n32[nf >> 1] * 32 + (nf & 1) * 16 + kg * 4;
+      if (n >= N) continue;
+      Vec<f16, 4> o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = (float)acc[mf][nf][r] * sa * (float)wscales[n + r];
+        if constexpr (!GROUP) v -= asum * (float)w_szs[n + r];
+        o[r] = (f16)v;
+      }
+      store_vec<f16, 4>(out + (int64_t)m * ldc + n, o);
+    }
+  }
+}
+
 template <bool GROUP>
 static int launch(hipStream_t st, void* out, const void* a, const void* w, const void* zeros, const void* scales_i8,
                   const void* wscales, const void* ascales, const void* w_szs, const void* a_ssums, int64_t M, int64_t N,
@@ -193,7 +341,11 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   if (M <= 16) SGLK_GO_SPLIT(1, 16)
   else if (M <= 32) SGLK_GO_SPLIT(2, 8)
   else if (M <= 64) SGLK_GO_SPLIT(4, 8)
-  else SGLK_GO(8);
+  else {
+    qserve_w4a8_tile_kernel<GROUP><<<dim3(gx, (unsigned)cdiv(M, 128)), 256, 0, st>>>(
+        (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,
+        (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc);
+  }
 #undef SGLK_GO
 #undef SGLK_GO_SPLIT
   return check_launch(GROUP ? "qserve_w4a8_per_group_gemm" : "qserve_w4a8_per_chn_gemm");

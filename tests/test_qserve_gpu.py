@@ -10,7 +10,7 @@ from oracle import qserve as oq
 
 pytestmark = pytest.mark.gpu
 
-MS = [1, 16, 32, 64, 128, 512, 1024]
+MS = [1, 16, 32, 64, 65, 128, 300, 512, 1024]
 NKS = [(128, 512), (512, 1024), (1024, 4096), (4096, 512), (96, 192)]
 
 
