@@ -35,6 +35,7 @@
 // Block = 4 waves; wave w owns NW 16-wide n tiles and all MT 16-row m tiles of the block's expert rows.
 // Experts are ragged: the grid is sized for the worst case and each block finds its (expert, row block)
 // from rows_per_expert on the device (no host sync).
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -529,12 +530,14 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // 32-row 140 + 98; avg 16: 151 + 97 vs 145 + 99; avg 32: 226 + 130 vs 191 + 141 vs 64-row 251 + 175
   // few column blocks (the Mixtral down projection: 32 of 128 columns x 8 experts = one workgroup per CU): 64-column
   // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
-  const bool narrow = group_shift == 7 && K % 1024 == 0 && (int64_t)(total_m < E ? total_m : E) * cdiv(N, 128) <= 384;
+  const int64_t bm = avg <= 10 ? 16 : 32;
+  const int64_t est_row_blocks = std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / bm);
+  const bool narrow = group_shift == 7 && K % 1024 == 0 && est_row_blocks * cdiv(N, 128) <= 384;
   if (avg <= 10) {
     if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
     return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   }
-  if (avg <= 40) {
+  if (avg <= 160) {  // (avg 64: 32-row tile 321 + 198 us, 64-row 352 + 230; avg 128: 571 + 352 vs 596 + 396; 256: 1021 + 615 vs 1008 + 471)
     if (narrow) return launch<T, 2, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
     return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   }

@@ -23,15 +23,20 @@ run_set() {  # name, program + args...
   timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/$name/pmc_fetch -- "$@" > $OUT/$name.fetch.log 2>&1
   timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/$name/pmc_write -- "$@" > $OUT/$name.write.log 2>&1
 }
+SETS=${1:-"bench_full bench attn moe mla qserve"}   # optional argument: the sets to (re)collect
 mkdir -p $OUT/bench $OUT/attn $OUT/moe $OUT/mla $OUT/qserve
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_full/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_full.trace.log 2>&1
-run_set bench python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra
-run_set attn python3 $R/tools/attn_bench.py
-run_set moe python3 $R/tools/moe_bench.py 64 2048
-run_set mla $K mla 128 8192 128
-run_set qserve python3 $R/tools/qserve_bench.py 16 4096
+for s in $SETS; do
+  case $s in
+    bench_full) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_full/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_full.trace.log 2>&1 ;;
+    bench) run_set bench python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra ;;
+    attn) run_set attn python3 $R/tools/attn_bench.py ;;
+    moe) run_set moe python3 $R/tools/moe_bench.py 64 2048 ;;
+    mla) run_set mla $K mla 128 8192 128 ;;
+    qserve) run_set qserve python3 $R/tools/qserve_bench.py 16 4096 ;;
+  esac
+done
 cd $R
-for s in bench_full bench attn moe mla qserve; do
+for s in $SETS; do
   python3 tools/summarize_prof.py $OUT/$s --to $OUT/digest --tag $s > $OUT/$s.summary.txt 2>&1
 done
 # drop the raw per-dispatch tables (tens of MB): the digests and logs are what is kept
