@@ -83,3 +83,63 @@ def test_fwd_is_deterministic(sglk, dev, mode):
     vs = [oa.gather_paged(vc, table[i], seqs_k[i]) for i in range(b)]
     ref, _ = oa.attention_ragged(q, ks, vs, cu, D ** -0.5, causal=True)
     torch.testing.assert_close(out.cpu().float(), ref, rtol=2e-2, atol=2e-2)
+
+
+# ---- round 2: the kernels whose K loops live on register rings with hand-ordered refills and LDS-only barriers
+@pytest.mark.parametrize("fmt", ["int4", "int4_zp", "mxfp4", "bf16"])
+@pytest.mark.parametrize("rows", [[1, 0, 3, 2, 0, 1, 5, 4], [9, 24, 12, 20, 16, 16, 10, 21], [70, 3, 0, 129, 64, 33, 1, 90]])
+def test_grouped_gemms_are_deterministic(sglk, dev, fmt, rows):
+    """every tile of the two grouped GEMMs (16 / 32 / 64 rows, wide and narrow column tiles, vector scale loads) on ragged
+    row counts, 200 times"""
+    from oracle import moe as omoe
+    from test_moe_gpu import make_int4, make_mxfp4
+    g = torch.Generator().manual_seed(len(fmt) + sum(rows))
+    E, N, K, dt = len(rows), 384, 2048, torch.bfloat16
+    total = sum(rows)
+    act = (torch.randn(total, K, generator=g) * 0.1).to(dt)
+    rows_t = torch.tensor(rows, dtype=torch.int32)
+    out = torch.empty(total, N, dtype=dt, device=dev)
+    ad, rd = act.to(dev), rows_t.to(dev)
+    if fmt == "bf16":
+        w = (torch.randn(E, N, K, generator=g) * 0.05).to(dt)
+        wd = w.to(dev)
+
+        def run():
+            torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, ad, wd, None, rd, E, 0, False, 1.702, 7.0)
+            return out
+        ref = omoe.moe_grouped_mm(act, w, None, rows_t)
+    elif fmt == "mxfp4":
+        packed, scales = make_mxfp4(E, N, K, g, 113, 124)
+        pd, sd = packed.to(dev), scales.to(dev)
+
+        def run():
+            torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(out, ad, pd, sd, None, None, rd, E, False, 32)
+            return out
+        ref = omoe.moe_grouped_mm_w4a16(act, packed, scales, None, None, rows_t, 32, mxfp4=True)
+    else:
+        packed, scales, zeros = make_int4(E, N, K, 128, dt, fmt == "int4_zp", g)
+        pd, sd = packed.to(dev), scales.to(dev)
+        zd = zeros.to(dev) if zeros is not None else None
+
+        def run():
+            torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(out, ad, pd, sd, zd, None, rd, E, True, 128)
+            return out
+        ref = omoe.moe_grouped_mm_w4a16(act, packed, scales, zeros, None, rows_t, 128)
+    res = _repeat_equal(run, f"grouped gemm {fmt} rows={rows}")
+    torch.testing.assert_close(res.cpu().float(), ref.float(), rtol=5e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M", [1, 48, 200, 1024])
+def test_qserve_is_deterministic(sglk, dev, M):
+    """the in-workgroup split-K kernels (M <= 64) and the LDS-staged tile kernel"""
+    from oracle import qserve as oq
+    g = torch.Generator().manual_seed(M)
+    N, K = 256, 1024
+    a, b = torch.randn(M, K, generator=g) * 0.01, torch.randn(N, K, generator=g) * 0.01
+    a_q, a_scale = oq.sym_quantize(a)
+    b_q, chn, s8, z8 = oq.progressive_group_quantize(b)
+    w, ws, s8f, z8f = oq.per_group_inputs(b_q, chn, s8, z8)
+    args = (a_q.to(dev), w.to(dev), z8f.to(dev), s8f.to(dev), ws.to(dev), a_scale.to(dev))
+    out = _repeat_equal(lambda: sglk.qserve_w4a8_per_group_gemm(*args), f"qserve per-group M={M}")
+    ref = oq.w4a8_per_group_gemm(a_q, b_q, a_scale, chn, s8, z8)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-5)
