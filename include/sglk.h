@@ -285,7 +285,9 @@ SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const vo
  *          seqlens_k = cumulative [b+1].
  *   is_causal / window (left,right; < 0 = unlimited), bottom-right aligned; softcap 0 = off;
  *   sinks fp32 [Hq] or NULL; num_splits >= 1 (> 1 needs part_o fp32 [splits,total_q,Hq,D] and
- *   part_lse fp32 [splits,Hq,total_q]); sglk_attn_auto_splits gives the "0 = auto" choice. */
+ *   part_lse fp32 [splits,Hq,total_q]); sglk_attn_auto_splits gives the "0 = auto" choice (about one workgroup per
+ *   CU for decode-sized batches - at most 16 packed rows per kv head - two otherwise, never for prefill).
+ *   All k / v strides are in elements, non-negative and below 2^31. */
 SGLK_API int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
                                        int64_t max_seqlen_k);
 /* kv_layout 0: ragged k / v [total_k, Hk, D] (strides token, head), seqlens_k = cumulative offsets [b + 1];

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void qserve_w4a8_ker
 
 // Many rows (M > 64): a 128 x 128 tile per workgroup, 4 waves as 2 (m) x 2 (n), a wave owns 64 rows x two 32-column
 // weight blocks = 4 x 4 MFMA tiles. The activation tile [128 rows][64 B] of a k step is staged ONCE per workgroup in LDS
-// (global -> registers two steps ahead -> LDS one step ahead, two buffers, one LDS-only barrier per step) instead of being
+// (two 64-deep steps per stage: global -> registers two stages ahead -> LDS one stage ahead, two buffers, one LDS-only
+// barrier per 128 k) instead of being
 // pulled through the vector L1 by every wave: per 16 MFMAs a wave now reads 4 KiB of activations from LDS and 2 KiB of
 // weights from global memory, against 8 KiB + 1 KiB through the L1 before. LDS image: row r at 64 r, its four 16-byte
 // parts at (part ^ swz[(r >> 2) & 3]) with swz = {0, 3, 2, 1}: a ds_read_b128 serves lanes {0-3, 12-15, 20-27} together
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
     const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales_i8, const f16* __restrict__ wscales,
     const f16* __restrict__ ascales, const f16* __restrict__ w_szs, const f16* __restrict__ a_ssums, int M, int N,
     int K, int64_t lda, int64_t ldc) {
-  __shared__ __attribute__((aligned(1024))) char as[2][128 * 64];
+  __shared__ __attribute__((aligned(1024))) char as[2][2][128 * 64];  // [stage buffer][k step of the stage]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -237,18 +238,24 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
       }
     }
   };
-  auto load_a = [&](int ks, v4i (&r)[2]) {
-    ks = ks < nks ? ks : nks - 1;
+  // a stage = two 64-deep k steps: one barrier per 128 k
+  auto load_a = [&](int st, v4i (&r)[4]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const v4i*>(ap[i] + ks * 64);
-  };
-  auto store_a = [&](int buf, const v4i (&r)[2]) {
+    for (int h = 0; h < 2; ++h) {
+      int ks = 2 * st + h;
+      ks = ks < nks ? ks : nks - 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<v4i*>(&as[buf][aoff[i]]) = r[i];
+      for (int i = 0; i < 2; ++i) r[2 * h + i] = *reinterpret_cast<const v4i*>(ap[i] + ks * 64);
+    }
   };
-
+  auto store_a = [&](int buf, const v4i (&r)[4]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<v4i*>(&as[buf][h][aoff[i]]) = r[2 * h + i];
+  };
   uint32_t wq_[2][2][4], sq_[2][2][4];
-  v4i aq_[2];
+  v4i aq_[4];
   load_a(0, aq_);
   store_a(0, aq_);
   load_a(1, aq_);
@@ -259,13 +266,14 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
   __builtin_amdgcn_sched_barrier(0);
 
   for (int ks0 = 0; ks0 < nks; ks0 += 2) {
+    const int st = ks0 >> 1, buf = st & 1;
+    // stage st is in LDS, everyone is done reading the other buffer (LDS-only barrier: the loads in flight stay there)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    store_a(buf ^ 1, aq_);
+    load_a(st + 2, aq_);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int ks = ks0 + u;
-      // step ks is in LDS, everyone is done reading the other buffer (LDS-only barrier: the loads in flight stay there)
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      store_a(u ^ 1, aq_);
-      load_a(ks + 2, aq_);
       const uint32_t keep = ks < nks ? 0xffffffffu : 0u;  // (a step past K multiplies zero weights: no branch)
       v4i wop[4];                                          // [2 q + half]
 #pragma unroll
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
       }
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf) {
-        const v4i af = *reinterpret_cast<const v4i*>(&as[u][rd + mf * 1024]);
+        const v4i af = *reinterpret_cast<const v4i*>(&as[buf][u][rd + mf * 1024]);
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop[nf], af, acc[mf][nf], 0, 0, 0);
       }
