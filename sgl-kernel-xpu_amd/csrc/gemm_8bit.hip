@@ -819,18 +819,20 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Blockwise kernel for few rows (decode: M <= 64; above that the tile kernel wins). The 256 x 256 tile kernel above would put 56 workgroups on
-// 256 CUs and stream the 58.7 MB of Llama-3-8B FFN weights at ~1 TB/s. Here the work is a weight stream: one wave
-// per 16 weight rows (n), no LDS, no barriers. Per 128-deep K block a lane loads its 32 bytes of b^T (row n = lane
-// % 16, 16-byte chunks lane / 16 and lane / 16 + 4: the same k order as above) through a kD-deep register ring with
-// static slots, and the 32-byte activation fragments of up to MF = 4 m-tiles (they sit in L2 / the vector L1 for
-// all waves); one v_mfma_scale_f32_16x16x128_f8f6f4 per m-tile and K block, block scale on the VALU as above.
-// KS > 1 lets 2 / 4 waves split the K range of one n-tile and add their partial sums through LDS in a fixed order
-// (more bytes in flight; not used: it measured slower).
+// Kernel for few rows (decode: M <= 128; above that the tile kernel wins). The 256 x 256 tile kernel above would put 56
+// workgroups on 256 CUs and stream the 58.7 MB of Llama-3-8B FFN weights at ~1 TB/s. Here the work is a weight stream:
+// one wave per 16 weight rows (n), weights never touch LDS. Per 128-deep K block a lane loads its 32 bytes of b^T (row
+// n = lane % 16, 16-byte chunks lane / 16 and lane / 16 + 4: the same k order as above) through a kD-deep register
+// ring with static slots; one v_mfma_scale_f32_16x16x128_f8f6f4 per m-tile and K block, block scale on the VALU as
+// above. A workgroup is 4 waves = 4 / KS n-tiles x KS waves that share an n-tile and take the K blocks kb = KS i + kpart
+// (interleaved); their partial sums meet in LDS and are added in a fixed order. KS is chosen by the host so that the
+// launch has ~200+ workgroups: a CU on its own pulls ~20 GB/s through its L1, so N = 4096 with KS = 1 (64 workgroups)
+// ran at 1.2 TB/s. With more than 16 rows (MF >= 2) the activations of a step - [16 MF rows] x [KS K blocks] - are
+// staged once per workgroup in LDS (LDSA below); with one m-tile every lane fetches its own 32 bytes.
 // grid = (N / (16 * 4 / KS), ceil(M / (16 MF))); operands swapped as above: a lane owns 4 consecutive n of one m.
 // MODE_FP8_ROWCOL / MODE_INT8_ROWCOL (fp8_scaled_mm / int8_scaled_mm): the same stream, the MFMAs chain into the
 // accumulator and the epilogue applies sa[m] * sb[n] (+ bias) in the tile kernel's rounding order.
-template <typename OutT, int MODE, int MF, int KS, bool HW_SCALE>  // KS waves split the K range of one 16-row n-tile
+template <typename OutT, int MODE, int MF, int KS, bool HW_SCALE>  // KS waves split the K blocks of one 16-row n-tile
 __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
@@ -838,36 +840,46 @@ __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
   constexpr bool kBlockwise = MODE == MODE_BLOCKWISE;
   using AccT = typename std::conditional<MODE == MODE_INT8_ROWCOL, v4i, v4f>::type;
   constexpr int kD = 8;  // K blocks of weights in flight per wave
-  static_assert(KS == 1 || kBlockwise, "the K split is only wired for the blockwise mode");
-  __shared__ float red[KS > 1 ? 4 * MF * 256 : 1];
+  // LDSA: the activation tiles of a step ([KS blocks][16 MF rows][128 B]) are staged once per workgroup in LDS instead
+  // of being fetched by each wave in MFMA layout (at MF = 4 that was 128 B of activations per lane and block against 32 B
+  // of weights): global -> registers two steps ahead -> LDS one step ahead, two buffers, an LDS-only barrier per step.
+  // A wave without weight rows (n0 >= N) runs along for the staging and the barriers.
+  constexpr bool LDSA = MF >= 2;
+  constexpr int kTile = 16 * MF * 128;                    // one K block of activations
+  constexpr int kStage = LDSA ? 2 * KS * kTile : 0;       // two buffers of KS blocks
+  constexpr int kRed = KS > 1 ? 4 * MF * 256 * 4 : 0;     // partial sums (after the loop: shares the staging memory)
+  constexpr int kSmem = kStage > kRed ? kStage : (kRed > 16 ? kRed : 16);
+  __shared__ __attribute__((aligned(1024))) char smem[kSmem];
+  float* red = reinterpret_cast<float*>(smem);
+  char* abuf = smem;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = (blockIdx.x * (4 / KS) + wave / KS) * 16;
   const int kpart = wave % KS;
-  const bool live = n0 < N;  // (dead waves still join the barrier below)
+  const bool live = n0 < N;  // (dead waves still join the barriers)
   const int m0 = blockIdx.y * (16 * MF);
   const int j = lane & 15, g = lane >> 4;
   const int nkb_all = K / BK;
-  const int per = (nkb_all + KS - 1) / KS;
-  const int kb_lo = kpart * per;
-  const int nkb = live ? ((kb_lo + per < nkb_all ? kb_lo + per : nkb_all) - kb_lo) : 0;  // this wave's K blocks (may be <= 0)
+  const int nsteps = (nkb_all + KS - 1) / KS;        // steps of the workgroup
+  const int nmine = (nkb_all - kpart + KS - 1) / KS;  // K blocks of this wave: kpart, kpart + KS, ... (nsteps or one less)
+  const int nkb = (live || LDSA) ? nsteps : 0;
 
   int nrow = n0 + j;
   nrow = nrow < N ? nrow : N - 1;
-  const uint8_t* bl = b + (int64_t)nrow * ldb + g * 16 + (int64_t)kb_lo * BK;
+  const uint8_t* bl = b + (int64_t)nrow * ldb + g * 16 + kpart * BK;
   const uint8_t* al[MF];
   const float* sl[MF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     int m = m0 + mf * 16 + j;
     m = m < M ? m : M - 1;
-    al[mf] = a + (int64_t)m * lda + g * 16 + (int64_t)kb_lo * BK;
-    sl[mf] = kBlockwise ? sa + (int64_t)m * sa_sm + (int64_t)kb_lo * sa_sk : sa;
+    al[mf] = a + (int64_t)m * lda + g * 16 + kpart * BK;
+    sl[mf] = kBlockwise ? sa + (int64_t)m * sa_sm + (int64_t)kpart * sa_sk : sa;
   }
   const int nblk_max = (N + 127) / 128 - 1;
   int nblk = n0 >> 7;
   nblk = nblk < nblk_max ? nblk : nblk_max;
-  const float* sbw = kBlockwise ? sb + (int64_t)nblk * sb_sn + (int64_t)kb_lo * sb_sk : sb;
+  const float* sbw = kBlockwise ? sb + (int64_t)nblk * sb_sn + (int64_t)kpart * sb_sk : sb;
 
   auto load32 = [](const uint8_t* p) -> v8i {
     const v4i lo = *reinterpret_cast<const v4i*>(p), hi = *reinterpret_cast<const v4i*>(p + 64);
@@ -882,47 +894,100 @@ __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
   const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
   if (nkb > 0) {
-    v8i wq[kD];
-#pragma unroll
-    for (int d = 0; d < kD; ++d) wq[d] = load32(bl + (int64_t)(d < nkb ? d : 0) * BK);
     v8i af[2][MF];
     float sv[2][MF], sbq[2];
+    // LDSA staging: 16-byte chunk cid = tid + 256 i of the [16 MF rows][KS blocks][8 chunks] step (a row's KS * 128 bytes are
+    // contiguous in global memory): block tile kblk, row, chunk at (chunk ^ (row & 7))
+    constexpr int AL = LDSA ? MF * KS / 2 : 1;
+    v4i areg[AL];
+    const uint8_t* ag[AL];
+    int aoff[AL], akb[AL];
+    if constexpr (LDSA) {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int cid = threadIdx.x + 256 * i, row = cid / (8 * KS), c = cid % (8 * KS), kblk = c >> 3, ch = c & 7;
+        int m = m0 + row;
+        m = m < M ? m : M - 1;
+        ag[i] = a + (int64_t)m * lda + ch * 16;
+        akb[i] = kblk;
+        aoff[i] = kblk * kTile + row * 128 + ((ch ^ (row & 7)) << 4);
+      }
+    }
+    auto load_stage = [&](int kb) {  // activations of step kb -> registers (blocks past the end: block 0, never multiplied)
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int kk = kb * KS + akb[i];
+        areg[i] = *reinterpret_cast<const v4i*>(ag[i] + (int64_t)(kk < nkb_all ? kk : 0) * BK);
+      }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) *reinterpret_cast<v4i*>(&abuf[buf * (KS * kTile) + aoff[i]]) = areg[i];
+    };
     auto load_a = [&](int kb, int slot) {
-      const int kc = kb < nkb ? kb : 0;
+      const int kc = kb < nmine ? kb * KS : 0;
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        af[slot][mf] = load32(al[mf] + (int64_t)kc * BK);
+        if constexpr (!LDSA) af[slot][mf] = load32(al[mf] + (int64_t)kc * BK);
         if constexpr (kBlockwise) sv[slot][mf] = sl[mf][(int64_t)kc * sa_sk];
       }
       if constexpr (kBlockwise) sbq[slot] = sbw[(int64_t)kc * sb_sk];
     };
+    if constexpr (LDSA) {
+      load_stage(0);
+      store_stage(0);
+      load_stage(1);
+    }
     load_a(0, 0);
     load_a(1, 1);
+    __builtin_amdgcn_sched_barrier(0);  // (activation requests in front of the weight ring's, as in the steady state)
+    v8i wq[kD];
+#pragma unroll
+    for (int d = 0; d < kD; ++d) {
+      wq[d] = load32(bl + (int64_t)(d < nmine ? d * KS : 0) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
-    // One K block: multiply from ring slot u, THEN refill it (requested before its last use the new block has to live in
+    // One step: multiply from ring slot u, THEN refill it (requested before its last use the new block has to live in
     // other registers and the loop end moves the ring back into place with copies, each waiting for the load into its
     // source - i.e. for the whole ring).
     auto step = [&](int u, int kb) {
+      if constexpr (LDSA) {
+        // step kb is in LDS buffer kb % 2 (= u % 2: kD is even); everyone is done reading the other one
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        store_stage((u & 1) ^ 1);
+        load_stage(kb + 2);
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        if constexpr (MODE == MODE_INT8_ROWCOL) {
-          acc[mf] = mfma_i8_k128(wq[u], af[u & 1][mf], acc[mf]);
-        } else if constexpr (MODE == MODE_FP8_ROWCOL) {
-          acc[mf] = mfma_k128<HW_SCALE>(wq[u], af[u & 1][mf], acc[mf]);
-        } else {
-          const v4f cur = mfma_k128<HW_SCALE>(wq[u], af[u & 1][mf], zero);
-          const float sc = sv[u & 1][mf] * sbq[u & 1];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mf][r] = __builtin_fmaf(cur[r], sc, acc[mf][r]);
+        for (int mf = 0; mf < MF; ++mf) {
+          const int row = mf * 16 + j;
+          const char* rb = &abuf[(u & 1) * (KS * kTile) + kpart * kTile + row * 128];
+          const v4i lo = *reinterpret_cast<const v4i*>(rb + ((g ^ (row & 7)) << 4));
+          const v4i hi = *reinterpret_cast<const v4i*>(rb + (((g + 4) ^ (row & 7)) << 4));
+          af[u & 1][mf] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
       }
-      // (activations first: vmcnt retires in order, so the wait for the 2-deep activation ring two steps from now also waits
-      // for every weight request in front of it - this way the two youngest weight blocks stay in flight behind it)
+      if (KS == 1 || kb < nmine) {  // (wave-uniform; only the last step of a K that is not a multiple of KS blocks)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          if constexpr (MODE == MODE_INT8_ROWCOL) {
+            acc[mf] = mfma_i8_k128(wq[u], af[u & 1][mf], acc[mf]);
+          } else if constexpr (MODE == MODE_FP8_ROWCOL) {
+            acc[mf] = mfma_k128<HW_SCALE>(wq[u], af[u & 1][mf], acc[mf]);
+          } else {
+            const v4f cur = mfma_k128<HW_SCALE>(wq[u], af[u & 1][mf], zero);
+            const float sc = sv[u & 1][mf] * sbq[u & 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mf][r] = __builtin_fmaf(cur[r], sc, acc[mf][r]);
+          }
+        }
+      }
+      // (activations / scales first: vmcnt retires in order, so the wait for their 2-deep ring two steps from now also
+      // waits for every weight request in front of it - this way the two youngest weight blocks stay in flight behind it)
       load_a(kb + 2, u & 1);
       const int kn = kb + kD;
-      wq[u] = load32(bl + (int64_t)(kn < nkb ? kn : 0) * BK);
+      wq[u] = load32(bl + (int64_t)(kn < nmine ? kn * KS : 0) * BK);
     };
-    // whole groups of kD blocks without a branch (a conditional step merges its loads with the old registers through
+    // whole groups of kD steps without a branch (a conditional step merges its loads with the old registers through
     // copies), then the rest
     int kb0 = 0;
     for (; kb0 + kD <= nkb; kb0 += kD) {
@@ -936,6 +1001,7 @@ __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
 
   if constexpr (KS > 1) {
     // the KS partial sums of an n-tile meet in LDS and are added in a fixed order by the first wave of the group
+    if constexpr (LDSA) __syncthreads();  // (the staging buffers are read until the last step)
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) *reinterpret_cast<AccT*>(&red[((wave * MF + mf) * 64 + lane) * 4]) = acc[mf];
     __syncthreads();
@@ -1024,9 +1090,9 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       tail_halves = tail_halves || (left > 0 && 2 * left <= slots);
     }
   }
-  // few rows: the weight-streaming kernel (variant 5 forces it, variant 6 forbids it)
+  // few rows: the weight-streaming kernel (variant 5 forces it, 7 forces it without the K split, 6 forbids it)
   {
-    if ((M <= 64 && g_gemm_variant == 4) || g_gemm_variant == 5) {
+    if ((M <= 128 && g_gemm_variant == 4) || g_gemm_variant == 5 || g_gemm_variant == 7) {
 #define SGLK_GO_SKINNY(MF, KS)                                                                               \
   {                                                                                                          \
     const dim3 sg((unsigned)cdiv(N, 16 * (4 / KS)), (unsigned)cdiv(M, 16 * MF));                             \
@@ -1038,10 +1104,20 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
           lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn)))                                                       \
   }
-      // (splitting K over 2 / 4 waves of a workgroup - template KS - measured slower: 18 -> 22 us at M = 1, N = 14336)
-      if (M <= 16) SGLK_GO_SKINNY(1, 1)
-      else if (M <= 32) SGLK_GO_SKINNY(2, 1)
-      else SGLK_GO_SKINNY(4, 1)
+      // K split over the waves of a workgroup until the launch has ~200 workgroups (at N = 14336 the split measured
+      // slower: 18 -> 22 us at M = 1; at N = 4096, K = 14336 the unsplit launch has 64 workgroups: 44 us)
+      const bool mf8 = M > 64 && cdiv(N, 16) >= 768 && g_gemm_variant != 5;  // 128 rows per workgroup: weights read once
+      const int64_t ntile = cdiv(N, 16) * (mf8 ? 1 : cdiv(M, M <= 16 ? 16 : M <= 32 ? 32 : 64));
+      const int ks = (K / BK < 8 || ntile >= 768 || g_gemm_variant == 7) ? 1 : (ntile >= 384 ? 2 : 4);
+#define SGLK_GO_SKINNY_KS(MF)                                                                                \
+  {                                                                                                          \
+    if (ks == 1) SGLK_GO_SKINNY(MF, 1) else if (ks == 2) SGLK_GO_SKINNY(MF, 2) else SGLK_GO_SKINNY(MF, 4)    \
+  }
+      if (M <= 16) SGLK_GO_SKINNY_KS(1)
+      else if (M <= 32) SGLK_GO_SKINNY_KS(2)
+      else if (!mf8) SGLK_GO_SKINNY_KS(4)
+      else SGLK_GO_SKINNY(8, 1)
+#undef SGLK_GO_SKINNY_KS
 #undef SGLK_GO_SKINNY
       return check_launch("gemm_8bit(skinny)");
     }

@@ -57,8 +57,8 @@ def test_mfma_lane_maps_known_answer(sglk, dev):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("M", [1, 3, 5, 127, 128, 512])
-@pytest.mark.parametrize("N,K", [(128, 512), (512, 1024), (1024, 4096), (4096, 512), (14080, 1024), (8192, 8192)])
+@pytest.mark.parametrize("M", [1, 3, 5, 17, 40, 100, 127, 128, 512])
+@pytest.mark.parametrize("N,K", [(128, 512), (512, 1024), (1024, 4096), (4096, 512), (14080, 1024), (8192, 8192), (640, 1152)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fp8_blockwise(sglk, dev, M, N, K, dtype):
     if M > 128 and N * K > 4096 * 4096:
@@ -129,8 +129,8 @@ def test_fp8_blockwise_golden(sglk, dev):
         torch.testing.assert_close(out.float(), c["out"].float(), rtol=2e-2, atol=2e-3)
 
 
-@pytest.mark.parametrize("M", [1, 128, 512, 777])
-@pytest.mark.parametrize("N,K", [(16, 512), (128, 1024), (512, 4096), (4096, 512), (1024, 8192)])
+@pytest.mark.parametrize("M", [1, 24, 100, 128, 512, 777])
+@pytest.mark.parametrize("N,K", [(16, 512), (128, 1024), (512, 4096), (4096, 512), (1024, 8192), (320, 1152)])
 @pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fp8_scaled_mm(sglk, dev, M, N, K, with_bias, dtype):
@@ -147,8 +147,8 @@ def test_fp8_scaled_mm(sglk, dev, M, N, K, with_bias, dtype):
     torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("M", [1, 16, 64, 512, 1000])
-@pytest.mark.parametrize("N,K", [(16, 512), (128, 1024), (1024, 4096), (8192, 512), (16384, 1024)])
+@pytest.mark.parametrize("M", [1, 16, 64, 90, 512, 1000])
+@pytest.mark.parametrize("N,K", [(16, 512), (128, 1024), (1024, 4096), (8192, 512), (16384, 1024), (320, 1152)])
 @pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_int8_scaled_mm(sglk, dev, M, N, K, with_bias, dtype):
