@@ -424,14 +424,21 @@ struct TileDesc {
   uint32_t nrec_a, nrec_b, nrec_s, nrec_o;  // bytes in range of the four resources (0: nothing)
   int ncols;                                // valid columns of the tile (<= BN)
   int wrows;                                // rows per wm half of the wave grid: 128 (256-row tile) or 64 (128-row half tile)
+  int m0, n0;                               // first row / column (row / column scale modes: the epilogue's scales and bias)
 };
 
-template <typename OutT, bool HW_SCALE, int PROBE, int MS>  // MS m-steps per K block: 8 = 256-row tiles, 4 = 128-row half tiles
-__global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
+// MODE_FP8_ROWCOL / MODE_INT8_ROWCOL (fp8_scaled_mm / int8_scaled_mm): the same pipeline without the block scales - the
+// MFMAs of a tile chain into its accumulators (int8: two K = 64 MFMAs per fragment pair), no promotion FMAs, no scale
+// DMA; the first K block of the next tile fetches the finished tile's row scales, column scales and bias at its top and
+// applies them in the stores (the oracle's rounding order). Requires sb and bias 16-byte aligned as well.
+template <typename OutT, int MODE, bool HW_SCALE, int PROBE, int MS>  // MS m-steps per K block: 8 = 256-row tiles, 4 = 128-row half tiles
+__global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-    const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
-    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves,
-    uint32_t* __restrict__ stamps) {
+    const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
+    int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m,
+    int tiles_n, int all_halves, uint32_t* __restrict__ stamps) {
+  constexpr bool kBW = MODE == MODE_BLOCKWISE;
+  using AccT = typename std::conditional<MODE == MODE_INT8_ROWCOL, v4i, v4f>::type;
   __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -495,18 +502,20 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     live = live && rows_a > 0;  // the lower half of an edge tile may be empty
     d.ncols = rows_b;
     d.wrows = MS * 16;
+    d.m0 = m0;
+    d.n0 = n0;
     d.pa = a + (int64_t)m0 * lda;
     d.pb = b + (int64_t)n0 * ldb;
-    d.ps = sa + (int64_t)m0 * sa_sm;
+    d.ps = kBW ? sa + (int64_t)m0 * sa_sm : sa;
     d.po = (void*)(out + (int64_t)m0 * ldc + n0);
     d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * lda + K) : 0u;
     d.nrec_b = live ? (uint32_t)((int64_t)(rows_b - 1) * ldb + K) : 0u;
     // row scales: waves 0..3 fetch 64 rows each (4 B per lane); waves 4..7 fetch nothing (zeros into the spare KiB)
-    d.nrec_s = (live && wave < 4) ? (uint32_t)(((int64_t)(rows_a - 1) * sa_sm + (int64_t)(nkb - 1) * sa_sk + 1) * 4) : 0u;
+    d.nrec_s = (kBW && live && wave < 4) ? (uint32_t)(((int64_t)(rows_a - 1) * sa_sm + (int64_t)(nkb - 1) * sa_sk + 1) * 4) : 0u;
     d.nrec_o = (live && kStore) ? (uint32_t)(((int64_t)(rows_a - 1) * ldc + rows_b) * (int64_t)sizeof(OutT)) : 0u;
     int nblk = (n0 + wn * 64) >> 7;
     nblk = nblk < nblk_max ? nblk : nblk_max;
-    d.sbw = sb + (int64_t)nblk * sb_sn;
+    d.sbw = kBW ? sb + (int64_t)nblk * sb_sn : sb;
     return d;
   };
   auto pick = [](bool c, const TileDesc& x, const TileDesc& y) -> TileDesc {  // scalar selects
@@ -515,6 +524,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     d.po = c ? x.po : y.po;
     d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_s = c ? x.nrec_s : y.nrec_s;
     d.nrec_o = c ? x.nrec_o : y.nrec_o;  d.ncols = c ? x.ncols : y.ncols;  d.wrows = c ? x.wrows : y.wrows;
+    d.m0 = c ? x.m0 : y.m0;  d.n0 = c ? x.n0 : y.n0;
     return d;
   };
 
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     const int kb = PROBE == 4 ? 0 : kb_;  // probe 4: every block re-fetches block 0 (L2 hits, no stores)
     char* base = smem + s * kStageBytes;
     if (sub == 2) {
-      if (!kLeadDma || wave < 4)
+      if (kBW && (!kLeadDma || wave < 4))
         __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s),
                                                  SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, voff_s,
                                                  kb * (int)sa_sk * 4, 0, 0);
@@ -572,7 +582,36 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
   // stores: lane (j, g) owns row wm*128 + mf*16 + j, columns wn*64 + h*32 + g*8 .. +7 (h = 0, 1) of the tile
   const uint32_t orow_off_full = (uint32_t)(((int64_t)(wm * 128 + j) * ldc + wn * 64 + g * 8) * (int64_t)sizeof(OutT));
   const uint32_t orow_off_half = (uint32_t)(((int64_t)(wm * 64 + j) * ldc + wn * 64 + g * 8) * (int64_t)sizeof(OutT));
-  auto store_rows = [&](const TileDesc& d, const float (&accm)[4][4], int mf) {
+  // row / column scale modes: what the stores of a finished tile need (fetched at the top of the next tile's first K block)
+  struct Epi {
+    float sa[8];
+    v4f sb[2][2];
+    Vec<OutT, 8> bias[2];
+  };
+  auto load_epi = [&](const TileDesc& d) -> Epi {
+    Epi e;
+#pragma unroll
+    for (int mf = 0; mf < MS; ++mf) {
+      int m = d.m0 + wm * (MS * 16) + mf * 16 + j;
+      m = m < M ? m : M - 1;
+      e.sa[mf] = sa[m];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int n = d.n0 + wn * 64 + h * 32 + g * 8;  // (N % 8 == 0: the 8 columns are all in range or all dropped by the store)
+      n = n < N ? n : 0;
+      e.sb[h][0] = *reinterpret_cast<const v4f*>(sb + n);
+      e.sb[h][1] = *reinterpret_cast<const v4f*>(sb + n + 4);
+      if (bias != nullptr) {
+        e.bias[h] = load_vec<OutT, 8>(bias + n);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) e.bias[h][c] = (OutT)0.f;
+      }
+    }
+    return e;
+  };
+  auto store_rows = [&](const TileDesc& d, const auto& accm, int mf, const Epi& e) {
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
     const int soff = __builtin_amdgcn_readfirstlane(mf * 16 * (int)ldc * (int)sizeof(OutT));
     const uint32_t orow_off = MS == 8 ? orow_off_full : orow_off_half;
@@ -580,9 +619,19 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     for (int h = 0; h < 2; ++h) {
       Vec<OutT, 8> v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = (OutT)accm[2 * h][r];
-        v[4 + r] = (OutT)accm[2 * h + 1][r];
+      for (int c = 0; c < 8; ++c) {
+        if constexpr (kBW) {
+          v[c] = (OutT)accm[2 * h + (c >> 2)][c & 3];
+        } else {
+          // (the tile kernel's / the oracle's rounding order)
+          const float t = ((float)accm[2 * h + (c >> 2)][c & 3] * e.sa[mf]) * e.sb[h][c >> 2][c & 3];
+          if constexpr (MODE == MODE_FP8_ROWCOL) {
+            v[c] = (OutT)t;
+            if (bias != nullptr) v[c] = (OutT)((float)v[c] + (float)e.bias[h][c]);
+          } else {
+            v[c] = (bias != nullptr) ? (OutT)(t + (float)e.bias[h][c]) : (OutT)t;
+          }
+        }
       }
       // a column past the tile's valid ones would land in the next row: push those lanes out of range instead
       const uint32_t vo = (wn * 64 + h * 32 + g * 8 < d.ncols) ? orow_off + h * 32 * (uint32_t)sizeof(OutT) : 0x80000000u;
@@ -595,14 +644,16 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     }
   };
 
-  // Accumulators as scalars: the promotion FMAs below are inline asm on single registers.
-  float acc[8][4][4];
+  // Accumulators as scalars (blockwise: the promotion FMAs below are inline asm on single registers) or as the MFMAs'
+  // C / D operands (row / column scale modes).
+  typename std::conditional<kBW, float[8][4][4], AccT[8][4]>::type acc;
 #pragma unroll
   for (int mf = 0; mf < 8; ++mf)
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[mf][nf][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[mf][nf][r] = 0;
+  Epi epi;
 
   // The main loop is written as a fixed instruction stream: LDS reads, MFMAs and the block-scale FMAs are inline asm
   // (asm volatile statements keep their order; the compiler only allocates registers), the waits are counted by hand
@@ -621,8 +672,20 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
 #define SGLK_RD4(dst, addr, imm) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define SGLK_FRAG(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
 // cur[cb][nf] = n-fragment nf x m-fragment buffer mb (zero C: the partial of ONE 128-deep block)
-#define SGLK_MFMA(cb, nf, mb)                                                                                  \
-  if constexpr (HW_SCALE)                                                                                      \
+#define SGLK_MFMA(cb, nf, mb, row)                                                                             \
+  if constexpr (MODE == MODE_INT8_ROWCOL) {                                                                    \
+    asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0\n\tv_mfma_i32_16x16x64_i8 %0, %3, %4, %0"               \
+                 : "+v"(acc[row][nf])                                                                          \
+                 : "v"(nlo[nf]), "v"(mlo[mb]), "v"(nhi[nf]), "v"(mhi[mb]));                                    \
+  } else if constexpr (MODE == MODE_FP8_ROWCOL && HW_SCALE) {                                                  \
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"                  \
+                 : "+v"(acc[row][nf])                                                                          \
+                 : "v"(SGLK_FRAG(nlo[nf], nhi[nf])), "v"(SGLK_FRAG(mlo[mb], mhi[mb])), "v"(one_e8m0));         \
+  } else if constexpr (MODE == MODE_FP8_ROWCOL) {                                                              \
+    asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0"                                                  \
+                 : "+v"(acc[row][nf])                                                                          \
+                 : "v"(SGLK_FRAG(nlo[nf], nhi[nf])), "v"(SGLK_FRAG(mlo[mb], mhi[mb])));                        \
+  } else if constexpr (HW_SCALE)                                                                               \
     asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"                   \
                  : "=&v"(cur[cb][nf])                                                                          \
                  : "v"(SGLK_FRAG(nlo[nf], nhi[nf])), "v"(SGLK_FRAG(mlo[mb], mhi[mb])), "v"(one_e8m0));         \
@@ -632,8 +695,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
                  : "v"(SGLK_FRAG(nlo[nf], nhi[nf])), "v"(SGLK_FRAG(mlo[mb], mhi[mb])));
 // acc[row][nf][:] += cur[cb][nf][:] * scp
 #define SGLK_PROMOTE(row, cb, nf)                                                                              \
-  _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                             \
-      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[row][nf][r_]) : "v"(cur[cb][nf][r_]), "v"(scp));
+  if constexpr (kBW) {                                                                                         \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                                           \
+        asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[row][nf][r_]) : "v"(cur[cb][nf][r_]), "v"(scp));    \
+  }
 
   v4i nlo[4], nhi[4], mlo[2], mhi[2];
   float raw[2];
@@ -659,32 +724,39 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     } else {                                                                                                   \
       asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(mlo[cb_]), "+v"(mhi[cb_]), "+v"(raw[cb_]));                   \
     }                                                                                                          \
-    const float sc_ = raw[cb_] * sbv;                                                                          \
+    float sc_ = 0.f;                                                                                           \
+    if constexpr (kBW) sc_ = raw[cb_] * sbv;                                                                   \
     if constexpr (STORE && 2 * (mf) + 1 < (MS)) {                                                              \
       constexpr int r0_ = 2 * (mf) + 1 < (MS) ? 2 * (mf) : 0, r1_ = r0_ + 1; /* (in range also when discarded) */ \
-      store_rows(prv, acc[r0_], r0_);                                                                          \
-      store_rows(prv, acc[r1_], r1_);                                                                          \
+      store_rows(prv, acc[r0_], r0_, epi);                                                                     \
+      store_rows(prv, acc[r1_], r1_, epi);                                                                     \
       _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) _Pragma("unroll") for (int r = 0; r < 4; ++r) {         \
-        acc[r0_][nf][r] = 0.f;                                                                                 \
-        acc[r1_][nf][r] = 0.f;                                                                                 \
+        acc[r0_][nf][r] = 0;                                                                                   \
+        acc[r1_][nf][r] = 0;                                                                                   \
       }                                                                                                        \
-      asm volatile("" : "+v"(acc[r0_][0][0]), "+v"(acc[r1_][0][0]));                                           \
+      if constexpr (kBW) {                                                                                     \
+        asm volatile("" : "+v"(acc[r0_][0][0]), "+v"(acc[r1_][0][0]));                                         \
+      } else {                                                                                                 \
+        _Pragma("unroll") for (int nf = 0; nf < 4; ++nf) asm volatile("" : "+v"(acc[r0_][nf]), "+v"(acc[r1_][nf])); \
+      }                                                                                                        \
     }                                                                                                          \
-    SGLK_MFMA(cb_, 0, cb_)                                                                                     \
+    SGLK_MFMA(cb_, 0, cb_, (mf))                                                                               \
     SGLK_PROMOTE(prow_, pb_, 0)                                                                                \
     if ((mf) == 0) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(nlo[1]), "+v"(nhi[1]));                          \
-    SGLK_MFMA(cb_, 1, cb_)                                                                                     \
+    SGLK_MFMA(cb_, 1, cb_, (mf))                                                                               \
     SGLK_PROMOTE(prow_, pb_, 1)                                                                                \
     if (kDma && (mf) < 3) dma_piece(d1, kb1, s ^ 1, (mf) + 1, 0);                                              \
     if ((mf) == 0) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(nlo[2]), "+v"(nhi[2]));                          \
-    SGLK_MFMA(cb_, 2, cb_)                                                                                     \
+    SGLK_MFMA(cb_, 2, cb_, (mf))                                                                               \
     SGLK_PROMOTE(prow_, pb_, 2)                                                                                \
     if ((mf) == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(nlo[3]), "+v"(nhi[3]));                          \
-    SGLK_MFMA(cb_, 3, cb_)                                                                                     \
+    SGLK_MFMA(cb_, 3, cb_, (mf))                                                                               \
     SGLK_PROMOTE(prow_, pb_, 3)                                                                                \
     if (kDma && (mf) < 3) dma_piece(d1, kb1, s ^ 1, (mf) + 1, 1);                                              \
-    scp = sc_;                                                                                                 \
-    asm volatile("" : "+v"(scp));                                                                              \
+    if constexpr (kBW) {                                                                                       \
+      scp = sc_;                                                                                               \
+      asm volatile("" : "+v"(scp));                                                                            \
+    }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
 #define SGLK_BLOCK(STORE, MS)                                                                                  \
@@ -695,6 +767,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     const bool in1 = kb + 1 < nkb, in2 = kb + 2 < nkb;                                                         \
     const TileDesc d1 = pick(in1, cur_t, nxt), d2 = pick(in2, cur_t, nxt);                                     \
     const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
+    if constexpr (STORE && !kBW) epi = load_epi(prv);                                                          \
     {                                                                                                          \
       int fo = frag_off_a;                                                                                     \
       asm volatile("" : "+v"(fo));                                                                             \
@@ -704,7 +777,8 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
       SGLK_STEP(4, STORE, MS) SGLK_STEP(5, STORE, MS) SGLK_STEP(6, STORE, MS)                                  \
     }                                                                                                          \
     /* the block's barrier: next block landed everywhere, nobody reads stage s any more */                    \
-    float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
+    float sbv_next = 0.f;                                                                                      \
+    if constexpr (kBW) sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                \
     if constexpr (PROBE == 5) {                                                                                \
       const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memtime();                                              \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(mlo[1]), "+v"(mhi[1]), "+v"(raw[1]) : : "memory");   \
@@ -728,33 +802,36 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     /* the MFMA just issued has consumed) and the first DMA pieces of the block after it                      */ \
     {                                                                                                          \
       constexpr int kLast = (MS) - 1;                                                                          \
-      const float sc_ = raw[1] * sbv;                                                                          \
+      float sc_ = 0.f;                                                                                         \
+      if constexpr (kBW) sc_ = raw[1] * sbv;                                                                   \
       int foa = frag_off_a, fob = frag_off_b;                                                                  \
       asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
       uint32_t nb_lo = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fob, nb_hi = nb_lo ^ 64u;   \
       uint32_t na_lo = nbase + (uint32_t)(wm * d1.wrows * 128) + (uint32_t)foa, na_hi = na_lo ^ 64u;           \
       uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * d1.wrows * 4) + (uint32_t)((foa >> 7) << 2);    \
       asm volatile("" : "+v"(nb_lo), "+v"(nb_hi), "+v"(na_lo), "+v"(na_hi), "+v"(nts));                        \
-      SGLK_MFMA(1, 0, 1)                                                                                       \
+      SGLK_MFMA(1, 0, 1, kLast)                                                                                \
       SGLK_PROMOTE(kLast - 1, 0, 0)                                                                            \
       SGLK_RD16(nlo[0], nb_lo, kNfImm[0]);  SGLK_RD16(nhi[0], nb_hi, kNfImm[0]);                               \
       SGLK_RD16(mlo[0], na_lo, 0);          SGLK_RD16(mhi[0], na_hi, 0);                                       \
       SGLK_RD4(raw[0], nts, 0);                                                                                \
-      SGLK_MFMA(1, 1, 1)                                                                                       \
+      SGLK_MFMA(1, 1, 1, kLast)                                                                                \
       SGLK_PROMOTE(kLast - 1, 0, 1)                                                                            \
       SGLK_RD16(nlo[1], nb_lo, kNfImm[1]);  SGLK_RD16(nhi[1], nb_hi, kNfImm[1]);                               \
       if (kDma) dma_piece(d2, kb2, s, 0, 0);                                                                   \
-      SGLK_MFMA(1, 2, 1)                                                                                       \
+      SGLK_MFMA(1, 2, 1, kLast)                                                                                \
       SGLK_PROMOTE(kLast - 1, 0, 2)                                                                            \
       SGLK_RD16(nlo[2], nb_lo, kNfImm[2]);  SGLK_RD16(nhi[2], nb_hi, kNfImm[2]);                               \
       if (kDma) dma_piece(d2, kb2, s, 0, 1);                                                                   \
-      SGLK_MFMA(1, 3, 1)                                                                                       \
+      SGLK_MFMA(1, 3, 1, kLast)                                                                                \
       SGLK_PROMOTE(kLast - 1, 0, 3)                                                                            \
       SGLK_RD16(nlo[3], nb_lo, kNfImm[3]);  SGLK_RD16(nhi[3], nb_hi, kNfImm[3]);                               \
       if (kDma) dma_piece(d2, kb2, s, 0, 2);                                                                   \
-      scp = sc_;                                                                                               \
-      sbv = sbv_next;                                                                                          \
-      asm volatile("" : "+v"(scp));                                                                            \
+      if constexpr (kBW) {                                                                                     \
+        scp = sc_;                                                                                             \
+        sbv = sbv_next;                                                                                        \
+        asm volatile("" : "+v"(scp));                                                                          \
+      }                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
     }                                                                                                          \
     ++gblk;                                                                                                    \
@@ -770,7 +847,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
     dma_piece(cur_t, 0, 0, part, 1);
   }
   dma_piece(cur_t, 0, 0, 0, 2);
-  sbv = cur_t.sbw[0];
+  sbv = kBW ? cur_t.sbw[0] : 0.f;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   asm volatile("" : "+v"(sbv));
   {
@@ -804,10 +881,18 @@ __global__ __launch_bounds__(512) void gemm_fp8_blockwise_persist_kernel(
 #undef SGLK_STEP
   // the reads and DMA issued by the last step have no consumer: drain them; promote the last m-step; store the last unit
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(cur[1][0]), "+v"(cur[1][1]), "+v"(cur[1][2]), "+v"(cur[1][3]));  // (MFMA -> VALU)
+  if constexpr (kBW) {
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(cur[1][0]), "+v"(cur[1][1]), "+v"(cur[1][2]), "+v"(cur[1][3]));  // (MFMA -> VALU)
+  } else {
+    epi = load_epi(prv);
+    // (the last MFMAs' results are read by compiler-scheduled VALU code: give the matrix pipe time to retire them)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) asm volatile("" : "+v"(acc[MS - 1][nf]));
+  }
   SGLK_PROMOTE(MS - 1, 1, 0) SGLK_PROMOTE(MS - 1, 1, 1) SGLK_PROMOTE(MS - 1, 1, 2) SGLK_PROMOTE(MS - 1, 1, 3)
 #pragma unroll
-  for (int mf = 0; mf < MS; ++mf) store_rows(prv, acc[mf], mf);
+  for (int mf = 0; mf < MS; ++mf) store_rows(prv, acc[mf], mf, epi);
   if constexpr (PROBE == 5) {
     if (stamps != nullptr && gblk >= 60) stamps[((int64_t)blockIdx.x * 8 + wave) * 64 + lane] = stampv;  // (window complete)
   }
@@ -1080,7 +1165,8 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   const unsigned pgrid = grid < (unsigned)num_cus() ? ((grid + 7) / 8) * 8 : (unsigned)num_cus();
   // (the row-scale DMA addresses its K blocks and rows with 32-bit byte offsets inside one buffer resource)
   const bool persist_ok = K / BK >= 2 && N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)out % 16 == 0 && ldc < (1ll << 22) &&
-                          ((K / BK - 1) * sa_sk + 256 * sa_sm) * 4 < (1ll << 31);
+                          ((K / BK - 1) * sa_sk + 256 * sa_sm) * 4 < (1ll << 31) &&
+                          (MODE == MODE_BLOCKWISE || ((uintptr_t)sb % 16 == 0 && (uintptr_t)bias % 16 == 0));
   // does any XCD cut its last partial round into half tiles (same rule as in the kernel)?
   bool tail_halves = false;
   {
@@ -1092,7 +1178,10 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   }
   // few rows: the weight-streaming kernel (variant 5 forces it, 7 forces it without the K split, 6 forbids it)
   {
-    if ((M <= 128 && g_gemm_variant == 4) || g_gemm_variant == 5 || g_gemm_variant == 7) {
+    // (up to 512 rows also when the tile kernel would have few units: M = 256, N = 4096, K = 14336 is 32 units of 128 x
+    // 256 - 134 us there, 51 us here; from ~96 units on the tile kernel wins)
+    const bool few = M <= 128 || (M <= 512 && cdiv(M, 128) * cdiv(N, 256) <= 80);
+    if ((few && g_gemm_variant == 4) || g_gemm_variant == 5 || g_gemm_variant == 7) {
 #define SGLK_GO_SKINNY(MF, KS)                                                                               \
   {                                                                                                          \
     const dim3 sg((unsigned)cdiv(N, 16 * (4 / KS)), (unsigned)cdiv(M, 16 * MF));                             \
@@ -1132,17 +1221,17 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n)
 #define SGLK_GO_PIPE(V, H, P)                                                                                \
   if (all_halves) {                                                                                          \
-    gemm_fp8_blockwise_persist_kernel<OutT, H, P, 4><<<hgrid, 512, 0, st>>>(                                 \
-        (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,     \
-        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_gemm_stamps);                                     \
+    gemm_8bit_persist_kernel<OutT, MODE, H, P, 4><<<hgrid, 512, 0, st>>>(                                 \
+        (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
+        ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_gemm_stamps);                                     \
   } else {                                                                                                   \
-    gemm_fp8_blockwise_persist_kernel<OutT, H, P, 8><<<pgrid, 512, 0, st>>>(                                 \
-        (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,     \
-        sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps);                                     \
+    gemm_8bit_persist_kernel<OutT, MODE, H, P, 8><<<pgrid, 512, 0, st>>>(                                 \
+        (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
+        ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps);                                     \
     if (tail_halves)                                                                                         \
-      gemm_fp8_blockwise_persist_kernel<OutT, H, P, 4><<<pgrid, 512, 0, st>>>(                               \
-          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc,   \
-          sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps);                                   \
+      gemm_8bit_persist_kernel<OutT, MODE, H, P, 4><<<pgrid, 512, 0, st>>>(                               \
+          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
+          ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps);                                   \
   }
 #ifdef SGLK_PROBES
 #define SGLK_GO(V, H)                                                                                        \
@@ -1162,14 +1251,14 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       default: SGLK_GO_PIPE(V, H, 0); break;                                                                 \
     }                                                                                                        \
   } else {                                                                                                   \
-    SGLK_GO_VAR(V, H, 0);                                                                                    \
+    if (variant == 0 || variant == 1) { SGLK_GO_VAR(V, H, 0); } else { SGLK_GO_PIPE(V, H, 0) }               \
   }
 #else
 #define SGLK_GO(V, H)                                                                                        \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
     if (variant == 1) { SGLK_GO_VAR(V, H, 1); } else { SGLK_GO_PIPE(V, H, 0) }                               \
   } else {                                                                                                   \
-    SGLK_GO_VAR(V, H, 0);                                                                                    \
+    if (variant == 1) { SGLK_GO_VAR(V, H, 0); } else { SGLK_GO_PIPE(V, H, 0) }                               \
   }
 #endif
   if (vec) {
