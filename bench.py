@@ -135,7 +135,7 @@ def side_metrics(sgl_kernel, dev):
     g = torch.Generator(device="cpu").manual_seed(3)
     bw = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev).t()
     sbw = (torch.rand(N // 128, K // 128, generator=g) * 1e-3 + 1e-4).to(dev).t()
-    for m in (1, 16, 64, 256, 1024):
+    for m in (1, 16, 64, 128, 256, 1024):
         am = ((torch.rand(m, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev)
         sam = (torch.rand(K // 128, m, generator=g) * 1e-3 + 1e-4).to(dev).t()
         ms = timeit(lambda: sgl_kernel.fp8_blockwise_scaled_mm(am, bw, sam, sbw, torch.bfloat16), iters=50)
@@ -146,6 +146,25 @@ def side_metrics(sgl_kernel, dev):
             sb1 = torch.rand(N, 1, device=dev) * 1e-3 + 1e-4
             ms = timeit(lambda: sgl_kernel.fp8_scaled_mm(am, bw, sa1, sb1, torch.bfloat16), iters=50)
             out[f"fp8_scaled_mm_M{m}_us"] = round(ms * 1e3, 1)
+    # fp8_scaled_mm / int8_scaled_mm at the headline shape (row x column scales: the persistent pipeline without block scales)
+    am = ((torch.rand(M, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev)
+    sa1 = torch.rand(M, 1, device=dev) * 1e-3 + 1e-4
+    sb1 = torch.rand(N, 1, device=dev) * 1e-3 + 1e-4
+    ms = timeit(lambda: sgl_kernel.fp8_scaled_mm(am, bw, sa1, sb1, torch.bfloat16), iters=30)
+    out["fp8_scaled_mm_M4096_TFLOPs"] = round(2.0 * M * N * K / ms / 1e9, 1)
+    ai = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(dev)
+    bi = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(dev).t()
+    ms = timeit(lambda: sgl_kernel.int8_scaled_mm(ai, bi, sa1, sb1, torch.bfloat16), iters=30)
+    out["int8_scaled_mm_M4096_TOPs"] = round(2.0 * M * N * K / ms / 1e9, 1)
+    del bw, sbw, ai, bi, am
+    # the down projection of the same layer at decode: N=4096, K=14336 (few n-tiles: K split over the waves of a workgroup)
+    bw = ((torch.rand(K, N, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev).t()
+    sbw = (torch.rand(K // 128, N // 128, generator=g) * 1e-3 + 1e-4).to(dev).t()
+    for m in (1, 16, 64):
+        am = ((torch.rand(m, N, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev)
+        sam = (torch.rand(N // 128, m, generator=g) * 1e-3 + 1e-4).to(dev).t()
+        ms = timeit(lambda: sgl_kernel.fp8_blockwise_scaled_mm(am, bw, sam, sbw, torch.bfloat16), iters=50)
+        out[f"fp8_blockwise_gemm_down_M{m}_us"] = round(ms * 1e3, 1)
     del bw, sbw
     # flash_mla_decode, BASELINE configs[3]: bs=128, seq=8192, kv_lora 512 + rope 64, paged (64), bf16.
     # Bytes as benchmark/bench_flash_mla_decode.py:109-115 of the reference: q + kv cache + table + seq_lens + out.
