@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
                                                         int K, int group_shift, int probe) {
   // probe (libsglk_probes.so only; 0 in the release library): timing experiments with garbage results -
   // 1: one activation row for all 16 m rows, 2: no output stores, 4: non-temporal weight loads, 8: scales read once,
-  // 16: no weight expansion / MFMAs (stream only), 32: no barrier, 64: no activation staging
+  // 16: no weight expansion / MFMAs (stream only), 32: no barrier, 64: no activation staging, 128: no MFMAs (expansion and
+  // LDS reads kept), 256: no expansion
 #ifndef SGLK_PROBES
   probe = 0;
 #endif
@@ -400,19 +401,28 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
     if (probe & 16) {
 #pragma unroll
       for (int nt = 0; nt < NW; ++nt) acc[0][nt][0] += __uint_as_float(wd[nt][0] ^ wd[nt][1] ^ wd[nt][2] ^ wd[nt][3]) + (SV ? sv_get(sv_cur[nt], u) : (float)sc[nt][0]);
-      continue;
-    }
+    } else {
+    // (requesting the activation fragments of the whole block up front, ahead of the first step's expansion, measured no
+    // faster on the decode tiles: 142 -> 147 us)
     static_for4([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // (k steps past K multiply zero activations: no tail branch)
       v4i wf[NW];
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) wf[nt] = !is_int4 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
+      for (int nt = 0; nt < NW; ++nt) {
+        if (probe & 256) wf[nt] = (v4i){(int)wd[nt][j], (int)wd[nt][j] + 1, (int)wd[nt][j] + 2, (int)wd[nt][j] + 3};
+        else wf[nt] = !is_int4 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
         const int slot = kTranspose ? 4 * j + g : ((0x84C0 >> (4 * g)) & 15) + j;  // (see store_a)
         const v4i af = *reinterpret_cast<const v4i*>(abase + row * AROW + ((slot ^ l15) << 4));
+        if (probe & 128) {
+#pragma unroll
+          for (int nt = 0; nt < NW; ++nt) part[mt][nt][0] += __uint_as_float((uint32_t)(af[0] ^ af[1] ^ af[2] ^ af[3] ^ wf[nt][0] ^ wf[nt][1] ^ wf[nt][2] ^ wf[nt][3]));
+          continue;
+        }
         if constexpr (is_int4) asum[mt] = W4<T>::mma(af, ones, asum[mt]);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
@@ -454,6 +464,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
       // the body is one basic block now: without fences the scheduler interleaves all steps and spills
       __builtin_amdgcn_sched_barrier(0);
     });
+    }  // (probe 16)
     // Refill ring slot u with block kb + kD AFTER the last use of what it held: requested before (at the top of the
     // block) the new value had to live in other registers while the old one was still being expanded, and the loop end
     // moved all kD slots back into place with copies - each copy waits for the load into its source, so the whole ring was
@@ -520,7 +531,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // GroupGemmW4A16Xe20.cpp:266-277). The row counts are ragged around the average, and a second row block of an expert
   // streams its weights again, so a tile is chosen that holds ~1.5x the average; 64-row tiles are the largest whose K loop
   // stays free of register spills.
-  const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 1 : g_w4_mt == 2 ? 32 : 1000) : total_m / E;
+  const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 1 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 200 : 1000) : total_m / E;
   // (16-column tiles per wave - 64 columns per workgroup, twice the workgroups - were slower at every decode shape: the
   // activation staging and the barrier are per workgroup, 155 vs 145 us at N = 28672, K = 4096)
   // (the 16 / 32-row tiles fetch the scales of four 128-deep blocks with one 8-byte load: groups of 128, K % 512 == 0)
@@ -535,12 +546,15 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   const bool narrow = group_shift == 7 && K % 1024 == 0 && est_row_blocks * cdiv(N, 128) <= 384;
   if (avg <= 10) {
     if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+    // (eight blocks in flight per wave at 128 columns: 175 registers, two waves per SIMD instead of three - no faster)
     return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   }
   if (avg <= 160) {  // (avg 64: 32-row tile 321 + 198 us, 64-row 352 + 230; avg 128: 571 + 352 vs 596 + 396; 256: 1021 + 615 vs 1008 + 471)
     if (narrow) return launch<T, 2, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
     return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   }
+  // (128-row tiles and 64-column wave tiles both measured slower at 512 rows per expert: 1 wave per SIMD; the prefill side is
+  // bound by L2 traffic - 64 x 128 tiles re-read activations 224 times and weights 8 times, 11 GB at ~10 TB/s)
   return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
 }
 
