@@ -173,7 +173,7 @@ def side_metrics(sgl_kernel, dev):
     cache = torch.randn(bs * n_pages, page, 576, device=dev, dtype=torch.bfloat16)
     table = torch.randint(0, bs * n_pages, (bs, n_pages), device=dev, dtype=torch.int32)
     seq_lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
-    for H in (128, 16):
+    for H in (128, 64, 32, 16):  # the head counts of the reference benchmark (bench_flash_mla_decode.py:26-35)
         qq = torch.randn(bs, H, 576, device=dev, dtype=torch.bfloat16) * 100
         q_nope, q_pe = qq[..., :512], qq[..., 512:].contiguous()
         ws = torch.empty(sgl_kernel.flash_mla_get_workspace_size(seq, bs, H, page, -1), device=dev, dtype=torch.uint8)

@@ -1212,7 +1212,9 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
     }
   }
   // up to 512 rows the 128-row tiling (every tile as two halves) fills more CUs: see the kernel comment
-  const bool all_halves = M <= 512 && g_gemm_variant == 4;  // (M = 1024: 77 us against 64 us with 256-row tiles)
+  // (M = 1024, N = 14336: 77 us against 64 us with 256-row tiles; but when the 256-row tiles cover at most half of the CUs -
+  // M = 1024, N = 4096 is 64 tiles - halves double the workgroups at 0.6x the time each)
+  const bool all_halves = (M <= 512 || grid <= (unsigned)num_cus() / 2) && g_gemm_variant == 4;
   const unsigned hgrid = 2 * grid < (unsigned)num_cus() ? ((2 * grid + 7) / 8) * 8 : (unsigned)num_cus();
   const int variant = (!persist_ok && g_gemm_variant != 0 && g_gemm_variant != 1) ? 1 : g_gemm_variant;
 #define SGLK_GO_VAR(V, H, VAR)                                                                               \
