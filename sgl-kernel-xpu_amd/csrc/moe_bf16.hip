@@ -50,13 +50,16 @@ __device__ __forceinline__ float gated_act(float x, float y) {
   }
 }
 
-template <typename T, int MT, int NW, int FUSE>
-__global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, const T* __restrict__ act,
+template <typename T, int MT, int NW, int FUSE, int WV = 4>  // WV waves per workgroup (8: the prefill tile, 128 x 256)
+__global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, const T* __restrict__ act,
                                                        const T* __restrict__ w, const float* __restrict__ bias,
                                                        const int32_t* __restrict__ rows_per_expert, int E, int N, int K,
                                                        int64_t ldb, int64_t w_stride_e) {
   constexpr int BM = 16 * MT;
-  constexpr int BN = 64 * NW;
+  constexpr int BN = 16 * NW * WV;
+  constexpr int NT_ = 64 * WV;       // threads
+  constexpr int AL = MT * 4 / WV;    // 16-byte activation chunks per thread and block
+  static_assert(MT * 4 % WV == 0, "the chunks of a block must divide over the threads");
   __shared__ __attribute__((aligned(256))) char smem[2 * BM * 256];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,26 +88,26 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
   // (a scalar base per workgroup and 32-bit per-thread offsets; the zeroing of chunks past K happens on the way to LDS and
   // not behind the load: a select right after a load waits for it on the spot, with every younger load in flight)
   const T* act_blk = act + (int64_t)m0 * K;
-  uint32_t aoff[MT];
+  uint32_t aoff[AL];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int idx = i * 256 + tid;
+  for (int i = 0; i < AL; ++i) {
+    const int idx = i * NT_ + tid;
     const int row = idx >> 4, c = idx & 15;
     aoff[i] = (uint32_t)(row < m_valid ? row : m_valid - 1) * (uint32_t)K + c * 8;
   }
-  auto load_a = [&](int kb, v4i (&r)[MT]) {
+  auto load_a = [&](int kb, v4i (&r)[AL]) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int c = (i * 256 + tid) & 15;
+    for (int i = 0; i < AL; ++i) {
+      const int c = (i * NT_ + tid) & 15;
       const bool in = kb * 128 + c * 8 < K;  // past K: read k = 0 instead (zeroed in store_a; no branch)
       r[i] = *reinterpret_cast<const v4i*>(act_blk + (aoff[i] + (in ? (uint32_t)kb * 128u : 0u)));
     }
   };
-  auto store_a = [&](int buf, int kb, const v4i (&r)[MT]) {
+  auto store_a = [&](int buf, int kb, const v4i (&r)[AL]) {
     char* base = smem + buf * (BM * 256);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int idx = i * 256 + tid;
+    for (int i = 0; i < AL; ++i) {
+      const int idx = i * NT_ + tid;
       const int row = idx >> 4, c = idx & 15;
       const bool in = kb * 128 + c * 8 < K;
       const v4i zero = {0, 0, 0, 0};
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
     for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   const int nkb = (K + 127) >> 7;
-  v4i wq_[2][NW][4], aq_[2][MT];
+  v4i wq_[2][NW][4], aq_[2][AL];
   // (activation requests in front of the weight ring's, as in the steady state: the waits the compiler counts for the loop
   // are the worse of the two ways into it)
   // (and fenced: the scheduler otherwise interleaves the two slots' requests, slot 0 then looks as young as slot 1)
@@ -209,16 +212,16 @@ __global__ __launch_bounds__(256) void moe_bf16_kernel(T* __restrict__ out, cons
   }
 }
 
-template <typename T, int MT, int NW>
+template <typename T, int MT, int NW, int WV = 4>
 static int launch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
                   int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
-  constexpr int BM = 16 * MT, BN = 64 * NW;
+  constexpr int BM = 16 * MT, BN = 16 * NW * WV;
   const bool gated = fuse == FUSE_SILU || fuse == FUSE_GELU;
   const int64_t wgs = moe_tile_launch_size(total_m, E, BM, gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN));
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20: problem too large for one launch");
   dim3 grid((unsigned)wgs);
 #define SGLK_GO(F) \
-  moe_bf16_kernel<T, MT, NW, F><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E, N, K, ldb, w_stride_e)
+  moe_bf16_kernel<T, MT, NW, F, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E, N, K, ldb, w_stride_e)
   switch (fuse) {
     case FUSE_SILU: SGLK_GO(FUSE_SILU); break;
     case FUSE_GELU: SGLK_GO(FUSE_GELU); break;
@@ -229,6 +232,12 @@ static int launch(hipStream_t st, void* out, const void* act, const void* w, con
   return check_launch("moe_grouped_mm_nt_xe20");
 }
 
+#ifdef SGLK_PROBES
+static int g_bf16_wv = 8;
+#else
+constexpr int g_bf16_wv = 8;
+#endif
+
 template <typename T>
 static int dispatch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
                     int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
@@ -237,6 +246,8 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* w, c
   if (avg <= 10) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   if (avg <= 24) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   if (avg <= 96) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  // (eight waves share the staged activation tile, 128 x 256: half the activation traffic and barriers per flop)
+  if (g_bf16_wv != 4) return launch<T, 8, 2, 8>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   return launch<T, 8, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
 }
 
@@ -264,3 +275,7 @@ extern "C" int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* 
   return dispatch<f16>(st, out, activations, weights, bias, rows_per_expert, total_m, (int)n_experts, (int)N, (int)K, ldb,
                        weight_stride_e, fused_act);
 }
+
+#ifdef SGLK_PROBES
+extern "C" SGLK_API void sglk_debug_set_moe_bf16_waves(int wv) { sglk::g_bf16_wv = wv; }
+#endif

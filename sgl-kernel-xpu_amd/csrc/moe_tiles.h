@@ -33,7 +33,11 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
 }
 
 // every wave of the workgroup computes the same (wave-uniform) answer
-__device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ rows_per_expert, int E, int BM, int NB) {
+// cols_fast: consecutive tiles (= the workgroups resident on one XCD at a time) walk the column blocks of ONE row block and
+// share its activations in that XCD's L2; otherwise they walk the row blocks of one column block. The larger operand of a
+// tile should be the shared one: 64 rows x K 16-bit activations against 128 columns x K / 2 bytes of 4-bit weights.
+__device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ rows_per_expert, int E, int BM, int NB,
+                                                 bool cols_fast = false) {
   const int lane = threadIdx.x & 63;
   int MB = 0;
   for (int c0 = 0; c0 < E; c0 += 64) {
@@ -48,7 +52,7 @@ __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ row
   int L = blockIdx.x;
   if (L >= real) return t;
   if (L < real8) L = (L & 7) * (real8 >> 3) + (L >> 3);
-  const int mblk = L % MB;
+  const int mblk = cols_fast ? L / NB : L % MB;
   int e = 0, row0 = 0, rows_e = 0, blk = 0, base_b = 0, base_r = 0;
   for (int c0 = 0; c0 < E; c0 += 64) {
     const int r = c0 + lane < E ? rows_per_expert[c0 + lane] : 0;
@@ -71,7 +75,7 @@ __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ row
   blk = __builtin_amdgcn_readfirstlane(blk);
   t.m0 = __builtin_amdgcn_readfirstlane(row0) + blk * BM;
   t.m_valid = __builtin_amdgcn_readfirstlane(rows_e) - blk * BM;
-  t.col_block = L / MB;
+  t.col_block = cols_fast ? L % NB : L / MB;
   return t;
 }
 

@@ -146,21 +146,23 @@ __device__ __forceinline__ void static_for4(F&& f) {
 
 // PB: scale groups per 128-deep block (4, 2, 1 for groups 32, 64, >= 128); FMT: 0 = int4, two's-complement codes (scales
 // of type T), 2 = int4, unsigned codes with zero points of type T, 1 = mxfp4 (scales = E8M0 bytes, group 32, no zeros)
-template <typename T, int MT, int NW, int PB, int FMT>
-__global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
+template <typename T, int MT, int NW, int PB, int FMT, int WV = 4>  // WV waves per workgroup (8: the prefill tile, 64 x 256)
+__global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
                                                         const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
                                                         const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
                                                         int K, int group_shift, int probe) {
   // probe (libsglk_probes.so only; 0 in the release library): timing experiments with garbage results -
   // 1: one activation row for all 16 m rows, 2: no output stores, 4: non-temporal weight loads, 8: scales read once,
-  // 16: no weight expansion / MFMAs (stream only), 32: no barrier, 64: no activation staging, 128: no MFMAs (expansion and
-  // LDS reads kept), 256: no expansion
+  // 16: no weight expansion / MFMAs (stream only), 32: no barrier, 64: no activation staging, 512: row blocks fastest in the
+  // tile order also for the 64-row tiles. (Probes inside the MFMA steps - no MFMAs, no expansion - were used once and removed:
+  // their branches cost the diagnostic build 35 % at prefill sizes.)
 #ifndef SGLK_PROBES
   probe = 0;
 #endif
   constexpr int BM = 16 * MT;
-  constexpr int BN = 64 * NW;
+  constexpr int BN = 16 * NW * WV;
+  constexpr int NT_ = 64 * WV;  // threads
   // kD: 128-deep blocks of weights / scales in flight per wave (register ring, the K loop is unrolled kD times).
   // (decode tiles: 8 KiB of weights in flight per wave; the large tiles: registers. A spill in this loop is reloaded
   // through scratch, i.e. behind an s_waitcnt vmcnt(0) that empties the rings: build.py's check_isa rejects one.)
@@ -182,7 +184,10 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
   const int l15 = lane & 15, g = lane >> 4;
 
   // ---- which (expert, block of its rows, column block): see moe_tiles.h
-  const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, (N + BN - 1) / BN);
+  // (64-row tiles of a projection with more k than columns: the column blocks of a row block run together and share its
+  // activations in L2 - 731 against 755 us for the Mixtral down projection at 512 rows per expert; the gate / up projection
+  // measured the other way round, 1609 against 1706 us. Probe 512 flips the choice.)
+  const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, (N + BN - 1) / BN, MT >= 4 && ((N < K) != ((probe & 512) != 0)));
   if (tile.expert < 0) return;
   const int e = tile.expert, m0 = tile.m0, m_valid = tile.m_valid;
   const int n_base = tile.col_block * BN + wave * (NW * 16);
@@ -213,18 +218,19 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
   // (a scalar base per workgroup and 32-bit per-thread offsets: 64-bit per-thread row addresses of the large tiles were
   // spilled and reloaded inside the K loop)
   const T* act_blk = act + (int64_t)m0 * K;
-  constexpr int AL = MT * AS;        // 16-byte chunks per thread and stage: chunk q = i * 256 + tid of [BM][16 AS]
+  constexpr int AL = MT * AS * 4 / WV;  // 16-byte chunks per thread and stage: chunk q = i * NT_ + tid of [BM][16 AS]
+  static_assert(MT * AS * 4 % WV == 0, "stage chunks must divide over the threads");
   uint32_t aoff[AL];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
-    const int q = i * 256 + tid;
+    const int q = i * NT_ + tid;
     const int row = q / (16 * AS), c = q % (16 * AS);
     aoff[i] = (uint32_t)((probe & 1) ? 0 : row < m_valid ? row : m_valid - 1) * (uint32_t)K + c * 8;
   }
   auto load_a = [&](int st, v4i (&r)[AL]) {  // stage st = blocks st * AS .. + AS - 1
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      const int c = (i * 256 + tid) % (16 * AS);
+      const int c = (i * NT_ + tid) % (16 * AS);
       const bool in = st * (128 * AS) + c * 8 < K;  // past K: read k = 0 instead (zeroed on the way to LDS; no branch)
       r[i] = *reinterpret_cast<const v4i*>(act_blk + (aoff[i] + (in ? (uint32_t)st * (128u * AS) : 0u)));
     }
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
     char* base = smem + buf * (BM * AROW);
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      const int q = i * 256 + tid;
+      const int q = i * NT_ + tid;
       const int row = q / (16 * AS), c = q % (16 * AS);
       const bool in = st * (128 * AS) + c * 8 < K;
       const v4i zero = {0, 0, 0, 0};
@@ -409,20 +415,12 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __
       // (k steps past K multiply zero activations: no tail branch)
       v4i wf[NW];
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) {
-        if (probe & 256) wf[nt] = (v4i){(int)wd[nt][j], (int)wd[nt][j] + 1, (int)wd[nt][j] + 2, (int)wd[nt][j] + 3};
-        else wf[nt] = !is_int4 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
-      }
+      for (int nt = 0; nt < NW; ++nt) wf[nt] = !is_int4 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
         const int slot = kTranspose ? 4 * j + g : ((0x84C0 >> (4 * g)) & 15) + j;  // (see store_a)
         const v4i af = *reinterpret_cast<const v4i*>(abase + row * AROW + ((slot ^ l15) << 4));
-        if (probe & 128) {
-#pragma unroll
-          for (int nt = 0; nt < NW; ++nt) part[mt][nt][0] += __uint_as_float((uint32_t)(af[0] ^ af[1] ^ af[2] ^ af[3] ^ wf[nt][0] ^ wf[nt][1] ^ wf[nt][2] ^ wf[nt][3]));
-          continue;
-        }
         if constexpr (is_int4) asum[mt] = W4<T>::mma(af, ones, asum[mt]);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[mt][nt] = W4<T>::mma(af, wf[nt], part[mt][nt]);
@@ -498,26 +496,26 @@ static int g_w4_probe = 0, g_w4_mt = 0;
 constexpr int g_w4_probe = 0, g_w4_mt = 0;
 #endif
 
-template <typename T, int MT, int NW, int PB, int FMT = 0>
+template <typename T, int MT, int NW, int PB, int FMT = 0, int WV = 4>
 static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
-  constexpr int BM = 16 * MT, BN = 64 * NW;
+  constexpr int BM = 16 * MT, BN = 16 * NW * WV;
   const int64_t wgs = moe_tile_launch_size(total_m, E, BM, cdiv(N, BN));
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20_w4a16: problem too large for one launch");
   dim3 grid((unsigned)wgs);
-  moe_w4a16_kernel<T, MT, NW, PB, FMT><<<grid, 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
+  moe_w4a16_kernel<T, MT, NW, PB, FMT, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
                                                              rows, E, N, K, group_shift, g_w4_probe);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
 }
 
-template <typename T, int MT, int NW>
+template <typename T, int MT, int NW, int WV = 4>
 static int launch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
   if (group_shift < 0)  // mxfp4: E8M0 scales per 32
-    return launch_pb<T, MT, NW, 4, 1>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 5);
+    return launch_pb<T, MT, NW, 4, 1, WV>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 5);
 #define SGLK_W4_GO(PB)                                                                                                    \
-  return zeros != nullptr ? launch_pb<T, MT, NW, PB, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift) \
-                          : launch_pb<T, MT, NW, PB, 0>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift)
+  return zeros != nullptr ? launch_pb<T, MT, NW, PB, 2, WV>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift) \
+                          : launch_pb<T, MT, NW, PB, 0, WV>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift)
   if (group_shift == 5) SGLK_W4_GO(4);
   if (group_shift == 6) SGLK_W4_GO(2);
   SGLK_W4_GO(1);
@@ -549,12 +547,16 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
     // (eight blocks in flight per wave at 128 columns: 175 registers, two waves per SIMD instead of three - no faster)
     return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   }
+  // (128-row tiles and 64-column wave tiles both measured slower at 512 rows per expert: 1 wave per SIMD; the prefill side is
+  // bound by L2 traffic - 64 x 128 tiles re-read activations 224 times and weights 8 times, 11 GB at ~10 TB/s)
+  // eight waves share a staged activation tile (64 x 256): half the activation traffic and barriers per flop of the 64 x 128
+  // tile - 512 rows per expert 1.90 -> 1.61 ms (gate / up), 0.84 -> 0.73 ms (down); 128 rows 0.49 (0.48 with 32-row tiles) -> 0.43 ms
+  if (g_w4_mt == 8 || (g_w4_mt == 0 && avg >= 112 && N % 256 == 0))
+    return launch<T, 4, 2, 8>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   if (avg <= 160) {  // (avg 64: 32-row tile 321 + 198 us, 64-row 352 + 230; avg 128: 571 + 352 vs 596 + 396; 256: 1021 + 615 vs 1008 + 471)
     if (narrow) return launch<T, 2, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
     return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
   }
-  // (128-row tiles and 64-column wave tiles both measured slower at 512 rows per expert: 1 wave per SIMD; the prefill side is
-  // bound by L2 traffic - 64 x 128 tiles re-read activations 224 times and weights 8 times, 11 GB at ~10 TB/s)
   return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
 }
 
