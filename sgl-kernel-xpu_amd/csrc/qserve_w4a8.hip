@@ -254,27 +254,38 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i) *reinterpret_cast<v4i*>(&as[buf][h][aoff[i]]) = r[2 * h + i];
   };
-  uint32_t wq_[2][2][4], sq_[2][2][4];
+  // (weights four steps ahead instead of two measured the same: 153 us at 4096^3)
+  constexpr int kD = 2;
+  uint32_t wq_[kD][2][4], sq_[kD][2][4];
   v4i aq_[4];
   load_a(0, aq_);
   store_a(0, aq_);
   load_a(1, aq_);
   __builtin_amdgcn_sched_barrier(0);
-  load_w(0, wq_[0], sq_[0]);
-  __builtin_amdgcn_sched_barrier(0);
-  load_w(1, wq_[1], sq_[1]);
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int ks0 = 0; ks0 < nks; ks0 += 2) {
-    const int st = ks0 >> 1, buf = st & 1;
-    // stage st is in LDS, everyone is done reading the other buffer (LDS-only barrier: the loads in flight stay there)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    store_a(buf ^ 1, aq_);
-    load_a(st + 2, aq_);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+  for (int d = 0; d < kD; ++d) {
+    load_w(d, wq_[d], sq_[d]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  for (int ks0 = 0; ks0 < nks; ks0 += kD) {
+#pragma unroll
+    for (int u = 0; u < kD; ++u) {
       const int ks = ks0 + u;
+      const int st = ks >> 1, buf = st & 1;
+      if ((u & 1) == 0) {
+        // stage st is in LDS, everyone is done reading the other buffer (LDS-only barrier: the loads in flight stay there)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        store_a(buf ^ 1, aq_);
+        load_a(st + 2, aq_);
+      }
       const uint32_t keep = ks < nks ? 0xffffffffu : 0u;  // (a step past K multiplies zero weights: no branch)
+      // the step's four activation fragments are requested in front of the weight arithmetic (read one at a time in front
+      // of its MFMAs, each read exposed the LDS latency: four times per step)
+      v4i afq[4];
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) afq[mf] = *reinterpret_cast<const v4i*>(&as[buf][u & 1][rd + mf * 1024]);
+      __builtin_amdgcn_sched_barrier(0);
       v4i wop[4];                                          // [2 q + half]
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -292,12 +303,11 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
       }
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf) {
-        const v4i af = *reinterpret_cast<const v4i*>(&as[buf][u][rd + mf * 1024]);
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop[nf], af, acc[mf][nf], 0, 0, 0);
+        for (int nf = 0; nf < 4; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop[nf], afq[mf], acc[mf][nf], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      load_w(ks + 2, wq_[u], sq_[u]);  // (after the slot's last use: see the kernel above)
+      load_w(ks + kD, wq_[u], sq_[u]);  // (after the slot's last use: see the kernel above)
       __builtin_amdgcn_sched_barrier(0);
     }
   }
