@@ -167,6 +167,38 @@ def test_int8_scaled_mm(sglk, dev, M, N, K, with_bias, dtype):
     assert (out != ref).float().mean() < 1e-3
 
 
+@pytest.mark.parametrize("kind", ["fp8", "int8"])
+@pytest.mark.parametrize("M,N,K", [(4096, 14336, 4096), (2304, 7424, 1024), (1024, 4096, 14336), (640, 4104, 512)])
+def test_scaled_mm_full_size_sampled(sglk, dev, kind, M, N, K):
+    """The persistent pipeline in the row / column scale modes at sizes the CPU oracle cannot cover whole: whole rounds
+    plus a last partial round of half tiles (896 and 261 tiles), every tile as two halves (64 tiles), an N that is not
+    a multiple of 256. Oracle on sampled rows (all columns); finiteness and exact row-scale linearity on everything."""
+    g = torch.Generator().manual_seed(M + N + K)
+    if kind == "fp8":
+        a = ((torch.rand(M, K, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8)
+        b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8).t()
+        sa, sb = torch.rand(M, generator=g) * 1e-3 + 1e-4, torch.rand(N, generator=g) * 1e-3 + 1e-4
+        op, ref_op = sglk.fp8_scaled_mm, ogemm.fp8_scaled_mm
+    else:
+        a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8)
+        b = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).t()
+        sa, sb = torch.rand(M, generator=g) * 1e-2 + 1e-3, torch.rand(N, generator=g) * 1e-2 + 1e-3
+        op, ref_op = sglk.int8_scaled_mm, ogemm.int8_scaled_mm
+    bias = torch.randn(N, generator=g).to(torch.bfloat16)
+    ad, bd, sbd, biasd = a.to(dev), to_dev_colmajor(b, dev), sb.to(dev), bias.to(dev)
+    out = op(ad, bd, sa.to(dev), sbd, torch.bfloat16, biasd).cpu()
+    assert torch.isfinite(out.float()).all()
+    rows = torch.randperm(M, generator=g)[:40].sort().values
+    rows = torch.cat([rows, torch.tensor([0, M - 1])]).unique()
+    ref = ref_op(a[rows], b, sa[rows], sb, torch.bfloat16, bias)
+    torch.testing.assert_close(out[rows].float(), ref.float(), rtol=2e-2, atol=2e-2)
+    # doubling the row scales doubles every product exactly (power of two), the bias term stays: (out2 - bias) == 2 (out - bias)
+    # holds only up to the output rounding, so check it without the bias, where it is exact
+    o1 = op(ad, bd, sa.to(dev), sbd, torch.bfloat16, None).cpu()
+    o2 = op(ad, bd, (sa * 2).to(dev), sbd, torch.bfloat16, None).cpu()
+    assert torch.equal(o2.float(), o1.float() * 2)
+
+
 def test_scaled_mm_golden(sglk, dev):
     for c in load_golden("scaled_mm"):
         bias = c["bias"].to(dev) if c["bias"] is not None else None
