@@ -169,6 +169,7 @@ def check_isa(verbose=True):
     for src_name, pat in (("attn_fwd.hip", r"attn_prefill_kernelI"), ("attn_fwd.hip", r"attn_decode_kernelI"),
                           ("moe_w4a16.hip", r"moe_w4a16_kernelIDF16.Li\dELi\dELi1ELi\dE"),
                           ("moe_w4a16.hip", r"moe_w4a16_kernelIDF16.Li\dELi\dELi4ELi1E"),
+                          ("moe_w4a16.hip", r"moe_w4a16_ksplit_kernelI"),
                           ("moe_bf16.hip", r"moe_bf16_kernelI")):
         path = _asm_path(src_name)
         if not os.path.exists(path):

@@ -490,6 +490,197 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Few workgroups, long K (the Mixtral down projection with one or two active experts: 64 column blocks for 256 CUs, 48 us
+// for 59 MB): a workgroup owns 32 columns and its four waves split K into quarters. Every wave is on its own - its 16 x 128
+// activation slices go through a wave-private LDS image (global -> registers four blocks ahead -> LDS one block ahead;
+// LDS instructions of a wave execute in order, so no barrier), its weights through the same register ring as above - and the
+// four partial sums meet in LDS once, added in a fixed order by wave 0. int4 codes, groups of 128, 16 rows, K % 2048 == 0.
+template <typename T, int FMT>
+__global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict__ out, const T* __restrict__ act,
+                                                                  const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
+                                                                  const void* __restrict__ zeros_, const float* __restrict__ bias,
+                                                                  const int32_t* __restrict__ rows_per_expert, int E, int N, int K) {
+  constexpr int NW = 2, kD = 4, BN = 16 * NW, AROW = 256, kImg = 16 * AROW;
+  constexpr bool has_zp = FMT == 2;
+  __shared__ __attribute__((aligned(256))) char smem[4 * 2 * kImg];  // [wave][buffer]: 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const MoeTile tile = find_moe_tile(rows_per_expert, E, 16, (N + BN - 1) / BN);
+  if (tile.expert < 0) return;
+  const int e = tile.expert, m0 = tile.m0, m_valid = tile.m_valid;
+  const int n_base = tile.col_block * BN;
+  const int kgroups = K >> 7;
+  const int per = kgroups >> 2;           // 128-deep blocks of this wave (a multiple of kD)
+  const int kb_off = wave * per;
+  const T* scales = reinterpret_cast<const T*>(scales_);
+  const T* zeros = reinterpret_cast<const T*>(zeros_);
+  const uint8_t* wexp = wq + (int64_t)e * N * (K / 2);
+  const T* sexp = scales + (int64_t)e * N * kgroups;
+  const T* zexp = has_zp ? zeros + (int64_t)e * N * kgroups : sexp;
+  uint32_t woff[NW], soff[NW];
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt) {
+    int n = n_base + nt * 16 + l15;
+    n = n < N ? n : N - 1;
+    woff[nt] = (uint32_t)n * (uint32_t)(K / 2) + 16 * g + (uint32_t)kb_off * 64u;
+    soff[nt] = (uint32_t)n * (uint32_t)kgroups + (uint32_t)kb_off;
+  }
+  // activation slice of a block: 16 rows x 16 chunks of 16 bytes, chunk q = i * 64 + lane
+  const T* act_blk = act + (int64_t)m0 * K + (int64_t)kb_off * 128;
+  char* img = smem + wave * (2 * kImg);
+  uint32_t aoff[4], loff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 64 + lane, row = q >> 4, c = q & 15;
+    aoff[i] = (uint32_t)(row < m_valid ? row : m_valid - 1) * (uint32_t)K + c * 8;
+    const int slot = ((0x84C0 >> (c & 12)) & 15) + (c & 3);  // (the permuted-k slots of the kernel above)
+    loff[i] = (uint32_t)(row * AROW + ((slot ^ (row & 15)) << 4));
+  }
+  auto load_a = [&](int kb, v4i (&r)[4]) {
+    const uint32_t ko = (uint32_t)(kb < per ? kb : 0) * 128u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const v4i*>(act_blk + (aoff[i] + ko));
+  };
+  auto store_a = [&](int buf, const v4i (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const v4i v = r[i];
+      v4i p;  // element order (a0,a4,a1,a5,a2,a6,a3,a7) to match expand_nibbles
+      p[0] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x05040100u);
+      p[1] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x07060302u);
+      p[2] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x05040100u);
+      p[3] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x07060302u);
+      *reinterpret_cast<v4i*>(img + buf * kImg + loff[i]) = p;
+    }
+  };
+  uint32_t wq_[kD][NW][4];
+  auto load_w = [&](int kb, uint32_t (&dst)[NW][4]) {
+    const uint32_t koff = (uint32_t)(kb < per ? kb : 0) * 64u;
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+      const v4i t = *reinterpret_cast<const v4i*>(wexp + woff[nt] + koff);
+      dst[nt][0] = t[0]; dst[nt][1] = t[1]; dst[nt][2] = t[2]; dst[nt][3] = t[3];
+    }
+  };
+  typedef uint32_t SVec __attribute__((ext_vector_type(2)));  // the kD = 4 scales of a trip: one 8-byte load
+  SVec sv_cur[NW], sv_nxt[NW], zv_cur[NW], zv_nxt[NW];
+  auto load_sv = [&](int kb0, SVec (&sd)[NW], SVec (&zd)[NW]) {
+    const int k0 = kb0 < per ? kb0 : 0;
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+      sd[nt] = *reinterpret_cast<const SVec*>(sexp + soff[nt] + k0);
+      if constexpr (has_zp) zd[nt] = *reinterpret_cast<const SVec*>(zexp + soff[nt] + k0);
+    }
+  };
+  auto sv_get = [&](const SVec& v, int u) -> float {
+    const uint32_t d = v[u >> 1];
+    const uint16_t h = (u & 1) ? (uint16_t)(d >> 16) : (uint16_t)d;
+    return (float)__builtin_bit_cast(T, h);
+  };
+  v4f acc[NW], part[NW], asum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt) {
+    acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    part[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+  }
+  const v4i ones = {(int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes, (int)W4<T>::kOnes};
+  uint32_t magic = W4<T>::kMagic, nib_mask = (0xFu << W4<T>::kShift) | (0xFu << (W4<T>::kShift + 16));
+  asm volatile("" : "+v"(magic), "+s"(nib_mask));
+
+  v4i aq_[kD][4];
+#pragma unroll
+  for (int d = 0; d < kD; ++d) load_a(d, aq_[d]);
+  store_a(0, aq_[0]);
+  load_a(kD, aq_[0]);
+  load_sv(0, sv_cur, zv_cur);
+  load_sv(kD, sv_nxt, zv_nxt);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int d = 0; d < kD; ++d) {
+    load_w(d, wq_[d]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int kb0 = 0; kb0 < per; kb0 += kD) {
+#pragma unroll
+    for (int u = 0; u < kD; ++u) {
+      const int kb = kb0 + u, buf = kb & 1;
+      if (u == 0 && kb0 > 0) {
+#pragma unroll
+        for (int nt = 0; nt < NW; ++nt) {
+          sv_cur[nt] = sv_nxt[nt];
+          if constexpr (has_zp) zv_cur[nt] = zv_nxt[nt];
+        }
+        load_sv(kb0 + kD, sv_nxt, zv_nxt);
+      }
+      // the image of block kb was written a block ago; this wave's own reads of the other buffer are done (in-order LDS)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      store_a(buf ^ 1, aq_[(u + 1) % kD]);
+      load_a(kb + 1 + kD, aq_[(u + 1) % kD]);
+      uint32_t wd[NW][4];
+#pragma unroll
+      for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wd[nt][t] = FMT == 0 ? (wq_[u][nt][t] ^ 0x88888888u) : wq_[u][nt][t];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the stores above are in LDS before the reads below are issued)
+      const char* abase = img + buf * kImg;
+      static_for4([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        v4i wf[NW];
+#pragma unroll
+        for (int nt = 0; nt < NW; ++nt) wf[nt] = expand_nibbles<T>(wd[nt][j], nib_mask, magic);
+        const int slot = ((0x84C0 >> (4 * g)) & 15) + j;
+        const v4i af = *reinterpret_cast<const v4i*>(abase + l15 * AROW + ((slot ^ l15) << 4));
+        asum = W4<T>::mma(af, ones, asum);
+#pragma unroll
+        for (int nt = 0; nt < NW; ++nt) part[nt] = W4<T>::mma(af, wf[nt], part[nt]);
+        if constexpr (j == 3) {
+#pragma unroll
+          for (int nt = 0; nt < NW; ++nt) {
+            const float sc = sv_get(sv_cur[nt], u);
+            const float z = has_zp ? 16.0f + sv_get(zv_cur[nt], u) : 24.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][r] = __builtin_fmaf(sc, __builtin_fmaf(-z, asum[r], part[nt][r]), acc[nt][r]);
+            part[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+          }
+          asum = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      load_w(kb + kD, wq_[u]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- the four partial sums meet in LDS (over the images: every wave is past its last read), fixed order
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+  if (wave != 0) {
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) *reinterpret_cast<v4f*>(&red[(((wave - 1) * NW + nt) * 64 + lane) * 4]) = acc[nt];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+      const v4f o = *reinterpret_cast<const v4f*>(&red[((w * NW + nt) * 64 + lane) * 4]);
+      acc[nt][0] += o[0]; acc[nt][1] += o[1]; acc[nt][2] += o[2]; acc[nt][3] += o[3];
+    }
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt) {
+    const int n = n_base + nt * 16 + l15;
+    if (n >= N) continue;
+    const float bv = bias ? bias[(int64_t)e * N + n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * g + r;
+      if (row < m_valid) out[(int64_t)(m0 + row) * N + n] = (T)(acc[nt][r] + bv);
+    }
+  }
+}
+
 #ifdef SGLK_PROBES
 static int g_w4_probe = 0, g_w4_mt = 0;
 #else
@@ -529,7 +720,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // GroupGemmW4A16Xe20.cpp:266-277). The row counts are ragged around the average, and a second row block of an expert
   // streams its weights again, so a tile is chosen that holds ~1.5x the average; 64-row tiles are the largest whose K loop
   // stays free of register spills.
-  const int64_t avg = g_w4_mt ? (g_w4_mt == 1 ? 1 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 200 : 1000) : total_m / E;
+  const int64_t avg = g_w4_mt ? ((g_w4_mt == 1 || g_w4_mt == 11 || g_w4_mt == 12) ? 1 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 200 : 1000) : total_m / E;
   // (16-column tiles per wave - 64 columns per workgroup, twice the workgroups - were slower at every decode shape: the
   // activation staging and the barrier are per workgroup, 155 vs 145 us at N = 28672, K = 4096)
   // (the 16 / 32-row tiles fetch the scales of four 128-deep blocks with one 8-byte load: groups of 128, K % 512 == 0)
@@ -541,8 +732,20 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
   const int64_t bm = avg <= 10 ? 16 : 32;
   const int64_t est_row_blocks = std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / bm);
-  const bool narrow = group_shift == 7 && K % 1024 == 0 && est_row_blocks * cdiv(N, 128) <= 384;
+  const bool narrow = group_shift == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
   if (avg <= 10) {
+    // fewer workgroups than CUs even with 64-column tiles, long K: four waves split K (see moe_w4a16_ksplit_kernel)
+    const bool ksplit = group_shift == 7 && K % 2048 == 0 && ((K >= 8192 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1;
+    if (ksplit) {
+      const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 32));
+      if (wgs < ((int64_t)1 << 31)) {
+        if (zeros != nullptr)
+          moe_w4a16_ksplit_kernel<T, 2><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
+        else
+          moe_w4a16_ksplit_kernel<T, 0><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
+        return check_launch("moe_grouped_mm_nt_xe20_w4a16");
+      }
+    }
     if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
     // (eight blocks in flight per wave at 128 columns: 175 registers, two waves per SIMD instead of three - no faster)
     return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);

@@ -141,7 +141,9 @@ def make_int4(E, N, K, gs, dtype, explicit_zero, g):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("gs", [32, 64, 128, 256])
 @pytest.mark.parametrize("rows,N,K", [([2] * 8, 128, 256), ([0, 5, 17, 0, 1, 33, 0, 129], 200, 512),
-                                      ([300, 0, 40, 7], 1024, 1280), ([1] * 8, 4096, 1024)])
+                                      ([300, 0, 40, 7], 1024, 1280), ([1] * 8, 4096, 1024),
+                                      # few rows, long K (groups of 128: the four waves of a workgroup split K)
+                                      ([3, 0, 16, 7], 104, 8192), ([1] * 8, 256, 10240)])
 def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
     if K % gs:
         pytest.skip("K not a multiple of the group")
