@@ -496,12 +496,14 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
 // activation slices go through a wave-private LDS image (global -> registers four blocks ahead -> LDS one block ahead;
 // LDS instructions of a wave execute in order, so no barrier), its weights through the same register ring as above - and the
 // four partial sums meet in LDS once, added in a fixed order by wave 0. int4 codes, groups of 128, 16 rows, K % 2048 == 0.
-template <typename T, int FMT>
+// SPLIT = false: the same independent waves without the K split - a workgroup owns 128 columns, every wave 32 of them over
+// all of K (no reduction): the barrier-free variant of the 16-row tile above.
+template <typename T, int FMT, bool SPLIT = true>
 __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict__ out, const T* __restrict__ act,
                                                                   const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
                                                                   const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                                   const int32_t* __restrict__ rows_per_expert, int E, int N, int K) {
-  constexpr int NW = 2, kD = 4, BN = 16 * NW, AROW = 256, kImg = 16 * AROW;
+  constexpr int NW = 2, kD = 4, BN = SPLIT ? 16 * NW : 64 * NW, AROW = 256, kImg = 16 * AROW;
   constexpr bool has_zp = FMT == 2;
   __shared__ __attribute__((aligned(256))) char smem[4 * 2 * kImg];  // [wave][buffer]: 32 KiB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -510,10 +512,10 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
   const MoeTile tile = find_moe_tile(rows_per_expert, E, 16, (N + BN - 1) / BN);
   if (tile.expert < 0) return;
   const int e = tile.expert, m0 = tile.m0, m_valid = tile.m_valid;
-  const int n_base = tile.col_block * BN;
+  const int n_base = tile.col_block * BN + (SPLIT ? 0 : wave * (16 * NW));
   const int kgroups = K >> 7;
-  const int per = kgroups >> 2;           // 128-deep blocks of this wave (a multiple of kD)
-  const int kb_off = wave * per;
+  const int per = SPLIT ? kgroups >> 2 : kgroups;  // 128-deep blocks of this wave (a multiple of kD)
+  const int kb_off = SPLIT ? wave * per : 0;
   const T* scales = reinterpret_cast<const T*>(scales_);
   const T* zeros = reinterpret_cast<const T*>(zeros_);
   const uint8_t* wexp = wq + (int64_t)e * N * (K / 2);
@@ -653,6 +655,7 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
     }
   }
   // ---- the four partial sums meet in LDS (over the images: every wave is past its last read), fixed order
+  if constexpr (SPLIT) {
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);
   if (wave != 0) {
@@ -668,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
       const v4f o = *reinterpret_cast<const v4f*>(&red[((w * NW + nt) * 64 + lane) * 4]);
       acc[nt][0] += o[0]; acc[nt][1] += o[1]; acc[nt][2] += o[2]; acc[nt][3] += o[3];
     }
+  }
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
     const int n = n_base + nt * 16 + l15;
@@ -720,7 +724,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // GroupGemmW4A16Xe20.cpp:266-277). The row counts are ragged around the average, and a second row block of an expert
   // streams its weights again, so a tile is chosen that holds ~1.5x the average; 64-row tiles are the largest whose K loop
   // stays free of register spills.
-  const int64_t avg = g_w4_mt ? ((g_w4_mt == 1 || g_w4_mt == 11 || g_w4_mt == 12) ? 1 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 200 : 1000) : total_m / E;
+  const int64_t avg = g_w4_mt ? ((g_w4_mt == 1 || g_w4_mt == 11 || g_w4_mt == 12 || g_w4_mt == 13) ? 1 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 200 : 1000) : total_m / E;
   // (16-column tiles per wave - 64 columns per workgroup, twice the workgroups - were slower at every decode shape: the
   // activation staging and the barrier are per workgroup, 155 vs 145 us at N = 28672, K = 4096)
   // (the 16 / 32-row tiles fetch the scales of four 128-deep blocks with one 8-byte load: groups of 128, K % 512 == 0)
@@ -735,7 +739,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   const bool narrow = group_shift == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
   if (avg <= 10) {
     // fewer workgroups than CUs even with 64-column tiles, long K: four waves split K (see moe_w4a16_ksplit_kernel)
-    const bool ksplit = group_shift == 7 && K % 2048 == 0 && ((K >= 8192 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1;
+    const bool ksplit = group_shift == 7 && K % 2048 == 0 && ((K >= 8192 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
     if (ksplit) {
       const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 32));
       if (wgs < ((int64_t)1 << 31)) {
@@ -746,6 +750,17 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
         return check_launch("moe_grouped_mm_nt_xe20_w4a16");
       }
     }
+#ifdef SGLK_PROBES  // (diagnostic build: the independent waves without the K split - gate / up projection 114-143 -> 119-158 us,
+    // down projection at 16 rows per expert 72 -> 62 us against 67 us with the split)
+    if (g_w4_mt == 13 && group_shift == 7 && K % 512 == 0) {
+      const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 128));
+      if (zeros != nullptr)
+        moe_w4a16_ksplit_kernel<T, 2, false><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
+      else
+        moe_w4a16_ksplit_kernel<T, 0, false><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
+      return check_launch("moe_grouped_mm_nt_xe20_w4a16");
+    }
+#endif
     if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
     // (eight blocks in flight per wave at 128 columns: 175 registers, two waves per SIMD instead of three - no faster)
     return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
