@@ -734,12 +734,17 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // 32-row 140 + 98; avg 16: 151 + 97 vs 145 + 99; avg 32: 226 + 130 vs 191 + 141 vs 64-row 251 + 175
   // few column blocks (the Mixtral down projection: 32 of 128 columns x 8 experts = one workgroup per CU): 64-column
   // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
-  const int64_t bm = avg <= 10 ? 16 : 32;
+  // (a narrow projection keeps the 16-row tile up to an average of 20 rows: ragged counts around 16 - 64 tokens, top-2 of 8 -
+  // 81 us against 96 us with the 32-row tile for the down projection; the gate / up projection measured 151 against 145)
+  const bool narrow16 = group_shift == 7 && K % 1024 == 0 &&
+                        std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / 16) * cdiv(N, 128) <= 384;
+  const bool small = avg <= 10 || (narrow16 && avg <= 20 && g_w4_mt == 0);
+  const int64_t bm = small ? 16 : 32;
   const int64_t est_row_blocks = std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / bm);
   const bool narrow = group_shift == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
-  if (avg <= 10) {
+  if (small) {
     // fewer workgroups than CUs even with 64-column tiles, long K: four waves split K (see moe_w4a16_ksplit_kernel)
-    const bool ksplit = group_shift == 7 && K % 2048 == 0 && ((K >= 8192 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
+    const bool ksplit = group_shift == 7 && K % 2048 == 0 && ((K >= 8192 && avg <= 10 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
     if (ksplit) {
       const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 32));
       if (wgs < ((int64_t)1 << 31)) {
