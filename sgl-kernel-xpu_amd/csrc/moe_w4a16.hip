@@ -115,6 +115,20 @@ __device__ __forceinline__ v4i expand_mxfp4(uint32_t w) {
   return r;
 }
 
+// mxfp4 through the conversion instruction of gfx950: v_cvt_scalef32_pk_bf16_fp4 turns the two e2m1 codes of one byte
+// (low nibble first) into two bf16 times 2^(exponent of the f32 operand) - exact, scale included, one instruction per
+// dword of results (tools/fp4_cvt_probe.cpp prints what it does at the ends of the E8M0 range: 2^-127 comes out as the
+// bf16 subnormal, the top of the range as inf). dword p = k offsets 2p, 2p + 1: the natural order.
+__device__ __forceinline__ v4i expand_mxfp4_hw(uint32_t w, float scale) {
+  typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
+  v4i r;
+  r[0] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 0));
+  r[1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 1));
+  r[2] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 2));
+  r[3] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 3));
+  return r;
+}
+
 // 4x4 transpose of dwords across the four 16-lane groups: in: lane group g holds d[t] = M[g][t];
 // out: lane group g holds d[t] = M[t][g].
 __device__ __forceinline__ void transpose4(uint32_t (&d)[4]) {
@@ -145,7 +159,10 @@ __device__ __forceinline__ void static_for4(F&& f) {
 }
 
 // PB: scale groups per 128-deep block (4, 2, 1 for groups 32, 64, >= 128); FMT: 0 = int4, two's-complement codes (scales
-// of type T), 2 = int4, unsigned codes with zero points of type T, 1 = mxfp4 (scales = E8M0 bytes, group 32, no zeros)
+// of type T), 2 = int4, unsigned codes with zero points of type T, 1 = mxfp4 (scales = E8M0 bytes, group 32, no zeros),
+// 3 = mxfp4 with bf16 activations through v_cvt_scalef32_pk_bf16_fp4: the 16 bytes a lane loads per 128-deep block are ONE
+// scale group (k = 32 g ..), the conversion applies that lane's scale, so the block needs no per-group fold, no lane
+// transposes, and runs on the PB = 1 machinery (scales read as one dword = the block's four E8M0 bytes per row)
 template <typename T, int MT, int NW, int PB, int FMT, int WV = 4>  // WV waves per workgroup (8: the prefill tile, 64 x 256)
 __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T* __restrict__ out, const T* __restrict__ act,
                                                         const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   // SV: the scales (zero points) of the kD = 4 / 8 blocks of one trip of the K loop are ONE 8- / 16-byte load per row,
   // requested a trip ahead (groups of 128, K a multiple of 512 / 1024: the host sends other shapes elsewhere). A quarter of the scale
   // requests, and the one loop-carried register set is rotated at the top of the trip, where its load is the oldest in flight.
-  constexpr bool SV = PB == 1 && kD >= 4 && FMT != 1;
+  constexpr bool SV = PB == 1 && kD >= 4 && FMT != 1;  // (FMT 3: the kD dwords of E8M0 bytes of a trip, one 16- / 32-byte load)
   __shared__ __attribute__((aligned(256))) char smem[2 * BM * AROW];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -192,12 +209,13 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   const int e = tile.expert, m0 = tile.m0, m_valid = tile.m_valid;
   const int n_base = tile.col_block * BN + wave * (NW * 16);
 
-  using S = typename std::conditional<FMT == 1, uint8_t, T>::type;  // stored scale type
+  using S = typename std::conditional<FMT == 1, uint8_t, typename std::conditional<FMT == 3, uint32_t, T>::type>::type;  // stored scale type
+  static_assert(FMT != 3 || (PB == 1 && std::is_same<T, bf16>::value), "the fp4 conversion path: bf16, one dword of scales per block");
   const S* scales = reinterpret_cast<const S*>(scales_);
   const S* zeros = reinterpret_cast<const S*>(zeros_);
   const int kgroups = K >> group_shift;         // scales per row
   constexpr bool has_zp = FMT == 2;
-  constexpr bool is_int4 = FMT != 1;
+  constexpr bool is_int4 = FMT == 0 || FMT == 2;
 
   // ---- per-lane weight / scale rows (clamped; stores are guarded): 32-bit offsets from per-expert bases
   const uint8_t* wexp = wq + (int64_t)e * N * (K / 2);
@@ -247,11 +265,13 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
       const v4i zero = {0, 0, 0, 0};
       const v4i v = in ? r[i] : zero;
       // element order (a0,a4,a1,a5,a2,a6,a3,a7) to match expand_nibbles
-      v4i p;
-      p[0] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x05040100u);
-      p[1] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x07060302u);
-      p[2] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x05040100u);
-      p[3] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x07060302u);
+      v4i p = v;  // (FMT 3: the conversion delivers the natural element order)
+      if constexpr (FMT != 3) {
+        p[0] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x05040100u);
+        p[1] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x07060302u);
+        p[2] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x05040100u);
+        p[3] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x07060302u);
+      }
       // (the swizzle permutes the 16 chunks of a 128-deep block among themselves)
       // position of chunk cb = c % 16 of a 128-deep block inside its 256-byte row piece: slot(cb) ^ (row & 15); slot is the
       // identity when the k-steps read chunks 4 j + g, and {0, 12, 4, 8}[cb / 4] + cb % 4 when they read chunks 4 g + j
@@ -315,7 +335,7 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
     }
   };
   // (kD 16-bit scales of a row = kD / 2 dwords: one 8- or 16-byte load)
-  typedef uint32_t SVec __attribute__((ext_vector_type(kD >= 4 ? kD / 2 : 2)));
+  typedef uint32_t SVec __attribute__((ext_vector_type(kD >= 4 ? (FMT == 3 ? kD : kD / 2) : 2)));
   SVec sv_cur[NW], sv_nxt[NW], zv_cur[NW], zv_nxt[NW];
   auto load_sv = [&](int kb0, SVec (&sd)[NW], SVec (&zd)[NW]) {
     int kg0 = (probe & 8) ? 0 : kb0;
@@ -410,12 +430,24 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
     } else {
     // (requesting the activation fragments of the whole block up front, ahead of the first step's expansion, measured no
     // faster on the decode tiles: 142 -> 147 us)
+    float lane_scale[NW];  // FMT 3: 2^(E8M0 byte - 127) of this lane's group (k = 128 kb + 32 g ..); byte 0 = the f32 subnormal
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt) {
+      lane_scale[nt] = 1.f;
+      if constexpr (FMT == 3) {
+        const uint32_t e8 = ((SV ? (uint32_t)sv_cur[nt][u] : (uint32_t)sc[nt][0]) >> (8 * g)) & 0xffu;
+        lane_scale[nt] = __uint_as_float(e8 ? e8 << 23 : 0x00400000u);
+      }
+    }
     static_for4([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       // (k steps past K multiply zero activations: no tail branch)
       v4i wf[NW];
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) wf[nt] = !is_int4 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
+      for (int nt = 0; nt < NW; ++nt) {
+        if constexpr (FMT == 3) wf[nt] = expand_mxfp4_hw(wd[nt][j], lane_scale[nt]);
+        else wf[nt] = !is_int4 ? expand_mxfp4<T>(wd[nt][j]) : expand_nibbles<T>(wd[nt][j], nib_mask, magic);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int row = mt * 16 + l15;
@@ -432,7 +464,9 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) {
           float s, z = 0.f;
-          if constexpr (!is_int4) {
+          if constexpr (FMT == 3) {
+            s = 1.f;  // (the conversion has applied the scales)
+          } else if constexpr (!is_int4) {
             const uint32_t e = sc[nt][ki];  // E8M0: 2^(byte - 127); byte 0 is the subnormal 2^-127
             s = __uint_as_float(e ? e << 23 : 0x00400000u);
           } else if constexpr (SV) {
@@ -686,9 +720,9 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
 }
 
 #ifdef SGLK_PROBES
-static int g_w4_probe = 0, g_w4_mt = 0;
+static int g_w4_probe = 0, g_w4_mt = 0, g_w4_fp4hw = 1;
 #else
-constexpr int g_w4_probe = 0, g_w4_mt = 0;
+constexpr int g_w4_probe = 0, g_w4_mt = 0, g_w4_fp4hw = 1;
 #endif
 
 template <typename T, int MT, int NW, int PB, int FMT = 0, int WV = 4>
@@ -705,7 +739,12 @@ static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq,
 
 template <typename T, int MT, int NW, int WV = 4>
 static int launch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
-                  const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
+                  const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift,
+                  bool fp4hw = false) {
+  if constexpr (std::is_same<T, bf16>::value) {
+    if (fp4hw)  // mxfp4 through the conversion instruction: one dword of scale bytes per 128-deep block
+      return launch_pb<T, MT, NW, 1, 3, WV>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 7);
+  }
   if (group_shift < 0)  // mxfp4: E8M0 scales per 32
     return launch_pb<T, MT, NW, 4, 1, WV>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 5);
 #define SGLK_W4_GO(PB)                                                                                                    \
@@ -724,24 +763,27 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // GroupGemmW4A16Xe20.cpp:266-277). The row counts are ragged around the average, and a second row block of an expert
   // streams its weights again, so a tile is chosen that holds ~1.5x the average; 64-row tiles are the largest whose K loop
   // stays free of register spills.
+  // mxfp4 with bf16 activations goes through the conversion instruction and the group-128 machinery (FMT 3)
+  const bool fp4hw = group_shift < 0 && std::is_same<T, bf16>::value && K % 128 == 0 && (uintptr_t)scales % 4 == 0 && g_w4_fp4hw != 0;
+  const int gp = fp4hw ? 7 : group_shift;  // the group shift the tile policy sees
   const int64_t avg = g_w4_mt ? ((g_w4_mt == 1 || g_w4_mt == 11 || g_w4_mt == 12 || g_w4_mt == 13) ? 1 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 200 : 1000) : total_m / E;
   // (16-column tiles per wave - 64 columns per workgroup, twice the workgroups - were slower at every decode shape: the
   // activation staging and the barrier are per workgroup, 155 vs 145 us at N = 28672, K = 4096)
   // (the 16 / 32-row tiles fetch the scales of four 128-deep blocks with one 8-byte load: groups of 128, K % 512 == 0)
-  const bool small_ok = group_shift != 7 && group_shift != 8 ? true : (group_shift == 7 && K % 512 == 0);
-  if (!small_ok) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  const bool small_ok = gp != 7 && gp != 8 ? true : (gp == 7 && K % 512 == 0);
+  if (!small_ok) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
   // measured on ragged counts around the average (gate/up + down projection of Mixtral, us): avg 8: 16-row tile 124 + 75,
   // 32-row 140 + 98; avg 16: 151 + 97 vs 145 + 99; avg 32: 226 + 130 vs 191 + 141 vs 64-row 251 + 175
   // few column blocks (the Mixtral down projection: 32 of 128 columns x 8 experts = one workgroup per CU): 64-column
   // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
   // (a narrow projection keeps the 16-row tile up to an average of 20 rows: ragged counts around 16 - 64 tokens, top-2 of 8 -
   // 81 us against 96 us with the 32-row tile for the down projection; the gate / up projection measured 151 against 145)
-  const bool narrow16 = group_shift == 7 && K % 1024 == 0 &&
+  const bool narrow16 = gp == 7 && K % 1024 == 0 &&
                         std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / 16) * cdiv(N, 128) <= 384;
   const bool small = avg <= 10 || (narrow16 && avg <= 20 && g_w4_mt == 0);
   const int64_t bm = small ? 16 : 32;
   const int64_t est_row_blocks = std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / bm);
-  const bool narrow = group_shift == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
+  const bool narrow = gp == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
   if (small) {
     // fewer workgroups than CUs even with 64-column tiles, long K: four waves split K (see moe_w4a16_ksplit_kernel)
     const bool ksplit = group_shift == 7 && K % 2048 == 0 && ((K >= 8192 && avg <= 10 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
@@ -766,21 +808,21 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
       return check_launch("moe_grouped_mm_nt_xe20_w4a16");
     }
 #endif
-    if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+    if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
     // (eight blocks in flight per wave at 128 columns: 175 registers, two waves per SIMD instead of three - no faster)
-    return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+    return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
   }
   // (128-row tiles and 64-column wave tiles both measured slower at 512 rows per expert: 1 wave per SIMD; the prefill side is
   // bound by L2 traffic - 64 x 128 tiles re-read activations 224 times and weights 8 times, 11 GB at ~10 TB/s)
   // eight waves share a staged activation tile (64 x 256): half the activation traffic and barriers per flop of the 64 x 128
   // tile - 512 rows per expert 1.90 -> 1.61 ms (gate / up), 0.84 -> 0.73 ms (down); 128 rows 0.49 (0.48 with 32-row tiles) -> 0.43 ms
   if (g_w4_mt == 8 || (g_w4_mt == 0 && avg >= 112 && N % 256 == 0))
-    return launch<T, 4, 2, 8>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+    return launch<T, 4, 2, 8>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
   if (avg <= 160) {  // (avg 64: 32-row tile 321 + 198 us, 64-row 352 + 230; avg 128: 571 + 352 vs 596 + 396; 256: 1021 + 615 vs 1008 + 471)
-    if (narrow) return launch<T, 2, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
-    return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+    if (narrow) return launch<T, 2, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
+    return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
   }
-  return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift);
+  return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
 }
 
 }  // namespace

@@ -40,3 +40,23 @@ for T in (64, 2048):
     for _ in range(n): f()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / n * 1e3
     print(f"fused_experts bf16 T={T}: {ms:.3f} ms  {2.0*T*topk*3*Hd*I/ms/1e9:.1f} TFLOP/s  weights {(w1b.numel()+w2b.numel())*2/ms/1e6:.0f} GB/s")
+
+# mxfp4 weights (e2m1 codes, E8M0 scale bytes per 32)
+del w1b, w2b
+w1m = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
+w2m = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
+s1m = torch.randint(118, 124, (E, 2 * I, Hd // 32), device=dev, dtype=torch.uint8)
+s2m = torch.randint(118, 124, (E, Hd, I // 32), device=dev, dtype=torch.uint8)
+for T in (1, 64, 2048):
+    x = torch.randn(T, Hd, device=dev, dtype=torch.bfloat16) * 0.1
+    logits = torch.randn(T, E, device=dev, dtype=torch.bfloat16)
+    tw = torch.empty(T, topk, device=dev, dtype=torch.float32)
+    ti = torch.empty(T, topk, device=dev, dtype=torch.int32)
+    sgl_kernel.topk_softmax(tw, ti, logits, True)
+    f = lambda: sgl_kernel.fused_experts(x, w1m, w2m, tw, ti, use_mxfp4_w4a16=True, w1_scale=s1m, w2_scale=s2m)
+    for _ in range(20): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 30 if T <= 256 else 10
+    for _ in range(n): f()
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / n * 1e3
+    print(f"fused_experts mxfp4 T={T}: {ms:.3f} ms  {2.0*T*topk*3*Hd*I/ms/1e9:.1f} TFLOP/s  weights {(w1m.numel()+w2m.numel())/ms/1e6:.0f} GB/s")
