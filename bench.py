@@ -236,6 +236,18 @@ def side_metrics(sgl_kernel, dev):
         out[f"fused_experts_w4a16_mixtral_T{T}_ms"] = round(ms, 4)
         out[f"fused_experts_w4a16_mixtral_T{T}_TFLOPs"] = round(2.0 * T * topk * 3 * Hd * I / ms / 1e9, 1)
         out[f"fused_experts_w4a16_mixtral_T{T}_weight_GBs"] = round((w1.numel() + w2.numel()) / ms / 1e6, 1)
+    # the same layer with mxfp4 weights (e2m1 codes, one E8M0 scale byte per 32)
+    s1m = torch.randint(118, 124, (E, 2 * I, Hd // 32), device=dev, dtype=torch.uint8)
+    s2m = torch.randint(118, 124, (E, Hd, I // 32), device=dev, dtype=torch.uint8)
+    for T in (64, 2048):
+        xx = torch.randn(T, Hd, device=dev, dtype=torch.bfloat16) * 0.1
+        logits = torch.randn(T, E, device=dev, dtype=torch.bfloat16)
+        tw = torch.empty(T, topk, device=dev, dtype=torch.float32)
+        ti = torch.empty(T, topk, device=dev, dtype=torch.int32)
+        sgl_kernel.topk_softmax(tw, ti, logits, True)
+        ms = timeit(lambda: sgl_kernel.fused_experts(xx, w1, w2, tw, ti, use_mxfp4_w4a16=True, w1_scale=s1m, w2_scale=s2m),
+                    iters=40 if T <= 256 else 8)
+        out[f"fused_experts_mxfp4_mixtral_T{T}_ms"] = round(ms, 4)
     return out
 
 
