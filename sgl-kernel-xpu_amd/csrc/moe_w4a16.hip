@@ -539,6 +539,9 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
                                                                   const int32_t* __restrict__ rows_per_expert, int E, int N, int K) {
   constexpr int NW = 2, kD = 4, BN = SPLIT ? 16 * NW : 64 * NW, AROW = 256, kImg = 16 * AROW;
   constexpr bool has_zp = FMT == 2;
+  constexpr bool kFp4 = FMT == 3;  // mxfp4 through the conversion instruction (bf16): scales = one dword of E8M0 bytes per block
+  static_assert(!kFp4 || std::is_same<T, bf16>::value, "the fp4 conversion path is bf16 only");
+  using S = typename std::conditional<kFp4, uint32_t, T>::type;
   __shared__ __attribute__((aligned(256))) char smem[4 * 2 * kImg];  // [wave][buffer]: 32 KiB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -550,11 +553,11 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
   const int kgroups = K >> 7;
   const int per = SPLIT ? kgroups >> 2 : kgroups;  // 128-deep blocks of this wave (a multiple of kD)
   const int kb_off = SPLIT ? wave * per : 0;
-  const T* scales = reinterpret_cast<const T*>(scales_);
-  const T* zeros = reinterpret_cast<const T*>(zeros_);
+  const S* scales = reinterpret_cast<const S*>(scales_);
+  const S* zeros = reinterpret_cast<const S*>(zeros_);
   const uint8_t* wexp = wq + (int64_t)e * N * (K / 2);
-  const T* sexp = scales + (int64_t)e * N * kgroups;
-  const T* zexp = has_zp ? zeros + (int64_t)e * N * kgroups : sexp;
+  const S* sexp = scales + (int64_t)e * N * kgroups;
+  const S* zexp = has_zp ? zeros + (int64_t)e * N * kgroups : sexp;
   uint32_t woff[NW], soff[NW];
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
@@ -583,11 +586,13 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const v4i v = r[i];
-      v4i p;  // element order (a0,a4,a1,a5,a2,a6,a3,a7) to match expand_nibbles
-      p[0] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x05040100u);
-      p[1] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x07060302u);
-      p[2] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x05040100u);
-      p[3] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x07060302u);
+      v4i p = v;  // int4: element order (a0,a4,a1,a5,a2,a6,a3,a7) to match expand_nibbles; fp4: the natural order
+      if constexpr (!kFp4) {
+        p[0] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x05040100u);
+        p[1] = (int)__builtin_amdgcn_perm((uint32_t)v[2], (uint32_t)v[0], 0x07060302u);
+        p[2] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x05040100u);
+        p[3] = (int)__builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[1], 0x07060302u);
+      }
       *reinterpret_cast<v4i*>(img + buf * kImg + loff[i]) = p;
     }
   };
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
       dst[nt][0] = t[0]; dst[nt][1] = t[1]; dst[nt][2] = t[2]; dst[nt][3] = t[3];
     }
   };
-  typedef uint32_t SVec __attribute__((ext_vector_type(2)));  // the kD = 4 scales of a trip: one 8-byte load
+  typedef uint32_t SVec __attribute__((ext_vector_type(kFp4 ? 4 : 2)));  // the kD = 4 scales of a trip: one 8- / 16-byte load
   SVec sv_cur[NW], sv_nxt[NW], zv_cur[NW], zv_nxt[NW];
   auto load_sv = [&](int kb0, SVec (&sd)[NW], SVec (&zd)[NW]) {
     const int k0 = kb0 < per ? kb0 : 0;
@@ -665,19 +670,31 @@ __global__ __launch_bounds__(256, 2) void moe_w4a16_ksplit_kernel(T* __restrict_
         constexpr int j = decltype(jc)::value;
         v4i wf[NW];
 #pragma unroll
-        for (int nt = 0; nt < NW; ++nt) wf[nt] = expand_nibbles<T>(wd[nt][j], nib_mask, magic);
+        for (int nt = 0; nt < NW; ++nt) {
+          if constexpr (kFp4) {
+            const uint32_t e8 = ((uint32_t)sv_cur[nt][u] >> (8 * g)) & 0xffu;  // this lane's group: k = 128 kb + 32 g ..
+            wf[nt] = expand_mxfp4_hw(wd[nt][j], __uint_as_float(e8 ? e8 << 23 : 0x00400000u));
+          } else {
+            wf[nt] = expand_nibbles<T>(wd[nt][j], nib_mask, magic);
+          }
+        }
         const int slot = ((0x84C0 >> (4 * g)) & 15) + j;
         const v4i af = *reinterpret_cast<const v4i*>(abase + l15 * AROW + ((slot ^ l15) << 4));
-        asum = W4<T>::mma(af, ones, asum);
+        if constexpr (!kFp4) asum = W4<T>::mma(af, ones, asum);
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) part[nt] = W4<T>::mma(af, wf[nt], part[nt]);
         if constexpr (j == 3) {
 #pragma unroll
           for (int nt = 0; nt < NW; ++nt) {
-            const float sc = sv_get(sv_cur[nt], u);
-            const float z = has_zp ? 16.0f + sv_get(zv_cur[nt], u) : 24.0f;
+            if constexpr (kFp4) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nt][r] = __builtin_fmaf(sc, __builtin_fmaf(-z, asum[r], part[nt][r]), acc[nt][r]);
+              for (int r = 0; r < 4; ++r) acc[nt][r] += part[nt][r];
+            } else {
+              const float sc = sv_get(sv_cur[nt], u);
+              const float z = has_zp ? 16.0f + sv_get(zv_cur[nt], u) : 24.0f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[nt][r] = __builtin_fmaf(sc, __builtin_fmaf(-z, asum[r], part[nt][r]), acc[nt][r]);
+            }
             part[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
           }
           asum = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -786,11 +803,19 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   const bool narrow = gp == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
   if (small) {
     // fewer workgroups than CUs even with 64-column tiles, long K: four waves split K (see moe_w4a16_ksplit_kernel)
-    const bool ksplit = group_shift == 7 && K % 2048 == 0 && ((K >= 8192 && avg <= 10 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
+    const bool ksplit = (group_shift == 7 || fp4hw) && K % 2048 == 0 && ((K >= 8192 && avg <= 10 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
     if (ksplit) {
       const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 32));
       if (wgs < ((int64_t)1 << 31)) {
-        if (zeros != nullptr)
+        bool done = false;
+        if constexpr (std::is_same<T, bf16>::value) {
+          if (fp4hw) {
+            moe_w4a16_ksplit_kernel<T, 3><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, nullptr, bias, rows, E, N, K);
+            done = true;
+          }
+        }
+        if (done) {
+        } else if (zeros != nullptr)
           moe_w4a16_ksplit_kernel<T, 2><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
         else
           moe_w4a16_ksplit_kernel<T, 0><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
