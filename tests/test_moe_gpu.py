@@ -143,7 +143,9 @@ def make_int4(E, N, K, gs, dtype, explicit_zero, g):
 @pytest.mark.parametrize("rows,N,K", [([2] * 8, 128, 256), ([0, 5, 17, 0, 1, 33, 0, 129], 200, 512),
                                       ([300, 0, 40, 7], 1024, 1280), ([1] * 8, 4096, 1024),
                                       # few rows, long K (groups of 128: the four waves of a workgroup split K)
-                                      ([3, 0, 16, 7], 104, 8192), ([1] * 8, 256, 10240)])
+                                      ([3, 0, 16, 7], 104, 8192), ([1] * 8, 256, 10240),
+                                      # many rows: the eight-wave 64 x 256 tile
+                                      ([130, 200, 112, 150], 512, 1024)])
 def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
     if K % gs:
         pytest.skip("K not a multiple of the group")
@@ -311,7 +313,8 @@ def test_fused_experts_mixtral_shape_sampled(sglk, dev, T):
 
 # ---------------------------------------------------------------------- 16-bit weights
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("rows", [[2] * 8, [0, 17, 1, 0, 130, 3, 64, 33], [300] + [0] * 7])
+@pytest.mark.parametrize("rows", [[2] * 8, [0, 17, 1, 0, 130, 3, 64, 33], [300] + [0] * 7,
+                                  [200, 130, 97, 255, 128, 100, 190, 140]])  # (the last: the eight-wave 128 x 256 tile)
 @pytest.mark.parametrize("N,K", [(128, 256), (352, 2816), (2816, 176), (1024, 1000)])
 @pytest.mark.parametrize("with_bias", [False, True])
 def test_grouped_mm_16bit(sglk, dev, dt, rows, N, K, with_bias):
@@ -330,7 +333,12 @@ def test_grouped_mm_16bit(sglk, dev, dt, rows, N, K, with_bias):
 
 def test_grouped_mm_16bit_fused_act(sglk, dev):
     g = torch.Generator().manual_seed(5)
-    E, rows, N, K, dt = 8, [5, 0, 9, 1, 40, 2, 2, 7], 256, 512, torch.bfloat16
+    _check_fused_act_16bit(sglk, dev, g, [5, 0, 9, 1, 40, 2, 2, 7], 256, 512)
+    _check_fused_act_16bit(sglk, dev, g, [150, 99, 260, 128, 0, 131, 100, 177], 608, 384)  # eight-wave tiles, ragged N / 2
+
+
+def _check_fused_act_16bit(sglk, dev, g, rows, N, K):
+    E, dt = len(rows), torch.bfloat16
     act = (torch.randn(sum(rows), K, generator=g) * 0.1).to(dt)
     w = (torch.randn(E, N, K, generator=g) * 0.1).to(dt)
     r = torch.tensor(rows, dtype=torch.int32)
