@@ -130,7 +130,8 @@ def test_fp8_blockwise_golden(sglk, dev):
 
 
 @pytest.mark.parametrize("M", [1, 24, 100, 128, 512, 777])
-@pytest.mark.parametrize("N,K", [(16, 512), (128, 1024), (512, 4096), (4096, 512), (1024, 8192), (320, 1152)])
+@pytest.mark.parametrize("N,K", [(16, 512), (128, 1024), (512, 4096), (4096, 512), (1024, 8192), (320, 1152),
+                                 (12288, 512)])  # (the last: 128-row workgroups of the few-row kernel at M = 100, 128)
 @pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fp8_scaled_mm(sglk, dev, M, N, K, with_bias, dtype):
