@@ -273,26 +273,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
       }
     }
   };
-  // fp8 cache: 8 bytes -> 8 elements of T (every e4m3 / e5m2 value is exact in bf16 and fp16)
+  // fp8 cache: 8 bytes -> 8 elements of T (every e4m3 / e5m2 value is exact in bf16 and fp16): one
+  // v_cvt_scalef32_pk_{bf16,f16}_{fp8,bf8} per pair, unit scale (cvt_pk_f32 + two f32 -> T conversions + packing before)
   auto widen = [&](const v4i& x) -> v4i {
     if constexpr (KV8 == 0) {
       return x;
     } else {
+      typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
+      typedef _Float16 v2h_ __attribute__((ext_vector_type(2)));
       v4i r;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-          float f0, f1;
-          if constexpr (KV8 == 1) {
-            const auto f = w == 0 ? __builtin_amdgcn_cvt_pk_f32_fp8(x[h], false) : __builtin_amdgcn_cvt_pk_f32_fp8(x[h], true);
-            f0 = f[0]; f1 = f[1];
-          } else {
-            const auto f = w == 0 ? __builtin_amdgcn_cvt_pk_f32_bf8(x[h], false) : __builtin_amdgcn_cvt_pk_f32_bf8(x[h], true);
-            f0 = f[0]; f1 = f[1];
-          }
-          const uint32_t lo = (uint16_t)M::cvt(f0), hi = (uint16_t)M::cvt(f1);
-          r[2 * h + w] = (int)(lo | (hi << 16));
+        if constexpr (std::is_same<T, bf16>::value && KV8 == 1) {
+          r[2 * h] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(x[h], 1.0f, false));
+          r[2 * h + 1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(x[h], 1.0f, true));
+        } else if constexpr (std::is_same<T, bf16>::value) {
+          r[2 * h] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(x[h], 1.0f, false));
+          r[2 * h + 1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(x[h], 1.0f, true));
+        } else if constexpr (KV8 == 1) {
+          r[2 * h] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x[h], 1.0f, false));
+          r[2 * h + 1] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x[h], 1.0f, true));
+        } else {
+          r[2 * h] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(x[h], 1.0f, false));
+          r[2 * h + 1] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(x[h], 1.0f, true));
         }
       }
       return r;
