@@ -869,6 +869,10 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
   SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "activations must be bfloat16 or half");
   SGLK_REQUIRE((uintptr_t)activations % 16 == 0 && (uintptr_t)packed_weights % 16 == 0,
                "moe_grouped_mm_nt_xe20_w4a16: activations and packed_weights must be 16-byte aligned");
+  // (per-lane weight / activation / scale offsets inside one expert are 32-bit)
+  SGLK_REQUIRE(N * (K / 2) < (1ll << 32) && 256 * K < (1ll << 32) && N < (1ll << 31) && K < (1ll << 31),
+               "moe_grouped_mm_nt_xe20_w4a16: one expert's packed weights must stay below 4 GiB (N=%lld, K=%lld)",
+               (long long)N, (long long)K);
   if (total_m == 0) return SGLK_OK;
   const int gs = !is_int4 ? -1 : group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : 8;
   hipStream_t st = (hipStream_t)stream;
