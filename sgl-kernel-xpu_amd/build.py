@@ -101,7 +101,7 @@ def _functions(asm_text, pattern):
 def check_isa(verbose=True):
     """Guards for hand-managed registers, run on the assembly the build just produced.
 
-    * mla_rows128_kernel keeps O in the fixed registers a0..a255 named only in inline asm: the compiler must not
+    * mla_rows128_kernel / mla_rows128x_kernel keep O in the fixed registers a0..a255 named only in inline asm: the compiler must not
       touch the AGPR file itself in that kernel (no AGPR operand outside ;;#ASMSTART..;;#ASMEND), must not spill,
       and the kernel descriptor must allocate 256 AGPRs.
     * gemm_8bit_persist_kernel counts its LDS waits by hand: a VGPR spill (scratch access = vector-memory
@@ -120,7 +120,7 @@ def check_isa(verbose=True):
         return ["%s missing (build with this script first)" % path]
     text = open(path).read()
     found = 0
-    for name, body in _functions(text, r"mla_rows128_kernelI"):
+    for name, body in _functions(text, r"mla_rows128x?_kernelI"):
         found += 1
         in_asm = False
         for ln in body:

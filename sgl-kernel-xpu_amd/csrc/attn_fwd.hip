@@ -971,6 +971,9 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const
   }
   const int rows_total = seqlen_q * G;  // <= 16
   if (rows_total <= 0) return;
+  // the host picked this kernel from the caller's max_seqlen_q: a sequence with more rows than that promise would be
+  // written only in part. Fail the launch loudly instead of returning garbage rows.
+  if (rows_total > kRowsPerWave) __builtin_trap();
   const int shift = seqlen_k - seqlen_q;
 
   const int my_row = l15;
@@ -1442,6 +1445,9 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
     while ((1ll << page_shift) < page_size) ++page_shift;
   }
   if (batch == 0 || total_q == 0) return SGLK_OK;
+  SGLK_REQUIRE(max_seqlen_q >= 1 && max_seqlen_q <= total_q,
+               "fwd: max_seqlen_q must be an upper bound of the query lengths in [1, total_q], got %lld",
+               (long long)max_seqlen_q);
   SGLK_REQUIRE(num_splits >= 1, "fwd: num_splits must be resolved (>= 1) before the C-ABI call");
   SGLK_REQUIRE(num_splits == 1 || (part_o != nullptr && part_lse != nullptr), "fwd: split-KV needs partial buffers");
   AttnParams p;

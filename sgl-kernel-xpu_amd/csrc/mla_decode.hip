@@ -45,6 +45,7 @@ namespace sglk {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef short v8s __attribute__((ext_vector_type(8)));
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
 // Here a workgroup is 4 waves, one per SIMD, 512 registers each. Wave w owns rows 32w .. 32w+31 (two 16-row
 // tiles): every K fragment and every transposed V fragment is read once and feeds TWO MFMAs (LDS read traffic
 // halves). O (2 x 32 tiles x 4 = 256 registers) lives in the FIXED registers a0..a255, named in the asm text; the
-// compiler never sees those values (tools/check_isa.py verifies that it does not touch the AGPR file itself in this
+// compiler never sees those values (check_isa in build.py verifies that it does not touch the AGPR file itself in this
 // kernel: under VGPR pressure it would park values there). Next to Q (144 VGPRs) the rings hold K fragments 2
 // k-steps ahead and V fragments 4 tiles ahead - all the registers there are (252 of 256 used).
 // One wave per SIMD has no other wave to overlap with, so the overlap is written out: iteration j runs QK^T of tile
@@ -1046,6 +1047,454 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, 
   });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// rows128 kernel, 32x32x16 form (round 3). Same contract, launch geometry, LDS image and DMA ring as the kernel above;
+// what changes is the shape of the matrix instructions and with it who owns a row:
+//   * S^T[32 tokens, 32 rows] = K . Q^T and O^T[32 dims, 32 rows] += V^T . P^T with v_mfma_f32_32x32x16: lane (l31, u)
+//     owns ROW 32 wave + l31 in both products, so the running maximum, the row sum and the rescale factor are per-lane
+//     scalars (one v_permlane32_swap joins the two token halves of a row) and the S accumulator, rounded to 16 bits, IS
+//     the B operand of the second product (tokens in the order the accumulator holds them; the transposed V reads
+//     fetch their tokens in that order). ~85 vector instructions per 32-token tile instead of 268.
+//   * a 32-cycle MFMA holds the SIMD's vector issue port for 8 of its cycles (16x16x32: 8 of 16): the softmax of tile
+//     j fits in the gaps of the P.V MFMAs of tile j-1 (<= 3 per gap, at most one v_exp), which the 16-cycle form could
+//     not hide (measured on the kernel above: removing its softmax saved 0.49 us of a 2.85 us tile).
+//   * the image "chunk c of row r at c ^ (((r&3)<<2)|((r>>2)&3))" serves the row reads (ds_read_b128: K as the A operand,
+//     token l31, dims 16 ks + 8 u ..) and the transposed reads (ds_read_b64_tr_b16: V^T as the A operand, dims 32 dt +
+//     l31, tokens 16 s + 8 e + 4 u ..) of this shape without bank conflicts and without the pi / tau permutations.
+//   * registers: O^T 16 x 16 = 256 accumulators (the compiler puts them into the AGPR half), Q^T 36 x 4 = 144 VGPRs,
+//     the rest rings and softmax state: all real MFMA builtins, so the compiler does the hazard and wait bookkeeping.
+template <typename T>
+struct Mfma32;
+template <>
+struct Mfma32<bf16> {
+  static __device__ __forceinline__ v16f run(const v8s& a, const v8s& b, const v16f& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+  }
+  template <int R>  // accumulator = the fixed registers a[R : R+15]
+  static __device__ __forceinline__ void acc_agpr(const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(R), "i"(R + 15));
+  }
+  static __device__ __forceinline__ void acc_v(v16f& c, const v8s& a, const v8s& b) {  // accumulator pinned to VGPRs
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ void first_v(v16f& c, const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ int pack(float lo, float hi) {
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    const v2bf r = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(int, r);
+  }
+  static __device__ __forceinline__ float add2(int packed, float acc) {  // acc + lo + hi of the ROUNDED pair
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    const v2bf one = {(__bf16)1.0f, (__bf16)1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, packed), one, acc, false);
+  }
+};
+template <>
+struct Mfma32<f16> {
+  static __device__ __forceinline__ v16f run(const v8s& a, const v8s& b, const v16f& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  }
+  template <int R>
+  static __device__ __forceinline__ void acc_agpr(const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(R), "i"(R + 15));
+  }
+  static __device__ __forceinline__ void acc_v(v16f& c, const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ void first_v(v16f& c, const v8s& a, const v8s& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+  }
+  static __device__ __forceinline__ int pack(float lo, float hi) {
+    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+    const v2h r = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(int, r);
+  }
+  static __device__ __forceinline__ float add2(int packed, float acc) {
+    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+    const v2h one = {(_Float16)1.0f, (_Float16)1.0f};
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, packed), one, acc, false);
+  }
+};
+
+#ifdef SGLK_PROBES
+// in-kernel stamps (diagnostic build): per wave, shader cycles summed over the tiles of [0] the tile-landed wait, [1] the
+// barrier, [2] the DMA issue, [3] QK^T, [4] P.V + softmax (+ rescale), [5] prologue, [6] epilogue, [7] tiles
+__device__ unsigned long long g_mla_stamps[8 * 4 * 4096];
+#endif
+template <typename T, int kKA, int kVA, bool kStamp = false>
+__global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p, const T* __restrict__ q_nope,
+                                                                    const T* __restrict__ q_pe,
+                                                                    const char* __restrict__ cache,
+                                                                    const int32_t* __restrict__ seq_lens,
+                                                                    const int32_t* __restrict__ page_table,
+                                                                    const int32_t* __restrict__ cu_seqlens_q) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using M = Mfma32<T>;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int H = p.H;
+  const int l31 = lane & 31, u = lane >> 5;
+
+  // ---- this lane's row: (token slot, head) of workgroup row 32 wave + l31
+  const int hp_mask = (1 << p.hp_shift) - 1;
+  const int row = wave * 32 + l31;
+  const int my_tok = row >> p.hp_shift, my_head = row & hp_mask;
+  int q_row0 = b, n_tok = 1, seq, kv_first;
+  if (cu_seqlens_q != nullptr) {
+    const int q0 = cu_seqlens_q[b], sq = cu_seqlens_q[b + 1] - q0, sk = seq_lens[b];
+    const int t0 = (int)blockIdx.z << (7 - p.hp_shift);
+    if (t0 >= sq) return;
+    const int tpw = 1 << (7 - p.hp_shift);
+    n_tok = (sq - t0) < tpw ? (sq - t0) : tpw;
+    q_row0 = q0 + t0;
+    kv_first = p.causal ? sk - sq + t0 + 1 : sk;
+    seq = p.causal ? sk - sq + t0 + n_tok : sk;
+  } else {
+    seq = seq_lens[b];
+    kv_first = seq;
+  }
+  if (seq < 0) seq = 0;
+  const bool ok = my_tok < n_tok && my_head < H;
+  const int kv_row = (cu_seqlens_q != nullptr && p.causal && my_tok < n_tok) ? kv_first + my_tok : seq;  // this row's horizon
+  const bool work = __any(ok) && p.probe != 1;
+  const int ntiles = (seq + kTile - 1) / kTile;
+  const int tps = (ntiles + p.splits - 1) / p.splits;
+  const int t_begin = split * tps;
+  const int t_end = (t_begin + tps < ntiles) ? (t_begin + tps) : ntiles;
+  const int n_my = t_end - t_begin;
+
+  const int32_t* table = page_table + (int64_t)b * p.table_stride;
+  const int page_mask = (1 << p.page_shift) - 1;
+
+  // ---- LDS-DMA of one tile (as in the kernel above): wave w fills column block w and rope rows 8w .. 8w+7
+  const uint32_t dma_lo0 = (uint32_t)((lane >> 4) * kRowBytes + wave * 256 + 16 * ((lane & 15) ^ ((lane >> 4) << 2)));
+  const uint32_t dma_ro = (uint32_t)((((wave & 1) * 8 + (lane >> 3)) * kRowBytes) + 1024 +
+                                     16 * ((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)));
+  // (the DMA instructions are asm text: an LDS-DMA the compiler can see makes it wait vmcnt(0) in front of the next LDS
+  //  read it can see - any read may alias the DMA's LDS write - which would empty the ring once per tile)
+  auto dma16 = [&](const char* src, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_dst) : "memory", "m0");
+  };
+  auto stage_tile = [&](int t, int st, int pg0, int pg1) {
+    const uint32_t base = (uint32_t)(uintptr_t)SGLK_LDS(smem) + (uint32_t)(st * kStageBytes);
+    const int tok0 = t * kTile;
+    const char* sA = cache + (int64_t)pg0 * p.page_stride_bytes + (int64_t)(tok0 & page_mask) * kRowBytes;
+    const char* sB = p.page_shift == 4 ? cache + (int64_t)pg1 * p.page_stride_bytes : sA + 16 * kRowBytes;
+#pragma unroll
+    for (int rg = 0; rg < 8; ++rg) {
+      const char* sbase = (rg < 4 ? sA : sB) + (rg & 3) * 4 * kRowBytes;
+      dma16(sbase + (dma_lo0 ^ (uint32_t)((rg & 3) << 4)), base + (uint32_t)(wave * 8192 + rg * 1024));
+    }
+    dma16((wave < 2 ? sA : sB) + dma_ro, base + (uint32_t)(kMainBytes + wave * 1024));
+  };
+  auto load_pages = [&](int j, int& pg0, int& pg1) {
+    const int tok0 = (t_begin + (j < n_my ? j : n_my - 1)) * kTile;
+    pg0 = table[tok0 >> p.page_shift];
+    pg1 = pg0;
+    if (p.page_shift == 4 && tok0 + 16 < seq) pg1 = table[(tok0 + 16) >> 4];
+  };
+
+  // ---- nothing to do for this split (decode only: an empty sequence, or more splits than tiles)
+  if (n_my <= 0) {
+    if (ok) {
+      if (p.splits == 1) {
+        T* out = (T*)p.out + ((int64_t)(q_row0 + my_tok) * H + my_head) * kLatent;
+        for (int d = u * 256; d < u * 256 + 256; ++d) out[d] = (T)0.f;
+      } else {
+        float* wo = p.ws_o + (((int64_t)b * p.splits + split) * H + my_head) * kLatent;
+        for (int d = u * 256; d < u * 256 + 256; ++d) wo[d] = 0.f;
+        if (u == 0) p.ws_lse[((int64_t)b * p.splits + split) * H + my_head] = -INFINITY;
+      }
+    }
+    return;
+  }
+
+  // ---- Q^T fragments (B operand of K . Q^T): lane supplies q[row][16 ks + 8 u .. + 8)
+  v8s qf[36];
+  {
+    const int64_t qrow = q_row0 + (ok ? my_tok : 0);
+    const T* qn = q_nope + qrow * p.qn_sb + (int64_t)(ok ? my_head : 0) * p.qn_sh + 8 * u;
+    const T* qp = q_pe + qrow * p.qp_sb + (int64_t)(ok ? my_head : 0) * p.qp_sh + 8 * u;
+    const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 36; ++ks) {
+      const T* src = ks < 32 ? qn + 16 * ks : qp + 16 * (ks - 32);
+      const v8s v = *reinterpret_cast<const v8s*>(src);
+      qf[ks] = ok ? v : zero;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q is in registers before any LDS-DMA is counted
+
+  // ---- per-lane LDS read offsets inside a stage
+  // K row read, k-step ks: block ks / 8, chunk 2 (ks % 8) + u of token row l31  ->  kbase ^ (32 (ks % 8)) + 8192 (ks / 8)
+  const uint32_t kbase = (uint32_t)(256 * l31 + 16 * (u ^ sw_main(l31)));
+  const uint32_t rbase = (uint32_t)(kMainBytes + 128 * l31 + 16 * (u ^ ((l31 >> 1) & 7)));  // rope: ^ (32 (ks - 32))
+  // V^T transposed read of dim tile dt, k-step s, token half e (tokens 16 s + 8 e + 4 u + qq, dims 32 dt + 16 hh + 4 pp ..):
+  //   8192 (dt / 4) + 4096 s + 2048 e + (vbase ^ (64 (dt % 4)) ^ (32 e))
+  const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, hh = (lane >> 4) & 1;
+  const uint32_t vbase = (uint32_t)(256 * (4 * u + qq) + 8 * (pp & 1) + 16 * ((qq << 2) | ((2 * hh + (pp >> 1)) ^ u)));
+
+  // O^T tile dt = a[16 dt .. 16 dt + 15], named only in asm text; the clobbers tell the compiler that the kernel owns the
+  // whole AGPR file (build.py check_isa verifies that it places nothing there)
+  asm volatile("" ::: "a0", "a255");
+  static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
+
+  constexpr bool kWide = std::is_same<T, bf16>::value;  // weights with fp32's exponent range: see the kernel above
+  constexpr float kLazy = kWide ? 50.0f : 8.0f;
+  const float sl2 = p.scale_log2;
+  const float head_raw = (kWide && sl2 > 0.f) ? 50.0f / sl2 : 0.f;  // 2^50 in units of the raw logits
+  float m_ref = -INFINITY, m_run = -INFINITY, l_run = 0.f;
+
+  int pgn0, pgn1;
+  {
+    int a0, a1;
+    load_pages(0, a0, a1);
+    stage_tile(t_begin, 0, a0, a1);
+    if (n_my > 1) {
+      load_pages(1, a0, a1);
+      stage_tile(t_begin + 1, 1, a0, a1);
+    }
+  }
+  load_pages(2, pgn0, pgn1);
+
+  // ---- S^T of tile j (raw logits) in VGPRs (asm MFMAs: left to itself the compiler puts this accumulator into a0..a15),
+  // K fragments kKA k-steps ahead, in program order. The first MFMA takes the constant 0 as its addend: no VALU write
+  // feeds an asm MFMA (the hazard recogniser cannot see one).
+  typedef const v8s __attribute__((address_space(3))) * lds_v8s;
+  typedef v4s __attribute__((address_space(3))) * lds_v4s;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
+  auto qk_tile = [&](int j, v16f& s) {
+    const uint32_t sb = lds_base + (uint32_t)((j & 3) * kStageBytes);
+    uint32_t kb = kbase, rb = rbase;
+    asm volatile("" : "+v"(kb), "+v"(rb));  // (derive the chunk addresses here, not across the whole loop)
+    v8s kr[kKA];
+    auto k_addr = [&](int ks) -> uint32_t {
+      const uint32_t off = ks < 32 ? ((kb ^ (uint32_t)((ks & 7) << 5)) + (uint32_t)((ks >> 3) * 8192))
+                                   : (rb ^ (uint32_t)((ks - 32) << 5));
+      return sb + off;
+    };
+#pragma unroll
+    for (int ks = 0; ks < kKA; ++ks) kr[ks] = *(lds_v8s)(uintptr_t)k_addr(ks);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 36>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      if constexpr (ks == 0) M::first_v(s, kr[ks % kKA], qf[ks]);
+      else M::acc_v(s, kr[ks % kKA], qf[ks]);
+      if constexpr (ks + kKA < 36) {
+        // the next address is computed while this slot is still reserved (its MFMA was issued just before: the compiler
+        // would otherwise be free to put the address into the operand registers the matrix pipe is still reading)
+        const uint32_t a = k_addr(ks + kKA);
+        asm volatile("" ::"v"(kr[ks % kKA]), "v"(a));
+        kr[ks % kKA] = *(lds_v8s)(uintptr_t)a;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("" : "+v"(s));
+#pragma unroll
+    for (int i = 0; i < kKA; ++i) asm volatile("" ::"v"(kr[i]));  // (the ring stays reserved past the last MFMAs)
+  };
+
+  // ---- the softmax of a tile as micro-ops (a few vector instructions each): one per gap of the P . V MFMAs of the
+  // previous tile. State between micro-ops:
+  float mt = 0.f, mb = 0.f, alpha = 1.0f, mneg = 0.f, psum = 0.f;
+  bool upd = false;
+  v8s pfn[2];
+  auto mask_tile = [&](int j, v16f& s) {  // (rare, uniform: keys past a row's horizon)
+    const int t = t_begin + j;
+    if (t * kTile + kTile > kv_first || t * kTile + kTile > seq) {
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s));  // (asm MFMA result -> VALU read wait states)
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        if (t * kTile + (v & 3) + 8 * (v >> 2) + 4 * u >= kv_row) s[v] = -INFINITY;
+    }
+  };
+  auto sm_op = [&](auto kc, v16f& s) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k == 0) {
+      mt = fmaxf(fmaxf(s[0], s[1]), s[2]);
+      mb = fmaxf(fmaxf(s[3], s[4]), s[5]);
+    } else if constexpr (k == 1) {
+      mt = fmaxf(fmaxf(mt, s[6]), s[7]);
+      mb = fmaxf(fmaxf(mb, s[8]), s[9]);
+    } else if constexpr (k == 2) {
+      mt = fmaxf(fmaxf(mt, s[10]), s[11]);
+      mb = fmaxf(fmaxf(mb, s[12]), s[13]);
+    } else if constexpr (k == 3) {
+      mt = fmaxf(fmaxf(mt, s[14]), s[15]);
+      mt = fmaxf(mt, mb);
+    } else if constexpr (k == 4) {  // the other 16 tokens of this row live in lane ^ 32
+      float c0 = mt, c1 = mt;
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
+      mt = fmaxf(c0, c1);
+    } else if constexpr (k == 5) {
+      // lazy reference (see the kernel above): it moves only when a weight would pass 2^kLazy, then to 2^50 (bf16) above
+      // the running maximum; all rows of the wave move together (one rescale pass serves them all)
+      upd = __any((mt - m_ref) * sl2 > kLazy);  // (first tile: +inf; nothing but masked keys so far: NaN -> false)
+      m_run = fmaxf(m_run, mt);
+    } else if constexpr (k == 6) {
+      const float cand = upd ? m_run + head_raw : -INFINITY;  // (selects, no branch in the MFMA stream)
+      const float m_new = fmaxf(m_ref, cand);
+      alpha = m_new > m_ref ? __builtin_amdgcn_exp2f((m_ref - m_new) * sl2) : 1.0f;
+      m_ref = m_new;
+    } else if constexpr (k == 7) {
+      mneg = m_ref == -INFINITY ? 0.f : -m_ref * sl2;
+      psum = 0.f;
+    } else if constexpr (k < 24) {  // weights 0 .. 15; a finished pair is rounded and packed in the next slot
+      constexpr int v = k - 8;
+      s[v] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[v], sl2, mneg));
+      if constexpr ((v & 1) == 0 && v >= 2) {
+        const int pk = M::pack(s[v - 2], s[v - 1]);
+        psum = M::add2(pk, psum);  // the row sum takes the ROUNDED weights (numerator and denominator round alike)
+        pfn[(v - 2) >> 3][(v - 2) & 7] = (short)(pk & 0xffff);
+        pfn[(v - 2) >> 3][((v - 2) & 7) + 1] = (short)((unsigned)pk >> 16);
+      }
+    } else if constexpr (k == 24) {
+      const int pk = M::pack(s[14], s[15]);
+      psum = M::add2(pk, psum);
+      pfn[1][6] = (short)(pk & 0xffff);
+      pfn[1][7] = (short)((unsigned)pk >> 16);
+    } else if constexpr (k == 25) {
+      l_run = l_run * alpha + psum;
+    }
+  };
+  constexpr int kSmOps = 26;
+
+  // ---- O^T += V^T . P^T of tile jv (asm MFMAs on the fixed accumulators, in program order), V^T fragments kVA steps
+  // ahead; step m = (dim tiles 2 (m / 4), 2 (m / 4) + 1) x (k-step (m / 2) % 2): two accumulators alternate
+  auto pv_tile = [&](int jv, const v8s (&pf)[2], auto with_softmax, v16f& s) {
+    constexpr bool kSm = decltype(with_softmax)::value;
+    const uint32_t sb = lds_base + (uint32_t)((jv & 3) * kStageBytes);
+    uint32_t vb0 = vbase;
+    asm volatile("" : "+v"(vb0));
+    const uint32_t vb1 = (vb0 ^ 32u) + 2048u;
+    v8s vf[kVA];
+    auto v_read = [&](int m) -> v8s {
+      const int dt = 2 * (m >> 2) + (m & 1), ss = (m >> 1) & 1;
+      const uint32_t x = (uint32_t)((dt & 3) << 6), c = (uint32_t)((dt >> 2) * 8192 + ss * 4096);
+      const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(uintptr_t)(sb + ((vb0 ^ x) + c)));
+      const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(uintptr_t)(sb + ((vb1 ^ x) + c)));
+      return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+#pragma unroll
+    for (int m = 0; m < kVA; ++m) vf[m] = v_read(m);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 32>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int dt = 2 * (m >> 2) + (m & 1), ss = (m >> 1) & 1;
+      M::template acc_agpr<dt * 16>(vf[m % kVA], pf[ss]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kSm && m >= 2 && m - 2 < kSmOps) sm_op(std::integral_constant<int, m - 2>{}, s);
+      // the fragment's registers stay reserved past the micro-op (a VALU write into an operand of the MFMA issued just
+      // before is not interlocked); the refill of this slot lands tens of cycles later
+      asm volatile("" ::"v"(vf[m % kVA]));
+      if constexpr (m + kVA < 32) vf[m % kVA] = v_read(m + kVA);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // the operands of the last MFMAs stay reserved until the matrix pipe has read them; the nops also cover the
+    // MFMA -> v_accvgpr_read wait states of the rescale / the epilogue
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::"v"(pf[0]), "v"(pf[1]));
+#pragma unroll
+    for (int i = 0; i < kVA; ++i) asm volatile("" ::"v"(vf[i]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  v8s pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+  unsigned long long st_sum[7] = {0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+  auto stamp = [&](int k) {
+    if constexpr (kStamp) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      st_sum[k] += now - st_t;
+      st_t = now;
+    }
+  };
+  if constexpr (kStamp) st_t = __builtin_amdgcn_s_memtime();
+  for (int j = 0; j < n_my; ++j) {
+    stamp(j == 0 ? 5 : 4);
+    if (j + 1 < n_my) wait_vmcnt<9>(); else wait_vmcnt<0>();
+    stamp(0);
+    __builtin_amdgcn_s_barrier();  // tile j landed for every wave; every wave is done with tile j-2
+    stamp(1);
+    // (the page ids count as used here on every path: no scalar load is outstanding - on the LDS reads' counter - in the
+    //  phases below, so the compiler waits for LDS reads by count instead of for everything)
+    asm volatile("" ::"s"(pgn0), "s"(pgn1));
+    if (j + 2 < n_my) stage_tile(t_begin + j + 2, (j + 2) & 3, pgn0, pgn1);
+    stamp(2);
+    if (work) {
+      v16f s;
+      qk_tile(j, s);
+      mask_tile(j, s);
+      __builtin_amdgcn_sched_barrier(0);
+      stamp(3);
+      if (j > 0) {
+        pv_tile(j - 1, pf, std::true_type{}, s);  // P . V of tile j-1 with the softmax of tile j in its gaps
+        if (upd) {  // rare: the reference moved, rescale O (AGPR -> VGPR -> AGPR) before the next P . V
+          const v4f a4 = {alpha, alpha, alpha, alpha};
+          static_for<0, 32>([&](auto ic) { agpr_scale8<decltype(ic)::value * 8>(a4); });
+          asm volatile("s_nop 7");
+        }
+      } else {
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s));  // (asm MFMA result -> VALU read wait states)
+        static_for<0, kSmOps>([&](auto kc) { sm_op(kc, s); });  // (O is zero: nothing to rescale)
+      }
+      pf[0] = pfn[0];
+      pf[1] = pfn[1];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    load_pages(j + 3, pgn0, pgn1);
+  }
+  if (work) {
+    v16f dummy;
+    pv_tile(n_my - 1, pf, std::false_type{}, dummy);
+  }
+  stamp(4);
+#ifdef SGLK_PROBES
+  auto write_stamps = [&]() {
+    if constexpr (kStamp) {
+      stamp(6);
+      if (lane == 0) {
+        unsigned long long* d = g_mla_stamps + (((size_t)b * p.splits + split) * 4 + wave) % 4096 * 8;
+        for (int k = 0; k < 7; ++k) d[k] = st_sum[k];
+        d[7] = (unsigned long long)n_my;
+      }
+    }
+  };
+#else
+  auto write_stamps = [&]() {};
+#endif
+
+  // ---- epilogue: O^T tile dt, register v: dim 32 dt + 8 (v / 4) + 4 u + v % 4 of this lane's row
+  if (p.probe == 1) return;
+  float c0 = l_run, c1 = l_run;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));
+  const float l_tot = c0 + c1;
+  const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (p.splits == 1) {
+    T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + (ok ? my_head : 0)) * kLatent + 4 * u;
+    static_for<0, 64>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;  // dim tile i / 4, register group i % 4
+      const v4f v = agpr_read4<i * 4>();
+      const int lo = M::pack(v[0] * inv_l, v[1] * inv_l), hi = M::pack(v[2] * inv_l, v[3] * inv_l);
+      if (ok) *reinterpret_cast<v2i*>(out + 32 * (i >> 2) + 8 * (i & 3)) = (v2i){lo, hi};
+    });
+  } else {
+    float* wo = p.ws_o + (((int64_t)b * p.splits + split) * H + (ok ? my_head : 0)) * kLatent + 4 * u;
+    static_for<0, 64>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const v4f v = agpr_read4<i * 4>();
+      if (ok) *reinterpret_cast<v4f*>(wo + 32 * (i >> 2) + 8 * (i & 3)) = (v4f){v[0] * inv_l, v[1] * inv_l, v[2] * inv_l, v[3] * inv_l};
+    });
+    if (ok && u == 0)
+      p.ws_lse[((int64_t)b * p.splits + split) * H + my_head] = l_tot > 0.f ? m_ref * sl2 + log2f(l_tot) : -INFINITY;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  write_stamps();
+}
+
 // out[b,h,:] = sum_s w_s O_s / sum_s w_s,  w_s = 2^(lse_s - max lse)
 template <typename T>
 __global__ __launch_bounds__(128) void mla_reduce_kernel(T* __restrict__ out, const float* __restrict__ ws_o,
@@ -1099,6 +1548,49 @@ static int launch_rows128(hipStream_t st, const MlaParams& p, int B, const void*
   return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
 }
 
+template <typename T, int KA, int VA>
+static int launch_rows128x_v(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
+                             const void* cache, const int32_t* seq_lens, const int32_t* page_table,
+                             const int32_t* cu_seqlens_q, int token_blocks) {
+  static unsigned long long attr_done = 0;
+  constexpr int lds = 4 * kStageBytes;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, KA, VA>), lds, &attr_done,
+                               "flash_mla_decode"))
+    return rc;
+  mla_rows128x_kernel<T, KA, VA><<<dim3(p.splits, B, token_blocks), kThreads2, lds, st>>>(
+      p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
+  return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
+}
+#ifdef SGLK_PROBES
+static int g_mla_variant = 0;  // ring depths of the rows128x kernel (kbench)
+#endif
+template <typename T>
+static int launch_rows128x(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
+                           const void* cache, const int32_t* seq_lens, const int32_t* page_table,
+                           const int32_t* cu_seqlens_q = nullptr, int token_blocks = 1) {
+#ifdef SGLK_PROBES
+#define SGLK_V(KA, VA) return launch_rows128x_v<T, KA, VA>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table, cu_seqlens_q, token_blocks)
+  if constexpr (std::is_same<T, bf16>::value) {
+    if (g_mla_variant == 1) SGLK_V(5, 5);
+    if (g_mla_variant == 2) SGLK_V(6, 6);
+    if (g_mla_variant == 3) SGLK_V(4, 6);
+    if (g_mla_variant == 4) SGLK_V(6, 4);
+    if (g_mla_variant == 5) SGLK_V(2, 2);
+    if (g_mla_variant == 9) {
+      static unsigned long long attr2 = 0;
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 3, 4, true>), 4 * kStageBytes, &attr2,
+                                   "flash_mla_decode"))
+        return rc;
+      mla_rows128x_kernel<T, 3, 4, true><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(
+          p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
+      return check_launch("flash_mla_decode");
+    }
+  }
+#undef SGLK_V
+#endif
+  return launch_rows128x_v<T, 3, 4>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table, cu_seqlens_q, token_blocks);
+}
+
 // Diagnostic build only (-DSGLK_PROBES, tools/kbench): force the number of waves per 16-head group (0 = automatic;
 // 9 = never the rows128 kernel) and the streaming-only timing probe (garbage results). The release library has
 // neither switch.
@@ -1118,6 +1610,8 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
   if (g_mla_waves_per_group > 0 && g_mla_waves_per_group <= w) w = g_mla_waves_per_group;
   int rc;
   if (ngroups > 4 && g_mla_waves_per_group == 0) {
+    rc = launch_rows128x<T>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table);
+  } else if (ngroups > 4 && g_mla_waves_per_group == 10) {  // (hook: the 16x16x32 form of round 2, for A/B timing)
     rc = launch_rows128<T>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table);
   } else
   switch (w) {
@@ -1140,6 +1634,10 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
 #ifdef SGLK_PROBES
 extern "C" SGLK_API void sglk_debug_set_mla_waves_per_group(int w) { sglk::g_mla_waves_per_group = w; }
 extern "C" SGLK_API void sglk_debug_set_mla_probe(int v) { sglk::g_mla_probe = v; }
+extern "C" SGLK_API void sglk_debug_set_mla_variant(int v) { sglk::g_mla_variant = v; }
+extern "C" SGLK_API int sglk_debug_get_mla_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sglk::g_mla_stamps), (size_t)n * 8);
+}
 #endif
 
 // Number of KV splits used when the caller passes num_kv_splits < 1: about one workgroup per CU, and at
@@ -1265,7 +1763,12 @@ extern "C" int sglk_flash_mla_prefill(sglk_stream_t stream, void* out, const voi
       return launch_w<bf16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
     return launch_w<f16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
   }
+  if (g_mla_waves_per_group == 10) {
+    if (dtype == SGLK_BF16)
+      return launch_rows128<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+    return launch_rows128<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+  }
   if (dtype == SGLK_BF16)
-    return launch_rows128<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
-  return launch_rows128<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+    return launch_rows128x<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
+  return launch_rows128x<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
 }

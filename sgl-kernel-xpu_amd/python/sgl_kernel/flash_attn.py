@@ -67,6 +67,10 @@ def _scale_or_default(softmax_scale, q, qv):
 def _as_ragged(q, cu_seqlens_q, max_seqlen_q):
     """(q [total, h, d], cu_seqlens_q, max_seqlen_q). A padded [b, s, h, d] batch becomes ragged rows with equal lengths."""
     if cu_seqlens_q is not None:
+        # ragged q without a usable bound: the row count is always one (no device read-back: graph-capture safe);
+        # it only costs the tuned decode / prefill kernel choice, never correctness
+        if max_seqlen_q is None or max_seqlen_q <= 0 or max_seqlen_q > q.size(0):
+            max_seqlen_q = q.size(0)
         return q, cu_seqlens_q, max_seqlen_q
     b, s = q.size(0), q.size(1)
     cu = torch.arange(0, b + 1, dtype=torch.int32, device=q.device) * s

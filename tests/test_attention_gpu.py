@@ -15,15 +15,14 @@ pytestmark = pytest.mark.gpu
 
 
 def pt_seq(q, k, v, scale, causal, window, softcap, sinks):
-    """The same math in the input dtype (no upcast) — the reference's yardstick `out_pt`."""
+    """The same math in the input dtype (no upcast) — the reference's yardstick `out_pt`: scores, probabilities and the
+    output rounded to the input dtype. (The products run as fp32 matmuls of the rounded operands and their results are
+    rounded: what a 16-bit matmul with fp32 accumulation returns, without the CPU's slow half-precision GEMM.)"""
     dt = q.dtype
-    o, _ = oa.attention_seq(q, (k.float() * scale).to(dt).float() / scale if False else k, v, scale, causal=causal,
-                            window=window, softcap=softcap, sinks=sinks)
-    # low-precision emulation: scores and probabilities rounded to the input dtype
     sq, Hq, D = q.shape
     g = Hq // k.shape[1]
     kf = (k * scale).repeat_interleave(g, dim=1)
-    scores = torch.einsum("thd,shd->hts", q, kf.to(dt)).float()
+    scores = torch.einsum("thd,shd->hts", q.float(), kf.to(dt).float()).to(dt).float()
     if softcap > 0:
         scores = torch.tanh(scores / softcap) * softcap
     sk = k.shape[0]
@@ -43,7 +42,7 @@ def pt_seq(q, k, v, scale, causal, window, softcap, sinks):
     attn = torch.nan_to_num(torch.softmax(scores, dim=-1), nan=0.0).to(dt)
     if sinks is not None:
         attn = attn[..., :-1]
-    return torch.einsum("hts,shd->thd", attn, v.repeat_interleave(g, dim=1)).float()
+    return torch.einsum("hts,shd->thd", attn.float(), v.repeat_interleave(g, dim=1).float()).to(dt).float()
 
 
 def check(out, ref, pt, what=""):
@@ -55,51 +54,82 @@ def check(out, ref, pt, what=""):
     assert m <= 1.5 * m_pt + 1e-6, f"{what}: mean err {m:.3e} > 1.5 x {m_pt:.3e}"
 
 
-def run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, D, page, causal=False, window=(-1, -1), softcap=0.0,
-              use_sink=False, num_splits=0, seed=0, use_out=False):
+_CASE_CACHE = {}
+
+
+def paged_case(dtype, seqs_q, seqs_k, Hq, Hk, D, causal, window, softcap, use_sink, seed):
+    """Logical inputs + the CPU oracle and its low-precision yardstick for one ragged batch. Nothing here depends on the
+    page size or the split count, so the (slow) CPU side is computed once per logical case and reused by every
+    (page, num_splits) launch of it (one entry kept: the callers iterate page / splits innermost)."""
+    key = (dtype, tuple(seqs_q), tuple(seqs_k), Hq, Hk, D, causal, tuple(window), softcap, use_sink, seed)
+    hit = _CASE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    _CASE_CACHE.clear()
     g = torch.Generator().manual_seed(seed)
     b = len(seqs_q)
     q = torch.randn(sum(seqs_q), Hq, D, generator=g).to(dtype)
     cu_q = torch.tensor([0] + list(itertools.accumulate(seqs_q)), dtype=torch.int32)
-    pages_per_seq = (max(seqs_k) + page - 1) // page
-    n_pages = b * pages_per_seq + 3
-    kc = torch.randn(n_pages, page, Hk, D, generator=g).to(dtype)
-    vc = torch.randn(n_pages, page, Hk, D, generator=g).to(dtype)
-    table = torch.randperm(n_pages, generator=g)[: b * pages_per_seq].view(b, pages_per_seq).to(torch.int32)
-    lens = torch.tensor(seqs_k, dtype=torch.int32)
+    s_pad = (max(seqs_k) + 255) // 256 * 256  # whole pages for every page size used (32..256); the tail is random too
+    k_log = torch.randn(b, s_pad, Hk, D, generator=g).to(dtype)
+    v_log = torch.randn(b, s_pad, Hk, D, generator=g).to(dtype)
     sinks = torch.randn(Hq, generator=g) if use_sink else None
     scale = D ** -0.5
-    ks = [oa.gather_paged(kc, table[i], seqs_k[i]) for i in range(b)]
-    vs = [oa.gather_paged(vc, table[i], seqs_k[i]) for i in range(b)]
+    ks = [k_log[i, :seqs_k[i]] for i in range(b)]
+    vs = [v_log[i, :seqs_k[i]] for i in range(b)]
     ref, ref_lse = oa.attention_ragged(q, ks, vs, cu_q, scale, causal=causal, window=window, softcap=softcap, sinks=sinks)
     pt = torch.zeros_like(ref)
     for i in range(b):
         s, e = cu_q[i], cu_q[i + 1]
         if e > s:
             pt[s:e] = pt_seq(q[s:e], ks[i], vs[i], scale, causal, window, softcap, sinks)
-    out_buf = torch.empty(q.shape, dtype=dtype, device=dev) if use_out else None
+    case = dict(q=q, cu_q=cu_q, k_log=k_log, v_log=v_log, sinks=sinks, scale=scale, ref=ref, ref_lse=ref_lse, pt=pt,
+                dev={})
+    _CASE_CACHE[key] = case
+    return case
+
+
+def run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, D, page, causal=False, window=(-1, -1), softcap=0.0,
+              use_sink=False, num_splits=0, seed=0, use_out=False):
+    c = paged_case(dtype, seqs_q, seqs_k, Hq, Hk, D, causal, window, softcap, use_sink, seed)
+    b = len(seqs_q)
+    if page not in c["dev"]:  # cut the logical rows into shuffled pages (3 spare pages of noise), upload once per page size
+        c["dev"].clear()
+        g = torch.Generator().manual_seed(seed * 131 + page)
+        pages_per_seq = (max(seqs_k) + page - 1) // page
+        n_pages = b * pages_per_seq + 3
+        table = torch.randperm(n_pages, generator=g)[: b * pages_per_seq].view(b, pages_per_seq)
+        kc = torch.randn(n_pages, page, Hk, D, generator=g).to(dtype) if n_pages * page * Hk * D < 2**22 else \
+            torch.zeros(n_pages, page, Hk, D, dtype=dtype)
+        vc = kc.clone()
+        kc[table.view(-1)] = c["k_log"][:, :pages_per_seq * page].reshape(b * pages_per_seq, page, Hk, D)
+        vc[table.view(-1)] = c["v_log"][:, :pages_per_seq * page].reshape(b * pages_per_seq, page, Hk, D)
+        assert torch.equal(oa.gather_paged(kc, table[b - 1], seqs_k[b - 1]), c["k_log"][b - 1, :seqs_k[b - 1]])
+        c["dev"][page] = (c["q"].to(dev), kc.to(dev), vc.to(dev), torch.tensor(seqs_k, dtype=torch.int32, device=dev),
+                          table.to(torch.int32).to(dev), c["cu_q"].to(dev), c["sinks"].to(dev) if use_sink else None)
+    q_d, kc_d, vc_d, lens_d, table_d, cu_q_d, sinks_d = c["dev"][page]
+    out_buf = torch.empty(q_d.shape, dtype=dtype, device=dev) if use_out else None
     res = sglk.flash_attn_with_kvcache(
-        q.to(dev), kc.to(dev), vc.to(dev), cache_seqlens=lens.to(dev), page_table=table.to(dev),
-        cu_seqlens_q=cu_q.to(dev), max_seqlen_q=max(seqs_q), softmax_scale=scale,
-        sinks=sinks.to(dev) if use_sink else None, causal=causal, window_size=window, softcap=softcap,
+        q_d, kc_d, vc_d, cache_seqlens=lens_d, page_table=table_d, cu_seqlens_q=cu_q_d, max_seqlen_q=max(seqs_q),
+        softmax_scale=c["scale"], sinks=sinks_d, causal=causal, window_size=window, softcap=softcap,
         num_splits=num_splits, return_softmax_lse=True, out=out_buf)
     out, lse = res[0], res[1]
     if use_out:
         assert out.data_ptr() == out_buf.data_ptr()
-    check(out.cpu(), ref, pt, f"paged D={D} page={page}")
-    fin = torch.isfinite(ref_lse)
-    torch.testing.assert_close(lse.cpu()[fin], ref_lse[fin], rtol=1e-3, atol=1e-3)
+    check(out.cpu(), c["ref"], c["pt"], f"paged D={D} page={page} splits={num_splits}")
+    fin = torch.isfinite(c["ref_lse"])
+    torch.testing.assert_close(lse.cpu()[fin], c["ref_lse"][fin], rtol=1e-3, atol=1e-3)
 
 
 # ---------------------------------------------------------------------- paged kv-cache, mixed prefill/decode batches
+@pytest.mark.parametrize("page", [64, 128])  # outermost decorator = fastest-varying: both page sizes reuse one oracle run
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("heads", [(16, 16), (16, 4), (8, 1)])
 @pytest.mark.parametrize("causal,local", [(False, True), (False, False), (True, False)])
-@pytest.mark.parametrize("page", [64, 128])
 @pytest.mark.parametrize("D", [64, 128, 256])
 def test_kvcache_paged(sglk, dev, dtype, heads, causal, local, page, D):
     Hq, Hk = heads
-    idx = hash((str(dtype), heads, causal, local, page, D)) % 5
+    idx = (heads[1] + 3 * causal + 2 * local + D // 64 + (dtype == torch.float16)) % 5  # same for both page sizes
     sq, sk = [(3, 1024), (64, 800), (64, 256), (3, 799), (128, 128)][idx]
     g = torch.Generator().manual_seed(idx)
     seqs_k = torch.randint(max(1, sk - 20), sk + 1, (3,), generator=g).tolist()
@@ -115,11 +145,11 @@ def test_kvcache_other_head_dims(sglk, dev, D, sq, sk):
 
 
 # --------------------------------------------------------------------------------------------------- decode
+@pytest.mark.parametrize("page", [64, 128])  # fastest-varying: the CPU oracle of a logical case runs once for both
 @pytest.mark.parametrize("heads", [(16, 16), (16, 4), (16, 1), (8, 1), (32, 8)])
 @pytest.mark.parametrize("local", [False, True])
-@pytest.mark.parametrize("page", [64, 128])
 @pytest.mark.parametrize("D", [64, 128, 256])
-@pytest.mark.parametrize("batch,seqlen_k", [(1, 1), (4, 63), (1, 64), (4, 65), (1, 129), (4, 1024), (1, 4033), (4, 4097),
+@pytest.mark.parametrize("batch,seqlen_k", [(1, 1), (4, 63), (1, 64), (4, 65), (1, 129), (4, 1024), (1, 4033), (2, 4097),
                                             (2, 8192)])
 def test_decode(sglk, dev, heads, local, page, D, batch, seqlen_k):
     Hq, Hk = heads
@@ -145,7 +175,7 @@ def test_decode_kernel_features(sglk, dev, dtype, heads, sq, feature):
     seqs_q = [min(sq, k) for k in seqs_k]
     kw = dict(causal="causal" in feature, window=(100, 0) if feature == "local" else (-1, -1),
               softcap=20.0 if feature == "softcap" else 0.0, use_sink="sinks" in feature)
-    for page, splits in ((32, 0), (64, 1), (256, 3), (64, 16)):
+    for page, splits in ((32, 0), (64, 1), (64, 16), (256, 3)):
         run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, 128, page, num_splits=splits, seed=sq + Hq, **kw)
 
 
@@ -245,6 +275,23 @@ def test_errors(sglk, dev):
         sglk.flash_attn_varlen_func(q, k.to(torch.bfloat16), k, cu, cuk, 4, 8)
     with pytest.raises(RuntimeError, match="must divide"):
         sglk.flash_attn_varlen_func(q[:, :1].repeat(1, 3, 1), k.repeat(1, 2, 1), k.repeat(1, 2, 1), cu, cuk, 4, 8)
+
+
+def test_missing_max_seqlen_q_is_safe(sglk, dev):
+    """ragged q with max_seqlen_q left at 0 (the reference wrapper's default for cu_seqlens_q calls): d = 128 and 40 packed
+    rows must not be handed to the 16-row decode kernel; the wrapper substitutes the row count as the bound."""
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(40, 4, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(300, 2, 128, generator=g).to(torch.bfloat16)
+    v = torch.randn(300, 2, 128, generator=g).to(torch.bfloat16)
+    cu_q = torch.tensor([0, 20, 40], dtype=torch.int32)
+    cu_k = torch.tensor([0, 100, 300], dtype=torch.int32)
+    args = (q.to(dev), k.to(dev), v.to(dev), cu_q.to(dev), cu_k.to(dev))
+    good = sglk.flash_attn_varlen_func(*args, 20, 200, causal=True)
+    lazy = sglk.flash_attn_varlen_func(*args, 0, 200, causal=True)
+    assert torch.equal(good, lazy)
+    ref, _ = oa.attention_ragged(q, [k[:100], k[100:]], [v[:100], v[100:]], cu_q, 128 ** -0.5, causal=True)
+    torch.testing.assert_close(lazy.float().cpu(), ref, rtol=2e-2, atol=2e-2)
 
 
 # ---------------------------------------------------------------------- fp8 KV cache (reference :1697-1830)

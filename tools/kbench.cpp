@@ -17,6 +17,8 @@
 extern "C" void sglk_debug_set_gemm_variant(int);
 extern "C" void sglk_debug_set_mla_waves_per_group(int);
 extern "C" void sglk_debug_set_mla_probe(int);
+extern "C" void sglk_debug_set_mla_variant(int);
+extern "C" int sglk_debug_get_mla_stamps(unsigned long long*, int);
 extern "C" void sglk_debug_set_gemm_stamps(uint32_t*);
 extern "C" void sglk_debug_set_w4a16_probe(int probe, int force_mt);
 
@@ -617,8 +619,55 @@ int main(int argc, char** argv) {
         if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
       };
       std::vector<float> all;
-      const double ms = time_ms(run, 100, 50, &all);
       const double bytes = (double)B * H * 576 * 2 + (double)B * S * 576 * 2 + table.size() * 4 + B * 4 + (double)B * H * 512 * 2;
+      if (getenv("MLA_STAMPS")) {  // in-kernel stamps of the rows128x kernel: mean cycles per tile and wave in each segment
+        sglk_debug_set_mla_variant(9);
+        for (int i = 0; i < 20; ++i) run();
+        HIP_CHECK(hipDeviceSynchronize());
+        std::vector<unsigned long long> st(8 * 4 * 4096);
+        sglk_debug_get_mla_stamps(st.data(), (int)st.size());
+        const int nw = (int)std::min<int64_t>(4096, B * (splits > 0 ? splits : 1) * 4);
+        const char* names[7] = {"tile-landed wait", "barrier", "DMA issue", "QK^T", "PV+softmax", "prologue", "epilogue"};
+        for (int wv = 0; wv < 4; ++wv) {
+          double sum[7] = {0}, tiles = 0;
+          for (int i = wv; i < nw; i += 4) { for (int k = 0; k < 7; ++k) sum[k] += (double)st[i * 8 + k]; tiles += (double)st[i * 8 + 7]; }
+          printf("wave %d:", wv);
+          for (int k = 0; k < 5; ++k) printf("  %s %.0f", names[k], sum[k] / tiles);
+          printf("  | per launch: prologue %.0f epilogue %.0f tiles %.0f\n", sum[5] / (nw / 4), sum[6] / (nw / 4), tiles / (nw / 4));
+        }
+        sglk_debug_set_mla_variant(0);
+        if (ws) HIP_CHECK(hipFree(ws));
+        if (ai >= argc) break;
+        continue;
+      }
+      if (getenv("MLA_VARIANTS")) {  // interleaved rounds of the ring-depth variants of the rows128x kernel
+        const int nv = atoi(getenv("MLA_VARIANTS"));
+        for (int round = 0; round < 3; ++round)
+          for (int v = 0; v <= nv; ++v) {
+            sglk_debug_set_mla_variant(v);
+            const double m = time_ms(run, 60, 30, &all);
+            printf("mla[variant %d] B=%lld S=%lld H=%lld splits=%lld median %.4f ms min %.4f -> %.1f GB/s, %.1f TFLOP/s\n", v,
+                   (long long)B, (long long)S, (long long)H, (long long)splits, m, all[0], bytes / m / 1e6,
+                   2.0 * B * H * S * 1088 / m / 1e9);
+          }
+        if (ws) HIP_CHECK(hipFree(ws));
+        if (ai >= argc) break;
+        continue;
+      }
+      if (getenv("MLA_AB")) {  // interleaved rounds of the round-2 (16x16x32, hook 10) and the current rows128 kernel
+        for (int round = 0; round < 3; ++round)
+          for (int w : {10, 0}) {
+            sglk_debug_set_mla_waves_per_group(w);
+            const double m = time_ms(run, 60, 30, &all);
+            printf("mla[%s] B=%lld S=%lld H=%lld splits=%lld median %.4f ms min %.4f -> %.1f GB/s, %.1f TFLOP/s\n",
+                   w == 10 ? "r2 16x16" : "r3 32x32", (long long)B, (long long)S, (long long)H, (long long)splits, m, all[0],
+                   bytes / m / 1e6, 2.0 * B * H * S * 1088 / m / 1e9);
+          }
+        if (ws) HIP_CHECK(hipFree(ws));
+        if (ai >= argc) break;
+        continue;
+      }
+      const double ms = time_ms(run, 100, 50, &all);
       printf("mla B=%lld S=%lld H=%lld splits=%lld median %.4f ms min %.4f -> %.1f GB/s, %.1f TFLOP/s\n", (long long)B,
              (long long)S, (long long)H, (long long)splits, ms, all[0], bytes / ms / 1e6,
              2.0 * B * H * S * 1088 / ms / 1e9);
