@@ -158,6 +158,26 @@ __device__ __forceinline__ v4f agpr_read4() {
   return (v4f){t0, t1, t2, t3};
 }
 
+// a[R .. R+7] *= f * f (one scalar factor, applied as two multiplies: the rescale factor 2^-(move) of the rows128x kernel
+// spans up to ~2^-220, which a single fp32 factor cannot hold)
+template <int R>
+__device__ __forceinline__ void agpr_scale8_sq(float f) {
+  float t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(
+      "v_accvgpr_read_b32 %0, a[%9]\n\tv_accvgpr_read_b32 %1, a[%10]\n\tv_accvgpr_read_b32 %2, a[%11]\n\t"
+      "v_accvgpr_read_b32 %3, a[%12]\n\tv_accvgpr_read_b32 %4, a[%13]\n\tv_accvgpr_read_b32 %5, a[%14]\n\t"
+      "v_accvgpr_read_b32 %6, a[%15]\n\tv_accvgpr_read_b32 %7, a[%16]\n\t"
+      "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\t"
+      "v_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8\n\t"
+      "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %8\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %8\n\t"
+      "v_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %8\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %8\n\t"
+      "v_accvgpr_write_b32 a[%9], %0\n\tv_accvgpr_write_b32 a[%10], %1\n\tv_accvgpr_write_b32 a[%11], %2\n\t"
+      "v_accvgpr_write_b32 a[%12], %3\n\tv_accvgpr_write_b32 a[%13], %4\n\tv_accvgpr_write_b32 a[%14], %5\n\t"
+      "v_accvgpr_write_b32 a[%15], %6\n\tv_accvgpr_write_b32 a[%16], %7"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+      : "v"(f), "i"(R), "i"(R + 1), "i"(R + 2), "i"(R + 3), "i"(R + 4), "i"(R + 5), "i"(R + 6), "i"(R + 7));
+}
+
 __device__ __forceinline__ int sw_main(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 template <int N>
@@ -169,6 +189,13 @@ __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+}
+
+// hand-counted LDS wait that orders the asm reads of (lo, hi) in front of their first use
+template <int N>
+__device__ __forceinline__ void wait_lgkm(v2i& lo, v2i& hi) {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit field");
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "i"(N));
 }
 
 struct MlaParams {
@@ -1074,6 +1101,11 @@ struct Mfma32<bf16> {
   static __device__ __forceinline__ void acc_agpr(const v8s& a, const v8s& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(R), "i"(R + 15));
   }
+  template <int R, int N>  // the same behind its own hand-counted LDS wait (one statement: no compiler nop in between)
+  static __device__ __forceinline__ void wait_acc_agpr(const v8s& a, const v8s& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(R),
+                 "i"(R + 15), "i"(N));
+  }
   static __device__ __forceinline__ void acc_v(v16f& c, const v8s& a, const v8s& b) {  // accumulator pinned to VGPRs
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
   }
@@ -1100,6 +1132,11 @@ struct Mfma32<f16> {
   static __device__ __forceinline__ void acc_agpr(const v8s& a, const v8s& b) {
     asm volatile("v_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(R), "i"(R + 15));
   }
+  template <int R, int N>
+  static __device__ __forceinline__ void wait_acc_agpr(const v8s& a, const v8s& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_32x32x16_f16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "i"(R),
+                 "i"(R + 15), "i"(N));
+  }
   static __device__ __forceinline__ void acc_v(v16f& c, const v8s& a, const v8s& b) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
   }
@@ -1121,9 +1158,24 @@ struct Mfma32<f16> {
 #ifdef SGLK_PROBES
 // in-kernel stamps (diagnostic build): per wave, shader cycles summed over the tiles of [0] the tile-landed wait, [1] the
 // barrier, [2] the DMA issue, [3] QK^T, [4] P.V + softmax (+ rescale), [5] prologue, [6] epilogue, [7] tiles
-__device__ unsigned long long g_mla_stamps[8 * 4 * 4096];
+__device__ unsigned long long g_mla_stamps[16 * 4 * 4096];
 #endif
-template <typename T, int kKA, int kVA, bool kStamp = false>
+// kProbe (diagnostic build, garbage results): 1 = P.V without its LDS reads, 2 = QK^T without its LDS reads, 3 = both,
+// 4 = no DMA, 5 = no reads and no DMA, 6 = no softmax micro-ops, 9 = P.V as 32 bare MFMAs (no reads, no waits, no
+// micro-ops, no fences), 10 = 9 + the fences, 11 = 10 + the wait statements, 13 = QK^T accumulates into a0..a15
+// order of the 32 P.V MFMAs of a tile: step m -> (dim tile, k-step). kOrd 0: the two k-steps of a dim tile back to back
+// (the second takes the first's result through the pipeline's own forwarding); 1: four accumulators in rotation; 2: two
+// in rotation (the first version: a dependent MFMA that is not issued directly behind its producer waits for the
+// producer's write-back, ~100 cycles after its issue - 52 cycles per MFMA, found with the in-kernel stamps)
+template <int kOrd>
+__host__ __device__ constexpr int pv_dt(int m) {
+  return kOrd == 0 ? (m >> 1) : kOrd == 1 ? 4 * (m >> 3) + (m & 3) : 2 * (m >> 2) + (m & 1);
+}
+template <int kOrd>
+__host__ __device__ constexpr int pv_ss(int m) {
+  return kOrd == 0 ? (m & 1) : kOrd == 1 ? ((m >> 2) & 1) : ((m >> 1) & 1);
+}
+template <typename T, int kKA, int kVA, bool kStamp = false, int kProbe = 0, int kOrd = 0, bool kDmaQK = true>
 __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p, const T* __restrict__ q_nope,
                                                                     const T* __restrict__ q_pe,
                                                                     const char* __restrict__ cache,
@@ -1192,11 +1244,14 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
     }
     dma16((wave < 2 ? sA : sB) + dma_ro, base + (uint32_t)(kMainBytes + wave * 1024));
   };
+  // page ids of local tile j (clamped to the last one): two unconditional scalar loads - for pages of 32 tokens and more
+  // both name the same page - so that nothing waits on them where they are issued
   auto load_pages = [&](int j, int& pg0, int& pg1) {
     const int tok0 = (t_begin + (j < n_my ? j : n_my - 1)) * kTile;
-    pg0 = table[tok0 >> p.page_shift];
-    pg1 = pg0;
-    if (p.page_shift == 4 && tok0 + 16 < seq) pg1 = table[(tok0 + 16) >> 4];
+    const int i0 = tok0 >> p.page_shift;
+    const int i1 = (tok0 + 16 < seq) ? ((tok0 + 16) >> p.page_shift) : i0;
+    pg0 = table[i0];
+    pg1 = table[i1];
   };
 
   // ---- nothing to do for this split (decode only: an empty sequence, or more splits than tiles)
@@ -1244,53 +1299,147 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
   asm volatile("" ::: "a0", "a255");
   static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
 
-  constexpr bool kWide = std::is_same<T, bf16>::value;  // weights with fp32's exponent range: see the kernel above
-  constexpr float kLazy = kWide ? 50.0f : 8.0f;
+  // Lazy reference (the idea of the kernel above, wider here): bf16 weights have fp32's exponent range, so the reference
+  // need not be the maximum. When it moves it is set 2^kHead ABOVE the row's running maximum (weights restart at 2^-kHead)
+  // and it moves again only when a weight would pass 2^kLazy: kHead + kLazy = 190 binades of growth per move (100 in the
+  // kernel above; the reference benchmark's q x 100 logits grow by ~220 binades over a split, and every move of any of
+  // a wave's 32 rows costs the wave - and, through the tile barrier, the workgroup - a 768-instruction pass over O).
+  // Range: 2^kLazy x keys x |V| stays below 2^127 for a million keys and |V| < 2^16; a weight 2^-24 below the largest
+  // one is still >= 2^-124 (normal); the rescale factor 2^-(move), down to ~2^-220, is applied as two multiplies by its
+  // square root. f16 weights must stay in [2^-14, 2^16): threshold 2^8, no headroom.
+  constexpr bool kWide = std::is_same<T, bf16>::value;
+  constexpr float kLazy = kWide ? 90.0f : 8.0f, kHead = kWide ? 100.0f : 0.0f;
   const float sl2 = p.scale_log2;
-  const float head_raw = (kWide && sl2 > 0.f) ? 50.0f / sl2 : 0.f;  // 2^50 in units of the raw logits
+  const float head_raw = (kWide && sl2 > 0.f) ? kHead / sl2 : 0.f;  // 2^kHead in units of the raw logits
   float m_ref = -INFINITY, m_run = -INFINITY, l_run = 0.f;
 
+  // Every tile slot past the split's last tile re-loads the last tile into a stage nobody reads (two duplicates per split):
+  // the DMA needs no condition and every tile-landed wait is the same vmcnt(9).
+  auto tile_of = [&](int j) { return t_begin + (j < n_my ? j : n_my - 1); };
   int pgn0, pgn1;
   {
     int a0, a1;
     load_pages(0, a0, a1);
-    stage_tile(t_begin, 0, a0, a1);
-    if (n_my > 1) {
-      load_pages(1, a0, a1);
-      stage_tile(t_begin + 1, 1, a0, a1);
-    }
+    stage_tile(tile_of(0), 0, a0, a1);
+    load_pages(1, a0, a1);
+    stage_tile(tile_of(1), 1, a0, a1);
   }
   load_pages(2, pgn0, pgn1);
+
+  // ---- The tile pipeline (per wave; one wave per SIMD has nobody to overlap with, so the overlap is written out):
+  //   iteration j:  QK^T(j)   with the second half of softmax(j-1) - exponentials, rounding, row sum - in its MFMA gaps
+  //                 P.V(j-1)  with the first half of softmax(j)    - row maximum, reference decision   - in its MFMA gaps
+  // so that an MFMA gap carries at most ~3 vector instructions (a 32-cycle MFMA holds the issue port for 8 cycles: more
+  // than ~24 cycles of other issue per gap is paid in full; measured with in-kernel stamps on the first version, which
+  // had the whole softmax and two address adds per read in the P.V gaps: 77 cycles per P.V MFMA).
+  // State carried between phases: s_prev = raw logits of tile j-1 (exponentiated in place during QK^T(j)), mneg = the
+  // reference they are taken against, pf = the rounded weights (B operand of P.V), alpha / upd = the pending rescale.
+  typedef const v8s __attribute__((address_space(3))) * lds_v8s;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
+  float mt = 0.f, mb = 0.f, alpha = 1.0f, mneg = 0.f, psum = 0.f;
+  bool upd = false;
+  v8s pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+
+  // second half of the softmax of the tile whose raw logits are in sp (reference mneg, fixed by the first half)
+  auto exp_op = [&](auto kc, v16f& sp) {
+    constexpr int k = decltype(kc)::value;
+    // (each micro-op ends in an empty volatile asm on its result: the optimiser would otherwise sink the whole chain
+    //  to its first use behind the MFMA loop - a sched_barrier only binds the machine scheduler)
+    // slots 3 p, 3 p + 1: weights 2 p, 2 p + 1 (one multiply-add and one exponential each); slot 3 p + 2: the pair is
+    // rounded, packed and added to the row sum. One slot per MFMA gap: <= ~15 cycles of issue next to the K read.
+    constexpr int pr = k / 3, r = k % 3;
+    if constexpr (k < 24 && r < 2) {
+      float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sp[2 * pr + r], sl2, mneg));
+      asm volatile("" : "+v"(e));
+      sp[2 * pr + r] = e;
+    } else if constexpr (k < 24) {
+      int pk = M::pack(sp[2 * pr], sp[2 * pr + 1]);
+      psum = M::add2(pk, psum);  // the row sum takes the ROUNDED weights (numerator and denominator round alike)
+      asm volatile("" : "+v"(pk), "+v"(psum));
+      pf[pr >> 2][2 * (pr & 3)] = (short)(pk & 0xffff);
+      pf[pr >> 2][2 * (pr & 3) + 1] = (short)((unsigned)pk >> 16);
+    } else if constexpr (k == 24) {
+      l_run += psum;
+      asm volatile("" : "+v"(l_run));
+    }
+  };
+  constexpr int kExpOps = 25;
+  // first half: row maximum of the raw logits in sc, then the lazy reference (see the kernel above): it moves only when a
+  // weight would pass 2^kLazy, then to 2^50 (bf16) above the running maximum; all rows of the wave move together (one
+  // rescale pass serves them all). Leaves alpha / upd for the rescale of O and takes l_run to the new reference.
+  auto max_op = [&](auto kc, v16f& sc) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k == 0) {
+      mt = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+      mb = fmaxf(fmaxf(sc[3], sc[4]), sc[5]);
+    } else if constexpr (k == 1) {
+      mt = fmaxf(fmaxf(mt, sc[6]), sc[7]);
+      mb = fmaxf(fmaxf(mb, sc[8]), sc[9]);
+    } else if constexpr (k == 2) {
+      mt = fmaxf(fmaxf(mt, sc[10]), sc[11]);
+      mb = fmaxf(fmaxf(mb, sc[12]), sc[13]);
+    } else if constexpr (k == 3) {
+      mt = fmaxf(fmaxf(mt, sc[14]), sc[15]);
+      mt = fmaxf(mt, mb);
+    } else if constexpr (k == 4) {  // the other 16 tokens of this row live in lane ^ 32
+      float c0 = mt, c1 = mt;
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
+      mt = fmaxf(c0, c1);
+    } else if constexpr (k == 5) {
+      upd = __any((mt - m_ref) * sl2 > kLazy);  // (first tile: +inf; nothing but masked keys so far: NaN -> false)
+      m_run = fmaxf(m_run, mt);
+    } else if constexpr (k == 6) {
+      const float cand = upd ? m_run + head_raw : -INFINITY;  // (selects, no branch in the MFMA stream)
+      const float m_new = fmaxf(m_ref, cand);
+      alpha = m_new > m_ref ? __builtin_amdgcn_exp2f((m_ref - m_new) * sl2 * 0.5f) : 1.0f;  // (the factor's square root)
+      m_ref = m_new;
+    } else if constexpr (k == 7) {
+      mneg = m_ref == -INFINITY ? 0.f : -m_ref * sl2;
+      l_run = l_run * alpha * alpha;
+      psum = 0.f;
+    }
+    asm volatile("" : "+v"(mt), "+v"(mb), "+v"(alpha), "+v"(mneg), "+v"(l_run), "+v"(m_ref), "+v"(m_run));  // (as above)
+  };
+  constexpr int kMaxOps = 8;
 
   // ---- S^T of tile j (raw logits) in VGPRs (asm MFMAs: left to itself the compiler puts this accumulator into a0..a15),
   // K fragments kKA k-steps ahead, in program order. The first MFMA takes the constant 0 as its addend: no VALU write
   // feeds an asm MFMA (the hazard recogniser cannot see one).
-  typedef const v8s __attribute__((address_space(3))) * lds_v8s;
-  typedef v4s __attribute__((address_space(3))) * lds_v4s;
-  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
-  auto qk_tile = [&](int j, v16f& s) {
+  auto qk_tile = [&](int j, v16f& s, auto with_exp, v16f& sp, auto&& dma_piece) {
+    constexpr bool kExp = decltype(with_exp)::value;
     const uint32_t sb = lds_base + (uint32_t)((j & 3) * kStageBytes);
     uint32_t kb = kbase, rb = rbase;
     asm volatile("" : "+v"(kb), "+v"(rb));  // (derive the chunk addresses here, not across the whole loop)
     v8s kr[kKA];
+    // eight base addresses (chunk pair ks % 8 of the stage), pinned in registers: the column block ks / 8 is then an
+    // immediate of the read (left alone the compiler adds stage + block in an SGPR and spends a v_add per read)
+    uint32_t ka[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ka[i] = sb + (kb ^ (uint32_t)(i << 5));
+      asm volatile("" : "+v"(ka[i]));
+    }
     auto k_addr = [&](int ks) -> uint32_t {
-      const uint32_t off = ks < 32 ? ((kb ^ (uint32_t)((ks & 7) << 5)) + (uint32_t)((ks >> 3) * 8192))
-                                   : (rb ^ (uint32_t)((ks - 32) << 5));
-      return sb + off;
+      return ks < 32 ? ka[ks & 7] + (uint32_t)((ks >> 3) * 8192) : sb + (rb ^ (uint32_t)((ks - 32) << 5));
     };
 #pragma unroll
     for (int ks = 0; ks < kKA; ++ks) kr[ks] = *(lds_v8s)(uintptr_t)k_addr(ks);
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 36>([&](auto kc) {
       constexpr int ks = decltype(kc)::value;
-      if constexpr (ks == 0) M::first_v(s, kr[ks % kKA], qf[ks]);
+      if constexpr (kProbe == 13) M::template acc_agpr<0>(kr[ks % kKA], qf[ks]);  // (is an AGPR accumulator cheaper to fill around?)
+      else if constexpr (kProbe == 14) M::template acc_agpr<16 * (ks & 3)>(kr[ks % kKA], qf[ks]);  // (four independent chains?)
+      else if constexpr (kProbe == 15) M::template acc_agpr<16 * (ks & 1)>(kr[ks % kKA], qf[ks]);  // (two?)
+      else if constexpr (ks == 0) M::first_v(s, kr[ks % kKA], qf[ks]);
       else M::acc_v(s, kr[ks % kKA], qf[ks]);
-      if constexpr (ks + kKA < 36) {
-        // the next address is computed while this slot is still reserved (its MFMA was issued just before: the compiler
-        // would otherwise be free to put the address into the operand registers the matrix pipe is still reading)
-        const uint32_t a = k_addr(ks + kKA);
-        asm volatile("" ::"v"(kr[ks % kKA]), "v"(a));
-        kr[ks % kKA] = *(lds_v8s)(uintptr_t)a;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kDmaQK && kExp && (ks & 3) == 2) dma_piece(std::integral_constant<int, (ks >> 2)>{});
+      if constexpr (kExp && ks >= 1 && ks - 1 < kExpOps && kProbe != 6) exp_op(std::integral_constant<int, ks - 1>{}, sp);
+      if constexpr (ks + kKA < 36 && kProbe != 2 && kProbe != 3 && kProbe != 5) {
+        // (the slot stays reserved up to its refill: the MFMA issued just before is still reading it, and the compiler
+        //  would otherwise be free to put a temporary there)
+        asm volatile("" ::"v"(kr[ks % kKA]));
+        kr[ks % kKA] = *(lds_v8s)(uintptr_t)k_addr(ks + kKA);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -1298,12 +1447,6 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
 #pragma unroll
     for (int i = 0; i < kKA; ++i) asm volatile("" ::"v"(kr[i]));  // (the ring stays reserved past the last MFMAs)
   };
-
-  // ---- the softmax of a tile as micro-ops (a few vector instructions each): one per gap of the P . V MFMAs of the
-  // previous tile. State between micro-ops:
-  float mt = 0.f, mb = 0.f, alpha = 1.0f, mneg = 0.f, psum = 0.f;
-  bool upd = false;
-  v8s pfn[2];
   auto mask_tile = [&](int j, v16f& s) {  // (rare, uniform: keys past a row's horizon)
     const int t = t_begin + j;
     if (t * kTile + kTile > kv_first || t * kTile + kTile > seq) {
@@ -1313,98 +1456,74 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
         if (t * kTile + (v & 3) + 8 * (v >> 2) + 4 * u >= kv_row) s[v] = -INFINITY;
     }
   };
-  auto sm_op = [&](auto kc, v16f& s) {
-    constexpr int k = decltype(kc)::value;
-    if constexpr (k == 0) {
-      mt = fmaxf(fmaxf(s[0], s[1]), s[2]);
-      mb = fmaxf(fmaxf(s[3], s[4]), s[5]);
-    } else if constexpr (k == 1) {
-      mt = fmaxf(fmaxf(mt, s[6]), s[7]);
-      mb = fmaxf(fmaxf(mb, s[8]), s[9]);
-    } else if constexpr (k == 2) {
-      mt = fmaxf(fmaxf(mt, s[10]), s[11]);
-      mb = fmaxf(fmaxf(mb, s[12]), s[13]);
-    } else if constexpr (k == 3) {
-      mt = fmaxf(fmaxf(mt, s[14]), s[15]);
-      mt = fmaxf(mt, mb);
-    } else if constexpr (k == 4) {  // the other 16 tokens of this row live in lane ^ 32
-      float c0 = mt, c1 = mt;
-      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
-      mt = fmaxf(c0, c1);
-    } else if constexpr (k == 5) {
-      // lazy reference (see the kernel above): it moves only when a weight would pass 2^kLazy, then to 2^50 (bf16) above
-      // the running maximum; all rows of the wave move together (one rescale pass serves them all)
-      upd = __any((mt - m_ref) * sl2 > kLazy);  // (first tile: +inf; nothing but masked keys so far: NaN -> false)
-      m_run = fmaxf(m_run, mt);
-    } else if constexpr (k == 6) {
-      const float cand = upd ? m_run + head_raw : -INFINITY;  // (selects, no branch in the MFMA stream)
-      const float m_new = fmaxf(m_ref, cand);
-      alpha = m_new > m_ref ? __builtin_amdgcn_exp2f((m_ref - m_new) * sl2) : 1.0f;
-      m_ref = m_new;
-    } else if constexpr (k == 7) {
-      mneg = m_ref == -INFINITY ? 0.f : -m_ref * sl2;
-      psum = 0.f;
-    } else if constexpr (k < 24) {  // weights 0 .. 15; a finished pair is rounded and packed in the next slot
-      constexpr int v = k - 8;
-      s[v] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[v], sl2, mneg));
-      if constexpr ((v & 1) == 0 && v >= 2) {
-        const int pk = M::pack(s[v - 2], s[v - 1]);
-        psum = M::add2(pk, psum);  // the row sum takes the ROUNDED weights (numerator and denominator round alike)
-        pfn[(v - 2) >> 3][(v - 2) & 7] = (short)(pk & 0xffff);
-        pfn[(v - 2) >> 3][((v - 2) & 7) + 1] = (short)((unsigned)pk >> 16);
-      }
-    } else if constexpr (k == 24) {
-      const int pk = M::pack(s[14], s[15]);
-      psum = M::add2(pk, psum);
-      pfn[1][6] = (short)(pk & 0xffff);
-      pfn[1][7] = (short)((unsigned)pk >> 16);
-    } else if constexpr (k == 25) {
-      l_run = l_run * alpha + psum;
-    }
-  };
-  constexpr int kSmOps = 26;
 
-  // ---- O^T += V^T . P^T of tile jv (asm MFMAs on the fixed accumulators, in program order), V^T fragments kVA steps
-  // ahead; step m = (dim tiles 2 (m / 4), 2 (m / 4) + 1) x (k-step (m / 2) % 2): two accumulators alternate
-  auto pv_tile = [&](int jv, const v8s (&pf)[2], auto with_softmax, v16f& s) {
-    constexpr bool kSm = decltype(with_softmax)::value;
+  // ---- O^T += V^T . P^T of tile jv: asm MFMAs on the fixed accumulators and asm transposed reads (the compiler cannot
+  // fold an immediate offset into the read intrinsic: two address adds per read), in program order with hand-counted waits,
+  // V^T fragments kVA steps ahead; step m = (dim tile pv_dt(m), k-step pv_ss(m)). Eight base addresses per tile (token
+  // half e x dim tile % 4), everything else is an immediate.
+  auto pv_tile = [&](int jv, auto with_max, v16f& sc) {
+    constexpr bool kMax = decltype(with_max)::value;
     const uint32_t sb = lds_base + (uint32_t)((jv & 3) * kStageBytes);
     uint32_t vb0 = vbase;
     asm volatile("" : "+v"(vb0));
     const uint32_t vb1 = (vb0 ^ 32u) + 2048u;
-    v8s vf[kVA];
-    auto v_read = [&](int m) -> v8s {
-      const int dt = 2 * (m >> 2) + (m & 1), ss = (m >> 1) & 1;
-      const uint32_t x = (uint32_t)((dt & 3) << 6), c = (uint32_t)((dt >> 2) * 8192 + ss * 4096);
-      const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(uintptr_t)(sb + ((vb0 ^ x) + c)));
-      const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(uintptr_t)(sb + ((vb1 ^ x) + c)));
-      return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
+    uint32_t va[2][4];
 #pragma unroll
-    for (int m = 0; m < kVA; ++m) vf[m] = v_read(m);
+    for (int x = 0; x < 4; ++x) {
+      va[0][x] = sb + (vb0 ^ (uint32_t)(x << 6));
+      va[1][x] = sb + (vb1 ^ (uint32_t)(x << 6));
+    }
+    v2i vlo[kVA], vhi[kVA];
+    auto v_issue = [](auto mc, v2i& lo, v2i& hi, const uint32_t a0, const uint32_t a1) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int dt = pv_dt<kOrd>(m), ss = pv_ss<kOrd>(m), c = (dt >> 2) * 8192 + ss * 4096;
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(c));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(c));
+    };
+#define SGLK_V_ISSUE(M_) v_issue(std::integral_constant<int, (M_)>{}, vlo[(M_) % kVA], vhi[(M_) % kVA], \
+                                 va[0][pv_dt<kOrd>(M_) & 3], va[1][pv_dt<kOrd>(M_) & 3])
+    static_for<0, kVA>([&](auto mc) { constexpr int m0 = decltype(mc)::value; SGLK_V_ISSUE(m0); });
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 32>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      constexpr int dt = 2 * (m >> 2) + (m & 1), ss = (m >> 1) & 1;
-      M::template acc_agpr<dt * 16>(vf[m % kVA], pf[ss]);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kSm && m >= 2 && m - 2 < kSmOps) sm_op(std::integral_constant<int, m - 2>{}, s);
+      constexpr int dt = pv_dt<kOrd>(m), ss = pv_ss<kOrd>(m);
+      constexpr int ahead = (32 - m < kVA ? 32 - m : kVA) - 1;  // fragments issued after this one
+      if constexpr (kProbe == 21 && (m & 7) == 7) asm volatile("s_waitcnt lgkmcnt(0)");
+      // (the two halves are coalesced into the 4-register operand in place - no copy may sit between the reads and the
+      //  wait the MFMA statement starts with; the ISA shows none)
+      const v8s f = __builtin_bit_cast(v8s, __builtin_shufflevector(vlo[m % kVA], vhi[m % kVA], 0, 1, 2, 3));
+      constexpr int wcnt = (kProbe == 1 || kProbe == 3 || kProbe == 5 || kProbe == 11) ? 0 : kProbe >= 9 ? 15 : 2 * ahead;
+      M::template wait_acc_agpr<dt * 16, wcnt>(f, pf[ss]);
+      if constexpr (kProbe != 9) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kProbe == 18 || kProbe == 19 || kProbe == 20) {  // (how many independent VALU fillers hide in a gap?)
+        float d0 = (float)m, d1 = d0, d2 = d0, d3 = d0;
+        constexpr int reps = kProbe == 18 ? 1 : kProbe == 19 ? 2 : 3;
+#pragma unroll
+        for (int r = 0; r < reps; ++r)
+          asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_add_f32 %3, %3, %3"
+                       : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+      }
+      if constexpr (kProbe == 21) {  // (two LDS reads per gap, never waited for)
+        v2i x0, x1;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=v"(x0), "=v"(x1) : "v"(va[0][0]));
+      }
+      if constexpr (kMax && m >= 2 && m - 2 < kMaxOps && kProbe != 6 && kProbe < 9) max_op(std::integral_constant<int, m - 2>{}, sc);
       // the fragment's registers stay reserved past the micro-op (a VALU write into an operand of the MFMA issued just
       // before is not interlocked); the refill of this slot lands tens of cycles later
-      asm volatile("" ::"v"(vf[m % kVA]));
-      if constexpr (m + kVA < 32) vf[m % kVA] = v_read(m + kVA);
-      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::"v"(f));
+      if constexpr (m + kVA < 32 && kProbe != 1 && kProbe != 3 && kProbe != 5 && kProbe < 9) SGLK_V_ISSUE(m + kVA);
+      if constexpr (kProbe != 9) __builtin_amdgcn_sched_barrier(0);
     });
+#undef SGLK_V_ISSUE
     // the operands of the last MFMAs stay reserved until the matrix pipe has read them; the nops also cover the
     // MFMA -> v_accvgpr_read wait states of the rescale / the epilogue
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::"v"(pf[0]), "v"(pf[1]));
 #pragma unroll
-    for (int i = 0; i < kVA; ++i) asm volatile("" ::"v"(vf[i]));
+    for (int i = 0; i < kVA; ++i) asm volatile("" ::"v"(vlo[i]), "v"(vhi[i]));
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  v8s pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
-  unsigned long long st_sum[7] = {0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+  unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
   auto stamp = [&](int k) {
     if constexpr (kStamp) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -1412,54 +1531,106 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
       st_t = now;
     }
   };
-  if constexpr (kStamp) st_t = __builtin_amdgcn_s_memtime();
-  for (int j = 0; j < n_my; ++j) {
-    stamp(j == 0 ? 5 : 4);
-    if (j + 1 < n_my) wait_vmcnt<9>(); else wait_vmcnt<0>();
+  unsigned long long clk0 = 0, rt0 = 0;
+  if constexpr (kStamp) {
+    st_t = __builtin_amdgcn_s_memtime();
+    clk0 = st_t;
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
+  // One iteration: tile j's QK^T (+ exponentials of tile j-1 from s_prv), then P.V of tile j-1 (+ maxima of tile j in
+  // s_cur). The page ids of tile j+3 are requested before the DMA of tile j+2 is issued and awaited behind it, the DMA
+  // instructions themselves go out in the gaps of the QK^T MFMAs (each costs its wave ~60 cycles of issue: ~570 cycles
+  // per tile as a block in front of the MFMAs).
+  auto iter = [&](int j, v16f& s_cur, v16f& s_prv) {
+    stamp(8);
+    wait_vmcnt<9>();
     stamp(0);
     __builtin_amdgcn_s_barrier();  // tile j landed for every wave; every wave is done with tile j-2
     stamp(1);
-    // (the page ids count as used here on every path: no scalar load is outstanding - on the LDS reads' counter - in the
-    //  phases below, so the compiler waits for LDS reads by count instead of for everything)
-    asm volatile("" ::"s"(pgn0), "s"(pgn1));
-    if (j + 2 < n_my) stage_tile(t_begin + j + 2, (j + 2) & 3, pgn0, pgn1);
+    const int pga = pgn0, pgb = pgn1;  // tile j+2
+    load_pages(j + 3, pgn0, pgn1);
+    constexpr bool do_dma = kProbe != 4 && kProbe != 5;
+    const uint32_t dbase = lds_base + (uint32_t)(((j + 2) & 3) * kStageBytes);
+    const int dtok0 = tile_of(j + 2) * kTile;
+    const char* sA = cache + (int64_t)pga * p.page_stride_bytes + (int64_t)(dtok0 & page_mask) * kRowBytes;
+    const char* sB = p.page_shift == 4 ? cache + (int64_t)pgb * p.page_stride_bytes : sA + 16 * kRowBytes;
+    auto dma_piece = [&](auto ic) {  // piece 0..7: row group of this wave's column block; 8: its rope rows
+      constexpr int rg = decltype(ic)::value;
+      if constexpr (do_dma) {
+        if constexpr (rg < 8)
+          dma16((rg < 4 ? sA : sB) + (rg & 3) * 4 * kRowBytes + (dma_lo0 ^ (uint32_t)((rg & 3) << 4)),
+                dbase + (uint32_t)(wave * 8192 + rg * 1024));
+        else
+          dma16((wave < 2 ? sA : sB) + dma_ro, dbase + (uint32_t)(kMainBytes + wave * 1024));
+      }
+    };
+    if constexpr (!kDmaQK) static_for<0, 9>([&](auto ic) { dma_piece(ic); });
     stamp(2);
     if (work) {
-      v16f s;
-      qk_tile(j, s);
-      mask_tile(j, s);
+      qk_tile(j, s_cur, std::true_type{}, s_prv, dma_piece);  // + exponentials of tile j-1 -> pf
+    } else {
+      if constexpr (kDmaQK) static_for<0, 9>([&](auto ic) { dma_piece(ic); });
+    }
+    // (the page ids count as used here on every path: no scalar load is outstanding - on the LDS reads' counter - in the
+    //  P.V phase below, and the QK^T phase of the next tile starts without one)
+    asm volatile("" ::"s"(pgn0), "s"(pgn1));
+    if (work) {
+      mask_tile(j, s_cur);
       __builtin_amdgcn_sched_barrier(0);
       stamp(3);
-      if (j > 0) {
-        pv_tile(j - 1, pf, std::true_type{}, s);  // P . V of tile j-1 with the softmax of tile j in its gaps
-        if (upd) {  // rare: the reference moved, rescale O (AGPR -> VGPR -> AGPR) before the next P . V
-          const v4f a4 = {alpha, alpha, alpha, alpha};
-          static_for<0, 32>([&](auto ic) { agpr_scale8<decltype(ic)::value * 8>(a4); });
-          asm volatile("s_nop 7");
-        }
-      } else {
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s));  // (asm MFMA result -> VALU read wait states)
-        static_for<0, kSmOps>([&](auto kc) { sm_op(kc, s); });  // (O is zero: nothing to rescale)
+      pv_tile(j - 1, std::true_type{}, s_cur);  // + row maxima / reference of tile j
+      stamp(4);
+      if (upd) {  // rare: the reference moved, rescale O (AGPR -> VGPR -> AGPR) before the next P . V
+        static_for<0, 32>([&](auto ic) { agpr_scale8_sq<decltype(ic)::value * 8>(alpha); });
+        asm volatile("s_nop 7");
       }
-      pf[0] = pfn[0];
-      pf[1] = pfn[1];
       __builtin_amdgcn_sched_barrier(0);
     }
-    load_pages(j + 3, pgn0, pgn1);
+  };
+  v16f s_a, s_b;
+  {  // tile 0: nothing to overlap with
+    stamp(5);
+    wait_vmcnt<9>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::"s"(pgn0), "s"(pgn1));
+    if constexpr (kProbe != 4 && kProbe != 5) stage_tile(tile_of(2), 2, pgn0, pgn1);
+    load_pages(3, pgn0, pgn1);
+    asm volatile("" ::"s"(pgn0), "s"(pgn1));
+    if (work) {
+      auto no_dma = [](auto) {};
+      qk_tile(0, s_b, std::false_type{}, s_b, no_dma);
+      mask_tile(0, s_b);
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s_b));  // (asm MFMA result -> VALU read wait states)
+      static_for<0, kMaxOps>([&](auto kc) { max_op(kc, s_b); });  // (O is zero: nothing to rescale)
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+  int j = 1;
+  for (; j + 1 < n_my; j += 2) {  // (two tiles per trip: the logits of the tile in flight and of the one before swap roles)
+    iter(j, s_a, s_b);
+    iter(j + 1, s_b, s_a);
+  }
+  const bool odd_tail = j < n_my;
+  if (odd_tail) iter(j, s_a, s_b);
   if (work) {
+    if (odd_tail) static_for<0, kExpOps>([&](auto kc) { exp_op(kc, s_a); });
+    else static_for<0, kExpOps>([&](auto kc) { exp_op(kc, s_b); });
+    __builtin_amdgcn_sched_barrier(0);
     v16f dummy;
-    pv_tile(n_my - 1, pf, std::false_type{}, dummy);
+    pv_tile(n_my - 1, std::false_type{}, dummy);
   }
+  wait_vmcnt<0>();  // (the duplicate tiles: no LDS-DMA may be in flight when the workgroup ends and its LDS is handed on)
   stamp(4);
 #ifdef SGLK_PROBES
   auto write_stamps = [&]() {
     if constexpr (kStamp) {
       stamp(6);
       if (lane == 0) {
-        unsigned long long* d = g_mla_stamps + (((size_t)b * p.splits + split) * 4 + wave) % 4096 * 8;
-        for (int k = 0; k < 7; ++k) d[k] = st_sum[k];
-        d[7] = (unsigned long long)n_my;
+        unsigned long long* d = g_mla_stamps + (((size_t)b * p.splits + split) * 4 + wave) % 4096 * 16;
+        for (int k = 0; k < 12; ++k) d[k] = st_sum[k];
+        d[12] = __builtin_amdgcn_s_memtime() - clk0;       // shader cycles of the whole tile loop + epilogue
+        d[13] = __builtin_amdgcn_s_memrealtime() - rt0;    // the same in 100 MHz ticks
+        d[15] = (unsigned long long)n_my;
       }
     }
   };
@@ -1576,15 +1747,53 @@ static int launch_rows128x(hipStream_t st, const MlaParams& p, int B, const void
     if (g_mla_variant == 3) SGLK_V(4, 6);
     if (g_mla_variant == 4) SGLK_V(6, 4);
     if (g_mla_variant == 5) SGLK_V(2, 2);
-    if (g_mla_variant == 9) {
-      static unsigned long long attr2 = 0;
-      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 3, 4, true>), 4 * kStageBytes, &attr2,
-                                   "flash_mla_decode"))
+#define SGLK_STAMPED(PR)                                                                                               \
+  if (g_mla_variant == 90 + PR) {                                                                                      \
+    static unsigned long long attr2 = 0;                                                                               \
+    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 3, 4, true, PR>), 4 * kStageBytes, \
+                                 &attr2, "flash_mla_decode"))                                                          \
+      return rc;                                                                                                       \
+    mla_rows128x_kernel<T, 3, 4, true, PR><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(        \
+        p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);                   \
+    return check_launch("flash_mla_decode");                                                                           \
+  }
+    SGLK_STAMPED(0) SGLK_STAMPED(1) SGLK_STAMPED(2) SGLK_STAMPED(3) SGLK_STAMPED(4) SGLK_STAMPED(5) SGLK_STAMPED(6)
+    SGLK_STAMPED(9) SGLK_STAMPED(10) SGLK_STAMPED(11) SGLK_STAMPED(13) SGLK_STAMPED(14) SGLK_STAMPED(15) SGLK_STAMPED(18) SGLK_STAMPED(19) SGLK_STAMPED(20) SGLK_STAMPED(21)
+#undef SGLK_STAMPED
+#define SGLK_STAMPED_ORD(V, ORD)                                                                                       \
+  if (g_mla_variant == 90 + V) {                                                                                       \
+    static unsigned long long attr2 = 0;                                                                               \
+    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 3, 4, true, 0, ORD>),           \
+                                 4 * kStageBytes, &attr2, "flash_mla_decode"))                                         \
+      return rc;                                                                                                       \
+    mla_rows128x_kernel<T, 3, 4, true, 0, ORD><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(    \
+        p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);                   \
+    return check_launch("flash_mla_decode");                                                                           \
+  }
+    SGLK_STAMPED_ORD(7, 1) SGLK_STAMPED_ORD(8, 2)
+    if (g_mla_variant == 90 + 16 || g_mla_variant == 90 + 17) {  // deeper rings
+      static unsigned long long attr4 = 0, attr5 = 0;
+      if (g_mla_variant == 90 + 16) {
+        if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 6, 4, true>), 4 * kStageBytes, &attr4, "mla")) return rc;
+        mla_rows128x_kernel<T, 6, 4, true><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(
+            p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
+      } else {
+        if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 2, 2, true>), 4 * kStageBytes, &attr5, "mla")) return rc;
+        mla_rows128x_kernel<T, 2, 2, true><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(
+            p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
+      }
+      return check_launch("flash_mla_decode");
+    }
+    if (g_mla_variant == 90 + 12) {  // DMA as a block in front of QK^T
+      static unsigned long long attr3 = 0;
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 3, 4, true, 0, 0, false>),
+                                   4 * kStageBytes, &attr3, "flash_mla_decode"))
         return rc;
-      mla_rows128x_kernel<T, 3, 4, true><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(
+      mla_rows128x_kernel<T, 3, 4, true, 0, 0, false><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(
           p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
       return check_launch("flash_mla_decode");
     }
+#undef SGLK_STAMPED_ORD
   }
 #undef SGLK_V
 #endif

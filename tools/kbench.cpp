@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "sglk.h"
@@ -620,20 +621,23 @@ int main(int argc, char** argv) {
       };
       std::vector<float> all;
       const double bytes = (double)B * H * 576 * 2 + (double)B * S * 576 * 2 + table.size() * 4 + B * 4 + (double)B * H * 512 * 2;
-      if (getenv("MLA_STAMPS")) {  // in-kernel stamps of the rows128x kernel: mean cycles per tile and wave in each segment
-        sglk_debug_set_mla_variant(9);
-        for (int i = 0; i < 20; ++i) run();
-        HIP_CHECK(hipDeviceSynchronize());
-        std::vector<unsigned long long> st(8 * 4 * 4096);
-        sglk_debug_get_mla_stamps(st.data(), (int)st.size());
-        const int nw = (int)std::min<int64_t>(4096, B * (splits > 0 ? splits : 1) * 4);
-        const char* names[7] = {"tile-landed wait", "barrier", "DMA issue", "QK^T", "PV+softmax", "prologue", "epilogue"};
-        for (int wv = 0; wv < 4; ++wv) {
-          double sum[7] = {0}, tiles = 0;
-          for (int i = wv; i < nw; i += 4) { for (int k = 0; k < 7; ++k) sum[k] += (double)st[i * 8 + k]; tiles += (double)st[i * 8 + 7]; }
-          printf("wave %d:", wv);
-          for (int k = 0; k < 5; ++k) printf("  %s %.0f", names[k], sum[k] / tiles);
-          printf("  | per launch: prologue %.0f epilogue %.0f tiles %.0f\n", sum[5] / (nw / 4), sum[6] / (nw / 4), tiles / (nw / 4));
+      if (getenv("MLA_STAMPS")) {  // in-kernel stamps of the rows128x kernel: mean cycles per tile (wave 0) in each segment
+        std::vector<int> probes;
+        { std::string e = getenv("MLA_STAMPS"); size_t pos = 0; while (pos < e.size()) { probes.push_back(atoi(e.c_str() + pos)); pos = e.find(',', pos); if (pos == std::string::npos) break; ++pos; } }
+        for (int prb : probes) {
+          sglk_debug_set_mla_variant(90 + prb);
+          for (int i = 0; i < 20; ++i) run();
+          HIP_CHECK(hipDeviceSynchronize());
+          std::vector<unsigned long long> st(16 * 4 * 4096);
+          sglk_debug_get_mla_stamps(st.data(), (int)st.size());
+          const int nw = (int)std::min<int64_t>(4096, B * (splits > 0 ? splits : 1) * 4);
+          double sum[14] = {0}, tiles = 0;
+          for (int i = 0; i < nw; i += 4) { for (int k = 0; k < 14; ++k) sum[k] += (double)st[i * 16 + k]; tiles += (double)st[i * 16 + 15]; }
+          printf("probe %2d: landed-wait %.0f barrier %.0f DMA-issue %.0f QK %.0f PV %.0f tail %.0f | per launch: prologue %.0f epilogue %.0f\n",
+                 prb, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[8] / tiles,
+                 sum[5] / (nw / 4), sum[6] / (nw / 4));
+          printf("          in-kernel clock %.0f MHz (%.0f cycles in %.1f us per workgroup)\n", sum[12] / sum[13] * 100.0,
+                 sum[12] / (nw / 4), sum[13] / (nw / 4) / 100.0);
         }
         sglk_debug_set_mla_variant(0);
         if (ws) HIP_CHECK(hipFree(ws));
