@@ -183,7 +183,17 @@ def side_metrics(sgl_kernel, dev):
         out[f"flash_mla_decode_bs128_seq8192_h{H}_GBs"] = round(nbytes / ms / 1e6, 1)
         out[f"flash_mla_decode_bs128_seq8192_h{H}_ms"] = round(ms, 4)
         out[f"flash_mla_decode_bs128_seq8192_h{H}_TFLOPs"] = round(2.0 * bs * H * seq * (576 + 512) / ms / 1e9, 1)
-    del cache, table, seq_lens
+    # the same with 128-token pages (bench_flash_mla_decode.py sweeps page sizes 64 and 128)
+    cache128 = cache.view(bs * n_pages // 2, 128, 576)
+    table128 = torch.randint(0, bs * n_pages // 2, (bs, n_pages // 2), device=dev, dtype=torch.int32)
+    qq = torch.randn(bs, 128, 576, device=dev, dtype=torch.bfloat16) * 100
+    q_nope, q_pe = qq[..., :512], qq[..., 512:].contiguous()
+    ws = torch.empty(sgl_kernel.flash_mla_get_workspace_size(seq, bs, 128, 128, -1), device=dev, dtype=torch.uint8)
+    ms = timeit(lambda: sgl_kernel.flash_mla_decode(q_nope, q_pe, cache128, seq_lens, table128, ws, 576 ** -0.5, -1), iters=50)
+    nbytes = qq.numel() * 2 + cache.numel() * 2 + table128.numel() * 4 + seq_lens.numel() * 4 + bs * 128 * 512 * 2
+    out["flash_mla_decode_bs128_seq8192_h128_page128_GBs"] = round(nbytes / ms / 1e6, 1)
+    out["flash_mla_decode_bs128_seq8192_h128_page128_ms"] = round(ms, 4)
+    del cache, table, seq_lens, cache128, table128
     # flash_mla_prefill (same latent cache layout): 16 sequences, 512 new tokens each over 4096 cached keys, causal
     pb, psq, psk = 16, 512, 4096
     pcache = torch.randn(pb * psk // page, page, 576, device=dev, dtype=torch.bfloat16)
@@ -218,14 +228,58 @@ def side_metrics(sgl_kernel, dev):
                                                 max_seqlen_q=seq, causal=True), iters=5)
     out["fwd_prefill_causal_bs16_h32_kv8_d128_seq4096_TFLOPs"] = round(4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9, 1)
     out["fwd_prefill_causal_bs16_h32_kv8_d128_seq4096_ms"] = round(ms, 4)
-    del kc, vc, qp, qd
+    # chunked prefill: 128 new tokens per sequence over the 4096 cached keys (bench_flash_attn.py's q = 128 leg)
+    qc = torch.randn(bs * 128, hq, d, device=dev, dtype=torch.bfloat16)
+    cuc = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * 128
+    ms = timeit(lambda: flash_attn_with_kvcache(qc, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cuc,
+                                                max_seqlen_q=128, causal=True), iters=20)
+    out["fwd_chunk_prefill_q128_bs16_h32_kv8_d128_seq4096_ms"] = round(ms, 4)
+    out["fwd_chunk_prefill_q128_bs16_h32_kv8_d128_seq4096_TFLOPs"] = round(
+        4.0 * bs * hq * d * (128 * (seq - 128) + 128 * 129 / 2) / ms / 1e9, 1)
+    # decode with 128-token pages (the reference benchmark sweeps page sizes 64 and 128)
+    kc128, vc128 = kc.view(n_pages // 2, 128, hk, d), vc.view(n_pages // 2, 128, hk, d)
+    pt128 = torch.randperm(n_pages // 2, device=dev).to(torch.int32).view(bs, seq // 128)
+    ms = timeit(lambda: flash_attn_with_kvcache(qd, kc128, vc128, cache_seqlens=lens, page_table=pt128, causal=True), iters=20)
+    out["fwd_decode_bs16_h32_kv8_d128_seq4096_page128_GBs"] = round((kc.numel() + vc.numel() + 2 * qd.numel()) * 2 / ms / 1e6, 1)
+    del kc, vc, qp, qd, qc, kc128, vc128
+    # decode at the other head dims / an fp8 KV cache the reference instantiates (FMHADecodeXe20.cmake:13-16, :62-111)
+    for dd, kvdt in ((64, torch.bfloat16), (256, torch.bfloat16), (128, FP8)):
+        npg = bs * seq // page
+        kcd = torch.randn(npg, page, hk, dd, device=dev, dtype=torch.bfloat16).to(kvdt)
+        vcd = torch.randn(npg, page, hk, dd, device=dev, dtype=torch.bfloat16).to(kvdt)
+        ptd = torch.randperm(npg, device=dev).to(torch.int32).view(bs, seq // page)
+        qdd = torch.randn(bs, 1, hq, dd, device=dev, dtype=torch.bfloat16)
+        kw = {}
+        if kvdt == FP8:
+            kw = dict(k_descale=torch.ones(1, device=dev), v_descale=torch.ones(1, device=dev))
+        ms = timeit(lambda: flash_attn_with_kvcache(qdd, kcd, vcd, cache_seqlens=lens, page_table=ptd, causal=True, **kw), iters=20)
+        tag = f"d{dd}" + ("_fp8kv" if kvdt == FP8 else "")
+        out[f"fwd_decode_bs16_h32_kv8_{tag}_seq4096_GBs"] = round(
+            ((kcd.numel() + vcd.numel()) * kcd.element_size() + 2 * qdd.numel() * 2) / ms / 1e6, 1)
+        out[f"fwd_decode_bs16_h32_kv8_{tag}_seq4096_ms"] = round(ms, 4)
+        del kcd, vcd
+    # MoE routing latencies (reference benchmark/bench_moe_align_block_size.py, bench_moe_topk_softmax.py)
+    for toks, ne, tk in ((4096, 8, 2), (4096, 256, 8)):
+        logits = torch.randn(toks, ne, device=dev, dtype=torch.float32)
+        tw = torch.empty(toks, tk, device=dev, dtype=torch.float32)
+        ti = torch.empty(toks, tk, device=dev, dtype=torch.int32)
+        ms = timeit(lambda: sgl_kernel.topk_softmax(tw, ti, logits, True), iters=50)
+        out[f"topk_softmax_T{toks}_E{ne}_top{tk}_us"] = round(ms * 1e3, 1)
+        for blk in (64, 128):
+            max_pad = toks * tk + ne * (blk - 1)
+            sorted_ids = torch.empty(max_pad, device=dev, dtype=torch.int32)
+            expert_ids = torch.empty((max_pad + blk - 1) // blk, device=dev, dtype=torch.int32)
+            n_post = torch.empty(1, device=dev, dtype=torch.int32)
+            cumsum = torch.zeros(ne + 1, device=dev, dtype=torch.int32)
+            ms = timeit(lambda: sgl_kernel.moe_align_block_size(ti, ne, blk, sorted_ids, expert_ids, n_post, cumsum), iters=50)
+            out[f"moe_align_block_size_T{toks}_E{ne}_top{tk}_block{blk}_us"] = round(ms * 1e3, 1)
     # fused_experts int4 W4A16, BASELINE configs[4]: Mixtral-8x7B (8 experts, top-2, hidden 4096, inter 14336, group 128)
     E, Hd, I, gs, topk = 8, 4096, 14336, 128, 2
     w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
     w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
     s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01
     s2 = torch.rand(E, Hd, I // gs, device=dev).to(torch.bfloat16) * 0.01
-    for T in (1, 64, 2048):
+    for T in (1, 32, 64, 512, 2048, 4096):  # (the reference benchmark sweeps 1 .. 4096 tokens, bench_fused_experts_w4a16.py:459)
         xx = torch.randn(T, Hd, device=dev, dtype=torch.bfloat16) * 0.1
         logits = torch.randn(T, E, device=dev, dtype=torch.bfloat16)
         tw = torch.empty(T, topk, device=dev, dtype=torch.float32)
@@ -251,6 +305,32 @@ def side_metrics(sgl_kernel, dev):
     return out
 
 
+def roofline_extra(ex):
+    """Fraction of the bounding roofline per extra leg (MI355X_MICROARCH.md peaks: HBM 8 TB/s, bf16 MFMA 2.5 PFLOP/s,
+    fp8 / int8 MFMA 5 P): {leg: {"bound", "achieved", "peak", "unit", "frac"}}. Latency-bound legs (routing) carry no
+    fraction."""
+    out = {}
+
+    def put(leg, bound, achieved, peak, unit):
+        out[leg] = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": round(achieved / peak, 4)}
+
+    for k, v in ex.items():
+        if k.endswith("_GBs") and "weight" not in k and "fp8_blockwise_gemm" not in k:
+            put(k[:-4], "hbm", v, PEAK_HBM_GBS, "GB/s")
+        elif k.endswith("_weight_GBs") and ("_T1_" in k or "_T32_" in k or "_T64_" in k or "_M1_" in k or "_M16_" in k or "_M64_" in k):
+            put(k[:-4], "hbm", v, PEAK_HBM_GBS, "GB/s")  # few rows: the weight stream bounds the GEMM
+        elif k.endswith("_TFLOPs"):
+            if k.startswith("fp8_scaled_mm"):
+                put(k[:-7], "mfma", v, PEAK_FP8_TFLOPS, "TFLOP/s")
+            elif "_T1_" in k or "_T32_" in k or "_T64_" in k or "flash_mla_decode" in k:
+                continue  # (their bound is HBM: the GB/s entry above)
+            else:
+                put(k[:-7], "mfma", v, 2500.0, "TFLOP/s")
+        elif k.endswith("_TOPs"):
+            put(k[:-5], "mfma", v, 5000.0, "TOP/s")
+    return out
+
+
 def spawn_replicas(args, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and pass rank 0's
     JSON line through. The parent never touches the GPU (no torch.cuda call), the children are ordinary
@@ -267,13 +347,44 @@ def spawn_replicas(args, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0 or "")
+    # Poll all ranks: when one dies (bad GPU, import error) its siblings would sit in init_process_group / barrier until
+    # the collective timeout, so the first non-zero exit ends the others; an overall limit ends a hang.
+    import threading
+    import time
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("SGLK_BENCH_TIMEOUT_S", "3000"))
+    rcs = [None] * len(procs)
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, pr in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = pr.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = (r, rcs[r])
+        if failed is not None or time.time() > deadline:
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    pr.terminate()
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        rcs[r] = pr.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    sys.stdout.write("".join(c for c in chunks if c))
     sys.stdout.flush()
+    if failed is not None:
+        sys.exit("bench.py: rank %d exited with %s; the other ranks were stopped" % failed)
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        sys.exit("bench.py: rank(s) failed: %s" % bad)
+        sys.exit("bench.py: rank(s) failed or timed out: %s" % bad)
 
 
 def init_ranks(args):
@@ -473,6 +584,7 @@ def main(argv=None):
             result["roofline_flash_decode"] = mla_roofline(sgl_kernel, dev)
         if world == 1 and not args.no_extra:
             result["extra"] = side_metrics(sgl_kernel, dev)
+            result["roofline_extra"] = roofline_extra(result["extra"])
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)

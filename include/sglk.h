@@ -265,7 +265,8 @@ SGLK_API int sglk_apply_shuffle_mul_sum(sglk_stream_t stream, const void* input,
 /* moe_grouped_mm_nt_xe20_w4a16: reference src/sycl/GroupGemmW4A16Xe20.cpp:92-283 (schema
  * torch_extension_sycl.cc:214-217). out [total_m, N]; activations [total_m, K]; packed_weights
  * [E, N, K/2] (low nibble = even k); scales / zeros [E, N, K/group] (activation dtype; zeros may be
- * NULL = signed codes); bias fp32 [E, N] or NULL; rows_per_expert int32 [E] (counts).
+ * NULL = signed codes); bias fp32 [E, N] or NULL; rows_per_expert int32 [E] (counts). activations, packed_weights,
+ * scales and zeros must be 16-byte aligned.
  * is_int4 == 0: mxfp4 weights (OCP e2m1 nibbles), scales = E8M0 bytes [E, N, K/32], group_size 32, zeros NULL
  * (reference GroupGemmW4A16Xe20.cpp:140-168, kernels/moe/xe20/w4a16/gemm_xe2.hpp:238-448). */
 SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const void* activations,
@@ -274,6 +275,17 @@ SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const vo
                                        const int32_t* rows_per_expert, int64_t total_m,
                                        int64_t n_experts, int64_t N, int64_t K, int64_t group_size,
                                        int is_int4, int dtype);
+/* The same GEMM with the gate / up activation of fused_experts in its epilogue (reference python/sgl_kernel/moe.py:
+ * 751-835 runs the GEMM, writes [rows, 2I] and calls silu_and_mul / gelu_tanh_and_mul on it; the 16-bit GEMM has the
+ * fused form, kernels/moe/xe20/bf16/moe_mainloop.hpp:232-247). fused_act: 0 none, 1 silu, 2 gelu (tanh): W rows
+ * [0, N/2) gate, [N/2, N) up, out [total_m, N/2] = T(act(gate + b) * (up + b)) from the fp32 accumulators;
+ * 3 relu2: out [total_m, N] = T(max(x + b, 0)^2). */
+SGLK_API int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, const void* activations,
+                                           const void* packed_weights, const void* scales,
+                                           const void* zeros, const float* bias,
+                                           const int32_t* rows_per_expert, int64_t total_m,
+                                           int64_t n_experts, int64_t N, int64_t K, int64_t group_size,
+                                           int is_int4, int dtype, int fused_act);
 
 /* ---- flash-attention forward ---------------------------------------------------
  * fwd (mha_fwd): reference src/sycl/flash_attention.cpp:1332-1435 (schema

@@ -164,8 +164,9 @@ def check_isa(verbose=True):
         found += n
         if n == 0:
             problems.append("no gemm_8bit_persist_kernel instantiation found")
-    # (moe_w4a16: the group >= 128 instantiations, PB = 1 - AWQ / GPTQ / Mixtral checkpoints - and the mxfp4 ones; the
-    # group-32 / 64 int4 tiles of 32 rows and more still spill and are reported by --check only)
+    # (moe_w4a16: the group >= 128 instantiations, PB = 1 - AWQ / GPTQ / Mixtral checkpoints - and the mxfp4 ones are
+    # build-breaking; the group-32 / 64 int4 tiles, PB = 2 / 4, are only reported - `build.py --check` lists every
+    # spilling instantiation as a warning, see check_isa_warnings; none spills with ROCm 7.2.0 at present)
     for src_name, pat in (("attn_fwd.hip", r"attn_prefill_kernelI"), ("attn_fwd.hip", r"attn_decode_kernelI"),
                           ("moe_w4a16.hip", r"moe_w4a16_kernelIDF16.Li\dELi\dELi1ELi\dE"),
                           ("moe_w4a16.hip", r"moe_w4a16_kernelIDF16.Li\dELi\dELi4ELi1E"),
@@ -191,6 +192,23 @@ def check_isa(verbose=True):
         for pr in problems[:20]:
             print("  " + pr)
     return problems
+
+
+def check_isa_warnings(verbose=True):
+    """Non-fatal pass (build.py --check): every moe_w4a16_kernel instantiation that spills, whatever its group size."""
+    path = _asm_path("moe_w4a16.hip")
+    if not os.path.exists(path):
+        return []
+    warn = []
+    for name, body in _functions(open(path).read(), r"moe_w4a16_kernelI"):
+        n = sum(1 for ln in body if "scratch_" in ln.split(";")[0])
+        if n:
+            warn.append("%s: %d scratch accesses (spills)" % (name, n))
+    if verbose:
+        print("[build] check_isa (warnings only): %d moe_w4a16_kernel instantiations spill" % len(warn), flush=True)
+        for w in warn:
+            print("  warning: " + w)
+    return warn
 
 
 def _compile_all(obj_dir, extra_flags, jobs, force, verbose, headers):
@@ -304,7 +322,9 @@ if __name__ == "__main__":
     ap.add_argument("--check", action="store_true", help="only run the ISA check on the last build's assembly")
     a = ap.parse_args()
     if a.check:
-        sys.exit(1 if check_isa() else 0)
+        rc = 1 if check_isa() else 0
+        check_isa_warnings()
+        sys.exit(rc)
     build(a.jobs, a.force, not a.no_torch)
     if a.probes:
         build_probes(a.jobs, a.force)

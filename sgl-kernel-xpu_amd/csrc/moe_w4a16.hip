@@ -168,7 +168,12 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
                                                         const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
                                                         const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
-                                                        int K, int group_shift, int probe) {
+                                                        int K, int group_shift, int probe, int fuse) {
+  // fuse (the gate / up activation of fused_experts in this GEMM's epilogue, as moe_bf16.hip does for 16-bit weights;
+  // reference python/sgl_kernel/moe.py:751-835 runs GEMM, then a separate act-and-mul over a [rows, 2I] intermediate):
+  //   1 silu, 2 gelu (tanh form): W holds gate rows [0, N/2) then up rows [N/2, N); a workgroup takes BN/2 gate columns
+  //   AND the BN/2 up columns that go with them (wave tiles nt < NW/2 gate, nt >= NW/2 up), out[m, n] = T(act(gate) * up)
+  //   is [total_m, N/2]: the product is formed on the fp32 accumulators, one rounding. 3 relu2: out = T(max(x, 0)^2).
   // probe (libsglk_probes.so only; 0 in the release library): timing experiments with garbage results -
   // 1: one activation row for all 16 m rows, 2: no output stores, 4: non-temporal weight loads, 8: scales read once,
   // 16: no weight expansion / MFMAs (stream only), 32: no barrier, 64: no activation staging, 512: row blocks fastest in the
@@ -204,10 +209,21 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   // (64-row tiles of a projection with more k than columns: the column blocks of a row block run together and share its
   // activations in L2 - 731 against 755 us for the Mixtral down projection at 512 rows per expert; the gate / up projection
   // measured the other way round, 1609 against 1706 us. Probe 512 flips the choice.)
-  const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, (N + BN - 1) / BN, MT >= 4 && ((N < K) != ((probe & 512) != 0)));
+  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2);
+  const int Nh = N >> 1;  // gated: output width
+  const int col_blocks = gated ? (Nh + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN;
+  const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, col_blocks, MT >= 4 && ((N < K) != ((probe & 512) != 0)));
   if (tile.expert < 0) return;
   const int e = tile.expert, m0 = tile.m0, m_valid = tile.m_valid;
   const int n_base = tile.col_block * BN + wave * (NW * 16);
+  // weight row of this lane for wave tile nt (gated: the up half mirrors the gate half)
+  auto col_of = [&](int nt) -> int {
+    if (!gated) return n_base + nt * 16 + l15;
+    constexpr int H2 = NW >= 2 ? NW / 2 : 1;
+    const int ng = tile.col_block * (BN / 2) + wave * (H2 * 16) + (nt % H2) * 16 + l15;  // gate column = output column
+    return nt < H2 ? ng : Nh + ng;
+  };
+  const int n_lim = gated ? Nh : N;  // valid gate / plain columns
 
   using S = typename std::conditional<FMT == 1, uint8_t, typename std::conditional<FMT == 3, uint32_t, T>::type>::type;  // stored scale type
   static_assert(FMT != 3 || (PB == 1 && std::is_same<T, bf16>::value), "the fp4 conversion path: bf16, one dword of scales per block");
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   uint32_t woff[NW], soff[NW];
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
-    int n = n_base + nt * 16 + l15;
+    int n = col_of(nt);
     n = n < N ? n : N - 1;
     woff[nt] = (uint32_t)n * (uint32_t)(K / 2) + 16 * g;
     soff[nt] = (uint32_t)n * (uint32_t)kgroups;
@@ -507,7 +523,35 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   }
   }
 
-  // ---- epilogue: lane owns out[m = 16 mt + 4 g + r][n = n_base + 16 nt + l15]
+  // ---- epilogue: lane owns out[m = 16 mt + 4 g + r][column of wave tile nt]
+  if (gated) {
+    if constexpr (NW >= 2) {
+      constexpr int H2 = NW / 2;
+#pragma unroll
+      for (int nt = 0; nt < H2; ++nt) {
+        const int n = col_of(nt);  // gate column = output column
+        if (n >= Nh) continue;
+        const float bg = bias ? bias[(int64_t)e * N + n] : 0.f, bu = bias ? bias[(int64_t)e * N + Nh + n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + 4 * g + r;
+            const float x = acc[mt][nt][r] + bg, y = acc[mt][nt + H2][r] + bu;
+            float a;
+            if (fuse == 1) {
+              a = x / (1.0f + expf(-x));
+            } else {
+              const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+              a = x * (0.5f * (1.0f + tanhf(inner)));
+            }
+            if (row < m_valid) out[(int64_t)(m0 + row) * Nh + n] = (T)(a * y);
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
     const int n = n_base + nt * 16 + l15;
@@ -518,7 +562,12 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = mt * 16 + 4 * g + r;
-        if (row < m_valid && !((probe & 2) && acc[mt][nt][r] != 12345.f)) out[(int64_t)(m0 + row) * N + n] = (T)(acc[mt][nt][r] + bv);
+        float v = acc[mt][nt][r] + bv;
+        if (fuse == 3) {
+          v = fmaxf(v, 0.f);
+          v = v * v;
+        }
+        if (row < m_valid && !((probe & 2) && acc[mt][nt][r] != 12345.f)) out[(int64_t)(m0 + row) * N + n] = (T)v;
       }
     }
   }
@@ -744,29 +793,30 @@ constexpr int g_w4_probe = 0, g_w4_mt = 0, g_w4_fp4hw = 1;
 
 template <typename T, int MT, int NW, int PB, int FMT = 0, int WV = 4>
 static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
-                  const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
+                  const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift, int fuse) {
   constexpr int BM = 16 * MT, BN = 16 * NW * WV;
-  const int64_t wgs = moe_tile_launch_size(total_m, E, BM, cdiv(N, BN));
+  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2);
+  const int64_t wgs = moe_tile_launch_size(total_m, E, BM, gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN));
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20_w4a16: problem too large for one launch");
   dim3 grid((unsigned)wgs);
   moe_w4a16_kernel<T, MT, NW, PB, FMT, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
-                                                             rows, E, N, K, group_shift, g_w4_probe);
+                                                             rows, E, N, K, group_shift, g_w4_probe, fuse);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
 }
 
 template <typename T, int MT, int NW, int WV = 4>
 static int launch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift,
-                  bool fp4hw = false) {
+                  bool fp4hw = false, int fuse = 0) {
   if constexpr (std::is_same<T, bf16>::value) {
     if (fp4hw)  // mxfp4 through the conversion instruction: one dword of scale bytes per 128-deep block
-      return launch_pb<T, MT, NW, 1, 3, WV>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 7);
+      return launch_pb<T, MT, NW, 1, 3, WV>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 7, fuse);
   }
   if (group_shift < 0)  // mxfp4: E8M0 scales per 32
-    return launch_pb<T, MT, NW, 4, 1, WV>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 5);
+    return launch_pb<T, MT, NW, 4, 1, WV>(st, out, act, wq, scales, nullptr, bias, rows, total_m, E, N, K, 5, fuse);
 #define SGLK_W4_GO(PB)                                                                                                    \
-  return zeros != nullptr ? launch_pb<T, MT, NW, PB, 2, WV>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift) \
-                          : launch_pb<T, MT, NW, PB, 0, WV>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift)
+  return zeros != nullptr ? launch_pb<T, MT, NW, PB, 2, WV>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fuse) \
+                          : launch_pb<T, MT, NW, PB, 0, WV>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fuse)
   if (group_shift == 5) SGLK_W4_GO(4);
   if (group_shift == 6) SGLK_W4_GO(2);
   SGLK_W4_GO(1);
@@ -775,7 +825,7 @@ static int launch(hipStream_t st, void* out, const void* act, const void* wq, co
 
 template <typename T>
 static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
-                    const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift) {
+                    const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift, int fuse) {
   // Tile policy by average rows per expert (the reference switches policies the same way,
   // GroupGemmW4A16Xe20.cpp:266-277). The row counts are ragged around the average, and a second row block of an expert
   // streams its weights again, so a tile is chosen that holds ~1.5x the average; 64-row tiles are the largest whose K loop
@@ -788,22 +838,23 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // activation staging and the barrier are per workgroup, 155 vs 145 us at N = 28672, K = 4096)
   // (the 16 / 32-row tiles fetch the scales of four 128-deep blocks with one 8-byte load: groups of 128, K % 512 == 0)
   const bool small_ok = gp != 7 && gp != 8 ? true : (gp == 7 && K % 512 == 0);
-  if (!small_ok) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
+  if (!small_ok) return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw, fuse);
   // measured on ragged counts around the average (gate/up + down projection of Mixtral, us): avg 8: 16-row tile 124 + 75,
   // 32-row 140 + 98; avg 16: 151 + 97 vs 145 + 99; avg 32: 226 + 130 vs 191 + 141 vs 64-row 251 + 175
   // few column blocks (the Mixtral down projection: 32 of 128 columns x 8 experts = one workgroup per CU): 64-column
   // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
   // (a narrow projection keeps the 16-row tile up to an average of 20 rows: ragged counts around 16 - 64 tokens, top-2 of 8 -
   // 81 us against 96 us with the 32-row tile for the down projection; the gate / up projection measured 151 against 145)
-  const bool narrow16 = gp == 7 && K % 1024 == 0 &&
+  const bool gated_epi = fuse == 1 || fuse == 2;  // (needs the two-tile wave: no 16-column wave tiles, no K split)
+  const bool narrow16 = !gated_epi && gp == 7 && K % 1024 == 0 &&
                         std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / 16) * cdiv(N, 128) <= 384;
   const bool small = avg <= 10 || (narrow16 && avg <= 20 && g_w4_mt == 0);
   const int64_t bm = small ? 16 : 32;
   const int64_t est_row_blocks = std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / bm);
-  const bool narrow = gp == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
+  const bool narrow = !gated_epi && gp == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
   if (small) {
     // fewer workgroups than CUs even with 64-column tiles, long K: four waves split K (see moe_w4a16_ksplit_kernel)
-    const bool ksplit = (group_shift == 7 || fp4hw) && K % 2048 == 0 && ((K >= 8192 && avg <= 10 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
+    const bool ksplit = fuse == 0 && (group_shift == 7 || fp4hw) && K % 2048 == 0 && ((K >= 8192 && avg <= 10 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
     if (ksplit) {
       const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 32));
       if (wgs < ((int64_t)1 << 31)) {
@@ -824,7 +875,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
     }
 #ifdef SGLK_PROBES  // (diagnostic build: the independent waves without the K split - gate / up projection 114-143 -> 119-158 us,
     // down projection at 16 rows per expert 72 -> 62 us against 67 us with the split)
-    if (g_w4_mt == 13 && group_shift == 7 && K % 512 == 0) {
+    if (fuse == 0 && g_w4_mt == 13 && group_shift == 7 && K % 512 == 0) {
       const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 128));
       if (zeros != nullptr)
         moe_w4a16_ksplit_kernel<T, 2, false><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
@@ -833,21 +884,21 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
       return check_launch("moe_grouped_mm_nt_xe20_w4a16");
     }
 #endif
-    if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
+    if (narrow) return launch<T, 1, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw, fuse);
     // (eight blocks in flight per wave at 128 columns: 175 registers, two waves per SIMD instead of three - no faster)
-    return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
+    return launch<T, 1, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw, fuse);
   }
   // (128-row tiles and 64-column wave tiles both measured slower at 512 rows per expert: 1 wave per SIMD; the prefill side is
   // bound by L2 traffic - 64 x 128 tiles re-read activations 224 times and weights 8 times, 11 GB at ~10 TB/s)
   // eight waves share a staged activation tile (64 x 256): half the activation traffic and barriers per flop of the 64 x 128
   // tile - 512 rows per expert 1.90 -> 1.61 ms (gate / up), 0.84 -> 0.73 ms (down); 128 rows 0.49 (0.48 with 32-row tiles) -> 0.43 ms
   if (g_w4_mt == 8 || (g_w4_mt == 0 && avg >= 112 && N % 256 == 0))
-    return launch<T, 4, 2, 8>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
+    return launch<T, 4, 2, 8>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw, fuse);
   if (avg <= 160) {  // (avg 64: 32-row tile 321 + 198 us, 64-row 352 + 230; avg 128: 571 + 352 vs 596 + 396; 256: 1021 + 615 vs 1008 + 471)
-    if (narrow) return launch<T, 2, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
-    return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
+    if (narrow) return launch<T, 2, 1>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw, fuse);
+    return launch<T, 2, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw, fuse);
   }
-  return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw);
+  return launch<T, 4, 2>(st, out, act, wq, scales, zeros, bias, rows, total_m, E, N, K, group_shift, fp4hw, fuse);
 }
 
 }  // namespace
@@ -858,7 +909,20 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
                                          const float* bias, const int32_t* rows_per_expert, int64_t total_m,
                                          int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
                                          int dtype) {
+  return sglk_moe_grouped_mm_w4a16_act(stream, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
+                                       n_experts, N, K, group_size, is_int4, dtype, 0);
+}
+
+extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, const void* activations,
+                                             const void* packed_weights, const void* scales, const void* zeros,
+                                             const float* bias, const int32_t* rows_per_expert, int64_t total_m,
+                                             int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
+                                             int dtype, int fused_act) {
   using namespace sglk;
+  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 3,
+               "moe_grouped_mm_nt_xe20_w4a16: fused_act must be 0 (none), 1 (silu), 2 (gelu) or 3 (relu2)");
+  SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2) || N % 16 == 0,
+               "moe_grouped_mm_nt_xe20_w4a16: a gated epilogue needs N (gate + up rows) to be a multiple of 16");
   SGLK_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256,
                "group_size must be 32, 64, 128 or 256; got %lld", (long long)group_size);
   SGLK_REQUIRE(is_int4 || (group_size == 32 && zeros == nullptr),
@@ -869,6 +933,9 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
   SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "activations must be bfloat16 or half");
   SGLK_REQUIRE((uintptr_t)activations % 16 == 0 && (uintptr_t)packed_weights % 16 == 0,
                "moe_grouped_mm_nt_xe20_w4a16: activations and packed_weights must be 16-byte aligned");
+  // (the decode tiles fetch a row's scales / zero points of a whole trip of the K loop with one 8- to 32-byte load)
+  SGLK_REQUIRE((uintptr_t)scales % 16 == 0 && (zeros == nullptr || (uintptr_t)zeros % 16 == 0),
+               "moe_grouped_mm_nt_xe20_w4a16: scales and zeros must be 16-byte aligned");
   // (per-lane weight / activation / scale offsets inside one expert are 32-bit)
   SGLK_REQUIRE(N * (K / 2) < (1ll << 32) && 256 * K < (1ll << 32) && N < (1ll << 31) && K < (1ll << 31),
                "moe_grouped_mm_nt_xe20_w4a16: one expert's packed weights must stay below 4 GiB (N=%lld, K=%lld)",
@@ -878,9 +945,9 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16)
     return dispatch<bf16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
-                          (int)n_experts, (int)N, (int)K, gs);
+                          (int)n_experts, (int)N, (int)K, gs, fused_act);
   return dispatch<f16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
-                       (int)n_experts, (int)N, (int)K, gs);
+                       (int)n_experts, (int)N, (int)K, gs, fused_act);
 }
 
 #ifdef SGLK_PROBES

@@ -636,10 +636,10 @@ void apply_shuffle_mul_sum(const Tensor& input, Tensor& output, const Tensor& pe
                                        (float)routed_scaling_factor, dtype_code(input.scalar_type(), "input"), fdt));
 }
 
-void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
-                                  const Tensor& scales, const std::optional<Tensor>& zeros,
-                                  const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
-                                  bool is_int4, int64_t group_size) {
+static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
+                          const Tensor& scales, const std::optional<Tensor>& zeros,
+                          const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
+                          bool is_int4, int64_t group_size, int64_t fused_act) {
   CHECK_GPU(output);
   CHECK_GPU(activations);
   CHECK_GPU(packed_weights);
@@ -679,7 +679,10 @@ void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, con
   TORCH_CHECK(n_experts == rows_per_expert.size(0), "rows_per_expert must have n_experts elements");
   TORCH_CHECK(rows_per_expert.scalar_type() == at::kInt, "rows_per_expert must be int32");
   TORCH_CHECK(output.size(0) == total_m, "output rows must match activations rows");
-  TORCH_CHECK(output.size(1) == gemm_n, "output must have N columns");
+  TORCH_CHECK(fused_act >= 0 && fused_act <= 3, "activation_type must be 0 (none), 1 (silu), 2 (gelu) or 3 (relu2)");
+  const bool gated = fused_act == 1 || fused_act == 2;
+  TORCH_CHECK(output.size(1) == (gated ? gemm_n / 2 : gemm_n), gated ? "output must have N / 2 columns (gate rows, then up rows in W)"
+                                                                     : "output must have N columns");
   TORCH_CHECK(gemm_n % 8 == 0, "N must be divisible by 8");
   TORCH_CHECK(activations.scalar_type() == at::kBFloat16 || activations.scalar_type() == at::kHalf,
               "activations must be bfloat16 or half");
@@ -701,10 +704,37 @@ void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, con
     zeros_ptr = zeros->data_ptr();
   }
   const c10::OptionalDeviceGuard guard(activations.device());
-  SGLK_CALL(sglk_moe_grouped_mm_w4a16(stream_of(activations), output.data_ptr(), activations.data_ptr(),
-                                      packed_weights.data_ptr(), scales.data_ptr(), zeros_ptr, bias_ptr,
-                                      rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
-                                      group_size, is_int4 ? 1 : 0, dtype_code(activations.scalar_type(), "activations")));
+  // the C-ABI wants 16-byte aligned scales / zeros (vector loads of a row's groups): a view at an odd storage offset is
+  // copied once here instead of being refused
+  Tensor scales_al = scales, zeros_al;
+  if (reinterpret_cast<uintptr_t>(scales.data_ptr()) % 16 != 0) scales_al = scales.clone();
+  if (zeros_ptr != nullptr && reinterpret_cast<uintptr_t>(zeros_ptr) % 16 != 0) {
+    zeros_al = zeros->clone();
+    zeros_ptr = zeros_al.data_ptr();
+  }
+  SGLK_CALL(sglk_moe_grouped_mm_w4a16_act(stream_of(activations), output.data_ptr(), activations.data_ptr(),
+                                          packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr, bias_ptr,
+                                          rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
+                                          group_size, is_int4 ? 1 : 0,
+                                          dtype_code(activations.scalar_type(), "activations"), (int)fused_act));
+}
+
+void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
+                                  const Tensor& scales, const std::optional<Tensor>& zeros,
+                                  const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
+                                  bool is_int4, int64_t group_size) {
+  moe_w4a16_impl(output, activations, packed_weights, scales, zeros, bias, rows_per_expert, n_experts, is_int4, group_size, 0);
+}
+
+// authored (no reference op: the reference runs GEMM 1 and the gate / up activation as two launches,
+// python/sgl_kernel/moe.py:751-835): the same GEMM with the activation on its fp32 accumulators.
+// activation_type: 1 silu, 2 gelu (tanh) - output [total_m, N / 2]; 3 relu2 - output [total_m, N]
+void moe_grouped_mm_nt_w4a16_act(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
+                                 const Tensor& scales, const std::optional<Tensor>& zeros,
+                                 const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
+                                 bool is_int4, int64_t group_size, int64_t activation_type) {
+  moe_w4a16_impl(output, activations, packed_weights, scales, zeros, bias, rows_per_expert, n_experts, is_int4, group_size,
+                 activation_type);
 }
 
 // ---- moe_grouped_mm_nt_xe20 (reference src/sycl/GroupGemmXe20.cpp:160-275) ---------------------------------
@@ -1574,6 +1604,11 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "moe_grouped_mm_nt_xe20_w4a16(Tensor! output, Tensor activations, Tensor packed_weights, Tensor scales, "
       "Tensor? zeros, Tensor? bias, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size) -> ()");
   m.impl("moe_grouped_mm_nt_xe20_w4a16", c10::kCUDA, &moe_grouped_mm_nt_xe20_w4a16);
+  m.def(
+      "moe_grouped_mm_nt_w4a16_act(Tensor! output, Tensor activations, Tensor packed_weights, Tensor scales, "
+      "Tensor? zeros, Tensor? bias, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size, "
+      "int activation_type) -> ()");
+  m.impl("moe_grouped_mm_nt_w4a16_act", c10::kCUDA, &moe_grouped_mm_nt_w4a16_act);
   m.def(
       "prepare_moe_input(Tensor topk_ids, Tensor! expert_offsets, Tensor? blockscale_offsets, Tensor! problem_sizes1,"
       " Tensor! problem_sizes2, Tensor! input_permutation, Tensor! output_permutation, int num_experts, int n, int k)"

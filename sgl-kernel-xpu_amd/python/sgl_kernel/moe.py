@@ -280,18 +280,14 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
         else:
             _ops.moe_grouped_mm_nt_xe20(out, a, w, bias, rows_per_expert, p.experts, p.act_type, fuse_act, 1.702, 7.0)
 
-    # ---- GEMM 1 (+ gate/up activation)
-    if not p.four_bit:  # gate/up activation (or relu2) on the fp32 accumulators in the GEMM's epilogue
-        h = scratch("intermediate_cache1_fused", (p.rows, p.inter))
+    # ---- GEMM 1 with the gate / up activation (or relu2) on its fp32 accumulators, in the epilogue: no [rows, 2I]
+    # intermediate, no separate act-and-mul launch (the reference runs them as two launches, moe.py:751-835)
+    h = scratch("intermediate_cache1_fused", (p.rows, p.inter))
+    if not p.four_bit:
         grouped_mm(h, x, w1, None, None, b1, 0, fuse_act=True)
     else:
-        gu = scratch("intermediate_cache1_unfused", (p.rows, p.gate_factor * p.inter))
-        grouped_mm(gu, x, w1, w1_scale, w1_zp, b1, p.group1)
-        if p.act_op is not None:
-            h = scratch("intermediate_cache2", (p.rows, p.inter))
-            getattr(_ops, p.act_op)(h, gu)
-        else:
-            h = torch.square(torch.relu(gu))
+        _ops.moe_grouped_mm_nt_w4a16_act(h, x, w1, w1_scale, w1_zp, b1, rows_per_expert, p.experts, p.int4, p.group1,
+                                         {0: 1, 1: 2, 3: 3}[p.act_type])
     if w2_g_idx_perm is not None:
         h = _gather_channels_per_expert(h, w2_g_idx_perm, rows_per_expert, p.experts)
 

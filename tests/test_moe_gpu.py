@@ -174,6 +174,54 @@ def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
     torch.testing.assert_close(out.cpu().float(), exact.to(dtype).float(), rtol=1e-2, atol=2e-3)
 
 
+@pytest.mark.parametrize("act_type", [1, 2, 3])  # silu, gelu (tanh), relu2
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gs,explicit_zero", [(128, False), (32, True), (64, False)])
+@pytest.mark.parametrize("rows,N,K", [([2] * 8, 256, 256), ([0, 5, 17, 0, 1, 33, 0, 129], 416, 512),
+                                      ([300, 0, 40, 7], 1024, 1280), ([1] * 8, 4096, 1024),
+                                      ([130, 200, 112, 150], 512, 1024), ([3, 0, 16, 7], 208, 8192)])
+def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit_zero, rows, N, K):
+    """the gate / up activation (or relu2) in the epilogue of the W4A16 GEMM (authored op moe_grouped_mm_nt_w4a16_act):
+    act(gate) * up from the fp32 accumulators, one rounding, against the exact-code fp32 definition; and within the
+    reference tolerance of the two-launch route (GEMM rounded to T, then silu_and_mul / gelu_tanh_and_mul on it)."""
+    g = torch.Generator().manual_seed(len(rows) * 31 + N + K + gs + act_type)
+    E, total = len(rows), sum(rows)
+    act = (torch.randn(total, K, generator=g) * 0.1).to(dtype)
+    packed, scales, zeros = make_int4(E, N, K, gs, dtype, explicit_zero, g)
+    bias = torch.randn(E, N, generator=g) * 0.05 if (N % 256 == 0) else None
+    rows_t = torch.tensor(rows, dtype=torch.int32)
+    gated = act_type != 3
+    out = torch.full((total, N // 2 if gated else N), float("nan"), dtype=dtype, device=dev)
+    wq = packed.view(torch.int8 if explicit_zero else torch.uint8).to(dev)
+    d = lambda t: t.to(dev) if t is not None else None
+    torch.ops.sgl_kernel.moe_grouped_mm_nt_w4a16_act(out, act.to(dev), wq, scales.to(dev), d(zeros), d(bias), rows_t.to(dev),
+                                                     E, True, gs, act_type)
+    codes = omoe.unpack_int4(packed, signed=zeros is None).float()
+    z = zeros.float().repeat_interleave(gs, dim=-1) if zeros is not None else 0.0
+    w_exact = (codes - z) * scales.float().repeat_interleave(gs, dim=-1)
+    r0, x = 0, torch.empty(total, N)
+    for e, r in enumerate(rows):
+        x[r0:r0 + r] = act[r0:r0 + r].float() @ w_exact[e].t() + (bias[e] if bias is not None else 0.0)
+        r0 += r
+    if act_type == 1:
+        ref = torch.nn.functional.silu(x[:, :N // 2]) * x[:, N // 2:]
+    elif act_type == 2:
+        ref = torch.nn.functional.gelu(x[:, :N // 2], approximate="tanh") * x[:, N // 2:]
+    else:
+        ref = torch.relu(x) ** 2
+    torch.testing.assert_close(out.cpu().float(), ref.to(dtype).float(), rtol=1e-2, atol=2e-3)
+    # the two-launch route of the reference (its own tolerance, tests/test_moe_gemm.py:386)
+    gu = torch.empty(total, N, dtype=dtype, device=dev)
+    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(gu, act.to(dev), wq, scales.to(dev), d(zeros), d(bias), rows_t.to(dev), E,
+                                                      True, gs)
+    if gated:
+        two = torch.empty(total, N // 2, dtype=dtype, device=dev)
+        (torch.ops.sgl_kernel.silu_and_mul if act_type == 1 else torch.ops.sgl_kernel.gelu_tanh_and_mul)(two, gu)
+    else:
+        two = torch.relu(gu.float()) ** 2
+    torch.testing.assert_close(out.cpu().float(), two.cpu().float(), rtol=5e-2, atol=2e-2)
+
+
 def test_w4a16_golden(sglk, dev):
     for c in load_golden("moe_w4a16")["grouped_mm"]:
         E = c["packed"].shape[0]
