@@ -33,6 +33,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef short v8s __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 
@@ -935,13 +936,21 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
 //   * two tiles in flight per wave (32 KiB; 256 KiB per CU at two workgroups per CU);
 //   * the page id of a tile is fetched two tiles ahead, in front of the loads of the tile one ahead (vmcnt retires in
 //     order: see the general kernel).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const T* __restrict__ q,
+// Head dims 64 / 128 / 256 and an fp8 (e4m3 / e5m2) cache (round 3; reference instantiations FMHADecodeXe20.cmake:13-16,
+// :62-111): D / 32 k-steps, D / 16 output tiles; the V image is made of 128-dim column blocks of [32 tokens][256 B] with the
+// swizzle of the d = 128 image (d = 64 fills half a block); d = 256 takes the whole register file (one workgroup per CU:
+// 64 KiB of K / V per wave in flight is still far more than the latency needs). fp8: K bytes go to registers as they are
+// and are widened right before their MFMAs (v_cvt_scalef32_pk_*), V is widened on its way into the LDS image; the K
+// descale is folded into the softmax scale, the V descale into the final normalisation (as the general kernel does).
+template <typename T, int D, int KV8>
+__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_decode_kernel(AttnParams p, const T* __restrict__ q,
                                                              const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                              const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
                                                              const int32_t* __restrict__ page_table) {
   using M = Mfma<T>;
-  constexpr int D = 128, KS = 4, NT = 8, VIMG = kTile * 256;  // V image of a tile: 8 KiB
+  constexpr int KS = D / 32, NT = D / 16, NB = (D + 127) / 128, VIMG = NB * kTile * 256;  // V image of a tile: NB x 8 KiB
+  constexpr int ES = KV8 ? 1 : 2;  // bytes per cache element
+  static_assert(D == 64 || D == 128 || D == 256, "decode kernel: head dims 64, 128, 256");
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [4 waves][2] V images; the merge reuses them
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1031,8 +1040,8 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const
   const uint32_t kst = (uint32_t)(p.paged ? p.k_s1 : p.k_s0), vst = (uint32_t)(p.paged ? p.v_s1 : p.v_s0);
   const int64_t kbase_off = (p.paged == 2 ? (int64_t)cache_row * p.k_s0 + (int64_t)hk * p.k_s2
                                           : (int64_t)hk * (p.paged ? p.k_s2 : p.k_s1)) + 8 * pig;
-  const int64_t vbase_off = (p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
-                                          : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1)) + 8 * (lane & 15);
+  const int64_t vbase_row = (p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
+                                          : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1));
   const int last_key = seqlen_k - 1;
   auto tile_of = [&](int j) { return t_lo + wave + kWaves * (j < nw ? j : nw - 1); };  // (past the end: the last tile again)
   auto fetch_page = [&](int t) -> int {
@@ -1040,12 +1049,21 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const
     pos = pos < last_key ? pos : last_key;
     return pg_src[(pos + pos_base) >> pos_shift];
   };
+  // K fragment registers: [ks][half] token 16 half + tau(l15), dims 32 ks + 8 pig .. (16-bit: 16 bytes; fp8: 8 bytes,
+  // widened right before the MFMA)
+  using KV = typename std::conditional<KV8 == 0, v4i, v2i>::type;
   struct KRegs {
-    v4i k[2 * KS];  // [ks][half]: token 16 half + tau(l15), dims 32 ks + 8 pig ..
+    KV k[2 * KS];
   };
+  // V staging registers: 16 bytes per lane and load. 16-bit cache: chunk c of a token row = dims 8 c ..; a 128-dim block
+  // row is 16 chunks (d = 64: 8). fp8: 16 bytes = 16 dims = two 16-byte chunks of the widened row.
+  constexpr int CPR = D * ES / 16;               // 16-byte pieces per token row in the cache
+  constexpr int TPL = 64 / CPR > 0 ? 64 / CPR : 1;  // tokens per load instruction (d = 256, 16-bit: 32 pieces -> 2 tokens)
+  constexpr int NVL = kTile * CPR / 64;          // loads per tile and lane
   struct VRegs {
-    v4i v[8];       // chunk lane + 64 i of the [32 tokens][16 chunks] tile: token 4 i + lane / 16, chunk lane % 16
+    v4i v[NVL];
   };
+  const int v_piece = lane % CPR, v_tok = lane / CPR;  // this lane's piece of the row, its token within a load
   auto issue_k = [&](int t, int page, KRegs& r) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1054,18 +1072,46 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const
       const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
       const int64_t off = (int64_t)((uint64_t)(uint32_t)page * kpg + ((uint64_t)cp * kst + (uint64_t)kbase_off));
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) r.k[2 * ks + h] = *reinterpret_cast<const v4i*>(kcache + (off + 32 * ks) * 2);
+      for (int ks = 0; ks < KS; ++ks) r.k[2 * ks + h] = *reinterpret_cast<const KV*>(kcache + (off + 32 * ks) * ES);
     }
   };
   auto issue_v = [&](int t, int page, VRegs& r) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int pos = t * kTile + 4 * i + (lane >> 4);
+    for (int i = 0; i < NVL; ++i) {
+      int pos = t * kTile + TPL * i + v_tok;
       pos = pos < last_key ? pos : last_key;
       const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
-      const int64_t off = (int64_t)((uint64_t)(uint32_t)page * vpg + ((uint64_t)cp * vst + (uint64_t)vbase_off));
-      r.v[i] = *reinterpret_cast<const v4i*>(vcache + off * 2);
+      const int64_t off = (int64_t)((uint64_t)(uint32_t)page * vpg + ((uint64_t)cp * vst + (uint64_t)vbase_row));
+      r.v[i] = *reinterpret_cast<const v4i*>(vcache + off * ES + 16 * v_piece);
     }
+  };
+  // fp8: 8 bytes -> 8 elements of T (exact), one v_cvt_scalef32_pk_* per pair, unit scale
+  auto widen8 = [&](int lo, int hi) -> v4i {
+    typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 v2h_ __attribute__((ext_vector_type(2)));
+    v4i r;
+    const int x[2] = {lo, hi};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (std::is_same<T, bf16>::value && KV8 == 1) {
+        r[2 * h] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(x[h], 1.0f, false));
+        r[2 * h + 1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(x[h], 1.0f, true));
+      } else if constexpr (std::is_same<T, bf16>::value) {
+        r[2 * h] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(x[h], 1.0f, false));
+        r[2 * h + 1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(x[h], 1.0f, true));
+      } else if constexpr (KV8 == 1) {
+        r[2 * h] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x[h], 1.0f, false));
+        r[2 * h + 1] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x[h], 1.0f, true));
+      } else {
+        r[2 * h] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(x[h], 1.0f, false));
+        r[2 * h + 1] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(x[h], 1.0f, true));
+      }
+    }
+    return r;
+  };
+  auto kfrag = [&](const KV& x) -> v8s {
+    if constexpr (KV8 == 0) return __builtin_bit_cast(v8s, x);
+    else return __builtin_bit_cast(v8s, widen8(x[0], x[1]));
   };
 
   int vbase0;
@@ -1081,7 +1127,8 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const
   for (int nt = 0; nt < NT; ++nt) o[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   const float log2e = 1.4426950408889634f;
-  const float scale = p.scale, sc2 = scale * log2e;
+  const float kd = (KV8 != 0 && p.k_descale) ? p.k_descale[0] : 1.f, vd = (KV8 != 0 && p.v_descale) ? p.v_descale[0] : 1.f;
+  const float scale = p.scale * kd, sc2 = scale * log2e;  // (the K descale multiplies every logit)
   __shared__ float xch_all[kWaves * 16];
   float* xch = xch_all + wave * 16;
 
@@ -1094,15 +1141,23 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const
     v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      s0 = M::run(__builtin_bit_cast(v8s, kr.k[2 * ks]), qf[ks], s0);
-      s1 = M::run(__builtin_bit_cast(v8s, kr.k[2 * ks + 1]), qf[ks], s1);
+      s0 = M::run(kfrag(kr.k[2 * ks]), qf[ks], s0);
+      s1 = M::run(kfrag(kr.k[2 * ks + 1]), qf[ks], s1);
     }
     // V image of this tile (wave-private: no barrier; LDS operations of a wave complete in order)
     char* vb = vimg + buf * VIMG;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = 4 * i + (lane >> 4), ch = lane & 15;
-      *reinterpret_cast<v4i*>(vb + row * 256 + ((ch ^ sw_main(row)) << 4)) = vr.v[i];
+    for (int i = 0; i < NVL; ++i) {
+      const int row = TPL * i + v_tok;
+      if constexpr (KV8 == 0) {
+        const int blk = v_piece >> 4, ch = v_piece & 15;  // 128-dim column block, 16-byte chunk inside it
+        *reinterpret_cast<v4i*>(vb + blk * (kTile * 256) + row * 256 + ((ch ^ sw_main(row)) << 4)) = vr.v[i];
+      } else {  // 16 fp8 -> two chunks of 8 elements
+        const int blk = v_piece >> 3, ch = (v_piece & 7) * 2;
+        char* rowp = vb + blk * (kTile * 256) + row * 256;
+        *reinterpret_cast<v4i*>(rowp + ((ch ^ sw_main(row)) << 4)) = widen8(vr.v[i][0], vr.v[i][1]);
+        *reinterpret_cast<v4i*>(rowp + (((ch + 1) ^ sw_main(row)) << 4)) = widen8(vr.v[i][2], vr.v[i][3]);
+      }
     }
     issue_v(tile_of(j + 1), page_v, vr);
     issue_k(tile_of(j + 2), page_k, kr);
@@ -1171,7 +1226,7 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const char* a = vb + (vbase0 ^ ((nt & 7) << 5));
+      const char* a = vb + (nt >> 3) * (kTile * 256) + (vbase0 ^ ((nt & 7) << 5));
       const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a));
       const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a + 4096));
       v8s vf;
@@ -1245,7 +1300,7 @@ __global__ __launch_bounds__(256, 2) void attn_decode_kernel(AttnParams p, const
     lse_val = m2 + logf(l2);
     l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
   }
-  const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
+  const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? vd / l_tot : 0.f;  // (V descale folded in)
   if (lane < 16) xch[lane] = inv_l;
   const v4f i4 = *reinterpret_cast<const v4f*>(xch + 4 * g4);
 #pragma unroll
@@ -1334,14 +1389,14 @@ static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, co
   return check_launch("fwd(prefill)");
 }
 
-template <typename T>
+template <typename T, int D, int KV8>
 static int launch_decode(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                          const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch) {
-  constexpr int lds = kWaves * 2 * kTile * 256;  // 64 KiB
+  constexpr int lds = kWaves * 2 * ((D + 127) / 128) * kTile * 256;  // 64 KiB (d = 256: 128 KiB)
   static unsigned long long attr_done = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_decode_kernel<T>), lds, &attr_done, "fwd")) return rc;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_decode_kernel<T, D, KV8>), lds, &attr_done, "fwd")) return rc;
   dim3 grid((unsigned)(p.Hk * p.splits), (unsigned)batch);
-  attn_decode_kernel<T><<<grid, 256, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  attn_decode_kernel<T, D, KV8><<<grid, 256, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   if (int rc = check_launch("fwd(decode)")) return rc;
   if (p.splits > 1) {
     attn_reduce_kernel<T><<<dim3(p.Hq, p.total_q), 128, 0, st>>>((T*)p.out, p.lse, p.part_o, p.part_lse, p.sinks,
@@ -1360,10 +1415,21 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
   if (kv8 == 0 && d == 128 && p.splits == 1 && p.softcap <= 0.f && max_rows >= 128 && p.q_s0 % 8 == 0 && p.o_s0 % 4 == 0 &&
       p.o_s1 % 4 == 0)
     return launch_prefill<T>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
-  // decode-sized problems at head dim 128: every sequence has at most 16 packed rows per kv head; a tile within one page
-  if (kv8 == 0 && d == 128 && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) && p.leftpad_k == nullptr &&
-      p.q_s0 % 8 == 0)
-    return launch_decode<T>(st, p, q, k, v, cu_q, seq_k, table, batch);
+  // decode-sized problems at head dims 64 / 128 / 256 (16-bit or fp8 cache): every sequence has at most 16 packed rows per
+  // kv head; a tile within one page
+  if ((d == 64 || d == 128 || d == 256) && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) &&
+      p.leftpad_k == nullptr && p.q_s0 % 8 == 0 &&
+      (kv8 == 0 || (p.k_s0 % 16 == 0 && p.k_s1 % 16 == 0 && p.k_s2 % 16 == 0 && p.v_s0 % 16 == 0 && p.v_s1 % 16 == 0 &&
+                    p.v_s2 % 16 == 0 && (uintptr_t)v % 16 == 0))) {  // (fp8: V rows are fetched in 16-byte pieces)
+#define SGLK_DEC_GO(DD)                                                                                     \
+  return kv8 == 0   ? launch_decode<T, DD, 0>(st, p, q, k, v, cu_q, seq_k, table, batch)                     \
+         : kv8 == 1 ? launch_decode<T, DD, 1>(st, p, q, k, v, cu_q, seq_k, table, batch)                     \
+                    : launch_decode<T, DD, 2>(st, p, q, k, v, cu_q, seq_k, table, batch)
+    if (d == 64) SGLK_DEC_GO(64);
+    if (d == 128) SGLK_DEC_GO(128);
+    SGLK_DEC_GO(256);
+#undef SGLK_DEC_GO
+  }
   if (kv8 != 0) {  // fp8 KV cache: built for the head dims the reference exercises (and 64)
 #define SGLK_FP8_GO(DKP)                                                                              \
   return kv8 == 1 ? launch<T, DKP, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)            \
