@@ -35,7 +35,7 @@ PEAK_FP8_TFLOPS = 5000.0  # MI355X_MICROARCH.md: dense FP8 MFMA peak (MX K=128 f
 PEAK_HBM_GBS = 8000.0
 GEMM_KERNEL = ("gemm_8bit_persist_kernel<bf16, blockwise> (two launches: 256-row tiles, then 128-row half tiles of "
                "the last partial round)")
-PMC_FILE = os.path.join("profiles", "r02", "bench_pmc.json")
+PMC_FILE = os.path.join("profiles", "r03", "bench_pmc.json")
 CLOCK_RAMP_S = 0.15  # untimed steady-state run of the step before the W warm-up steps
 
 
@@ -51,8 +51,8 @@ def make_inputs(dev, seed):
 
 
 def pmc_traffic_bytes():
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/gpu_profiles_r02.sh ->
-    profiles/r02/bench_pmc.json): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (tools/gpu_profiles_r03.sh ->
+    profiles/r03/bench_pmc.json): FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts 128-B
     requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section) and is doubled."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
@@ -460,7 +460,7 @@ def mla_roofline(sgl_kernel, dev, heads=128):
     nbytes = qq.numel() * 2 + cache.numel() * 2 + table.numel() * 4 + seq_lens.numel() * 4 + bs * heads * 512 * 2
     return {
         "bound": "hbm",
-        "kernel": "mla_rows128_kernel<bf16> (+ split merge)" if heads > 64 else "mla_decode_kernel<bf16> (+ split merge)",
+        "kernel": "mla_rows128x_kernel<bf16> (32x32x16 MFMA, row per lane; + split merge)" if heads > 64 else "mla_decode_kernel<bf16> (+ split merge)",
         "workload": f"flash_mla_decode bs={bs} seq={seq} heads={heads} kv_lora=512 rope=64 page={page} bf16",
         "achieved": round(nbytes / avg / 1e6, 1),
         "peak": PEAK_HBM_GBS,

@@ -98,9 +98,35 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const IdT* __restrict__
   const int tid = threadIdx.x;
   for (int i = tid; i < num_experts; i += 1024) counts[i] = 0;
   __syncthreads();
-  for (int64_t i = tid; i < numel; i += 1024) {
-    const int b = (int)topk_ids[i] + 1;
-    if (b >= 0 && b < num_experts) atomicAdd(&counts[b], 1);
+  // Counting. Eight ids per thread are requested before any is used (one memory round trip per 8192 ids instead of one per
+  // 1024: the single workgroup is latency-bound). With few buckets (a top-2-of-8 routing puts 8192 ids on 9 counters)
+  // the lanes of a wave that hit the same bucket send ONE atomic; with many buckets plain atomics collide rarely and the
+  // aggregation loop (one trip per distinct bucket of the wave) would cost more than it saves.
+  const bool aggregate = num_experts <= 32;
+  for (int64_t i0 = 0; i0 < numel; i0 += 8 * 1024) {
+    int bs[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t i = i0 + r * 1024 + tid;
+      const int b = i < numel ? (int)topk_ids[i] + 1 : -1;
+      bs[r] = b < num_experts ? b : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int b = bs[r];
+      if (!aggregate) {
+        if (b >= 0) atomicAdd(&counts[b], 1);
+        continue;
+      }
+      unsigned long long todo = __ballot(b >= 0);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int b0 = __shfl(b, leader, 64);
+        const unsigned long long same = __ballot(b == b0);
+        if ((tid & 63) == leader) atomicAdd(&counts[b0], __builtin_popcountll(same));
+        todo &= ~same;
+      }
+    }
   }
   __syncthreads();
   // exclusive scan of the padded counts by one wave (num_experts is at most a few hundred)
@@ -146,12 +172,28 @@ template <typename IdT>
 __global__ __launch_bounds__(256) void moe_align_sort_kernel(const IdT* __restrict__ topk_ids,
                                                              int32_t* sorted_token_ids, int32_t* cumsum,
                                                              int num_experts, int64_t numel) {
+  // wave-aggregated ranks: one returning atomic per (wave, bucket) hands out a run of slots, the lanes take theirs by
+  // their position among the wave's lanes of that bucket (the order inside a bucket is unspecified, as in the reference)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
-    const int b = (int)topk_ids[i] + 1;
-    if (b >= 0 && b < num_experts) {
-      const int rank = atomicAdd(&cumsum[b], 1);
-      sorted_token_ids[rank] = (int32_t)i;
+  const int lane = threadIdx.x & 63;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < numel; i0 += stride) {
+    const int64_t i = i0 + threadIdx.x;
+    int b = i < numel ? (int)topk_ids[i] + 1 : -1;
+    if (b >= num_experts) b = -1;
+    if (num_experts > 32) {  // many buckets: plain returning atomics (see the counting kernel)
+      if (b >= 0) sorted_token_ids[atomicAdd(&cumsum[b], 1)] = (int32_t)i;
+      continue;
+    }
+    unsigned long long todo = __ballot(b >= 0);
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const int b0 = __shfl(b, leader, 64);
+      const unsigned long long same = __ballot(b == b0);
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&cumsum[b0], __builtin_popcountll(same));
+      base = __shfl(base, leader, 64);
+      if (b == b0) sorted_token_ids[base + __builtin_popcountll(same & ((1ull << lane) - 1ull))] = (int32_t)i;
+      todo &= ~same;
     }
   }
 }

@@ -1,22 +1,26 @@
-"""fwd decode at BASELINE configs[2] (bs=16, 32 q heads / 8 kv heads, d=128, seq=4096, paged 64, bf16): time vs num_splits."""
+"""fwd decode at BASELINE configs[2] geometry (bs=16, 32 q heads / 8 kv heads, seq=4096, paged 64): time vs num_splits for
+the head dims / cache types of the decode kernel (d = 64 / 128 / 256 bf16, d = 128 fp8 e4m3)."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "python"))
 from sgl_kernel.flash_attn import flash_attn_with_kvcache
 dev = "cuda"
-bs, hq, hk, d, seq, page = 16, 32, 8, 128, 4096, 64
-n_pages = bs * seq // page
-kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
-vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
-lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
-qd = torch.randn(bs, 1, hq, d, device=dev, dtype=torch.bfloat16)
+bs, hq, hk, seq, page = 16, 32, 8, 4096, 64
 def timeit(f, warm=30, it=100):
     for _ in range(warm): f()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(it): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / it * 1e3
-for name, pt in (("random pages", torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, -1)),
-                 ("sequential pages", torch.arange(n_pages, device=dev, dtype=torch.int32).view(bs, -1))):
-    for splits in (0, 1, 2, 4, 8, 16, 32, 64):
-        ms = timeit(lambda: flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, page_table=pt, num_splits=splits))
-        print(f"{name}: num_splits={splits:2d}: {ms:.4f} ms  {(kc.numel()+vc.numel())*2/ms/1e6:.0f} GB/s")
+cases = [(int(a.split(":")[0]), a.split(":")[1]) for a in sys.argv[1:]] or [(128, "bf16"), (64, "bf16"), (256, "bf16"), (128, "fp8")]
+for d, kv in cases:
+    n_pages = bs * seq // page
+    kvdt = torch.float8_e4m3fn if kv == "fp8" else torch.bfloat16
+    kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16).to(kvdt)
+    vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16).to(kvdt)
+    lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+    qd = torch.randn(bs, 1, hq, d, device=dev, dtype=torch.bfloat16)
+    kw = dict(k_descale=torch.ones(1, device=dev), v_descale=torch.ones(1, device=dev)) if kv == "fp8" else {}
+    pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, -1)
+    for splits in (0, 1, 2, 3, 4, 6, 8, 16):
+        ms = timeit(lambda: flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, page_table=pt, num_splits=splits, **kw))
+        print(f"d={d} {kv}: num_splits={splits:2d}: {ms:.4f} ms  {(kc.numel()+vc.numel())*kc.element_size()/ms/1e6:.0f} GB/s")

@@ -11,6 +11,7 @@ export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
 cd /tmp && export TMPDIR=/tmp
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
 SQ2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+mkdir -p $OUT
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/trace -- "$@" > $OUT/$name.trace.log 2>&1
 timeout 900 rocprofv3 --pmc $SQ1 --output-format csv -d $OUT/$name/pmc_sq1 -- "$@" > $OUT/$name.sq1.log 2>&1
 timeout 900 rocprofv3 --pmc $SQ2 --output-format csv -d $OUT/$name/pmc_sq2 -- "$@" > $OUT/$name.sq2.log 2>&1
