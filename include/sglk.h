@@ -279,13 +279,14 @@ SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const vo
  * 751-835 runs the GEMM, writes [rows, 2I] and calls silu_and_mul / gelu_tanh_and_mul on it; the 16-bit GEMM has the
  * fused form, kernels/moe/xe20/bf16/moe_mainloop.hpp:232-247). fused_act: 0 none, 1 silu, 2 gelu (tanh): W rows
  * [0, N/2) gate, [N/2, N) up, out [total_m, N/2] = T(act(gate + b) * (up + b)) from the fp32 accumulators;
- * 3 relu2: out [total_m, N] = T(max(x + b, 0)^2). */
+ * 3 relu2: out [total_m, N] = T(max(x + b, 0)^2); 4 the DeepSeek-V4 clamped swiglu (reference silu_and_mul_clamp,
+ * python/sgl_kernel/elementwise.py:231-255): gate = min(gate, act_limit), up = clamp(up, +-act_limit), silu(gate) * up. */
 SGLK_API int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, const void* activations,
                                            const void* packed_weights, const void* scales,
                                            const void* zeros, const float* bias,
                                            const int32_t* rows_per_expert, int64_t total_m,
                                            int64_t n_experts, int64_t N, int64_t K, int64_t group_size,
-                                           int is_int4, int dtype, int fused_act);
+                                           int is_int4, int dtype, int fused_act, float act_limit);
 
 /* ---- flash-attention forward ---------------------------------------------------
  * fwd (mha_fwd): reference src/sycl/flash_attention.cpp:1332-1435 (schema

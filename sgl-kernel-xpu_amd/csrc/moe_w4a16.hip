@@ -168,12 +168,14 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
                                                         const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
                                                         const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
-                                                        int K, int group_shift, int probe, int fuse) {
+                                                        int K, int group_shift, int probe, int fuse, float act_limit) {
   // fuse (the gate / up activation of fused_experts in this GEMM's epilogue, as moe_bf16.hip does for 16-bit weights;
   // reference python/sgl_kernel/moe.py:751-835 runs GEMM, then a separate act-and-mul over a [rows, 2I] intermediate):
   //   1 silu, 2 gelu (tanh form): W holds gate rows [0, N/2) then up rows [N/2, N); a workgroup takes BN/2 gate columns
   //   AND the BN/2 up columns that go with them (wave tiles nt < NW/2 gate, nt >= NW/2 up), out[m, n] = T(act(gate) * up)
   //   is [total_m, N/2]: the product is formed on the fp32 accumulators, one rounding. 3 relu2: out = T(max(x, 0)^2).
+  //   4 DeepSeek-V4 swiglu (reference silu_and_mul_clamp, python/sgl_kernel/elementwise.py:231-255): gate = min(gate, limit),
+  //   up = clamp(up, -limit, limit), then silu(gate) * up.
   // probe (libsglk_probes.so only; 0 in the release library): timing experiments with garbage results -
   // 1: one activation row for all 16 m rows, 2: no output stores, 4: non-temporal weight loads, 8: scales read once,
   // 16: no weight expansion / MFMAs (stream only), 32: no barrier, 64: no activation staging, 512: row blocks fastest in the
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   // (64-row tiles of a projection with more k than columns: the column blocks of a row block run together and share its
   // activations in L2 - 731 against 755 us for the Mixtral down projection at 512 rows per expert; the gate / up projection
   // measured the other way round, 1609 against 1706 us. Probe 512 flips the choice.)
-  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2);
+  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4);
   const int Nh = N >> 1;  // gated: output width
   const int col_blocks = gated ? (Nh + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN;
   const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, col_blocks, MT >= 4 && ((N < K) != ((probe & 512) != 0)));
@@ -537,9 +539,13 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = mt * 16 + 4 * g + r;
-            const float x = acc[mt][nt][r] + bg, y = acc[mt][nt + H2][r] + bu;
+            float x = acc[mt][nt][r] + bg, y = acc[mt][nt + H2][r] + bu;
+            if (fuse == 4) {
+              x = fminf(x, act_limit);
+              y = fminf(fmaxf(y, -act_limit), act_limit);
+            }
             float a;
-            if (fuse == 1) {
+            if (fuse == 1 || fuse == 4) {
               a = x / (1.0f + expf(-x));
             } else {
               const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -791,16 +797,19 @@ static int g_w4_probe = 0, g_w4_mt = 0, g_w4_fp4hw = 1;
 constexpr int g_w4_probe = 0, g_w4_mt = 0, g_w4_fp4hw = 1;
 #endif
 
+// (the clamp bound of fused_act 4 rides beside the launch parameters: one value per call, set by the C-ABI entry)
+static thread_local float t_act_limit = 0.f;
+
 template <typename T, int MT, int NW, int PB, int FMT = 0, int WV = 4>
 static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift, int fuse) {
   constexpr int BM = 16 * MT, BN = 16 * NW * WV;
-  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2);
+  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4);
   const int64_t wgs = moe_tile_launch_size(total_m, E, BM, gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN));
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20_w4a16: problem too large for one launch");
   dim3 grid((unsigned)wgs);
   moe_w4a16_kernel<T, MT, NW, PB, FMT, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
-                                                             rows, E, N, K, group_shift, g_w4_probe, fuse);
+                                                             rows, E, N, K, group_shift, g_w4_probe, fuse, t_act_limit);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
 }
 
@@ -845,7 +854,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
   // (a narrow projection keeps the 16-row tile up to an average of 20 rows: ragged counts around 16 - 64 tokens, top-2 of 8 -
   // 81 us against 96 us with the 32-row tile for the down projection; the gate / up projection measured 151 against 145)
-  const bool gated_epi = fuse == 1 || fuse == 2;  // (needs the two-tile wave: no 16-column wave tiles, no K split)
+  const bool gated_epi = fuse == 1 || fuse == 2 || fuse == 4;  // (needs the two-tile wave: no 16-column wave tiles, no K split)
   const bool narrow16 = !gated_epi && gp == 7 && K % 1024 == 0 &&
                         std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / 16) * cdiv(N, 128) <= 384;
   const bool small = avg <= 10 || (narrow16 && avg <= 20 && g_w4_mt == 0);
@@ -910,18 +919,20 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
                                          int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
                                          int dtype) {
   return sglk_moe_grouped_mm_w4a16_act(stream, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
-                                       n_experts, N, K, group_size, is_int4, dtype, 0);
+                                       n_experts, N, K, group_size, is_int4, dtype, 0, 0.f);
 }
 
 extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, const void* activations,
                                              const void* packed_weights, const void* scales, const void* zeros,
                                              const float* bias, const int32_t* rows_per_expert, int64_t total_m,
                                              int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
-                                             int dtype, int fused_act) {
+                                             int dtype, int fused_act, float act_limit) {
   using namespace sglk;
-  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 3,
-               "moe_grouped_mm_nt_xe20_w4a16: fused_act must be 0 (none), 1 (silu), 2 (gelu) or 3 (relu2)");
-  SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2) || N % 16 == 0,
+  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 4,
+               "moe_grouped_mm_nt_xe20_w4a16: fused_act must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2) or 4 (clamped swiglu)");
+  SGLK_REQUIRE(fused_act != 4 || act_limit > 0.f, "moe_grouped_mm_nt_xe20_w4a16: the clamped swiglu needs a positive limit");
+  t_act_limit = act_limit;
+  SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2 || fused_act == 4) || N % 16 == 0,
                "moe_grouped_mm_nt_xe20_w4a16: a gated epilogue needs N (gate + up rows) to be a multiple of 16");
   SGLK_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256,
                "group_size must be 32, 64, 128 or 256; got %lld", (long long)group_size);

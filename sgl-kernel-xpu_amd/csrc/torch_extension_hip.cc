@@ -639,7 +639,7 @@ void apply_shuffle_mul_sum(const Tensor& input, Tensor& output, const Tensor& pe
 static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
                           const Tensor& scales, const std::optional<Tensor>& zeros,
                           const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
-                          bool is_int4, int64_t group_size, int64_t fused_act) {
+                          bool is_int4, int64_t group_size, int64_t fused_act, double act_limit) {
   CHECK_GPU(output);
   CHECK_GPU(activations);
   CHECK_GPU(packed_weights);
@@ -679,8 +679,8 @@ static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tens
   TORCH_CHECK(n_experts == rows_per_expert.size(0), "rows_per_expert must have n_experts elements");
   TORCH_CHECK(rows_per_expert.scalar_type() == at::kInt, "rows_per_expert must be int32");
   TORCH_CHECK(output.size(0) == total_m, "output rows must match activations rows");
-  TORCH_CHECK(fused_act >= 0 && fused_act <= 3, "activation_type must be 0 (none), 1 (silu), 2 (gelu) or 3 (relu2)");
-  const bool gated = fused_act == 1 || fused_act == 2;
+  TORCH_CHECK(fused_act >= 0 && fused_act <= 4, "activation_type must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2) or 4 (clamped swiglu)");
+  const bool gated = fused_act == 1 || fused_act == 2 || fused_act == 4;
   TORCH_CHECK(output.size(1) == (gated ? gemm_n / 2 : gemm_n), gated ? "output must have N / 2 columns (gate rows, then up rows in W)"
                                                                      : "output must have N columns");
   TORCH_CHECK(gemm_n % 8 == 0, "N must be divisible by 8");
@@ -716,25 +716,25 @@ static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tens
                                           packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr, bias_ptr,
                                           rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
                                           group_size, is_int4 ? 1 : 0,
-                                          dtype_code(activations.scalar_type(), "activations"), (int)fused_act));
+                                          dtype_code(activations.scalar_type(), "activations"), (int)fused_act, (float)act_limit));
 }
 
 void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
                                   const Tensor& scales, const std::optional<Tensor>& zeros,
                                   const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
                                   bool is_int4, int64_t group_size) {
-  moe_w4a16_impl(output, activations, packed_weights, scales, zeros, bias, rows_per_expert, n_experts, is_int4, group_size, 0);
+  moe_w4a16_impl(output, activations, packed_weights, scales, zeros, bias, rows_per_expert, n_experts, is_int4, group_size, 0, 0.0);
 }
 
 // authored (no reference op: the reference runs GEMM 1 and the gate / up activation as two launches,
 // python/sgl_kernel/moe.py:751-835): the same GEMM with the activation on its fp32 accumulators.
-// activation_type: 1 silu, 2 gelu (tanh) - output [total_m, N / 2]; 3 relu2 - output [total_m, N]
+// activation_type: 1 silu, 2 gelu (tanh), 4 clamped swiglu (act_limit) - output [total_m, N / 2]; 3 relu2 - output [total_m, N]
 void moe_grouped_mm_nt_w4a16_act(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
                                  const Tensor& scales, const std::optional<Tensor>& zeros,
                                  const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
-                                 bool is_int4, int64_t group_size, int64_t activation_type) {
+                                 bool is_int4, int64_t group_size, int64_t activation_type, double act_limit) {
   moe_w4a16_impl(output, activations, packed_weights, scales, zeros, bias, rows_per_expert, n_experts, is_int4, group_size,
-                 activation_type);
+                 activation_type, act_limit);
 }
 
 // ---- moe_grouped_mm_nt_xe20 (reference src/sycl/GroupGemmXe20.cpp:160-275) ---------------------------------
@@ -825,7 +825,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
   TORCH_CHECK(!q_v.has_value(), "q_v is not supported yet");  // as the reference: flash_attention.cpp:603-609
   TORCH_CHECK(!rotary_cos.has_value() && !rotary_sin.has_value() && !seqlens_rotary.has_value(),
               "fwd: in-kernel rotary embedding is not supported");
-  TORCH_CHECK(!q_descale.has_value(), "fwd: q_descale is not supported (q is never fp8 on this build)");
+  // q_descale: the reference takes it and never reads it (q must be Half / BFloat16, flash_attention.cpp:308-312, :914-918;
+  // only k_descale / v_descale reach its kernels, :561-572, :1092-1096): accepted and ignored here as well.
+  if (q_descale.has_value()) {
+    CHECK_GPU(*q_descale);
+    TORCH_CHECK(q_descale->scalar_type() == at::kFloat, "q_descale must be float32");
+  }
   // per-tensor descale: a scalar or an expanded scalar (reference get_per_tensor_descale_ptr, flash_attention.cpp:45-70)
   auto descale_ptr = [&](const std::optional<Tensor>& t, const char* name) -> const float* {
     if (!fp8_kv || !t.has_value()) return nullptr;
@@ -1607,7 +1612,7 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
   m.def(
       "moe_grouped_mm_nt_w4a16_act(Tensor! output, Tensor activations, Tensor packed_weights, Tensor scales, "
       "Tensor? zeros, Tensor? bias, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size, "
-      "int activation_type) -> ()");
+      "int activation_type, float act_limit=0.0) -> ()");
   m.impl("moe_grouped_mm_nt_w4a16_act", c10::kCUDA, &moe_grouped_mm_nt_w4a16_act);
   m.def(
       "prepare_moe_input(Tensor topk_ids, Tensor! expert_offsets, Tensor? blockscale_offsets, Tensor! problem_sizes1,"

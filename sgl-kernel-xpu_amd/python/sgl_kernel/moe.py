@@ -239,8 +239,11 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     assert not use_fp8_w8a8, "current MoE does not support use_fp8_w8a8"
     assert a1_scale is None and a2_scale is None, "current MoE does not support a1_scale / a2_scale"
     assert block_shape is None, "current MoE does not support block_shape"
-    if gemm1_alpha is not None or swiglu_limit is not None:
-        raise NotImplementedError("fused_experts: the clamped swiglu variants (gpt-oss, DeepSeek-V4) are outside this build")
+    if gemm1_alpha is not None:
+        raise NotImplementedError("fused_experts: the gpt-oss swiglu (interleaved gate / up columns, gemm1_alpha) is outside this build")
+    if swiglu_limit is not None:  # DeepSeek-V4 clamp (reference moe.py:699-709): silu only, 4-bit weights only
+        assert activation == "silu" and swiglu_limit == 10
+        assert use_mxfp4_w4a16 or use_int4_w4a16, "swiglu_limit requires use_mxfp4_w4a16=True or use_int4_w4a16=True"
     assert is_xe2_arch(), "this MoE path is built for gfx950 (MI355X) only"
     if w1_g_idx_perm is not None or w2_g_idx_perm is not None:
         assert use_int4_w4a16, "w1_g_idx_perm/w2_g_idx_perm only apply to use_int4_w4a16"
@@ -286,8 +289,9 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     if not p.four_bit:
         grouped_mm(h, x, w1, None, None, b1, 0, fuse_act=True)
     else:
+        fused = 4 if swiglu_limit is not None else {0: 1, 1: 2, 3: 3}[p.act_type]
         _ops.moe_grouped_mm_nt_w4a16_act(h, x, w1, w1_scale, w1_zp, b1, rows_per_expert, p.experts, p.int4, p.group1,
-                                         {0: 1, 1: 2, 3: 3}[p.act_type])
+                                         fused, float(swiglu_limit or 0.0))
     if w2_g_idx_perm is not None:
         h = _gather_channels_per_expert(h, w2_g_idx_perm, rows_per_expert, p.experts)
 

@@ -336,6 +336,20 @@ def test_fp8_kvcache(sglk, dev, fp8_dtype, heads, D, page, sq, causal):
         assert diff.max().item() <= 2e-2 and diff.mean().item() <= 2e-3, (layout, diff.max().item(), diff.mean().item())
 
 
+def test_q_descale_is_accepted_and_ignored(sglk, dev):
+    """the reference parses q_descale and never reads it (q is always 16-bit there, flash_attention.cpp:290, :308-312)"""
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(2, 1, 8, 128, generator=g).to(torch.bfloat16).to(dev)
+    kc = torch.randn(4, 64, 2, 128, generator=g).to(torch.bfloat16).to(dev)
+    vc = torch.randn(4, 64, 2, 128, generator=g).to(torch.bfloat16).to(dev)
+    lens = torch.tensor([100, 128], dtype=torch.int32, device=dev)
+    table = torch.tensor([[0, 1], [2, 3]], dtype=torch.int32, device=dev)
+    a = sglk.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, page_table=table)
+    b = sglk.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, page_table=table,
+                                     q_descale=torch.full((2, 2), 3.0, device=dev))
+    assert torch.equal(a, b)
+
+
 def test_fp8_kvcache_requires_descale(sglk, dev):
     kc = torch.zeros(2, 64, 2, 128, device=dev).to(torch.float8_e4m3fn)
     q = torch.zeros(1, 1, 2, 128, device=dev, dtype=torch.bfloat16)

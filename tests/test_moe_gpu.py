@@ -174,7 +174,7 @@ def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
     torch.testing.assert_close(out.cpu().float(), exact.to(dtype).float(), rtol=1e-2, atol=2e-3)
 
 
-@pytest.mark.parametrize("act_type", [1, 2, 3])  # silu, gelu (tanh), relu2
+@pytest.mark.parametrize("act_type", [1, 2, 3, 4])  # silu, gelu (tanh), relu2, DeepSeek-V4 clamped swiglu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("gs,explicit_zero", [(128, False), (32, True), (64, False)])
 @pytest.mark.parametrize("rows,N,K", [([2] * 8, 256, 256), ([0, 5, 17, 0, 1, 33, 0, 129], 416, 512),
@@ -194,8 +194,9 @@ def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit
     out = torch.full((total, N // 2 if gated else N), float("nan"), dtype=dtype, device=dev)
     wq = packed.view(torch.int8 if explicit_zero else torch.uint8).to(dev)
     d = lambda t: t.to(dev) if t is not None else None
+    limit = 0.25  # (small enough that the clamp of act_type 4 bites on these inputs)
     torch.ops.sgl_kernel.moe_grouped_mm_nt_w4a16_act(out, act.to(dev), wq, scales.to(dev), d(zeros), d(bias), rows_t.to(dev),
-                                                     E, True, gs, act_type)
+                                                     E, True, gs, act_type, limit)
     codes = omoe.unpack_int4(packed, signed=zeros is None).float()
     z = zeros.float().repeat_interleave(gs, dim=-1) if zeros is not None else 0.0
     w_exact = (codes - z) * scales.float().repeat_interleave(gs, dim=-1)
@@ -207,6 +208,9 @@ def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit
         ref = torch.nn.functional.silu(x[:, :N // 2]) * x[:, N // 2:]
     elif act_type == 2:
         ref = torch.nn.functional.gelu(x[:, :N // 2], approximate="tanh") * x[:, N // 2:]
+    elif act_type == 4:  # reference silu_and_mul_clamp: gate = min(gate, limit), up = clamp(up, +-limit)
+        ref = torch.nn.functional.silu(x[:, :N // 2].clamp(max=limit)) * x[:, N // 2:].clamp(-limit, limit)
+        assert (x[:, :N // 2] > limit).any() and (x[:, N // 2:].abs() > limit).any()
     else:
         ref = torch.relu(x) ** 2
     torch.testing.assert_close(out.cpu().float(), ref.to(dtype).float(), rtol=1e-2, atol=2e-3)
@@ -214,12 +218,53 @@ def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit
     gu = torch.empty(total, N, dtype=dtype, device=dev)
     torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(gu, act.to(dev), wq, scales.to(dev), d(zeros), d(bias), rows_t.to(dev), E,
                                                       True, gs)
-    if gated:
+    if act_type == 4:
+        guf = gu.float()
+        two = torch.nn.functional.silu(guf[:, :N // 2].clamp(max=limit)) * guf[:, N // 2:].clamp(-limit, limit)
+    elif gated:
         two = torch.empty(total, N // 2, dtype=dtype, device=dev)
         (torch.ops.sgl_kernel.silu_and_mul if act_type == 1 else torch.ops.sgl_kernel.gelu_tanh_and_mul)(two, gu)
     else:
         two = torch.relu(gu.float()) ** 2
     torch.testing.assert_close(out.cpu().float(), two.cpu().float(), rtol=5e-2, atol=2e-2)
+
+
+def test_fused_experts_swiglu_limit(sglk, dev):
+    """DeepSeek-V4 clamp (reference moe.py:699-709, tests/test_fused_experts_mxfp4_dsv4_shapes.py:59-61): with a limit no
+    pre-activation reaches, the clamped layer equals the plain silu layer bit for bit; with inputs scaled up it equals the
+    layer built from the same ops with the clamp done by hand."""
+    g = torch.Generator().manual_seed(21)
+    T, E, topk, H, I, gs, dt = 48, 8, 2, 512, 1024, 128, torch.bfloat16
+    x = (torch.randn(T, H, generator=g) * 0.1).to(dt).to(dev)
+    w1, s1, _ = make_int4(E, 2 * I, H, gs, dt, False, g)
+    w2, s2, _ = make_int4(E, H, I, gs, dt, False, g)
+    w1, s1, w2, s2 = w1.view(torch.uint8).to(dev), s1.to(dev), w2.view(torch.uint8).to(dev), s2.to(dev)
+    tw = torch.rand(T, topk, generator=g).to(dev)
+    ti = torch.stack([torch.randperm(E, generator=g)[:topk] for _ in range(T)]).to(torch.int32).to(dev)
+    kw = dict(use_int4_w4a16=True, w1_scale=s1, w2_scale=s2)
+    plain = sglk.fused_experts(x, w1, w2, tw, ti, **kw)
+    clamped = sglk.fused_experts(x, w1, w2, tw, ti, swiglu_limit=10, **kw)
+    assert torch.equal(plain, clamped)  # (|pre-activations| stay far below 10 here)
+    big = sglk.fused_experts(x * 64, w1, w2, tw, ti, swiglu_limit=10, **kw)
+    big_plain = sglk.fused_experts(x * 64, w1, w2, tw, ti, **kw)
+    assert not torch.equal(big, big_plain)
+    # the same layer by hand: one expert-contiguous pass through the unfused GEMM, clamp, silu * up, second GEMM, combine
+    ref = torch.zeros(T, H, dtype=torch.float32, device=dev)
+    for e in range(E):
+        rows = (ti == e).any(dim=1).nonzero().flatten()
+        if rows.numel() == 0:
+            continue
+        cnt = torch.zeros(E, dtype=torch.int32, device=dev)
+        cnt[e] = rows.numel()
+        gu = torch.empty(rows.numel(), 2 * I, dtype=dt, device=dev)
+        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(gu, (x * 64)[rows].contiguous(), w1, s1, None, None, cnt, E, True, gs)
+        guf = gu.float()
+        h = (torch.nn.functional.silu(guf[:, :I].clamp(max=10.0)) * guf[:, I:].clamp(-10.0, 10.0)).to(dt)
+        y = torch.empty(rows.numel(), H, dtype=dt, device=dev)
+        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(y, h, w2, s2, None, None, cnt, E, True, gs)
+        wsel = (tw * (ti == e)).sum(dim=1)[rows]
+        ref[rows] += y.float() * wsel[:, None]
+    torch.testing.assert_close(big.float(), ref, rtol=5e-2, atol=5e-2 * ref.abs().max().item())
 
 
 def test_w4a16_golden(sglk, dev):
