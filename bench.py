@@ -156,7 +156,24 @@ def side_metrics(sgl_kernel, dev):
     bi = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(dev).t()
     ms = timeit(lambda: sgl_kernel.int8_scaled_mm(ai, bi, sa1, sb1, torch.bfloat16), iters=30)
     out["int8_scaled_mm_M4096_TOPs"] = round(2.0 * M * N * K / ms / 1e9, 1)
-    del bw, sbw, ai, bi, am
+    # QServe W4A8 at the same shape (random codes in the QServe packing; group scales 1..7, zero terms -8..7)
+    wq = torch.randint(-128, 128, (N, K // 2), generator=g, dtype=torch.int8).to(dev)
+    ws16 = (torch.rand(N, device=dev) * 0.01).half()
+    wz16 = (torch.rand(N, device=dev) * 0.01).half()
+    z8 = torch.randint(-8, 8, (K // 128, N), generator=g, dtype=torch.int8).to(dev)
+    s8 = torch.randint(1, 8, (K // 128, N), generator=g, dtype=torch.int8).to(dev)
+    sa16 = (torch.rand(M, device=dev) * 0.01).half()
+    ssum = torch.rand(M, device=dev).half()
+    qo = torch.empty(M, N, device=dev, dtype=torch.float16)
+    ms = timeit(lambda: sgl_kernel.qserve_w4a8_per_chn_gemm(ai, wq, ws16, sa16, wz16, ssum, qo), iters=30)
+    out["qserve_w4a8_per_chn_M4096_TOPs"] = round(2.0 * M * N * K / ms / 1e9, 1)
+    ms = timeit(lambda: sgl_kernel.qserve_w4a8_per_group_gemm(ai, wq, z8, s8, ws16, sa16, qo), iters=30)
+    out["qserve_w4a8_per_group_M4096_TOPs"] = round(2.0 * M * N * K / ms / 1e9, 1)
+    for m in (1, 64):
+        ms = timeit(lambda: sgl_kernel.qserve_w4a8_per_group_gemm(ai[:m], wq, z8, s8, ws16, sa16[:m], qo[:m]), iters=50)
+        out[f"qserve_w4a8_per_group_M{m}_us"] = round(ms * 1e3, 1)
+        out[f"qserve_w4a8_per_group_M{m}_weight_GBs"] = round(N * K / 2 / ms / 1e6, 1)
+    del bw, sbw, ai, bi, am, wq, qo
     # the down projection of the same layer at decode: N=4096, K=14336 (few n-tiles: K split over the waves of a workgroup)
     bw = ((torch.rand(K, N, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev).t()
     sbw = (torch.rand(K // 128, N // 128, generator=g) * 1e-3 + 1e-4).to(dev).t()

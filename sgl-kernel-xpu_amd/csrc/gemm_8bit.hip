@@ -44,6 +44,7 @@ namespace {
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 256, BN = 256, BK = 128;
@@ -63,7 +64,8 @@ __device__ __forceinline__ v8i read_frag(const char* tile, int off) {
   return r;
 }
 
-enum { MODE_BLOCKWISE = 0, MODE_FP8_ROWCOL = 1, MODE_INT8_ROWCOL = 2 };
+// MODE_W4A8_CHN / MODE_W4A8_GRP: the QServe W4A8 GEMMs (qserve_w4a8.hip) on the persistent pipeline, see below
+enum { MODE_BLOCKWISE = 0, MODE_FP8_ROWCOL = 1, MODE_INT8_ROWCOL = 2, MODE_W4A8_CHN = 3, MODE_W4A8_GRP = 4 };
 
 // fp8 e4m3 x e4m3, K = 128, D = A*B + C
 // fragment = two 16-byte LDS reads at (addr) and (addr ^ 64); addr is a 32-bit LDS byte address
@@ -436,9 +438,12 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
     int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m,
-    int tiles_n, int all_halves, uint32_t* __restrict__ stamps) {
+    int tiles_n, int all_halves, uint32_t* __restrict__ stamps, const void* __restrict__ x0,
+    const void* __restrict__ x1) {
   constexpr bool kBW = MODE == MODE_BLOCKWISE;
-  using AccT = typename std::conditional<MODE == MODE_INT8_ROWCOL, v4i, v4f>::type;
+  constexpr bool kW4 = MODE == MODE_W4A8_CHN || MODE == MODE_W4A8_GRP, kGrp = MODE == MODE_W4A8_GRP;
+  constexpr bool kI8 = MODE == MODE_INT8_ROWCOL || kW4;
+  using AccT = typename std::conditional<kI8, v4i, v4f>::type;
   __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -505,11 +510,11 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
     d.m0 = m0;
     d.n0 = n0;
     d.pa = a + (int64_t)m0 * lda;
-    d.pb = b + (int64_t)n0 * ldb;
+    d.pb = kW4 ? b + (int64_t)n0 * (K >> 1) : b + (int64_t)n0 * ldb;  // (W4: 32-column groups of K/32 512-byte blocks)
     d.ps = kBW ? sa + (int64_t)m0 * sa_sm : sa;
     d.po = (void*)(out + (int64_t)m0 * ldc + n0);
     d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * lda + K) : 0u;
-    d.nrec_b = live ? (uint32_t)((int64_t)(rows_b - 1) * ldb + K) : 0u;
+    d.nrec_b = !live ? 0u : kW4 ? (uint32_t)((int64_t)(rows_b >> 5) * (K >> 5) * 512) : (uint32_t)((int64_t)(rows_b - 1) * ldb + K);
     // row scales: waves 0..3 fetch 64 rows each (4 B per lane); waves 4..7 fetch nothing (zeros into the spare KiB)
     d.nrec_s = (kBW && live && wave < 4) ? (uint32_t)(((int64_t)(rows_a - 1) * sa_sm + (int64_t)(nkb - 1) * sa_sk + 1) * 4) : 0u;
     d.nrec_o = (live && kStore) ? (uint32_t)(((int64_t)(rows_a - 1) * ldc + rows_b) * (int64_t)sizeof(OutT)) : 0u;
@@ -540,6 +545,9 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
   for (int ii = 0; ii < 4; ++ii)
     voff_b[ii] = (uint32_t)(lane >> 3) * (uint32_t)ldb + (((lane & 7) ^ ((ii << 1) | ((lane >> 4) & 1))) << 4);
   const uint32_t voff_s = (uint32_t)tid * (uint32_t)sa_sm * 4u;
+  // W4: a 1-KiB piece = two 512-byte blocks (k32 = 2 ks, 2 ks + 1 of one 32-column group); its 16-byte chunks (blk, c, e)
+  // land at e * 256 + blk * 128 + c * 16, so that the fragment read of one e touches 256 contiguous bytes
+  const uint32_t voff_w = (uint32_t)(((lane >> 3) & 1) * 512 + (lane & 7) * 64 + (lane >> 4) * 16);
 
   // LDS-DMA of K block kb of tile d into stage s, one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = rows
   // of b^T, two pieces (sub 0, 1) each; (part 0, sub 2) = the block's row scales
@@ -552,6 +560,15 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
                                                  SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4, voff_s,
                                                  kb * (int)sa_sk * 4, 0, 0);
       return;
+    }
+    if constexpr (kW4) {
+      if (part == 3) return;
+      if (part == 2) {  // the wave's 32-column group: k steps sub = 0, 1 of the K block
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b),
+                                                 SGLK_LDS(base + kTileBytes + (wave * 2 + sub) * 1024), 16, voff_w,
+                                                 (wave * (K >> 5) + kb * 4 + sub * 2) * 512, 0, 0);
+        return;
+      }
     }
     const int ii = (part & 1) * 2 + sub;
     auto one = [&](int piece) {
@@ -587,9 +604,31 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
     float sa[8];
     v4f sb[2][2];
     Vec<OutT, 8> bias[2];
+    // W4: lane (j, g) owns row j of an m-fragment and columns wn*64 + (nf>>1)*32 + (nf&1)*16 + 4 g .. + 3 of n-fragment nf
+    float asum[8];
+    Vec<f16, 4> sw[4], wz[4];
   };
   auto load_epi = [&](const TileDesc& d) -> Epi {
     Epi e;
+    if constexpr (kW4) {
+      const f16* ascales = reinterpret_cast<const f16*>(sa);
+      const f16* wscales = reinterpret_cast<const f16*>(sb);
+#pragma unroll
+      for (int mf = 0; mf < MS; ++mf) {
+        int m = d.m0 + wm * (MS * 16) + mf * 16 + j;
+        m = m < M ? m : M - 1;
+        e.sa[mf] = (float)ascales[m];
+        if constexpr (!kGrp) e.asum[mf] = (float)reinterpret_cast<const f16*>(x0)[m];
+      }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        int n = d.n0 + wn * 64 + (nf >> 1) * 32 + (nf & 1) * 16 + g * 4;  // (N % 32 == 0: in range or dropped as a whole)
+        n = n < N ? n : 0;
+        e.sw[nf] = load_vec<f16, 4>(wscales + n);
+        if constexpr (!kGrp) e.wz[nf] = load_vec<f16, 4>(reinterpret_cast<const f16*>(bias) + n);
+      }
+      return e;
+    }
 #pragma unroll
     for (int mf = 0; mf < MS; ++mf) {
       int m = d.m0 + wm * (MS * 16) + mf * 16 + j;
@@ -615,6 +654,25 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
     const int soff = __builtin_amdgcn_readfirstlane(mf * 16 * (int)ldc * (int)sizeof(OutT));
     const uint32_t orow_off = MS == 8 ? orow_off_full : orow_off_half;
+    if constexpr (kW4) {
+      // (orow_off addresses column wn*64 + 8 g; this layout wants wn*64 + 4 g + 16 (nf&1) + 32 (nf>>1))
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        Vec<f16, 4> v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = (float)accm[nf][r] * e.sa[mf] * (float)e.sw[nf][r];  // (the small kernels' / the oracle's order)
+          if constexpr (!kGrp) t -= e.asum[mf] * (float)e.wz[nf][r];
+          v[r] = (f16)t;
+        }
+        const int col = wn * 64 + (nf >> 1) * 32 + (nf & 1) * 16 + g * 4;
+        const uint32_t vo = col < d.ncols ? orow_off + (uint32_t)(((nf >> 1) * 32 + (nf & 1) * 16 - g * 4) * 2) : 0x80000000u;
+        const v2i data = __builtin_bit_cast(v2i, v);
+        __builtin_amdgcn_raw_buffer_store_b64(data, ro, (int)vo, soff, 0);
+        asm volatile("s_nop 4" ::"v"(data));  // (see below)
+      }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       Vec<OutT, 8> v;
@@ -673,7 +731,7 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
 #define SGLK_FRAG(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
 // cur[cb][nf] = n-fragment nf x m-fragment buffer mb (zero C: the partial of ONE 128-deep block)
 #define SGLK_MFMA(cb, nf, mb, row)                                                                             \
-  if constexpr (MODE == MODE_INT8_ROWCOL) {                                                                    \
+  if constexpr (kI8) {                                                                    \
     asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0\n\tv_mfma_i32_16x16x64_i8 %0, %3, %4, %0"               \
                  : "+v"(acc[row][nf])                                                                          \
                  : "v"(nlo[nf]), "v"(mlo[mb]), "v"(nhi[nf]), "v"(mhi[mb]));                                    \
@@ -702,6 +760,63 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
 
   v4i nlo[4], nhi[4], mlo[2], mhi[2];
   float raw[2];
+  // ---- W4 (QServe): the packed 4-bit weights of the K block sit in LDS as they are in memory (the 32 x 32 block IS an MFMA
+  // layout: dword e of lane (j = 8 b + c, kg) = k 16 kg + 4 e .. + 3 of row j in the low and of row 16 + j in the high
+  // nibbles). rw[q][ks][p] = dwords e = 2 p, 2 p + 1 of the wave's 32-column group q, 64-deep k step ks; one AND and one
+  // shift + AND per dword make n-fragments 2 q (rows j) and 2 q + 1 (rows 16 + j): nlo = step 0, nhi = step 1.
+  // Per group: the K block is the group; (code * s8 + zs8) is formed as u8 + 128 in ONE packed 16-bit multiply-add per
+  // dword (code * s8 + (zs8 + 128) is in 1..255: no carries between bytes) and flipped back to int8 by an XOR.
+  v2i rw[2][2][2];
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  uint32_t smul[2][2] = {{0, 0}, {0, 0}}, zadd[2][2] = {{0, 0}, {0, 0}};  // [q][half]: s8 in both 16-bit halves, zs8 + 128 in all bytes
+  uint32_t szraw[2][2] = {{0, 0}, {0, 0}};                                 // [q][s8 / zs8]: the dword of columns c, 8+c, 16+c, 24+c
+  const int wj_c = j & 7, wj_b = j >> 3;
+  const uint32_t w_lane = (uint32_t)((g >> 1) * 128 + wj_c * 16 + (g & 1) * 8 + wj_b * 4 + wn * 4096);
+  auto load_sz = [&](const TileDesc& d, int kb) {  // group scales / zero terms of K block kb -> szraw (used one block later)
+    if constexpr (kGrp) {
+      const __amdgpu_buffer_rsrc_t r0 = make_rsrc(x0, (uint32_t)((int64_t)(K >> 7) * N));
+      const __amdgpu_buffer_rsrc_t r1 = make_rsrc(x1, (uint32_t)((int64_t)(K >> 7) * N));
+      const int so = __builtin_amdgcn_readfirstlane(kb * N + d.n0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        szraw[q][0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r0, wn * 64 + q * 32 + wj_c * 4, so, 0);
+        szraw[q][1] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r1, wn * 64 + q * 32 + wj_c * 4, so, 0);
+      }
+    }
+  };
+  auto prep_sz = [&]() {
+    if constexpr (kGrp) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t sv = (szraw[q][0] >> ((2 * h + wj_b) * 8)) & 0xffu;
+          const uint32_t zv = ((szraw[q][1] >> ((2 * h + wj_b) * 8)) & 0xffu) ^ 0x80u;
+          smul[q][h] = sv | (sv << 16);
+          const uint32_t z2 = zv | (zv << 8);
+          zadd[q][h] = z2 | (z2 << 16);
+        }
+    }
+  };
+  auto unpack_w = [&](const v2i (&r)[2], v4i& flo, v4i& fhi, int q) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t wd = (uint32_t)r[e >> 1][e & 1];
+      uint32_t lo = wd & 0x0f0f0f0fu, hi = (wd >> 4) & 0x0f0f0f0fu;
+      if constexpr (kGrp) {
+        lo = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, lo) * __builtin_bit_cast(u16x2, smul[q][0]) +
+                                                  __builtin_bit_cast(u16x2, zadd[q][0]))) ^ 0x80808080u;
+        hi = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, hi) * __builtin_bit_cast(u16x2, smul[q][1]) +
+                                                  __builtin_bit_cast(u16x2, zadd[q][1]))) ^ 0x80808080u;
+      }
+      flo[e] = (int)lo;
+      fhi[e] = (int)hi;
+    }
+  };
+// the eight fragment reads of a K block: ds_read2st64_b32 (offsets in units of 256 B: piece (q, ks) at 2 q + ks KiB, e at 256 e)
+#define SGLK_RDW(q, ks, addr)                                                                                  \
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(rw[q][ks][0]) : "v"(addr), "n"((q) * 8 + (ks) * 4), "n"((q) * 8 + (ks) * 4 + 1)); \
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(rw[q][ks][1]) : "v"(addr), "n"((q) * 8 + (ks) * 4 + 2), "n"((q) * 8 + (ks) * 4 + 3));
   float sbv;
   v4f cur[2][4];    // partials of the running (mf & 1) and the previous m-step
   float scp = 0.f;  // row scale x column-block scale of the previous m-step
@@ -742,6 +857,11 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
     }                                                                                                          \
     SGLK_MFMA(cb_, 0, cb_, (mf))                                                                               \
     SGLK_PROMOTE(prow_, pb_, 0)                                                                                \
+    if constexpr (kW4 && (mf) == 0) { /* the last quarter of the block's weight unpack (see the last m-step) */ \
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(rw[1][1][0]), "+v"(rw[1][1][1]));                             \
+      unpack_w(rw[1][1], nhi[2], nhi[3], 1);                                                                   \
+      asm volatile("" : "+v"(nhi[2]), "+v"(nhi[3]));                                                           \
+    }                                                                                                          \
     if ((mf) == 0) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(nlo[1]), "+v"(nhi[1]));                          \
     SGLK_MFMA(cb_, 1, cb_, (mf))                                                                               \
     SGLK_PROMOTE(prow_, pb_, 1)                                                                                \
@@ -768,6 +888,7 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
     const TileDesc d1 = pick(in1, cur_t, nxt), d2 = pick(in2, cur_t, nxt);                                     \
     const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
     if constexpr (STORE && !kBW) epi = load_epi(prv);                                                          \
+    load_sz(d1, kb1);                                                                                          \
     {                                                                                                          \
       int fo = frag_off_a;                                                                                     \
       asm volatile("" : "+v"(fo));                                                                             \
@@ -810,6 +931,30 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
       uint32_t na_lo = nbase + (uint32_t)(wm * d1.wrows * 128) + (uint32_t)foa, na_hi = na_lo ^ 64u;           \
       uint32_t nts = nbase + 2 * kTileBytes + (uint32_t)(wm * d1.wrows * 4) + (uint32_t)((foa >> 7) << 2);    \
       asm volatile("" : "+v"(nb_lo), "+v"(nb_hi), "+v"(na_lo), "+v"(na_hi), "+v"(nts));                        \
+      if constexpr (kW4) {                                                                                     \
+        uint32_t nw = nbase + (uint32_t)kTileBytes + w_lane;                                                   \
+        asm volatile("" : "+v"(nw));                                                                           \
+        prep_sz();                                                                                             \
+        SGLK_MFMA(1, 0, 1, kLast)                                                                              \
+        SGLK_RDW(0, 0, nw) SGLK_RDW(0, 1, nw)                                                                  \
+        SGLK_RD16(mlo[0], na_lo, 0);          SGLK_RD16(mhi[0], na_hi, 0);                                     \
+        SGLK_MFMA(1, 1, 1, kLast)                                                                              \
+        SGLK_RDW(1, 0, nw) SGLK_RDW(1, 1, nw)                                                                  \
+        if (kDma) dma_piece(d2, kb2, s, 0, 0);                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(rw[0][0][0]), "+v"(rw[0][0][1]));                           \
+        unpack_w(rw[0][0], nlo[0], nlo[1], 0);                                                                 \
+        asm volatile("" : "+v"(nlo[0]), "+v"(nlo[1]));                                                         \
+        SGLK_MFMA(1, 2, 1, kLast)                                                                              \
+        if (kDma) dma_piece(d2, kb2, s, 0, 1);                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(rw[0][1][0]), "+v"(rw[0][1][1]));                           \
+        unpack_w(rw[0][1], nhi[0], nhi[1], 0);                                                                 \
+        asm volatile("" : "+v"(nhi[0]), "+v"(nhi[1]));                                                         \
+        SGLK_MFMA(1, 3, 1, kLast)                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rw[1][0][0]), "+v"(rw[1][0][1]), "+v"(mlo[0]), "+v"(mhi[0])); \
+        unpack_w(rw[1][0], nlo[2], nlo[3], 1);                                                                 \
+        asm volatile("" : "+v"(nlo[2]), "+v"(nlo[3]));                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+      } else {                                                                                                 \
       SGLK_MFMA(1, 0, 1, kLast)                                                                                \
       SGLK_PROMOTE(kLast - 1, 0, 0)                                                                            \
       SGLK_RD16(nlo[0], nb_lo, kNfImm[0]);  SGLK_RD16(nhi[0], nb_hi, kNfImm[0]);                               \
@@ -833,6 +978,7 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
         asm volatile("" : "+v"(scp));                                                                          \
       }                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
+      }                                                                                                        \
     }                                                                                                          \
     ++gblk;                                                                                                    \
   }
@@ -854,12 +1000,29 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
     const uint32_t b_lo = lds_base + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)frag_off_b, b_hi = b_lo ^ 64u;
     const uint32_t a_lo = lds_base + (uint32_t)(wm * cur_t.wrows * 128) + (uint32_t)frag_off_a, a_hi = a_lo ^ 64u;
     const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * cur_t.wrows * 4) + (uint32_t)(j << 2);
+    if constexpr (kW4) {
+      const uint32_t w0 = lds_base + (uint32_t)kTileBytes + w_lane;
+      load_sz(cur_t, 0);
+      SGLK_RDW(0, 0, w0) SGLK_RDW(0, 1, w0) SGLK_RDW(1, 0, w0) SGLK_RDW(1, 1, w0)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                   : "+v"(rw[0][0][0]), "+v"(rw[0][0][1]), "+v"(rw[0][1][0]), "+v"(rw[0][1][1]), "+v"(rw[1][0][0]),
+                     "+v"(rw[1][0][1]), "+v"(rw[1][1][0]), "+v"(rw[1][1][1]), "+v"(szraw[0][0]), "+v"(szraw[0][1]),
+                     "+v"(szraw[1][0]), "+v"(szraw[1][1]));
+      prep_sz();
+      unpack_w(rw[0][0], nlo[0], nlo[1], 0);
+      unpack_w(rw[0][1], nhi[0], nhi[1], 0);
+      unpack_w(rw[1][0], nlo[2], nlo[3], 1);
+      unpack_w(rw[1][1], nhi[2], nhi[3], 1);
+      SGLK_RD16(mlo[0], a_lo, 0);          SGLK_RD16(mhi[0], a_hi, 0);
+      SGLK_RD4(raw[0], ts0, 0);
+    } else {
     SGLK_RD16(nlo[0], b_lo, kNfImm[0]);  SGLK_RD16(nhi[0], b_hi, kNfImm[0]);
     SGLK_RD16(mlo[0], a_lo, 0);          SGLK_RD16(mhi[0], a_hi, 0);
     SGLK_RD4(raw[0], ts0, 0);
     SGLK_RD16(nlo[1], b_lo, kNfImm[1]);  SGLK_RD16(nhi[1], b_hi, kNfImm[1]);
     SGLK_RD16(nlo[2], b_lo, kNfImm[2]);  SGLK_RD16(nhi[2], b_hi, kNfImm[2]);
     SGLK_RD16(nlo[3], b_lo, kNfImm[3]);  SGLK_RD16(nhi[3], b_hi, kNfImm[3]);
+    }
   }
   if (kDma) {
     dma_piece(cur_t, 1, 1, 0, 0);
@@ -900,6 +1063,7 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
 #undef SGLK_MFMA
 #undef SGLK_RD16
 #undef SGLK_RD4
+#undef SGLK_RDW
 #undef SGLK_FRAG
 }
 
@@ -1225,15 +1389,15 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   if (all_halves) {                                                                                          \
     gemm_8bit_persist_kernel<OutT, MODE, H, P, 4><<<hgrid, 512, 0, st>>>(                                 \
         (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
-        ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_gemm_stamps);                                     \
+        ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_gemm_stamps, nullptr, nullptr);                                     \
   } else {                                                                                                   \
     gemm_8bit_persist_kernel<OutT, MODE, H, P, 8><<<pgrid, 512, 0, st>>>(                                 \
         (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
-        ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps);                                     \
+        ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps, nullptr, nullptr);                                     \
     if (tail_halves)                                                                                         \
       gemm_8bit_persist_kernel<OutT, MODE, H, P, 4><<<pgrid, 512, 0, st>>>(                               \
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
-          ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps);                                   \
+          ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps, nullptr, nullptr);                                   \
   }
 #ifdef SGLK_PROBES
 #define SGLK_GO(V, H)                                                                                        \
@@ -1288,6 +1452,53 @@ static int check_common(const char* op, const void* a, const void* b, int64_t M,
 }
 
 }  // namespace
+
+// QServe W4A8 on the persistent pipeline (called from qserve_w4a8.hip above 128 rows). Returns 0 when the shape does not
+// qualify (the caller falls back to its own tile kernel), 1 after launching.
+int qserve_w4a8_persist(hipStream_t st, bool group, void* out, const void* a, const void* w, const void* zeros,
+                        const void* scales_i8, const void* wscales, const void* ascales, const void* w_szs,
+                        const void* a_ssums, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc) {
+  if (K % BK != 0 || K / BK < 2 || N % 32 != 0 || ldc % 4 != 0 || (uintptr_t)out % 8 != 0 || ldc >= (1ll << 22) ||
+      lda * 256 >= (1ll << 32) || (uintptr_t)wscales % 8 != 0 || (!group && (uintptr_t)w_szs % 8 != 0) ||
+      (K >> 7) * N >= (1ll << 31) || (group && ((uintptr_t)scales_i8 % 4 != 0 || (uintptr_t)zeros % 4 != 0)))
+    return 0;
+  const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
+  const unsigned grid = (unsigned)(tiles_m * tiles_n);
+  const unsigned pgrid = grid < (unsigned)num_cus() ? ((grid + 7) / 8) * 8 : (unsigned)num_cus();
+  bool tail_halves = false;
+  {
+    const int slots = (int)pgrid >> 3, q = (int)grid >> 3, r8 = (int)grid & 7;
+    for (int len = q; len <= q + (r8 ? 1 : 0); ++len) {
+      const int left = len - (len / slots) * slots;
+      tail_halves = tail_halves || (left > 0 && 2 * left <= slots);
+    }
+  }
+  const bool all_halves = M <= 512 || grid <= (unsigned)num_cus() / 2;
+  const unsigned hgrid = 2 * grid < (unsigned)num_cus() ? ((2 * grid + 7) / 8) * 8 : (unsigned)num_cus();
+  // kernel arguments: sa <- ascales, sb <- wscales, bias <- w_szs, x0 <- a_ssums (per channel) / scales_i8 (per group),
+  // x1 <- zeros (per group)
+#define SGLK_GO_W4(MODE, MS, G, AH)                                                                          \
+  gemm_8bit_persist_kernel<f16, MODE, true, 0, MS><<<G, 512, 0, st>>>(                                        \
+      (f16*)out, (const uint8_t*)a, (const uint8_t*)w, (const float*)ascales, (const float*)wscales,         \
+      (const f16*)w_szs, (int)M, (int)N, (int)K, lda, 0, ldc, 0, 0, 0, 0, tiles_m, tiles_n, AH, nullptr,      \
+      group ? scales_i8 : a_ssums, zeros)
+#define SGLK_GO_W4M(MODE)                                                                                    \
+  if (all_halves) {                                                                                          \
+    SGLK_GO_W4(MODE, 4, hgrid, 1);                                                                           \
+  } else {                                                                                                   \
+    SGLK_GO_W4(MODE, 8, pgrid, 0);                                                                           \
+    if (tail_halves) SGLK_GO_W4(MODE, 4, pgrid, 0);                                                          \
+  }
+  if (group) {
+    SGLK_GO_W4M(MODE_W4A8_GRP)
+  } else {
+    SGLK_GO_W4M(MODE_W4A8_CHN)
+  }
+#undef SGLK_GO_W4M
+#undef SGLK_GO_W4
+  return 1;
+}
+
 }  // namespace sglk
 
 // The K=128 fp8 MFMA is issued in its MX encoding with unit E8M0 scales (twice the rate of the plain encoding, the

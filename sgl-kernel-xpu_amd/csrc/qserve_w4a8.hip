@@ -23,6 +23,12 @@
 #include "common.h"
 
 namespace sglk {
+
+// gemm_8bit.hip: the persistent 256 x 256 tile pipeline with the packed weights staged in LDS (many rows)
+int qserve_w4a8_persist(hipStream_t st, bool group, void* out, const void* a, const void* w, const void* zeros,
+                        const void* scales_i8, const void* wscales, const void* ascales, const void* w_szs,
+                        const void* a_ssums, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldc);
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -126,13 +132,16 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void qserve_w4a8_ker
   }
 
   if constexpr (SPLIT > 1) {
-    extern __shared__ int red[];  // [SPLIT - 1][MF][2][64 lanes][4]
+    // (dword r of a lane at stride 64: every LDS access is 64 consecutive dwords - the 16-byte form had a bank-conflict ratio of
+    // 0.75 in the r02 profile)
+    extern __shared__ int red[];  // [SPLIT - 1][MF][2][4][64 lanes]
     if (wave > 0) {
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          *reinterpret_cast<v4i*>(red + ((((wave - 1) * MF + mf) * 2 + h) * 64 + lane) * 4) = acc[mf][h];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(((((wave - 1) * MF + mf) * 2 + h) * 4 + r) << 6) + lane] = acc[mf][h][r];
     }
     __syncthreads();
     if (wave > 0) return;
@@ -141,8 +150,8 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void qserve_w4a8_ker
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const v4i t = *reinterpret_cast<const v4i*>(red + (((w * MF + mf) * 2 + h) * 64 + lane) * 4);
-          acc[mf][h][0] += t[0]; acc[mf][h][1] += t[1]; acc[mf][h][2] += t[2]; acc[mf][h][3] += t[3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mf][h][r] += red[((((w * MF + mf) * 2 + h) * 4 + r) << 6) + lane];
         }
     }
   }
@@ -335,6 +344,13 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
   }
 }
 
+#ifdef SGLK_PROBES
+static int g_qserve_persist_rows = 128;
+#define kPersistRows g_qserve_persist_rows
+#else
+constexpr int kPersistRows = 128;  // above this many rows: the persistent pipeline of gemm_8bit.hip
+#endif
+
 template <bool GROUP>
 static int launch(hipStream_t st, void* out, const void* a, const void* w, const void* zeros, const void* scales_i8,
                   const void* wscales, const void* ascales, const void* w_szs, const void* a_ssums, int64_t M, int64_t N,
@@ -359,7 +375,9 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   if (M <= 16) SGLK_GO_SPLIT(1, 16)
   else if (M <= 32) SGLK_GO_SPLIT(2, 8)
   else if (M <= 64) SGLK_GO_SPLIT(4, 8)
-  else {
+  else if (M > kPersistRows && qserve_w4a8_persist(st, GROUP, out, a, w, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, M, N, K,
+                                                   lda, ldc)) {
+  } else {
     qserve_w4a8_tile_kernel<GROUP><<<dim3(gx, (unsigned)cdiv(M, 128)), 256, 0, st>>>(
         (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,
         (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc);
@@ -383,6 +401,10 @@ static int check(const char* op, const void* out, const void* a, const void* w, 
 
 }  // namespace
 }  // namespace sglk
+
+#ifdef SGLK_PROBES
+extern "C" SGLK_API void sglk_debug_set_qserve_persist_rows(int rows) { sglk::g_qserve_persist_rows = rows; }
+#endif
 
 extern "C" int sglk_qserve_w4a8_per_chn_gemm(sglk_stream_t stream, void* out, const void* in_feats, const void* kernel,
                                              const void* wscales, const void* ascales, const void* w_szs,

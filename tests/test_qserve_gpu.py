@@ -10,8 +10,8 @@ from oracle import qserve as oq
 
 pytestmark = pytest.mark.gpu
 
-MS = [1, 16, 32, 64, 65, 128, 300, 512, 1024]
-NKS = [(128, 512), (512, 1024), (1024, 4096), (4096, 512), (96, 192)]
+MS = [1, 16, 32, 64, 65, 128, 129, 300, 512, 1024, 2049]  # (> 128 rows: the persistent pipeline of gemm_8bit.hip)
+NKS = [(128, 512), (512, 1024), (1024, 4096), (4096, 512), (96, 192), (2080, 384), (7200, 128)]
 
 
 def make(M, N, K, seed):
