@@ -33,7 +33,7 @@ GROUP = 128
 FP8 = torch.float8_e4m3fn
 PEAK_FP8_TFLOPS = 5000.0  # MI355X_MICROARCH.md: dense FP8 MFMA peak (MX K=128 form), 2:1 sparsity excluded
 PEAK_HBM_GBS = 8000.0
-GEMM_KERNEL = ("gemm_8bit_persist_kernel<bf16, blockwise> (two launches: 256-row tiles, then 128-row half tiles of "
+GEMM_KERNEL = ("gemm_fp8bw_x32_kernel<bf16> (two launches: 256-row tiles, then 128-row half tiles of "
                "the last partial round)")
 PMC_FILE = os.path.join("profiles", "r03", "bench_pmc.json")
 CLOCK_RAMP_S = 0.15  # untimed steady-state run of the step before the W warm-up steps
@@ -58,7 +58,7 @@ def pmc_traffic_bytes():
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             pmc = json.load(f)
         # one GEMM = one launch of each instantiation of the persistent kernel (whole tiles, then half tiles)
-        ks = [v for name, v in pmc.items() if "persist_kernel" in name]
+        ks = [v for name, v in pmc.items() if "gemm_fp8bw_x32_kernel" in name or "persist_kernel" in name]
         return int(sum(2 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"] for k in ks) * 1024) if ks else None
     except Exception:
         return None

@@ -104,7 +104,7 @@ def check_isa(verbose=True):
     * mla_rows128_kernel / mla_rows128x_kernel keep O in the fixed registers a0..a255 named only in inline asm: the compiler must not
       touch the AGPR file itself in that kernel (no AGPR operand outside ;;#ASMSTART..;;#ASMEND), must not spill,
       and the kernel descriptor must allocate 256 AGPRs.
-    * gemm_8bit_persist_kernel counts its LDS waits by hand: a VGPR spill (scratch access = vector-memory
+    * gemm_8bit_persist_kernel / gemm_fp8bw_x32_kernel count their LDS waits by hand: a VGPR spill (scratch access = vector-memory
       traffic inside the counted vmcnt window) breaks the counts.
     * attn_prefill_kernel / attn_decode_kernel are sized for two 256-register waves per SIMD: a spill means the tile
       shape no longer fits.
@@ -154,7 +154,7 @@ def check_isa(verbose=True):
     else:
         text = open(path).read()
         n = 0
-        for name, body in _functions(text, r"gemm_8bit_persist_kernelI"):
+        for name, body in _functions(text, r"(gemm_8bit_persist_kernelI|gemm_fp8bw_x32_kernelI)"):
             n += 1
             for ln in body:
                 code = ln.split(";")[0]

@@ -35,6 +35,7 @@
 // form; int8: two v_mfma_i32_16x16x64_i8 per block) and the scales are applied once in the
 // epilogue:  fp8 : out = T(T(acc * sa[m] * sb[n]) + bias[n])   (bias added in T, after the cast)
 //            int8: out = T(float(acc) * sa[m] * sb[n] + bias[n]) (bias added in fp32)
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -1068,6 +1069,373 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// fp8_blockwise_scaled_mm on the 32 x 32 x 64 form of the MX MFMA: the same persistent pipeline (tile walk, LDS image of
+// a, LDS-DMA through buffer resources, one barrier per K block in front of its last m-step, the finished tile stored in
+// the first K block of the next one), other arithmetic schedule. Measured on the register-only streams of
+// tools/kbench: a v_mfma_scale_f32_16x16x128_f8f6f4 keeps the SIMD's vector issue for nearly all of its
+// 32 cycles, so its four promotion FMAs, the LDS reads and the DMA pieces ADD to the matrix time; the 64-cycle 32x32x64
+// form holds it for ~11, and the 16 FMAs of a 32 x 32 partial fit into the gap behind it.
+//  * wave tile 64 (n) x 32 MS (m) as 2 n-fragments x MS m-fragments of 32 rows; lane (i = lane % 32, h = lane / 32) supplies
+//    row i, 16-byte chunks 4 h + {0, 1} (first MFMA of a K block) and 4 h + {2, 3} (second) - the same for both operands,
+//    so the MFMAs pair equal k. Both LDS tiles use a's key (chunk c of row r at c ^ ((r >> 1) & 7)): conflict-free for
+//    ds_read_b128 over 32 rows of one chunk.
+//  * an m-step is A1 B1 A2 B2 (A, B = the two n-fragments; 1, 2 = the two K halves; A2 accumulates onto A1 in cur0, B2 onto
+//    B1 in cur1). cur0 is folded into the accumulators behind B2 (its A2 was issued a whole MFMA earlier), cur1 behind the
+//    next step's A1: no FMA sits behind the MFMA it depends on, and every gap carries at most 16 FMAs.
+//  * n-fragment row i of the MFMA is LDS row 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3) of its 32: a lane then owns 16
+//    consecutive output columns of one row (two 16-byte stores per 32 x 32 tile).
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <typename OutT, int MS, int PROBE>  // MS m-steps (32 rows) per K block: 4 = 256-row tiles, 2 = 128-row half tiles
+__global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
+    OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+    const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
+    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves,
+    uint32_t* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nkb = K / BK;  // >= 2
+  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1;
+  // (diagnostic build: stamps != nullptr) shader cycles and 100 MHz ticks of the whole workgroup -> the clock it ran at
+  const uint64_t st_c0 = stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  // (diagnostic build) 5: every DMA piece out of range (issue + LDS write of zeros, no fetch); 6: a / b pieces as plain
+  // loads into registers (fetch, no LDS write); results are garbage, no stores
+
+  // ---- this workgroup's units: the tile walk of gemm_8bit_persist_kernel
+  const int nt = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int q8 = nt >> 3, rem = nt & 7;
+  const int run_first = xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8;
+  const int run_len = q8 + (xcd < rem ? 1 : 0);
+  const int nblk_max = (N + 127) / 128 - 1;
+  const int rounds = run_len / slots, left = run_len - rounds * slots;
+  const bool split = left > 0 && 2 * left <= slots;
+  constexpr bool kHalf = MS == 2;
+  const int n_units = (kHalf && all_halves) ? (2 * run_len > slot ? (2 * run_len - slot + slots - 1) / slots : 0)
+                      : kHalf             ? ((split && slot < 2 * left) ? 1 : 0)
+                                          : (split ? rounds : rounds + (slot < left ? 1 : 0));
+  if (n_units == 0) return;
+
+  auto describe = [&](int unit) -> TileDesc {  // unit >= n_units: the null tile
+    TileDesc d;
+    bool live = unit < n_units;
+    const int ht = slot + unit * slots;
+    const int local = !live ? 0 : (kHalf && all_halves) ? (ht >> 1) : kHalf ? rounds * slots + (slot >> 1) : slot + unit * slots;
+    const int lower = all_halves ? (ht & 1) : (slot & 1);
+    const int tile = run_first + local;
+    constexpr int GM = 4;
+    const int group = tile / (GM * tiles_n);
+    const int first_m = group * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_group = tile - group * GM * tiles_n;
+    const int tm = __builtin_amdgcn_readfirstlane(first_m + in_group % gsz);
+    const int tn = __builtin_amdgcn_readfirstlane(in_group / gsz);
+    const int trows = kHalf ? BM / 2 : BM;
+    const int m0 = tm * BM + ((kHalf && lower) ? BM / 2 : 0), n0 = tn * BN;
+    const int rows_a = (M - m0) < trows ? (M - m0) : trows, rows_b = (N - n0) < BN ? (N - n0) : BN;
+    live = live && rows_a > 0;
+    d.ncols = rows_b;
+    d.wrows = MS * 32;
+    d.m0 = m0;
+    d.n0 = n0;
+    d.pa = a + (int64_t)m0 * lda;
+    d.pb = b + (int64_t)n0 * ldb;
+    d.ps = sa + (int64_t)m0 * sa_sm;
+    d.po = (void*)(out + (int64_t)m0 * ldc + n0);
+    d.nrec_a = (live && PROBE != 5) ? (uint32_t)((int64_t)(rows_a - 1) * lda + K) : 0u;
+    d.nrec_b = (live && PROBE != 5) ? (uint32_t)((int64_t)(rows_b - 1) * ldb + K) : 0u;
+    d.nrec_s = (live && wave < 4) ? (uint32_t)(((int64_t)(rows_a - 1) * sa_sm + (int64_t)(nkb - 1) * sa_sk + 1) * 4) : 0u;
+    d.nrec_o = (live && kStore) ? (uint32_t)(((int64_t)(rows_a - 1) * ldc + rows_b) * (int64_t)sizeof(OutT)) : 0u;
+    int nblk = (n0 + wn * 64) >> 7;
+    nblk = nblk < nblk_max ? nblk : nblk_max;
+    d.sbw = sb + (int64_t)nblk * sb_sn;
+    return d;
+  };
+  auto pick = [](bool c, const TileDesc& x, const TileDesc& y) -> TileDesc {  // scalar selects
+    TileDesc d;
+    d.pa = c ? x.pa : y.pa;  d.pb = c ? x.pb : y.pb;  d.ps = c ? x.ps : y.ps;  d.sbw = c ? x.sbw : y.sbw;
+    d.po = c ? x.po : y.po;
+    d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_s = c ? x.nrec_s : y.nrec_s;
+    d.nrec_o = c ? x.nrec_o : y.nrec_o;  d.ncols = c ? x.ncols : y.ncols;  d.wrows = c ? x.wrows : y.wrows;
+    d.m0 = c ? x.m0 : y.m0;  d.n0 = c ? x.n0 : y.n0;
+    return d;
+  };
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
+  // DMA piece p of a tile = rows 8p..8p+7; lane -> row 8p + lane/8, chunk (lane%8) ^ key(row), key = (row>>1)&7 =
+  // (4 (p&1) + lane/16) & 7 for both tiles
+  uint32_t voff_a[2], voff_b[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const uint32_t ch = (uint32_t)(((lane & 7) ^ ((par * 4 + (lane >> 4)) & 7)) << 4);
+    voff_a[par] = (uint32_t)(lane >> 3) * (uint32_t)lda + ch;
+    voff_b[par] = (uint32_t)(lane >> 3) * (uint32_t)ldb + ch;
+  }
+  const uint32_t voff_s = (uint32_t)tid * (uint32_t)sa_sm * 4u;
+  // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = rows of b^T (sub 0, 1 each); (part 0, sub 2) = row scales
+  auto dma_piece = [&](const TileDesc& d, int kb_, int s, int part, int sub) {
+    const int kb = PROBE == 4 ? 0 : kb_;
+    char* base = smem + s * kStageBytes;
+    if (sub == 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s), SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4,
+                                               voff_s, kb * (int)sa_sk * 4, 0, 0);
+      return;
+    }
+    const int ii = (part & 1) * 2 + sub, piece = wave * 4 + ii;
+    if constexpr (PROBE == 6) {
+      const v4i t = __builtin_amdgcn_raw_buffer_load_b128(part < 2 ? make_rsrc(d.pa, d.nrec_a) : make_rsrc(d.pb, d.nrec_b),
+                                                          part < 2 ? voff_a[ii & 1] : voff_b[ii & 1],
+                                                          kb * BK + piece * 8 * (int)(part < 2 ? lda : ldb), 0);
+      asm volatile("" ::"v"(t));
+      return;
+    }
+    if (part < 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pa, d.nrec_a), SGLK_LDS(base + piece * 1024), 16,
+                                               voff_a[ii & 1], kb * BK + piece * 8 * (int)lda, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b), SGLK_LDS(base + kTileBytes + piece * 1024), 16,
+                                               voff_b[ii & 1], kb * BK + piece * 8 * (int)ldb, 0, 0);
+    }
+  };
+
+  // fragment addressing (byte offsets inside a stage)
+  const int li = lane & 31, lh = lane >> 5;
+  const int brow = ((li >> 2) & 1) * 16 + (li >> 3) * 4 + (li & 3);  // LDS row of MFMA row li inside a 32-row n-fragment
+  const int frag_off_a = li * 128 + (((4 * lh) ^ ((li >> 1) & 7)) << 4);        // chunk 4h; chunks 4h + q at ^ (q << 4)
+  const int frag_off_b = brow * 128 + (((4 * lh) ^ ((brow >> 1) & 7)) << 4);
+
+  // stores: lane (i, h) owns row wm * 32 MS + 32 mf + i, columns wn * 64 + 32 nf + 16 h .. + 15
+  const uint32_t orow_off = (uint32_t)(((int64_t)(wm * (MS * 32) + li) * ldc + wn * 64 + lh * 16) * (int64_t)sizeof(OutT));
+  auto store_frag = [&](const TileDesc& d, const float (&accm)[2][16], int mf) {
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
+    const int soff = __builtin_amdgcn_readfirstlane(mf * 32 * (int)ldc * (int)sizeof(OutT));
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int hv = 0; hv < 2; ++hv) {
+        Vec<OutT, 8> v;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (OutT)accm[nf][hv * 8 + c];
+        const uint32_t vo = (wn * 64 + nf * 32 + lh * 16 + hv * 8 < d.ncols)
+                                ? orow_off + (uint32_t)((nf * 32 + hv * 8) * (int)sizeof(OutT)) : 0x80000000u;
+        const v4i data = __builtin_bit_cast(v4i, v);
+        __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, 0);
+        asm volatile("s_nop 4" ::"v"(data));  // (store data is read for a few cycles after issue: see the kernel above)
+      }
+  };
+
+  float acc[MS][2][16];
+#pragma unroll
+  for (int mf = 0; mf < MS; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+#define X32_RD16(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+#define X32_RD4(dst, addr, imm) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+#define X32_FRAG(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
+// first / second MFMA of a 32 x 32 partial (K halves s = 0, 1)
+#define X32_MFMA1(cur, nf)                                                                                     \
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"                      \
+               : "=&v"(cur)                                                                                    \
+               : "v"(X32_FRAG(nq[nf][0][0], nq[nf][0][1])), "v"(X32_FRAG(mq[0][0], mq[0][1])), "v"(one_e8m0));
+#define X32_MFMA2(cur, nf)                                                                                     \
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"                     \
+               : "+v"(cur)                                                                                     \
+               : "v"(X32_FRAG(nq[nf][1][0], nq[nf][1][1])), "v"(X32_FRAG(mq[1][0], mq[1][1])), "v"(one_e8m0));
+// acc[row][nf][:] += cur[:] * sc
+#define X32_PROMOTE(row, nf, cur)                                                                              \
+  _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                                            \
+      asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[row][nf][r_]) : "v"(cur[r_]), "v"(sc));
+
+  v4i nq[2][2][2];  // [n-fragment][K half][chunk]
+  v4i mq[2][2];     // [K half][chunk] of the running m-fragment (each half is re-read right behind its last MFMA)
+  float raw, sbv;
+  v16f cur0, cur1;
+  float sc = 0.f;   // row scale x column-block scale of the partial that is folded next
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cur1[r] = 0.f;  // (the first step folds nothing)
+  int one_e8m0 = 127;
+  asm volatile("" : "+v"(one_e8m0), "+v"(sc), "+v"(cur1));
+  int gblk = 0;
+
+  // m-step mf of a K block. LAST: behind the block's barrier; its gaps carry the reads of the next block's fragments.
+  // LDS reads in issue order - a step: m half 0 (2), m half 1 (2), row scale; the last step: n0 half 0 (2), n1 half 0 (2),
+  // m half 0 (2), n0 half 1 (2), n1 half 1 (2), m half 1 (2), row scale.
+#define X32_STEP(mf, STORE, LAST)                                                                              \
+  {                                                                                                            \
+    constexpr int prow_ = ((mf) + MS - 1) % MS;                                                                \
+    if ((mf) == 0) {                                                                                           \
+      asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(nq[0][0][0]), "+v"(nq[0][0][1]), "+v"(nq[1][0][0]), "+v"(nq[1][0][1]), \
+                                            "+v"(mq[0][0]), "+v"(mq[0][1]));                                   \
+    } else if (!(LAST)) {                                                                                      \
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(mq[0][0]), "+v"(mq[0][1]));                                   \
+    }                                                                                                          \
+    X32_MFMA1(cur0, 0)                                                                                         \
+    if (LAST) { X32_RD16(nq[0][0][0], nb0, 0); X32_RD16(nq[0][0][1], nb1, 0); }                                \
+    asm volatile("s_nop 2" : "+v"(cur1)); /* (B2 of the step before is >= 18 passes old when the first FMA issues) */ \
+    X32_PROMOTE(prow_, 1, cur1)                                                                                \
+    X32_MFMA1(cur1, 1)                                                                                         \
+    if (LAST) {                                                                                                \
+      X32_RD16(nq[1][0][0], nb0, 4096);  X32_RD16(nq[1][0][1], nb1, 4096);                                     \
+      X32_RD16(mq[0][0], na0, 0);        X32_RD16(mq[0][1], na1, 0);                                           \
+      if (kDma) dma_piece(d2, kb2, s, 0, 0);                                                                   \
+      if (kDma && MS == 2) dma_piece(d2, kb2, s, 1, 0);                                                        \
+    } else {                                                                                                   \
+      X32_RD16(mq[0][0], a0, ((mf) + 1) * 4096);  X32_RD16(mq[0][1], a1, ((mf) + 1) * 4096);                   \
+      if (kDma && MS == 4 && (mf) == 0) dma_piece(d1, kb1, s ^ 1, 1, 0);                                       \
+      if (kDma && MS == 4 && (mf) == 1) dma_piece(d1, kb1, s ^ 1, 2, 1);                                       \
+      if (kDma && MS == 2) dma_piece(d1, kb1, s ^ 1, 2, 0);                                                    \
+    }                                                                                                          \
+    if constexpr (STORE) {                                                                                     \
+      store_frag(prv, acc[mf], (mf));                                                                          \
+      _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f; \
+      asm volatile("" : "+v"(acc[mf][0][0]), "+v"(acc[mf][1][0]));                                             \
+    }                                                                                                          \
+    if (!(LAST)) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(mq[1][0]), "+v"(mq[1][1]), "+v"(raw));             \
+    X32_MFMA2(cur0, 0)                                                                                         \
+    const float scn_ = raw * sbv;                                                                              \
+    if (LAST) {                                                                                                \
+      X32_RD16(nq[0][1][0], nb2, 0);  X32_RD16(nq[0][1][1], nb3, 0);                                           \
+      if (kDma) dma_piece(d2, kb2, s, 0, 1);                                                                   \
+      if (kDma && MS == 2) dma_piece(d2, kb2, s, 1, 1);                                                        \
+    } else {                                                                                                   \
+      /* (the block's last pieces go out two m-steps before its barrier: issued in the step in front of it they were */ \
+      /* still in flight at the vmcnt(0) there: +54 us at the headline shape)                                        */ \
+      if (kDma && MS == 4 && (mf) == 0) { dma_piece(d1, kb1, s ^ 1, 1, 1); dma_piece(d1, kb1, s ^ 1, 2, 0); }  \
+      if (kDma && MS == 4 && (mf) == 1) { dma_piece(d1, kb1, s ^ 1, 3, 0); dma_piece(d1, kb1, s ^ 1, 3, 1); }  \
+      if (kDma && MS == 2) { dma_piece(d1, kb1, s ^ 1, 2, 1); dma_piece(d1, kb1, s ^ 1, 3, 0); }               \
+    }                                                                                                          \
+    X32_MFMA2(cur1, 1)                                                                                         \
+    if (LAST) {                                                                                                \
+      X32_RD16(nq[1][1][0], nb2, 4096);  X32_RD16(nq[1][1][1], nb3, 4096);                                     \
+      X32_RD16(mq[1][0], na2, 0);        X32_RD16(mq[1][1], na3, 0);                                           \
+      X32_RD4(raw, nts, 0);                                                                                    \
+      if (kDma) dma_piece(d2, kb2, s, 0, 2);                                                                   \
+    } else {                                                                                                   \
+      X32_RD16(mq[1][0], a2, ((mf) + 1) * 4096);  X32_RD16(mq[1][1], a3, ((mf) + 1) * 4096);                   \
+      X32_RD4(raw, ts_addr, ((mf) + 1) * 128);                                                                 \
+      if (kDma && MS == 2) dma_piece(d1, kb1, s ^ 1, 3, 1);                                                    \
+    }                                                                                                          \
+    sc = scn_;                                                                                                 \
+    asm volatile("" : "+v"(sc), "+v"(cur0));                                                                   \
+    X32_PROMOTE((mf), 0, cur0)                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+#define X32_BLOCK(STORE)                                                                                       \
+  {                                                                                                            \
+    const int s = gblk & 1;                                                                                    \
+    const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);                                             \
+    const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStageBytes);                                       \
+    const bool in1 = kb + 1 < nkb, in2 = kb + 2 < nkb;                                                         \
+    const TileDesc d1 = pick(in1, cur_t, nxt), d2 = pick(in2, cur_t, nxt);                                     \
+    const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
+    uint32_t a0, a1, a2, a3, ts_addr, nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0, na0 = 0, na1 = 0, na2 = 0, na3 = 0, nts = 0; \
+    {                                                                                                          \
+      int fo = frag_off_a;                                                                                     \
+      asm volatile("" : "+v"(fo));                                                                             \
+      a0 = sbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)fo;                                            \
+      a1 = a0 ^ 16u;  a2 = a0 ^ 32u;  a3 = a0 ^ 48u;                                                           \
+      ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * (MS * 32) * 4) + (uint32_t)((fo >> 7) << 2);          \
+    }                                                                                                          \
+    if constexpr (MS == 4) { X32_STEP(0, STORE, false) X32_STEP(1, STORE, false) X32_STEP(2, STORE, false) }   \
+    else { X32_STEP(0, STORE, false) }                                                                         \
+    float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                  \
+                 : "+v"(mq[0][0]), "+v"(mq[0][1]), "+v"(mq[1][0]), "+v"(mq[1][1]), "+v"(raw)                    \
+                 :                                                                                             \
+                 : "memory");                                                                                  \
+    asm volatile("" : "+v"(sbv_next));                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    {                                                                                                          \
+      int foa = frag_off_a, fob = frag_off_b;                                                                  \
+      asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
+      nb0 = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fob;                                    \
+      nb1 = nb0 ^ 16u;  nb2 = nb0 ^ 32u;  nb3 = nb0 ^ 48u;                                                     \
+      na0 = nbase + (uint32_t)(wm * d1.wrows * 128) + (uint32_t)foa;                                           \
+      na1 = na0 ^ 16u;  na2 = na0 ^ 32u;  na3 = na0 ^ 48u;                                                     \
+      nts = nbase + 2 * kTileBytes + (uint32_t)(wm * d1.wrows * 4) + (uint32_t)((foa >> 7) << 2);              \
+      asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(nb3), "+v"(na0), "+v"(na1), "+v"(na2), "+v"(na3), "+v"(nts)); \
+    }                                                                                                          \
+    X32_STEP(MS - 1, STORE, true)                                                                              \
+    sbv = sbv_next;                                                                                            \
+    ++gblk;                                                                                                    \
+  }
+
+  int unit = 0;
+  TileDesc cur_t = describe(0);
+  TileDesc prv = describe(n_units);  // the null tile: nothing to store yet
+  // ---- prologue: block 0 of the first unit lands, its fragments are read (in the last step's order), part 0 of block 1 goes out
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    dma_piece(cur_t, 0, 0, part, 0);
+    dma_piece(cur_t, 0, 0, part, 1);
+  }
+  dma_piece(cur_t, 0, 0, 0, 2);
+  sbv = cur_t.sbw[0];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("" : "+v"(sbv));
+  {
+    const uint32_t b0 = lds_base + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)frag_off_b;
+    const uint32_t p0 = lds_base + (uint32_t)(wm * cur_t.wrows * 128) + (uint32_t)frag_off_a;
+    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * cur_t.wrows * 4) + (uint32_t)(li << 2);
+    const uint32_t b1 = b0 ^ 16u, b2 = b0 ^ 32u, b3 = b0 ^ 48u, p1 = p0 ^ 16u, p2 = p0 ^ 32u, p3 = p0 ^ 48u;
+    X32_RD16(nq[0][0][0], b0, 0);     X32_RD16(nq[0][0][1], b1, 0);
+    X32_RD16(nq[1][0][0], b0, 4096);  X32_RD16(nq[1][0][1], b1, 4096);
+    X32_RD16(mq[0][0], p0, 0);        X32_RD16(mq[0][1], p1, 0);
+    X32_RD16(nq[0][1][0], b2, 0);     X32_RD16(nq[0][1][1], b3, 0);
+    X32_RD16(nq[1][1][0], b2, 4096);  X32_RD16(nq[1][1][1], b3, 4096);
+    X32_RD16(mq[1][0], p2, 0);        X32_RD16(mq[1][1], p3, 0);
+    X32_RD4(raw, ts0, 0);
+  }
+  if (kDma) {
+    dma_piece(cur_t, 1, 1, 0, 0);
+    dma_piece(cur_t, 1, 1, 0, 1);
+    dma_piece(cur_t, 1, 1, 0, 2);
+    if (MS == 2) {
+      dma_piece(cur_t, 1, 1, 1, 0);
+      dma_piece(cur_t, 1, 1, 1, 1);
+    }
+  }
+
+  for (; unit < n_units; ++unit) {
+    const TileDesc nxt = describe(unit + 1);
+    {
+      const int kb = 0;
+      X32_BLOCK(true)
+    }
+    for (int kb = 1; kb < nkb; ++kb) X32_BLOCK(false)
+    prv = cur_t;
+    cur_t = nxt;
+  }
+#undef X32_BLOCK
+#undef X32_STEP
+  // drain the reads and DMA of the last step; fold the last partial; store the last unit
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(cur1));  // (MFMA -> VALU)
+  X32_PROMOTE(MS - 1, 1, cur1)
+#pragma unroll
+  for (int mf = 0; mf < MS; ++mf) store_frag(prv, acc[mf], mf);
+  if (stamps != nullptr && tid == 0) {
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    stamps[(blockIdx.x + (MS == 2 ? 256 : 0)) * 4 + 0] = (uint32_t)(c1 - st_c0);
+    stamps[(blockIdx.x + (MS == 2 ? 256 : 0)) * 4 + 1] = (uint32_t)(r1 - st_r0);
+    stamps[(blockIdx.x + (MS == 2 ? 256 : 0)) * 4 + 2] = (uint32_t)(n_units * nkb);
+    stamps[(blockIdx.x + (MS == 2 ? 256 : 0)) * 4 + 3] = MS;
+  }
+#undef X32_PROMOTE
+#undef X32_MFMA1
+#undef X32_MFMA2
+#undef X32_RD16
+#undef X32_RD4
+#undef X32_FRAG
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Kernel for few rows (decode: M <= 128; above that the tile kernel wins). The 256 x 256 tile kernel above would put 56
 // workgroups on 256 CUs and stream the 58.7 MB of Llama-3-8B FFN weights at ~1 TB/s. Here the work is a weight stream:
 // one wave per 16 weight rows (n), weights never touch LDS. Per 128-deep K block a lane loads its 32 bytes of b^T (row
@@ -1381,6 +1749,14 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   const bool all_halves = (M <= 512 || grid <= (unsigned)num_cus() / 2) && g_gemm_variant == 4;
   const unsigned hgrid = 2 * grid < (unsigned)num_cus() ? ((2 * grid + 7) / 8) * 8 : (unsigned)num_cus();
   const int variant = (!persist_ok && g_gemm_variant != 0 && g_gemm_variant != 1) ? 1 : g_gemm_variant;
+  // SGLK_FP8_BLOCKWISE_SCHEDULE=16 (environment, read once): the 16x16x128 schedule of gemm_8bit_persist_kernel instead of
+  // the 32x32x64 one (results differ only in the fp32 summation order inside a 128-deep block); kept for A/B timing on a
+  // given device
+  static const bool sched16 = [] {
+    const char* e = getenv("SGLK_FP8_BLOCKWISE_SCHEDULE");
+    return e != nullptr && atoi(e) == 16;
+  }();
+  (void)sched16;
 #define SGLK_GO_VAR(V, H, VAR)                                                                               \
   gemm_8bit_kernel<OutT, MODE, V, H, VAR><<<grid, 512, 0, st>>>(                                             \
       (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K,   \
@@ -1399,10 +1775,31 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
           ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps, nullptr, nullptr);                                   \
   }
+// (blockwise: the 32 x 32 x 64 schedule; the 16 x 16 x 128 one stays for the row / column scale modes and as probe 22)
+#define SGLK_GO_X32(P)                                                                                       \
+  if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
+    if (all_halves) {                                                                                        \
+      gemm_fp8bw_x32_kernel<OutT, 2, P><<<hgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
+          (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_gemm_stamps); \
+    } else {                                                                                                 \
+      gemm_fp8bw_x32_kernel<OutT, 4, P><<<pgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
+          (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps); \
+      if (tail_halves)                                                                                       \
+        gemm_fp8bw_x32_kernel<OutT, 2, P><<<pgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
+            (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps); \
+    }                                                                                                        \
+  }
 #ifdef SGLK_PROBES
 #define SGLK_GO(V, H)                                                                                        \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
     switch (variant) {                                                                                       \
+      case 22: SGLK_GO_PIPE(V, H, 0); break;                                                                 \
+      case 23: SGLK_GO_X32(1); break;                                                                        \
+      case 24: SGLK_GO_X32(2); break;                                                                        \
+      case 25: SGLK_GO_X32(3); break;                                                                        \
+      case 26: SGLK_GO_X32(4); break;                                                                        \
+      case 27: SGLK_GO_X32(5); break;                                                                        \
+      case 28: SGLK_GO_X32(6); break;                                                                        \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
@@ -1414,7 +1811,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 18: SGLK_GO_PIPE(V, H, 5); break;                                                                 \
       case 20: SGLK_GO_PIPE(V, H, 6); break;                                                                 \
       case 21: SGLK_GO_PIPE(V, H, 7); break;                                                                 \
-      default: SGLK_GO_PIPE(V, H, 0); break;                                                                 \
+      default: SGLK_GO_X32(0); break;                                                                        \
     }                                                                                                        \
   } else {                                                                                                   \
     if (variant == 0 || variant == 1) { SGLK_GO_VAR(V, H, 0); } else { SGLK_GO_PIPE(V, H, 0) }               \
@@ -1422,7 +1819,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
 #else
 #define SGLK_GO(V, H)                                                                                        \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
-    if (variant == 1) { SGLK_GO_VAR(V, H, 1); } else { SGLK_GO_PIPE(V, H, 0) }                               \
+    if (variant == 1) { SGLK_GO_VAR(V, H, 1); } else if (sched16) { SGLK_GO_PIPE(V, H, 0) } else { SGLK_GO_X32(0) } \
   } else {                                                                                                   \
     if (variant == 1) { SGLK_GO_VAR(V, H, 0); } else { SGLK_GO_PIPE(V, H, 0) }                               \
   }
@@ -1435,6 +1832,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
 #undef SGLK_GO
 #undef SGLK_GO_VAR
 #undef SGLK_GO_PIPE
+#undef SGLK_GO_X32
   return check_launch("gemm_8bit");
 }
 

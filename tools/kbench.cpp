@@ -414,6 +414,30 @@ int main(int argc, char** argv) {
       const double ms = time_ms(run, 300, 100, &all);  // long warm-up: clocks ramp for tens of ms
       printf("gemm M=%lld N=%lld K=%lld variant=%d median %.4f ms  min %.4f  -> %.1f TFLOP/s (%.1f at min)\n", (long long)M,
              (long long)N, (long long)K, var, ms, all[0], 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / all[0] / 1e9);
+      if (getenv("GEMM_CLOCK")) {  // the 32x32x64 kernel's own stamps: the clock each workgroup ran at, cycles per K block
+        uint32_t* st;
+        HIP_CHECK(hipMalloc(&st, 512 * 16));
+        HIP_CHECK(hipMemset(st, 0, 512 * 16));
+        sglk_debug_set_gemm_stamps(st);
+        for (int r = 0; r < 20; ++r) run();
+        HIP_CHECK(hipDeviceSynchronize());
+        sglk_debug_set_gemm_stamps(nullptr);
+        std::vector<uint32_t> h(512 * 4);
+        HIP_CHECK(hipMemcpy(h.data(), st, h.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<double> mhz, cpb;
+        for (int w = 0; w < 512; ++w)
+          if (h[w * 4 + 1] && h[w * 4 + 3] == 4) {
+            mhz.push_back(100.0 * h[w * 4] / h[w * 4 + 1]);
+            cpb.push_back((double)h[w * 4] / h[w * 4 + 2]);
+          }
+        if (!mhz.empty()) {
+          std::sort(mhz.begin(), mhz.end());
+          std::sort(cpb.begin(), cpb.end());
+          printf("  in-kernel (256-row launch, %zu workgroups): clock median %.0f MHz (min %.0f max %.0f); shader cycles per K block median %.0f"
+                 " (MFMA time 2048)\n", mhz.size(), mhz[mhz.size() / 2], mhz.front(), mhz.back(), cpb[cpb.size() / 2]);
+        }
+        HIP_CHECK(hipFree(st));
+      }
       if (ai >= argc) break;
     }
     return 0;
