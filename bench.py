@@ -64,6 +64,35 @@ def pmc_traffic_bytes():
         return None
 
 
+def gemm_clock(gemm, dev):
+    """Median shader clock (MHz) and shader cycles per K block of the 256-row launch of the GEMM, from the stamps its
+    workgroups write when sglk_diag_set_gemm_clock_stamps (include/sglk.h) is armed. None if the entry is missing."""
+    import ctypes
+
+    try:
+        lib = ctypes.CDLL(os.path.join(ROOT, "sgl-kernel-xpu_amd", "python", "sgl_kernel", "libsglk.so"))
+        arm = lib.sglk_diag_set_gemm_clock_stamps
+    except (OSError, AttributeError):
+        return None
+    arm.argtypes = [ctypes.c_void_p]
+    arm.restype = None
+    buf = torch.zeros(512 * 4, dtype=torch.int32, device=dev)
+    arm(buf.data_ptr())
+    try:
+        for _ in range(20):
+            gemm()
+        torch.cuda.synchronize()
+    finally:
+        arm(None)
+    st = buf.cpu().view(512, 4)[:256].to(torch.float64)
+    st = st[(st[:, 1] > 0) & (st[:, 3] == 4)]
+    if st.numel() == 0:
+        return None
+    mhz = (100.0 * st[:, 0] / st[:, 1]).median().item()
+    cpb = (st[:, 0] / st[:, 2]).median().item()
+    return {"mhz": round(mhz), "cycles_per_k_block": round(cpb)}
+
+
 def cpu_baseline(seconds_budget=20.0):
     """CPU oracle on a bounded row sample of the same workload (same N, K; fewer rows)."""
     from oracle import gemm as ogemm
@@ -558,6 +587,8 @@ def main(argv=None):
     gemm_ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
     gemm_avg_ms = sum(gemm_ms) / len(gemm_ms)
 
+    clock = gemm_clock(gemm, dev)
+
     flop = 2.0 * M * N * K
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * flop / (ms_per_step * 1e-3) / 1e12
@@ -592,6 +623,13 @@ def main(argv=None):
             "traffic": pmc_traffic_bytes(),
             "kernel_ms_avg": round(gemm_avg_ms, 4),
             "kernel_ms_median": round(gemm_ms[len(gemm_ms) // 2], 4),
+            # the kernel's own s_memtime / s_memrealtime stamps (untimed launches right after the timed region): the
+            # shader clock the part sustains under this kernel, and the matrix-pipe share of a K block in shader cycles
+            # (2 waves x 16 MFMAs x 64 cycles per SIMD and K block)
+            "sustained_clock_mhz": clock and clock["mhz"],
+            "cycles_per_k_block": clock and clock["cycles_per_k_block"],
+            "mfma_busy_by_cycles": clock and round(2048.0 / clock["cycles_per_k_block"], 4),
+            "frac_at_sustained_clock": clock and round(achieved / (PEAK_FP8_TFLOPS * clock["mhz"] / 2400.0), 4),
         },
     }
     if rank == 0:

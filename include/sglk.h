@@ -127,6 +127,11 @@ SGLK_API int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const
                                           int64_t ldb, int64_t ldc, int64_t sa_stride_m,
                                           int64_t sa_stride_k, int64_t sb_stride_k,
                                           int64_t sb_stride_n, int out_dtype);
+/* Diagnostic (no reference counterpart): while device_buf is not NULL, every workgroup of the large-M kernel of
+ * fp8_blockwise_scaled_mm writes four uint32 at device_buf[4 * (workgroup + 256 * (launch of 128-row half tiles))]:
+ * {shader cycles, 100 MHz ticks, K blocks processed, m-steps per block} - shader clock = 100 MHz * cycles / ticks.
+ * 512 x 4 uint32; process-wide, not thread-safe; bench.py reports the clock the part sustains under the kernel with it. */
+SGLK_API void sglk_diag_set_gemm_clock_stamps(uint32_t* device_buf);
 
 /* ---- per-token / per-channel scaled GEMM ------------------------------------
  * fp8_scaled_mm / int8_scaled_mm: declared in reference

@@ -55,6 +55,7 @@ FILE_FLAGS = {
     "attn_fwd.hip": ["-fno-slp-vectorize"],
     "moe_w4a16.hip": ["-fno-slp-vectorize"],
     "moe_bf16.hip": ["-fno-slp-vectorize"],
+    "moe_persist.hip": ["-fno-slp-vectorize"],
     "mla_decode.hip": ["-fno-slp-vectorize"],
 }
 
@@ -75,7 +76,7 @@ def run(cmd):
 
 
 # sources whose device assembly is kept next to the object (-save-temps=obj) for check_isa
-ISA_CHECKED = ("mla_decode.hip", "gemm_8bit.hip", "attn_fwd.hip", "moe_w4a16.hip", "moe_bf16.hip")
+ISA_CHECKED = ("mla_decode.hip", "gemm_8bit.hip", "attn_fwd.hip", "moe_w4a16.hip", "moe_bf16.hip", "moe_persist.hip")
 
 
 def _asm_path(src_name, obj_dir=None):
@@ -171,7 +172,7 @@ def check_isa(verbose=True):
                           ("moe_w4a16.hip", r"moe_w4a16_kernelIDF16.Li\dELi\dELi1ELi\dE"),
                           ("moe_w4a16.hip", r"moe_w4a16_kernelIDF16.Li\dELi\dELi4ELi1E"),
                           ("moe_w4a16.hip", r"moe_w4a16_ksplit_kernelI"),
-                          ("moe_bf16.hip", r"moe_bf16_kernelI")):
+                          ("moe_bf16.hip", r"moe_bf16_kernelI"), ("moe_persist.hip", r"moe_persist_kernelI")):
         path = _asm_path(src_name)
         if not os.path.exists(path):
             problems.append("%s missing" % path)

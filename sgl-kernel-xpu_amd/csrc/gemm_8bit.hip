@@ -1685,6 +1685,8 @@ static uint32_t* g_gemm_stamps = nullptr;
 constexpr int g_gemm_variant = 4;
 constexpr uint32_t* g_gemm_stamps = nullptr;
 #endif
+// sglk_diag_set_gemm_clock_stamps: where the workgroups of gemm_fp8bw_x32_kernel leave their clock stamps (nullptr: nowhere)
+static uint32_t* g_clock_stamps = nullptr;
 
 template <typename OutT, int MODE>
 static int launch(hipStream_t st, void* out, const void* a, const void* b, const float* sa, const float* sb,
@@ -1780,13 +1782,13 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
     if (all_halves) {                                                                                        \
       gemm_fp8bw_x32_kernel<OutT, 2, P><<<hgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
-          (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_gemm_stamps); \
+          (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_clock_stamps); \
     } else {                                                                                                 \
       gemm_fp8bw_x32_kernel<OutT, 4, P><<<pgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
-          (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps); \
+          (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_clock_stamps); \
       if (tail_halves)                                                                                       \
         gemm_fp8bw_x32_kernel<OutT, 2, P><<<pgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
-            (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps); \
+            (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_clock_stamps); \
     }                                                                                                        \
   }
 #ifdef SGLK_PROBES
@@ -1905,10 +1907,12 @@ int qserve_w4a8_persist(hipStream_t st, bool group, void* out, const void* a, co
 static int g_fp8_hw_scale = 1;
 extern "C" SGLK_API void sglk_debug_set_fp8_mfma_form(int hw_scale) { g_fp8_hw_scale = hw_scale; }
 extern "C" SGLK_API void sglk_debug_set_gemm_variant(int v) { sglk::g_gemm_variant = v; }
-extern "C" SGLK_API void sglk_debug_set_gemm_stamps(uint32_t* p) { sglk::g_gemm_stamps = p; }
+extern "C" SGLK_API void sglk_debug_set_gemm_stamps(uint32_t* p) { sglk::g_gemm_stamps = p; sglk::g_clock_stamps = p; }
 #else
 constexpr int g_fp8_hw_scale = 1;
 #endif
+
+extern "C" void sglk_diag_set_gemm_clock_stamps(uint32_t* device_buf) { sglk::g_clock_stamps = device_buf; }
 
 extern "C" int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const void* a, const void* b,
                                             const float* sa, const float* sb, int64_t M, int64_t N,

@@ -16,11 +16,19 @@
 // bytes k = 32 j + 8 g .. + 7 of its row per 32-deep MFMA step: 64 contiguous bytes per row and instruction, 256 per
 // 128-deep block), two blocks ahead in a static register ring; the activation tile [BM x 128] goes through LDS once
 // per block for all 4 waves (loaded one block ahead, written to LDS the iteration after; LDS-only barrier).
+#include <algorithm>
+
 #include "common.h"
 #include "moe_tiles.h"
 
 namespace sglk {
+// moe_persist.hip: the dense tile pipeline for prefill row counts (returns 1 after launching, 0 if the shape does not qualify)
+int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const float* bias,
+                    const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, bool w4,
+                    int fuse, float act_limit);
 namespace {
+
+static thread_local int t_tail_flag = 0;  // kMoeTailFlag while the launch covers only the rows moe_persist.hip left over
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -221,7 +229,7 @@ static int launch(hipStream_t st, void* out, const void* act, const void* w, con
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20: problem too large for one launch");
   dim3 grid((unsigned)wgs);
 #define SGLK_GO(F) \
-  moe_bf16_kernel<T, MT, NW, F, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E, N, K, ldb, w_stride_e)
+  moe_bf16_kernel<T, MT, NW, F, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E | t_tail_flag, N, K, ldb, w_stride_e)
   switch (fuse) {
     case FUSE_SILU: SGLK_GO(FUSE_SILU); break;
     case FUSE_GELU: SGLK_GO(FUSE_GELU); break;
@@ -241,7 +249,9 @@ constexpr int g_bf16_wv = 8;
 template <typename T>
 static int dispatch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
                     int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
-  const int64_t avg = total_m / E;  // tile policy by average rows per expert, as the reference (GroupGemmXe20.cpp:226-274)
+  // tile policy by average rows per expert, as the reference (GroupGemmXe20.cpp:226-274); tail mode: total_m is the worst case
+  // that sizes the launch, the tails of routed experts are a few dozen rows
+  const int64_t avg = t_tail_flag ? std::min<int64_t>(total_m / E, 24) : total_m / E;
   // (ragged counts: a tile that holds ~1.5x the average rows, a second row block of an expert streams its weights again)
   if (avg <= 10) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   if (avg <= 24) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
@@ -269,6 +279,18 @@ extern "C" int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* 
   SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2) || N % 2 == 0, "moe_grouped_mm_nt_xe20: a gated epilogue needs an even N");
   if (total_m == 0) return SGLK_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (int rc = moe_persist_try(st, out, activations, weights, nullptr, bias, rows_per_expert, total_m, (int)n_experts, (int)N,
+                               (int)K, ldb, weight_stride_e, dtype, false, fused_act, 0.f)) {
+    if (rc < 0) return rc;
+    t_tail_flag = kMoeTailFlag;  // the experts' last rows (at most 128 each) on the streaming kernel
+    const int64_t tail_m = std::min<int64_t>(total_m, 128 * n_experts);
+    rc = dtype == SGLK_BF16 ? dispatch<bf16>(st, out, activations, weights, bias, rows_per_expert, tail_m, (int)n_experts, (int)N,
+                                             (int)K, ldb, weight_stride_e, fused_act)
+                            : dispatch<f16>(st, out, activations, weights, bias, rows_per_expert, tail_m, (int)n_experts, (int)N,
+                                            (int)K, ldb, weight_stride_e, fused_act);
+    t_tail_flag = 0;
+    return rc;
+  }
   if (dtype == SGLK_BF16)
     return dispatch<bf16>(st, out, activations, weights, bias, rows_per_expert, total_m, (int)n_experts, (int)N, (int)K, ldb,
                           weight_stride_e, fused_act);

@@ -1,0 +1,501 @@
+// Grouped GEMM for MoE experts at PREFILL row counts on gfx950: out_e = A_e @ W_e^T (+ gated activation) for ragged expert
+// row lists, 16-bit weights (moe_grouped_mm_nt_xe20) or symmetric int4 weights with groups of 128 (.._xe20_w4a16).
+//
+// Replaces, above ~200 rows per expert, the streaming kernels of moe_bf16.hip / moe_w4a16.hip (reference:
+// src/sycl/GroupGemmXe20.cpp, src/sycl/GroupGemmW4A16Xe20.cpp:92-283 and their CuTe kernels): those give a wave its own
+// weight stream and 64..128-row tiles, so at 512 rows per expert every column block re-reads the activations 224 times and
+// every row block the weights - 11 GB through L2 for the Mixtral gate / up projection of 2048 tokens, matrix pipe busy 0.39.
+// Here the work is a dense tile pipeline, the one of gemm_fp8bw_x32_kernel (gemm_8bit.hip):
+//  * persistent workgroups (one per CU) walk 256 x 256 tiles (row block of an expert x column block), XCD by XCD, the
+//    column blocks of a row block next to each other (they share its activations in the XCD's L2);
+//  * per 64-deep K block the a tile [256 rows][128 B] and the b tile [256 weight rows][128 B] go global -> LDS by LDS-DMA
+//    through buffer resources (rows past the expert's end / past N are out of range: zeros), two stages, ONE barrier per block
+//    in front of its last m-step; the n-fragments of the next block are read behind that barrier into the registers the
+//    last step's MFMAs have just consumed;
+//  * 8 waves as 2 (m) x 4 (n), wave tile 128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x16 (128 accumulator registers, the
+//    MFMAs of a tile chain over all of K); lane (i, h) supplies row i, 16-byte chunk 2 s + h of the row for k-step s - the
+//    same for both operands; chunk c of LDS row r sits at c ^ ((r >> 1) & 7): conflict-free ds_read_b128;
+//  * MFMA row i of an n-fragment is weight row 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3) of its 32: a lane owns 16
+//    consecutive output columns of one row (16-byte stores);
+//  * gated epilogues (silu / gelu / clamped swiglu): a tile takes 128 gate columns and the 128 up columns that go with
+//    them - n-fragment 0 of a wave is gate, 1 is up, the product is formed in the lane that holds both;
+//  * int4: the 4-bit codes never reach the MFMA loop. Every thread fetches 16 bytes (32 codes of one weight row) of the
+//    NEXT K block one block ahead, turns them into 32 values of the activation type - (code * scale) rounded once, exactly
+//    what the reference's dequantisation produces (gemm_xe2.hpp:52-76) - and writes them into the b tile of the next stage:
+//    the workgroup expands each code once (92 VALU per thread and block), not once per wave.
+#include <type_traits>
+
+#include "common.h"
+#include "moe_tiles.h"
+
+namespace sglk {
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 256, kBN = 256, kBKB = 128;      // tile rows, weight rows, bytes of K per block (64 elements)
+constexpr int kTile = kBM * kBKB;                    // 32 KiB per operand and stage
+constexpr int kStage = 2 * kTile;
+
+#define MP_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mp_rsrc(const void* p, uint32_t nrec) {
+  const uint64_t u = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+}
+
+struct MpParams {
+  void* out;
+  const void* act;
+  const void* w;        // 16-bit: [E][N][ldb] elements; int4: [E][N][K/2] bytes
+  const void* scales;   // int4: [E][N][K/128] in the activation type
+  const int32_t* rows;  // [E]
+  int E, N, K, fuse;    // fuse: 0 none, 1 silu, 2 gelu (tanh), 3 relu2, 4 clamped swiglu (1, 2, 4 gated: N = gate + up rows)
+  float act_limit;
+  int64_t ldb, stride_e;  // 16-bit weights: row stride / expert stride in elements
+};
+
+struct MpTile {
+  const char* pa;  // first activation row of the block
+  const char* pb;  // the expert's weights (+ the tile's first weight row)
+  const char* ps;  // the expert's scales (+ the tile's first weight row)
+  char* po;        // first output element of the tile
+  uint32_t nrec_a, nrec_b, nrec_o;
+  int ncols;       // valid output columns of the tile
+};
+
+// MS m-steps (32 rows per wave half) per K block: 4 = 256-row blocks; 2 = 128-row blocks. An expert's rows are cut in 256-row
+// blocks; a remainder of at most 128 rows is a 128-row block of the second launch (MS = 2), a larger one a (partly empty)
+// 256-row block: with ~512 +- 20 rows per expert (Mixtral, 2048 tokens) half of the experts have a remainder of ~20 rows, which
+// as 256-row blocks cost a quarter more tiles.
+template <typename T, bool W4, int MS>
+__global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][a tile, b tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int K = p.K, N = p.N;
+  const int nkb = K >> 6;  // >= 2
+  const bool gated = p.fuse == 1 || p.fuse == 2 || p.fuse == 4;
+  const int Nout = gated ? N >> 1 : N;
+  const int NB = gated ? (Nout + 127) >> 7 : (N + kBN - 1) / kBN;
+  const int64_t a_row = (int64_t)K * 2;                                   // bytes
+  const int64_t b_row = W4 ? (int64_t)(K >> 1) : p.ldb * 2;               // bytes per weight row
+  const int64_t b_exp = W4 ? (int64_t)N * (K >> 1) : p.stride_e * 2;      // bytes per expert
+  const int kgroups = K >> 7;
+
+  // ---- the tiles: MB row blocks (all experts) x NB column blocks, column blocks fastest; XCD x owns a contiguous run
+  // row blocks of an expert with r rows in THIS launch
+  auto blocks_of = [](int r) -> int {
+    const int full = r >> 8, tail = r & 255;
+    return MS == 4 ? full + (tail > 128 ? 1 : 0) : ((tail > 0 && tail <= 128) ? 1 : 0);
+  };
+  int MB = 0;
+  for (int c0 = 0; c0 < p.E; c0 += 64) {
+    const int r = c0 + lane < p.E ? p.rows[c0 + lane] : 0;
+    MB += __shfl(wave_inclusive_scan(blocks_of(r), lane), 63, 64);
+  }
+  MB = __builtin_amdgcn_readfirstlane(MB);
+  const int nt = MB * NB;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int q8 = nt >> 3, rem = nt & 7;
+  const int run_first = xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8;
+  const int run_len = q8 + (xcd < rem ? 1 : 0);
+  const int n_units = run_len > slot ? (run_len - slot + slots - 1) / slots : 0;
+  if (n_units == 0) return;
+
+  auto describe = [&](int unit) -> MpTile {  // unit >= n_units: the null tile
+    MpTile d;
+    const bool live = unit < n_units;
+    const int tile = live ? run_first + slot + unit * slots : 0;
+    const int mblk = tile / NB, cb = tile - mblk * NB;
+    // (expert, block of its rows) of row block mblk: lanes = experts, wave prefix sums (moe_tiles.h)
+    int e = 0, row0 = 0, rows_e = 0, blk = 0, base_b = 0, base_r = 0;
+    for (int c0 = 0; c0 < p.E; c0 += 64) {
+      const int r = c0 + lane < p.E ? p.rows[c0 + lane] : 0;
+      const int nb = blocks_of(r);
+      const int ib = wave_inclusive_scan(nb, lane), ir = wave_inclusive_scan(r, lane);
+      const bool hit = mblk >= base_b + ib - nb && mblk < base_b + ib;
+      const unsigned long long m = __ballot(hit);
+      if (m != 0) {
+        const int src = __builtin_ctzll(m);
+        e = c0 + src;
+        blk = mblk - (base_b + __shfl(ib - nb, src, 64));
+        row0 = base_r + __shfl(ir - r, src, 64);
+        rows_e = __shfl(r, src, 64);
+        break;
+      }
+      base_b += __shfl(ib, 63, 64);
+      base_r += __shfl(ir, 63, 64);
+    }
+    e = __builtin_amdgcn_readfirstlane(e);
+    blk = __builtin_amdgcn_readfirstlane(blk);
+    rows_e = __builtin_amdgcn_readfirstlane(rows_e);
+    const int first = MS == 4 ? blk * kBM : (rows_e & ~255);  // first row of the block inside its expert
+    const int m0 = __builtin_amdgcn_readfirstlane(row0) + first;
+    int rows_a = rows_e - first;
+    rows_a = rows_a < MS * 64 ? rows_a : MS * 64;
+    const int c0 = gated ? cb * 128 : cb * kBN;          // first output column (gated: = first gate row)
+    const int cols = gated ? (Nout - c0 < 128 ? Nout - c0 : 128) : (N - c0 < kBN ? N - c0 : kBN);
+    d.ncols = cols;
+    d.pa = (const char*)p.act + (int64_t)m0 * a_row;
+    d.pb = (const char*)p.w + (int64_t)e * b_exp + (int64_t)c0 * b_row;
+    d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + c0) * kgroups * 2 : nullptr;
+    d.po = (char*)p.out + ((int64_t)m0 * Nout + c0) * 2;
+    d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * a_row + (int64_t)K * 2) : 0u;
+    // (b: the resource spans the expert's rows from the tile's first one to row N - 1: weight rows past N read zeros)
+    d.nrec_b = live ? (uint32_t)((int64_t)(N - c0) * b_row) : 0u;
+    d.nrec_o = live ? (uint32_t)(((int64_t)(rows_a - 1) * Nout + cols) * 2) : 0u;
+    return d;
+  };
+  auto pick = [](bool c, const MpTile& x, const MpTile& y) -> MpTile {
+    MpTile d;
+    d.pa = c ? x.pa : y.pa;  d.pb = c ? x.pb : y.pb;  d.ps = c ? x.ps : y.ps;  d.po = c ? x.po : y.po;
+    d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_o = c ? x.nrec_o : y.nrec_o;
+    d.ncols = c ? x.ncols : y.ncols;
+    return d;
+  };
+  // weight row (relative to the tile's first) of LDS row `slot`: the wave that owns columns wn * 64 .. reads slots wn * 64 ..;
+  // gated: its first 32 slots are gate rows c0 + 32 wn .., its last 32 the up rows N/2 further on
+  auto wrow_of = [&](int s) -> int { return gated ? ((s >> 6) * 32 + (s & 31) + ((s & 32) ? Nout : 0)) : s; };
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)MP_LDS(smem);
+  // DMA piece = 8 LDS rows x 128 B; lane -> row lane / 8, chunk (lane % 8) ^ key(row), key = (row >> 1) & 7
+  uint32_t voff_a[2], voff_b[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const uint32_t ch = (uint32_t)(((lane & 7) ^ ((par * 4 + (lane >> 4)) & 7)) << 4);
+    voff_a[par] = (uint32_t)(lane >> 3) * (uint32_t)a_row + ch;
+    voff_b[par] = (uint32_t)(lane >> 3) * (uint32_t)b_row + ch;
+  }
+  // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = weight rows (16-bit weights only), sub 0, 1 each
+  auto dma_piece = [&](const MpTile& d, int kb, int s, int part, int sub) {
+    char* base = smem + s * kStage;
+    const int ii = (part & 1) * 2 + sub, piece = wave * 4 + ii;
+    if (part < 2) {
+      if (MS == 2 && wave >= 4) return;  // (rows 128.. of the a tile do not exist)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pa, d.nrec_a), MP_LDS(base + piece * 1024), 16, voff_a[ii & 1],
+                                               kb * kBKB + piece * 8 * (int)a_row, 0, 0);
+    } else if constexpr (!W4) {
+      const int wr = __builtin_amdgcn_readfirstlane(wrow_of(piece * 8));  // (8 slots of a piece are 8 consecutive weight rows)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pb, d.nrec_b), MP_LDS(base + kTile + piece * 1024), 16,
+                                               voff_b[ii & 1], kb * kBKB + wr * (int)b_row, 0, 0);
+    }
+  };
+
+  // ---- int4: thread (slot = tid / 2, half = tid % 2) expands codes [32 half, 32 half + 32) of its weight row per K block
+  const int pslot = tid >> 1, phalf = tid & 1;
+  const uint32_t pvoff_w = (uint32_t)wrow_of(pslot) * (uint32_t)b_row + (uint32_t)phalf * 16u;
+  const uint32_t pvoff_s = (uint32_t)wrow_of(pslot) * (uint32_t)kgroups * 2u;
+  const uint32_t pwr = (uint32_t)(pslot * 128);           // LDS row of the b tile
+  const uint32_t pkey = (uint32_t)((pslot >> 1) & 7);
+  v4i raw_c = {0, 0, 0, 0}, raw_n = {0, 0, 0, 0};
+  uint32_t sraw_c = 0, sraw_n = 0;
+  auto load_raw = [&](const MpTile& d, int kb, v4i& raw, uint32_t& sr) {
+    if constexpr (W4) {
+      raw = __builtin_amdgcn_raw_buffer_load_b128(mp_rsrc(d.pb, d.nrec_b), (int)pvoff_w, kb * 32, 0);
+      sr = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.ps, d.nrec_b == 0 ? 0u : 0x7fffffffu), (int)pvoff_s,
+                                                           (kb >> 1) * 2, 0);
+    }
+  };
+  v4i wexp[4];
+  auto expand = [&](const v4i& raw, uint32_t sr, int q) {  // dword q of the 16 bytes -> 8 values -> wexp[q]
+    const float s16 = (float)__builtin_bit_cast(T, (uint16_t)sr) * 0.0625f;
+    const uint32_t wd = (uint32_t)raw[q];
+    const uint32_t x = (wd << 4) & 0xF0F0F0F0u, y = wd & 0xF0F0F0F0u;  // signed bytes 16 * code: even / odd k
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float f0 = (float)(int8_t)(x >> (8 * b)) * s16, f1 = (float)(int8_t)(y >> (8 * b)) * s16;
+      const T t0 = (T)f0, t1 = (T)f1;
+      wexp[q][b] = (int)((uint32_t)__builtin_bit_cast(uint16_t, t0) | ((uint32_t)__builtin_bit_cast(uint16_t, t1) << 16));
+    }
+  };
+
+  // ---- fragment addressing (byte offsets inside a stage): lane (i, h): row i, chunk (2 s + h) ^ key(row) = (chunk h) ^ (s << 5)
+  const int li = lane & 31, lh = lane >> 5;
+  const int brow = ((li >> 2) & 1) * 16 + (li >> 3) * 4 + (li & 3);
+  const int frag_off_a = li * 128 + ((lh ^ ((li >> 1) & 7)) << 4);
+  const int frag_off_b = brow * 128 + ((lh ^ ((brow >> 1) & 7)) << 4);
+
+  // ---- stores: lane (i, h) owns row wm * 128 + 32 mf + i; plain: columns wn * 64 + 32 nf + 16 h .. + 15 of the tile;
+  // gated: columns wn * 32 + 16 h .. + 15 (gate = n-fragment 0, up = n-fragment 1)
+  const uint32_t orow_off = (uint32_t)(((int64_t)(wm * (MS * 32) + li) * Nout + (gated ? wn * 32 : wn * 64) + lh * 16) * 2);
+  auto act_mul = [&](float x, float y) -> float {
+    if (p.fuse == 4) {
+      x = fminf(x, p.act_limit);
+      y = fminf(fmaxf(y, -p.act_limit), p.act_limit);
+    }
+    // (hardware exp2 / reciprocal, ~1 ulp each: the libm forms are ~40 instructions per element, and the 64 elements per
+    // lane and m-step of the store block - straight-line code - then thrash the instruction cache once per tile)
+    float a;
+    if (p.fuse == 1 || p.fuse == 4) {
+      a = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));  // x * sigmoid(x)
+    } else {
+      const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      // 0.5 (1 + tanh(u)) = 1 / (1 + exp(-2 u))
+      a = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.885390081777927f * inner));
+    }
+    return a * y;
+  };
+  auto store_frag = [&](const MpTile& d, const v16f (&accm)[2], int mf) {
+    const __amdgpu_buffer_rsrc_t ro = mp_rsrc(d.po, d.nrec_o);
+    const int soff = __builtin_amdgcn_readfirstlane(mf * 32 * Nout * 2);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+      if (gated && nf == 1) break;
+#pragma unroll
+      for (int hv = 0; hv < 2; ++hv) {
+        Vec<T, 8> v;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float t = accm[nf][hv * 8 + c];
+          if (gated) {
+            t = act_mul(t, accm[1][hv * 8 + c]);
+          } else if (p.fuse == 3) {
+            t = fmaxf(t, 0.f);
+            t = t * t;
+          }
+          v[c] = (T)t;
+        }
+        const int col = (gated ? wn * 32 : wn * 64 + nf * 32) + lh * 16 + hv * 8;
+        const uint32_t vo = col < d.ncols ? orow_off + (uint32_t)((nf * 32 + hv * 8) * 2) : 0x80000000u;
+        const v4i data = __builtin_bit_cast(v4i, v);
+        __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, 0);
+        asm volatile("s_nop 4" ::"v"(data));  // (store data is read for a few cycles after issue: gemm_8bit.hip)
+      }
+    }
+  };
+
+  v16f acc[MS][2];
+#pragma unroll
+  for (int mf = 0; mf < MS; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
+
+#define MP_RD16(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+#define MP_WR16(addr, src) asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(src) : "memory")
+#define MP_MFMA(mf, nf, s)                                                                                     \
+  if constexpr (std::is_same<T, bf16>::value) {                                                                \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(nq[nf][s]), "v"(mq[s]));   \
+  } else {                                                                                                     \
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(nq[nf][s]), "v"(mq[s]));    \
+  }
+
+  v4i nq[2][4];  // [n-fragment][k-step]
+  v4i mq[4];     // [k-step] of the running m-fragment (each re-read right behind its second MFMA)
+  int gblk = 0;
+
+  // m-step mf of a K block: k-steps s = 0..3, two MFMAs each. LAST: behind the block's barrier; its gaps carry the reads of the
+  // next block's fragments (per k-step: n0, n1, m). WR: the step that ends with the int4 producer's 4 LDS stores (the step
+  // in front of the barrier). The lgkmcnt of the wait in front of k-step s: step 0 9 / 7 / 5 / 3 (12 reads of the last
+  // step, one re-read per k-step behind them), other steps 3.
+#define MP_STEP(mf, STORE, LAST, WR)                                                                           \
+  {                                                                                                            \
+    if constexpr (STORE) { /* first K block of a tile: the finished tile's rows of this step leave before the step's MFMAs */ \
+      store_frag(prv, acc[mf], (mf));                                                                          \
+      _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f; \
+      asm volatile("" : "+v"(acc[mf][0]), "+v"(acc[mf][1]));                                                   \
+    }                                                                                                          \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                         \
+      if (!(LAST)) {                                                                                           \
+        if ((mf) == 0) {                                                                                       \
+          if (s_ == 0) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(nq[0][0]), "+v"(nq[1][0]), "+v"(mq[0]));     \
+          if (s_ == 1) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(nq[0][1]), "+v"(nq[1][1]), "+v"(mq[1]));     \
+          if (s_ == 2) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(nq[0][2]), "+v"(nq[1][2]), "+v"(mq[2]));     \
+          if (s_ == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(nq[0][3]), "+v"(nq[1][3]), "+v"(mq[3]));     \
+        } else {                                                                                               \
+          asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(mq[s_]));                                                 \
+        }                                                                                                      \
+      }                                                                                                        \
+      MP_MFMA(mf, 0, s_)                                                                                       \
+      MP_MFMA(mf, 1, s_)                                                                                       \
+      if (LAST) {                                                                                              \
+        const uint32_t x_ = (uint32_t)(s_ << 5);                                                               \
+        MP_RD16(nq[0][s_], nb0 ^ x_, 0);                                                                       \
+        MP_RD16(nq[1][s_], nb0 ^ x_, 4096);                                                                    \
+        MP_RD16(mq[s_], na0 ^ x_, 0);                                                                          \
+        if (s_ < 2) dma_piece(d2, kb2, s, 0, s_);                                                              \
+      } else {                                                                                                 \
+        MP_RD16(mq[s_], a0 ^ (uint32_t)(s_ << 5), ((mf) + 1) * 4096);                                          \
+        if (MS == 4) {                                                                                         \
+          if ((mf) == 0 && s_ == 0) dma_piece(d1, kb1, s ^ 1, 1, 0);                                           \
+          if ((mf) == 0 && s_ == 1) dma_piece(d1, kb1, s ^ 1, 1, 1);                                           \
+          if ((mf) == 0 && s_ == 2) dma_piece(d1, kb1, s ^ 1, 2, 0);                                           \
+          if ((mf) == 1 && s_ == 0) dma_piece(d1, kb1, s ^ 1, 2, 1);                                           \
+          if ((mf) == 1 && s_ == 1) dma_piece(d1, kb1, s ^ 1, 3, 0);                                           \
+          if ((mf) == 1 && s_ == 2) dma_piece(d1, kb1, s ^ 1, 3, 1);                                           \
+        } else {                                                                                               \
+          if (s_ == 0) { dma_piece(d1, kb1, s ^ 1, 1, 0); dma_piece(d1, kb1, s ^ 1, 1, 1); }                   \
+          if (s_ == 1) { dma_piece(d1, kb1, s ^ 1, 2, 0); dma_piece(d1, kb1, s ^ 1, 2, 1); }                   \
+          if (s_ == 2) dma_piece(d1, kb1, s ^ 1, 3, 0);                                                        \
+          if (s_ == 3) dma_piece(d1, kb1, s ^ 1, 3, 1);                                                        \
+        }                                                                                                      \
+      }                                                                                                        \
+      if (W4 && !(LAST) && MS == 4 && (mf) < 2 && (s_ == 0 || s_ == 2)) expand(raw_c, sraw_c, 2 * (mf) + (s_ >> 1)); \
+      if (W4 && !(LAST) && MS == 2) expand(raw_c, sraw_c, s_);                                                 \
+    }                                                                                                          \
+    if constexpr (W4 && (WR)) { /* the producer's 64 bytes of the next block's b tile (the barrier follows) */  \
+      const uint32_t wb_ = nbase + (uint32_t)kTile + pwr;                                                      \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
+        const uint32_t ad_ = wb_ + ((((uint32_t)(4 * phalf + q_)) ^ pkey) << 4);                               \
+        MP_WR16(ad_, wexp[q_]);                                                                                \
+      }                                                                                                        \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+#define MP_BLOCK(STORE)                                                                                        \
+  {                                                                                                            \
+    const int s = gblk & 1;                                                                                    \
+    const uint32_t sbase = lds_base + (uint32_t)(s * kStage);                                                  \
+    const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStage);                                            \
+    const bool in1 = kb + 1 < nkb, in2 = kb + 2 < nkb;                                                         \
+    const MpTile d1 = pick(in1, cur_t, nxt), d2 = pick(in2, cur_t, nxt);                                       \
+    const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
+    uint32_t a0, nb0 = 0, na0 = 0;                                                                             \
+    {                                                                                                          \
+      int fo = frag_off_a;                                                                                     \
+      asm volatile("" : "+v"(fo));                                                                             \
+      a0 = sbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)fo;                                            \
+    }                                                                                                          \
+    load_raw(d2, kb2, raw_n, sraw_n);                                                                          \
+    if constexpr (MS == 4) { MP_STEP(0, STORE, false, false) MP_STEP(1, STORE, false, false) MP_STEP(2, STORE, false, true) } \
+    else { MP_STEP(0, STORE, false, true) }                                                                    \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    {                                                                                                          \
+      int foa = frag_off_a, fob = frag_off_b;                                                                  \
+      asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
+      nb0 = nbase + (uint32_t)(kTile + wn * 64 * 128) + (uint32_t)fob;                                         \
+      na0 = nbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)foa;                                          \
+      asm volatile("" : "+v"(nb0), "+v"(na0));                                                                 \
+    }                                                                                                          \
+    MP_STEP(MS - 1, STORE, true, false)                                                                        \
+    raw_c = raw_n;                                                                                             \
+    sraw_c = sraw_n;                                                                                           \
+    ++gblk;                                                                                                    \
+  }
+
+  int unit = 0;
+  MpTile cur_t = describe(0);
+  MpTile prv = describe(n_units);  // the null tile: nothing to store yet
+  // ---- prologue: block 0 of the first unit lands (int4: is expanded), its fragments are read in the last step's order,
+  // part 0 of block 1 goes out (int4: the codes of block 1 are requested)
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    dma_piece(cur_t, 0, 0, part, 0);
+    dma_piece(cur_t, 0, 0, part, 1);
+  }
+  if constexpr (W4) {
+    load_raw(cur_t, 0, raw_c, sraw_c);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_c), "+v"(sraw_c));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) expand(raw_c, sraw_c, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t ad = lds_base + (uint32_t)kTile + pwr + ((((uint32_t)(4 * phalf + q)) ^ pkey) << 4);
+      MP_WR16(ad, wexp[q]);
+    }
+    load_raw(cur_t, 1, raw_c, sraw_c);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  {
+    const uint32_t b0 = lds_base + (uint32_t)(kTile + wn * 64 * 128) + (uint32_t)frag_off_b;
+    const uint32_t p0 = lds_base + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)frag_off_a;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint32_t x = (uint32_t)(s << 5);
+      MP_RD16(nq[0][s], b0 ^ x, 0);
+      MP_RD16(nq[1][s], b0 ^ x, 4096);
+      MP_RD16(mq[s], p0 ^ x, 0);
+    }
+  }
+  dma_piece(cur_t, 1, 1, 0, 0);
+  dma_piece(cur_t, 1, 1, 0, 1);
+
+  for (; unit < n_units; ++unit) {
+    const MpTile nxt = describe(unit + 1);
+    {
+      const int kb = 0;
+      MP_BLOCK(true)
+    }
+    for (int kb = 1; kb < nkb; ++kb) MP_BLOCK(false)
+    prv = cur_t;
+    cur_t = nxt;
+  }
+#undef MP_BLOCK
+#undef MP_STEP
+  // drain the reads and DMA of the last step; the MFMAs of the last step retire; store the last unit
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[MS - 1][0]), "+v"(acc[MS - 1][1]));
+#pragma unroll
+  for (int mf = 0; mf < MS; ++mf) store_frag(prv, acc[mf], mf);
+#undef MP_MFMA
+#undef MP_RD16
+#undef MP_WR16
+}
+
+#ifdef SGLK_PROBES
+static int g_mp_own_tails = 0;
+#else
+constexpr int g_mp_own_tails = 0;
+#endif
+#ifdef SGLK_PROBES
+static int g_mp_min_avg_rows = 192;
+#define kMinAvgRows g_mp_min_avg_rows
+#else
+constexpr int kMinAvgRows = 192;  // average rows per expert from which the tile pipeline takes over
+#endif
+
+
+template <typename T, bool W4>
+static int launch_persist(hipStream_t st, const MpParams& p) {
+  static unsigned long long attr_done4 = 0, attr_done2 = 0;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 4>), 2 * kStage, &attr_done4, "moe_persist"))
+    return rc;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 2>), 2 * kStage, &attr_done2, "moe_persist"))
+    return rc;
+  moe_persist_kernel<T, W4, 4><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
+  // Remainders of at most 128 rows: the callers run their streaming kernels over them (moe_tiles.h, tail mode) - a few
+  // dozen rows per expert are a weight stream, 70 us for the Mixtral down projection against 275 us as 128-row tiles here
+  // (K = 14336: 96 long tiles on 256 CUs). MOE_PERSIST_TAILS=1 in the diagnostic build runs them here instead.
+  if (g_mp_own_tails) moe_persist_kernel<T, W4, 2><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
+  return 0;
+}
+
+}  // namespace
+
+// Called by sglk_moe_grouped_mm / sglk_moe_grouped_mm_w4a16_act. Returns 0 when the shape does not qualify (the caller goes
+// on with its streaming kernels), 1 after launching, a negative error code on failure.
+int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const float* bias,
+                    const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, bool w4,
+                    int fuse, float act_limit) {
+  const bool gated = fuse == 1 || fuse == 2 || fuse == 4;
+  const int Nout = gated ? N / 2 : N;
+  if (bias != nullptr || total_m < (int64_t)kMinAvgRows * E || num_cus() % 8 != 0) return 0;
+  if (K % (w4 ? 128 : 64) != 0 || K < 128 || N % 8 != 0 || (gated && (N % 64 != 0)) || (uintptr_t)out % 16 != 0 ||
+      (uintptr_t)act % 16 != 0 || (uintptr_t)w % 16 != 0 || Nout % 8 != 0)
+    return 0;
+  const int64_t b_row = w4 ? K / 2 : ldb * 2;
+  if ((!w4 && (ldb % 8 != 0 || stride_e % 8 != 0)) || (int64_t)N * b_row >= (1ll << 32) || 264ll * K * 2 >= (1ll << 32) ||
+      256ll * Nout * 2 + 512 >= (1ll << 31) || (w4 && ((uintptr_t)scales % 2 != 0 || (int64_t)N * (K / 128) * 2 >= (1ll << 31))))
+    return 0;
+  MpParams p;
+  p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.rows = rows;
+  p.E = E;  p.N = N;  p.K = K;  p.fuse = fuse;  p.act_limit = act_limit;  p.ldb = ldb;  p.stride_e = stride_e;
+  int rc;
+  if (dtype == SGLK_BF16) rc = w4 ? launch_persist<bf16, true>(st, p) : launch_persist<bf16, false>(st, p);
+  else rc = w4 ? launch_persist<f16, true>(st, p) : launch_persist<f16, false>(st, p);
+  return rc ? rc : 1;
+}
+
+}  // namespace sglk
+
+#ifdef SGLK_PROBES
+extern "C" SGLK_API void sglk_debug_set_moe_persist_min_rows(int rows) { sglk::g_mp_min_avg_rows = rows; }
+extern "C" SGLK_API void sglk_debug_set_moe_persist_own_tails(int on) { sglk::g_mp_own_tails = on; }
+#endif

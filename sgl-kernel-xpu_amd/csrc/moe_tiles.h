@@ -36,13 +36,23 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
 // cols_fast: consecutive tiles (= the workgroups resident on one XCD at a time) walk the column blocks of ONE row block and
 // share its activations in that XCD's L2; otherwise they walk the row blocks of one column block. The larger operand of a
 // tile should be the shared one: 64 rows x K 16-bit activations against 128 columns x K / 2 bytes of 4-bit weights.
+// Tail mode (bit 30 of E, kMoeTailFlag): the launch covers only what the tile pipeline of moe_persist.hip leaves over - of every
+// expert the rows behind its last full 256-row block when they are at most 128 (more are a block of their own there).
+constexpr int kMoeTailFlag = 1 << 30;
+__device__ __forceinline__ int moe_tail_rows(int r) {
+  const int t = r & 255;
+  return t <= 128 ? t : 0;
+}
 __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ rows_per_expert, int E, int BM, int NB,
                                                  bool cols_fast = false) {
   const int lane = threadIdx.x & 63;
+  const bool tail_mode = (E & kMoeTailFlag) != 0;
+  E &= ~kMoeTailFlag;
   int MB = 0;
   for (int c0 = 0; c0 < E; c0 += 64) {
     const int r = c0 + lane < E ? rows_per_expert[c0 + lane] : 0;
-    MB += __shfl(wave_inclusive_scan((r + BM - 1) / BM, lane), 63, 64);
+    const int rr = tail_mode ? moe_tail_rows(r) : r;
+    MB += __shfl(wave_inclusive_scan((rr + BM - 1) / BM, lane), 63, 64);
   }
   MB = __builtin_amdgcn_readfirstlane(MB);
   MoeTile t = {-1, 0, 0, 0};
@@ -56,7 +66,8 @@ __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ row
   int e = 0, row0 = 0, rows_e = 0, blk = 0, base_b = 0, base_r = 0;
   for (int c0 = 0; c0 < E; c0 += 64) {
     const int r = c0 + lane < E ? rows_per_expert[c0 + lane] : 0;
-    const int nb = (r + BM - 1) / BM;
+    const int rr = tail_mode ? moe_tail_rows(r) : r;
+    const int nb = (rr + BM - 1) / BM;
     const int ib = wave_inclusive_scan(nb, lane), ir = wave_inclusive_scan(r, lane);
     const bool hit = mblk >= base_b + ib - nb && mblk < base_b + ib;
     const unsigned long long m = __ballot(hit);
@@ -64,8 +75,8 @@ __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ row
       const int src = __builtin_ctzll(m);
       e = c0 + src;
       blk = mblk - (base_b + __shfl(ib - nb, src, 64));
-      row0 = base_r + __shfl(ir - r, src, 64);
-      rows_e = __shfl(r, src, 64);
+      row0 = base_r + __shfl(ir - r, src, 64) + __shfl(r - rr, src, 64);  // (tail mode: the expert's first rows are not ours)
+      rows_e = __shfl(rr, src, 64);
       break;
     }
     base_b += __shfl(ib, 63, 64);

@@ -42,6 +42,10 @@
 #include "moe_tiles.h"
 
 namespace sglk {
+// moe_persist.hip: the dense tile pipeline for prefill row counts (returns 1 after launching, 0 if the shape does not qualify)
+int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const float* bias,
+                    const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, bool w4,
+                    int fuse, float act_limit);
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -799,6 +803,7 @@ constexpr int g_w4_probe = 0, g_w4_mt = 0, g_w4_fp4hw = 1;
 
 // (the clamp bound of fused_act 4 rides beside the launch parameters: one value per call, set by the C-ABI entry)
 static thread_local float t_act_limit = 0.f;
+static thread_local int t_tail_flag = 0;  // kMoeTailFlag while the launches cover only the rows moe_persist.hip left over
 
 template <typename T, int MT, int NW, int PB, int FMT = 0, int WV = 4>
 static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
@@ -809,7 +814,7 @@ static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq,
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20_w4a16: problem too large for one launch");
   dim3 grid((unsigned)wgs);
   moe_w4a16_kernel<T, MT, NW, PB, FMT, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
-                                                             rows, E, N, K, group_shift, g_w4_probe, fuse, t_act_limit);
+                                                             rows, E | t_tail_flag, N, K, group_shift, g_w4_probe, fuse, t_act_limit);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
 }
 
@@ -842,7 +847,10 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // mxfp4 with bf16 activations goes through the conversion instruction and the group-128 machinery (FMT 3)
   const bool fp4hw = group_shift < 0 && std::is_same<T, bf16>::value && K % 128 == 0 && (uintptr_t)scales % 4 == 0 && g_w4_fp4hw != 0;
   const int gp = fp4hw ? 7 : group_shift;  // the group shift the tile policy sees
-  const int64_t avg = g_w4_mt ? ((g_w4_mt == 1 || g_w4_mt == 11 || g_w4_mt == 12 || g_w4_mt == 13) ? 1 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 200 : 1000) : total_m / E;
+  // (tail mode: total_m is the worst case that sizes the launch - 128 rows per expert; the tiles are chosen for what the tails
+  // of routed experts look like, a few dozen rows)
+  const int64_t pol_m = t_tail_flag ? std::min<int64_t>(total_m, 24 * (int64_t)E) : total_m;
+  const int64_t avg = g_w4_mt ? ((g_w4_mt == 1 || g_w4_mt == 11 || g_w4_mt == 12 || g_w4_mt == 13) ? 1 : g_w4_mt == 2 ? 32 : g_w4_mt == 4 ? 200 : 1000) : pol_m / E;
   // (16-column tiles per wave - 64 columns per workgroup, twice the workgroups - were slower at every decode shape: the
   // activation staging and the barrier are per workgroup, 155 vs 145 us at N = 28672, K = 4096)
   // (the 16 / 32-row tiles fetch the scales of four 128-deep blocks with one 8-byte load: groups of 128, K % 512 == 0)
@@ -856,10 +864,10 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // 81 us against 96 us with the 32-row tile for the down projection; the gate / up projection measured 151 against 145)
   const bool gated_epi = fuse == 1 || fuse == 2 || fuse == 4;  // (needs the two-tile wave: no 16-column wave tiles, no K split)
   const bool narrow16 = !gated_epi && gp == 7 && K % 1024 == 0 &&
-                        std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / 16) * cdiv(N, 128) <= 384;
+                        std::max<int64_t>(std::min<int64_t>(pol_m, E), pol_m / 16) * cdiv(N, 128) <= 384;
   const bool small = avg <= 10 || (narrow16 && avg <= 20 && g_w4_mt == 0);
   const int64_t bm = small ? 16 : 32;
-  const int64_t est_row_blocks = std::max<int64_t>(std::min<int64_t>(total_m, E), total_m / bm);
+  const int64_t est_row_blocks = std::max<int64_t>(std::min<int64_t>(pol_m, E), pol_m / bm);
   const bool narrow = !gated_epi && gp == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
   if (small) {
     // fewer workgroups than CUs even with 64-column tiles, long K: four waves split K (see moe_w4a16_ksplit_kernel)
@@ -870,15 +878,15 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
         bool done = false;
         if constexpr (std::is_same<T, bf16>::value) {
           if (fp4hw) {
-            moe_w4a16_ksplit_kernel<T, 3><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, nullptr, bias, rows, E, N, K);
+            moe_w4a16_ksplit_kernel<T, 3><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, nullptr, bias, rows, E | t_tail_flag, N, K);
             done = true;
           }
         }
         if (done) {
         } else if (zeros != nullptr)
-          moe_w4a16_ksplit_kernel<T, 2><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
+          moe_w4a16_ksplit_kernel<T, 2><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E | t_tail_flag, N, K);
         else
-          moe_w4a16_ksplit_kernel<T, 0><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
+          moe_w4a16_ksplit_kernel<T, 0><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E | t_tail_flag, N, K);
         return check_launch("moe_grouped_mm_nt_xe20_w4a16");
       }
     }
@@ -887,9 +895,9 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
     if (fuse == 0 && g_w4_mt == 13 && group_shift == 7 && K % 512 == 0) {
       const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 128));
       if (zeros != nullptr)
-        moe_w4a16_ksplit_kernel<T, 2, false><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
+        moe_w4a16_ksplit_kernel<T, 2, false><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E | t_tail_flag, N, K);
       else
-        moe_w4a16_ksplit_kernel<T, 0, false><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E, N, K);
+        moe_w4a16_ksplit_kernel<T, 0, false><<<dim3((unsigned)wgs), 256, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias, rows, E | t_tail_flag, N, K);
       return check_launch("moe_grouped_mm_nt_xe20_w4a16");
     }
 #endif
@@ -954,6 +962,21 @@ extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, co
   if (total_m == 0) return SGLK_OK;
   const int gs = !is_int4 ? -1 : group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : 8;
   hipStream_t st = (hipStream_t)stream;
+  if (is_int4 && group_size == 128 && zeros == nullptr) {
+    if (int rc = moe_persist_try(st, out, activations, packed_weights, scales, bias, rows_per_expert, total_m, (int)n_experts,
+                                 (int)N, (int)K, 0, 0, dtype, true, fused_act, act_limit)) {
+      if (rc < 0) return rc;
+      // the experts' last rows (at most 128 each) on the streaming kernels, sized for the worst case
+      t_tail_flag = kMoeTailFlag;
+      const int64_t tail_m = std::min<int64_t>(total_m, 128 * n_experts);
+      rc = dtype == SGLK_BF16 ? dispatch<bf16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, tail_m,
+                                               (int)n_experts, (int)N, (int)K, gs, fused_act)
+                              : dispatch<f16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, tail_m,
+                                              (int)n_experts, (int)N, (int)K, gs, fused_act);
+      t_tail_flag = 0;
+      return rc;
+    }
+  }
   if (dtype == SGLK_BF16)
     return dispatch<bf16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
                           (int)n_experts, (int)N, (int)K, gs, fused_act);

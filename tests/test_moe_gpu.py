@@ -145,7 +145,9 @@ def make_int4(E, N, K, gs, dtype, explicit_zero, g):
                                       # few rows, long K (groups of 128: the four waves of a workgroup split K)
                                       ([3, 0, 16, 7], 104, 8192), ([1] * 8, 256, 10240),
                                       # many rows: the eight-wave 64 x 256 tile
-                                      ([130, 200, 112, 150], 512, 1024)])
+                                      ([130, 200, 112, 150], 512, 1024),
+                                      # prefill row counts: the dense tile pipeline of moe_persist.hip (groups of 128, no zero points)
+                                      ([300, 200, 513, 256], 512, 1280), ([700, 0, 1, 900], 200, 256)])
 def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
     if K % gs:
         pytest.skip("K not a multiple of the group")
@@ -179,7 +181,8 @@ def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
 @pytest.mark.parametrize("gs,explicit_zero", [(128, False), (32, True), (64, False)])
 @pytest.mark.parametrize("rows,N,K", [([2] * 8, 256, 256), ([0, 5, 17, 0, 1, 33, 0, 129], 416, 512),
                                       ([300, 0, 40, 7], 1024, 1280), ([1] * 8, 4096, 1024),
-                                      ([130, 200, 112, 150], 512, 1024), ([3, 0, 16, 7], 208, 8192)])
+                                      ([130, 200, 112, 150], 512, 1024), ([3, 0, 16, 7], 208, 8192),
+                                      ([300, 200, 513, 256], 1024, 1280), ([260, 250, 300, 310], 384, 256)])  # (moe_persist.hip)
 def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit_zero, rows, N, K):
     """the gate / up activation (or relu2) in the epilogue of the W4A16 GEMM (authored op moe_grouped_mm_nt_w4a16_act):
     act(gate) * up from the fp32 accumulators, one rounding, against the exact-code fp32 definition; and within the
@@ -407,7 +410,8 @@ def test_fused_experts_mixtral_shape_sampled(sglk, dev, T):
 # ---------------------------------------------------------------------- 16-bit weights
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("rows", [[2] * 8, [0, 17, 1, 0, 130, 3, 64, 33], [300] + [0] * 7,
-                                  [200, 130, 97, 255, 128, 100, 190, 140]])  # (the last: the eight-wave 128 x 256 tile)
+                                  [200, 130, 97, 255, 128, 100, 190, 140],  # (the eight-wave 128 x 256 tile)
+                                  [300, 200, 513, 256, 260, 250, 300, 310]])  # (moe_persist.hip where K % 64 == 0, no bias)
 @pytest.mark.parametrize("N,K", [(128, 256), (352, 2816), (2816, 176), (1024, 1000)])
 @pytest.mark.parametrize("with_bias", [False, True])
 def test_grouped_mm_16bit(sglk, dev, dt, rows, N, K, with_bias):
@@ -428,6 +432,7 @@ def test_grouped_mm_16bit_fused_act(sglk, dev):
     g = torch.Generator().manual_seed(5)
     _check_fused_act_16bit(sglk, dev, g, [5, 0, 9, 1, 40, 2, 2, 7], 256, 512)
     _check_fused_act_16bit(sglk, dev, g, [150, 99, 260, 128, 0, 131, 100, 177], 608, 384)  # eight-wave tiles, ragged N / 2
+    _check_fused_act_16bit(sglk, dev, g, [300, 200, 513, 256, 260, 250, 300, 310], 640, 384)  # moe_persist.hip (no bias)
 
 
 def _check_fused_act_16bit(sglk, dev, g, rows, N, K):

@@ -1,0 +1,38 @@
+"""W4A16 grouped GEMMs of fused_experts (Mixtral shapes) timed one by one: uniform and routed (ragged) rows per expert."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "python"))
+import sgl_kernel  # noqa
+dev = "cuda"
+E, Hd, I, gs, topk = 8, 4096, 14336, 128, 2
+
+
+def timeit(f, it=10):
+    for _ in range(5): f()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(it): f()
+    en.record(); torch.cuda.synchronize()
+    return st.elapsed_time(en) / it
+
+
+w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
+w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
+s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01
+s2 = torch.rand(E, Hd, I // gs, device=dev).to(torch.bfloat16) * 0.01
+for T in (int(a) for a in (sys.argv[1:] or ["2048"])):
+    total = T * topk
+    ti = torch.randn(T, E, device=dev).topk(topk, dim=-1).indices
+    routed = torch.bincount(ti.flatten(), minlength=E).to(torch.int32)
+    for name, rows in (("uniform", torch.full((E,), total // E, dtype=torch.int32, device=dev)), ("routed", routed)):
+        x = torch.randn(total, Hd, device=dev, dtype=torch.bfloat16) * 0.1
+        h = torch.empty(total, I, device=dev, dtype=torch.bfloat16)
+        y = torch.empty(total, Hd, device=dev, dtype=torch.bfloat16)
+        op = torch.ops.sgl_kernel
+        t1 = timeit(lambda: op.moe_grouped_mm_nt_w4a16_act(h, x, w1, s1, None, None, rows, E, True, gs, 1, 0.0))
+        t2 = timeit(lambda: op.moe_grouped_mm_nt_xe20_w4a16(y, h, w2, s2, None, None, rows, E, True, gs))
+        gu = torch.empty(total, 2 * I, device=dev, dtype=torch.bfloat16)
+        t3 = timeit(lambda: op.moe_grouped_mm_nt_xe20_w4a16(gu, x, w1, s1, None, None, rows, E, True, gs))
+        del gu
+        fl1, fl2 = 2.0 * total * 2 * I * Hd, 2.0 * total * Hd * I
+        print(f"T={T} {name} rows={rows.tolist()}: gate/up {t1*1e3:.0f} us ({fl1/t1/1e9:.0f} TFLOP/s)  down {t2*1e3:.0f} us ({fl2/t2/1e9:.0f} TFLOP/s)  gate/up without the activation {t3*1e3:.0f} us")
