@@ -71,9 +71,10 @@ struct MpTile {
 // blocks; a remainder of at most 128 rows is a 128-row block of the second launch (MS = 2), a larger one a (partly empty)
 // 256-row block: with ~512 +- 20 rows per expert (Mixtral, 2048 tokens) half of the experts have a remainder of ~20 rows, which
 // as 256-row blocks cost a quarter more tiles.
-template <typename T, bool W4, int MS>
+template <typename T, int FMT, int MS>  // FMT: 0 16-bit weights, 1 int4 (symmetric, groups of 128), 2 mxfp4 (E8M0 scale per 32)
 __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][a tile, b tile]
+  constexpr bool W4 = FMT != 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   const int64_t a_row = (int64_t)K * 2;                                   // bytes
   const int64_t b_row = W4 ? (int64_t)(K >> 1) : p.ldb * 2;               // bytes per weight row
   const int64_t b_exp = W4 ? (int64_t)N * (K >> 1) : p.stride_e * 2;      // bytes per expert
-  const int kgroups = K >> 7;
+  const int kgroups = FMT == 2 ? K >> 5 : K >> 7;  // scales per weight row
+  constexpr int kSB = FMT == 2 ? 1 : 2;             // bytes per scale
 
   // ---- the tiles: MB row blocks (all experts) x NB column blocks, column blocks fastest; XCD x owns a contiguous run
   // row blocks of an expert with r rows in THIS launch
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     d.ncols = cols;
     d.pa = (const char*)p.act + (int64_t)m0 * a_row;
     d.pb = (const char*)p.w + (int64_t)e * b_exp + (int64_t)c0 * b_row;
-    d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + c0) * kgroups * 2 : nullptr;
+    d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + c0) * kgroups * kSB : nullptr;
     d.po = (char*)p.out + ((int64_t)m0 * Nout + c0) * 2;
     d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * a_row + (int64_t)K * 2) : 0u;
     // (b: the resource spans the expert's rows from the tile's first one to row N - 1: weight rows past N read zeros)
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // ---- int4: thread (slot = tid / 2, half = tid % 2) expands codes [32 half, 32 half + 32) of its weight row per K block
   const int pslot = tid >> 1, phalf = tid & 1;
   const uint32_t pvoff_w = (uint32_t)wrow_of(pslot) * (uint32_t)b_row + (uint32_t)phalf * 16u;
-  const uint32_t pvoff_s = (uint32_t)wrow_of(pslot) * (uint32_t)kgroups * 2u;
+  // (mxfp4: the thread's 32 codes are one scale group - byte 2 kb + half of the row's scales)
+  const uint32_t pvoff_s = (uint32_t)wrow_of(pslot) * (uint32_t)kgroups * (uint32_t)kSB + (FMT == 2 ? (uint32_t)phalf : 0u);
   const uint32_t pwr = (uint32_t)(pslot * 128);           // LDS row of the b tile
   const uint32_t pkey = (uint32_t)((pslot >> 1) & 7);
   v4i raw_c = {0, 0, 0, 0}, raw_n = {0, 0, 0, 0};
@@ -197,12 +200,27 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   auto load_raw = [&](const MpTile& d, int kb, v4i& raw, uint32_t& sr) {
     if constexpr (W4) {
       raw = __builtin_amdgcn_raw_buffer_load_b128(mp_rsrc(d.pb, d.nrec_b), (int)pvoff_w, kb * 32, 0);
-      sr = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.ps, d.nrec_b == 0 ? 0u : 0x7fffffffu), (int)pvoff_s,
-                                                           (kb >> 1) * 2, 0);
+      if constexpr (FMT == 2)
+        sr = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(mp_rsrc(d.ps, d.nrec_b == 0 ? 0u : 0x7fffffffu), (int)pvoff_s,
+                                                                     kb * 2, 0);
+      else
+        sr = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.ps, d.nrec_b == 0 ? 0u : 0x7fffffffu),
+                                                                       (int)pvoff_s, (kb >> 1) * 2, 0);
     }
   };
   v4i wexp[4];
   auto expand = [&](const v4i& raw, uint32_t sr, int q) {  // dword q of the 16 bytes -> 8 values -> wexp[q]
+    if constexpr (FMT == 2) {
+      // v_cvt_scalef32_pk_bf16_fp4: the two e2m1 codes of byte b (low nibble first) times 2^(E8M0 - 127), exact (moe_w4a16.hip)
+      typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
+      const float sc = __uint_as_float(sr ? sr << 23 : 0x00400000u);
+      const uint32_t wd = (uint32_t)raw[q];
+      wexp[q][0] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 0));
+      wexp[q][1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 1));
+      wexp[q][2] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 2));
+      wexp[q][3] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 3));
+      return;
+    }
     const float s16 = (float)__builtin_bit_cast(T, (uint16_t)sr) * 0.0625f;
     const uint32_t wd = (uint32_t)raw[q];
     const uint32_t x = (wd << 4) & 0xF0F0F0F0u, y = wd & 0xF0F0F0F0u;  // signed bytes 16 * code: even / odd k
@@ -452,7 +470,7 @@ constexpr int kMinAvgRows = 192;  // average rows per expert from which the tile
 #endif
 
 
-template <typename T, bool W4>
+template <typename T, int W4>
 static int launch_persist(hipStream_t st, const MpParams& p) {
   static unsigned long long attr_done4 = 0, attr_done2 = 0;
   if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 4>), 2 * kStage, &attr_done4, "moe_persist"))
@@ -472,24 +490,27 @@ static int launch_persist(hipStream_t st, const MpParams& p) {
 // Called by sglk_moe_grouped_mm / sglk_moe_grouped_mm_w4a16_act. Returns 0 when the shape does not qualify (the caller goes
 // on with its streaming kernels), 1 after launching, a negative error code on failure.
 int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const float* bias,
-                    const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, bool w4,
+                    const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
                     int fuse, float act_limit) {
   const bool gated = fuse == 1 || fuse == 2 || fuse == 4;
   const int Nout = gated ? N / 2 : N;
   if (bias != nullptr || total_m < (int64_t)kMinAvgRows * E || num_cus() % 8 != 0) return 0;
-  if (K % (w4 ? 128 : 64) != 0 || K < 128 || N % 8 != 0 || (gated && (N % 64 != 0)) || (uintptr_t)out % 16 != 0 ||
+  if (w4 == 2 && dtype != SGLK_BF16) return 0;  // (the fp4 conversion instruction is used in its bf16 form)
+  if (K % (w4 == 1 ? 128 : 64) != 0 || K < 128 || N % 8 != 0 || (gated && (N % 64 != 0)) || (uintptr_t)out % 16 != 0 ||
       (uintptr_t)act % 16 != 0 || (uintptr_t)w % 16 != 0 || Nout % 8 != 0)
     return 0;
   const int64_t b_row = w4 ? K / 2 : ldb * 2;
   if ((!w4 && (ldb % 8 != 0 || stride_e % 8 != 0)) || (int64_t)N * b_row >= (1ll << 32) || 264ll * K * 2 >= (1ll << 32) ||
-      256ll * Nout * 2 + 512 >= (1ll << 31) || (w4 && ((uintptr_t)scales % 2 != 0 || (int64_t)N * (K / 128) * 2 >= (1ll << 31))))
+      256ll * Nout * 2 + 512 >= (1ll << 31) ||
+      (w4 == 1 && ((uintptr_t)scales % 2 != 0 || (int64_t)N * (K / 128) * 2 >= (1ll << 31))) ||
+      (w4 == 2 && (int64_t)N * (K / 32) >= (1ll << 31)))
     return 0;
   MpParams p;
   p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.rows = rows;
   p.E = E;  p.N = N;  p.K = K;  p.fuse = fuse;  p.act_limit = act_limit;  p.ldb = ldb;  p.stride_e = stride_e;
   int rc;
-  if (dtype == SGLK_BF16) rc = w4 ? launch_persist<bf16, true>(st, p) : launch_persist<bf16, false>(st, p);
-  else rc = w4 ? launch_persist<f16, true>(st, p) : launch_persist<f16, false>(st, p);
+  if (dtype == SGLK_BF16) rc = w4 == 2 ? launch_persist<bf16, 2>(st, p) : w4 ? launch_persist<bf16, 1>(st, p) : launch_persist<bf16, 0>(st, p);
+  else rc = w4 ? launch_persist<f16, 1>(st, p) : launch_persist<f16, 0>(st, p);
   return rc ? rc : 1;
 }
 

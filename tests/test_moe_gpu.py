@@ -304,7 +304,8 @@ def make_mxfp4(E, N, K, g, exp_lo=110, exp_hi=135):
                                       ([129] * 8, 1024, 1024), ([0, 5, 17, 0, 1, 33, 0, 129], 200, 512),
                                       ([300, 0, 40, 7], 1024, 1280), ([1] * 8, 4096, 1024),
                                       # few rows, long K: the four waves of a workgroup split K (bf16: conversion path)
-                                      ([3, 0, 16, 7], 104, 8192), ([1] * 8, 256, 10240)])
+                                      ([3, 0, 16, 7], 104, 8192), ([1] * 8, 256, 10240),
+                                      ([300, 200, 513, 256], 1024, 1280), ([700, 0, 1, 900], 200, 192)])  # (moe_persist.hip)
 def test_moe_grouped_mm_w4a16_mxfp4(sglk, dev, dtype, rows, N, K):
     """reference tests/test_moe_gemm.py:805-885 (rows per expert {2, 6, 33, 129}, E=8, K=1024, N=2*512) + ragged rows"""
     g = torch.Generator().manual_seed(len(rows) * 17 + N + K)
