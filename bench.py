@@ -288,6 +288,15 @@ def side_metrics(sgl_kernel, dev):
     ms = timeit(lambda: flash_attn_with_kvcache(qd, kc128, vc128, cache_seqlens=lens, page_table=pt128, causal=True), iters=20)
     out["fwd_decode_bs16_h32_kv8_d128_seq4096_page128_GBs"] = round((kc.numel() + vc.numel() + 2 * qd.numel()) * 2 / ms / 1e6, 1)
     del kc, vc, qp, qd, qc, kc128, vc128
+    # prefill at head dim 64 (the reference's other prefill instantiation): same batch / heads / length
+    kc64 = torch.randn(n_pages, page, hk, 64, device=dev, dtype=torch.bfloat16)
+    vc64 = torch.randn(n_pages, page, hk, 64, device=dev, dtype=torch.bfloat16)
+    qp64 = torch.randn(bs * seq, hq, 64, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: flash_attn_with_kvcache(qp64, kc64, vc64, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                max_seqlen_q=seq, causal=True), iters=5)
+    out["fwd_prefill_causal_bs16_h32_kv8_d64_seq4096_TFLOPs"] = round(4.0 * bs * hq * 64 * seq * seq / 2 / ms / 1e9, 1)
+    out["fwd_prefill_causal_bs16_h32_kv8_d64_seq4096_ms"] = round(ms, 4)
+    del kc64, vc64, qp64
     # decode at the other head dims / an fp8 KV cache the reference instantiates (FMHADecodeXe20.cmake:13-16, :62-111)
     for dd, kvdt in ((64, torch.bfloat16), (256, torch.bfloat16), (128, FP8)):
         npg = bs * seq // page

@@ -575,14 +575,18 @@ struct Mfma32<f16> {
   }
 };
 
-template <typename T>
+// Head dim 64 (round 3; reference instantiations FMHAPrefillXe20.cmake): the same kernel with 128-byte LDS rows - 8 chunks per
+// row, one staging load per thread, tile and operand; K chunk c of row r at c ^ ((r >> 1) & 7) (rows two apart share their
+// banks), V chunk c at c ^ (((r >> 1) & 1) << 2); 8 + 8 MFMAs per wave and tile against the same softmax work.
+template <typename T, int D>
 __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
                                                            const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                            const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
                                                            const int32_t* __restrict__ page_table) {
   using M = Mfma<T>;
   using M32 = Mfma32<T>;
-  constexpr int D = 128, KS = D / 16, DB = D / 32, ROWB = D * 2, TILE_BYTES = kPTile * ROWB;
+  constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, TILE_BYTES = kPTile * ROWB;
+  constexpr int CPR = D / 8, NCH = CPR / 8, RPP = 512 / CPR;  // 16-byte chunks per row, staging loads per thread, rows per pass
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][K tile, V tile]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -670,52 +674,54 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
                                      : (int64_t)hk * (p.paged ? p.k_s2 : p.k_s1);
   const int64_t vbase = p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
                                      : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1);
-  const int srow = tid >> 4, sch = (tid & 15) * 8;  // this thread's token rows srow, srow + 32 and chunk of a tile
+  const int srow = tid / CPR, sch = (tid % CPR) * 8;  // this thread's token rows srow (+ RPP) and chunk of a tile
   const int last_key = seqlen_k - 1;
-  struct Pages { int pg[2]; };
+  struct Pages { int pg[NCH]; };
   // (without a page table the fetch reads cu_q[b], a valid word, and the page stride below is 0: no branch, so that the
   // loaded registers are not merged with constants behind a wait)
   const int32_t* pg_src = use_table ? table_b : cu_q + b;
   auto fetch_pages = [&](int t) -> Pages {
     Pages r;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int pos = t * kPTile + srow + 32 * i;
+    for (int i = 0; i < NCH; ++i) {
+      int pos = t * kPTile + srow + RPP * i;
       pos = pos < last_key ? pos : last_key;
       r.pg[i] = pg_src[(pos + pos_base) >> pos_shift];
     }
     return r;
   };
-  auto issue_load = [&](int t, const Pages& pages, const char* cache, uint32_t s0, uint32_t st, int64_t base, v4i (&dst)[2]) {
+  auto issue_load = [&](int t, const Pages& pages, const char* cache, uint32_t s0, uint32_t st, int64_t base, v4i (&dst)[NCH]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int pos = t * kPTile + srow + 32 * i;
+    for (int i = 0; i < NCH; ++i) {
+      int pos = t * kPTile + srow + RPP * i;
       pos = pos < last_key ? pos : last_key;
       const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
       const int64_t off = (int64_t)((uint64_t)(uint32_t)pages.pg[i] * s0 + ((uint64_t)cp * st + (uint64_t)(base + sch)));
       dst[i] = *reinterpret_cast<const v4i*>(cache + off * 2);
     }
   };
-  auto write_k = [&](int buf, const v4i (&src)[2]) {
+  auto write_k = [&](int buf, const v4i (&src)[NCH]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = tid + 512 * i;
-      const int row = c >> 4, ch = c & 15;
-      *reinterpret_cast<v4i*>(smem + buf * TILE_BYTES + row * ROWB + ((ch ^ (row & 15)) << 4)) = src[i];
+      const int row = c / CPR, ch = c % CPR;
+      const int key = D == 128 ? (row & 15) : ((row >> 1) & 7);
+      *reinterpret_cast<v4i*>(smem + buf * TILE_BYTES + row * ROWB + ((ch ^ key) << 4)) = src[i];
     }
   };
-  auto write_v = [&](int buf, const v4i (&src)[2]) {
+  auto write_v = [&](int buf, const v4i (&src)[NCH]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       const int c = tid + 512 * i;
-      const int row = c >> 4, ch = c & 15;
-      *reinterpret_cast<v4i*>(smem + (2 + buf) * TILE_BYTES + row * ROWB + ((ch ^ ((row & 3) << 2)) << 4)) = src[i];
+      const int row = c / CPR, ch = c % CPR;
+      const int key = D == 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2);
+      *reinterpret_cast<v4i*>(smem + (2 + buf) * TILE_BYTES + row * ROWB + ((ch ^ key) << 4)) = src[i];
     }
   };
 
   // ---- per-lane LDS read offsets
   // K (A operand of K . Q^T): token row 32 beta + l31, chunk 2 ks + u at position chunk ^ (row & 15)
-  const int krow_off = l31 * ROWB, kkey = l31 & 15;  // (32 beta does not change row & 15)
+  const int krow_off = l31 * ROWB, kkey = D == 128 ? (l31 & 15) : ((l31 >> 1) & 7);  // (32 beta does not change the key)
   // V^T (A operand of V^T . P^T) by transpose reads: 16 lanes fetch 4 tokens x 16 dims; lane -> (token qq, 4-dim quad pp)
   const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, hh = (lane >> 4) & 1;
   const int vlane_off = (4 * u + qq) * ROWB + 8 * (pp & 1);  // + token group offsets below; row & 3 == qq
@@ -745,8 +751,8 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   // Measured on the 16 x 4096 prefill, causal / full: this 817 / 942 TFLOP/s, waves 0..3 vs 4..7 809 / 917, even vs odd
   // waves 777 / 872, no skew 783 / 900.)
   const bool late_barrier = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) == 0;
-  v4i sk[2], sv[2];
-  Pages pg_v = {{0, 0}}, pg_k = {{0, 0}}, pg_pre = {{0, 0}};  // page ids of tiles t + 1, t + 2 and (in flight) t + 3
+  v4i sk[NCH], sv[NCH];
+  Pages pg_v = {}, pg_k = {}, pg_pre = {};  // page ids of tiles t + 1, t + 2 and (in flight) t + 3
   if (n_tiles > 0) {
     pg_v = fetch_pages(t_lo);
     pg_k = fetch_pages(t_lo + 1);
@@ -867,24 +873,25 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
     {
       v8s vf[4];
       auto read_v = [&](int m, v8s& dst) {
-        const int s4 = m >> 2, db = m & 3;
-        const int chunk = ((4 * db + vchunk_lo) ^ (qq << 2)) << 4;
+        const int s4 = m / DB, db = m % DB;
+        const int chunk = ((4 * db + vchunk_lo) ^ ((D == 128 ? qq : (qq >> 1)) << 2)) << 4;
         const char* a = vb + (32 * (s4 >> 1) + 16 * (s4 & 1)) * ROWB + vlane_off + chunk;
         const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a));
         const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a + 8 * ROWB));
         dst[0] = v0[0]; dst[1] = v0[1]; dst[2] = v0[2]; dst[3] = v0[3];
         dst[4] = v1[0]; dst[5] = v1[1]; dst[6] = v1[2]; dst[7] = v1[3];
       };
+      constexpr int NPV = 4 * DB;
 #pragma unroll
       for (int m = 0; m < 4; ++m) read_v(m, vf[m]);
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        o[m & 3] = M32::run(vf[m & 3], pf[m >> 2], o[m & 3]);
-        if (m + 4 < 16) read_v(m + 4, vf[m & 3]);
+      for (int m = 0; m < NPV; ++m) {
+        o[m % DB] = M32::run(vf[m & 3], pf[m / DB], o[m % DB]);
+        if (m + 4 < NPV) read_v(m + 4, vf[m & 3]);
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-      for (int m = 0; m < 12; ++m) {
+      for (int m = 0; m < NPV - 4; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
@@ -1378,14 +1385,14 @@ static int launch(hipStream_t st, const AttnParams& p, const void* q, const void
   return SGLK_OK;
 }
 
-template <typename T>
+template <typename T, int D>
 static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                           const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
-  constexpr int lds = 2 * 2 * kPTile * 256;  // 64 KiB
+  constexpr int lds = 2 * 2 * kPTile * D * 2;  // 64 KiB (d = 64: 32 KiB)
   static unsigned long long attr_done = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T>), lds, &attr_done, "fwd")) return rc;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D>), lds, &attr_done, "fwd")) return rc;
   dim3 grid((unsigned)cdiv(max_rows, kPBlockM), (unsigned)p.Hk, (unsigned)batch);
-  attn_prefill_kernel<T><<<grid, 512, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  attn_prefill_kernel<T, D><<<grid, 512, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   return check_launch("fwd(prefill)");
 }
 
@@ -1412,9 +1419,10 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
   const int d = p.D;
   // prefill-sized problems at head dim 128 (Llama-3 / BASELINE configs[2]): the 256-row kernel. A row block must be worth
   // filling: at least 128 packed rows per (sequence, kv head) at the longest sequence.
-  if (kv8 == 0 && d == 128 && p.splits == 1 && p.softcap <= 0.f && max_rows >= 128 && p.q_s0 % 8 == 0 && p.o_s0 % 4 == 0 &&
-      p.o_s1 % 4 == 0)
-    return launch_prefill<T>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (kv8 == 0 && (d == 128 || d == 64) && p.splits == 1 && p.softcap <= 0.f && max_rows >= 128 && p.q_s0 % 8 == 0 &&
+      p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0)
+    return d == 128 ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
+                    : launch_prefill<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
   // decode-sized problems at head dims 64 / 128 / 256 (16-bit or fp8 cache): every sequence has at most 16 packed rows per
   // kv head; a tile within one page
   if ((d == 64 || d == 128 || d == 256) && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) &&
