@@ -23,7 +23,8 @@
 
 namespace sglk {
 // moe_persist.hip: the dense tile pipeline for prefill row counts (returns 1 after launching, 0 if the shape does not qualify)
-int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const float* bias,
+int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const void* zeros,
+                    int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
                     int fuse, float act_limit);
 namespace {
@@ -279,7 +280,7 @@ extern "C" int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* 
   SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2) || N % 2 == 0, "moe_grouped_mm_nt_xe20: a gated epilogue needs an even N");
   if (total_m == 0) return SGLK_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (int rc = moe_persist_try(st, out, activations, weights, nullptr, bias, rows_per_expert, total_m, (int)n_experts, (int)N,
+  if (int rc = moe_persist_try(st, out, activations, weights, nullptr, nullptr, 0, bias, rows_per_expert, total_m, (int)n_experts, (int)N,
                                (int)K, ldb, weight_stride_e, dtype, 0, fused_act, 0.f)) {
     if (rc < 0) return rc;
     t_tail_flag = kMoeTailFlag;  // the experts' last rows (at most 128 each) on the streaming kernel

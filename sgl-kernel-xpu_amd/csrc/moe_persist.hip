@@ -1,5 +1,5 @@
 // Grouped GEMM for MoE experts at PREFILL row counts on gfx950: out_e = A_e @ W_e^T (+ gated activation) for ragged expert
-// row lists, 16-bit weights (moe_grouped_mm_nt_xe20) or symmetric int4 weights with groups of 128 (.._xe20_w4a16).
+// row lists, 16-bit weights (moe_grouped_mm_nt_xe20) or 4-bit weights - int4 with / without zero points, mxfp4 (.._xe20_w4a16).
 //
 // Replaces, above ~200 rows per expert, the streaming kernels of moe_bf16.hip / moe_w4a16.hip (reference:
 // src/sycl/GroupGemmXe20.cpp, src/sycl/GroupGemmW4A16Xe20.cpp:92-283 and their CuTe kernels): those give a wave its own
@@ -51,7 +51,9 @@ struct MpParams {
   void* out;
   const void* act;
   const void* w;        // 16-bit: [E][N][ldb] elements; int4: [E][N][K/2] bytes
-  const void* scales;   // int4: [E][N][K/128] in the activation type
+  const void* scales;   // int4: [E][N][K/group] in the activation type; mxfp4: [E][N][K/32] E8M0 bytes
+  const void* zeros;    // int4 with zero points (FMT 3): [E][N][K/group] in the activation type, codes unsigned
+  int gshift;           // int4: log2(group)
   const int32_t* rows;  // [E]
   int E, N, K, fuse;    // fuse: 0 none, 1 silu, 2 gelu (tanh), 3 relu2, 4 clamped swiglu (1, 2, 4 gated: N = gate + up rows)
   float act_limit;
@@ -62,6 +64,7 @@ struct MpTile {
   const char* pa;  // first activation row of the block
   const char* pb;  // the expert's weights (+ the tile's first weight row)
   const char* ps;  // the expert's scales (+ the tile's first weight row)
+  const char* pz;  // the expert's zero points (FMT 3)
   char* po;        // first output element of the tile
   uint32_t nrec_a, nrec_b, nrec_o;
   int ncols;       // valid output columns of the tile
@@ -71,7 +74,8 @@ struct MpTile {
 // blocks; a remainder of at most 128 rows is a 128-row block of the second launch (MS = 2), a larger one a (partly empty)
 // 256-row block: with ~512 +- 20 rows per expert (Mixtral, 2048 tokens) half of the experts have a remainder of ~20 rows, which
 // as 256-row blocks cost a quarter more tiles.
-template <typename T, int FMT, int MS>  // FMT: 0 16-bit weights, 1 int4 (symmetric, groups of 128), 2 mxfp4 (E8M0 scale per 32)
+// FMT: 0 16-bit weights, 1 int4 (two's-complement codes, no zero points), 2 mxfp4 (E8M0 scale per 32), 3 int4 with zero points
+template <typename T, int FMT, int MS>
 __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][a tile, b tile]
   constexpr bool W4 = FMT != 0;
@@ -86,7 +90,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   const int64_t a_row = (int64_t)K * 2;                                   // bytes
   const int64_t b_row = W4 ? (int64_t)(K >> 1) : p.ldb * 2;               // bytes per weight row
   const int64_t b_exp = W4 ? (int64_t)N * (K >> 1) : p.stride_e * 2;      // bytes per expert
-  const int kgroups = FMT == 2 ? K >> 5 : K >> 7;  // scales per weight row
+  const int gshift = FMT == 2 ? 5 : p.gshift;
+  const int kgroups = K >> gshift;                  // scales per weight row
   constexpr int kSB = FMT == 2 ? 1 : 2;             // bytes per scale
 
   // ---- the tiles: MB row blocks (all experts) x NB column blocks, column blocks fastest; XCD x owns a contiguous run
@@ -146,6 +151,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     d.pa = (const char*)p.act + (int64_t)m0 * a_row;
     d.pb = (const char*)p.w + (int64_t)e * b_exp + (int64_t)c0 * b_row;
     d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + c0) * kgroups * kSB : nullptr;
+    d.pz = FMT == 3 ? (const char*)p.zeros + ((int64_t)e * N + c0) * kgroups * 2 : nullptr;
     d.po = (char*)p.out + ((int64_t)m0 * Nout + c0) * 2;
     d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * a_row + (int64_t)K * 2) : 0u;
     // (b: the resource spans the expert's rows from the tile's first one to row N - 1: weight rows past N read zeros)
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   };
   auto pick = [](bool c, const MpTile& x, const MpTile& y) -> MpTile {
     MpTile d;
-    d.pa = c ? x.pa : y.pa;  d.pb = c ? x.pb : y.pb;  d.ps = c ? x.ps : y.ps;  d.po = c ? x.po : y.po;
+    d.pa = c ? x.pa : y.pa;  d.pb = c ? x.pb : y.pb;  d.ps = c ? x.ps : y.ps;  d.pz = c ? x.pz : y.pz;  d.po = c ? x.po : y.po;
     d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_o = c ? x.nrec_o : y.nrec_o;
     d.ncols = c ? x.ncols : y.ncols;
     return d;
@@ -188,11 +194,15 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     }
   };
 
-  // ---- int4: thread (slot = tid / 2, half = tid % 2) expands codes [32 half, 32 half + 32) of its weight row per K block
-  const int pslot = tid >> 1, phalf = tid & 1;
+  // ---- int4 / mxfp4: thread (slot, half) expands codes [32 half, 32 half + 32) of its weight row per K block
+  // (tid -> (slot, half) so that the eight lanes of a ds_write_b128 group hold eight different swizzle keys: 16-slot block
+  // tid / 32, half (tid / 16) % 2, slot parity (tid / 8) % 2, key tid % 8. With slot = tid / 2 two lanes of a group shared a
+  // key and a 128-byte bank window: SQ_LDS_BANK_CONFLICT was 20 % of the LDS cycles in the first r03 profile.)
+  const int pslot = (tid >> 5) * 16 + 2 * (tid & 7) + ((tid >> 3) & 1), phalf = (tid >> 4) & 1;
   const uint32_t pvoff_w = (uint32_t)wrow_of(pslot) * (uint32_t)b_row + (uint32_t)phalf * 16u;
-  // (mxfp4: the thread's 32 codes are one scale group - byte 2 kb + half of the row's scales)
-  const uint32_t pvoff_s = (uint32_t)wrow_of(pslot) * (uint32_t)kgroups * (uint32_t)kSB + (FMT == 2 ? (uint32_t)phalf : 0u);
+  // (the thread's 32 codes lie in ONE scale group: group (64 kb + 32 half) >> gshift of the row)
+  const uint32_t pvoff_s = (uint32_t)wrow_of(pslot) * (uint32_t)kgroups * (uint32_t)kSB +
+                           (uint32_t)((phalf * 32) >> gshift) * (uint32_t)kSB;
   const uint32_t pwr = (uint32_t)(pslot * 128);           // LDS row of the b tile
   const uint32_t pkey = (uint32_t)((pslot >> 1) & 7);
   v4i raw_c = {0, 0, 0, 0}, raw_n = {0, 0, 0, 0};
@@ -200,12 +210,17 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   auto load_raw = [&](const MpTile& d, int kb, v4i& raw, uint32_t& sr) {
     if constexpr (W4) {
       raw = __builtin_amdgcn_raw_buffer_load_b128(mp_rsrc(d.pb, d.nrec_b), (int)pvoff_w, kb * 32, 0);
-      if constexpr (FMT == 2)
+      const int so = ((kb * 64) >> gshift) * kSB;
+      if constexpr (FMT == 2) {
         sr = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(mp_rsrc(d.ps, d.nrec_b == 0 ? 0u : 0x7fffffffu), (int)pvoff_s,
-                                                                     kb * 2, 0);
-      else
+                                                                     so, 0);
+      } else {
         sr = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.ps, d.nrec_b == 0 ? 0u : 0x7fffffffu),
-                                                                       (int)pvoff_s, (kb >> 1) * 2, 0);
+                                                                       (int)pvoff_s, so, 0);
+        if constexpr (FMT == 3)  // (zero point in the high half)
+          sr |= (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.pz, d.nrec_b == 0 ? 0u : 0x7fffffffu),
+                                                                          (int)pvoff_s, so, 0) << 16;
+      }
     }
   };
   v4i wexp[4];
@@ -219,6 +234,18 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       wexp[q][1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 1));
       wexp[q][2] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 2));
       wexp[q][3] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 3));
+      return;
+    }
+    if constexpr (FMT == 3) {  // unsigned codes: (code - zero) * scale, rounded once
+      const float sc = (float)__builtin_bit_cast(T, (uint16_t)sr), zp = (float)__builtin_bit_cast(T, (uint16_t)(sr >> 16));
+      const uint32_t wd = (uint32_t)raw[q];
+      const uint32_t x = wd & 0x0F0F0F0Fu, y = (wd >> 4) & 0x0F0F0F0Fu;  // even / odd k
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float f0 = ((float)(uint8_t)(x >> (8 * b)) - zp) * sc, f1 = ((float)(uint8_t)(y >> (8 * b)) - zp) * sc;
+        const T t0 = (T)f0, t1 = (T)f1;
+        wexp[q][b] = (int)((uint32_t)__builtin_bit_cast(uint16_t, t0) | ((uint32_t)__builtin_bit_cast(uint16_t, t1) << 16));
+      }
       return;
     }
     const float s16 = (float)__builtin_bit_cast(T, (uint16_t)sr) * 0.0625f;
@@ -489,28 +516,34 @@ static int launch_persist(hipStream_t st, const MpParams& p) {
 
 // Called by sglk_moe_grouped_mm / sglk_moe_grouped_mm_w4a16_act. Returns 0 when the shape does not qualify (the caller goes
 // on with its streaming kernels), 1 after launching, a negative error code on failure.
-int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const float* bias,
+int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const void* zeros,
+                    int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
                     int fuse, float act_limit) {
   const bool gated = fuse == 1 || fuse == 2 || fuse == 4;
   const int Nout = gated ? N / 2 : N;
   if (bias != nullptr || total_m < (int64_t)kMinAvgRows * E || num_cus() % 8 != 0) return 0;
   if (w4 == 2 && dtype != SGLK_BF16) return 0;  // (the fp4 conversion instruction is used in its bf16 form)
-  if (K % (w4 == 1 ? 128 : 64) != 0 || K < 128 || N % 8 != 0 || (gated && (N % 64 != 0)) || (uintptr_t)out % 16 != 0 ||
+  if (K % 64 != 0 || K < 128 || N % 8 != 0 || (gated && (N % 64 != 0)) || (uintptr_t)out % 16 != 0 ||
       (uintptr_t)act % 16 != 0 || (uintptr_t)w % 16 != 0 || Nout % 8 != 0)
     return 0;
   const int64_t b_row = w4 ? K / 2 : ldb * 2;
   if ((!w4 && (ldb % 8 != 0 || stride_e % 8 != 0)) || (int64_t)N * b_row >= (1ll << 32) || 264ll * K * 2 >= (1ll << 32) ||
       256ll * Nout * 2 + 512 >= (1ll << 31) ||
-      (w4 == 1 && ((uintptr_t)scales % 2 != 0 || (int64_t)N * (K / 128) * 2 >= (1ll << 31))) ||
+      (w4 == 1 && (group_shift < 5 || group_shift > 8 || (uintptr_t)scales % 2 != 0 || (uintptr_t)zeros % 2 != 0 ||
+                   (int64_t)N * (K >> group_shift) * 2 >= (1ll << 31))) ||
       (w4 == 2 && (int64_t)N * (K / 32) >= (1ll << 31)))
     return 0;
   MpParams p;
-  p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.rows = rows;
+  p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.gshift = group_shift;  p.rows = rows;
   p.E = E;  p.N = N;  p.K = K;  p.fuse = fuse;  p.act_limit = act_limit;  p.ldb = ldb;  p.stride_e = stride_e;
   int rc;
-  if (dtype == SGLK_BF16) rc = w4 == 2 ? launch_persist<bf16, 2>(st, p) : w4 ? launch_persist<bf16, 1>(st, p) : launch_persist<bf16, 0>(st, p);
-  else rc = w4 ? launch_persist<f16, 1>(st, p) : launch_persist<f16, 0>(st, p);
+  const int fmt = w4 == 1 && zeros != nullptr ? 3 : w4;
+  if (dtype == SGLK_BF16)
+    rc = fmt == 3 ? launch_persist<bf16, 3>(st, p) : fmt == 2 ? launch_persist<bf16, 2>(st, p)
+         : fmt == 1 ? launch_persist<bf16, 1>(st, p) : launch_persist<bf16, 0>(st, p);
+  else
+    rc = fmt == 3 ? launch_persist<f16, 3>(st, p) : fmt == 1 ? launch_persist<f16, 1>(st, p) : launch_persist<f16, 0>(st, p);
   return rc ? rc : 1;
 }
 

@@ -43,7 +43,8 @@
 
 namespace sglk {
 // moe_persist.hip: the dense tile pipeline for prefill row counts (returns 1 after launching, 0 if the shape does not qualify)
-int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const float* bias,
+int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const void* zeros,
+                    int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
                     int fuse, float act_limit);
 namespace {
@@ -962,8 +963,8 @@ extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, co
   if (total_m == 0) return SGLK_OK;
   const int gs = !is_int4 ? -1 : group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : 8;
   hipStream_t st = (hipStream_t)stream;
-  if ((is_int4 && group_size == 128 && zeros == nullptr) || !is_int4) {
-    if (int rc = moe_persist_try(st, out, activations, packed_weights, scales, bias, rows_per_expert, total_m, (int)n_experts,
+  {
+    if (int rc = moe_persist_try(st, out, activations, packed_weights, scales, is_int4 ? zeros : nullptr, gs, bias, rows_per_expert, total_m, (int)n_experts,
                                  (int)N, (int)K, 0, 0, dtype, is_int4 ? 1 : 2, fused_act, act_limit)) {
       if (rc < 0) return rc;
       // the experts' last rows (at most 128 each) on the streaming kernels, sized for the worst case
