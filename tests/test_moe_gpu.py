@@ -429,6 +429,28 @@ def test_grouped_mm_16bit(sglk, dev, dt, rows, N, K, with_bias):
     torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=2e-2, atol=2e-3)
 
 
+def test_grouped_mm_many_experts_tile_pipeline(sglk, dev):
+    """moe_persist.hip beyond one wave of experts (72: two passes of the 64-lane prefix sums), with empty experts, one-row
+    experts, a 3000-row expert, and the shortest K it takes (two 64-deep blocks); 16-bit and int4 weights."""
+    g = torch.Generator().manual_seed(72)
+    E, N, K, dt = 72, 256, 128, torch.bfloat16
+    rows = [200 + 7 * (i % 9) for i in range(E)]
+    rows[3], rows[40], rows[65], rows[70] = 0, 1, 3000, 0
+    total = sum(rows)
+    act = (torch.randn(total, K, generator=g) * 0.1).to(dt)
+    r = torch.tensor(rows, dtype=torch.int32)
+    w = (torch.randn(E, N, K, generator=g) * 0.1).to(dt)
+    out = torch.full((total, N), float("nan"), dtype=dt, device=dev)
+    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, act.to(dev), w.to(dev), None, r.to(dev), E, 0, False, 1.702, 7.0)
+    torch.testing.assert_close(out.cpu().float(), omoe.moe_grouped_mm(act, w, None, r).float(), rtol=2e-2, atol=2e-3)
+    packed, scales, _ = make_int4(E, N, K, 128, dt, False, g)
+    out4 = torch.full((total, N), float("nan"), dtype=dt, device=dev)
+    torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(out4, act.to(dev), packed.to(dev), scales.to(dev), None, None, r.to(dev), E,
+                                                      True, 128)
+    ref4 = omoe.moe_grouped_mm_w4a16(act, packed, scales, None, None, r, 128)
+    torch.testing.assert_close(out4.cpu(), ref4, rtol=5e-2, atol=2e-2)
+
+
 def test_grouped_mm_16bit_fused_act(sglk, dev):
     g = torch.Generator().manual_seed(5)
     _check_fused_act_16bit(sglk, dev, g, [5, 0, 9, 1, 40, 2, 2, 7], 256, 512)
