@@ -54,6 +54,10 @@ struct MpParams {
   const void* scales;   // int4: [E][N][K/group] in the activation type; mxfp4: [E][N][K/32] E8M0 bytes
   const void* zeros;    // int4 with zero points (FMT 3): [E][N][K/group] in the activation type, codes unsigned
   int gshift;           // int4: log2(group)
+  uint32_t* stamps;     // diagnostic (sglk_diag_set_moe_clock_stamps): per workgroup {shader cycles, 100 MHz ticks, K blocks, MS}
+  int prio47;           // s_setprio value of waves 4..7 (0..3)
+  int blocks128;        // MS = 2 launch: 0 = only the <= 128-row remainders of 256-row blocks; 1 = all rows in 128-row blocks
+                        // (remainders of at most 64 rows excepted: the caller's streaming kernels take them)
   const int32_t* rows;  // [E]
   int E, N, K, fuse;    // fuse: 0 none, 1 silu, 2 gelu (tanh), 3 relu2, 4 clamped swiglu (1, 2, 4 gated: N = gate + up rows)
   float act_limit;
@@ -96,7 +100,9 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
 
   // ---- the tiles: MB row blocks (all experts) x NB column blocks, column blocks fastest; XCD x owns a contiguous run
   // row blocks of an expert with r rows in THIS launch
-  auto blocks_of = [](int r) -> int {
+  const bool b128 = MS == 2 && p.blocks128 != 0;
+  auto blocks_of = [&](int r) -> int {
+    if (b128) return (r >> 7) + ((r & 127) > 64 ? 1 : 0);
     const int full = r >> 8, tail = r & 255;
     return MS == 4 ? full + (tail > 128 ? 1 : 0) : ((tail > 0 && tail <= 128) ? 1 : 0);
   };
@@ -106,6 +112,16 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     MB += __shfl(wave_inclusive_scan(blocks_of(r), lane), 63, 64);
   }
   MB = __builtin_amdgcn_readfirstlane(MB);
+  // The two waves of a SIMD (w, w + 4) share its matrix pipe and issue ports; at equal priority the older one wins every
+  // arbitration: stamps at the blocks' barriers showed waves 0..3 waiting ~1250 of a block's ~4100 cycles for waves 4..7.
+  // A static priority for waves 4..7 swaps the roles exactly (they then wait 1350 cycles for waves 0..3) and leaves the
+  // block time where it was; kept as a diagnostic knob, off by default.
+  if (wave >= 4) {
+    if (p.prio47 == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p.prio47 == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.prio47 == 3) __builtin_amdgcn_s_setprio(3);
+  }
+  const uint64_t st_c0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   const int nt = MB * NB;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int q8 = nt >> 3, rem = nt & 7;
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     e = __builtin_amdgcn_readfirstlane(e);
     blk = __builtin_amdgcn_readfirstlane(blk);
     rows_e = __builtin_amdgcn_readfirstlane(rows_e);
-    const int first = MS == 4 ? blk * kBM : (rows_e & ~255);  // first row of the block inside its expert
+    const int first = MS == 4 ? blk * kBM : b128 ? blk * 128 : (rows_e & ~255);  // first row of the block inside its expert
     const int m0 = __builtin_amdgcn_readfirstlane(row0) + first;
     int rows_a = rows_e - first;
     rows_a = rows_a < MS * 64 ? rows_a : MS * 64;
@@ -334,6 +350,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   v4i nq[2][4];  // [n-fragment][k-step]
   v4i mq[4];     // [k-step] of the running m-fragment (each re-read right behind its second MFMA)
   int gblk = 0;
+  uint32_t st_own = 0, st_bar = 0;
 
   // m-step mf of a K block: k-steps s = 0..3, two MFMAs each. LAST: behind the block's barrier; its gaps carry the reads of the
   // next block's fragments (per k-step: n0, n1, m). WR: the step that ends with the int4 producer's 4 LDS stores (the step
@@ -364,22 +381,12 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
         MP_RD16(nq[0][s_], nb0 ^ x_, 0);                                                                       \
         MP_RD16(nq[1][s_], nb0 ^ x_, 4096);                                                                    \
         MP_RD16(mq[s_], na0 ^ x_, 0);                                                                          \
-        if (s_ < 2) dma_piece(d2, kb2, s, 0, s_);                                                              \
+        /* (all of a's pieces of block + 2 go out here, a whole block ahead of their barrier: with parts 1..3 in the */ \
+        /* next block's first two steps the wait at the barrier cost ~2100 cycles per block)                      */ \
+        dma_piece(d2, kb2, s, s_ >> 1, s_ & 1);                                                                \
       } else {                                                                                                 \
         MP_RD16(mq[s_], a0 ^ (uint32_t)(s_ << 5), ((mf) + 1) * 4096);                                          \
-        if (MS == 4) {                                                                                         \
-          if ((mf) == 0 && s_ == 0) dma_piece(d1, kb1, s ^ 1, 1, 0);                                           \
-          if ((mf) == 0 && s_ == 1) dma_piece(d1, kb1, s ^ 1, 1, 1);                                           \
-          if ((mf) == 0 && s_ == 2) dma_piece(d1, kb1, s ^ 1, 2, 0);                                           \
-          if ((mf) == 1 && s_ == 0) dma_piece(d1, kb1, s ^ 1, 2, 1);                                           \
-          if ((mf) == 1 && s_ == 1) dma_piece(d1, kb1, s ^ 1, 3, 0);                                           \
-          if ((mf) == 1 && s_ == 2) dma_piece(d1, kb1, s ^ 1, 3, 1);                                           \
-        } else {                                                                                               \
-          if (s_ == 0) { dma_piece(d1, kb1, s ^ 1, 1, 0); dma_piece(d1, kb1, s ^ 1, 1, 1); }                   \
-          if (s_ == 1) { dma_piece(d1, kb1, s ^ 1, 2, 0); dma_piece(d1, kb1, s ^ 1, 2, 1); }                   \
-          if (s_ == 2) dma_piece(d1, kb1, s ^ 1, 3, 0);                                                        \
-          if (s_ == 3) dma_piece(d1, kb1, s ^ 1, 3, 1);                                                        \
-        }                                                                                                      \
+        if ((mf) == 0) dma_piece(d1, kb1, s ^ 1, 2 + (s_ >> 1), s_ & 1); /* (16-bit weights: the b pieces) */    \
       }                                                                                                        \
       if (W4 && !(LAST) && MS == 4 && (mf) < 2 && (s_ == 0 || s_ == 2)) expand(raw_c, sraw_c, 2 * (mf) + (s_ >> 1)); \
       if (W4 && !(LAST) && MS == 2) expand(raw_c, sraw_c, s_);                                                 \
@@ -410,6 +417,15 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     load_raw(d2, kb2, raw_n, sraw_n);                                                                          \
     if constexpr (MS == 4) { MP_STEP(0, STORE, false, false) MP_STEP(1, STORE, false, false) MP_STEP(2, STORE, false, true) } \
     else { MP_STEP(0, STORE, false, true) }                                                                    \
+    if (FMT <= 1 && p.stamps != nullptr) { /* diagnostic: where the block's barrier time goes (own data / the other waves) */ \
+      const uint64_t t0_ = __builtin_amdgcn_s_memtime();                                                       \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
+      const uint64_t t1_ = __builtin_amdgcn_s_memtime();                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
+      const uint64_t t2_ = __builtin_amdgcn_s_memtime();                                                       \
+      st_own += (uint32_t)(t1_ - t0_);                                                                         \
+      st_bar += (uint32_t)(t2_ - t1_);                                                                         \
+    } else                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     {                                                                                                          \
@@ -461,6 +477,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   }
   dma_piece(cur_t, 1, 1, 0, 0);
   dma_piece(cur_t, 1, 1, 0, 1);
+  dma_piece(cur_t, 1, 1, 1, 0);
+  dma_piece(cur_t, 1, 1, 1, 1);
 
   for (; unit < n_units; ++unit) {
     const MpTile nxt = describe(unit + 1);
@@ -479,21 +497,33 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[MS - 1][0]), "+v"(acc[MS - 1][1]));
 #pragma unroll
   for (int mf = 0; mf < MS; ++mf) store_frag(prv, acc[mf], mf);
+  if (p.stamps != nullptr && lane == 0) {
+    const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (wave == 0) {
+      uint32_t* o = p.stamps + blockIdx.x * 4;
+      o[0] = (uint32_t)(c1 - st_c0);  o[1] = (uint32_t)(r1 - st_r0);  o[2] = (uint32_t)(n_units * nkb);  o[3] = MS;
+    }
+    uint32_t* w = p.stamps + 1024 + (blockIdx.x * 8 + wave) * 2;  // per wave: cycles waiting for its own data / at the barrier
+    w[0] = st_own;  w[1] = st_bar;
+  }
 #undef MP_MFMA
 #undef MP_RD16
 #undef MP_WR16
 }
 
+static uint32_t* g_mp_stamps = nullptr;  // sglk_diag_set_moe_clock_stamps
+static int g_mp_prio47 = 0;  // (sglk_diag_set_moe_prio: 1..3 swaps which half waits, the block time stays - DESIGN 4.10)
 #ifdef SGLK_PROBES
 static int g_mp_own_tails = 0;
 #else
 constexpr int g_mp_own_tails = 0;
 #endif
+constexpr int kMinAvgRows128 = 96;  // ... and with 128-row blocks
 #ifdef SGLK_PROBES
 static int g_mp_min_avg_rows = 192;
 #define kMinAvgRows g_mp_min_avg_rows
 #else
-constexpr int kMinAvgRows = 192;  // average rows per expert from which the tile pipeline takes over
+constexpr int kMinAvgRows = 192;  // average rows per expert from which the tile pipeline takes over with 256-row blocks
 #endif
 
 
@@ -504,6 +534,10 @@ static int launch_persist(hipStream_t st, const MpParams& p) {
     return rc;
   if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 2>), 2 * kStage, &attr_done2, "moe_persist"))
     return rc;
+  if (p.blocks128) {  // 96 .. 191 rows per expert on average: 128-row blocks
+    moe_persist_kernel<T, W4, 2><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
+    return 0;
+  }
   moe_persist_kernel<T, W4, 4><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
   // Remainders of at most 128 rows: the callers run their streaming kernels over them (moe_tiles.h, tail mode) - a few
   // dozen rows per expert are a weight stream, 70 us for the Mixtral down projection against 275 us as 128-row tiles here
@@ -515,14 +549,16 @@ static int launch_persist(hipStream_t st, const MpParams& p) {
 }  // namespace
 
 // Called by sglk_moe_grouped_mm / sglk_moe_grouped_mm_w4a16_act. Returns 0 when the shape does not qualify (the caller goes
-// on with its streaming kernels), 1 after launching, a negative error code on failure.
+// on with its streaming kernels), 1 after launching 256-row blocks (the caller runs the tails in kMoeTailFlag mode), 2 after
+// launching 128-row blocks (kMoeTailFlag128), a negative error code on failure.
 int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const void* zeros,
                     int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
                     int fuse, float act_limit) {
   const bool gated = fuse == 1 || fuse == 2 || fuse == 4;
   const int Nout = gated ? N / 2 : N;
-  if (bias != nullptr || total_m < (int64_t)kMinAvgRows * E || num_cus() % 8 != 0) return 0;
+  if (bias != nullptr || total_m < (int64_t)kMinAvgRows128 * E || num_cus() % 8 != 0) return 0;
+  const bool blocks128 = total_m < (int64_t)kMinAvgRows * E;
   if (w4 == 2 && dtype != SGLK_BF16) return 0;  // (the fp4 conversion instruction is used in its bf16 form)
   if (K % 64 != 0 || K < 128 || N % 8 != 0 || (gated && (N % 64 != 0)) || (uintptr_t)out % 16 != 0 ||
       (uintptr_t)act % 16 != 0 || (uintptr_t)w % 16 != 0 || Nout % 8 != 0)
@@ -535,6 +571,9 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
       (w4 == 2 && (int64_t)N * (K / 32) >= (1ll << 31)))
     return 0;
   MpParams p;
+  p.blocks128 = blocks128 ? 1 : 0;
+  p.stamps = g_mp_stamps;
+  p.prio47 = g_mp_prio47;
   p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.gshift = group_shift;  p.rows = rows;
   p.E = E;  p.N = N;  p.K = K;  p.fuse = fuse;  p.act_limit = act_limit;  p.ldb = ldb;  p.stride_e = stride_e;
   int rc;
@@ -544,10 +583,13 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
          : fmt == 1 ? launch_persist<bf16, 1>(st, p) : launch_persist<bf16, 0>(st, p);
   else
     rc = fmt == 3 ? launch_persist<f16, 3>(st, p) : fmt == 1 ? launch_persist<f16, 1>(st, p) : launch_persist<f16, 0>(st, p);
-  return rc ? rc : 1;
+  return rc ? rc : (blocks128 ? 2 : 1);
 }
 
 }  // namespace sglk
+
+extern "C" void sglk_diag_set_moe_clock_stamps(uint32_t* device_buf) { sglk::g_mp_stamps = device_buf; }
+extern "C" SGLK_API void sglk_diag_set_moe_prio(int prio) { sglk::g_mp_prio47 = prio; }
 
 #ifdef SGLK_PROBES
 extern "C" SGLK_API void sglk_debug_set_moe_persist_min_rows(int rows) { sglk::g_mp_min_avg_rows = rows; }

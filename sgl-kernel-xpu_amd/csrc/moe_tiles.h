@@ -36,22 +36,24 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
 // cols_fast: consecutive tiles (= the workgroups resident on one XCD at a time) walk the column blocks of ONE row block and
 // share its activations in that XCD's L2; otherwise they walk the row blocks of one column block. The larger operand of a
 // tile should be the shared one: 64 rows x K 16-bit activations against 128 columns x K / 2 bytes of 4-bit weights.
-// Tail mode (bit 30 of E, kMoeTailFlag): the launch covers only what the tile pipeline of moe_persist.hip leaves over - of every
-// expert the rows behind its last full 256-row block when they are at most 128 (more are a block of their own there).
-constexpr int kMoeTailFlag = 1 << 30;
-__device__ __forceinline__ int moe_tail_rows(int r) {
-  const int t = r & 255;
-  return t <= 128 ? t : 0;
+// Tail mode (bit 30 or 29 of E: kMoeTailFlag / kMoeTailFlag128): the launch covers only what the tile pipeline of
+// moe_persist.hip leaves over - of every expert the rows behind its last full block of B = 256 (128) rows when they are at
+// most B / 2 (more are a block of their own there).
+constexpr int kMoeTailFlag = 1 << 30, kMoeTailFlag128 = 1 << 29;
+__host__ __device__ __forceinline__ int moe_tail_rows(int r, int B) {
+  const int t = r & (B - 1);
+  return t <= B / 2 ? t : 0;
 }
 __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ rows_per_expert, int E, int BM, int NB,
                                                  bool cols_fast = false) {
   const int lane = threadIdx.x & 63;
-  const bool tail_mode = (E & kMoeTailFlag) != 0;
-  E &= ~kMoeTailFlag;
+  const bool tail_mode = (E & (kMoeTailFlag | kMoeTailFlag128)) != 0;
+  const int tail_b = (E & kMoeTailFlag) ? 256 : 128;
+  E &= ~(kMoeTailFlag | kMoeTailFlag128);
   int MB = 0;
   for (int c0 = 0; c0 < E; c0 += 64) {
     const int r = c0 + lane < E ? rows_per_expert[c0 + lane] : 0;
-    const int rr = tail_mode ? moe_tail_rows(r) : r;
+    const int rr = tail_mode ? moe_tail_rows(r, tail_b) : r;
     MB += __shfl(wave_inclusive_scan((rr + BM - 1) / BM, lane), 63, 64);
   }
   MB = __builtin_amdgcn_readfirstlane(MB);
@@ -66,7 +68,7 @@ __device__ __forceinline__ MoeTile find_moe_tile(const int32_t* __restrict__ row
   int e = 0, row0 = 0, rows_e = 0, blk = 0, base_b = 0, base_r = 0;
   for (int c0 = 0; c0 < E; c0 += 64) {
     const int r = c0 + lane < E ? rows_per_expert[c0 + lane] : 0;
-    const int rr = tail_mode ? moe_tail_rows(r) : r;
+    const int rr = tail_mode ? moe_tail_rows(r, tail_b) : r;
     const int nb = (rr + BM - 1) / BM;
     const int ib = wave_inclusive_scan(nb, lane), ir = wave_inclusive_scan(r, lane);
     const bool hit = mblk >= base_b + ib - nb && mblk < base_b + ib;

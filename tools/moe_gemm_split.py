@@ -20,6 +20,29 @@ w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
 w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
 s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01
 s2 = torch.rand(E, Hd, I // gs, device=dev).to(torch.bfloat16) * 0.01
+import ctypes
+lib = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "python", "sgl_kernel", "libsglk.so"))
+lib.sglk_diag_set_moe_clock_stamps.argtypes = [ctypes.c_void_p]
+stamps = torch.zeros(256 * 4 + 256 * 8 * 2, dtype=torch.int32, device=dev)
+
+
+def clock_of(f):
+    lib.sglk_diag_set_moe_clock_stamps(stamps.data_ptr())
+    for _ in range(5): f()
+    torch.cuda.synchronize()
+    lib.sglk_diag_set_moe_clock_stamps(None)
+    hst = stamps.cpu()
+    st = hst[:1024].view(256, 4).double()
+    ok = st[:, 1] > 0
+    wv = hst[1024:].view(256, 8, 2).double()[ok] / st[ok][:, 2].view(-1, 1, 1)   # per K block
+    st = st[ok]
+    return (f"{(100 * st[:, 0] / st[:, 1]).median().item():.0f} MHz, {(st[:, 0] / st[:, 2]).median().item():.0f} cycles per K block; "
+            f"per wave and block: own-data wait waves 0-3 {wv[:, :4, 0].mean().item():.0f} / 4-7 {wv[:, 4:, 0].mean().item():.0f}, "
+            f"barrier wait {wv[:, :4, 1].mean().item():.0f} / {wv[:, 4:, 1].mean().item():.0f}")
+
+
+if os.environ.get("MOE_PRIO"):
+    lib.sglk_diag_set_moe_prio(int(os.environ["MOE_PRIO"]))
 for T in (int(a) for a in (sys.argv[1:] or ["2048"])):
     total = T * topk
     ti = torch.randn(T, E, device=dev).topk(topk, dim=-1).indices
@@ -34,5 +57,8 @@ for T in (int(a) for a in (sys.argv[1:] or ["2048"])):
         gu = torch.empty(total, 2 * I, device=dev, dtype=torch.bfloat16)
         t3 = timeit(lambda: op.moe_grouped_mm_nt_xe20_w4a16(gu, x, w1, s1, None, None, rows, E, True, gs))
         del gu
+        if total >= 96 * E:
+            print("   gate/up:", clock_of(lambda: op.moe_grouped_mm_nt_w4a16_act(h, x, w1, s1, None, None, rows, E, True, gs, 1, 0.0)),
+                  "| down:", clock_of(lambda: op.moe_grouped_mm_nt_xe20_w4a16(y, h, w2, s2, None, None, rows, E, True, gs)))
         fl1, fl2 = 2.0 * total * 2 * I * Hd, 2.0 * total * Hd * I
         print(f"T={T} {name} rows={rows.tolist()}: gate/up {t1*1e3:.0f} us ({fl1/t1/1e9:.0f} TFLOP/s)  down {t2*1e3:.0f} us ({fl2/t2/1e9:.0f} TFLOP/s)  gate/up without the activation {t3*1e3:.0f} us")
