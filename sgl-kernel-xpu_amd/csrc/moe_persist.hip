@@ -70,7 +70,7 @@ struct MpTile {
   const char* ps;  // the expert's scales (+ the tile's first weight row)
   const char* pz;  // the expert's zero points (FMT 3)
   char* po;        // first output element of the tile
-  uint32_t nrec_a, nrec_b, nrec_o;
+  uint32_t nrec_a, nrec_b, nrec_o, nrec_s;  // bytes in range (0: nothing); nrec_s: scales / zero points from ps / pz
   int ncols;       // valid output columns of the tile
 };
 
@@ -173,12 +173,15 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     // (b: the resource spans the expert's rows from the tile's first one to row N - 1: weight rows past N read zeros)
     d.nrec_b = live ? (uint32_t)((int64_t)(N - c0) * b_row) : 0u;
     d.nrec_o = live ? (uint32_t)(((int64_t)(rows_a - 1) * Nout + cols) * 2) : 0u;
+    // (weight rows past N of an edge tile: their scales lie past the tensor too - out of range, read as zero)
+    d.nrec_s = (live && W4) ? (uint32_t)((int64_t)(N - c0) * kgroups * kSB) : 0u;
     return d;
   };
   auto pick = [](bool c, const MpTile& x, const MpTile& y) -> MpTile {
     MpTile d;
     d.pa = c ? x.pa : y.pa;  d.pb = c ? x.pb : y.pb;  d.ps = c ? x.ps : y.ps;  d.pz = c ? x.pz : y.pz;  d.po = c ? x.po : y.po;
     d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_o = c ? x.nrec_o : y.nrec_o;
+    d.nrec_s = c ? x.nrec_s : y.nrec_s;
     d.ncols = c ? x.ncols : y.ncols;
     return d;
   };
@@ -228,13 +231,13 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       raw = __builtin_amdgcn_raw_buffer_load_b128(mp_rsrc(d.pb, d.nrec_b), (int)pvoff_w, kb * 32, 0);
       const int so = ((kb * 64) >> gshift) * kSB;
       if constexpr (FMT == 2) {
-        sr = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(mp_rsrc(d.ps, d.nrec_b == 0 ? 0u : 0x7fffffffu), (int)pvoff_s,
+        sr = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(mp_rsrc(d.ps, d.nrec_s), (int)pvoff_s,
                                                                      so, 0);
       } else {
-        sr = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.ps, d.nrec_b == 0 ? 0u : 0x7fffffffu),
+        sr = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.ps, d.nrec_s),
                                                                        (int)pvoff_s, so, 0);
         if constexpr (FMT == 3)  // (zero point in the high half)
-          sr |= (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.pz, d.nrec_b == 0 ? 0u : 0x7fffffffu),
+          sr |= (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(mp_rsrc(d.pz, d.nrec_s),
                                                                           (int)pvoff_s, so, 0) << 16;
       }
     }
