@@ -134,7 +134,8 @@ SGLK_API int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const
 SGLK_API void sglk_diag_set_gemm_clock_stamps(uint32_t* device_buf);
 /* The same for the tile pipeline of the grouped MoE GEMMs (csrc/moe_persist.hip): 256 x 4 uint32, one record per workgroup of
  * the last launch, followed by 256 x 8 x 2 uint32: per wave the shader cycles spent in front of the K blocks' barriers waiting
- * for its own LDS-DMA / LDS data, and at the barriers themselves (5120 uint32 in all). */
+ * for its own LDS-DMA / LDS data, and at the barriers themselves (5120 uint32 in all; the per-wave part is filled by the
+ * diagnostic build of the library only). */
 SGLK_API void sglk_diag_set_moe_clock_stamps(uint32_t* device_buf);
 /* Diagnostic: s_setprio value (0..3) of waves 4..7 of that kernel's workgroups (default 0). */
 SGLK_API void sglk_diag_set_moe_prio(int prio);

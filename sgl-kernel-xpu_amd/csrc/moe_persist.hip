@@ -88,7 +88,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int K = p.K, N = p.N;
   const int nkb = K >> 6;  // >= 2
-  const bool gated = p.fuse == 1 || p.fuse == 2 || p.fuse == 4;
+  // (an opaque scalar: left as an expression the compiler re-evaluates `fuse` with a branch ladder at every use inside the K loop)
+  const bool gated = __builtin_amdgcn_readfirstlane((int)(p.fuse == 1 || p.fuse == 2 || p.fuse == 4)) != 0;
   const int Nout = gated ? N >> 1 : N;
   const int NB = gated ? (Nout + 127) >> 7 : (N + kBN - 1) / kBN;
   const int64_t a_row = (int64_t)K * 2;                                   // bytes
@@ -198,18 +199,24 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     voff_a[par] = (uint32_t)(lane >> 3) * (uint32_t)a_row + ch;
     voff_b[par] = (uint32_t)(lane >> 3) * (uint32_t)b_row + ch;
   }
-  // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = weight rows (16-bit weights only), sub 0, 1 each
+  // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = weight rows (16-bit weights only), sub 0, 1 each.
+  // The piece's row offset inside its tile is a per-wave constant (scalar registers, set once).
+  int a_poff[4], b_poff[4];
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    a_poff[ii] = __builtin_amdgcn_readfirstlane((wave * 4 + ii) * 8 * (int)a_row);
+    b_poff[ii] = __builtin_amdgcn_readfirstlane(wrow_of((wave * 4 + ii) * 8) * (int)b_row);  // (8 slots of a piece = 8 consecutive rows)
+  }
   auto dma_piece = [&](const MpTile& d, int kb, int s, int part, int sub) {
     char* base = smem + s * kStage;
     const int ii = (part & 1) * 2 + sub, piece = wave * 4 + ii;
     if (part < 2) {
       if (MS == 2 && wave >= 4) return;  // (rows 128.. of the a tile do not exist)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pa, d.nrec_a), MP_LDS(base + piece * 1024), 16, voff_a[ii & 1],
-                                               kb * kBKB + piece * 8 * (int)a_row, 0, 0);
+                                               kb * kBKB + a_poff[ii], 0, 0);
     } else if constexpr (!W4) {
-      const int wr = __builtin_amdgcn_readfirstlane(wrow_of(piece * 8));  // (8 slots of a piece are 8 consecutive weight rows)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pb, d.nrec_b), MP_LDS(base + kTile + piece * 1024), 16,
-                                               voff_b[ii & 1], kb * kBKB + wr * (int)b_row, 0, 0);
+                                               voff_b[ii & 1], kb * kBKB + b_poff[ii], 0, 0);
     }
   };
 
@@ -353,6 +360,11 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   v4i nq[2][4];  // [n-fragment][k-step]
   v4i mq[4];     // [k-step] of the running m-fragment (each re-read right behind its second MFMA)
   int gblk = 0;
+#ifdef SGLK_PROBES
+  constexpr bool kBarStamps = FMT <= 1;  // (the per-wave barrier stamps: diagnostic build, 16-bit and plain int4 weights)
+#else
+  constexpr bool kBarStamps = false;
+#endif
   uint32_t st_own = 0, st_bar = 0;
 
   // m-step mf of a K block: k-steps s = 0..3, two MFMAs each. LAST: behind the block's barrier; its gaps carry the reads of the
@@ -420,14 +432,18 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     load_raw(d2, kb2, raw_n, sraw_n);                                                                          \
     if constexpr (MS == 4) { MP_STEP(0, STORE, false, false) MP_STEP(1, STORE, false, false) MP_STEP(2, STORE, false, true) } \
     else { MP_STEP(0, STORE, false, true) }                                                                    \
-    if (FMT <= 1 && p.stamps != nullptr) { /* diagnostic: where the block's barrier time goes (own data / the other waves) */ \
-      const uint64_t t0_ = __builtin_amdgcn_s_memtime();                                                       \
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
-      const uint64_t t1_ = __builtin_amdgcn_s_memtime();                                                       \
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
-      const uint64_t t2_ = __builtin_amdgcn_s_memtime();                                                       \
-      st_own += (uint32_t)(t1_ - t0_);                                                                         \
-      st_bar += (uint32_t)(t2_ - t1_);                                                                         \
+    if constexpr (kBarStamps) { /* diagnostic build: where the block's barrier time goes (own data / the other waves) */ \
+      if (p.stamps != nullptr) {                                                                               \
+        const uint64_t t0_ = __builtin_amdgcn_s_memtime();                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
+        const uint64_t t1_ = __builtin_amdgcn_s_memtime();                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                       \
+        const uint64_t t2_ = __builtin_amdgcn_s_memtime();                                                     \
+        st_own += (uint32_t)(t1_ - t0_);                                                                       \
+        st_bar += (uint32_t)(t2_ - t1_);                                                                       \
+      } else {                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
+      }                                                                                                        \
     } else                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
     __builtin_amdgcn_sched_barrier(0);                                                                         \

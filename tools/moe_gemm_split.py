@@ -37,8 +37,8 @@ def clock_of(f):
     wv = hst[1024:].view(256, 8, 2).double()[ok] / st[ok][:, 2].view(-1, 1, 1)   # per K block
     st = st[ok]
     return (f"{(100 * st[:, 0] / st[:, 1]).median().item():.0f} MHz, {(st[:, 0] / st[:, 2]).median().item():.0f} cycles per K block; "
-            f"per wave and block: own-data wait waves 0-3 {wv[:, :4, 0].mean().item():.0f} / 4-7 {wv[:, 4:, 0].mean().item():.0f}, "
-            f"barrier wait {wv[:, :4, 1].mean().item():.0f} / {wv[:, 4:, 1].mean().item():.0f}")
+            f"per wave and block (diagnostic build of the library only): own-data wait waves 0-3 {wv[:, :4, 0].mean().item():.0f} / 4-7 "
+            f"{wv[:, 4:, 0].mean().item():.0f}, barrier wait {wv[:, :4, 1].mean().item():.0f} / {wv[:, 4:, 1].mean().item():.0f}")
 
 
 if os.environ.get("MOE_PRIO"):
