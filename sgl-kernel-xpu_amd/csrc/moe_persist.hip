@@ -249,17 +249,24 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       }
     }
   };
-  v4i wexp[4];
-  auto expand = [&](const v4i& raw, uint32_t sr, int q) {  // dword q of the 16 bytes -> 8 values -> wexp[q]
+  // dword q of the 16 bytes -> 8 values -> chunk 4 half + q of the thread's row of the b tile at wb (stored at once: keeping the
+  // four results of a block in registers until the block's barrier cost 12 registers and, with the staggered schedule, spills)
+  auto expand = [&](const v4i& raw, uint32_t sr, int q, uint32_t wb) {
+    v4i wx;
+    auto put = [&]() {
+      const uint32_t ad = wb + ((((uint32_t)(4 * phalf + q)) ^ pkey) << 4);
+      asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(wx) : "memory");
+    };
     if constexpr (FMT == 2) {
       // v_cvt_scalef32_pk_bf16_fp4: the two e2m1 codes of byte b (low nibble first) times 2^(E8M0 - 127), exact (moe_w4a16.hip)
       typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
       const float sc = __uint_as_float(sr ? sr << 23 : 0x00400000u);
       const uint32_t wd = (uint32_t)raw[q];
-      wexp[q][0] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 0));
-      wexp[q][1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 1));
-      wexp[q][2] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 2));
-      wexp[q][3] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 3));
+      wx[0] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 0));
+      wx[1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 1));
+      wx[2] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 2));
+      wx[3] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(wd, sc, 3));
+      put();
       return;
     }
     if constexpr (FMT == 3) {  // unsigned codes: (code - zero) * scale, rounded once
@@ -270,8 +277,9 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       for (int b = 0; b < 4; ++b) {
         const float f0 = ((float)(uint8_t)(x >> (8 * b)) - zp) * sc, f1 = ((float)(uint8_t)(y >> (8 * b)) - zp) * sc;
         const T t0 = (T)f0, t1 = (T)f1;
-        wexp[q][b] = (int)((uint32_t)__builtin_bit_cast(uint16_t, t0) | ((uint32_t)__builtin_bit_cast(uint16_t, t1) << 16));
+        wx[b] = (int)((uint32_t)__builtin_bit_cast(uint16_t, t0) | ((uint32_t)__builtin_bit_cast(uint16_t, t1) << 16));
       }
+      put();
       return;
     }
     const float s16 = (float)__builtin_bit_cast(T, (uint16_t)sr) * 0.0625f;
@@ -281,8 +289,9 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     for (int b = 0; b < 4; ++b) {
       const float f0 = (float)(int8_t)(x >> (8 * b)) * s16, f1 = (float)(int8_t)(y >> (8 * b)) * s16;
       const T t0 = (T)f0, t1 = (T)f1;
-      wexp[q][b] = (int)((uint32_t)__builtin_bit_cast(uint16_t, t0) | ((uint32_t)__builtin_bit_cast(uint16_t, t1) << 16));
+      wx[b] = (int)((uint32_t)__builtin_bit_cast(uint16_t, t0) | ((uint32_t)__builtin_bit_cast(uint16_t, t1) << 16));
     }
+    put();
   };
 
   // ---- fragment addressing (byte offsets inside a stage): lane (i, h): row i, chunk (2 s + h) ^ key(row) = (chunk h) ^ (s << 5)
@@ -403,15 +412,12 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
         MP_RD16(mq[s_], a0 ^ (uint32_t)(s_ << 5), ((mf) + 1) * 4096);                                          \
         if ((mf) == 0) dma_piece(d1, kb1, s ^ 1, 2 + (s_ >> 1), s_ & 1); /* (16-bit weights: the b pieces) */    \
       }                                                                                                        \
-      if (W4 && !(LAST) && MS == 4 && (mf) < 2 && (s_ == 0 || s_ == 2)) expand(raw_c, sraw_c, 2 * (mf) + (s_ >> 1)); \
-      if (W4 && !(LAST) && MS == 2) expand(raw_c, sraw_c, s_);                                                 \
-    }                                                                                                          \
-    if constexpr (W4 && (WR)) { /* the producer's 64 bytes of the next block's b tile (the barrier follows) */  \
-      const uint32_t wb_ = nbase + (uint32_t)kTile + pwr;                                                      \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                       \
-        const uint32_t ad_ = wb_ + ((((uint32_t)(4 * phalf + q_)) ^ pkey) << 4);                               \
-        MP_WR16(ad_, wexp[q_]);                                                                                \
-      }                                                                                                        \
+      /* the two waves of a SIMD (w, w + 4) run this stream in lockstep: with the expansion in the same gaps of both, its   */ \
+      /* VALU time adds to the block (neither has MFMAs ready for the other's VALU phase). Waves 0..3 expand in step 0,    */ \
+      /* waves 4..7 in step 2: each one's VALU phase lies beside the other's bare MFMAs.                                   */ \
+      if (W4 && !(LAST) && MS == 4 && (((mf) == 0 && wave < 4) || ((mf) == 2 && wave >= 4)))                               \
+        expand(raw_c, sraw_c, s_, nbase + (uint32_t)kTile + pwr);                                              \
+      if (W4 && !(LAST) && MS == 2) expand(raw_c, sraw_c, s_, nbase + (uint32_t)kTile + pwr);                  \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
@@ -474,12 +480,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     load_raw(cur_t, 0, raw_c, sraw_c);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_c), "+v"(sraw_c));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) expand(raw_c, sraw_c, q);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t ad = lds_base + (uint32_t)kTile + pwr + ((((uint32_t)(4 * phalf + q)) ^ pkey) << 4);
-      MP_WR16(ad, wexp[q]);
-    }
+    for (int q = 0; q < 4; ++q) expand(raw_c, sraw_c, q, lds_base + (uint32_t)kTile + pwr);
     load_raw(cur_t, 1, raw_c, sraw_c);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -60,5 +60,12 @@ for T in (int(a) for a in (sys.argv[1:] or ["2048"])):
         if total >= 96 * E:
             print("   gate/up:", clock_of(lambda: op.moe_grouped_mm_nt_w4a16_act(h, x, w1, s1, None, None, rows, E, True, gs, 1, 0.0)),
                   "| down:", clock_of(lambda: op.moe_grouped_mm_nt_xe20_w4a16(y, h, w2, s2, None, None, rows, E, True, gs)))
+        if os.environ.get("MOE_BF16") and total >= 96 * E:
+            wb = (torch.randn(E, 2 * I, Hd, device=dev) * 0.02).to(torch.bfloat16)
+            gu = torch.empty(total, 2 * I, device=dev, dtype=torch.bfloat16)
+            fb = lambda: op.moe_grouped_mm_nt_xe20(gu, x, wb, None, rows, E, 0, False, 1.702, 7.0)
+            tb = timeit(fb)
+            print(f"   16-bit weights gate/up (no activation): {tb*1e3:.0f} us;", clock_of(fb)[:60])
+            del wb, gu
         fl1, fl2 = 2.0 * total * 2 * I * Hd, 2.0 * total * Hd * I
         print(f"T={T} {name} rows={rows.tolist()}: gate/up {t1*1e3:.0f} us ({fl1/t1/1e9:.0f} TFLOP/s)  down {t2*1e3:.0f} us ({fl2/t2/1e9:.0f} TFLOP/s)  gate/up without the activation {t3*1e3:.0f} us")
