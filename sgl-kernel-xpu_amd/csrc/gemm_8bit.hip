@@ -1203,12 +1203,14 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
 
   // fragment addressing (byte offsets inside a stage)
   const int li = lane & 31, lh = lane >> 5;
-  const int brow = ((li >> 2) & 1) * 16 + (li >> 3) * 4 + (li & 3);  // LDS row of MFMA row li inside a 32-row n-fragment
+  // LDS row of MFMA row li inside a 32-row n-fragment: register v of lane (i, h) is column 16 (v / 8) + 8 h + v % 8, so that
+  // one store instruction writes 32 contiguous bytes per row (the two h lanes side by side)
+  const int brow = (li >> 4) * 16 + ((li >> 2) & 1) * 8 + ((li >> 3) & 1) * 4 + (li & 3);
   const int frag_off_a = li * 128 + (((4 * lh) ^ ((li >> 1) & 7)) << 4);        // chunk 4h; chunks 4h + q at ^ (q << 4)
   const int frag_off_b = brow * 128 + (((4 * lh) ^ ((brow >> 1) & 7)) << 4);
 
   // stores: lane (i, h) owns row wm * 32 MS + 32 mf + i, columns wn * 64 + 32 nf + 16 h .. + 15
-  const uint32_t orow_off = (uint32_t)(((int64_t)(wm * (MS * 32) + li) * ldc + wn * 64 + lh * 16) * (int64_t)sizeof(OutT));
+  const uint32_t orow_off = (uint32_t)(((int64_t)(wm * (MS * 32) + li) * ldc + wn * 64 + lh * 8) * (int64_t)sizeof(OutT));
   auto store_frag = [&](const TileDesc& d, const float (&accm)[2][16], int mf) {
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
     const int soff = __builtin_amdgcn_readfirstlane(mf * 32 * (int)ldc * (int)sizeof(OutT));
@@ -1219,8 +1221,8 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
         Vec<OutT, 8> v;
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = (OutT)accm[nf][hv * 8 + c];
-        const uint32_t vo = (wn * 64 + nf * 32 + lh * 16 + hv * 8 < d.ncols)
-                                ? orow_off + (uint32_t)((nf * 32 + hv * 8) * (int)sizeof(OutT)) : 0x80000000u;
+        const uint32_t vo = (wn * 64 + nf * 32 + hv * 16 + lh * 8 < d.ncols)
+                                ? orow_off + (uint32_t)((nf * 32 + hv * 16) * (int)sizeof(OutT)) : 0x80000000u;
         const v4i data = __builtin_bit_cast(v4i, v);
         __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, 0);
         asm volatile("s_nop 4" ::"v"(data));  // (store data is read for a few cycles after issue: see the kernel above)
@@ -1326,13 +1328,18 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     X32_PROMOTE((mf), 0, cur0)                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
-#define X32_BLOCK(STORE)                                                                                       \
+// WHERE: 0 = any block (the tiles of blocks + 1 / + 2 picked by scalar selects: the first block of a tile), 1 = blocks + 1 and
+// + 2 inside the running tile (the steady loop: no selects between its MFMAs - with them the compiler's placement of ~40 scalar
+// instructions differed between two instantiations of this very kernel by 5.6 % of the GEMM's time), 2 = the tile's last but
+// one block, 3 = its last block.
+#define X32_BLOCK(STORE, WHERE)                                                                                \
   {                                                                                                            \
     const int s = gblk & 1;                                                                                    \
     const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);                                             \
     const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStageBytes);                                       \
-    const bool in1 = kb + 1 < nkb, in2 = kb + 2 < nkb;                                                         \
-    const TileDesc d1 = pick(in1, cur_t, nxt), d2 = pick(in2, cur_t, nxt);                                     \
+    const bool in1 = (WHERE) == 0 ? kb + 1 < nkb : (WHERE) != 3, in2 = (WHERE) == 0 ? kb + 2 < nkb : (WHERE) == 1; \
+    const TileDesc d1 = (WHERE) == 0 ? pick(in1, cur_t, nxt) : (WHERE) == 3 ? nxt : cur_t;                     \
+    const TileDesc d2 = (WHERE) == 0 ? pick(in2, cur_t, nxt) : (WHERE) == 1 ? cur_t : nxt;                     \
     const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
     uint32_t a0, a1, a2, a3, ts_addr, nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0, na0 = 0, na1 = 0, na2 = 0, na3 = 0, nts = 0; \
     {                                                                                                          \
@@ -1350,6 +1357,10 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
                  :                                                                                             \
                  : "memory");                                                                                  \
     asm volatile("" : "+v"(sbv_next));                                                                         \
+    /* (timing probes 8 / 10, no stores: 64 .. 128 cycles of s_sleep for one half of the waves behind the barrier, to put the */ \
+    /* two waves of a SIMD half an m-step apart - no effect: 0.2205 .. 0.2225 ms with or without, against 0.2394 with stores)  */ \
+    if (PROBE == 10 && wave < 4) __builtin_amdgcn_s_sleep(1);                                                  \
+    if (PROBE == 8 && wave >= 4) __builtin_amdgcn_s_sleep(2);                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     {                                                                                                          \
       int foa = frag_off_a, fob = frag_off_b;                                                                  \
@@ -1406,9 +1417,19 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     const TileDesc nxt = describe(unit + 1);
     {
       const int kb = 0;
-      X32_BLOCK(true)
+      X32_BLOCK(true, 0)
     }
-    for (int kb = 1; kb < nkb; ++kb) X32_BLOCK(false)
+    if constexpr (PROBE == 11) {  // (the round's first form: every block picks its tiles)
+      for (int kb = 1; kb < nkb; ++kb) X32_BLOCK(false, 0)
+    } else {
+      int kb = 1;
+      for (; kb < nkb - 2; ++kb) X32_BLOCK(false, 1)
+      if (kb == nkb - 2) {
+        X32_BLOCK(false, 2)
+        ++kb;
+      }
+      if (kb == nkb - 1) X32_BLOCK(false, 3)
+    }
     prv = cur_t;
     cur_t = nxt;
   }
@@ -1802,6 +1823,10 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 26: SGLK_GO_X32(4); break;                                                                        \
       case 27: SGLK_GO_X32(5); break;                                                                        \
       case 28: SGLK_GO_X32(6); break;                                                                        \
+      case 30: SGLK_GO_X32(7); break;  /* no stagger */                                                      \
+      case 31: SGLK_GO_X32(8); break;                                                                        \
+      case 32: SGLK_GO_X32(10); break;                                                                       \
+      case 33: SGLK_GO_X32(11); break;                                                                       \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
