@@ -207,9 +207,11 @@ def test_varlen(sglk, dev, heads, causal, local, D, sq, sk):
     Hq, Hk = heads
     if sq * sk * Hq > 2**23 and D > 128:
         pytest.skip("CPU oracle time")
+    if sq * sk * Hq > 2**23 and D != 128 and Hk not in (Hq, 1 if D == 72 else 4):
+        pytest.skip("CPU oracle time: the long ragged case runs all three head layouts at D = 128, two at the padded head dims")
     dtype = torch.bfloat16 if (sq + D) % 2 else torch.float16
     g = torch.Generator().manual_seed(sq * 7 + sk + D)
-    b = 3
+    b = 3 if sq < 1024 else 2  # (the CPU oracle of the long case is 3-5 s per sequence triple)
     lens_q = torch.randint(max(1, sq - 20), sq + 1, (b,), generator=g).tolist()
     lens_k = torch.randint(max(1, sk - 20), sk + 1, (b,), generator=g).tolist()
     cu_q = torch.tensor([0] + list(itertools.accumulate(lens_q)), dtype=torch.int32)
