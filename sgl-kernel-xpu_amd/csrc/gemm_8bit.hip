@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nkb = K / BK;  // >= 2
-  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1;
+  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 14);
   // (diagnostic build: stamps != nullptr) shader cycles and 100 MHz ticks of the whole workgroup -> the clock it ran at
   const uint64_t st_c0 = stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   // (diagnostic build) 5: every DMA piece out of range (issue + LDS write of zeros, no fetch); 6: a / b pieces as plain
@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
         const uint32_t vo = (wn * 64 + nf * 32 + hv * 16 + lh * 8 < d.ncols)
                                 ? orow_off + (uint32_t)((nf * 32 + hv * 16) * (int)sizeof(OutT)) : 0x80000000u;
         const v4i data = __builtin_bit_cast(v4i, v);
-        __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, PROBE == 12 ? 2 : PROBE == 13 ? 3 : PROBE == 14 ? 17 : 0);  /* probes 12..14: nt / nt + sc0 / sc0 sc1 stores - 0.306 / 0.307 / 0.244 ms against 0.233 with the default policy (write-back through L2) */
         asm volatile("s_nop 4" ::"v"(data));  // (store data is read for a few cycles after issue: see the kernel above)
       }
   };
@@ -1827,6 +1827,9 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 31: SGLK_GO_X32(8); break;                                                                        \
       case 32: SGLK_GO_X32(10); break;                                                                       \
       case 33: SGLK_GO_X32(11); break;                                                                       \
+      case 34: SGLK_GO_X32(12); break;                                                                       \
+      case 35: SGLK_GO_X32(13); break;                                                                       \
+      case 36: SGLK_GO_X32(14); break;                                                                       \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
