@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nkb = K / BK;  // >= 2
-  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 14);
+  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 15);
   // (diagnostic build: stamps != nullptr) shader cycles and 100 MHz ticks of the whole workgroup -> the clock it ran at
   const uint64_t st_c0 = stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   // (diagnostic build) 5: every DMA piece out of range (issue + LDS write of zeros, no fetch); 6: a / b pieces as plain
@@ -1289,9 +1289,18 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
       if (kDma && MS == 2) dma_piece(d2, kb2, s, 1, 0);                                                        \
     } else {                                                                                                   \
       X32_RD16(mq[0][0], a0, ((mf) + 1) * 4096);  X32_RD16(mq[0][1], a1, ((mf) + 1) * 4096);                   \
-      if (kDma && MS == 4 && (mf) == 0) dma_piece(d1, kb1, s ^ 1, 1, 0);                                       \
-      if (kDma && MS == 4 && (mf) == 1) dma_piece(d1, kb1, s ^ 1, 2, 1);                                       \
-      if (kDma && MS == 2) dma_piece(d1, kb1, s ^ 1, 2, 0);                                                    \
+      if constexpr (PROBE == 15 && (STORE)) {                                                                  \
+        /* (probe 15: the store block's pieces all go out in front of its first store - see X32_BLOCK's wait) */ \
+        if ((mf) == 0) {                                                                                       \
+          if (MS == 4) { dma_piece(d1, kb1, s ^ 1, 1, 0); dma_piece(d1, kb1, s ^ 1, 1, 1); }                   \
+          dma_piece(d1, kb1, s ^ 1, 2, 0);  dma_piece(d1, kb1, s ^ 1, 2, 1);                                   \
+          dma_piece(d1, kb1, s ^ 1, 3, 0);  dma_piece(d1, kb1, s ^ 1, 3, 1);                                   \
+        }                                                                                                      \
+      } else {                                                                                                 \
+        if (kDma && MS == 4 && (mf) == 0) dma_piece(d1, kb1, s ^ 1, 1, 0);                                     \
+        if (kDma && MS == 4 && (mf) == 1) dma_piece(d1, kb1, s ^ 1, 2, 1);                                     \
+        if (kDma && MS == 2) dma_piece(d1, kb1, s ^ 1, 2, 0);                                                  \
+      }                                                                                                        \
     }                                                                                                          \
     if constexpr (STORE) {                                                                                     \
       store_frag(prv, acc[mf], (mf));                                                                          \
@@ -1308,9 +1317,11 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     } else {                                                                                                   \
       /* (the block's last pieces go out two m-steps before its barrier: issued in the step in front of it they were */ \
       /* still in flight at the vmcnt(0) there: +54 us at the headline shape)                                        */ \
-      if (kDma && MS == 4 && (mf) == 0) { dma_piece(d1, kb1, s ^ 1, 1, 1); dma_piece(d1, kb1, s ^ 1, 2, 0); }  \
-      if (kDma && MS == 4 && (mf) == 1) { dma_piece(d1, kb1, s ^ 1, 3, 0); dma_piece(d1, kb1, s ^ 1, 3, 1); }  \
-      if (kDma && MS == 2) { dma_piece(d1, kb1, s ^ 1, 2, 1); dma_piece(d1, kb1, s ^ 1, 3, 0); }               \
+      if constexpr (!(PROBE == 15 && (STORE))) {                                                               \
+        if (kDma && MS == 4 && (mf) == 0) { dma_piece(d1, kb1, s ^ 1, 1, 1); dma_piece(d1, kb1, s ^ 1, 2, 0); } \
+        if (kDma && MS == 4 && (mf) == 1) { dma_piece(d1, kb1, s ^ 1, 3, 0); dma_piece(d1, kb1, s ^ 1, 3, 1); } \
+        if (kDma && MS == 2) { dma_piece(d1, kb1, s ^ 1, 2, 1); dma_piece(d1, kb1, s ^ 1, 3, 0); }             \
+      }                                                                                                        \
     }                                                                                                          \
     X32_MFMA2(cur1, 1)                                                                                         \
     if (LAST) {                                                                                                \
@@ -1321,7 +1332,7 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     } else {                                                                                                   \
       X32_RD16(mq[1][0], a2, ((mf) + 1) * 4096);  X32_RD16(mq[1][1], a3, ((mf) + 1) * 4096);                   \
       X32_RD4(raw, ts_addr, ((mf) + 1) * 128);                                                                 \
-      if (kDma && MS == 2) dma_piece(d1, kb1, s ^ 1, 3, 1);                                                    \
+      if (kDma && MS == 2 && !(PROBE == 15 && (STORE))) dma_piece(d1, kb1, s ^ 1, 3, 1);                       \
     }                                                                                                          \
     sc = scn_;                                                                                                 \
     asm volatile("" : "+v"(sc), "+v"(cur0));                                                                   \
@@ -1352,10 +1363,25 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     if constexpr (MS == 4) { X32_STEP(0, STORE, false) X32_STEP(1, STORE, false) X32_STEP(2, STORE, false) }   \
     else { X32_STEP(0, STORE, false) }                                                                         \
     float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                  \
-                 : "+v"(mq[0][0]), "+v"(mq[0][1]), "+v"(mq[1][0]), "+v"(mq[1][1]), "+v"(raw)                    \
-                 :                                                                                             \
-                 : "memory");                                                                                  \
+    /* (probe 15: vmcnt retires in issue order and the store block's 4 (MS - 1) stores are its youngest operations, so */ \
+    /* the block's pieces have landed at vmcnt(4 (MS - 1)) and the stores get one more K block before anything waits -   */ \
+    /* 0.2376 against 0.2378 ms: one K block is a quarter of the time the 33 MB burst takes to drain)                     */ \
+    if constexpr (PROBE == 15 && (STORE) && MS == 4) {                                                         \
+      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier"                                               \
+                   : "+v"(mq[0][0]), "+v"(mq[0][1]), "+v"(mq[1][0]), "+v"(mq[1][1]), "+v"(raw)                  \
+                   :                                                                                           \
+                   : "memory");                                                                                \
+    } else if constexpr (PROBE == 15 && (STORE)) {                                                             \
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier"                                                \
+                   : "+v"(mq[0][0]), "+v"(mq[0][1]), "+v"(mq[1][0]), "+v"(mq[1][1]), "+v"(raw)                  \
+                   :                                                                                           \
+                   : "memory");                                                                                \
+    } else {                                                                                                   \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                \
+                   : "+v"(mq[0][0]), "+v"(mq[0][1]), "+v"(mq[1][0]), "+v"(mq[1][1]), "+v"(raw)                  \
+                   :                                                                                           \
+                   : "memory");                                                                                \
+    }                                                                                                          \
     asm volatile("" : "+v"(sbv_next));                                                                         \
     /* (timing probes 8 / 10, no stores: 64 .. 128 cycles of s_sleep for one half of the waves behind the barrier, to put the */ \
     /* two waves of a SIMD half an m-step apart - no effect: 0.2205 .. 0.2225 ms with or without, against 0.2394 with stores)  */ \
@@ -1830,6 +1856,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 34: SGLK_GO_X32(12); break;                                                                       \
       case 35: SGLK_GO_X32(13); break;                                                                       \
       case 36: SGLK_GO_X32(14); break;                                                                       \
+      case 37: SGLK_GO_X32(15); break;  /* counted vmcnt at the store block's barrier */                    \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
