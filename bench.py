@@ -12,7 +12,7 @@ so every rank runs an independent replica; rank 0 prints ONE JSON line. Without 
 `--gpus N` starts the N rank processes itself; under torch.distributed.run it uses the launcher's ranks.
 
 roofline.achieved is measured live with HIP events recorded on the launch stream around each GEMM
-launch of the timed region. cpu_baseline times the CPU oracle (torch eager, all host cores) on a row
+launch of the timed region. cpu_baseline times the CPU oracle (torch eager, best of a few thread-pool widths) on a row
 sample of the same workload (rank 0, N=1 only).
 """
 import argparse
@@ -98,28 +98,38 @@ def cpu_baseline(seconds_budget=20.0):
     from oracle import gemm as ogemm
     from oracle import quant as oquant
 
-    torch.set_num_threads(os.cpu_count() or 1)
     rows = 256
     g = torch.Generator().manual_seed(1)
     x = torch.randn(rows, K, generator=g).to(torch.bfloat16)
     b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).t()
     sb = (torch.rand(N // 128, K // 128, generator=g) * 1e-3 + 1e-4).t()
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        q, s, _ = oquant.per_token_group_quant_8bit(x, GROUP, FP8)
-        ogemm.fp8_blockwise_scaled_mm(q, b, s, sb, torch.bfloat16)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > seconds_budget or reps >= 8:
-            break
-    tflops = 2.0 * rows * N * K * reps / dt / 1e12
+    # The GPU boxes are shared 256-core hosts: a pool as wide as the host is not the fastest one for this oracle. Time a few
+    # widths within the budget and report the best, with the width it ran at.
+    ncpu = os.cpu_count() or 1
+    widths = sorted({min(w, ncpu) for w in (16, 64, ncpu)})
+    best, before = None, torch.get_num_threads()
+    for w in widths:
+        torch.set_num_threads(w)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            q, s, _ = oquant.per_token_group_quant_8bit(x, GROUP, FP8)
+            ogemm.fp8_blockwise_scaled_mm(q, b, s, sb, torch.bfloat16)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds_budget / len(widths) or reps >= 3:
+                break
+        tflops = 2.0 * rows * N * K * reps / dt / 1e12
+        if best is None or tflops > best[0]:
+            best = (tflops, w, reps)
+    torch.set_num_threads(before)
     return {
-        "value": round(tflops, 4),
+        "value": round(best[0], 4),
         "unit": "TFLOP/s",
-        "cores": torch.get_num_threads(),
+        "cores": best[1],
         "kind": "port",
-        "sample": f"{reps} pass(es) of quant+GEMM on {rows} of {M} rows (same N={N}, K={K}), torch-eager oracle",
+        "sample": f"{best[2]} pass(es) of quant+GEMM on {rows} of {M} rows (same N={N}, K={K}), torch-eager oracle, "
+                  f"best of thread-pool widths {widths}",
     }
 
 

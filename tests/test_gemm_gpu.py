@@ -61,13 +61,23 @@ def test_mfma_lane_maps_known_answer(sglk, dev):
 @pytest.mark.parametrize("N,K", [(128, 512), (512, 1024), (1024, 4096), (4096, 512), (14080, 1024), (8192, 8192), (640, 1152)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_fp8_blockwise(sglk, dev, M, N, K, dtype):
-    if M > 128 and N * K > 4096 * 4096:
-        pytest.skip("CPU oracle too slow; covered by the sampled full-size test")
     a, b, sa, sb = make_blockwise(M, N, K, seed=M * 7 + N + K)
     out = run_blockwise(sglk, dev, a, b, sa, sb, dtype)
     ref = ogemm.fp8_blockwise_scaled_mm(a, b, sa, sb, dtype)
     torch.testing.assert_close(out, ref, rtol=0.02, atol=1)  # reference tolerance (:83-85)
     # the reference tolerance is loose for |out| ~ 1e-2; also require agreement to output rounding
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("M", [129, 255, 257, 384, 1000, 2049, 4100])
+@pytest.mark.parametrize("N,K", [(512, 1024), (4096, 512), (640, 1152), (14080, 1024), (1000, 768), (136, 256), (2056, 2048)])
+def test_fp8_blockwise_tile_pipeline_edges(sglk, dev, M, N, K):
+    """the persistent tile loop (M > 128): full and 128-row half tiles, ragged last row / column blocks (N % 8 == 0 only),
+    two-block K, rounds that do and do not fill the 256 workgroups - every output element against the oracle"""
+    dtype = torch.bfloat16 if (M + N) % 2 else torch.float16
+    a, b, sa, sb = make_blockwise(M, N, K, seed=M + N + K)
+    out = run_blockwise(sglk, dev, a, b, sa, sb, dtype)
+    ref = ogemm.fp8_blockwise_scaled_mm(a, b, sa, sb, dtype)
     torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-3)
 
 
