@@ -148,10 +148,12 @@ def test_kvcache_other_head_dims(sglk, dev, D, sq, sk):
 @pytest.mark.parametrize("page", [64, 128])  # fastest-varying: the CPU oracle of a logical case runs once for both
 @pytest.mark.parametrize("heads", [(16, 16), (16, 4), (16, 1), (8, 1), (32, 8)])
 @pytest.mark.parametrize("local", [False, True])
-@pytest.mark.parametrize("D", [64, 128, 256])
-@pytest.mark.parametrize("batch,seqlen_k", [(1, 1), (4, 63), (1, 64), (4, 65), (1, 129), (4, 1024), (1, 4033), (2, 4097),
-                                            (2, 8192)])
+@pytest.mark.parametrize("D", [64, 128, 256, 512])
+@pytest.mark.parametrize("batch,seqlen_k", [(1, 1), (4, 63), (1, 64), (4, 65), (1, 129), (4, 512), (4, 1024), (1, 4033),
+                                            (1, 4096), (2, 4097), (4, 4608), (1, 5120), (2, 8192)])
 def test_decode(sglk, dev, heads, local, page, D, batch, seqlen_k):
+    """the reference's decode grid (tests/test_flash_attention.py:1177-1222: 13 cache lengths x d 64..512 x local x head
+    layouts x page 64 / 128, batch 1 and 4); its sink axis alternates over the grid, every case at three split counts"""
     Hq, Hk = heads
     g = torch.Generator().manual_seed(seqlen_k + D)
     seqs_k = torch.randint(max(1, seqlen_k - 30), seqlen_k + 1, (batch,), generator=g).tolist()
@@ -159,7 +161,7 @@ def test_decode(sglk, dev, heads, local, page, D, batch, seqlen_k):
     window = (seqlen_k // 3, 0) if local else (-1, -1)
     for splits in (0, 1, 5):
         run_paged(sglk, dev, torch.bfloat16, [1] * batch, seqs_k, Hq, Hk, D, page, window=window,
-                  use_sink=(D == 64 and not local), num_splits=splits, seed=seqlen_k)
+                  use_sink=((seqlen_k + (D >> 6) + Hk + int(local)) % 2 == 0), num_splits=splits, seed=seqlen_k)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -198,14 +200,28 @@ def test_decode_full_size_config_sampled(sglk, dev):
 # -------------------------------------------------------------------------------------------- ragged (non-paged)
 @pytest.mark.parametrize("heads", [(16, 16), (16, 4), (16, 1)])
 @pytest.mark.parametrize("causal,local", [(False, False), (True, False), (False, True)])
-@pytest.mark.parametrize("D", [72, 80, 128, 192, 256])
-@pytest.mark.parametrize("sq,sk", [(1, 1), (1, 239), (3, 799), (64, 128), (113, 203), (128, 217), (256, 512),
-                                   (108, 256), (1024, 1024)])
+@pytest.mark.parametrize("D", [72, 80, 128, 192, 256, 512])
+@pytest.mark.parametrize("sq,sk", [(1, 1), (1, 3), (2, 1), (511, 1), (3, 513), (1, 239), (3, 799), (64, 128), (128, 128),
+                                   (256, 256), (113, 203), (128, 217), (113, 211), (108, 256), (256, 512), (307, 256),
+                                   (640, 128), (512, 256), (1024, 1024), (1023, 1024), (1024, 1023)])
 def test_varlen(sglk, dev, heads, causal, local, D, sq, sk):
+    """the reference's ragged grid (tests/test_flash_attention.py:1912-1947: head layouts x masks x d x 20 length pairs; the
+    2048 x 2048 pair is test_varlen_2048 below); its softcap axis (0 / 15) alternates over the grid instead of doubling it"""
+    run_varlen(sglk, dev, heads, causal, local, D, sq, sk)
+
+
+@pytest.mark.parametrize("causal,local", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("D", [80, 128, 256])
+def test_varlen_2048(sglk, dev, causal, local, D):
+    run_varlen(sglk, dev, (16, 4), causal, local, D, 2048, 2048)
+
+
+def run_varlen(sglk, dev, heads, causal, local, D, sq, sk):
     Hq, Hk = heads
+    softcap = 15.0 if (sq + sk + D // 8 + Hk) % 2 else 0.0
     dtype = torch.bfloat16 if (sq + D) % 2 else torch.float16
     g = torch.Generator().manual_seed(sq * 7 + sk + D)
-    b = 3
+    b = 3 if sq < 2048 else 2
     lens_q = torch.randint(max(1, sq - 20), sq + 1, (b,), generator=g).tolist()
     lens_k = torch.randint(max(1, sk - 20), sk + 1, (b,), generator=g).tolist()
     cu_q = torch.tensor([0] + list(itertools.accumulate(lens_q)), dtype=torch.int32)
@@ -217,11 +233,11 @@ def test_varlen(sglk, dev, heads, causal, local, D, sq, sk):
     scale = D ** -0.5
     ks = [k[cu_k[i]:cu_k[i + 1]] for i in range(b)]
     vs = [v[cu_k[i]:cu_k[i + 1]] for i in range(b)]
-    ref, _ = oa.attention_ragged(q, ks, vs, cu_q, scale, causal=causal, window=window)
-    pt = torch.cat([pt_seq(q[cu_q[i]:cu_q[i + 1]], ks[i], vs[i], scale, causal, window, 0.0, None) for i in range(b)])
+    ref, _ = oa.attention_ragged(q, ks, vs, cu_q, scale, causal=causal, window=window, softcap=softcap)
+    pt = torch.cat([pt_seq(q[cu_q[i]:cu_q[i + 1]], ks[i], vs[i], scale, causal, window, softcap, None) for i in range(b)])
     out = sglk.flash_attn_varlen_func(q.to(dev), k.to(dev), v.to(dev), cu_q.to(dev), cu_k.to(dev), max(lens_q),
-                                      max(lens_k), causal=causal, window_size=window)
-    check(out.cpu(), ref, pt, f"varlen D={D}")
+                                      max(lens_k), causal=causal, window_size=window, softcap=softcap)
+    check(out.cpu(), ref, pt, f"varlen D={D} softcap={softcap}")
 
 
 def test_softcap_and_out_buffer(sglk, dev):
