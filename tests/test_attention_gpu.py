@@ -123,20 +123,33 @@ def run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, D, page, causal=False, w
 
 # ---------------------------------------------------------------------- paged kv-cache, mixed prefill/decode batches
 @pytest.mark.parametrize("page", [64, 128])  # outermost decorator = fastest-varying: both page sizes reuse one oracle run
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("heads", [(16, 16), (16, 4), (8, 1)])
 @pytest.mark.parametrize("causal,local", [(False, True), (False, False), (True, False)])
-@pytest.mark.parametrize("D", [64, 128, 256])
-def test_kvcache_paged(sglk, dev, dtype, heads, causal, local, page, D):
+@pytest.mark.parametrize("D", [64, 128, 256, 512])
+@pytest.mark.parametrize("sq,sk", [(3, 1024), (64, 800), (64, 256), (3, 799), (64, 2048), (128, 128), (256, 512), (512, 512)])
+def test_kvcache_paged(sglk, dev, heads, causal, local, page, D, sq, sk):
+    """the reference's paged kv-cache grid (tests/test_flash_attention.py:70-82, 630-658: 9 (seqlen_q, seqlen_k) pairs x d
+    64..512 x page 64 / 128 x masks x head layouts; the 2048 x 3577 pair is test_kvcache_paged_many_tiles below). Its dtype
+    and sink axes alternate over the grid instead of doubling it."""
     Hq, Hk = heads
-    idx = (heads[1] + 3 * causal + 2 * local + D // 64 + (dtype == torch.float16)) % 5  # same for both page sizes
-    sq, sk = [(3, 1024), (64, 800), (64, 256), (3, 799), (128, 128)][idx]
-    g = torch.Generator().manual_seed(idx)
+    par = sq + sk // 3 + Hk + 3 * causal + 2 * local + D // 64  # same for both page sizes
+    dtype = torch.float16 if par % 2 else torch.bfloat16
+    g = torch.Generator().manual_seed(sq + sk)
     seqs_k = torch.randint(max(1, sk - 20), sk + 1, (3,), generator=g).tolist()
     seqs_q = [min(sq, s) for s in seqs_k]
     window = (torch.randint(0, sk, (2,), generator=g).tolist()) if local else (-1, -1)
     run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, D, page, causal=causal, window=tuple(window),
-              use_sink=(D == 64), seed=idx)
+              use_sink=((par // 2) % 2 == 0), seed=sq + sk)
+
+
+@pytest.mark.parametrize("page", [64, 128])
+@pytest.mark.parametrize("causal,local", [(False, True), (False, False), (True, False)])
+@pytest.mark.parametrize("D", [128, 512])
+def test_kvcache_paged_many_tiles(sglk, dev, causal, local, page, D):
+    """(2048, 3577): "enough tiles to test the persistent scheduler" (reference :81), two sequences"""
+    window = (700, 300) if local else (-1, -1)
+    run_paged(sglk, dev, torch.bfloat16, [2048, 1999], [3577, 3001], 16, 4, D, page, causal=causal, window=window,
+              use_sink=causal, seed=D)
 
 
 @pytest.mark.parametrize("D,sq,sk", [(512, 3, 300), (512, 40, 130), (96, 17, 200), (192, 5, 77)])
@@ -312,12 +325,13 @@ def test_missing_max_seqlen_q_is_safe(sglk, dev):
 @pytest.mark.parametrize("D", [128, 256])
 @pytest.mark.parametrize("page", [64, 128])
 @pytest.mark.parametrize("sq", [1, 32, 64])
+@pytest.mark.parametrize("sk", [256, 512])
 @pytest.mark.parametrize("causal", [False, True])
-def test_fp8_kvcache(sglk, dev, fp8_dtype, heads, D, page, sq, causal):
+def test_fp8_kvcache(sglk, dev, fp8_dtype, heads, D, page, sq, sk, causal):
     """bf16 q against an fp8 paged KV cache with per-tensor descales (scalar and expanded-scalar layouts)."""
     Hq, Hk = heads
-    b, sk = 3, 512
-    g = torch.Generator().manual_seed(D + page + sq)
+    b = 3
+    g = torch.Generator().manual_seed(D + page + sq + sk)
     fp8_max = 448.0 if fp8_dtype == torch.float8_e4m3fn else 57344.0
     k_ref = torch.randn(b, sk, Hk, D, generator=g)
     v_ref = torch.randn(b, sk, Hk, D, generator=g)

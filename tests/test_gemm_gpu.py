@@ -81,6 +81,30 @@ def test_fp8_blockwise_tile_pipeline_edges(sglk, dev, M, N, K):
     torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-3)
 
 
+@pytest.mark.parametrize("M", [1, 3, 5, 127, 128, 512, 1024, 4096])
+@pytest.mark.parametrize("N", [128, 512, 1024, 4096, 8192, 14080])
+@pytest.mark.parametrize("K", [512, 1024, 4096, 8192, 14080, 16384])
+def test_fp8_blockwise_reference_grid(sglk, dev, M, N, K):
+    """the reference's whole M x N x K cross product (tests/test_fp8_blockwise_gemm.py:88-91; its out_dtype axis alternates
+    over the grid). Operands are drawn on the device; the oracle runs on up to 48 sampled rows x 3 sampled 128-column
+    blocks (all rows / blocks of the small cases), and every output must be finite."""
+    dtype = torch.bfloat16 if (M + N // 128 + K // 512) % 2 else torch.float16
+    g = torch.Generator(device=dev).manual_seed(M * 31 + N + K)
+    a = ((torch.rand(M, K, device=dev, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8)
+    b = ((torch.rand(N, K, device=dev, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8).t()
+    sa = (torch.randn(K // 128, M, device=dev, generator=g) * 1e-3).t()   # column-major, like the reference's
+    sb = (torch.randn(N // 128, K // 128, device=dev, generator=g) * 1e-3).t()
+    out = sglk.fp8_blockwise_scaled_mm(a, b, sa, sb, dtype)
+    assert out.shape == (M, N) and out.dtype == dtype and torch.isfinite(out.float()).all()
+    gc = torch.Generator().manual_seed(K + M)
+    rows = torch.randperm(M, generator=gc)[:48].sort().values
+    nblk = torch.randperm(N // 128, generator=gc)[:3].sort().values
+    cols = torch.cat([torch.arange(i * 128, (i + 1) * 128) for i in nblk.tolist()])
+    rd, cd, nd = rows.to(dev), cols.to(dev), nblk.to(dev)
+    ref = ogemm.fp8_blockwise_scaled_mm(a[rd].cpu(), b[:, cd].cpu(), sa[rd].cpu(), sb[:, nd].cpu(), dtype)
+    torch.testing.assert_close(out[rd][:, cd].float().cpu(), ref.float(), rtol=2e-2, atol=2e-3)
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 14336, 4096), (4096, 4096, 14336), (1024, 14080, 16384), (1, 14336, 4096),
                                    (16, 14336, 4096), (64, 4096, 14336), (300, 768, 384)])
 def test_fp8_blockwise_full_size_sampled(sglk, dev, M, N, K):
