@@ -27,8 +27,8 @@ def _states(tokens, heads, d, dt, seed):
     return torch.randn(tokens, heads, d, generator=g).to(dt), s_a, torch.randn(tokens, heads, d, generator=g).to(dt), s_b
 
 
-@pytest.mark.parametrize("tokens", [1, 256, 613, 1536])
-@pytest.mark.parametrize("heads", [8, 32])
+@pytest.mark.parametrize("tokens", [1, 256, 512, 613, 1024, 1536])
+@pytest.mark.parametrize("heads", [8, 16, 32])
 @pytest.mark.parametrize("d", [32, 48, 64, 128, 256, 512])
 @pytest.mark.parametrize("dt", [torch.half, torch.bfloat16, torch.float32])
 def test_merge_state_both_bases(sglk, dev, tokens, heads, d, dt):

@@ -45,10 +45,12 @@ def run_case(sglk, dev, dtype, page, H, sqs, sks, causal=True, seed=42):
 
 @pytest.mark.parametrize("idx", range(len(CASES)))
 @pytest.mark.parametrize("H", [16, 128])
-def test_mla_prefill_reference_matrix(sglk, dev, idx, H):
+@pytest.mark.parametrize("page", [16, 32, 64, 128])
+def test_mla_prefill_reference_matrix(sglk, dev, idx, H, page):
+    """the reference's matrix (tests/test_flash_mla_prefill.py:98-140: block sizes x head counts x length cases); its dtype
+    axis alternates over it"""
     sqs, sks = CASES[idx]
-    dtype = [torch.bfloat16, torch.float16][idx % 2]
-    page = [16, 32, 64, 128][(idx // 2) % 4]
+    dtype = [torch.bfloat16, torch.float16][(idx + page // 16 + H // 16) % 2]
     run_case(sglk, dev, dtype, page, H, sqs, sks, seed=idx)
 
 
