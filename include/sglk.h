@@ -94,6 +94,20 @@ enum sglk_act { SGLK_ACT_SILU = 0, SGLK_ACT_GELU_TANH = 1, SGLK_ACT_GELU = 2 };
 SGLK_API int sglk_act_and_mul(sglk_stream_t stream, void* out, const void* x, int64_t tokens,
                               int64_t d, int dtype, int act);
 
+/* silu_and_mul_clamp (the DeepSeek-V4 swiglu): reference src/sycl/SiluAndMulClamp.cpp:55-180 (schema
+ * torch_extension_sycl.cc:32), python/sgl_kernel/elementwise.py:231-255. x is [tokens, 2d] contiguous, gate half first:
+ *   g = bf16(min(bf16(x[t, j]), bf16(limit)));  u = bf16(clamp(bf16(x[t, d + j]), -bf16(limit), bf16(limit)));
+ *   out[t, j] = T(g * sigmoid(g) * u)           (the clamp is done in bf16 whatever T is; T is f16 or bf16) */
+SGLK_API int sglk_silu_and_mul_clamp(sglk_stream_t stream, void* out, const void* x, int64_t tokens, int64_t d,
+                                     int dtype, float limit);
+
+/* swiglu_gpt_oss_sigmoid_alpha: reference src/sycl/SwigluAlphaLimit.cpp:16-175 (schema torch_extension_sycl.cc:108),
+ * called by fused_experts for gemm1_alpha (python/sgl_kernel/moe.py:692-697, :787-789). x is [rows, 2 hidden]
+ * contiguous with gate / up INTERLEAVED (x[r, 2 j] = gate, x[r, 2 j + 1] = up); fp32 arithmetic, one rounding to T:
+ *   g = min(gate, limit);  u = clamp(up, -limit, limit);  out[r, j] = T(g * sigmoid(alpha * g) * (u + 1)) */
+SGLK_API int sglk_swiglu_alpha_limit(sglk_stream_t stream, void* out, const void* x, int64_t rows, int64_t hidden,
+                                     int dtype, float alpha, float limit);
+
 /* ---- per-token-group 8-bit quantisation -----------------------------------
  * sgl_per_token_group_quant_8bit: reference
  * src/sycl/per_token_group_quant_8bit.cpp:222-386 (schema :395-398).

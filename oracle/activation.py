@@ -24,3 +24,22 @@ def gelu_and_mul(x: torch.Tensor) -> torch.Tensor:
     d = x.shape[-1] // 2
     a, b = x[..., :d].float(), x[..., d:].float()
     return ((a * 0.5 * (1.0 + torch.erf(a * math.sqrt(0.5)))) * b).to(x.dtype)
+
+
+def silu_and_mul_clamp(x: torch.Tensor, limit: float) -> torch.Tensor:
+    """reference src/sycl/SiluAndMulClamp.cpp:61-74 (= tests/test_silu_and_mul_clamp.py:8-91): both halves clamped in bf16
+    whatever the input dtype - gate = min(gate, limit), up = clamp(up, -limit, limit) - then silu(gate) * up in fp32."""
+    d = x.shape[-1] // 2
+    lim = torch.tensor(limit, dtype=torch.float32).to(torch.bfloat16).float()
+    bf = lambda t: t.to(torch.bfloat16).float()
+    g = bf(torch.minimum(bf(x[..., :d].float()), lim))
+    u = bf(torch.maximum(-lim, torch.minimum(bf(x[..., d:].float()), lim)))
+    return (g * (1.0 / (1.0 + torch.exp(-g))) * u).to(x.dtype)
+
+
+def swiglu_gpt_oss_sigmoid_alpha(x: torch.Tensor, alpha: float, limit: float) -> torch.Tensor:
+    """reference src/sycl/SwigluAlphaLimit.cpp:16-49 (= tests/test_swiglu_with_alpha_limit.py:9-14, in fp32): x [rows, 2 hidden]
+    with gate / up interleaved; gate = min(gate, limit), up = clamp(up, -limit, limit), out = gate * sigmoid(alpha gate) * (up + 1)."""
+    gate = x[..., ::2].float().clamp(max=limit)
+    up = x[..., 1::2].float().clamp(min=-limit, max=limit)
+    return (gate * (1.0 / (1.0 + torch.exp(-(gate * alpha)))) * (up + 1.0)).to(x.dtype)

@@ -128,7 +128,8 @@ def moe_grouped_mm_w4a16(act, packed, scales, zeros, bias, rows_per_expert, grou
 
 
 def fused_experts_int4(x, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale, w1_zp=None, w2_zp=None, b1=None,
-                       b2=None, activation="silu", routed_scaling_factor=None, mxfp4=False):
+                       b2=None, activation="silu", routed_scaling_factor=None, mxfp4=False, gemm1_alpha=None,
+                       gemm1_limit=None):
     T = x.dtype
     E = w1.shape[0]
     K = w1.shape[2] * 2
@@ -139,7 +140,9 @@ def fused_experts_int4(x, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale, w1
     rows = torch.from_numpy(counts)
     h = moe_grouped_mm_w4a16(a, w1, w1_scale, w1_zp, b1.float() if b1 is not None else None, rows, K // w1_scale.shape[2],
                              mxfp4)
-    if activation == "silu":
+    if gemm1_alpha is not None:
+        h = oact.swiglu_gpt_oss_sigmoid_alpha(h, gemm1_alpha, gemm1_limit)
+    elif activation == "silu":
         h = oact.silu_and_mul(h)
     elif activation == "gelu":
         h = oact.gelu_tanh_and_mul(h)
@@ -200,7 +203,7 @@ def moe_grouped_mm_fused(act, weights, bias, rows_per_expert, activation):
 
 
 def fused_experts_16bit(x, w1, w2, topk_weights, topk_ids, b1=None, b2=None, activation="silu", routed_scaling_factor=None,
-                        fused_epilogue=False):
+                        fused_epilogue=False, gemm1_alpha=None, gemm1_limit=None):
     """fused_experts with 16-bit weights: the op sequence of reference python/sgl_kernel/moe.py:742-866 (GEMM1, gated
     activation in the activation dtype, GEMM2, fp32 weighted combine in slot order); same result as torch_naive_moe
     (tests/test_moe_gemm.py:59-137) up to the rounding of the two intermediates."""
@@ -210,7 +213,10 @@ def fused_experts_16bit(x, w1, w2, topk_weights, topk_ids, b1=None, b2=None, act
     counts, _, _, a_map, c_map = prepare_moe_input(topk_ids.numpy(), E, x.shape[1], topk)
     a = x[torch.from_numpy(a_map).long()]
     rows = torch.from_numpy(counts)
-    if fused_epilogue:  # the reference's fuse_act route (moe.py:812-860): no rounding between GEMM 1 and the activation
+    if gemm1_alpha is not None:  # gpt-oss swiglu (moe.py:692-697, :787-789): GEMM 1 rounded to T, interleaved gate / up
+        h = moe_grouped_mm(a, w1, b1.float() if b1 is not None else None, rows)
+        h = oact.swiglu_gpt_oss_sigmoid_alpha(h, gemm1_alpha, gemm1_limit)
+    elif fused_epilogue:  # the reference's fuse_act route (moe.py:812-860): no rounding between GEMM 1 and the activation
         h = moe_grouped_mm_fused(a, w1, b1.float() if b1 is not None else None, rows, activation)
     else:
         h = moe_grouped_mm(a, w1, b1.float() if b1 is not None else None, rows)

@@ -152,6 +152,41 @@ void gelu_tanh_and_mul(Tensor& out, Tensor& input) {
 }
 void gelu_and_mul(Tensor& out, Tensor& input) { act_and_mul_impl(out, input, SGLK_ACT_GELU, "gelu_and_mul"); }
 
+// reference src/sycl/SiluAndMulClamp.cpp:170-180 (same checks and messages)
+void silu_and_mul_clamp(Tensor& out, Tensor& input, double swiglu_limit) {
+  CHECK_GPU(input);
+  CHECK_GPU(out);
+  TORCH_CHECK(input.scalar_type() == at::kHalf || input.scalar_type() == at::kBFloat16,
+              "silu_and_mul_clamp: input must be Half or BFloat16");
+  TORCH_CHECK(out.scalar_type() == input.scalar_type(), "silu_and_mul_clamp: dtype mismatch");
+  TORCH_CHECK(input.dim() >= 1 && input.size(-1) % 2 == 0, "silu_and_mul_clamp: input last dim must be even");
+  TORCH_CHECK(out.numel() * 2 == input.numel(), "silu_and_mul_clamp: output numel must be half of input numel");
+  TORCH_CHECK(swiglu_limit > 0.0, "silu_and_mul_clamp: swiglu_limit must be > 0");
+  TORCH_CHECK(out.is_contiguous(), "silu_and_mul_clamp: out must be contiguous");
+  const int64_t d = input.size(-1) / 2;
+  const Tensor in_c = input.contiguous();
+  const c10::OptionalDeviceGuard guard(input.device());
+  SGLK_CALL(sglk_silu_and_mul_clamp(stream_of(input), out.data_ptr(), in_c.data_ptr(), out.numel() / d, d,
+                                    dtype_code(input.scalar_type(), "silu_and_mul_clamp"), (float)swiglu_limit));
+}
+
+// reference src/sycl/SwigluAlphaLimit.cpp:153-175 (same checks and messages)
+Tensor swiglu_gpt_oss_sigmoid_alpha(Tensor x, double alpha, double limit) {
+  CHECK_GPU(x);
+  TORCH_CHECK(x.scalar_type() == at::kFloat || x.scalar_type() == at::kHalf || x.scalar_type() == at::kBFloat16,
+              "Only float32, float16, and bfloat16 are supported");
+  TORCH_CHECK(x.is_contiguous(), "x must be contiguous");
+  TORCH_CHECK(x.dim() == 2, "x must be 2D [B, 2H]");
+  TORCH_CHECK(x.size(1) % 2 == 0, "Last dim must be even");
+  const int64_t rows = x.size(0), hidden = x.size(1) / 2;
+  Tensor y = at::empty({rows, hidden}, x.options());
+  if (rows == 0 || hidden == 0) return y;
+  const c10::OptionalDeviceGuard guard(x.device());
+  SGLK_CALL(sglk_swiglu_alpha_limit(stream_of(x), y.data_ptr(), x.data_ptr(), rows, hidden,
+                                    dtype_code(x.scalar_type(), "swiglu_gpt_oss_sigmoid_alpha"), (float)alpha, (float)limit));
+  return y;
+}
+
 // ---- per-token-group quant (reference src/sycl/per_token_group_quant_8bit.cpp:222-386) ------
 
 void sgl_per_token_group_quant_8bit(Tensor input, Tensor output_q, Tensor output_s, int64_t group_size,
@@ -1436,6 +1471,10 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
   m.impl("gelu_tanh_and_mul", c10::kCUDA, &gelu_tanh_and_mul);
   m.def("gelu_and_mul(Tensor! out, Tensor input) -> ()");
   m.impl("gelu_and_mul", c10::kCUDA, &gelu_and_mul);
+  m.def("silu_and_mul_clamp(Tensor! out, Tensor input, float swiglu_limit) -> ()");  // reference :32
+  m.impl("silu_and_mul_clamp", c10::kCUDA, &silu_and_mul_clamp);
+  m.def("swiglu_gpt_oss_sigmoid_alpha(Tensor x, float alpha, float limit) -> Tensor");  // reference :108
+  m.impl("swiglu_gpt_oss_sigmoid_alpha", c10::kCUDA, &swiglu_gpt_oss_sigmoid_alpha);
   m.def("rmsnorm(Tensor! output, Tensor input, Tensor weight, float eps) -> ()");
   m.impl("rmsnorm", c10::kCUDA, &rmsnorm);
   m.def("fused_add_rmsnorm(Tensor! input, Tensor! residual, Tensor weight, float eps) -> ()");

@@ -37,6 +37,7 @@ from sgl_kernel.elementwise import (  # noqa: E402
     rmsnorm,
     rotary_embedding,
     silu_and_mul,
+    silu_and_mul_clamp,
     store_cache,
     store_cache_xpu,
 )
@@ -58,6 +59,7 @@ from sgl_kernel.moe import (  # noqa: E402
     apply_shuffle_mul_sum,
     biased_topk,
     fused_experts,
+    swiglu_gpt_oss_sigmoid_alpha,
     moe_align_block_size,
     moe_fused_gate,
     prepare_moe_input,
@@ -87,9 +89,9 @@ _OUT_OF_SCOPE = frozenset(
     lightning_attention_decode flash_mla_sparse_fwd flash_mla_with_kvcache
     apply_rope_with_cos_sin_cache_inplace fused_k_norm_rope_flashmla
     fused_q_norm_rope fused_qk_rope fused_qk_rope_with_cos_sin_cache_inplace
-    multimodal_rotary_embedding silu_and_mul_clamp
+    multimodal_rotary_embedding
     cutlass_fp4_group_mm fp8_blockwise_scaled_grouped_mm hash_topk moe_sum
-    moe_sum_reduce swiglu_gpt_oss_sigmoid_alpha
+    moe_sum_reduce
     weak_ref_tensor
     """.split()
 )

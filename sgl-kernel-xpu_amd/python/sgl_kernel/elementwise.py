@@ -95,6 +95,16 @@ def gelu_and_mul(input: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     return _act_and_mul(torch.ops.sgl_kernel.gelu_and_mul, input, out)
 
 
+def silu_and_mul_clamp(input: torch.Tensor, out: torch.Tensor, swiglu_limit: float) -> None:
+    """The DeepSeek-V4 swiglu (reference elementwise.py:231-255): ``input`` [M, 2H] bf16 / fp16 with the gate half first,
+    ``out`` [M, H] pre-allocated. Both halves are clamped in bf16 - gate = min(gate, limit), up = clamp(up, -limit, limit) -
+    then ``out = silu(gate) * up`` in fp32, rounded to the input dtype. Returns nothing."""
+    if input.shape[-1] * input.dtype.itemsize % 16 != 0:
+        raise ValueError("The pointers must be multiple of 16 bytes.")
+    _check_shape(input, out)
+    torch.ops.sgl_kernel.silu_and_mul_clamp(out, input, swiglu_limit)
+
+
 def rotary_embedding(
     positions: torch.Tensor,
     query: torch.Tensor,

@@ -82,6 +82,15 @@ def apply_shuffle_mul_sum(input, output, permutation, factors, routed_scaling_fa
                                        1.0 if routed_scaling_factor is None else routed_scaling_factor, factors)
 
 
+def swiglu_gpt_oss_sigmoid_alpha(x, gemm1_alpha, gemm1_limit):
+    """x [B, 2H] with gate / up interleaved -> [B, H]: gate = min(gate, limit), up = clamp(up, -limit, limit),
+    gate * sigmoid(alpha * gate) * (up + 1) (reference moe.py:136-146)."""
+    assert gemm1_limit > 0, f"gemm1_limit must be positive, got {gemm1_limit}"
+    assert x.dim() == 2, f"x must be 2D [B, 2H], got {x.dim()}D"
+    assert x.size(1) % 2 == 0, f"Last dim must be even for gate/up split, got {x.size(1)}"
+    return _ops.swiglu_gpt_oss_sigmoid_alpha.default(x, gemm1_alpha, gemm1_limit)
+
+
 def scatter_tokens_to_experts(input, src2dst_map, output):
     _ops.scatter_tokens_to_experts.default(input, src2dst_map, output)
 
@@ -239,8 +248,10 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     assert not use_fp8_w8a8, "current MoE does not support use_fp8_w8a8"
     assert a1_scale is None and a2_scale is None, "current MoE does not support a1_scale / a2_scale"
     assert block_shape is None, "current MoE does not support block_shape"
-    if gemm1_alpha is not None:
-        raise NotImplementedError("fused_experts: the gpt-oss swiglu (interleaved gate / up columns, gemm1_alpha) is outside this build")
+    if gemm1_alpha is not None:  # gpt-oss swiglu (reference moe.py:692-697): silu with alpha / limit, interleaved gate / up
+        assert activation == "silu", "gemm1_alpha selects the gpt-oss swiglu: activation must be silu"
+        assert gemm1_limit is not None, "gemm1_limit must be provided when gemm1_alpha is set for swiglu for GPT-OSS"
+        assert swiglu_limit is None, "gemm1_alpha and swiglu_limit exclude each other"
     if swiglu_limit is not None:  # DeepSeek-V4 clamp (reference moe.py:699-709): silu only, 4-bit weights only
         assert activation == "silu" and swiglu_limit == 10
         assert use_mxfp4_w4a16 or use_int4_w4a16, "swiglu_limit requires use_mxfp4_w4a16=True or use_int4_w4a16=True"
@@ -286,7 +297,13 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     # ---- GEMM 1 with the gate / up activation (or relu2) on its fp32 accumulators, in the epilogue: no [rows, 2I]
     # intermediate, no separate act-and-mul launch (the reference runs them as two launches, moe.py:751-835)
     h = scratch("intermediate_cache1_fused", (p.rows, p.inter))
-    if not p.four_bit:
+    if gemm1_alpha is not None:
+        # gpt-oss: the columns of GEMM 1 are (gate, up) pairs, so the activation is the reference's own op on the rounded
+        # [rows, 2I] product (moe.py:751-789) - a second HBM pass the split-halves epilogues above do not need
+        full = scratch("intermediate_cache1", (p.rows, 2 * p.inter))
+        grouped_mm(full, x, w1, w1_scale, w1_zp, b1, p.group1)
+        h = _ops.swiglu_gpt_oss_sigmoid_alpha(full, float(gemm1_alpha), float(gemm1_limit))
+    elif not p.four_bit:
         grouped_mm(h, x, w1, None, None, b1, 0, fuse_act=True)
     else:
         fused = 4 if swiglu_limit is not None else {0: 1, 1: 2, 3: 3}[p.act_type]

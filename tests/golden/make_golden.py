@@ -614,7 +614,28 @@ def gen_rope():
     save("rope", cases)
 
 
+def gen_swiglu():
+    """swiglu_gpt_oss_sigmoid_alpha and silu_and_mul_clamp: inputs and outputs of the reference tests' own pure-torch
+    functions (tests/test_swiglu_with_alpha_limit.py:9-14, tests/test_silu_and_mul_clamp.py:8-91), on the CPU."""
+    ta = _import_ref("test_swiglu_with_alpha_limit")
+    tc = _import_ref("test_silu_and_mul_clamp")
+    g = torch.Generator().manual_seed(11)
+    alpha_cases, clamp_cases = [], []
+    for rows, hidden, alpha, limit, dt in [(1, 64, 0.5, 1.0, torch.float32), (16, 128, 1.0, 5.0, torch.bfloat16),
+                                           (128, 256, 2.0, 10.0, torch.float16), (5, 66, 1.702, 7.0, torch.bfloat16),
+                                           (3, 1024, 1.702, 7.0, torch.float32)]:
+        x = (torch.randn(rows, hidden, generator=g) * 4).to(dt)
+        alpha_cases.append(dict(x=x, alpha=alpha, limit=limit, out=ta.swiglu_gpt_oss_sigmoid_alpha_ref(x, alpha, limit)))
+    for M, H, dt in [(16, 32, torch.bfloat16), (128, 64, torch.float16), (16, 64, torch.bfloat16), (7, 40, torch.float16)]:
+        x = (torch.randn(M, 2 * H, generator=g) * 6).to(dt)
+        out = torch.zeros(M, H, dtype=dt)
+        tc.silu_and_mul_clamp_torch(x, out, 10.0)
+        clamp_cases.append(dict(x=x, limit=10.0, out=out))
+    save("swiglu", dict(alpha=alpha_cases, clamp=clamp_cases))
+
+
 GENERATORS = {
+    "swiglu": gen_swiglu,
     "rope": gen_rope,
     "attention": gen_attention,
     "moe_w4a16": gen_moe,

@@ -7,7 +7,8 @@ import torch
 
 def test_import_registers_ops(sglk):
     for name in ["rmsnorm", "fused_add_rmsnorm", "gemma_rmsnorm", "gemma_fused_add_rmsnorm", "silu_and_mul",
-                 "gelu_tanh_and_mul", "gelu_and_mul", "sgl_per_token_group_quant_8bit",
+                 "gelu_tanh_and_mul", "gelu_and_mul", "silu_and_mul_clamp", "swiglu_gpt_oss_sigmoid_alpha",
+                 "sgl_per_token_group_quant_8bit",
                  "fp8_blockwise_scaled_mm"]:
         assert hasattr(torch.ops.sgl_kernel, name), name
 
@@ -16,6 +17,11 @@ def test_schemas_match_reference_contract(sglk):
     # reference src/torch_extension_sycl.cc:41, :29, :395-398
     s = torch.ops.sgl_kernel.rmsnorm.default._schema
     assert str(s) == "sgl_kernel::rmsnorm(Tensor($0! -> ) output, Tensor input, Tensor weight, float eps) -> ()"
+    # reference src/torch_extension_sycl.cc:32, :108
+    assert str(torch.ops.sgl_kernel.silu_and_mul_clamp.default._schema) == \
+        "sgl_kernel::silu_and_mul_clamp(Tensor($0! -> ) out, Tensor input, float swiglu_limit) -> ()"
+    assert str(torch.ops.sgl_kernel.swiglu_gpt_oss_sigmoid_alpha.default._schema) == \
+        "sgl_kernel::swiglu_gpt_oss_sigmoid_alpha(Tensor x, float alpha, float limit) -> Tensor"
     s = torch.ops.sgl_kernel.sgl_per_token_group_quant_8bit.default._schema
     assert [a.name for a in s.arguments] == ["input", "output_q", "output_s", "group_size", "eps", "fp8_min",
                                              "fp8_max", "scale_ue8m0"]
@@ -59,6 +65,8 @@ class _Recorder:
         class _Op:
             def __call__(self, *a, **k):
                 rec.calls.append((name, a, k))
+                if name == "swiglu_gpt_oss_sigmoid_alpha":  # (the one op of these wrappers whose result is used)
+                    return a[0].new_empty(a[0].shape[0], a[0].shape[1] // 2)
                 return 0
 
             default = property(lambda self_: self_)
@@ -205,8 +213,18 @@ def test_fused_experts_plan_and_op_sequence(sglk, monkeypatch):
     rec.calls.clear()
     moe.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, swiglu_limit=10)
     assert rec.calls[2][1][10:] == (4, 10.0)
-    with pytest.raises(NotImplementedError, match="gpt-oss"):
-        moe.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, gemm1_alpha=1.702, gemm1_limit=7.0)
+    # gpt-oss swiglu (reference moe.py:692-697, :751-789): plain GEMM 1 to [rows, 2I], the interleaved-pairs op, GEMM 2
+    rec.calls.clear()
+    moe.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, gemm1_alpha=1.702, gemm1_limit=7.0)
+    assert rec.names() == ["prepare_moe_input", "scatter_tokens_to_experts", "moe_grouped_mm_nt_xe20_w4a16",
+                           "swiglu_gpt_oss_sigmoid_alpha", "moe_grouped_mm_nt_xe20_w4a16", "apply_shuffle_mul_sum"]
+    assert rec.calls[2][1][0].shape == (10, 128) and rec.calls[3][1][1:] == (1.702, 7.0)
+    assert rec.calls[4][1][1].shape == (10, 64)
+    with pytest.raises(AssertionError, match="gemm1_limit must be provided"):
+        moe.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, gemm1_alpha=1.702)
+    with pytest.raises(AssertionError, match="activation must be silu"):
+        moe.fused_experts(x, w1, w2, tw, ti, activation="gelu", use_int4_w4a16=True, w1_scale=s1, w2_scale=s2,
+                          gemm1_alpha=1.702, gemm1_limit=7.0)
     # relu2: no gate (gate_factor 1): relu^2 in the same epilogue; inplace writes over the input
     rec.calls.clear()
     x, w1, w2, tw, ti, s1, s2 = _moe_case(gated=False)

@@ -498,6 +498,50 @@ def test_fused_experts_16bit(sglk, dev, T, topk, E, H, I, activation, bias):
     torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=3e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("T,topk,E,H,I", [(1, 2, 8, 1024, 512), (4, 1, 8, 1024, 1024), (33, 6, 8, 1024, 1024),
+                                          (222, 2, 64, 1024, 512), (64, 1, 8, 4096, 512), (222, 6, 8, 1024, 4096)])
+@pytest.mark.parametrize("bias", [None, "bfloat16", "float32"])
+def test_fused_experts_gpt_oss_swiglu(sglk, dev, T, topk, E, H, I, bias):
+    """the ("silu", SWIGLU_ALPHA, SWIGLU_LIMIT) rows of reference tests/test_moe_gemm.py:141-160: gate / up interleaved in
+    w1's rows, gate = min(gate, 7), up = clamp(up, -7, 7), gate * sigmoid(1.702 gate) * (up + 1)"""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(T + H + I + topk)
+    x = (torch.randn(T, H, generator=g) * 0.5).to(dt)
+    w1 = (torch.randn(E, 2 * I, H, generator=g) * 0.1).to(dt)  # (pre-activations of +-10: both clamps take part)
+    w2 = (torch.randn(E, H, I, generator=g) * 0.03).to(dt)
+    b1 = b2 = None
+    if bias:
+        bdt = torch.bfloat16 if bias == "bfloat16" else torch.float32
+        b1 = (torch.randn(E, 2 * I, generator=g) * 0.5).to(bdt)
+        b2 = (torch.randn(E, H, generator=g) * 0.005).to(bdt)
+    score = torch.softmax(torch.randn(T, E, generator=g).to(dt).float(), dim=-1)
+    tw, ids = torch.topk(score, topk)
+    d = lambda t: t.to(dev) if t is not None else None
+    out = sglk.fused_experts(d(x), d(w1), d(w2), d(tw), d(ids), d(b1), d(b2), activation="silu", routed_scaling_factor=2.5,
+                             gemm1_alpha=1.702, gemm1_limit=7.0)
+    ref = omoe.fused_experts_16bit(x, w1, w2, tw, ids, b1, b2, "silu", 2.5, gemm1_alpha=1.702, gemm1_limit=7.0)
+    plain = omoe.fused_experts_16bit(x, w1, w2, tw, ids, b1, b2, "silu", 2.5)
+    assert (ref.float() - plain.float()).abs().max() > 0.05  # (the case tells the gpt-oss form from the split-halves silu)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=3e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("explicit_zero", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_experts_int4_gpt_oss_swiglu(sglk, dev, explicit_zero, dtype):
+    g = torch.Generator().manual_seed(5 + explicit_zero)
+    T, E, topk, H, I, gs = 40, 8, 2, 512, 256, 64
+    x = torch.randn(T, H, generator=g).to(dtype)
+    w1, s1, z1 = make_int4(E, 2 * I, H, gs, dtype, explicit_zero, g)
+    w2, s2, z2 = make_int4(E, H, I, gs, dtype, explicit_zero, g)
+    tw = torch.rand(T, topk, generator=g)
+    ids = torch.stack([torch.randperm(E, generator=g)[:topk] for _ in range(T)]).to(torch.int32)
+    d = lambda t: t.to(dev) if t is not None else None
+    out = sglk.fused_experts(d(x), d(w1), d(w2), d(tw), d(ids), use_int4_w4a16=True, w1_scale=d(s1), w2_scale=d(s2),
+                             w1_zp=d(z1), w2_zp=d(z2), gemm1_alpha=1.702, gemm1_limit=7.0)
+    ref = omoe.fused_experts_int4(x, w1, w2, tw, ids, s1, s2, z1, z2, gemm1_alpha=1.702, gemm1_limit=7.0)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=5e-2, atol=2e-2)  # reference tolerance (:386)
+
+
 def test_errors(sglk, dev):
     with pytest.raises(AssertionError):
         sglk.fused_experts(torch.zeros(1, 128, device=dev), torch.zeros(1, 2, 64, device=dev),

@@ -45,6 +45,17 @@ def test_activation_matches_reference_vectors():
             torch.testing.assert_close(fn(e["x"]), e["out"], rtol=e["rtol"], atol=e["atol"])
 
 
+def test_swiglu_variants_match_reference_vectors():
+    # outputs of the reference tests' own pure-torch functions (tests/test_swiglu_with_alpha_limit.py:9-14, which works in
+    # the input dtype - hence its 1e-1 tolerance for 16-bit inputs, :42-43 - and tests/test_silu_and_mul_clamp.py:8-91)
+    g = load_golden("swiglu")
+    for c in g["alpha"]:
+        tol = 1e-4 if c["x"].dtype == torch.float32 else 1e-1
+        torch.testing.assert_close(oact.swiglu_gpt_oss_sigmoid_alpha(c["x"], c["alpha"], c["limit"]), c["out"], rtol=tol, atol=tol)
+    for c in g["clamp"]:
+        torch.testing.assert_close(oact.silu_and_mul_clamp(c["x"], c["limit"]), c["out"], rtol=1e-2, atol=1e-2)
+
+
 def test_quant_matches_reference_vectors():
     for c in load_golden("quant"):
         x, gs = c["x"], c["group_size"]
