@@ -157,6 +157,11 @@ def side_metrics(sgl_kernel, dev):
     o2 = torch.empty(4096, 4096, device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: sgl_kernel.silu_and_mul(x2, out=o2))
     out["silu_and_mul_4096x8192_bf16_GBs"] = round(3 * o2.numel() * 2 / ms / 1e6, 1)
+    # the two swiglu variants of fused_experts on the same stream of bytes (two reads + one write per output element)
+    ms = timeit(lambda: sgl_kernel.silu_and_mul_clamp(x2, o2, 10.0))
+    out["silu_and_mul_clamp_4096x8192_bf16_GBs"] = round(3 * o2.numel() * 2 / ms / 1e6, 1)
+    ms = timeit(lambda: sgl_kernel.swiglu_gpt_oss_sigmoid_alpha(x2, 1.702, 7.0))
+    out["swiglu_gpt_oss_4096x8192_bf16_GBs"] = round(3 * o2.numel() * 2 / ms / 1e6, 1)
     q = torch.empty(4096, 4096, dtype=FP8, device=dev)
     s = torch.empty(32, 4096, dtype=torch.float32, device=dev).t()
     ms = timeit(lambda: sgl_kernel.sgl_per_token_group_quant_8bit(x, q, s, 128, 1e-10, -448.0, 448.0, False,
