@@ -5,6 +5,7 @@
 #   attn   : tools/attn_decode_sweep.py (fwd decode d = 64 / 128 / 256 / fp8 KV)
 #   moe    : tools/moe_bench.py 64 2048 (fused_experts int4 W4A16: streaming kernels at 64 tokens, moe_persist.hip at 2048)
 #   qserve : tools/qserve_bench.py 16 4096 (decode split kernel, W4A8 modes of the persistent int8 pipeline)
+#   swiglu : tools/swiglu_bench.py (silu_and_mul, silu_and_mul_clamp, swiglu_gpt_oss_sigmoid_alpha streams)
 # One rocprofv3 invocation per pass (tools/gpu_prof.sh), the program directly after "--", counters never with trace flags.
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
@@ -17,6 +18,7 @@ for s in $SETS; do
     attn) tools/gpu_prof.sh attn python3 $R/tools/attn_decode_sweep.py ;;
     moe) tools/gpu_prof.sh moe python3 $R/tools/moe_bench.py 64 2048 ;;
     qserve) tools/gpu_prof.sh qserve python3 $R/tools/qserve_bench.py 16 4096 ;;
+    swiglu) PROF_MEM=1 tools/gpu_prof.sh swiglu python3 $R/tools/swiglu_bench.py ;;
   esac
 done > $R/gpurun_out/r03/prof_all.log 2>&1
 ls $R/gpurun_out/r03/prof/digest
