@@ -88,8 +88,12 @@ __global__ __launch_bounds__(256) void silu_mul_clamp_kernel(T* __restrict__ out
     Vec<T, VEC> y;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float g = through_bf16(fminf(through_bf16((float)a[e]), lim));
-      const float u = through_bf16(fmaxf(-lim, fminf(through_bf16((float)b[e]), lim)));
+      // (the reference rounds the clamped values to bf16 once more: min / max of two bf16 values is one of them; and a
+      // bf16 input is its own rounding)
+      const float ga = sizeof(T) == 2 && __is_same(T, bf16) ? (float)a[e] : through_bf16((float)a[e]);
+      const float ub = sizeof(T) == 2 && __is_same(T, bf16) ? (float)b[e] : through_bf16((float)b[e]);
+      const float g = fminf(ga, lim);
+      const float u = fmaxf(-lim, fminf(ub, lim));
       y[e] = (T)(g * (1.0f / (1.0f + expf(-g))) * u);
     }
     store_vec<T, VEC>(out + idx * VEC, y);
