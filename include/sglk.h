@@ -141,18 +141,6 @@ SGLK_API int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const
                                           int64_t ldb, int64_t ldc, int64_t sa_stride_m,
                                           int64_t sa_stride_k, int64_t sb_stride_k,
                                           int64_t sb_stride_n, int out_dtype);
-/* Diagnostic (no reference counterpart): while device_buf is not NULL, every workgroup of the large-M kernel of
- * fp8_blockwise_scaled_mm writes four uint32 at device_buf[4 * (workgroup + 256 * (launch of 128-row half tiles))]:
- * {shader cycles, 100 MHz ticks, K blocks processed, m-steps per block} - shader clock = 100 MHz * cycles / ticks.
- * 512 x 4 uint32; process-wide, not thread-safe; bench.py reports the clock the part sustains under the kernel with it. */
-SGLK_API void sglk_diag_set_gemm_clock_stamps(uint32_t* device_buf);
-/* The same for the tile pipeline of the grouped MoE GEMMs (csrc/moe_persist.hip): 256 x 4 uint32, one record per workgroup of
- * the last launch, followed by 256 x 8 x 2 uint32: per wave the shader cycles spent in front of the K blocks' barriers waiting
- * for its own LDS-DMA / LDS data, and at the barriers themselves (5120 uint32 in all; the per-wave part is filled by the
- * diagnostic build of the library only). */
-SGLK_API void sglk_diag_set_moe_clock_stamps(uint32_t* device_buf);
-/* Diagnostic: s_setprio value (0..3) of waves 4..7 of that kernel's workgroups (default 0). */
-SGLK_API void sglk_diag_set_moe_prio(int prio);
 
 /* ---- per-token / per-channel scaled GEMM ------------------------------------
  * fp8_scaled_mm / int8_scaled_mm: declared in reference

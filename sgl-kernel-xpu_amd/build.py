@@ -263,6 +263,19 @@ def build_probes(jobs=None, force=False, verbose=True):
     return lib
 
 
+def build_ceiling(force=False, verbose=True):
+    """bench.py's MFMA ceiling probe (tools/mfma_ceiling.hip): its own small library, not linked into the product."""
+    src = os.path.join(ROOT, "tools", "mfma_ceiling.hip")
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    lib = os.path.join(bdir, "libsglk_ceiling.so")
+    if force or newer(lib, [src]):
+        dt, out = run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", lib])
+        if verbose:
+            print("[build] hipcc %-32s %5.1fs" % ("mfma_ceiling.hip", dt), flush=True)
+    return lib
+
+
 def build(jobs=None, force=False, with_torch=True, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -281,6 +294,7 @@ def build(jobs=None, force=False, with_torch=True, verbose=True):
         dt, out = run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs)
         if verbose:
             print("[build] link  %-32s %5.1fs" % ("libsglk.so", dt), flush=True)
+    build_ceiling(force, verbose)
     problems = check_isa(verbose)
     if problems:
         raise RuntimeError("ISA check failed (hand-managed registers are not safe with this compiler output):\n  "

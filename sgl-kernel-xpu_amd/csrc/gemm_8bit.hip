@@ -1086,21 +1086,31 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
 //    consecutive output columns of one row (two 16-byte stores per 32 x 32 tile).
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+// One PHASE of the kernel below: the units of one kind (MS = 4: whole 256-row tiles, MS = 2: 128-row half tiles) of this
+// workgroup, prologue to final stores. smem = the workgroup's kStages * kStageBytes of LDS.
 template <typename OutT, int MS, int PROBE>  // MS m-steps (32 rows) per K block: 4 = 256-row tiles, 2 = 128-row half tiles
-__global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
-    OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+__device__ __forceinline__ void gemm_fp8bw_x32_phase(
+    char* smem, OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
     int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves,
     uint32_t* __restrict__ stamps) {
-  __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nkb = K / BK;  // >= 2
-  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 15);
-  // (diagnostic build: stamps != nullptr) shader cycles and 100 MHz ticks of the whole workgroup -> the clock it ran at
+  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 14);
+  // LDS stage of this phase: a rows [64 MS][128 B], b^T rows [256][128 B], 256 row scales (+ 1 KiB spare). Whole tiles: two
+  // stages of 66 KiB. Half tiles: THREE stages of 50 KiB - with 1024 cycles of MFMAs per K block and the block's data
+  // requested one block ahead, the half-tile loop ran at the latency of its LDS-DMA (2450 shader cycles per block,
+  // in-kernel stamps); here block g + 2's b pieces go out in block g and block g + 3's a pieces behind its barrier.
+  constexpr int NST = MS == 2 ? 3 : 2;
+  constexpr int kOffB = MS * 64 * BK, kOffS = kOffB + kTileBytes, kStg = kOffS + 2048;
+  static_assert(NST * kStg <= 160 * 1024 - 8192, "LDS");
+#ifdef SGLK_PROBES
+  // (diagnostic build, stamps != nullptr) shader cycles and 100 MHz ticks of this phase -> the clock it ran at
   const uint64_t st_c0 = stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+#endif
   // (diagnostic build) 5: every DMA piece out of range (issue + LDS write of zeros, no fetch); 6: a / b pieces as plain
   // loads into registers (fetch, no LDS write); results are garbage, no stores
 
@@ -1178,13 +1188,14 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
   // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = rows of b^T (sub 0, 1 each); (part 0, sub 2) = row scales
   auto dma_piece = [&](const TileDesc& d, int kb_, int s, int part, int sub) {
     const int kb = PROBE == 4 ? 0 : kb_;
-    char* base = smem + s * kStageBytes;
+    char* base = smem + s * kStg;
     if (sub == 2) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s), SGLK_LDS(base + 2 * kTileBytes + wave * 256), 4,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s), SGLK_LDS(base + kOffS + wave * 256), 4,
                                                voff_s, kb * (int)sa_sk * 4, 0, 0);
       return;
     }
-    const int ii = (part & 1) * 2 + sub, piece = wave * 4 + ii;
+    // (half tiles: a has 128 rows = 16 pieces, two per wave - part 0 only)
+    const int ii = (MS == 2 && part < 2) ? sub : (part & 1) * 2 + sub, piece = (MS == 2 && part < 2) ? wave * 2 + sub : wave * 4 + ii;
     if constexpr (PROBE == 6) {
       const v4i t = __builtin_amdgcn_raw_buffer_load_b128(part < 2 ? make_rsrc(d.pa, d.nrec_a) : make_rsrc(d.pb, d.nrec_b),
                                                           part < 2 ? voff_a[ii & 1] : voff_b[ii & 1],
@@ -1196,7 +1207,7 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
       __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pa, d.nrec_a), SGLK_LDS(base + piece * 1024), 16,
                                                voff_a[ii & 1], kb * BK + piece * 8 * (int)lda, 0, 0);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b), SGLK_LDS(base + kTileBytes + piece * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.pb, d.nrec_b), SGLK_LDS(base + kOffB + piece * 1024), 16,
                                                voff_b[ii & 1], kb * BK + piece * 8 * (int)ldb, 0, 0);
     }
   };
@@ -1263,7 +1274,7 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
   for (int r = 0; r < 16; ++r) cur1[r] = 0.f;  // (the first step folds nothing)
   int one_e8m0 = 127;
   asm volatile("" : "+v"(one_e8m0), "+v"(sc), "+v"(cur1));
-  int gblk = 0;
+  int gblk = 0, stg = 0;  // K blocks done; (three stages) the stage of the running block
 
   // m-step mf of a K block. LAST: behind the block's barrier; its gaps carry the reads of the next block's fragments.
   // LDS reads in issue order - a step: m half 0 (2), m half 1 (2), row scale; the last step: n0 half 0 (2), n1 half 0 (2),
@@ -1285,22 +1296,12 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     if (LAST) {                                                                                                \
       X32_RD16(nq[1][0][0], nb0, 4096);  X32_RD16(nq[1][0][1], nb1, 4096);                                     \
       X32_RD16(mq[0][0], na0, 0);        X32_RD16(mq[0][1], na1, 0);                                           \
-      if (kDma) dma_piece(d2, kb2, s, 0, 0);                                                                   \
-      if (kDma && MS == 2) dma_piece(d2, kb2, s, 1, 0);                                                        \
+      if (kDma) dma_piece(dL, kbL, sL, 0, 0);                                                                  \
     } else {                                                                                                   \
       X32_RD16(mq[0][0], a0, ((mf) + 1) * 4096);  X32_RD16(mq[0][1], a1, ((mf) + 1) * 4096);                   \
-      if constexpr (PROBE == 15 && (STORE)) {                                                                  \
-        /* (probe 15: the store block's pieces all go out in front of its first store - see X32_BLOCK's wait) */ \
-        if ((mf) == 0) {                                                                                       \
-          if (MS == 4) { dma_piece(d1, kb1, s ^ 1, 1, 0); dma_piece(d1, kb1, s ^ 1, 1, 1); }                   \
-          dma_piece(d1, kb1, s ^ 1, 2, 0);  dma_piece(d1, kb1, s ^ 1, 2, 1);                                   \
-          dma_piece(d1, kb1, s ^ 1, 3, 0);  dma_piece(d1, kb1, s ^ 1, 3, 1);                                   \
-        }                                                                                                      \
-      } else {                                                                                                 \
-        if (kDma && MS == 4 && (mf) == 0) dma_piece(d1, kb1, s ^ 1, 1, 0);                                     \
-        if (kDma && MS == 4 && (mf) == 1) dma_piece(d1, kb1, s ^ 1, 2, 1);                                     \
-        if (kDma && MS == 2) dma_piece(d1, kb1, s ^ 1, 2, 0);                                                  \
-      }                                                                                                        \
+      if (kDma && MS == 4 && (mf) == 0) dma_piece(dE, kbE, sE, 1, 0);                                          \
+      if (kDma && MS == 4 && (mf) == 1) dma_piece(dE, kbE, sE, 2, 1);                                          \
+      if (kDma && MS == 2) dma_piece(dE, kbE, sE, 2, 0);                                                       \
     }                                                                                                          \
     if constexpr (STORE) {                                                                                     \
       store_frag(prv, acc[mf], (mf));                                                                          \
@@ -1312,67 +1313,75 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     const float scn_ = raw * sbv;                                                                              \
     if (LAST) {                                                                                                \
       X32_RD16(nq[0][1][0], nb2, 0);  X32_RD16(nq[0][1][1], nb3, 0);                                           \
-      if (kDma) dma_piece(d2, kb2, s, 0, 1);                                                                   \
-      if (kDma && MS == 2) dma_piece(d2, kb2, s, 1, 1);                                                        \
+      if (kDma) dma_piece(dL, kbL, sL, 0, 1);                                                                  \
     } else {                                                                                                   \
-      /* (the block's last pieces go out two m-steps before its barrier: issued in the step in front of it they were */ \
-      /* still in flight at the vmcnt(0) there: +54 us at the headline shape)                                        */ \
-      if constexpr (!(PROBE == 15 && (STORE))) {                                                               \
-        if (kDma && MS == 4 && (mf) == 0) { dma_piece(d1, kb1, s ^ 1, 1, 1); dma_piece(d1, kb1, s ^ 1, 2, 0); } \
-        if (kDma && MS == 4 && (mf) == 1) { dma_piece(d1, kb1, s ^ 1, 3, 0); dma_piece(d1, kb1, s ^ 1, 3, 1); } \
-        if (kDma && MS == 2) { dma_piece(d1, kb1, s ^ 1, 2, 1); dma_piece(d1, kb1, s ^ 1, 3, 0); }             \
-      }                                                                                                        \
+      /* (whole tiles: the block's last pieces go out two m-steps before its barrier: issued in the step in front of it */ \
+      /* they were still in flight at the vmcnt(0) there: +54 us at the headline shape)                                  */ \
+      if (kDma && MS == 4 && (mf) == 0) { dma_piece(dE, kbE, sE, 1, 1); dma_piece(dE, kbE, sE, 2, 0); }        \
+      if (kDma && MS == 4 && (mf) == 1) { dma_piece(dE, kbE, sE, 3, 0); dma_piece(dE, kbE, sE, 3, 1); }        \
+      if (kDma && MS == 2) { dma_piece(dE, kbE, sE, 2, 1); dma_piece(dE, kbE, sE, 3, 0); }                     \
     }                                                                                                          \
     X32_MFMA2(cur1, 1)                                                                                         \
     if (LAST) {                                                                                                \
       X32_RD16(nq[1][1][0], nb2, 4096);  X32_RD16(nq[1][1][1], nb3, 4096);                                     \
       X32_RD16(mq[1][0], na2, 0);        X32_RD16(mq[1][1], na3, 0);                                           \
       X32_RD4(raw, nts, 0);                                                                                    \
-      if (kDma) dma_piece(d2, kb2, s, 0, 2);                                                                   \
+      if (kDma) dma_piece(dL, kbL, sL, 0, 2);                                                                  \
     } else {                                                                                                   \
       X32_RD16(mq[1][0], a2, ((mf) + 1) * 4096);  X32_RD16(mq[1][1], a3, ((mf) + 1) * 4096);                   \
       X32_RD4(raw, ts_addr, ((mf) + 1) * 128);                                                                 \
-      if (kDma && MS == 2 && !(PROBE == 15 && (STORE))) dma_piece(d1, kb1, s ^ 1, 3, 1);                       \
+      if (kDma && MS == 2) dma_piece(dE, kbE, sE, 3, 1);                                                       \
     }                                                                                                          \
     sc = scn_;                                                                                                 \
     asm volatile("" : "+v"(sc), "+v"(cur0));                                                                   \
     X32_PROMOTE((mf), 0, cur0)                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
-// WHERE: 0 = any block (the tiles of blocks + 1 / + 2 picked by scalar selects: the first block of a tile), 1 = blocks + 1 and
-// + 2 inside the running tile (the steady loop: no selects between its MFMAs - with them the compiler's placement of ~40 scalar
-// instructions differed between two instantiations of this very kernel by 5.6 % of the GEMM's time), 2 = the tile's last but
-// one block, 3 = its last block.
+// WHERE: 0 = any block (the tiles of blocks + 1 / + 2 / + 3 picked by scalar selects: the first block of a tile), 1 = those
+// blocks inside the running tile (the steady loop: no selects between its MFMAs - with them the compiler's placement of ~40
+// scalar instructions differed between two instantiations of this very kernel by 5.6 % of the GEMM's time), 2 = the tile's last
+// but one block, 3 = its last block (whole tiles), 4 = 1 right behind the store block (half tiles: its wait counts the stores).
+// dE / kbE / sE: tile, K block and stage of the pieces that go out in front of the barrier (block + 1, with three stages
+// block + 2); dL / kbL / sL: of those behind it (block + 2 into the stage just read; with three stages block + 3).
 #define X32_BLOCK(STORE, WHERE)                                                                                \
   {                                                                                                            \
-    const int s = gblk & 1;                                                                                    \
-    const uint32_t sbase = lds_base + (uint32_t)(s * kStageBytes);                                             \
-    const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStageBytes);                                       \
-    const bool in1 = (WHERE) == 0 ? kb + 1 < nkb : (WHERE) != 3, in2 = (WHERE) == 0 ? kb + 2 < nkb : (WHERE) == 1; \
+    const int s = NST == 2 ? (gblk & 1) : stg;                                                                 \
+    const int s1 = NST == 2 ? (s ^ 1) : (s == 2 ? 0 : s + 1), s2 = NST == 2 ? s : (s1 == 2 ? 0 : s1 + 1);      \
+    const uint32_t sbase = lds_base + (uint32_t)(s * kStg);                                                    \
+    const uint32_t nbase = lds_base + (uint32_t)(s1 * kStg);                                                   \
+    constexpr bool steady_ = (WHERE) == 1 || (WHERE) == 4;                                                     \
+    const bool in1 = (WHERE) == 0 ? kb + 1 < nkb : (WHERE) != 3, in2 = (WHERE) == 0 ? kb + 2 < nkb : steady_,  \
+               in3 = (WHERE) == 0 ? kb + 3 < nkb : steady_;                                                    \
     const TileDesc d1 = (WHERE) == 0 ? pick(in1, cur_t, nxt) : (WHERE) == 3 ? nxt : cur_t;                     \
-    const TileDesc d2 = (WHERE) == 0 ? pick(in2, cur_t, nxt) : (WHERE) == 1 ? cur_t : nxt;                     \
-    const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
+    const TileDesc d2 = (WHERE) == 0 ? pick(in2, cur_t, nxt) : steady_ ? cur_t : nxt;                          \
+    const TileDesc d3 = NST == 2 ? d2 : (WHERE) == 0 ? pick(in3, cur_t, nxt) : steady_ ? cur_t : nxt;          \
+    const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb, kb3 = in3 ? kb + 3 : kb + 3 - nkb;    \
+    const TileDesc& dE = NST == 2 ? d1 : d2;                                                                   \
+    const TileDesc& dL = NST == 2 ? d2 : d3;                                                                   \
+    const int kbE = NST == 2 ? kb1 : kb2, kbL = NST == 2 ? kb2 : kb3, sE = NST == 2 ? s1 : s2, sL = s;         \
     uint32_t a0, a1, a2, a3, ts_addr, nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0, na0 = 0, na1 = 0, na2 = 0, na3 = 0, nts = 0; \
     {                                                                                                          \
       int fo = frag_off_a;                                                                                     \
       asm volatile("" : "+v"(fo));                                                                             \
       a0 = sbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)fo;                                            \
       a1 = a0 ^ 16u;  a2 = a0 ^ 32u;  a3 = a0 ^ 48u;                                                           \
-      ts_addr = sbase + 2 * kTileBytes + (uint32_t)(wm * (MS * 32) * 4) + (uint32_t)((fo >> 7) << 2);          \
+      ts_addr = sbase + (uint32_t)kOffS + (uint32_t)(wm * (MS * 32) * 4) + (uint32_t)((fo >> 7) << 2);         \
     }                                                                                                          \
     if constexpr (MS == 4) { X32_STEP(0, STORE, false) X32_STEP(1, STORE, false) X32_STEP(2, STORE, false) }   \
     else { X32_STEP(0, STORE, false) }                                                                         \
     float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
-    /* (probe 15: vmcnt retires in issue order and the store block's 4 (MS - 1) stores are its youngest operations, so */ \
-    /* the block's pieces have landed at vmcnt(4 (MS - 1)) and the stores get one more K block before anything waits -   */ \
-    /* 0.2376 against 0.2378 ms: one K block is a quarter of the time the 33 MB burst takes to drain)                     */ \
-    if constexpr (PROBE == 15 && (STORE) && MS == 4) {                                                         \
-      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier"                                               \
+    /* (round 3, probe 15 - counted vmcnt at the store block's barrier of whole tiles so that the stores get one more K block */ \
+    /* before anything waits - changed nothing, 0.2376 against 0.2378 ms: the 33 MB burst takes four K blocks to drain)          */ \
+    /* Half tiles, three stages: vmcnt retires in issue order; younger than block + 1's pieces are the 3 pieces issued behind    */ \
+    /* the last barrier and the 4 issued in this block's first step - plus the 4 stores of a store block's step, here or in the  */ \
+    /* block before.                                                                                                             */ \
+    if constexpr (NST == 3 && ((STORE) || (WHERE) == 4)) {                                                     \
+      asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)\n\ts_barrier"                                               \
                    : "+v"(mq[0][0]), "+v"(mq[0][1]), "+v"(mq[1][0]), "+v"(mq[1][1]), "+v"(raw)                  \
                    :                                                                                           \
                    : "memory");                                                                                \
-    } else if constexpr (PROBE == 15 && (STORE)) {                                                             \
-      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier"                                                \
+    } else if constexpr (NST == 3) {                                                                           \
+      asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier"                                                \
                    : "+v"(mq[0][0]), "+v"(mq[0][1]), "+v"(mq[1][0]), "+v"(mq[1][1]), "+v"(raw)                  \
                    :                                                                                           \
                    : "memory");                                                                                \
@@ -1391,16 +1400,17 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     {                                                                                                          \
       int foa = frag_off_a, fob = frag_off_b;                                                                  \
       asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
-      nb0 = nbase + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)fob;                                    \
+      nb0 = nbase + (uint32_t)(kOffB + wn * 64 * 128) + (uint32_t)fob;                                         \
       nb1 = nb0 ^ 16u;  nb2 = nb0 ^ 32u;  nb3 = nb0 ^ 48u;                                                     \
       na0 = nbase + (uint32_t)(wm * d1.wrows * 128) + (uint32_t)foa;                                           \
       na1 = na0 ^ 16u;  na2 = na0 ^ 32u;  na3 = na0 ^ 48u;                                                     \
-      nts = nbase + 2 * kTileBytes + (uint32_t)(wm * d1.wrows * 4) + (uint32_t)((foa >> 7) << 2);              \
+      nts = nbase + (uint32_t)kOffS + (uint32_t)(wm * d1.wrows * 4) + (uint32_t)((foa >> 7) << 2);             \
       asm volatile("" : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(nb3), "+v"(na0), "+v"(na1), "+v"(na2), "+v"(na3), "+v"(nts)); \
     }                                                                                                          \
     X32_STEP(MS - 1, STORE, true)                                                                              \
     sbv = sbv_next;                                                                                            \
     ++gblk;                                                                                                    \
+    stg = s1;                                                                                                  \
   }
 
   int unit = 0;
@@ -1409,17 +1419,32 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
   // ---- prologue: block 0 of the first unit lands, its fragments are read (in the last step's order), part 0 of block 1 goes out
 #pragma unroll
   for (int part = 0; part < 4; ++part) {
+    if (MS == 2 && part == 1) continue;
     dma_piece(cur_t, 0, 0, part, 0);
     dma_piece(cur_t, 0, 0, part, 1);
   }
   dma_piece(cur_t, 0, 0, 0, 2);
   sbv = cur_t.sbw[0];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (NST == 3) {  // all of block 1 and the a pieces + row scales of block 2 go out before anything waits
+    if (kDma) {
+      dma_piece(cur_t, 1, 1, 0, 0);  dma_piece(cur_t, 1, 1, 0, 1);
+      dma_piece(cur_t, 1, 1, 2, 0);  dma_piece(cur_t, 1, 1, 2, 1);
+      dma_piece(cur_t, 1, 1, 3, 0);  dma_piece(cur_t, 1, 1, 3, 1);
+      dma_piece(cur_t, 1, 1, 0, 2);
+      dma_piece(cur_t, 2, 2, 0, 0);  dma_piece(cur_t, 2, 2, 0, 1);
+      dma_piece(cur_t, 2, 2, 0, 2);
+      asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
   asm volatile("" : "+v"(sbv));
   {
-    const uint32_t b0 = lds_base + (uint32_t)(kTileBytes + wn * 64 * 128) + (uint32_t)frag_off_b;
+    const uint32_t b0 = lds_base + (uint32_t)(kOffB + wn * 64 * 128) + (uint32_t)frag_off_b;
     const uint32_t p0 = lds_base + (uint32_t)(wm * cur_t.wrows * 128) + (uint32_t)frag_off_a;
-    const uint32_t ts0 = lds_base + 2 * kTileBytes + (uint32_t)(wm * cur_t.wrows * 4) + (uint32_t)(li << 2);
+    const uint32_t ts0 = lds_base + (uint32_t)kOffS + (uint32_t)(wm * cur_t.wrows * 4) + (uint32_t)(li << 2);
     const uint32_t b1 = b0 ^ 16u, b2 = b0 ^ 32u, b3 = b0 ^ 48u, p1 = p0 ^ 16u, p2 = p0 ^ 32u, p3 = p0 ^ 48u;
     X32_RD16(nq[0][0][0], b0, 0);     X32_RD16(nq[0][0][1], b1, 0);
     X32_RD16(nq[1][0][0], b0, 4096);  X32_RD16(nq[1][0][1], b1, 4096);
@@ -1429,14 +1454,10 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     X32_RD16(mq[1][0], p2, 0);        X32_RD16(mq[1][1], p3, 0);
     X32_RD4(raw, ts0, 0);
   }
-  if (kDma) {
+  if (kDma && NST == 2) {
     dma_piece(cur_t, 1, 1, 0, 0);
     dma_piece(cur_t, 1, 1, 0, 1);
     dma_piece(cur_t, 1, 1, 0, 2);
-    if (MS == 2) {
-      dma_piece(cur_t, 1, 1, 1, 0);
-      dma_piece(cur_t, 1, 1, 1, 1);
-    }
   }
 
   for (; unit < n_units; ++unit) {
@@ -1447,6 +1468,14 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     }
     if constexpr (PROBE == 11) {  // (the round's first form: every block picks its tiles)
       for (int kb = 1; kb < nkb; ++kb) X32_BLOCK(false, 0)
+    } else if constexpr (NST == 3) {  // (three stages: the tile's last three blocks pick the tiles of the pieces they issue)
+      int kb = 1;
+      if (kb < nkb - 3) {
+        X32_BLOCK(false, 4)
+        ++kb;
+      }
+      for (; kb < nkb - 3; ++kb) X32_BLOCK(false, 1)
+      for (; kb < nkb; ++kb) X32_BLOCK(false, 0)
     } else {
       int kb = 1;
       for (; kb < nkb - 2; ++kb) X32_BLOCK(false, 1)
@@ -1467,6 +1496,7 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
   X32_PROMOTE(MS - 1, 1, cur1)
 #pragma unroll
   for (int mf = 0; mf < MS; ++mf) store_frag(prv, acc[mf], mf);
+#ifdef SGLK_PROBES
   if (stamps != nullptr && tid == 0) {
     const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     stamps[(blockIdx.x + (MS == 2 ? 256 : 0)) * 4 + 0] = (uint32_t)(c1 - st_c0);
@@ -1474,12 +1504,48 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     stamps[(blockIdx.x + (MS == 2 ? 256 : 0)) * 4 + 2] = (uint32_t)(n_units * nkb);
     stamps[(blockIdx.x + (MS == 2 ? 256 : 0)) * 4 + 3] = MS;
   }
+#endif
 #undef X32_PROMOTE
 #undef X32_MFMA1
 #undef X32_MFMA2
 #undef X32_RD16
 #undef X32_RD4
 #undef X32_FRAG
+}
+
+// The kernel: ONE launch per GEMM. A persistent workgroup (one per CU) runs two phases - its whole 256-row tiles
+// (MS = 4) and, when its XCD's last round is only partly filled, one 128-row half tile of that round (MS = 2) - so that
+// 896 tiles on 256 CUs (3.5 rounds) cost 3.5 rounds of every CU instead of a launch of three rounds, a pipeline drain,
+// and a second launch for the half round (round 3: 182 + 47 us). `half_first` picks the workgroups that run their half tile
+// BEFORE their whole tiles: their tile boundaries then lie half a tile away from the others', and the 128 KiB a
+// workgroup writes at each boundary no longer leave all 256 CUs within the same K block (the store burst of DESIGN 4.10).
+// all_halves: every tile as two half tiles (few rows: twice the workgroups), the MS = 2 phase only.
+// stagger: 0 = nobody, 1 = the upper half of an XCD's slots, 2 = every other pair of slots runs its half tile first.
+// Measured at (4096, 14336, 4096) in interleaved rounds on one device (kbench gemmab): 0.2200 / 0.2225 / 0.2250 ms for
+// 0 / 1 / 2 - what the halved burst gives, the XCD's L2 takes back (16 whole + 16 half tiles in flight share 4 + 4 + 2
+// panels in two K positions instead of 32 tiles sharing 4 + 8 in one): the release library uses 0.
+template <typename OutT, int PROBE>
+__global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
+    OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+    const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
+    int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves,
+    int stagger, uint32_t* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(256))) char smem[3 * (kStageBytes - kTileBytes / 2)];  // half tiles: 3 x 50 KiB; whole tiles 2 x 66 KiB
+  const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const bool half_first = all_halves || (stagger == 1 ? 2 * slot >= slots : stagger == 2 ? ((slot >> 1) & 1) != 0 : false);
+#pragma nounroll
+  for (int ph = 0; ph < (all_halves ? 1 : 2); ++ph) {
+    if ((ph == 0) == half_first) {
+      gemm_fp8bw_x32_phase<OutT, 2, PROBE>(smem, out, a, b, sa, sb, M, N, K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn,
+                                          tiles_m, tiles_n, all_halves, stamps);
+    } else {
+      gemm_fp8bw_x32_phase<OutT, 4, PROBE>(smem, out, a, b, sa, sb, M, N, K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn,
+                                          tiles_m, tiles_n, 0, stamps);
+    }
+    // (the phase has drained its own LDS reads and DMA; no wave may start the next prologue's DMA while another still
+    // reads the stages)
+    asm volatile("s_barrier" ::: "memory");
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1732,8 +1798,15 @@ static uint32_t* g_gemm_stamps = nullptr;
 constexpr int g_gemm_variant = 4;
 constexpr uint32_t* g_gemm_stamps = nullptr;
 #endif
-// sglk_diag_set_gemm_clock_stamps: where the workgroups of gemm_fp8bw_x32_kernel leave their clock stamps (nullptr: nowhere)
+// which workgroups of gemm_fp8bw_x32_kernel run their half tile first (see the kernel); the diagnostic build can change it
+// and can make the workgroups leave clock stamps (sglk_debug_set_gemm_stamps)
+#ifdef SGLK_PROBES
+static int g_gemm_stagger = 0;
 static uint32_t* g_clock_stamps = nullptr;
+#else
+constexpr int g_gemm_stagger = 0;
+constexpr uint32_t* g_clock_stamps = nullptr;
+#endif
 
 template <typename OutT, int MODE>
 static int launch(hipStream_t st, void* out, const void* a, const void* b, const float* sa, const float* sb,
@@ -1745,7 +1818,8 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   // persistent kernel: one workgroup per CU, a multiple of 8 so that every XCD gets the same number
   const unsigned pgrid = grid < (unsigned)num_cus() ? ((grid + 7) / 8) * 8 : (unsigned)num_cus();
   // (the row-scale DMA addresses its K blocks and rows with 32-bit byte offsets inside one buffer resource)
-  const bool persist_ok = K / BK >= 2 && N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)out % 16 == 0 && ldc < (1ll << 22) &&
+  // (the blockwise kernel's half-tile phase looks three K blocks ahead)
+  const bool persist_ok = K / BK >= (MODE == MODE_BLOCKWISE ? 3 : 2) && N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)out % 16 == 0 && ldc < (1ll << 22) &&
                           ((K / BK - 1) * sa_sk + 256 * sa_sm) * 4 < (1ll << 31) &&
                           (MODE == MODE_BLOCKWISE || ((uintptr_t)sb % 16 == 0 && (uintptr_t)bias % 16 == 0));
   // does any XCD cut its last partial round into half tiles (same rule as in the kernel)?
@@ -1798,14 +1872,6 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   const bool all_halves = (M <= 512 || grid <= (unsigned)num_cus() / 2) && g_gemm_variant == 4;
   const unsigned hgrid = 2 * grid < (unsigned)num_cus() ? ((2 * grid + 7) / 8) * 8 : (unsigned)num_cus();
   const int variant = (!persist_ok && g_gemm_variant != 0 && g_gemm_variant != 1) ? 1 : g_gemm_variant;
-  // SGLK_FP8_BLOCKWISE_SCHEDULE=16 (environment, read once): the 16x16x128 schedule of gemm_8bit_persist_kernel instead of
-  // the 32x32x64 one (results differ only in the fp32 summation order inside a 128-deep block); kept for A/B timing on a
-  // given device
-  static const bool sched16 = [] {
-    const char* e = getenv("SGLK_FP8_BLOCKWISE_SCHEDULE");
-    return e != nullptr && atoi(e) == 16;
-  }();
-  (void)sched16;
 #define SGLK_GO_VAR(V, H, VAR)                                                                               \
   gemm_8bit_kernel<OutT, MODE, V, H, VAR><<<grid, 512, 0, st>>>(                                             \
       (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K,   \
@@ -1827,16 +1893,9 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
 // (blockwise: the 32 x 32 x 64 schedule; the 16 x 16 x 128 one stays for the row / column scale modes and as probe 22)
 #define SGLK_GO_X32(P)                                                                                       \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
-    if (all_halves) {                                                                                        \
-      gemm_fp8bw_x32_kernel<OutT, 2, P><<<hgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
-          (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_clock_stamps); \
-    } else {                                                                                                 \
-      gemm_fp8bw_x32_kernel<OutT, 4, P><<<pgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
-          (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_clock_stamps); \
-      if (tail_halves)                                                                                       \
-        gemm_fp8bw_x32_kernel<OutT, 2, P><<<pgrid, 512, 0, st>>>((OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, \
-            (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_clock_stamps); \
-    }                                                                                                        \
+    gemm_fp8bw_x32_kernel<OutT, P><<<all_halves ? hgrid : pgrid, 512, 0, st>>>(                              \
+        (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, \
+        sb_sk, sb_sn, tiles_m, tiles_n, all_halves ? 1 : 0, tail_halves ? g_gemm_stagger : 0, g_clock_stamps);     \
   }
 #ifdef SGLK_PROBES
 #define SGLK_GO(V, H)                                                                                        \
@@ -1856,7 +1915,6 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 34: SGLK_GO_X32(12); break;                                                                       \
       case 35: SGLK_GO_X32(13); break;                                                                       \
       case 36: SGLK_GO_X32(14); break;                                                                       \
-      case 37: SGLK_GO_X32(15); break;  /* counted vmcnt at the store block's barrier */                    \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
@@ -1876,7 +1934,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
 #else
 #define SGLK_GO(V, H)                                                                                        \
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
-    if (variant == 1) { SGLK_GO_VAR(V, H, 1); } else if (sched16) { SGLK_GO_PIPE(V, H, 0) } else { SGLK_GO_X32(0) } \
+    if (variant == 1) { SGLK_GO_VAR(V, H, 1); } else { SGLK_GO_X32(0) }                                      \
   } else {                                                                                                   \
     if (variant == 1) { SGLK_GO_VAR(V, H, 0); } else { SGLK_GO_PIPE(V, H, 0) }                               \
   }
@@ -1963,11 +2021,10 @@ static int g_fp8_hw_scale = 1;
 extern "C" SGLK_API void sglk_debug_set_fp8_mfma_form(int hw_scale) { g_fp8_hw_scale = hw_scale; }
 extern "C" SGLK_API void sglk_debug_set_gemm_variant(int v) { sglk::g_gemm_variant = v; }
 extern "C" SGLK_API void sglk_debug_set_gemm_stamps(uint32_t* p) { sglk::g_gemm_stamps = p; sglk::g_clock_stamps = p; }
+extern "C" SGLK_API void sglk_debug_set_gemm_stagger(int s) { sglk::g_gemm_stagger = s; }
 #else
 constexpr int g_fp8_hw_scale = 1;
 #endif
-
-extern "C" void sglk_diag_set_gemm_clock_stamps(uint32_t* device_buf) { sglk::g_clock_stamps = device_buf; }
 
 extern "C" int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const void* a, const void* b,
                                             const float* sa, const float* sb, int64_t M, int64_t N,

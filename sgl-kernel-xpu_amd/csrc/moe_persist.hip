@@ -54,7 +54,7 @@ struct MpParams {
   const void* scales;   // int4: [E][N][K/group] in the activation type; mxfp4: [E][N][K/32] E8M0 bytes
   const void* zeros;    // int4 with zero points (FMT 3): [E][N][K/group] in the activation type, codes unsigned
   int gshift;           // int4: log2(group)
-  uint32_t* stamps;     // diagnostic (sglk_diag_set_moe_clock_stamps): per workgroup {shader cycles, 100 MHz ticks, K blocks, MS}
+  uint32_t* stamps;     // diagnostic build (sglk_debug_set_moe_clock_stamps): per workgroup {shader cycles, 100 MHz ticks, K blocks, MS}
   int prio47;           // s_setprio value of waves 4..7 (0..3)
   int blocks128;        // MS = 2 launch: 0 = only the <= 128-row remainders of 256-row blocks; 1 = all rows in 128-row blocks
                         // (remainders of at most 64 rows excepted: the caller's streaming kernels take them)
@@ -117,12 +117,19 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // arbitration: stamps at the blocks' barriers showed waves 0..3 waiting ~1250 of a block's ~4100 cycles for waves 4..7.
   // A static priority for waves 4..7 swaps the roles exactly (they then wait 1350 cycles for waves 0..3) and leaves the
   // block time where it was; kept as a diagnostic knob, off by default.
+#ifdef SGLK_PROBES
+  uint32_t* const stamps_ = p.stamps;
+  const int prio47_ = p.prio47;
+#else  // (the release library has neither the stamps nor the priority knob)
+  constexpr uint32_t* stamps_ = nullptr;
+  constexpr int prio47_ = 0;
+#endif
   if (wave >= 4) {
-    if (p.prio47 == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p.prio47 == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p.prio47 == 3) __builtin_amdgcn_s_setprio(3);
+    if (prio47_ == 1) __builtin_amdgcn_s_setprio(1);
+    else if (prio47_ == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio47_ == 3) __builtin_amdgcn_s_setprio(3);
   }
-  const uint64_t st_c0 = p.stamps ? __builtin_amdgcn_s_memtime() : 0, st_r0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  const uint64_t st_c0 = stamps_ ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamps_ ? __builtin_amdgcn_s_memrealtime() : 0;
   const int nt = MB * NB;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int q8 = nt >> 3, rem = nt & 7;
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     if constexpr (MS == 4) { MP_STEP(0, STORE, false, false) MP_STEP(1, STORE, false, false) MP_STEP(2, STORE, false, true) } \
     else { MP_STEP(0, STORE, false, true) }                                                                    \
     if constexpr (kBarStamps) { /* diagnostic build: where the block's barrier time goes (own data / the other waves) */ \
-      if (p.stamps != nullptr) {                                                                               \
+      if (stamps_ != nullptr) {                                                                               \
         const uint64_t t0_ = __builtin_amdgcn_s_memtime();                                                     \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
         const uint64_t t1_ = __builtin_amdgcn_s_memtime();                                                     \
@@ -517,13 +524,13 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[MS - 1][0]), "+v"(acc[MS - 1][1]));
 #pragma unroll
   for (int mf = 0; mf < MS; ++mf) store_frag(prv, acc[mf], mf);
-  if (p.stamps != nullptr && lane == 0) {
+  if (stamps_ != nullptr && lane == 0) {
     const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (wave == 0) {
-      uint32_t* o = p.stamps + blockIdx.x * 4;
+      uint32_t* o = stamps_ + blockIdx.x * 4;
       o[0] = (uint32_t)(c1 - st_c0);  o[1] = (uint32_t)(r1 - st_r0);  o[2] = (uint32_t)(n_units * nkb);  o[3] = MS;
     }
-    uint32_t* w = p.stamps + 1024 + (blockIdx.x * 8 + wave) * 2;  // per wave: cycles waiting for its own data / at the barrier
+    uint32_t* w = stamps_ + 1024 + (blockIdx.x * 8 + wave) * 2;  // per wave: cycles waiting for its own data / at the barrier
     w[0] = st_own;  w[1] = st_bar;
   }
 #undef MP_MFMA
@@ -531,8 +538,13 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
 #undef MP_WR16
 }
 
-static uint32_t* g_mp_stamps = nullptr;  // sglk_diag_set_moe_clock_stamps
-static int g_mp_prio47 = 0;  // (sglk_diag_set_moe_prio: 1..3 swaps which half waits, the block time stays - DESIGN 4.10)
+#ifdef SGLK_PROBES
+static uint32_t* g_mp_stamps = nullptr;  // sglk_debug_set_moe_clock_stamps
+static int g_mp_prio47 = 0;  // (sglk_debug_set_moe_prio: 1..3 swaps which half waits, the block time stays - DESIGN 4.10)
+#else
+constexpr uint32_t* g_mp_stamps = nullptr;
+constexpr int g_mp_prio47 = 0;
+#endif
 #ifdef SGLK_PROBES
 static int g_mp_own_tails = 0;
 #else
@@ -608,10 +620,12 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
 
 }  // namespace sglk
 
-extern "C" void sglk_diag_set_moe_clock_stamps(uint32_t* device_buf) { sglk::g_mp_stamps = device_buf; }
-extern "C" SGLK_API void sglk_diag_set_moe_prio(int prio) { sglk::g_mp_prio47 = prio; }
-
 #ifdef SGLK_PROBES
+// Diagnostic build only. Clock stamps of the tile pipeline: 256 x 4 uint32, one record per workgroup of the last launch
+// {shader cycles, 100 MHz ticks, K blocks, m-steps}, followed by 256 x 8 x 2 uint32: per wave the shader cycles spent in
+// front of the K blocks' barriers waiting for its own LDS-DMA / LDS data, and at the barriers themselves (5120 uint32).
+extern "C" SGLK_API void sglk_debug_set_moe_clock_stamps(uint32_t* device_buf) { sglk::g_mp_stamps = device_buf; }
+extern "C" SGLK_API void sglk_debug_set_moe_prio(int prio) { sglk::g_mp_prio47 = prio; }
 extern "C" SGLK_API void sglk_debug_set_moe_persist_min_rows(int rows) { sglk::g_mp_min_avg_rows = rows; }
 extern "C" SGLK_API void sglk_debug_set_moe_persist_own_tails(int on) { sglk::g_mp_own_tails = on; }
 #endif

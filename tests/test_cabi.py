@@ -60,3 +60,6 @@ def test_release_library_has_no_debug_switches():
     # build/libsglk_probes.so); a serving process must not be one dlsym away from wrong answers
     data = open(LIB, "rb").read()
     assert b"sglk_debug_" not in data, "the release libsglk.so exports sglk_debug_* switches"
+    # (round 3 shipped clock-stamp hooks under another prefix: process-global pointers every later launch wrote through)
+    assert b"sglk_diag_" not in data, "the release libsglk.so exports sglk_diag_* hooks"
+    assert b"SGLK_FP8_BLOCKWISE_SCHEDULE" not in data, "the release libsglk.so reads a schedule switch from the environment"

@@ -21,6 +21,7 @@ extern "C" void sglk_debug_set_mla_probe(int);
 extern "C" void sglk_debug_set_mla_variant(int);
 extern "C" int sglk_debug_get_mla_stamps(unsigned long long*, int);
 extern "C" void sglk_debug_set_gemm_stamps(uint32_t*);
+extern "C" void sglk_debug_set_gemm_stagger(int);
 extern "C" void sglk_debug_set_w4a16_probe(int probe, int force_mt);
 
 #define HIP_CHECK(x)                                                                 \
@@ -406,6 +407,7 @@ int main(int argc, char** argv) {
     for (int ai = 5; ai < argc || ai == 5; ++ai) {
       const int var = ai < argc ? atoi(argv[ai]) : 1;
       sglk_debug_set_gemm_variant(var);
+      if (getenv("GEMM_STAGGER")) sglk_debug_set_gemm_stagger(atoi(getenv("GEMM_STAGGER")));
       std::vector<float> all;
       auto run = [&] {
         int rc = sglk_fp8_blockwise_scaled_mm(0, out, a, b, sa, sb, M, N, K, K, K, N, 1, M, 1, K / 128, SGLK_BF16);
@@ -433,12 +435,61 @@ int main(int argc, char** argv) {
         if (!mhz.empty()) {
           std::sort(mhz.begin(), mhz.end());
           std::sort(cpb.begin(), cpb.end());
-          printf("  in-kernel (256-row launch, %zu workgroups): clock median %.0f MHz (min %.0f max %.0f); shader cycles per K block median %.0f"
+          printf("  in-kernel (whole tiles, %zu workgroups): clock median %.0f MHz (min %.0f max %.0f); shader cycles per K block median %.0f"
                  " (MFMA time 2048)\n", mhz.size(), mhz[mhz.size() / 2], mhz.front(), mhz.back(), cpb[cpb.size() / 2]);
+        }
+        mhz.clear();  cpb.clear();
+        for (int w = 0; w < 512; ++w)
+          if (h[w * 4 + 1] && h[w * 4 + 3] == 2) {
+            mhz.push_back(100.0 * h[w * 4] / h[w * 4 + 1]);
+            cpb.push_back((double)h[w * 4] / h[w * 4 + 2]);
+          }
+        if (!mhz.empty()) {
+          std::sort(mhz.begin(), mhz.end());
+          std::sort(cpb.begin(), cpb.end());
+          printf("  in-kernel (half tiles, %zu workgroups): clock median %.0f MHz; shader cycles per K block median %.0f (MFMA time 1024)\n",
+                 mhz.size(), mhz[mhz.size() / 2], cpb[cpb.size() / 2]);
         }
         HIP_CHECK(hipFree(st));
       }
       if (ai >= argc) break;
+    }
+    return 0;
+  }
+  if (!strcmp(argv[1], "gemmab")) {  // kbench gemmab M N K variant:stagger ... - interleaved rounds of the listed forms on one device
+    const int64_t M = atoll(argv[2]), N = atoll(argv[3]), K = atoll(argv[4]);
+    void* a = dev_random_bytes(M * K, 1, true);
+    void* b = dev_random_bytes(N * K, 2, true);
+    float* sa = dev_random_floats(M * (K / 128), 3, 1e-4f, 1e-3f);
+    float* sb = dev_random_floats((K / 128) * ((N + 127) / 128), 4, 1e-4f, 1e-3f);
+    void* out;
+    HIP_CHECK(hipMalloc(&out, M * N * 2));
+    std::vector<std::pair<int, int>> forms;
+    for (int ai = 5; ai < argc; ++ai) {
+      int v = 4, st = 1;
+      sscanf(argv[ai], "%d:%d", &v, &st);
+      forms.push_back({v, st});
+    }
+    auto run = [&] {
+      int rc = sglk_fp8_blockwise_scaled_mm(0, out, a, b, sa, sb, M, N, K, K, K, N, 1, M, 1, K / 128, SGLK_BF16);
+      if (rc) { fprintf(stderr, "error: %s\n", sglk_last_error()); exit(1); }
+    };
+    std::vector<std::vector<float>> all(forms.size());
+    const int rounds = getenv("ROUNDS") ? atoi(getenv("ROUNDS")) : 8;
+    for (int r = 0; r < rounds; ++r)
+      for (size_t f = 0; f < forms.size(); ++f) {
+        sglk_debug_set_gemm_variant(forms[f].first);
+        sglk_debug_set_gemm_stagger(forms[f].second);
+        std::vector<float> ms;
+        time_ms(run, r == 0 ? 300 : 40, 40, &ms);
+        all[f].insert(all[f].end(), ms.begin(), ms.end());
+      }
+    for (size_t f = 0; f < forms.size(); ++f) {
+      std::sort(all[f].begin(), all[f].end());
+      const double med = all[f][all[f].size() / 2];
+      printf("gemmab M=%lld N=%lld K=%lld variant=%d stagger=%d: median %.4f ms  min %.4f  p90 %.4f -> %.1f TFLOP/s\n", (long long)M,
+             (long long)N, (long long)K, forms[f].first, forms[f].second, med, all[f][0], all[f][all[f].size() * 9 / 10],
+             2.0 * M * N * K / med / 1e9);
     }
     return 0;
   }

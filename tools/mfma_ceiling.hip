@@ -1,0 +1,43 @@
+// bench.py's measured MFMA ceiling (NOT part of the product library): a register-only stream of the MX fp8 MFMA the headline
+// GEMM uses (v_mfma_scale_f32_32x32x64_f8f6f4, unit scales), random e4m3 operands held in registers, no memory traffic in
+// the loop, 512-thread workgroups = two waves per SIMD as in the GEMM, one workgroup per CU. What this loop reaches on
+// the device bench.py runs on is what the matrix pipes deliver at the clock the part holds under them (MI355X_MICROARCH.md,
+// "DVFS give-back"): the denominator next to the nominal 5 PFLOP/s.
+//   build: sgl-kernel-xpu_amd/build.py -> sgl-kernel-xpu_amd/build/libsglk_ceiling.so (ctypes from bench.py)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(512) void mfma_ceiling_kernel(const int* __restrict__ src, float* __restrict__ dst, int iters) {
+  v8i_t a[4], b[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) {
+      a[i][j] = src[(threadIdx.x * 8 + j + i * 4096) & 16383];
+      b[i][j] = src[(threadIdx.x * 8 + j + i * 4096 + 777) & 16383];
+    }
+  v16f_t acc[4] = {};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[n], a[u + 2 * (it & 1)], acc[n], 0, 0, 0, 127, 0, 127);
+  }
+  float s = 0;
+  for (int n = 0; n < 4; ++n)
+    for (int r = 0; r < 16; ++r) s += acc[n][r];
+  dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// src: 16384 random int32 (e4m3 bytes without NaN codes), dst: blocks * 512 floats. FLOP per launch = flop_per_launch().
+extern "C" __attribute__((visibility("default"))) int sglk_bench_mfma_ceiling(void* stream, const void* src, void* dst,
+                                                                              int blocks, int iters) {
+  mfma_ceiling_kernel<<<blocks, 512, 0, (hipStream_t)stream>>>((const int*)src, (float*)dst, iters);
+  return (int)hipGetLastError();
+}
+// 8 waves x 8 MFMAs per iteration x 2 * 32 * 32 * 64 FLOP
+extern "C" __attribute__((visibility("default"))) double sglk_bench_mfma_ceiling_flop(int blocks, int iters) {
+  return (double)blocks * 8.0 * 8.0 * iters * 2.0 * 32 * 32 * 64;
+}

@@ -21,16 +21,18 @@ w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
 s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01
 s2 = torch.rand(E, Hd, I // gs, device=dev).to(torch.bfloat16) * 0.01
 import ctypes
-lib = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "python", "sgl_kernel", "libsglk.so"))
-lib.sglk_diag_set_moe_clock_stamps.argtypes = [ctypes.c_void_p]
+# The stamps exist in the DIAGNOSTIC build only (build.py --probes). Run this tool with that build in front of the release
+# library so that the Python ops resolve to it:  LD_PRELOAD=sgl-kernel-xpu_amd/build/libsglk_probes.so python tools/moe_gemm_split.py
+lib = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so"))
+lib.sglk_debug_set_moe_clock_stamps.argtypes = [ctypes.c_void_p]
 stamps = torch.zeros(256 * 4 + 256 * 8 * 2, dtype=torch.int32, device=dev)
 
 
 def clock_of(f):
-    lib.sglk_diag_set_moe_clock_stamps(stamps.data_ptr())
+    lib.sglk_debug_set_moe_clock_stamps(stamps.data_ptr())
     for _ in range(5): f()
     torch.cuda.synchronize()
-    lib.sglk_diag_set_moe_clock_stamps(None)
+    lib.sglk_debug_set_moe_clock_stamps(None)
     hst = stamps.cpu()
     st = hst[:1024].view(256, 4).double()
     ok = st[:, 1] > 0
@@ -42,7 +44,7 @@ def clock_of(f):
 
 
 if os.environ.get("MOE_PRIO"):
-    lib.sglk_diag_set_moe_prio(int(os.environ["MOE_PRIO"]))
+    lib.sglk_debug_set_moe_prio(int(os.environ["MOE_PRIO"]))
 for T in (int(a) for a in (sys.argv[1:] or ["2048"])):
     total = T * topk
     ti = torch.randn(T, E, device=dev).topk(topk, dim=-1).indices
