@@ -219,14 +219,38 @@ def side_metrics(sgl_kernel, dev):
     out = {}
 
     def timeit(fn, iters=30):
+        """Device time per call: `iters` calls captured into ONE HIP graph and one replay of it timed with events (the
+        decode-sized kernels here take 5 - 20 us, less than a Python op call costs on a busy host: an eager loop would time
+        the host). Every op of the library is capture-safe by contract; if a capture fails the eager loop is timed."""
         for _ in range(max(5, iters)):  # the chip's clocks ramp for tens of milliseconds
             fn()
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(iters):
+                        fn()
+            torch.cuda.current_stream().wait_stream(side)
+            graph.replay()
+            torch.cuda.synchronize()
+            st.record()
+            graph.replay()
+            en.record()
+            torch.cuda.synchronize()
+            out["_timing"] = "device time per call: N calls in one HIP graph, one replay timed"
+            del graph
+            return st.elapsed_time(en) / iters
+        except Exception:
+            torch.cuda.synchronize()
         st.record()
         for _ in range(iters):
             fn()
         en.record()
         torch.cuda.synchronize()
+        out["_timing"] = "eager loop (graph capture failed)"
         return st.elapsed_time(en) / iters
 
     x = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
@@ -610,11 +634,38 @@ def mla_roofline(sgl_kernel, dev, heads=128):
         b_.record()
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
-    avg = sum(ms) / len(ms)
+    avg_eager = sum(ms) / len(ms)
+    # The op is two launches (the 2-us kernel that zeroes the merge counters, then the decode kernel): timed eagerly the pair
+    # carries the host's launch gap. Device time per call = `iters` calls captured in ONE HIP graph, median of five replays
+    # (events on the launch stream); the eager per-call average is reported next to it.
+    avg, how = avg_eager, "eager: HIP events around every call"
+    try:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(iters):
+                    run()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize()
+        reps = []
+        for _ in range(5):
+            st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st.record()
+            graph.replay()
+            en.record()
+            torch.cuda.synchronize()
+            reps.append(st.elapsed_time(en) / iters)
+        avg, how = sorted(reps)[2], f"{iters} calls in one HIP graph, median of 5 replays, HIP events on the launch stream"
+        del graph
+    except Exception:
+        torch.cuda.synchronize()
     nbytes = qq.numel() * 2 + cache.numel() * 2 + table.numel() * 4 + seq_lens.numel() * 4 + bs * heads * 512 * 2
     return {
         "bound": "hbm",
-        "kernel": "mla_rows128x_kernel<bf16> (32x32x16 MFMA, row per lane; + split merge)" if heads > 64 else "mla_decode_kernel<bf16> (+ split merge)",
+        "kernel": "mla_rows128x_kernel<bf16> (32x32x16 MFMA, row per lane; the split merge inside the kernel, + a counter-zeroing launch)" if heads > 64 else "mla_decode_kernel<bf16> (+ mla_reduce_kernel)",
         "workload": f"flash_mla_decode bs={bs} seq={seq} heads={heads} kv_lora=512 rope=64 page={page} bf16",
         "achieved": round(nbytes / avg / 1e6, 1),
         "peak": PEAK_HBM_GBS,
@@ -623,7 +674,9 @@ def mla_roofline(sgl_kernel, dev, heads=128):
         "bytes": nbytes,
         "traffic": mla_pmc_traffic_bytes(),
         "kernel_ms_avg": round(avg, 4),
-        "kernel_ms_median": round(ms[len(ms) // 2], 4),
+        "timing": how,
+        "eager_ms_avg": round(avg_eager, 4),
+        "eager_ms_median": round(ms[len(ms) // 2], 4),
         "tflops": round(2.0 * bs * heads * seq * (576 + 512) / avg / 1e9, 1),
     }
 

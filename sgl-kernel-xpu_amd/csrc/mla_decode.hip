@@ -202,6 +202,7 @@ struct MlaParams {
   void* out;                 // [B, H, 512] T
   float* ws_o;               // [B, splits, H, 512] fp32 (splits > 1)
   float* ws_lse;             // [B, splits, H]
+  uint32_t* ws_cnt;          // [B, 2] {tickets taken, partial results published}: zeroed by the host before every launch
   int64_t qn_sb, qn_sh, qp_sb, qp_sh;
   int64_t page_stride_bytes;
   int64_t table_stride;
@@ -1175,6 +1176,99 @@ template <int kOrd>
 __host__ __device__ constexpr int pv_ss(int m) {
   return kOrd == 0 ? (m & 1) : kOrd == 1 ? ((m >> 2) & 1) : ((m >> 1) & 1);
 }
+__global__ void mla_zero_counters_kernel(uint32_t* __restrict__ cnt, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cnt[i] = 0u;
+}
+
+// ---- split KV merged inside the kernel (rows128x kernel). The workgroup of a batch element that finishes LAST merges the
+// splits itself: no second launch, and its own partial result never leaves the registers. Every workgroup takes a ticket
+// when its tile loop is done; all but the last publish O / l (fp32, write-through stores) and their log2-sum-exp, then
+// count themselves in; the last one waits until the others - which took their tickets before it, so they are running their
+// epilogues - are counted in, and adds the partial results IN SPLIT ORDER (its own at its place): the sum does not depend
+// on who came last. Hand-off as cdna_hip_programming.md guideline 16: sc1 payload stores, every storing wave drains,
+// barrier, one agent-scope add; consumer: one lane polls relaxed, one agent acquire, barrier, loads. The two counters of a
+// batch element are zeroed by a memset node in front of every launch.
+typedef __attribute__((address_space(1))) uint32_t mla_gu32;
+__device__ __forceinline__ bool mla_take_ticket(const MlaParams& p, int b, char* smem, int tid) {
+  mla_gu32* cnt = (mla_gu32*)(p.ws_cnt + 2 * (int64_t)b);
+  uint32_t* lds_word = reinterpret_cast<uint32_t*>(smem);
+  __builtin_amdgcn_s_barrier();  // (every wave has left the tile loop: the stages are free)
+  if (tid == 0) *lds_word = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return (int)(*lds_word) == p.splits - 1;
+}
+__device__ __forceinline__ void mla_count_in(const MlaParams& p, int b, int tid) {
+  mla_gu32* cnt = (mla_gu32*)(p.ws_cnt + 2 * (int64_t)b);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every storing wave, in front of the barrier)
+  __builtin_amdgcn_s_barrier();
+  if (tid == 0) __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mla_wait_others(const MlaParams& p, int b, int tid) {
+  mla_gu32* cnt = (mla_gu32*)(p.ws_cnt + 2 * (int64_t)b);
+  if (tid == 0) {
+    // (bounded: a spin that never ends would take the device with it; an exhausted one shows up as a wrong result)
+    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+      if ((int)__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.splits - 1) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+// The last workgroup's merge for the row of lane (l31, u): out = sum_s w_s O_s / sum_s w_s, w_s = 2^(lse_s - max lse), s in
+// split order. OWN: this workgroup's O^T sits unnormalised in a0..a255 (x inv_l), log2-sum-exp my_lse; otherwise it had no keys.
+template <typename T, typename M, bool OWN>
+__device__ __forceinline__ void mla_merge_splits(const MlaParams& p, int b, int split, int H, bool ok, int hrow, T* out,
+                                                 int u, float my_lse, float inv_l) {
+  const float* lse_b = p.ws_lse + (int64_t)b * p.splits * H + hrow;
+  const float* wo_b = p.ws_o + ((int64_t)b * p.splits * H + hrow) * kLatent + 4 * u;
+  float mx = my_lse;
+  for (int s2 = 0; s2 < p.splits; ++s2)
+    if (s2 != split) mx = fmaxf(mx, lse_b[(int64_t)s2 * H]);
+  float wsum = 0.f;
+  for (int s2 = 0; s2 < p.splits; ++s2) {
+    const float l2 = s2 == split ? my_lse : lse_b[(int64_t)s2 * H];
+    if (l2 != -INFINITY) wsum += exp2f(l2 - mx);
+  }
+  const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+  static_for<0, 8>([&](auto cc) {  // 8 chunks of 8 register groups (32 accumulators of this lane's row)
+    constexpr int c0 = decltype(cc)::value * 8;
+    v4f acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < p.splits; ++s2) {
+      const float l2 = s2 == split ? my_lse : lse_b[(int64_t)s2 * H];
+      const float w = l2 == -INFINITY ? 0.f : exp2f(l2 - mx);
+      if (w == 0.f) continue;
+      if (s2 == split) {
+        if constexpr (OWN) {
+          static_for<0, 8>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const v4f v = agpr_read4<(c0 + k) * 4>();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[k][e] += w * (v[e] * inv_l);
+          });
+        }
+      } else {
+        const float* src = wo_b + (int64_t)s2 * H * kLatent;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const v4f v = *reinterpret_cast<const v4f*>(src + 32 * ((c0 + k) >> 2) + 8 * ((c0 + k) & 3));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[k][e] += w * v[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int lo = M::pack(acc[k][0] * inv, acc[k][1] * inv), hi = M::pack(acc[k][2] * inv, acc[k][3] * inv);
+      if (ok) *reinterpret_cast<v2i*>(out + 32 * ((c0 + k) >> 2) + 8 * ((c0 + k) & 3)) = (v2i){lo, hi};
+    }
+  });
+}
+
 template <typename T, int kKA, int kVA, bool kStamp = false, int kProbe = 0, int kOrd = 0, bool kDmaQK = true>
 __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p, const T* __restrict__ q_nope,
                                                                     const T* __restrict__ q_pe,
@@ -1260,10 +1354,19 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
       if (p.splits == 1) {
         T* out = (T*)p.out + ((int64_t)(q_row0 + my_tok) * H + my_head) * kLatent;
         for (int d = u * 256; d < u * 256 + 256; ++d) out[d] = (T)0.f;
+      }
+    }
+    if (p.splits > 1) {  // (no keys here: a log2-sum-exp of -inf takes part in the merge, no O - see mla_take_ticket)
+      if (!mla_take_ticket(p, b, smem, tid)) {
+        if (ok && u == 0)
+          __hip_atomic_store(p.ws_lse + ((int64_t)b * p.splits + split) * H + my_head, -INFINITY, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        mla_count_in(p, b, tid);
       } else {
-        float* wo = p.ws_o + (((int64_t)b * p.splits + split) * H + my_head) * kLatent;
-        for (int d = u * 256; d < u * 256 + 256; ++d) wo[d] = 0.f;
-        if (u == 0) p.ws_lse[((int64_t)b * p.splits + split) * H + my_head] = -INFINITY;
+        mla_wait_others(p, b, tid);
+        const int hrow = ok ? my_head : 0;
+        T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + hrow) * kLatent + 4 * u;
+        mla_merge_splits<T, M, false>(p, b, split, H, ok, hrow, out, u, -INFINITY, 0.f);
       }
     }
     return;
@@ -1653,14 +1756,26 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
       if (ok) *reinterpret_cast<v2i*>(out + 32 * (i >> 2) + 8 * (i & 3)) = (v2i){lo, hi};
     });
   } else {
-    float* wo = p.ws_o + (((int64_t)b * p.splits + split) * H + (ok ? my_head : 0)) * kLatent + 4 * u;
-    static_for<0, 64>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const v4f v = agpr_read4<i * 4>();
-      if (ok) *reinterpret_cast<v4f*>(wo + 32 * (i >> 2) + 8 * (i & 3)) = (v4f){v[0] * inv_l, v[1] * inv_l, v[2] * inv_l, v[3] * inv_l};
-    });
-    if (ok && u == 0)
-      p.ws_lse[((int64_t)b * p.splits + split) * H + my_head] = l_tot > 0.f ? m_ref * sl2 + log2f(l_tot) : -INFINITY;
+    const float my_lse = l_tot > 0.f ? m_ref * sl2 + log2f(l_tot) : -INFINITY;
+    if (!mla_take_ticket(p, b, smem, tid)) {
+      float* wo = p.ws_o + (((int64_t)b * p.splits + split) * H + (ok ? my_head : 0)) * kLatent + 4 * u;
+      static_for<0, 64>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const v4f v = agpr_read4<i * 4>();
+        const v4f w = {v[0] * inv_l, v[1] * inv_l, v[2] * inv_l, v[3] * inv_l};
+        float* const dst = wo + 32 * (i >> 2) + 8 * (i & 3);
+        if (ok) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+      });
+      if (ok && u == 0)
+        __hip_atomic_store(p.ws_lse + ((int64_t)b * p.splits + split) * H + my_head, my_lse, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      mla_count_in(p, b, tid);
+    } else {
+      mla_wait_others(p, b, tid);
+      const int hrow = ok ? my_head : 0;
+      T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + hrow) * kLatent + 4 * u;
+      mla_merge_splits<T, M, true>(p, b, split, H, ok, hrow, out, u, my_lse, inv_l);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   write_stamps();
@@ -1830,7 +1945,8 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
     default: rc = launch_w<T, 1>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
   }
   if (rc) return rc;
-  if (p.splits > 1) {
+  const bool merged_in_kernel = ngroups > 4 && g_mla_waves_per_group == 0;  // (the rows128x kernel merges its splits itself)
+  if (p.splits > 1 && !merged_in_kernel) {
     mla_reduce_kernel<T><<<dim3(p.H, B), 128, 0, st>>>((T*)p.out, p.ws_o, p.ws_lse, p.H, p.splits);
     return check_launch("flash_mla_decode(reduce)");
   }
@@ -1838,6 +1954,8 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
 }
 
 }  // namespace
+// bytes of the merge counters in front of the workspace: 8 per batch element, padded to 256 (keeps what follows aligned)
+static inline int64_t mla_counter_bytes(int64_t batch) { return (batch * 8 + 255) / 256 * 256; }
 }  // namespace sglk
 
 #ifdef SGLK_PROBES
@@ -1866,7 +1984,9 @@ extern "C" int64_t sglk_mla_decode_workspace_size(int64_t max_seq_len, int64_t b
                                                   int64_t num_kv_splits) {
   if (num_kv_splits < 1) num_kv_splits = sglk_mla_decode_auto_splits(batch, max_seq_len);
   if (num_kv_splits == 1) return 0;
-  return batch * num_kv_splits * num_heads * (sglk::kLatent + 1) * 4;
+  // {ticket, published} counters of the in-kernel merge (a block of their own at the start: the host zeroes exactly it), then
+  // fp32 partial O and the log2-sum-exps
+  return sglk::mla_counter_bytes(batch) + batch * num_kv_splits * num_heads * (sglk::kLatent + 1) * 4;
 }
 
 extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void* q_nope, const void* q_pe,
@@ -1893,7 +2013,7 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   const int64_t max_tiles = (max_seq + 31) / 32;
   if (splits > max_tiles) splits = max_tiles;
   if (splits > 1) {
-    const int64_t need = batch * splits * num_heads * (kLatent + 1) * 4;
+    const int64_t need = mla_counter_bytes(batch) + batch * splits * num_heads * (kLatent + 1) * 4;
     SGLK_REQUIRE(workspace != nullptr && workspace_bytes >= need,
                  "flash_mla_decode: workspace too small: %lld bytes given, %lld needed for %lld splits",
                  (long long)workspace_bytes, (long long)need, (long long)splits);
@@ -1901,7 +2021,8 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   }
   MlaParams p;
   p.out = out;
-  p.ws_o = (float*)workspace;
+  p.ws_cnt = (uint32_t*)workspace;
+  p.ws_o = workspace ? (float*)((char*)workspace + mla_counter_bytes(batch)) : nullptr;
   p.ws_lse = p.ws_o ? p.ws_o + batch * splits * num_heads * kLatent : nullptr;
   p.qn_sb = q_nope_stride_b;
   p.qn_sh = q_nope_stride_h;
@@ -1917,6 +2038,14 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   p.probe = g_mla_probe;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
+  if (splits > 1) {
+    // the merge counters are zeroed in front of every launch - by a kernel, not hipMemsetAsync: replayed from a captured
+    // graph (tests/test_graph_capture_gpu.py) the memset node left the counters of the capture-time warm-up in place, no
+    // workgroup drew the last ticket and the output was never written
+    const int nwords = (int)(mla_counter_bytes(batch) / 4);
+    mla_zero_counters_kernel<<<(nwords + 255) / 256, 256, 0, st>>>((uint32_t*)workspace, nwords);
+    if (int rc = check_launch("flash_mla_decode(counters)")) return rc;
+  }
   if (dtype == SGLK_BF16) return launch<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
   return launch<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
 }

@@ -53,6 +53,7 @@ struct MpParams {
   const void* w;        // 16-bit: [E][N][ldb] elements; int4: [E][N][K/2] bytes
   const void* scales;   // int4: [E][N][K/group] in the activation type; mxfp4: [E][N][K/32] E8M0 bytes
   const void* zeros;    // int4 with zero points (FMT 3): [E][N][K/group] in the activation type, codes unsigned
+  const float* bias;    // [E][N] fp32 or nullptr (BIAS instantiations)
   int gshift;           // int4: log2(group)
   uint32_t* stamps;     // diagnostic build (sglk_debug_set_moe_clock_stamps): per workgroup {shader cycles, 100 MHz ticks, K blocks, MS}
   int prio47;           // s_setprio value of waves 4..7 (0..3)
@@ -70,7 +71,8 @@ struct MpTile {
   const char* ps;  // the expert's scales (+ the tile's first weight row)
   const char* pz;  // the expert's zero points (FMT 3)
   char* po;        // first output element of the tile
-  uint32_t nrec_a, nrec_b, nrec_o, nrec_s;  // bytes in range (0: nothing); nrec_s: scales / zero points from ps / pz
+  const char* pbs; // the expert's bias (+ the tile's first weight row), BIAS only
+  uint32_t nrec_a, nrec_b, nrec_o, nrec_s, nrec_bs;  // bytes in range (0: nothing); nrec_s: scales / zero points from ps / pz
   int ncols;       // valid output columns of the tile
 };
 
@@ -79,7 +81,13 @@ struct MpTile {
 // 256-row block: with ~512 +- 20 rows per expert (Mixtral, 2048 tokens) half of the experts have a remainder of ~20 rows, which
 // as 256-row blocks cost a quarter more tiles.
 // FMT: 0 16-bit weights, 1 int4 (two's-complement codes, no zero points), 2 mxfp4 (E8M0 scale per 32), 3 int4 with zero points
-template <typename T, int FMT, int MS>
+// BIAS: out += bias[e][n] (fp32, in front of the activation). The bias enters through the matrix pipe: the first MFMA of a
+// tile's accumulator chain multiplies a weight-side operand whose k = 0, 1, 2 are the three 16-bit pieces of the fp32 bias of
+// the lane's weight row (hi + mid + lo = the fp32 value: 3 x 8 significant bits for bf16, 3 x 11 for fp16) with an
+// activation-side operand of three ones: the fp32 accumulator starts at exactly the bias, no registers are held across the
+// tile and nothing waits in the store block (the reference's grouped GEMM adds the bias in its epilogue,
+// src/sycl/GroupGemmW4A16Xe20.cpp:92-283; python/sgl_kernel/moe.py:574-587).
+template <typename T, int FMT, int MS, bool BIAS = false>
 __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][a tile, b tile]
   constexpr bool W4 = FMT != 0;
@@ -177,6 +185,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + c0) * kgroups * kSB : nullptr;
     d.pz = FMT == 3 ? (const char*)p.zeros + ((int64_t)e * N + c0) * kgroups * 2 : nullptr;
     d.po = (char*)p.out + ((int64_t)m0 * Nout + c0) * 2;
+    d.pbs = BIAS ? (const char*)(p.bias + (int64_t)e * N + c0) : nullptr;
+    d.nrec_bs = (live && BIAS) ? (uint32_t)((N - c0) * 4) : 0u;
     d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * a_row + (int64_t)K * 2) : 0u;
     // (b: the resource spans the expert's rows from the tile's first one to row N - 1: weight rows past N read zeros)
     d.nrec_b = live ? (uint32_t)((int64_t)(N - c0) * b_row) : 0u;
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     d.pa = c ? x.pa : y.pa;  d.pb = c ? x.pb : y.pb;  d.ps = c ? x.ps : y.ps;  d.pz = c ? x.pz : y.pz;  d.po = c ? x.po : y.po;
     d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_o = c ? x.nrec_o : y.nrec_o;
     d.nrec_s = c ? x.nrec_s : y.nrec_s;
+    d.pbs = c ? x.pbs : y.pbs;  d.nrec_bs = c ? x.nrec_bs : y.nrec_bs;
     d.ncols = c ? x.ncols : y.ncols;
     return d;
   };
@@ -376,6 +387,42 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   v4i nq[2][4];  // [n-fragment][k-step]
   v4i mq[4];     // [k-step] of the running m-fragment (each re-read right behind its second MFMA)
   int gblk = 0;
+  // BIAS: the weight-side operands of the two n-fragments (lane (i, 0): {hi, mid, lo, 0 ..} of weight row brow(i); lanes (i, 1):
+  // zeros) and the activation-side operand of ones, rebuilt at the top of every tile's first K block
+  // (only the two non-zero dwords of each operand live across the store block; the rest is rebuilt in front of the MFMA)
+  int bq[2][2] = {{0, 0}, {0, 0}};
+  const int lh_mask = lh == 0 ? -1 : 0;
+  const uint32_t bias_voff0 = (uint32_t)(wrow_of(wn * 64 + brow) * 4), bias_voff1 = (uint32_t)(wrow_of(wn * 64 + 32 + brow) * 4);
+  auto load_bias = [&](const MpTile& d) {
+    if constexpr (BIAS) {
+      const __amdgpu_buffer_rsrc_t rb = mp_rsrc(d.pbs, d.nrec_bs);
+      const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)bias_voff0, 0, 0));
+      const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)bias_voff1, 0, 0));
+      auto split = [&](float b) -> v4i {
+        const T hi = (T)b;
+        const float r1 = b - (float)hi;
+        const T mid = (T)r1;
+        const float r2 = r1 - (float)mid;
+        const T lo = (T)r2;
+        return (v4i){(int)((uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, mid) << 16)) & lh_mask,
+                     (int)(uint32_t)__builtin_bit_cast(uint16_t, lo) & lh_mask, 0, 0};
+      };
+      const v4i s0 = split(b0), s1 = split(b1);
+      bq[0][0] = s0[0];  bq[0][1] = s0[1];  bq[1][0] = s1[0];  bq[1][1] = s1[1];
+      asm volatile("" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]));
+    }
+  };
+#define MP_MFMA_BIAS(mf, nf)                                                                                   \
+  {                                                                                                            \
+    const v4i bop_ = {bq[nf][0], bq[nf][1], 0, 0};                                                             \
+    const v4i one_ = {(std::is_same<T, bf16>::value ? 0x3F803F80 : 0x3C003C00) & lh_mask,                      \
+                      (std::is_same<T, bf16>::value ? 0x00003F80 : 0x00003C00) & lh_mask, 0, 0};               \
+    if constexpr (std::is_same<T, bf16>::value) {                                                              \
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(bop_), "v"(one_)); \
+    } else {                                                                                                   \
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(bop_), "v"(one_));  \
+    }                                                                                                          \
+  }
 #ifdef SGLK_PROBES
   constexpr bool kBarStamps = FMT <= 1;  // (the per-wave barrier stamps: diagnostic build, 16-bit and plain int4 weights)
 #else
@@ -393,6 +440,10 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       store_frag(prv, acc[mf], (mf));                                                                          \
       _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f; \
       asm volatile("" : "+v"(acc[mf][0]), "+v"(acc[mf][1]));                                                   \
+      if constexpr (BIAS) { /* the accumulator chain of the new tile starts at its bias */                     \
+        MP_MFMA_BIAS(mf, 0) /* (s_nop in front: VALU writes of the operands / SrcC -> MFMA) */               \
+        MP_MFMA_BIAS(mf, 1)                                                                                    \
+      }                                                                                                        \
     }                                                                                                          \
     _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                         \
       if (!(LAST)) {                                                                                           \
@@ -442,6 +493,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       asm volatile("" : "+v"(fo));                                                                             \
       a0 = sbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)fo;                                            \
     }                                                                                                          \
+    if constexpr (BIAS && (STORE)) load_bias(cur_t);                                                          \
     load_raw(d2, kb2, raw_n, sraw_n);                                                                          \
     if constexpr (MS == 4) { MP_STEP(0, STORE, false, false) MP_STEP(1, STORE, false, false) MP_STEP(2, STORE, false, true) } \
     else { MP_STEP(0, STORE, false, true) }                                                                    \
@@ -534,6 +586,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     w[0] = st_own;  w[1] = st_bar;
   }
 #undef MP_MFMA
+#undef MP_MFMA_BIAS
 #undef MP_RD16
 #undef MP_WR16
 }
@@ -559,22 +612,22 @@ constexpr int kMinAvgRows = 192;  // average rows per expert from which the tile
 #endif
 
 
-template <typename T, int W4>
+template <typename T, int W4, bool BIAS = false>
 static int launch_persist(hipStream_t st, const MpParams& p) {
   static unsigned long long attr_done4 = 0, attr_done2 = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 4>), 2 * kStage, &attr_done4, "moe_persist"))
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 4, BIAS>), 2 * kStage, &attr_done4, "moe_persist"))
     return rc;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 2>), 2 * kStage, &attr_done2, "moe_persist"))
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 2, BIAS>), 2 * kStage, &attr_done2, "moe_persist"))
     return rc;
   if (p.blocks128) {  // 96 .. 191 rows per expert on average: 128-row blocks
-    moe_persist_kernel<T, W4, 2><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
+    moe_persist_kernel<T, W4, 2, BIAS><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
     return 0;
   }
-  moe_persist_kernel<T, W4, 4><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
+  moe_persist_kernel<T, W4, 4, BIAS><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
   // Remainders of at most 128 rows: the callers run their streaming kernels over them (moe_tiles.h, tail mode) - a few
   // dozen rows per expert are a weight stream, 70 us for the Mixtral down projection against 275 us as 128-row tiles here
   // (K = 14336: 96 long tiles on 256 CUs). MOE_PERSIST_TAILS=1 in the diagnostic build runs them here instead.
-  if (g_mp_own_tails) moe_persist_kernel<T, W4, 2><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
+  if (g_mp_own_tails) moe_persist_kernel<T, W4, 2, BIAS><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
   return 0;
 }
 
@@ -589,7 +642,7 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
                     int fuse, float act_limit) {
   const bool gated = fuse == 1 || fuse == 2 || fuse == 4;
   const int Nout = gated ? N / 2 : N;
-  if (bias != nullptr || total_m < (int64_t)kMinAvgRows128 * E || num_cus() % 8 != 0) return 0;
+  if (total_m < (int64_t)kMinAvgRows128 * E || num_cus() % 8 != 0 || (uintptr_t)bias % 4 != 0) return 0;
   const bool blocks128 = total_m < (int64_t)kMinAvgRows * E;
   if (w4 == 2 && dtype != SGLK_BF16) return 0;  // (the fp4 conversion instruction is used in its bf16 form)
   if (K % 64 != 0 || K < 128 || N % 8 != 0 || (gated && (N % 64 != 0)) || (uintptr_t)out % 16 != 0 ||
@@ -606,11 +659,18 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
   p.blocks128 = blocks128 ? 1 : 0;
   p.stamps = g_mp_stamps;
   p.prio47 = g_mp_prio47;
-  p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.gshift = group_shift;  p.rows = rows;
+  p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.bias = bias;  p.gshift = group_shift;  p.rows = rows;
   p.E = E;  p.N = N;  p.K = K;  p.fuse = fuse;  p.act_limit = act_limit;  p.ldb = ldb;  p.stride_e = stride_e;
   int rc;
   const int fmt = w4 == 1 && zeros != nullptr ? 3 : w4;
-  if (dtype == SGLK_BF16)
+  if (bias != nullptr) {
+    if (dtype == SGLK_BF16)
+      rc = fmt == 3 ? launch_persist<bf16, 3, true>(st, p) : fmt == 2 ? launch_persist<bf16, 2, true>(st, p)
+           : fmt == 1 ? launch_persist<bf16, 1, true>(st, p) : launch_persist<bf16, 0, true>(st, p);
+    else
+      rc = fmt == 3 ? launch_persist<f16, 3, true>(st, p) : fmt == 1 ? launch_persist<f16, 1, true>(st, p)
+                                                           : launch_persist<f16, 0, true>(st, p);
+  } else if (dtype == SGLK_BF16)
     rc = fmt == 3 ? launch_persist<bf16, 3>(st, p) : fmt == 2 ? launch_persist<bf16, 2>(st, p)
          : fmt == 1 ? launch_persist<bf16, 1>(st, p) : launch_persist<bf16, 0>(st, p);
   else

@@ -19,7 +19,7 @@
 // one m: 8-byte fp16 stores. The integer dot products are exact in int32; per group the weights are rebuilt as
 // int8 in registers (packed multiply by the small group scale, carry-free packed add of zs8) before the MFMA, so
 // both variants accumulate over all of K without rescaling.
-// No LDS, no barriers: a wave owns a 32-column block of W for all of K, 16*MF rows of A; loads run 2-4 k steps ahead.
+// (That lane map is what the tile kernels below use; the decode kernel reads the same bytes another way, see there.)
 #include "common.h"
 
 namespace sglk {
@@ -38,125 +38,161 @@ __device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b) {
   return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
 }
 
-// SPLIT = 1: workgroup = 4 waves on 4 neighbouring 32-column blocks, each over all of K.
-// SPLIT = 16 / 8 (few rows, M <= 16 / 64: the weight stream of a decode step): workgroup = SPLIT waves on ONE 32-column
-// block, wave w takes the 64-deep k steps w, w + SPLIT, ..; the int32 partial sums are added through LDS (exact) and wave
-// 0 finishes (8 waves above 16 rows: 16 would leave 128 registers per lane and spill).
-// With one wave per 32 columns over all of K a 4096 x 4096 layer is 128 waves of 64 dependent steps each: 19 us.
-template <bool GROUP, int MF, int SPLIT>
-__global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void qserve_w4a8_kernel(
+// Few rows (M <= 64: the weight stream of a decode step). Round 3's kernel gave a lane the four dwords e = 0..3 of "its" row
+// as the packing suggests: 4-byte loads 16 bytes apart (every instruction touched all the lines of its 1 KiB and used a
+// quarter of each), single-byte loads for the group scales, 16 waves of four short steps per workgroup - 24.5 us for the
+// 29 MB of a 14336 x 4096 layer (0.15 of HBM), the waves waiting on a counter 0.5 - 0.6 of their cycles. Here a lane takes
+// 32 CONTIGUOUS bytes of a block - chunks e = 2 p, 2 p + 1 of byte row c, i.e. k = {8 p .. 8 p + 7} and {16 + 8 p ..} of the four
+// rows c, 8 + c (low nibbles, dwords b = 0 / 1) and 16 + c, 24 + c (high nibbles) - as two 16-byte loads, and supplies one
+// of those four rows to each of FOUR MFMAs:
+//   lane = (c = lane % 8, q0 = lane / 8 % 2, p = lane / 16 % 2, q1 = lane / 32): MFMA row j = 8 q0 + c, k group kg = 2 q1 + p;
+//   q0 = which of the wave's two neighbouring 32-column blocks, q1 = which of the step's two 32-deep k blocks;
+//   MFMA t (0..3) multiplies weight rows 8 t + c of both blocks: 16 rows x 64 k, the wave 64 columns x 64 k per step;
+//   its A operand = dwords {X[b], Y[b], X[2 + b], Y[2 + b]} (X, Y = the two chunks, b = t % 2), nibble t / 2, which is k order
+//   {8 p .. 8 p + 7, 16 + 8 p .. 16 + 8 p + 7} of k block 2 ks + q1: the B operand is two 8-byte loads of the activation row.
+// The four group scales / zero terms a lane needs (columns c, 8 + c, 16 + c, 24 + c) are the four bytes of ONE dword of the
+// permuted scale row (position 4 c + q holds column 8 q + c). A workgroup = KS waves on one 64-column pair, wave w takes the
+// 64-deep steps w, w + KS, .. through a KD-deep static register ring (16 KiB of weights in flight per wave at KD = 8); the
+// int32 partial sums meet in LDS and are added in wave order (exact). KS is chosen by the host for ~1500 waves per launch,
+// KD so that the ring is no deeper than a wave's steps (slots past them would re-load the last step).
+// (Measured and dropped: a wave-step of the four consecutive blocks of ONE 32-column group - 2 KiB contiguous, 128 deep, twice
+// the workgroups - needs two MFMAs per row set, each with half of the row slots zeroed, and four activation loads per step:
+// 11.3 against 7.8 us at N = 14336, K = 4096, one row.)
+template <bool GROUP, int MF, int KS, int KD>
+__global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
     f16* __restrict__ out, const int8_t* __restrict__ a, const uint8_t* __restrict__ w,
     const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales_i8, const f16* __restrict__ wscales,
     const f16* __restrict__ ascales, const f16* __restrict__ w_szs, const f16* __restrict__ a_ssums, int M, int N,
     int K, int64_t lda, int64_t ldc) {
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n32 = SPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
-  if (SPLIT == 1 && n32 * 32 >= N) return;
+  const int pair = blockIdx.x;
   const int m0 = blockIdx.y * (16 * MF);
   const int j = lane & 15, kg = lane >> 4;
-  const int c = j & 7, b = j >> 3;
+  const int c = j & 7, q0 = j >> 3, p = kg & 1, q1 = kg >> 1;
+  const int n32 = pair * 2 + q0;
+  const int n32c = n32 * 32 < N ? n32 : pair * 2;  // (N = 32 mod 64: the pair's second block re-reads the first, not stored)
 
-  // weights: block (n32, k32) at (n32 * K/32 + k32) * 512; this lane's dword e of k step ks (64 deep): k32 = 2 ks + kg/2
-  const uint8_t* wl = w + ((int64_t)n32 * (K >> 5) + (kg >> 1)) * 512 + c * 64 + (kg & 1) * 8 + b * 4;
-  // activations: row m0 + 16 mf + j (clamped), 16 bytes at k = 64 ks + 16 kg
+  const uint8_t* wl = w + ((int64_t)n32c * (K >> 5) + q1) * 512 + c * 64 + p * 32;
   const int8_t* al[MF];
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     int m = m0 + mf * 16 + j;
     m = m < M ? m : M - 1;
-    al[mf] = a + (int64_t)m * lda + kg * 16;
+    al[mf] = a + (int64_t)m * lda + q1 * 32 + p * 8;
   }
-  // group scales / zero terms of this lane's two rows (low nibble: column 8 b + c -> position 4 c + b; high: 4 c + 2 + b)
-  const int8_t* s8 = GROUP ? scales_i8 + n32 * 32 + c * 4 + b : nullptr;
-  const int8_t* z8 = GROUP ? zeros + n32 * 32 + c * 4 + b : nullptr;
+  const int8_t* s8 = GROUP ? scales_i8 + n32c * 32 + c * 4 : nullptr;
+  const int8_t* z8 = GROUP ? zeros + n32c * 32 + c * 4 : nullptr;
 
-  v4i acc[MF][2];
+  v4i acc[MF][4];
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf) acc[mf][0] = acc[mf][1] = (v4i){0, 0, 0, 0};
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mf][t] = (v4i){0, 0, 0, 0};
 
-  // Weights, activations and group scales run kD 64-deep steps ahead of the MFMAs in a register ring with static slots
-  // (loop unrolled kD times): a load consumed in the iteration that issues it exposes the whole memory latency per step.
-  // Steps past K re-read the last one (their results are not accumulated).
   const int nks_all = K >> 6;
-  // this wave's steps: ks = kfirst + kstride * i, i < nks
-  const int kfirst = SPLIT == 1 ? 0 : wave, kstride = SPLIT;
-  const int nks = SPLIT == 1 ? nks_all : (nks_all > wave ? (nks_all - wave + SPLIT - 1) / SPLIT : 0);
-  constexpr int kD = MF <= 2 ? 4 : 2;
-  uint32_t wq_[kD][4], sq_[kD][4];
-  v4i aq_[kD][MF];
-  auto load_step = [&](int i, uint32_t (&wd)[4], uint32_t (&sz)[4], v4i (&af)[MF]) {
+  const int nks = nks_all > wave ? (nks_all - wave + KS - 1) / KS : 0;  // this wave's steps ks = wave + KS i
+  v4i wq_[KD][2];
+  v2i aq_[KD][MF][2];
+  uint32_t sq_[KD][2];
+  auto load_step = [&](int i, v4i (&wd)[2], v2i (&af)[MF][2], uint32_t (&sz)[2]) {
     i = i < nks ? i : nks - 1;
-    int ks = kfirst + kstride * (i > 0 ? i : 0);
+    int ks = wave + KS * (i > 0 ? i : 0);
     ks = ks < nks_all ? ks : nks_all - 1;  // (a wave without steps loads the last one; nothing is accumulated)
+    wd[0] = *reinterpret_cast<const v4i*>(wl + (int64_t)ks * 1024);
+    wd[1] = *reinterpret_cast<const v4i*>(wl + (int64_t)ks * 1024 + 16);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wd[e] = *reinterpret_cast<const uint32_t*>(wl + (int64_t)ks * 1024 + e * 16);
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) af[mf] = *reinterpret_cast<const v4i*>(al[mf] + ks * 64);
+    for (int mf = 0; mf < MF; ++mf) {
+      af[mf][0] = *reinterpret_cast<const v2i*>(al[mf] + ks * 64);
+      af[mf][1] = *reinterpret_cast<const v2i*>(al[mf] + ks * 64 + 16);
+    }
     if constexpr (GROUP) {
       const int64_t g = ks >> 1;
-      sz[0] = (uint8_t)s8[g * N]; sz[1] = (uint8_t)s8[g * N + 2];
-      sz[2] = (uint8_t)z8[g * N]; sz[3] = (uint8_t)z8[g * N + 2];
+      sz[0] = *reinterpret_cast<const uint32_t*>(s8 + g * N);
+      sz[1] = *reinterpret_cast<const uint32_t*>(z8 + g * N);
     }
   };
 #pragma unroll
-  for (int d = 0; d < kD; ++d) load_step(d, wq_[d], sq_[d], aq_[d]);
-  for (int ks0 = 0; ks0 < nks; ks0 += kD) {
+  for (int d = 0; d < KD; ++d) load_step(d, wq_[d], aq_[d], sq_[d]);
+  for (int ks0 = 0; ks0 < nks; ks0 += KD) {
 #pragma unroll
-    for (int u = 0; u < kD; ++u) {
-      // (steps past this wave's range multiply zero weights: no branch; the slot is refilled AFTER its last use, else the
-      // new step lives in other registers and the loop end moves the ring back with copies that wait for every load)
+    for (int u = 0; u < KD; ++u) {
+      // (steps past this wave's range multiply zero weights: no branch; a slot is refilled AFTER its last use, else the new
+      // step lives in other registers and the loop end moves the ring back with copies that wait for every load)
       const uint32_t keep = ks0 + u < nks ? 0xffffffffu : 0u;
-      v4i wlo, whi;
+      uint32_t lo[2][4], hi[2][4];  // [chunk][dword]: low / high nibbles as bytes
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t wd = wq_[u][e] & keep;
-        uint32_t lo = wd & 0x0f0f0f0fu, hi = (wd >> 4) & 0x0f0f0f0fu;
-        if constexpr (GROUP) {
-          // code * scale <= 15 * 17 fits a byte: one 32-bit multiply scales four codes; the add wraps per byte
-          lo = add_bytes(lo * sq_[u][0], (sq_[u][2] * 0x01010101u) & keep);
-          hi = add_bytes(hi * sq_[u][1], (sq_[u][3] * 0x01010101u) & keep);
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t wd = (uint32_t)wq_[u][x][e] & keep;
+          lo[x][e] = wd & 0x0f0f0f0fu;
+          hi[x][e] = (wd >> 4) & 0x0f0f0f0fu;
         }
-        wlo[e] = (int)lo;
-        whi[e] = (int)hi;
+      v4i wop[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int b = t & 1;
+        uint32_t d4[4] = {t < 2 ? lo[0][b] : hi[0][b], t < 2 ? lo[1][b] : hi[1][b], t < 2 ? lo[0][2 + b] : hi[0][2 + b],
+                          t < 2 ? lo[1][2 + b] : hi[1][2 + b]};
+        if constexpr (GROUP) {
+          // code * s8 + (zs8 + 128) is in 1..255 for every byte (|code * s8 + zs8| <= 127): one packed 16-bit multiply-add per
+          // dword, no carries between bytes; the XOR turns u8 + 128 back into int8
+          const uint32_t sv = (sq_[u][0] >> (8 * t)) & 0xffu;
+          const uint32_t zv = ((sq_[u][1] >> (8 * t)) & 0xffu) ^ 0x80u;
+          const uint32_t smul = sv | (sv << 16);
+          const uint32_t z2 = zv | (zv << 8);
+          const uint32_t zadd = (z2 | (z2 << 16)) & keep;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            d4[e] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, d4[e]) * __builtin_bit_cast(u16x2, smul) +
+                                                         __builtin_bit_cast(u16x2, zadd))) ^ (0x80808080u & keep);
+        }
+        wop[t] = (v4i){(int)d4[0], (int)d4[1], (int)d4[2], (int)d4[3]};
       }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        acc[mf][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wlo, aq_[u][mf], acc[mf][0], 0, 0, 0);
-        acc[mf][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(whi, aq_[u][mf], acc[mf][1], 0, 0, 0);
+        const v4i bop = {aq_[u][mf][0][0], aq_[u][mf][0][1], aq_[u][mf][1][0], aq_[u][mf][1][1]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mf][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop[t], bop, acc[mf][t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      load_step(ks0 + u + kD, wq_[u], sq_[u], aq_[u]);
+      load_step(ks0 + u + KD, wq_[u], aq_[u], sq_[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 
-  if constexpr (SPLIT > 1) {
-    // (dword r of a lane at stride 64: every LDS access is 64 consecutive dwords - the 16-byte form had a bank-conflict ratio of
-    // 0.75 in the r02 profile)
-    extern __shared__ int red[];  // [SPLIT - 1][MF][2][4][64 lanes]
+  if constexpr (KS > 1) {
+    // (dword r of a lane at stride 64: every LDS access is 64 consecutive dwords)
+    extern __shared__ int red[];  // [KS - 1][MF][4][4][64 lanes]
     if (wave > 0) {
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[(((((wave - 1) * MF + mf) * 2 + h) * 4 + r) << 6) + lane] = acc[mf][h][r];
+          for (int r = 0; r < 4; ++r) red[(((((wave - 1) * MF + mf) * 4 + t) * 4 + r) << 6) + lane] = acc[mf][t][r];
     }
     __syncthreads();
     if (wave > 0) return;
-    for (int w = 0; w < SPLIT - 1; ++w) {
+#pragma nounroll
+    for (int w2 = 0; w2 < KS - 1; ++w2) {
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int t = 0; t < 4; ++t) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mf][h][r] += red[((((w * MF + mf) * 2 + h) * 4 + r) << 6) + lane];
+          for (int r = 0; r < 4; ++r) acc[mf][t][r] += red[((((w2 * MF + mf) * 4 + t) * 4 + r) << 6) + lane];
         }
     }
   }
 
-  // ---- epilogue: lane (column m = j of the m fragment, rows n = 4 kg + r of the n fragment)
+  // ---- epilogue: lane (column m = j of the m fragment; MFMA rows 4 kg + r = block kg / 2, byte row 4 (kg % 2) + r):
+  // weight row t of that block's 8 t + c, i.e. columns n = 32 (2 pair + kg / 2) + 8 t + 4 (kg % 2) + r, r = 0..3 consecutive
+  const int nblk = pair * 2 + (kg >> 1);
+  if (nblk * 32 >= N) return;
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int m = m0 + mf * 16 + j;
@@ -164,12 +200,12 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void qserve_w4a8_ker
     const float sa = (float)ascales[m];
     const float asum = GROUP ? 0.f : (float)a_ssums[m];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int n = n32 * 32 + h * 16 + kg * 4;
+    for (int t = 0; t < 4; ++t) {
+      const int n = nblk * 32 + t * 8 + (kg & 1) * 4;
       Vec<f16, 4> o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = (float)acc[mf][h][r] * sa * (float)wscales[n + r];
+        float v = (float)acc[mf][t][r] * sa * (float)wscales[n + r];
         if constexpr (!GROUP) v -= asum * (float)w_szs[n + r];
         o[r] = (f16)v;
       }
@@ -356,34 +392,47 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
                   const void* wscales, const void* ascales, const void* w_szs, const void* a_ssums, int64_t M, int64_t N,
                   int64_t K, int64_t lda, int64_t ldc) {
   const unsigned gx = (unsigned)cdiv(N, 128);
-#define SGLK_GO(MF)                                                                                              \
-  qserve_w4a8_kernel<GROUP, MF, 1><<<dim3(gx, (unsigned)cdiv(M, 16 * MF)), 256, 0, st>>>(                        \
-      (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,            \
-      (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc)
-#define SGLK_GO_SPLIT(MF, SPLIT)                                                                                 \
+  // few rows: the weight stream. K is split over KS waves of a workgroup until the launch has ~1500 waves (a wave keeps
+  // at least four 64-deep steps); 16 waves (128 registers per lane) only with one m-tile and a 4-deep ring
+  const int64_t pairs = cdiv(N, 64);
+  // m-tiles per workgroup: 1 / 2 / 4 by the row count, fewer (the weights are then streamed once per group of m-tiles, the
+  // repeats from L2) when the launch would have under 128 workgroups - N = K = 4096, 64 rows: 24.9 us with 4 m-tiles on 64 workgroups
+  int mf = M <= 16 ? 1 : M <= 32 ? 2 : 4;
+  while (mf > 1 && pairs * cdiv(M, 16 * mf) < 128) mf /= 2;
+  int ks = 1;
+  while (ks < (M <= 16 ? 16 : 8) && pairs * cdiv(M, 16 * mf) * ks < 1536 && (K >> 6) >= 8 * ks) ks *= 2;
+  const bool deep = (K >> 6) / ks >= 8 && ks <= 8;  // (ring no deeper than a wave's steps)
+#define SGLK_GO_STREAM(MF, KS, KD)                                                                               \
   {                                                                                                              \
-    constexpr int lds = (SPLIT - 1) * MF * 2 * 64 * 16;                                                          \
+    constexpr int lds = (KS - 1) * MF * 4 * 64 * 16;                                                             \
     static unsigned long long attr_done = 0;                                                                     \
     if (lds > 64 * 1024)                                                                                         \
-      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&qserve_w4a8_kernel<GROUP, MF, SPLIT>), lds, &attr_done, \
-                                   "qserve_w4a8"))                                                               \
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&qserve_w4a8_stream_kernel<GROUP, MF, KS, KD>), lds,   \
+                                   &attr_done, "qserve_w4a8"))                                                   \
         return rc;                                                                                               \
-    qserve_w4a8_kernel<GROUP, MF, SPLIT><<<dim3((unsigned)(N / 32), (unsigned)cdiv(M, 16 * MF)), 64 * SPLIT, lds, st>>>( \
+    qserve_w4a8_stream_kernel<GROUP, MF, KS, KD><<<dim3((unsigned)pairs, (unsigned)cdiv(M, 16 * MF)), 64 * KS, lds, st>>>( \
         (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,          \
         (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc); \
   }
-  if (M <= 16) SGLK_GO_SPLIT(1, 16)
-  else if (M <= 32) SGLK_GO_SPLIT(2, 8)
-  else if (M <= 64) SGLK_GO_SPLIT(4, 8)
-  else if (M > kPersistRows && qserve_w4a8_persist(st, GROUP, out, a, w, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, M, N, K,
+#define SGLK_GO_STREAM_KS(MF, KD)                                                                                \
+  {                                                                                                              \
+    if (ks == 1) SGLK_GO_STREAM(MF, 1, KD) else if (ks == 2) SGLK_GO_STREAM(MF, 2, KD) else if (ks == 4) SGLK_GO_STREAM(MF, 4, KD) \
+    else SGLK_GO_STREAM(MF, 8, KD)                                                                               \
+  }
+  if (M <= 64) {
+    if (mf == 1) {
+      if (ks == 16) SGLK_GO_STREAM(1, 16, 4) else if (deep) SGLK_GO_STREAM_KS(1, 8) else SGLK_GO_STREAM_KS(1, 4)
+    } else if (mf == 2) SGLK_GO_STREAM_KS(2, 4)
+    else SGLK_GO_STREAM_KS(4, 2)
+  } else if (M > kPersistRows && qserve_w4a8_persist(st, GROUP, out, a, w, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, M, N, K,
                                                    lda, ldc)) {
   } else {
     qserve_w4a8_tile_kernel<GROUP><<<dim3(gx, (unsigned)cdiv(M, 128)), 256, 0, st>>>(
         (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,
         (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc);
   }
-#undef SGLK_GO
-#undef SGLK_GO_SPLIT
+#undef SGLK_GO_STREAM_KS
+#undef SGLK_GO_STREAM
   return check_launch(GROUP ? "qserve_w4a8_per_group_gemm" : "qserve_w4a8_per_chn_gemm");
 }
 

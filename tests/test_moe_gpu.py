@@ -451,6 +451,33 @@ def test_grouped_mm_many_experts_tile_pipeline(sglk, dev):
     torch.testing.assert_close(out4.cpu(), ref4, rtol=5e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_grouped_mm_bias_enters_exactly_on_the_tile_pipeline(sglk, dev, dt):
+    """moe_persist.hip feeds the fp32 bias through the matrix pipe as three 16-bit pieces (hi + mid + lo): with zero
+    activations the output must be the bias rounded ONCE to the output type, bit for bit - 256- and 128-row blocks, the
+    streaming kernels' remainders, 16-bit and int4 weights, magnitudes over 30 binades."""
+    g = torch.Generator().manual_seed(11)
+    for rows in ([300, 200, 513, 256, 260, 250, 300, 310], [130, 100, 150, 120, 97, 140, 128, 111]):
+        E, N, K = len(rows), 384, 256
+        total = sum(rows)
+        act = torch.zeros(total, K, dtype=dt)
+        w = (torch.randn(E, N, K, generator=g) * 0.1).to(dt)
+        mag = 2.0 ** torch.randint(-20, 10, (E, N), generator=g).float()
+        bias = torch.randn(E, N, generator=g) * mag
+        if dt == torch.float16:
+            bias = bias.clamp(-6e4, 6e4)
+        r = torch.tensor(rows, dtype=torch.int32)
+        out = torch.full((total, N), float("nan"), dtype=dt, device=dev)
+        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, act.to(dev), w.to(dev), bias.to(dev), r.to(dev), E, 0, False, 1.702, 7.0)
+        want = torch.cat([bias[e].to(dt).expand(n, N) for e, n in enumerate(rows)])
+        assert torch.equal(out.cpu(), want), (rows[0], dt)
+        packed, scales, _ = make_int4(E, N, K, 128, dt, False, g)
+        out4 = torch.full((total, N), float("nan"), dtype=dt, device=dev)
+        torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(out4, act.to(dev), packed.to(dev), scales.to(dev), None, bias.to(dev),
+                                                          r.to(dev), E, True, 128)
+        assert torch.equal(out4.cpu(), want), (rows[0], dt, "int4")
+
+
 def test_grouped_mm_16bit_fused_act(sglk, dev):
     g = torch.Generator().manual_seed(5)
     _check_fused_act_16bit(sglk, dev, g, [5, 0, 9, 1, 40, 2, 2, 7], 256, 512)

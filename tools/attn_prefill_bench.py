@@ -1,0 +1,30 @@
+"""fwd (flash attention) PREFILL legs only, for profiling attn_prefill_kernel (BASELINE configs[2]: bs=16, 32 q / 8 kv heads,
+seq=4096, paged 64, bf16): causal d=128, causal d=64, q=128 chunk prefill over 4096 keys."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "python"))
+from sgl_kernel.flash_attn import flash_attn_with_kvcache
+dev = "cuda"
+bs, hq, hk, seq, page = 16, 32, 8, 4096, 64
+n_pages = bs * seq // page
+pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, seq // page)
+lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+def timeit(f, warm, it):
+    for _ in range(warm): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(it): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / it * 1e3
+for d in (128, 64):
+    kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+    vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+    qp = torch.randn(bs * seq, hq, d, device=dev, dtype=torch.bfloat16)
+    cu = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * seq
+    ms = timeit(lambda: flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                max_seqlen_q=seq, causal=True), 5, 10)
+    print(f"prefill causal d={d}: {ms:.3f} ms  {4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9:.1f} TFLOP/s")
+    if d == 128:
+        qc = torch.randn(bs * 128, hq, d, device=dev, dtype=torch.bfloat16)
+        cuc = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * 128
+        ms = timeit(lambda: flash_attn_with_kvcache(qc, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cuc,
+                                                    max_seqlen_q=128, causal=True), 10, 30)
+        print(f"chunk prefill q=128 d=128: {ms:.4f} ms  {4.0 * bs * hq * d * (128 * (seq - 128) + 128 * 129 / 2) / ms / 1e9:.1f} TFLOP/s")

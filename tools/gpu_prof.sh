@@ -1,10 +1,10 @@
 #!/bin/bash
 # One profile set on the GPU box: kernel trace + two SQ counter passes (+ FETCH / WRITE with PROF_MEM=1) of ONE program,
-# digested by tools/summarize_prof.py into gpurun_out/r03/prof/digest/<name>_{kernel_stats.csv,pmc.json}.
+# digested by tools/summarize_prof.py into gpurun_out/<round>/prof/digest/<name>_{kernel_stats.csv,pmc.json}.
 #   tools/gpu_prof.sh <name> <program> [args...]     (the program directly after "--": no shell in between; counters
 #   are never combined with trace flags)
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/r03/prof
+OUT=$R/gpurun_out/${PROF_ROUND:-r04}/prof
 name=$1; shift
 mkdir -p $OUT/$name
 export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
