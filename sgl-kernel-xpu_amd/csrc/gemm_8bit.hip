@@ -1520,7 +1520,8 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
 // BEFORE their whole tiles: their tile boundaries then lie half a tile away from the others', and the 128 KiB a
 // workgroup writes at each boundary no longer leave all 256 CUs within the same K block (the store burst of DESIGN 4.10).
 // all_halves: every tile as two half tiles (few rows: twice the workgroups), the MS = 2 phase only.
-// stagger: 0 = nobody, 1 = the upper half of an XCD's slots, 2 = every other pair of slots runs its half tile first.
+// stagger: 0 = nobody, 1 = the upper half of an XCD's slots, 2 = every other pair of slots runs its half tile first,
+// 3 = every workgroup of the odd XCDs (the workgroups that share panels in an L2 stay in step), 4 = everybody.
 // Measured at (4096, 14336, 4096) in interleaved rounds on one device (kbench gemmab): 0.2200 / 0.2225 / 0.2250 ms for
 // 0 / 1 / 2 - what the halved burst gives, the XCD's L2 takes back (16 whole + 16 half tiles in flight share 4 + 4 + 2
 // panels in two K positions instead of 32 tiles sharing 4 + 8 in one): the release library uses 0.
@@ -1532,7 +1533,8 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     int stagger, uint32_t* __restrict__ stamps) {
   __shared__ __attribute__((aligned(256))) char smem[3 * (kStageBytes - kTileBytes / 2)];  // half tiles: 3 x 50 KiB; whole tiles 2 x 66 KiB
   const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  const bool half_first = all_halves || (stagger == 1 ? 2 * slot >= slots : stagger == 2 ? ((slot >> 1) & 1) != 0 : false);
+  const bool half_first = all_halves || (stagger == 1 ? 2 * slot >= slots : stagger == 2 ? ((slot >> 1) & 1) != 0
+                                         : stagger == 3 ? (blockIdx.x & 1) != 0 : stagger == 4);
 #pragma nounroll
   for (int ph = 0; ph < (all_halves ? 1 : 2); ++ph) {
     if ((ph == 0) == half_first) {

@@ -82,8 +82,8 @@ struct MpTile {
 // as 256-row blocks cost a quarter more tiles.
 // FMT: 0 16-bit weights, 1 int4 (two's-complement codes, no zero points), 2 mxfp4 (E8M0 scale per 32), 3 int4 with zero points
 // BIAS: out += bias[e][n] (fp32, in front of the activation). The bias enters through the matrix pipe: the first MFMA of a
-// tile's accumulator chain multiplies a weight-side operand whose k = 0, 1, 2 are the three 16-bit pieces of the fp32 bias of
-// the lane's weight row (hi + mid + lo = the fp32 value: 3 x 8 significant bits for bf16, 3 x 11 for fp16) with an
+// tile's accumulator chain (a bf16 MFMA, whatever T) multiplies a weight-side operand whose k = 0, 1, 2 are the three bf16
+// pieces of the fp32 bias of the lane's weight row (hi + mid + lo = the fp32 value: 3 x 8 significant bits) with an
 // activation-side operand of three ones: the fp32 accumulator starts at exactly the bias, no registers are held across the
 // tile and nothing waits in the store block (the reference's grouped GEMM adds the bias in its epilogue,
 // src/sycl/GroupGemmW4A16Xe20.cpp:92-283; python/sgl_kernel/moe.py:574-587).
@@ -103,6 +103,12 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   const int64_t a_row = (int64_t)K * 2;                                   // bytes
   const int64_t b_row = W4 ? (int64_t)(K >> 1) : p.ldb * 2;               // bytes per weight row
   const int64_t b_exp = W4 ? (int64_t)N * (K >> 1) : p.stride_e * 2;      // bytes per expert
+  // LDS stage: a rows [64 MS][128 B], b rows [256][128 B]. 256-row blocks: two stages of 64 KiB. 128-row blocks: THREE stages of
+  // 48 KiB - with 1024 cycles of MFMAs per K block and the block's data requested one block ahead the loop ran at the latency
+  // of its LDS-DMA (3200 shader cycles per block; the same finding as the half tiles of gemm_fp8bw_x32_kernel): block g + 2's
+  // b pieces (16-bit weights) go out in block g, block g + 3's a pieces behind its barrier, the 4-bit codes three blocks ahead.
+  constexpr int NST = MS == 2 ? 3 : 2;
+  constexpr int kOffB = MS * 64 * kBKB, kStg = kOffB + kTile;
   const int gshift = FMT == 2 ? 5 : p.gshift;
   const int kgroups = K >> gshift;                  // scales per weight row
   constexpr int kSB = FMT == 2 ? 1 : 2;             // bytes per scale
@@ -219,21 +225,27 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   }
   // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = weight rows (16-bit weights only), sub 0, 1 each.
   // The piece's row offset inside its tile is a per-wave constant (scalar registers, set once).
+  // (128-row blocks: the a tile has 16 pieces, two per wave - part 0 only, piece 2 wave + sub)
   int a_poff[4], b_poff[4];
 #pragma unroll
   for (int ii = 0; ii < 4; ++ii) {
-    a_poff[ii] = __builtin_amdgcn_readfirstlane((wave * 4 + ii) * 8 * (int)a_row);
+    a_poff[ii] = __builtin_amdgcn_readfirstlane((MS == 2 ? wave * 2 + (ii & 1) : wave * 4 + ii) * 8 * (int)a_row);
     b_poff[ii] = __builtin_amdgcn_readfirstlane(wrow_of((wave * 4 + ii) * 8) * (int)b_row);  // (8 slots of a piece = 8 consecutive rows)
   }
   auto dma_piece = [&](const MpTile& d, int kb, int s, int part, int sub) {
-    char* base = smem + s * kStage;
+    char* base = smem + s * kStg;
     const int ii = (part & 1) * 2 + sub, piece = wave * 4 + ii;
     if (part < 2) {
-      if (MS == 2 && wave >= 4) return;  // (rows 128.. of the a tile do not exist)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pa, d.nrec_a), MP_LDS(base + piece * 1024), 16, voff_a[ii & 1],
-                                               kb * kBKB + a_poff[ii], 0, 0);
+      if constexpr (MS == 2) {
+        if (part == 1) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pa, d.nrec_a), MP_LDS(base + (wave * 2 + sub) * 1024), 16,
+                                                 voff_a[sub], kb * kBKB + a_poff[sub], 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pa, d.nrec_a), MP_LDS(base + piece * 1024), 16, voff_a[ii & 1],
+                                                 kb * kBKB + a_poff[ii], 0, 0);
+      }
     } else if constexpr (!W4) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pb, d.nrec_b), MP_LDS(base + kTile + piece * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pb, d.nrec_b), MP_LDS(base + kOffB + piece * 1024), 16,
                                                voff_b[ii & 1], kb * kBKB + b_poff[ii], 0, 0);
     }
   };
@@ -249,8 +261,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
                            (uint32_t)((phalf * 32) >> gshift) * (uint32_t)kSB;
   const uint32_t pwr = (uint32_t)(pslot * 128);           // LDS row of the b tile
   const uint32_t pkey = (uint32_t)((pslot >> 1) & 7);
-  v4i raw_c = {0, 0, 0, 0}, raw_n = {0, 0, 0, 0};
-  uint32_t sraw_c = 0, sraw_n = 0;
+  v4i raw_c = {0, 0, 0, 0}, raw_n = {0, 0, 0, 0}, raw_nn = {0, 0, 0, 0};  // codes of blocks + 1, + 2 (and + 3: three stages)
+  uint32_t sraw_c = 0, sraw_n = 0, sraw_nn = 0;
   auto load_raw = [&](const MpTile& d, int kb, v4i& raw, uint32_t& sr) {
     if constexpr (W4) {
       raw = __builtin_amdgcn_raw_buffer_load_b128(mp_rsrc(d.pb, d.nrec_b), (int)pvoff_w, kb * 32, 0);
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
 
   v4i nq[2][4];  // [n-fragment][k-step]
   v4i mq[4];     // [k-step] of the running m-fragment (each re-read right behind its second MFMA)
-  int gblk = 0;
+  int gblk = 0, stg = 0;  // K blocks done; (three stages) the stage of the running block
   // BIAS: the weight-side operands of the two n-fragments (lane (i, 0): {hi, mid, lo, 0 ..} of weight row brow(i); lanes (i, 1):
   // zeros) and the activation-side operand of ones, rebuilt at the top of every tile's first K block
   // (only the two non-zero dwords of each operand live across the store block; the rest is rebuilt in front of the MFMA)
@@ -398,12 +410,14 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       const __amdgpu_buffer_rsrc_t rb = mp_rsrc(d.pbs, d.nrec_bs);
       const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)bias_voff0, 0, 0));
       const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)bias_voff1, 0, 0));
+      // (always bf16 pieces and the bf16 MFMA, whatever T: bf16 has fp32's exponent range, so hi + mid + lo IS the fp32 value;
+      // fp16 pieces of a small bias fall on the subnormal grid and came out an fp16 ulp off in 9 % of the elements)
       auto split = [&](float b) -> v4i {
-        const T hi = (T)b;
+        const bf16 hi = (bf16)b;
         const float r1 = b - (float)hi;
-        const T mid = (T)r1;
+        const bf16 mid = (bf16)r1;
         const float r2 = r1 - (float)mid;
-        const T lo = (T)r2;
+        const bf16 lo = (bf16)r2;
         return (v4i){(int)((uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, mid) << 16)) & lh_mask,
                      (int)(uint32_t)__builtin_bit_cast(uint16_t, lo) & lh_mask, 0, 0};
       };
@@ -415,13 +429,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
 #define MP_MFMA_BIAS(mf, nf)                                                                                   \
   {                                                                                                            \
     const v4i bop_ = {bq[nf][0], bq[nf][1], 0, 0};                                                             \
-    const v4i one_ = {(std::is_same<T, bf16>::value ? 0x3F803F80 : 0x3C003C00) & lh_mask,                      \
-                      (std::is_same<T, bf16>::value ? 0x00003F80 : 0x00003C00) & lh_mask, 0, 0};               \
-    if constexpr (std::is_same<T, bf16>::value) {                                                              \
-      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(bop_), "v"(one_)); \
-    } else {                                                                                                   \
-      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(bop_), "v"(one_));  \
-    }                                                                                                          \
+    const v4i one_ = {0x3F803F80 & lh_mask, 0x00003F80 & lh_mask, 0, 0};                                       \
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(bop_), "v"(one_)); \
   }
 #ifdef SGLK_PROBES
   constexpr bool kBarStamps = FMT <= 1;  // (the per-wave barrier stamps: diagnostic build, 16-bit and plain int4 weights)
@@ -465,28 +474,36 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
         MP_RD16(mq[s_], na0 ^ x_, 0);                                                                          \
         /* (all of a's pieces of block + 2 go out here, a whole block ahead of their barrier: with parts 1..3 in the */ \
         /* next block's first two steps the wait at the barrier cost ~2100 cycles per block)                      */ \
-        dma_piece(d2, kb2, s, s_ >> 1, s_ & 1);                                                                \
+        if (MS == 4 || s_ < 2) dma_piece(dL, kbL, sL, s_ >> 1, s_ & 1);                                        \
       } else {                                                                                                 \
         MP_RD16(mq[s_], a0 ^ (uint32_t)(s_ << 5), ((mf) + 1) * 4096);                                          \
-        if ((mf) == 0) dma_piece(d1, kb1, s ^ 1, 2 + (s_ >> 1), s_ & 1); /* (16-bit weights: the b pieces) */    \
+        if ((mf) == 0) dma_piece(dE, kbE, sE, 2 + (s_ >> 1), s_ & 1); /* (16-bit weights: the b pieces) */       \
       }                                                                                                        \
       /* the two waves of a SIMD (w, w + 4) run this stream in lockstep: with the expansion in the same gaps of both, its   */ \
       /* VALU time adds to the block (neither has MFMAs ready for the other's VALU phase). Waves 0..3 expand in step 0,    */ \
       /* waves 4..7 in step 2: each one's VALU phase lies beside the other's bare MFMAs.                                   */ \
       if (W4 && !(LAST) && MS == 4 && (((mf) == 0 && wave < 4) || ((mf) == 2 && wave >= 4)))                               \
-        expand(raw_c, sraw_c, s_, nbase + (uint32_t)kTile + pwr);                                              \
-      if (W4 && !(LAST) && MS == 2) expand(raw_c, sraw_c, s_, nbase + (uint32_t)kTile + pwr);                  \
+        expand(raw_c, sraw_c, s_, nbase + (uint32_t)kOffB + pwr);                                              \
+      if (W4 && !(LAST) && MS == 2) expand(raw_c, sraw_c, s_, nbase + (uint32_t)kOffB + pwr);                  \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   }
 #define MP_BLOCK(STORE)                                                                                        \
   {                                                                                                            \
-    const int s = gblk & 1;                                                                                    \
-    const uint32_t sbase = lds_base + (uint32_t)(s * kStage);                                                  \
-    const uint32_t nbase = lds_base + (uint32_t)((s ^ 1) * kStage);                                            \
-    const bool in1 = kb + 1 < nkb, in2 = kb + 2 < nkb;                                                         \
+    const int s = NST == 2 ? (gblk & 1) : stg;                                                                 \
+    const int s1 = NST == 2 ? (s ^ 1) : (s == 2 ? 0 : s + 1), s2 = NST == 2 ? s : (s1 == 2 ? 0 : s1 + 1);      \
+    const uint32_t sbase = lds_base + (uint32_t)(s * kStg);                                                    \
+    const uint32_t nbase = lds_base + (uint32_t)(s1 * kStg);                                                   \
+    const bool in1 = kb + 1 < nkb, in2 = kb + 2 < nkb, in3 = kb + 3 < nkb;                                     \
     const MpTile d1 = pick(in1, cur_t, nxt), d2 = pick(in2, cur_t, nxt);                                       \
-    const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb;                                       \
+    const MpTile d3 = NST == 2 ? d2 : pick(in3, cur_t, nxt);                                                   \
+    const int kb1 = in1 ? kb + 1 : 0, kb2 = in2 ? kb + 2 : kb + 2 - nkb, kb3 = in3 ? kb + 3 : kb + 3 - nkb;    \
+    /* dE / kbE / sE: the b pieces issued in front of the barrier (block + 1; three stages: block + 2); dL / kbL / sL: the a */ \
+    /* pieces issued behind it, into the stage just read (block + 2; three stages: block + 3)                                */ \
+    const MpTile& dE = NST == 2 ? d1 : d2;                                                                     \
+    const MpTile& dL = NST == 2 ? d2 : d3;                                                                     \
+    const int kbE = NST == 2 ? kb1 : kb2, kbL = NST == 2 ? kb2 : kb3, sE = NST == 2 ? s1 : s2, sL = s;         \
+    (void)d1; (void)kb1;                                                                                       \
     uint32_t a0, nb0 = 0, na0 = 0;                                                                             \
     {                                                                                                          \
       int fo = frag_off_a;                                                                                     \
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       a0 = sbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)fo;                                            \
     }                                                                                                          \
     if constexpr (BIAS && (STORE)) load_bias(cur_t);                                                          \
-    load_raw(d2, kb2, raw_n, sraw_n);                                                                          \
+    if constexpr (NST == 2) load_raw(d2, kb2, raw_n, sraw_n); else load_raw(d3, kb3, raw_nn, sraw_nn);         \
     if constexpr (MS == 4) { MP_STEP(0, STORE, false, false) MP_STEP(1, STORE, false, false) MP_STEP(2, STORE, false, true) } \
     else { MP_STEP(0, STORE, false, true) }                                                                    \
     if constexpr (kBarStamps) { /* diagnostic build: where the block's barrier time goes (own data / the other waves) */ \
@@ -509,20 +526,28 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       } else {                                                                                                 \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
       }                                                                                                        \
+    } else if constexpr (NST == 3) {                                                                           \
+      /* vmcnt retires in issue order; younger than block + 1's data are this wave's 2 a pieces of block + 2 (issued behind the */ \
+      /* last barrier) and, in this block, the 4 b pieces of block + 2 (16-bit weights) or the 2 - 3 code / scale loads of       */ \
+      /* block + 3; the stores of a tile's first block are younger still: the count stays (it then waits for a few of them too) */ \
+      constexpr int kYoung = FMT == 0 ? 6 : FMT == 3 ? 5 : 4;                                                  \
+      asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : "n"(kYoung) : "memory"); \
     } else                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     {                                                                                                          \
       int foa = frag_off_a, fob = frag_off_b;                                                                  \
       asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
-      nb0 = nbase + (uint32_t)(kTile + wn * 64 * 128) + (uint32_t)fob;                                         \
+      nb0 = nbase + (uint32_t)(kOffB + wn * 64 * 128) + (uint32_t)fob;                                         \
       na0 = nbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)foa;                                          \
       asm volatile("" : "+v"(nb0), "+v"(na0));                                                                 \
     }                                                                                                          \
     MP_STEP(MS - 1, STORE, true, false)                                                                        \
     raw_c = raw_n;                                                                                             \
     sraw_c = sraw_n;                                                                                           \
+    if constexpr (NST == 3) { raw_n = raw_nn;  sraw_n = sraw_nn; }                                             \
     ++gblk;                                                                                                    \
+    stg = s1;                                                                                                  \
   }
 
   int unit = 0;
@@ -539,12 +564,21 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     load_raw(cur_t, 0, raw_c, sraw_c);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_c), "+v"(sraw_c));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) expand(raw_c, sraw_c, q, lds_base + (uint32_t)kTile + pwr);
+    for (int q = 0; q < 4; ++q) expand(raw_c, sraw_c, q, lds_base + (uint32_t)kOffB + pwr);
     load_raw(cur_t, 1, raw_c, sraw_c);
+    if constexpr (NST == 3) load_raw(cur_t, 2, raw_n, sraw_n);
   }
+  if constexpr (NST == 3) {  // (all of block 1 and the a pieces of block 2 go out before anything waits: nkb >= 3)
+    dma_piece(cur_t, 1, 1, 0, 0);  dma_piece(cur_t, 1, 1, 0, 1);
+    dma_piece(cur_t, 1, 1, 2, 0);  dma_piece(cur_t, 1, 1, 2, 1);
+    dma_piece(cur_t, 1, 1, 3, 0);  dma_piece(cur_t, 1, 1, 3, 1);
+    dma_piece(cur_t, 2, 2, 0, 0);  dma_piece(cur_t, 2, 2, 0, 1);
+  }
+  // (three stages: block 0 has landed when only the pieces of blocks 1 and 2 - and the code loads - are outstanding; the wait
+  // is simply for everything: once per workgroup)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   {
-    const uint32_t b0 = lds_base + (uint32_t)(kTile + wn * 64 * 128) + (uint32_t)frag_off_b;
+    const uint32_t b0 = lds_base + (uint32_t)(kOffB + wn * 64 * 128) + (uint32_t)frag_off_b;
     const uint32_t p0 = lds_base + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)frag_off_a;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -554,10 +588,12 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       MP_RD16(mq[s], p0 ^ x, 0);
     }
   }
-  dma_piece(cur_t, 1, 1, 0, 0);
-  dma_piece(cur_t, 1, 1, 0, 1);
-  dma_piece(cur_t, 1, 1, 1, 0);
-  dma_piece(cur_t, 1, 1, 1, 1);
+  if constexpr (NST == 2) {
+    dma_piece(cur_t, 1, 1, 0, 0);
+    dma_piece(cur_t, 1, 1, 0, 1);
+    dma_piece(cur_t, 1, 1, 1, 0);
+    dma_piece(cur_t, 1, 1, 1, 1);
+  }
 
   for (; unit < n_units; ++unit) {
     const MpTile nxt = describe(unit + 1);
@@ -615,19 +651,20 @@ constexpr int kMinAvgRows = 192;  // average rows per expert from which the tile
 template <typename T, int W4, bool BIAS = false>
 static int launch_persist(hipStream_t st, const MpParams& p) {
   static unsigned long long attr_done4 = 0, attr_done2 = 0;
+  constexpr int kLds2 = 3 * (kTile / 2 + kTile);  // 128-row blocks: three stages of 48 KiB
   if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 4, BIAS>), 2 * kStage, &attr_done4, "moe_persist"))
     return rc;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 2, BIAS>), 2 * kStage, &attr_done2, "moe_persist"))
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 2, BIAS>), kLds2, &attr_done2, "moe_persist"))
     return rc;
   if (p.blocks128) {  // 96 .. 191 rows per expert on average: 128-row blocks
-    moe_persist_kernel<T, W4, 2, BIAS><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
+    moe_persist_kernel<T, W4, 2, BIAS><<<(unsigned)num_cus(), 512, kLds2, st>>>(p);
     return 0;
   }
   moe_persist_kernel<T, W4, 4, BIAS><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
   // Remainders of at most 128 rows: the callers run their streaming kernels over them (moe_tiles.h, tail mode) - a few
   // dozen rows per expert are a weight stream, 70 us for the Mixtral down projection against 275 us as 128-row tiles here
   // (K = 14336: 96 long tiles on 256 CUs). MOE_PERSIST_TAILS=1 in the diagnostic build runs them here instead.
-  if (g_mp_own_tails) moe_persist_kernel<T, W4, 2, BIAS><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);
+  if (g_mp_own_tails) moe_persist_kernel<T, W4, 2, BIAS><<<(unsigned)num_cus(), 512, kLds2, st>>>(p);
   return 0;
 }
 
@@ -644,6 +681,7 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
   const int Nout = gated ? N / 2 : N;
   if (total_m < (int64_t)kMinAvgRows128 * E || num_cus() % 8 != 0 || (uintptr_t)bias % 4 != 0) return 0;
   const bool blocks128 = total_m < (int64_t)kMinAvgRows * E;
+  if (blocks128 && K < 192) return 0;  // (the three-stage ring of the 128-row blocks looks three K blocks ahead)
   if (w4 == 2 && dtype != SGLK_BF16) return 0;  // (the fp4 conversion instruction is used in its bf16 form)
   if (K % 64 != 0 || K < 128 || N % 8 != 0 || (gated && (N % 64 != 0)) || (uintptr_t)out % 16 != 0 ||
       (uintptr_t)act % 16 != 0 || (uintptr_t)w % 16 != 0 || Nout % 8 != 0)

@@ -173,7 +173,15 @@ def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
     for e, r in enumerate(rows):
         exact[r0:r0 + r] = act[r0:r0 + r].float() @ w_exact[e].t() + (bias[e] if bias is not None else 0.0)
         r0 += r
-    torch.testing.assert_close(out.cpu().float(), exact.to(dtype).float(), rtol=1e-2, atol=2e-3)
+    # (prefill row counts run on the tile pipeline of moe_persist.hip, which rounds (code - zero) * scale once to the activation
+    # type as the reference's dequantisation does, gemm_xe2.hpp:52-76; an expert's last rows stay on the streaming kernels:
+    # every element is tight against one of the two definitions - the oracle's for the tile pipeline's rows)
+    o = out.cpu().float()
+    near_exact = torch.isclose(o, exact.to(dtype).float(), rtol=1e-2, atol=2e-3)
+    if sum(rows) < 96 * E:
+        assert near_exact.all(), "the streaming kernels keep the codes exact"
+    else:
+        assert (near_exact | torch.isclose(o, ref.float(), rtol=1e-2, atol=2e-3)).all()
 
 
 @pytest.mark.parametrize("act_type", [1, 2, 3, 4])  # silu, gelu (tanh), relu2, DeepSeek-V4 clamped swiglu
@@ -470,7 +478,10 @@ def test_grouped_mm_bias_enters_exactly_on_the_tile_pipeline(sglk, dev, dt):
         out = torch.full((total, N), float("nan"), dtype=dt, device=dev)
         torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, act.to(dev), w.to(dev), bias.to(dev), r.to(dev), E, 0, False, 1.702, 7.0)
         want = torch.cat([bias[e].to(dt).expand(n, N) for e, n in enumerate(rows)])
-        assert torch.equal(out.cpu(), want), (rows[0], dt)
+        bad = (out.cpu() != want).nonzero()
+        assert bad.numel() == 0, (rows[0], dt, bad.shape[0], [(int(i), int(j), float(out[i, j]), float(want[i, j]),
+                                                                 float(bias[[sum(rows[:e + 1]) > int(i) for e in range(E)].index(True), j]))
+                                                                for i, j in bad[:6]])
         packed, scales, _ = make_int4(E, N, K, 128, dt, False, g)
         out4 = torch.full((total, N), float("nan"), dtype=dt, device=dev)
         torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20_w4a16(out4, act.to(dev), packed.to(dev), scales.to(dev), None, bias.to(dev),
