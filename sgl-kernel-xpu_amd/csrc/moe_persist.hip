@@ -58,7 +58,8 @@ struct MpParams {
   uint32_t* stamps;     // diagnostic build (sglk_debug_set_moe_clock_stamps): per workgroup {shader cycles, 100 MHz ticks, K blocks, MS}
   int prio47;           // s_setprio value of waves 4..7 (0..3)
   int blocks128;        // MS = 2 launch: 0 = only the <= 128-row remainders of 256-row blocks; 1 = all rows in 128-row blocks
-                        // (remainders of at most 64 rows excepted: the caller's streaming kernels take them)
+                        // (remainders of at most 64 rows excepted: the caller's streaming kernels take them); 2 = the same
+                        // blocks as 128 x 512 tiles (WIDE)
   const int32_t* rows;  // [E]
   int E, N, K, fuse;    // fuse: 0 none, 1 silu, 2 gelu (tanh), 3 relu2, 4 clamped swiglu (1, 2, 4 gated: N = gate + up rows)
   float act_limit;
@@ -87,8 +88,16 @@ struct MpTile {
 // activation-side operand of three ones: the fp32 accumulator starts at exactly the bias, no registers are held across the
 // tile and nothing waits in the store block (the reference's grouped GEMM adds the bias in its epilogue,
 // src/sycl/GroupGemmW4A16Xe20.cpp:92-283; python/sgl_kernel/moe.py:574-587).
-template <typename T, int FMT, int MS, bool BIAS = false>
+// WIDE (with MS = 4): a tile of 128 activation rows x 512 weight rows for 96 .. 191 rows per expert. The 128-row blocks of MS = 2
+// do 1024 cycles of MFMAs per K block and barrier (3100 - 3200 shader cycles per block measured: 0.33 of the matrix pipe); here
+// the ROLES of the operands are swapped instead - the wave grid is 2 (activation rows) x 4 (weight rows), a wave HOLDS its two
+// activation fragments of a K block in registers (the n-fragment registers of the 256-row form) and STREAMS four weight
+// fragments past them (the m-steps of the 256-row form): the same 32 MFMAs per wave, K block and barrier, the same register
+// budget, the same LDS reads per MFMA as a 256 x 256 tile. Stage: a 16 KiB + b 64 KiB, two stages = all 160 KiB of LDS.
+// Gated epilogues: n-fragments 0, 1 of a wave are gate columns, 2, 3 the up columns that go with them.
+template <typename T, int FMT, int MS, bool BIAS = false, bool WIDE = false>
 __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
+  static_assert(!WIDE || MS == 4, "the wide tile streams four weight fragments per K block");
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][a tile, b tile]
   constexpr bool W4 = FMT != 0;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +108,10 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // (an opaque scalar: left as an expression the compiler re-evaluates `fuse` with a branch ladder at every use inside the K loop)
   const bool gated = __builtin_amdgcn_readfirstlane((int)(p.fuse == 1 || p.fuse == 2 || p.fuse == 4)) != 0;
   const int Nout = gated ? N >> 1 : N;
-  const int NB = gated ? (Nout + 127) >> 7 : (N + kBN - 1) / kBN;
+  constexpr int kRowsA = WIDE ? 128 : MS * 64;  // activation rows and weight rows (LDS slots) of a tile
+  constexpr int kRowsB = WIDE ? 512 : 256;
+  constexpr int kSW = kRowsB / 4;               // weight slots per wave column
+  const int NB = gated ? (Nout + kRowsB / 2 - 1) / (kRowsB / 2) : (N + kRowsB - 1) / kRowsB;
   const int64_t a_row = (int64_t)K * 2;                                   // bytes
   const int64_t b_row = W4 ? (int64_t)(K >> 1) : p.ldb * 2;               // bytes per weight row
   const int64_t b_exp = W4 ? (int64_t)N * (K >> 1) : p.stride_e * 2;      // bytes per expert
@@ -108,14 +120,14 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // of its LDS-DMA (3200 shader cycles per block; the same finding as the half tiles of gemm_fp8bw_x32_kernel): block g + 2's
   // b pieces (16-bit weights) go out in block g, block g + 3's a pieces behind its barrier, the 4-bit codes three blocks ahead.
   constexpr int NST = MS == 2 ? 3 : 2;
-  constexpr int kOffB = MS * 64 * kBKB, kStg = kOffB + kTile;
+  constexpr int kOffB = kRowsA * kBKB, kStg = kOffB + kRowsB * kBKB;
   const int gshift = FMT == 2 ? 5 : p.gshift;
   const int kgroups = K >> gshift;                  // scales per weight row
   constexpr int kSB = FMT == 2 ? 1 : 2;             // bytes per scale
 
   // ---- the tiles: MB row blocks (all experts) x NB column blocks, column blocks fastest; XCD x owns a contiguous run
   // row blocks of an expert with r rows in THIS launch
-  const bool b128 = MS == 2 && p.blocks128 != 0;
+  const bool b128 = (MS == 2 && p.blocks128 != 0) || WIDE;
   auto blocks_of = [&](int r) -> int {
     if (b128) return (r >> 7) + ((r & 127) > 64 ? 1 : 0);
     const int full = r >> 8, tail = r & 255;
@@ -179,12 +191,12 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     e = __builtin_amdgcn_readfirstlane(e);
     blk = __builtin_amdgcn_readfirstlane(blk);
     rows_e = __builtin_amdgcn_readfirstlane(rows_e);
-    const int first = MS == 4 ? blk * kBM : b128 ? blk * 128 : (rows_e & ~255);  // first row of the block inside its expert
+    const int first = (MS == 4 && !WIDE) ? blk * kBM : b128 ? blk * 128 : (rows_e & ~255);  // first row of the block inside its expert
     const int m0 = __builtin_amdgcn_readfirstlane(row0) + first;
     int rows_a = rows_e - first;
-    rows_a = rows_a < MS * 64 ? rows_a : MS * 64;
-    const int c0 = gated ? cb * 128 : cb * kBN;          // first output column (gated: = first gate row)
-    const int cols = gated ? (Nout - c0 < 128 ? Nout - c0 : 128) : (N - c0 < kBN ? N - c0 : kBN);
+    rows_a = rows_a < kRowsA ? rows_a : kRowsA;
+    const int c0 = gated ? cb * (kRowsB / 2) : cb * kRowsB;          // first output column (gated: = first gate row)
+    const int cols = gated ? (Nout - c0 < kRowsB / 2 ? Nout - c0 : kRowsB / 2) : (N - c0 < kRowsB ? N - c0 : kRowsB);
     d.ncols = cols;
     d.pa = (const char*)p.act + (int64_t)m0 * a_row;
     d.pb = (const char*)p.w + (int64_t)e * b_exp + (int64_t)c0 * b_row;
@@ -212,7 +224,10 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   };
   // weight row (relative to the tile's first) of LDS row `slot`: the wave that owns columns wn * 64 .. reads slots wn * 64 ..;
   // gated: its first 32 slots are gate rows c0 + 32 wn .., its last 32 the up rows N/2 further on
-  auto wrow_of = [&](int s) -> int { return gated ? ((s >> 6) * 32 + (s & 31) + ((s & 32) ? Nout : 0)) : s; };
+  // (wide tile: 128 slots per wave, its first 64 gate rows c0 + 64 wn .., its last 64 the up rows)
+  auto wrow_of = [&](int s) -> int {
+    return gated ? ((s / kSW) * (kSW / 2) + (s & (kSW / 2 - 1)) + ((s & (kSW / 2)) ? Nout : 0)) : s;
+  };
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)MP_LDS(smem);
   // DMA piece = 8 LDS rows x 128 B; lane -> row lane / 8, chunk (lane % 8) ^ key(row), key = (row >> 1) & 7
@@ -226,17 +241,21 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = weight rows (16-bit weights only), sub 0, 1 each.
   // The piece's row offset inside its tile is a per-wave constant (scalar registers, set once).
   // (128-row blocks: the a tile has 16 pieces, two per wave - part 0 only, piece 2 wave + sub)
-  int a_poff[4], b_poff[4];
+  // (wide tile: 16 a pieces as well; 64 b pieces, eight per wave: parts 2 .. 5)
+  constexpr bool kA2 = MS == 2 || WIDE;
+  constexpr int kBP = kRowsB / 64;  // b pieces per wave
+  int a_poff[4], b_poff[8];  // (b_poff[kBP]: a constant index past a 4-entry array in the never-taken wide calls made the host pass drop the 16-bit instantiations without a diagnostic)
 #pragma unroll
-  for (int ii = 0; ii < 4; ++ii) {
-    a_poff[ii] = __builtin_amdgcn_readfirstlane((MS == 2 ? wave * 2 + (ii & 1) : wave * 4 + ii) * 8 * (int)a_row);
-    b_poff[ii] = __builtin_amdgcn_readfirstlane(wrow_of((wave * 4 + ii) * 8) * (int)b_row);  // (8 slots of a piece = 8 consecutive rows)
-  }
+  for (int ii = 0; ii < 4; ++ii)
+    a_poff[ii] = __builtin_amdgcn_readfirstlane((kA2 ? wave * 2 + (ii & 1) : wave * 4 + ii) * 8 * (int)a_row);
+#pragma unroll
+  for (int ii = 0; ii < kBP; ++ii)
+    b_poff[ii] = __builtin_amdgcn_readfirstlane(wrow_of((wave * kBP + ii) * 8) * (int)b_row);  // (8 slots of a piece = 8 consecutive rows)
   auto dma_piece = [&](const MpTile& d, int kb, int s, int part, int sub) {
     char* base = smem + s * kStg;
-    const int ii = (part & 1) * 2 + sub, piece = wave * 4 + ii;
+    const int ii = part < 2 ? (part & 1) * 2 + sub : (part - 2) * 2 + sub, piece = part < 2 ? wave * 4 + ii : wave * kBP + ii;
     if (part < 2) {
-      if constexpr (MS == 2) {
+      if constexpr (kA2) {
         if (part == 1) return;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(mp_rsrc(d.pa, d.nrec_a), MP_LDS(base + (wave * 2 + sub) * 1024), 16,
                                                  voff_a[sub], kb * kBKB + a_poff[sub], 0, 0);
@@ -254,19 +273,25 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // (tid -> (slot, half) so that the eight lanes of a ds_write_b128 group hold eight different swizzle keys: 16-slot block
   // tid / 32, half (tid / 16) % 2, slot parity (tid / 8) % 2, key tid % 8. With slot = tid / 2 two lanes of a group shared a
   // key and a 128-byte bank window: SQ_LDS_BANK_CONFLICT was 20 % of the LDS cycles in the first r03 profile.)
+  // Wide tile: 512 slots, every thread takes (slot, half) and (slot + 256, half) - the second item's registers are the "2" ones.
   const int pslot = (tid >> 5) * 16 + 2 * (tid & 7) + ((tid >> 3) & 1), phalf = (tid >> 4) & 1;
   const uint32_t pvoff_w = (uint32_t)wrow_of(pslot) * (uint32_t)b_row + (uint32_t)phalf * 16u;
+  // (slot + 256 is weight row + 256 - gated: + 128, the same half of the next-but-one wave column: a scalar byte offset)
+  const int prow2 = gated ? 128 : 256;
   // (the thread's 32 codes lie in ONE scale group: group (64 kb + 32 half) >> gshift of the row)
   const uint32_t pvoff_s = (uint32_t)wrow_of(pslot) * (uint32_t)kgroups * (uint32_t)kSB +
                            (uint32_t)((phalf * 32) >> gshift) * (uint32_t)kSB;
-  const uint32_t pwr = (uint32_t)(pslot * 128);           // LDS row of the b tile
+  const uint32_t pwr = (uint32_t)(pslot * 128);           // LDS row of the b tile (second item: + 256 rows)
   const uint32_t pkey = (uint32_t)((pslot >> 1) & 7);
   v4i raw_c = {0, 0, 0, 0}, raw_n = {0, 0, 0, 0}, raw_nn = {0, 0, 0, 0};  // codes of blocks + 1, + 2 (and + 3: three stages)
   uint32_t sraw_c = 0, sraw_n = 0, sraw_nn = 0;
-  auto load_raw = [&](const MpTile& d, int kb, v4i& raw, uint32_t& sr) {
+  v4i raw_c2 = {0, 0, 0, 0};  // (wide tile: the second item; both items are re-loaded in place right behind their expansion)
+  uint32_t sraw_c2 = 0;
+  auto load_raw_at = [&](const MpTile& d, int kb, v4i& raw, uint32_t& sr, int drow) {
     if constexpr (W4) {
-      raw = __builtin_amdgcn_raw_buffer_load_b128(mp_rsrc(d.pb, d.nrec_b), (int)pvoff_w, kb * 32, 0);
-      const int so = ((kb * 64) >> gshift) * kSB;
+      raw = __builtin_amdgcn_raw_buffer_load_b128(mp_rsrc(d.pb, d.nrec_b), (int)pvoff_w,
+                                                  kb * 32 + __builtin_amdgcn_readfirstlane(drow * (int)b_row), 0);
+      const int so = ((kb * 64) >> gshift) * kSB + __builtin_amdgcn_readfirstlane(drow * kgroups * kSB);
       if constexpr (FMT == 2) {
         sr = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(mp_rsrc(d.ps, d.nrec_s), (int)pvoff_s,
                                                                      so, 0);
@@ -278,6 +303,10 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
                                                                           (int)pvoff_s, so, 0) << 16;
       }
     }
+  };
+  auto load_raw = [&](const MpTile& d, int kb, v4i& raw, uint32_t& sr) { load_raw_at(d, kb, raw, sr, 0); };
+  auto load_raw2 = [&](const MpTile& d, int kb, v4i& raw, uint32_t& sr) {
+    if constexpr (WIDE) load_raw_at(d, kb, raw, sr, prow2);
   };
   // dword q of the 16 bytes -> 8 values -> chunk 4 half + q of the thread's row of the b tile at wb (stored at once: keeping the
   // four results of a block in registers until the block's barrier cost 12 registers and, with the staggered schedule, spills)
@@ -332,7 +361,10 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
 
   // ---- stores: lane (i, h) owns row wm * 128 + 32 mf + i; plain: columns wn * 64 + 32 nf + 16 h .. + 15 of the tile;
   // gated: columns wn * 32 + 16 h .. + 15 (gate = n-fragment 0, up = n-fragment 1)
-  const uint32_t orow_off = (uint32_t)(((int64_t)(wm * (MS * 32) + li) * Nout + (gated ? wn * 32 : wn * 64) + lh * 16) * 2);
+  // (wide tile: row wm * 64 + 32 hf + i of held fragment hf; columns wn * 128 + 32 nf + 16 h .. of streamed fragment nf,
+  // gated wn * 64 + 32 nf + 16 h .. for nf = 0, 1)
+  const uint32_t orow_off = WIDE ? (uint32_t)(((int64_t)(wm * 64 + li) * Nout + (gated ? wn * 64 : wn * 128) + lh * 16) * 2)
+                                 : (uint32_t)(((int64_t)(wm * (MS * 32) + li) * Nout + (gated ? wn * 32 : wn * 64) + lh * 16) * 2);
   auto act_mul = [&](float x, float y) -> float {
     if (p.fuse == 4) {
       x = fminf(x, p.act_limit);
@@ -379,7 +411,38 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     }
   };
 
-  v16f acc[MS][2];
+  // wide tile, step nf of a tile's first K block: the finished tile's columns of streamed fragment nf, both held fragments
+  // (gated: nf = 0, 1 with the up values of fragment nf + 2)
+  auto store_frag_w = [&](const MpTile& d, const v16f (&accm)[2], const v16f (&upm)[2], int nf) {
+    const __amdgpu_buffer_rsrc_t ro = mp_rsrc(d.po, d.nrec_o);
+    if (gated && nf >= 2) return;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int soff = __builtin_amdgcn_readfirstlane(hf * 32 * Nout * 2);
+#pragma unroll
+      for (int hv = 0; hv < 2; ++hv) {
+        Vec<T, 8> v;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float t = accm[hf][hv * 8 + c];
+          if (gated) {
+            t = act_mul(t, upm[hf][hv * 8 + c]);
+          } else if (p.fuse == 3) {
+            t = fmaxf(t, 0.f);
+            t = t * t;
+          }
+          v[c] = (T)t;
+        }
+        const int col = (gated ? wn * 64 : wn * 128) + nf * 32 + lh * 16 + hv * 8;
+        const uint32_t vo = col < d.ncols ? orow_off + (uint32_t)((nf * 32 + hv * 8) * 2) : 0x80000000u;
+        const v4i data = __builtin_bit_cast(v4i, v);
+        __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, 0);
+        asm volatile("s_nop 4" ::"v"(data));
+      }
+    }
+  };
+
+  v16f acc[MS][2];  // [streamed step][held fragment]: 256-row form [m-step][n-fragment], wide tile [weight fragment][row fragment]
 #pragma unroll
   for (int mf = 0; mf < MS; ++mf)
 #pragma unroll
@@ -389,11 +452,14 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
 
 #define MP_RD16(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define MP_WR16(addr, src) asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(src) : "memory")
+// (the weight fragment is the MFMA's first operand either way: held nq in the 256-row form, streamed mq in the wide tile)
 #define MP_MFMA(mf, nf, s)                                                                                     \
   if constexpr (std::is_same<T, bf16>::value) {                                                                \
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(nq[nf][s]), "v"(mq[s]));   \
+    if constexpr (WIDE) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(mq[s]), "v"(nq[nf][s])); \
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(nq[nf][s]), "v"(mq[s])); \
   } else {                                                                                                     \
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(nq[nf][s]), "v"(mq[s]));    \
+    if constexpr (WIDE) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(mq[s]), "v"(nq[nf][s])); \
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(nq[nf][s]), "v"(mq[s])); \
   }
 
   v4i nq[2][4];  // [n-fragment][k-step]
@@ -402,14 +468,21 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // BIAS: the weight-side operands of the two n-fragments (lane (i, 0): {hi, mid, lo, 0 ..} of weight row brow(i); lanes (i, 1):
   // zeros) and the activation-side operand of ones, rebuilt at the top of every tile's first K block
   // (only the two non-zero dwords of each operand live across the store block; the rest is rebuilt in front of the MFMA)
-  int bq[2][2] = {{0, 0}, {0, 0}};
+  constexpr int kNFB = WIDE ? 4 : 2;  // weight fragments of a wave
+  float bq[kNFB];  // (the fp32 values live across the store block; the three pieces are made in front of each MFMA)
+#pragma unroll
+  for (int f = 0; f < kNFB; ++f) bq[f] = 0.f;
   const int lh_mask = lh == 0 ? -1 : 0;
-  const uint32_t bias_voff0 = (uint32_t)(wrow_of(wn * 64 + brow) * 4), bias_voff1 = (uint32_t)(wrow_of(wn * 64 + 32 + brow) * 4);
   auto load_bias = [&](const MpTile& d) {
     if constexpr (BIAS) {
       const __amdgpu_buffer_rsrc_t rb = mp_rsrc(d.pbs, d.nrec_bs);
-      const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)bias_voff0, 0, 0));
-      const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)bias_voff1, 0, 0));
+#pragma unroll
+      for (int f = 0; f < kNFB; ++f) {
+        bq[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, wrow_of(wn * kSW + f * 32 + brow) * 4, 0, 0));
+      }
+    }
+  };
+  auto bias_operand = [&](float bv) -> v4i {
       // (always bf16 pieces and the bf16 MFMA, whatever T: bf16 has fp32's exponent range, so hi + mid + lo IS the fp32 value;
       // fp16 pieces of a small bias fall on the subnormal grid and came out an fp16 ulp off in 9 % of the elements)
       auto split = [&](float b) -> v4i {
@@ -421,14 +494,11 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
         return (v4i){(int)((uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, mid) << 16)) & lh_mask,
                      (int)(uint32_t)__builtin_bit_cast(uint16_t, lo) & lh_mask, 0, 0};
       };
-      const v4i s0 = split(b0), s1 = split(b1);
-      bq[0][0] = s0[0];  bq[0][1] = s0[1];  bq[1][0] = s1[0];  bq[1][1] = s1[1];
-      asm volatile("" : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]));
-    }
+      return split(bv);
   };
 #define MP_MFMA_BIAS(mf, nf)                                                                                   \
   {                                                                                                            \
-    const v4i bop_ = {bq[nf][0], bq[nf][1], 0, 0};                                                             \
+    const v4i bop_ = bias_operand(bq[WIDE ? (mf) : (nf)]);                                                     \
     const v4i one_ = {0x3F803F80 & lh_mask, 0x00003F80 & lh_mask, 0, 0};                                       \
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[mf][nf]) : "v"(bop_), "v"(one_)); \
   }
@@ -446,7 +516,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
 #define MP_STEP(mf, STORE, LAST, WR)                                                                           \
   {                                                                                                            \
     if constexpr (STORE) { /* first K block of a tile: the finished tile's rows of this step leave before the step's MFMAs */ \
-      store_frag(prv, acc[mf], (mf));                                                                          \
+      if constexpr (WIDE) store_frag_w(prv, acc[mf], acc[(mf) < 2 ? (mf) + 2 : (mf)], (mf));                   \
+      else store_frag(prv, acc[mf], (mf));                                                                     \
       _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f; \
       asm volatile("" : "+v"(acc[mf][0]), "+v"(acc[mf][1]));                                                   \
       if constexpr (BIAS) { /* the accumulator chain of the new tile starts at its bias */                     \
@@ -474,16 +545,27 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
         MP_RD16(mq[s_], na0 ^ x_, 0);                                                                          \
         /* (all of a's pieces of block + 2 go out here, a whole block ahead of their barrier: with parts 1..3 in the */ \
         /* next block's first two steps the wait at the barrier cost ~2100 cycles per block)                      */ \
-        if (MS == 4 || s_ < 2) dma_piece(dL, kbL, sL, s_ >> 1, s_ & 1);                                        \
+        if (!kA2 || s_ < 2) dma_piece(dL, kbL, sL, kA2 ? 0 : (s_ >> 1), kA2 ? s_ : (s_ & 1));                  \
       } else {                                                                                                 \
         MP_RD16(mq[s_], a0 ^ (uint32_t)(s_ << 5), ((mf) + 1) * 4096);                                          \
         if ((mf) == 0) dma_piece(dE, kbE, sE, 2 + (s_ >> 1), s_ & 1); /* (16-bit weights: the b pieces) */       \
+        if (WIDE && (mf) == 1) dma_piece(dE, kbE, sE, 4 + (s_ >> 1), s_ & 1);                                  \
       }                                                                                                        \
       /* the two waves of a SIMD (w, w + 4) run this stream in lockstep: with the expansion in the same gaps of both, its   */ \
       /* VALU time adds to the block (neither has MFMAs ready for the other's VALU phase). Waves 0..3 expand in step 0,    */ \
       /* waves 4..7 in step 2: each one's VALU phase lies beside the other's bare MFMAs.                                   */ \
-      if (W4 && !(LAST) && MS == 4 && (((mf) == 0 && wave < 4) || ((mf) == 2 && wave >= 4)))                               \
+      if (W4 && !(LAST) && MS == 4 && !WIDE && (((mf) == 0 && wave < 4) || ((mf) == 2 && wave >= 4)))                     \
         expand(raw_c, sraw_c, s_, nbase + (uint32_t)kOffB + pwr);                                              \
+      /* wide tile, two items per thread: waves 0..3 in steps 0 and 1, waves 4..7 in steps 1 and 2 */          \
+      /* (each item's codes of block + 2 are requested into the same registers right behind its last expansion) */ \
+      if (W4 && !(LAST) && WIDE && (mf) == (wave < 4 ? 0 : 1)) {                                               \
+        expand(raw_c, sraw_c, s_, nbase + (uint32_t)kOffB + pwr);                                              \
+        if (s_ == 3) load_raw(d2, kb2, raw_c, sraw_c);                                                         \
+      }                                                                                                        \
+      if (W4 && !(LAST) && WIDE && (mf) == (wave < 4 ? 1 : 2)) {                                               \
+        expand(raw_c2, sraw_c2, s_, nbase + (uint32_t)(kOffB + 256 * 128) + pwr);                              \
+        if (s_ == 3) load_raw2(d2, kb2, raw_c2, sraw_c2);                                                      \
+      }                                                                                                        \
       if (W4 && !(LAST) && MS == 2) expand(raw_c, sraw_c, s_, nbase + (uint32_t)kOffB + pwr);                  \
     }                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
@@ -509,9 +591,15 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       int fo = frag_off_a;                                                                                     \
       asm volatile("" : "+v"(fo));                                                                             \
       a0 = sbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)fo;                                            \
+      if constexpr (WIDE) { /* the streamed fragments are the wave's 128 weight slots */                       \
+        int fb = frag_off_b;                                                                                   \
+        asm volatile("" : "+v"(fb));                                                                           \
+        a0 = sbase + (uint32_t)(kOffB + wn * 128 * 128) + (uint32_t)fb;                                        \
+      }                                                                                                        \
     }                                                                                                          \
     if constexpr (BIAS && (STORE)) load_bias(cur_t);                                                          \
-    if constexpr (NST == 2) load_raw(d2, kb2, raw_n, sraw_n); else load_raw(d3, kb3, raw_nn, sraw_nn);         \
+    if constexpr (WIDE) { /* (see the steps) */ }                                                              \
+    else if constexpr (NST == 2) load_raw(d2, kb2, raw_n, sraw_n); else load_raw(d3, kb3, raw_nn, sraw_nn);    \
     if constexpr (MS == 4) { MP_STEP(0, STORE, false, false) MP_STEP(1, STORE, false, false) MP_STEP(2, STORE, false, true) } \
     else { MP_STEP(0, STORE, false, true) }                                                                    \
     if constexpr (kBarStamps) { /* diagnostic build: where the block's barrier time goes (own data / the other waves) */ \
@@ -532,6 +620,11 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       /* block + 3; the stores of a tile's first block are younger still: the count stays (it then waits for a few of them too) */ \
       constexpr int kYoung = FMT == 0 ? 6 : FMT == 3 ? 5 : 4;                                                  \
       asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : "n"(kYoung) : "memory"); \
+    } else if constexpr (WIDE && W4) {                                                                         \
+      /* (the block's a pieces are older than the 2 x (2 .. 3) code / scale loads this wave issued behind its expansions - waves */ \
+      /* 4..7 right in front of this barrier: those may stay in flight)                                                          */ \
+      constexpr int kYoungW = FMT == 3 ? 6 : 4;                                                                \
+      asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : "n"(kYoungW) : "memory"); \
     } else                                                                                                     \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(mq[0]), "+v"(mq[1]), "+v"(mq[2]), "+v"(mq[3]) : : "memory"); \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
@@ -540,11 +633,14 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
       asm volatile("" : "+v"(foa), "+v"(fob));                                                                 \
       nb0 = nbase + (uint32_t)(kOffB + wn * 64 * 128) + (uint32_t)fob;                                         \
       na0 = nbase + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)foa;                                          \
+      if constexpr (WIDE) { /* held: the wave's 64 activation rows; streamed: its weight slots */              \
+        nb0 = nbase + (uint32_t)(wm * 64 * 128) + (uint32_t)foa;                                               \
+        na0 = nbase + (uint32_t)(kOffB + wn * 128 * 128) + (uint32_t)fob;                                      \
+      }                                                                                                        \
       asm volatile("" : "+v"(nb0), "+v"(na0));                                                                 \
     }                                                                                                          \
     MP_STEP(MS - 1, STORE, true, false)                                                                        \
-    raw_c = raw_n;                                                                                             \
-    sraw_c = sraw_n;                                                                                           \
+    if constexpr (!WIDE) { raw_c = raw_n;  sraw_c = sraw_n; }                                                  \
     if constexpr (NST == 3) { raw_n = raw_nn;  sraw_n = sraw_nn; }                                             \
     ++gblk;                                                                                                    \
     stg = s1;                                                                                                  \
@@ -556,16 +652,22 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // ---- prologue: block 0 of the first unit lands (int4: is expanded), its fragments are read in the last step's order,
   // part 0 of block 1 goes out (int4: the codes of block 1 are requested)
 #pragma unroll
-  for (int part = 0; part < 4; ++part) {
+  for (int part = 0; part < (WIDE ? 6 : 4); ++part) {
     dma_piece(cur_t, 0, 0, part, 0);
     dma_piece(cur_t, 0, 0, part, 1);
   }
   if constexpr (W4) {
     load_raw(cur_t, 0, raw_c, sraw_c);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_c), "+v"(sraw_c));
+    load_raw2(cur_t, 0, raw_c2, sraw_c2);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_c), "+v"(sraw_c), "+v"(raw_c2), "+v"(sraw_c2));
 #pragma unroll
     for (int q = 0; q < 4; ++q) expand(raw_c, sraw_c, q, lds_base + (uint32_t)kOffB + pwr);
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) expand(raw_c2, sraw_c2, q, lds_base + (uint32_t)(kOffB + 256 * 128) + pwr);
+    }
     load_raw(cur_t, 1, raw_c, sraw_c);
+    load_raw2(cur_t, 1, raw_c2, sraw_c2);
     if constexpr (NST == 3) load_raw(cur_t, 2, raw_n, sraw_n);
   }
   if constexpr (NST == 3) {  // (all of block 1 and the a pieces of block 2 go out before anything waits: nkb >= 3)
@@ -578,8 +680,11 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // is simply for everything: once per workgroup)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   {
-    const uint32_t b0 = lds_base + (uint32_t)(kOffB + wn * 64 * 128) + (uint32_t)frag_off_b;
-    const uint32_t p0 = lds_base + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)frag_off_a;
+    // (b0: the held fragments, p0: the first streamed one)
+    const uint32_t b0 = WIDE ? lds_base + (uint32_t)(wm * 64 * 128) + (uint32_t)frag_off_a
+                             : lds_base + (uint32_t)(kOffB + wn * 64 * 128) + (uint32_t)frag_off_b;
+    const uint32_t p0 = WIDE ? lds_base + (uint32_t)(kOffB + wn * 128 * 128) + (uint32_t)frag_off_b
+                             : lds_base + (uint32_t)(wm * (MS * 32) * 128) + (uint32_t)frag_off_a;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const uint32_t x = (uint32_t)(s << 5);
@@ -611,7 +716,10 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[MS - 1][0]), "+v"(acc[MS - 1][1]));
 #pragma unroll
-  for (int mf = 0; mf < MS; ++mf) store_frag(prv, acc[mf], mf);
+  for (int mf = 0; mf < MS; ++mf) {
+    if constexpr (WIDE) store_frag_w(prv, acc[mf], acc[mf < 2 ? mf + 2 : mf], mf);
+    else store_frag(prv, acc[mf], mf);
+  }
   if (stamps_ != nullptr && lane == 0) {
     const uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (wave == 0) {
@@ -636,8 +744,10 @@ constexpr int g_mp_prio47 = 0;
 #endif
 #ifdef SGLK_PROBES
 static int g_mp_own_tails = 0;
+static int g_mp_wide = 1;
 #else
 constexpr int g_mp_own_tails = 0;
+constexpr int g_mp_wide = 1;
 #endif
 constexpr int kMinAvgRows128 = 96;  // ... and with 128-row blocks
 #ifdef SGLK_PROBES
@@ -656,7 +766,18 @@ static int launch_persist(hipStream_t st, const MpParams& p) {
     return rc;
   if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 2, BIAS>), kLds2, &attr_done2, "moe_persist"))
     return rc;
-  if (p.blocks128) {  // 96 .. 191 rows per expert on average: 128-row blocks
+  if (p.blocks128) {  // 96 .. 191 rows per expert on average: 128-row blocks - as 128 x 512 tiles (WIDE); the diagnostic build
+                      // can fall back to the 128 x 256 tiles of MS = 2 for A / B timing
+    // (4-bit weights with a bias: the wide form needs 2 .. 6 registers more than a lane has - those stay on the MS = 2 form)
+    if constexpr (!(BIAS && W4 != 0)) if (g_mp_wide && p.blocks128 == 2) {
+      static unsigned long long attr_donew = 0;
+      constexpr int kLdsW = 2 * (128 * kBKB + 512 * kBKB);  // all 160 KiB
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<T, W4, 4, BIAS, true>), kLdsW, &attr_donew,
+                                   "moe_persist"))
+        return rc;
+      moe_persist_kernel<T, W4, 4, BIAS, true><<<(unsigned)num_cus(), 512, kLdsW, st>>>(p);
+      return 0;
+    }
     moe_persist_kernel<T, W4, 2, BIAS><<<(unsigned)num_cus(), 512, kLds2, st>>>(p);
     return 0;
   }
@@ -694,7 +815,10 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
       (w4 == 2 && (int64_t)N * (K / 32) >= (1ll << 31)))
     return 0;
   MpParams p;
-  p.blocks128 = blocks128 ? 1 : 0;
+  // 128-row blocks: as 128 x 512 tiles when that still gives every CU most of a tile (Mixtral gate / up at 512 tokens: 448 tiles;
+  // its down projection - 8 column blocks x 8 row blocks = 64 tiles of 224 K blocks - stays on the 128 x 256 tiles: 128 of them)
+  const int64_t wide_tiles = (total_m / 128) * ((Nout + (gated ? 255 : 511)) / (gated ? 256 : 512));
+  p.blocks128 = !blocks128 ? 0 : wide_tiles >= 192 ? 2 : 1;
   p.stamps = g_mp_stamps;
   p.prio47 = g_mp_prio47;
   p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.bias = bias;  p.gshift = group_shift;  p.rows = rows;
@@ -726,4 +850,5 @@ extern "C" SGLK_API void sglk_debug_set_moe_clock_stamps(uint32_t* device_buf) {
 extern "C" SGLK_API void sglk_debug_set_moe_prio(int prio) { sglk::g_mp_prio47 = prio; }
 extern "C" SGLK_API void sglk_debug_set_moe_persist_min_rows(int rows) { sglk::g_mp_min_avg_rows = rows; }
 extern "C" SGLK_API void sglk_debug_set_moe_persist_own_tails(int on) { sglk::g_mp_own_tails = on; }
+extern "C" SGLK_API void sglk_debug_set_moe_persist_wide(int on) { sglk::g_mp_wide = on; }
 #endif
