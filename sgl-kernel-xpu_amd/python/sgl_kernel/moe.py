@@ -9,8 +9,9 @@ apply_shuffle_mul_sum (:655-868); the grow-only scratch buffers keyed by (name, 
 `rows_per_expert` (the tensor the reference calls expert_offsets) holds COUNTS.
 
 This build's own structure: one `_Plan` derives every size and route from the arguments, `_Scratch` owns the
-buffers, the activation routes are a table. 4-bit weights (int4 / mxfp4 W4A16) take GEMM -> activation kernel ->
-GEMM; 16-bit weights take the grouped GEMM's fused activation epilogue (gate/up product or relu2).
+buffers, the activation routes are a table. 4-bit (int4 / mxfp4 W4A16) and 16-bit weights alike take GEMM 1 with the
+gate / up product (silu, gelu, the DeepSeek-V4 clamped swiglu) or relu2 in its epilogue, then GEMM 2; only the gpt-oss
+swiglu (gate / up interleaved in w1's rows) runs the reference's three steps GEMM -> swiglu_gpt_oss_sigmoid_alpha -> GEMM.
 """
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple

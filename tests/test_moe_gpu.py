@@ -560,10 +560,37 @@ def test_fused_experts_gpt_oss_swiglu(sglk, dev, T, topk, E, H, I, bias):
     ref = omoe.fused_experts_16bit(x, w1, w2, tw, ids, b1, b2, "silu", 2.5, gemm1_alpha=1.702, gemm1_limit=7.0)
     plain = omoe.fused_experts_16bit(x, w1, w2, tw, ids, b1, b2, "silu", 2.5)
     assert (ref.float() - plain.float()).abs().max() > 0.05  # (the case tells the gpt-oss form from the split-halves silu)
-    # reference tolerance (:165: rtol 3e-2, atol 1e-2) for outputs of its magnitude (<= 1); here they reach +-10 at I = 4096 and
+    # (a STRESS case next to test_fused_experts_gpt_oss_swiglu_reference_inputs, which runs the reference's inputs at the
+    # reference's tolerance) rtol 3e-2, atol 1e-2 for outputs of magnitude <= 1; here they reach +-10 at I = 4096 and
     # an ulp of the bf16 intermediate [rows, 2I] (rounded once on both sides, summed in a different order) moves an output by
     # ~0.4 % of that range, so the absolute part scales with the range
     torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=3e-2, atol=1e-2 * max(1.0, ref.float().abs().max().item()))
+
+
+@pytest.mark.parametrize("T,topk,E,H,I", [(1, 1, 8, 1024, 512), (33, 2, 8, 1024, 1024), (64, 6, 64, 1024, 512),
+                                          (222, 2, 8, 4096, 512), (222, 6, 64, 1024, 4096)])
+@pytest.mark.parametrize("bias", [None, "bfloat16", "float32"])
+def test_fused_experts_gpt_oss_swiglu_reference_inputs(sglk, dev, T, topk, E, H, I, bias):
+    """the same rows of reference tests/test_moe_gemm.py:141-160 with the reference's OWN input distribution (:23-24, :191-205:
+    activations and weights N(0, 0.01), biases N(0, 0.005), scores softmax of N(0, 1)) and its OWN tolerance (:190, :237:
+    rtol 1e-4, atol 1e-3) - the stress case above scales the inputs up until both clamps take part and needs a wider one."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(7 * T + H + I + topk + E)
+    x = (torch.randn(T, H, generator=g) * 0.01).to(dt)
+    w1 = (torch.randn(E, 2 * I, H, generator=g) * 0.01).to(dt)
+    w2 = (torch.randn(E, H, I, generator=g) * 0.01).to(dt)
+    b1 = b2 = None
+    if bias:
+        bdt = torch.bfloat16 if bias == "bfloat16" else torch.float32
+        b1 = (torch.randn(E, 2 * I, generator=g) * 0.005).to(bdt)
+        b2 = (torch.randn(E, H, generator=g) * 0.005).to(bdt)
+    score = torch.softmax(torch.randn(T, E, generator=g).to(dt).float(), dim=-1)
+    tw, ids = torch.topk(score, topk)
+    d = lambda t: t.to(dev) if t is not None else None
+    out = sglk.fused_experts(d(x), d(w1), d(w2), d(tw), d(ids), d(b1), d(b2), activation="silu", routed_scaling_factor=2.5,
+                             gemm1_alpha=1.702, gemm1_limit=7.0)
+    ref = omoe.fused_experts_16bit(x, w1, w2, tw, ids, b1, b2, "silu", 2.5, gemm1_alpha=1.702, gemm1_limit=7.0)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("explicit_zero", [False, True])
