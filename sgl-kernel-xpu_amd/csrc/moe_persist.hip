@@ -142,7 +142,9 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // The two waves of a SIMD (w, w + 4) share its matrix pipe and issue ports; at equal priority the older one wins every
   // arbitration: stamps at the blocks' barriers showed waves 0..3 waiting ~1250 of a block's ~4100 cycles for waves 4..7.
   // A static priority for waves 4..7 swaps the roles exactly (they then wait 1350 cycles for waves 0..3) and leaves the
-  // block time where it was; kept as a diagnostic knob, off by default.
+  // block time where it was; kept as a diagnostic knob, off by default. (Round 4: the halves taking turns at priority 1 inside
+  // every K block - waves 4..7 in steps 0, 1, waves 0..3 in steps 2, 3 - changed nothing either: 1115 / 513 us against 1128 / 508
+  // for the Mixtral gate / up and down projections at 512 rows per expert.)
 #ifdef SGLK_PROBES
   uint32_t* const stamps_ = p.stamps;
   const int prio47_ = p.prio47;

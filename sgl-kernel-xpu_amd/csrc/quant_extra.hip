@@ -73,15 +73,26 @@ __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(const T* __res
 }
 
 // ---- per tensor --------------------------------------------------------------------------------------------------
+// Both passes: a workgroup walks 16-KiB chunks (1024 vectors of 8 elements), four 16-byte loads in flight per lane. The second
+// pass walks the chunks in REVERSE order: what the first pass read last is what the caches still hold (a 32 MB activation
+// fits the Infinity Cache whole, the XCDs' L2s hold its tail).
 template <typename T>
 __global__ __launch_bounds__(256) void per_tensor_absmax_kernel(const T* __restrict__ x, float* __restrict__ s, int64_t n) {
-  const int64_t nvec = n / 8;
+  const int64_t nvec = n / 8, nchunk = (nvec + 1023) / 1024;
   float mx = 0.f;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-    const Vec<T, 8> t = load_vec<T, 8>(x + v * 8);
+  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    Vec<T, 8> t[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf((float)t[e]));
+    for (int j = 0; j < 4; ++j) {
+      const int64_t v = c * 1024 + j * 256 + threadIdx.x;
+      t[j] = load_vec<T, 8>(x + (v < nvec ? v : nvec - 1) * 8);  // (past the end: the last vector again - it counts anyway)
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf((float)t[j][e]));
   }
+  if (nvec == 0) mx = 0.f;
   for (int64_t i = nvec * 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     mx = fmaxf(mx, fabsf((float)x[i]));
   mx = wave_max(mx);
@@ -97,18 +108,28 @@ __global__ __launch_bounds__(256) void per_tensor_absmax_kernel(const T* __restr
 
 template <typename T>
 __global__ __launch_bounds__(256) void per_tensor_quant_fp8_kernel(const T* __restrict__ x, uint8_t* __restrict__ q,
-                                                                   const float* __restrict__ s, int64_t n) {
+                                                                   const float* __restrict__ s, int64_t n, int reverse) {
   const float inv = 1.0f / (s[0] + 1e-8f);
-  const int64_t nvec = n / 8;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-    const Vec<T, 8> t = load_vec<T, 8>(x + v * 8);
-    float f[8];
+  const int64_t nvec = n / 8, nchunk = (nvec + 1023) / 1024;
+  for (int64_t c0 = blockIdx.x; c0 < nchunk; c0 += gridDim.x) {
+    const int64_t c = reverse ? nchunk - 1 - c0 : c0;
+    Vec<T, 8> t[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = fmaxf(-kFp8Max, fminf((float)t[e] * inv, kFp8Max));
-    uint2 o;
-    o.x = pack4_e4m3(f[0], f[1], f[2], f[3]);
-    o.y = pack4_e4m3(f[4], f[5], f[6], f[7]);
-    *reinterpret_cast<uint2*>(q + v * 8) = o;
+    for (int j = 0; j < 4; ++j) {
+      const int64_t v = c * 1024 + j * 256 + threadIdx.x;
+      t[j] = load_vec<T, 8>(x + (v < nvec ? v : nvec - 1) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t v = c * 1024 + j * 256 + threadIdx.x;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fmaxf(-kFp8Max, fminf((float)t[j][e] * inv, kFp8Max));
+      uint2 o;
+      o.x = pack4_e4m3(f[0], f[1], f[2], f[3]);
+      o.y = pack4_e4m3(f[4], f[5], f[6], f[7]);
+      if (v < nvec) *reinterpret_cast<uint2*>(q + v * 8) = o;
+    }
   }
   for (int64_t i = nvec * 8 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float f = fmaxf(-kFp8Max, fminf((float)x[i] * inv, kFp8Max));
@@ -167,12 +188,14 @@ extern "C" int sglk_per_tensor_quant_fp8(sglk_stream_t stream, void* output_q, f
                "sgl_per_tensor_quant_fp8: input must be 16-byte and output 8-byte aligned");
   if (numel == 0) return SGLK_OK;
   hipStream_t st = (hipStream_t)stream;
-  int64_t blocks = cdiv(cdiv(numel, 8), 256);
+  int64_t blocks = cdiv(cdiv(numel, 8), 1024);
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
   SGLK_DISPATCH_FLOAT(dtype, T, {
     if (!is_static) per_tensor_absmax_kernel<T><<<(unsigned)blocks, 256, 0, st>>>((const T*)input, output_s, numel);
-    per_tensor_quant_fp8_kernel<T><<<(unsigned)blocks, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, numel);
+    per_tensor_quant_fp8_kernel<T><<<(unsigned)blocks, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, numel,
+                                                                     is_static ? 0 : 1);
   });
   return check_launch("sgl_per_tensor_quant_fp8");
 }
