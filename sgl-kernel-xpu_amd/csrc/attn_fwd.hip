@@ -949,8 +949,13 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
 // 64 KiB of K / V per wave in flight is still far more than the latency needs). fp8: K bytes go to registers as they are
 // and are widened right before their MFMAs (v_cvt_scalef32_pk_*), V is widened on its way into the LDS image; the K
 // descale is folded into the softmax scale, the V descale into the final normalisation (as the general kernel does).
-template <typename T, int D, int KV8>
-__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_decode_kernel(AttnParams p, const T* __restrict__ q,
+// NW waves per workgroup, wave w on the tiles w, w + NW, ..: four. Eight (two chains per SIMD without more KV splits) were
+// tried for the half-size tiles of d = 64 and of an fp8 cache, which sit at 0.46 of HBM: 36.1 against 34.5 us at d = 64, 37.6
+// against 35.9 with an fp8 cache, 55.2 against 53.0 at d = 128 (round 4, interleaved runs of the diagnostic build) - the
+// stream itself runs at 5.8 - 6.5 TB/s, what the short legs feel are ~12 us of fixed cost (first-tile latency chain, the
+// wave merge, the partial results and the reduce launch).
+template <typename T, int D, int KV8, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void attn_decode_kernel(AttnParams p, const T* __restrict__ q,
                                                              const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                              const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
                                                              const int32_t* __restrict__ page_table) {
@@ -1021,7 +1026,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_decode_kernel(At
     t_hi = e < t_hi ? e : t_hi;
   }
   const int n_tiles = t_hi - t_lo;
-  const int nw = n_tiles > wave ? (n_tiles - wave + kWaves - 1) / kWaves : 0;  // tiles of this wave: t_lo + wave + 4 j
+  const int nw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // tiles of this wave: t_lo + wave + NW j
 
   const int pig = (0x2130 >> (4 * g4)) & 3;
   const int tau = (l15 & 3) | (((l15 >> 2) & 1) << 3) | (((l15 >> 3) & 1) << 2);
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_decode_kernel(At
   const int64_t vbase_row = (p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
                                           : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1));
   const int last_key = seqlen_k - 1;
-  auto tile_of = [&](int j) { return t_lo + wave + kWaves * (j < nw ? j : nw - 1); };  // (past the end: the last tile again)
+  auto tile_of = [&](int j) { return t_lo + wave + NW * (j < nw ? j : nw - 1); };  // (past the end: the last tile again)
   auto fetch_page = [&](int t) -> int {
     int pos = t * kTile;
     pos = pos < last_key ? pos : last_key;
@@ -1136,7 +1141,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_decode_kernel(At
   const float log2e = 1.4426950408889634f;
   const float kd = (KV8 != 0 && p.k_descale) ? p.k_descale[0] : 1.f, vd = (KV8 != 0 && p.v_descale) ? p.v_descale[0] : 1.f;
   const float scale = p.scale * kd, sc2 = scale * log2e;  // (the K descale multiplies every logit)
-  __shared__ float xch_all[kWaves * 16];
+  __shared__ float xch_all[NW * 16];
   float* xch = xch_all + wave * 16;
 
   // Tile j of this wave: K(j) sits in kr (loaded two tiles ago), V(j) in vr (loaded one tile ago). Once V(j) is in its LDS
@@ -1266,18 +1271,18 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_decode_kernel(At
   // ---- merge the four waves' states into wave 0 (through the V images, everybody being done with them)
   __syncthreads();
   float* mo = reinterpret_cast<float*>(smem);            // [wave][nt][lane] v4f
-  float* mm = mo + kWaves * NT * 64 * 4;                 // [wave][lane] m, then [wave][lane] l
+  float* mm = mo + NW * NT * 64 * 4;                 // [wave][lane] m, then [wave][lane] l
   if (wave != 0) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<v4f*>(mo + ((wave * NT + nt) * 64 + lane) * 4) = o[nt];
     mm[wave * 64 + lane] = m_run;
-    mm[(kWaves + wave) * 64 + lane] = l_run;
+    mm[(NW + wave) * 64 + lane] = l_run;
   }
   __syncthreads();
   if (wave != 0) return;
-#pragma unroll
-  for (int w = 1; w < kWaves; ++w) {
-    const float m_w = mm[w * 64 + lane], l_w = mm[(kWaves + w) * 64 + lane];
+#pragma nounroll
+  for (int w = 1; w < NW; ++w) {
+    const float m_w = mm[w * 64 + lane], l_w = mm[(NW + w) * 64 + lane];
     const float m_new = fmaxf(m_run, m_w);
     const float m_use = m_new == -INFINITY ? 0.f : m_new;
     const float fa = __builtin_amdgcn_exp2f((m_run - m_use) * log2e), fb = __builtin_amdgcn_exp2f((m_w - m_use) * log2e);
@@ -1334,6 +1339,9 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_decode_kernel(At
 }
 
 // merge split-KV partials: out = sum_s exp(lse_s - L) O_s, L = log(sum_s exp(lse_s) [+ exp(sink)])
+// One workgroup per (head, token). The launch sits behind 30 - 50 us decode kernels, so its own latency counts: the partial
+// results of up to eight splits are requested TOGETHER with the log-sum-exps (one round trip instead of three dependent ones:
+// maximum, denominator, weighted sum each re-read the log-sum-exps before) and the arithmetic runs on registers in split order.
 template <typename T>
 __global__ __launch_bounds__(128) void attn_reduce_kernel(T* __restrict__ out, float* __restrict__ lse_out,
                                                           const float* __restrict__ part_o,
@@ -1342,13 +1350,55 @@ __global__ __launch_bounds__(128) void attn_reduce_kernel(T* __restrict__ out, f
                                                           int Hq, int D, int64_t o_s0, int64_t o_s1) {
   const int head = blockIdx.x;
   const int64_t tok = blockIdx.y;
-  float mx = -INFINITY;
-  for (int s = 0; s < splits; ++s) mx = fmaxf(mx, part_lse[((int64_t)s * Hq + head) * total_q + tok]);
+  const float* pl = part_lse + (int64_t)head * total_q + tok;
+  const int64_t ls = (int64_t)Hq * total_q;
+  const float* po = part_o + (tok * Hq + head) * D;
+  const int64_t os = (int64_t)total_q * Hq * D;
   const float sk = sinks ? sinks[head] : -INFINITY;
+  if (splits <= 8 && D <= 256) {
+    const int d0 = threadIdx.x, d1 = threadIdx.x + 128;
+    float l[8], v0[8], v1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int sc = s < splits ? s : 0;  // (past the last split: split 0 again, weight 0)
+      l[s] = pl[sc * ls];
+      v0[s] = d0 < D ? po[sc * os + d0] : 0.f;
+      v1[s] = d1 < D ? po[sc * os + d1] : 0.f;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < splits) mx = fmaxf(mx, l[s]);
+    const float mref = fmaxf(mx, sk);
+    float denom = 0.f;
+    if (mref != -INFINITY) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < splits) denom += expf(l[s] - mref);
+      if (sinks) denom += expf(sk - mref);
+    }
+    const float inv = denom > 0.f ? 1.0f / denom : 0.f;
+    float a0 = 0.f, a1 = 0.f;
+    if (mx != -INFINITY) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < splits && l[s] != -INFINITY) {
+          const float w = expf(l[s] - mref);
+          a0 += w * v0[s];
+          a1 += w * v1[s];
+        }
+    }
+    if (d0 < D) out[tok * o_s0 + (int64_t)head * o_s1 + d0] = (T)(a0 * inv);
+    if (d1 < D) out[tok * o_s0 + (int64_t)head * o_s1 + d1] = (T)(a1 * inv);
+    if (threadIdx.x == 0) lse_out[(int64_t)head * total_q + tok] = denom > 0.f ? mref + logf(denom) : -INFINITY;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int s = 0; s < splits; ++s) mx = fmaxf(mx, pl[s * ls]);
   const float mref = fmaxf(mx, sk);
   float denom = 0.f;
   if (mref != -INFINITY) {
-    for (int s = 0; s < splits; ++s) denom += expf(part_lse[((int64_t)s * Hq + head) * total_q + tok] - mref);
+    for (int s = 0; s < splits; ++s) denom += expf(pl[s * ls] - mref);
     if (sinks) denom += expf(sk - mref);
   }
   const float inv = denom > 0.f ? 1.0f / denom : 0.f;
@@ -1356,8 +1406,8 @@ __global__ __launch_bounds__(128) void attn_reduce_kernel(T* __restrict__ out, f
     float acc = 0.f;
     if (mx != -INFINITY) {
       for (int s = 0; s < splits; ++s) {
-        const float l = part_lse[((int64_t)s * Hq + head) * total_q + tok];
-        if (l != -INFINITY) acc += expf(l - mref) * part_o[(((int64_t)s * total_q + tok) * Hq + head) * D + d];
+        const float l = pl[s * ls];
+        if (l != -INFINITY) acc += expf(l - mref) * po[s * os + d];
       }
     }
     out[tok * o_s0 + (int64_t)head * o_s1 + d] = (T)(acc * inv);
@@ -1396,14 +1446,14 @@ static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, co
   return check_launch("fwd(prefill)");
 }
 
-template <typename T, int D, int KV8>
-static int launch_decode(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
-                         const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch) {
-  constexpr int lds = kWaves * 2 * ((D + 127) / 128) * kTile * 256;  // 64 KiB (d = 256: 128 KiB)
+template <typename T, int D, int KV8, int NW>
+static int launch_decode_nw(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
+                            const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch) {
+  constexpr int lds = NW * 2 * ((D + 127) / 128) * kTile * 256;  // four waves: 64 KiB (d = 256: 128 KiB); eight: 128 KiB
   static unsigned long long attr_done = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_decode_kernel<T, D, KV8>), lds, &attr_done, "fwd")) return rc;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_decode_kernel<T, D, KV8, NW>), lds, &attr_done, "fwd")) return rc;
   dim3 grid((unsigned)(p.Hk * p.splits), (unsigned)batch);
-  attn_decode_kernel<T, D, KV8><<<grid, 256, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  attn_decode_kernel<T, D, KV8, NW><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   if (int rc = check_launch("fwd(decode)")) return rc;
   if (p.splits > 1) {
     attn_reduce_kernel<T><<<dim3(p.Hq, p.total_q), 128, 0, st>>>((T*)p.out, p.lse, p.part_o, p.part_lse, p.sinks,
@@ -1411,6 +1461,23 @@ static int launch_decode(hipStream_t st, const AttnParams& p, const void* q, con
     return check_launch("fwd(reduce)");
   }
   return SGLK_OK;
+}
+
+#ifdef SGLK_PROBES
+static int g_attn_decode_waves = 0;  // 0: the policy below; 4 / 8: forced (sglk_debug_set_attn_decode_waves)
+#else
+constexpr int g_attn_decode_waves = 0;
+#endif
+
+template <typename T, int D, int KV8>
+static int launch_decode(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
+                         const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch) {
+  // eight waves where a tile is small (d = 64, fp8 cache at d <= 128); d = 256 needs the whole register file with four
+  if constexpr (D <= 128) {
+    const bool eight = g_attn_decode_waves == 8;  // (diagnostic build only: measured no faster, see the kernel comment)
+    if (eight) return launch_decode_nw<T, D, KV8, 8>(st, p, q, k, v, cu_q, seq_k, table, batch);
+  }
+  return launch_decode_nw<T, D, KV8, 4>(st, p, q, k, v, cu_q, seq_k, table, batch);
 }
 
 template <typename T>
@@ -1463,6 +1530,10 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
 // kv head: the four waves of a workgroup work on different tiles) want one workgroup per CU - measured at bs 16 x 8 kv
 // heads x 4096 keys: 1 / 2 / 4 / 8 splits 53.8 / 53.5 / 55.5 / 60.3 us; otherwise ~2 workgroups per CU. At least 8 tiles
 // (256 tokens) per split. Prefill-sized problems never split.
+#ifdef SGLK_PROBES
+extern "C" SGLK_API void sglk_debug_set_attn_decode_waves(int w) { sglk::g_attn_decode_waves = w; }
+#endif
+
 extern "C" int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
                                          int64_t max_seqlen_k) {
   const int64_t wgs = batch * num_heads_k * ((max_rows_per_kv_head + 63) / 64);

@@ -1564,7 +1564,9 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
 // grid = (N / (16 * 4 / KS), ceil(M / (16 MF))); operands swapped as above: a lane owns 4 consecutive n of one m.
 // MODE_FP8_ROWCOL / MODE_INT8_ROWCOL (fp8_scaled_mm / int8_scaled_mm): the same stream, the MFMAs chain into the
 // accumulator and the epilogue applies sa[m] * sb[n] (+ bias) in the tile kernel's rounding order.
-template <typename OutT, int MODE, int MF, int KS, bool HW_SCALE>  // KS waves split the K blocks of one 16-row n-tile
+// LA (one m-tile only): stage the activations in LDS as the MF >= 2 forms do. With 8 .. 16 rows every wave pulls 2 KB of
+// activations per K block through the L1 next to its 2 KB of weights (M = 16: 18.4 us against 13.4 at one row).
+template <typename OutT, int MODE, int MF, int KS, bool HW_SCALE, bool LA = false>  // KS waves split the K blocks of one 16-row n-tile
 __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
@@ -1576,7 +1578,7 @@ __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
   // of being fetched by each wave in MFMA layout (at MF = 4 that was 128 B of activations per lane and block against 32 B
   // of weights): global -> registers two steps ahead -> LDS one step ahead, two buffers, an LDS-only barrier per step.
   // A wave without weight rows (n0 >= N) runs along for the staging and the barriers.
-  constexpr bool LDSA = MF >= 2;
+  constexpr bool LDSA = MF >= 2 || LA;
   constexpr int kTile = 16 * MF * 128;                    // one K block of activations
   constexpr int kStage = LDSA ? 2 * KS * kTile : 0;       // two buffers of KS blocks
   constexpr int kRed = KS > 1 ? 4 * MF * 256 * 4 : 0;     // partial sums (after the loop: shares the staging memory)
@@ -1630,14 +1632,14 @@ __global__ __launch_bounds__(256) void gemm_8bit_skinny_kernel(
     float sv[2][MF], sbq[2];
     // LDSA staging: 16-byte chunk cid = tid + 256 i of the [16 MF rows][KS blocks][8 chunks] step (a row's KS * 128 bytes are
     // contiguous in global memory): block tile kblk, row, chunk at (chunk ^ (row & 7))
-    constexpr int AL = LDSA ? MF * KS / 2 : 1;
+    constexpr int AL = LDSA ? (MF * KS >= 2 ? MF * KS / 2 : 1) : 1;  // (MF = KS = 1: 128 chunks, the upper half of the threads repeat them)
     v4i areg[AL];
     const uint8_t* ag[AL];
     int aoff[AL], akb[AL];
     if constexpr (LDSA) {
 #pragma unroll
       for (int i = 0; i < AL; ++i) {
-        const int cid = threadIdx.x + 256 * i, row = cid / (8 * KS), c = cid % (8 * KS), kblk = c >> 3, ch = c & 7;
+        const int cid = (threadIdx.x + 256 * i) % (128 * MF * KS), row = cid / (8 * KS), c = cid % (8 * KS), kblk = c >> 3, ch = c & 7;
         int m = m0 + row;
         m = m < M ? m : M - 1;
         ag[i] = a + (int64_t)m * lda + ch * 16;
@@ -1803,6 +1805,11 @@ constexpr uint32_t* g_gemm_stamps = nullptr;
 // which workgroups of gemm_fp8bw_x32_kernel run their half tile first (see the kernel); the diagnostic build can change it
 // and can make the workgroups leave clock stamps (sglk_debug_set_gemm_stamps)
 #ifdef SGLK_PROBES
+static int g_skinny_la_rows = 4;
+#else
+constexpr int g_skinny_la_rows = 4;
+#endif
+#ifdef SGLK_PROBES
 static int g_gemm_stagger = 0;
 static uint32_t* g_clock_stamps = nullptr;
 #else
@@ -1839,17 +1846,18 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
     // 256 - 134 us there, 51 us here; from ~96 units on the tile kernel wins)
     const bool few = M <= 128 || (M <= 512 && cdiv(M, 128) * cdiv(N, 256) <= 80);
     if ((few && g_gemm_variant == 4) || g_gemm_variant == 5 || g_gemm_variant == 7) {
-#define SGLK_GO_SKINNY(MF, KS)                                                                               \
+#define SGLK_GO_SKINNY_(MF, KS, LA)                                                                          \
   {                                                                                                          \
     const dim3 sg((unsigned)cdiv(N, 16 * (4 / KS)), (unsigned)cdiv(M, 16 * MF));                             \
     SGLK_HW(hw_scale,                                                                                        \
-      (gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, true><<<sg, 256, 0, st>>>(                                \
+      (gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, true, LA><<<sg, 256, 0, st>>>(                            \
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
           lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn)),                                                       \
-      (gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, false><<<sg, 256, 0, st>>>(                               \
+      (gemm_8bit_skinny_kernel<OutT, MODE, MF, KS, false, LA><<<sg, 256, 0, st>>>(                           \
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, \
           lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn)))                                                       \
   }
+#define SGLK_GO_SKINNY(MF, KS) SGLK_GO_SKINNY_(MF, KS, false)
       // K split over the waves of a workgroup until the launch has ~200 workgroups (at N = 14336 the split measured
       // slower: 18 -> 22 us at M = 1; at N = 4096, K = 14336 the unsplit launch has 64 workgroups: 44 us)
       const bool mf8 = M > 64 && cdiv(N, 16) >= 768 && g_gemm_variant != 5;  // 128 rows per workgroup: weights read once
@@ -1859,12 +1867,15 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   {                                                                                                          \
     if (ks == 1) SGLK_GO_SKINNY(MF, 1) else if (ks == 2) SGLK_GO_SKINNY(MF, 2) else SGLK_GO_SKINNY(MF, 4)    \
   }
-      if (M <= 16) SGLK_GO_SKINNY_KS(1)
+      if (M <= 16 && M >= g_skinny_la_rows) {  // (4 .. 16 rows: the activations through LDS - M = 4 17.3 -> 16.0 us, 8 18.1 -> 16.1, 16 20.7 -> 16.2; 2 rows: no difference)
+        if (ks == 1) SGLK_GO_SKINNY_(1, 1, true) else if (ks == 2) SGLK_GO_SKINNY_(1, 2, true) else SGLK_GO_SKINNY_(1, 4, true)
+      } else if (M <= 16) SGLK_GO_SKINNY_KS(1)
       else if (M <= 32) SGLK_GO_SKINNY_KS(2)
       else if (!mf8) SGLK_GO_SKINNY_KS(4)
       else SGLK_GO_SKINNY(8, 1)
 #undef SGLK_GO_SKINNY_KS
 #undef SGLK_GO_SKINNY
+#undef SGLK_GO_SKINNY_
       return check_launch("gemm_8bit(skinny)");
     }
   }
@@ -2024,6 +2035,7 @@ extern "C" SGLK_API void sglk_debug_set_fp8_mfma_form(int hw_scale) { g_fp8_hw_s
 extern "C" SGLK_API void sglk_debug_set_gemm_variant(int v) { sglk::g_gemm_variant = v; }
 extern "C" SGLK_API void sglk_debug_set_gemm_stamps(uint32_t* p) { sglk::g_gemm_stamps = p; sglk::g_clock_stamps = p; }
 extern "C" SGLK_API void sglk_debug_set_gemm_stagger(int s) { sglk::g_gemm_stagger = s; }
+extern "C" SGLK_API void sglk_debug_set_skinny_la_rows(int r) { sglk::g_skinny_la_rows = r; }
 #else
 constexpr int g_fp8_hw_scale = 1;
 #endif

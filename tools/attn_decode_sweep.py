@@ -24,6 +24,10 @@ def timeit(f, warm=30, it=100):
         st.record(); g.replay(); en.record(); torch.cuda.synchronize()
         ts.append(st.elapsed_time(en) / it)
     return sorted(ts)[1]
+if os.environ.get("ATTN_WAVES"):  # diagnostic build only: LD_PRELOAD=sgl-kernel-xpu_amd/build/libsglk_probes.so ATTN_WAVES=4|8
+    import ctypes
+    ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
+                ).sglk_debug_set_attn_decode_waves(int(os.environ["ATTN_WAVES"]))
 cases = [(int(a.split(":")[0]), a.split(":")[1]) for a in sys.argv[1:]] or [(128, "bf16"), (64, "bf16"), (256, "bf16"), (128, "fp8")]
 for d, kv in cases:
     n_pages = bs * seq // page
@@ -34,6 +38,6 @@ for d, kv in cases:
     qd = torch.randn(bs, 1, hq, d, device=dev, dtype=torch.bfloat16)
     kw = dict(k_descale=torch.ones(1, device=dev), v_descale=torch.ones(1, device=dev)) if kv == "fp8" else {}
     pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, -1)
-    for splits in (0, 1, 2, 3, 4, 6, 8, 16):
+    for splits in [int(x) for x in os.environ.get("SPLITS", "0,1,2,3,4,6,8,16").split(",")]:
         ms = timeit(lambda: flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, page_table=pt, num_splits=splits, **kw))
         print(f"d={d} {kv}: num_splits={splits:2d}: {ms:.4f} ms  {(kc.numel()+vc.numel())*kc.element_size()/ms/1e6:.0f} GB/s")

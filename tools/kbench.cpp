@@ -22,6 +22,7 @@ extern "C" void sglk_debug_set_mla_variant(int);
 extern "C" int sglk_debug_get_mla_stamps(unsigned long long*, int);
 extern "C" void sglk_debug_set_gemm_stamps(uint32_t*);
 extern "C" void sglk_debug_set_gemm_stagger(int);
+extern "C" void sglk_debug_set_skinny_la_rows(int);
 extern "C" void sglk_debug_set_w4a16_probe(int probe, int force_mt);
 
 #define HIP_CHECK(x)                                                                 \
@@ -408,6 +409,7 @@ int main(int argc, char** argv) {
       const int var = ai < argc ? atoi(argv[ai]) : 1;
       sglk_debug_set_gemm_variant(var);
       if (getenv("GEMM_STAGGER")) sglk_debug_set_gemm_stagger(atoi(getenv("GEMM_STAGGER")));
+      if (getenv("GEMM_LA_ROWS")) sglk_debug_set_skinny_la_rows(atoi(getenv("GEMM_LA_ROWS")));
       std::vector<float> all;
       auto run = [&] {
         int rc = sglk_fp8_blockwise_scaled_mm(0, out, a, b, sa, sb, M, N, K, K, K, N, 1, M, 1, K / 128, SGLK_BF16);
