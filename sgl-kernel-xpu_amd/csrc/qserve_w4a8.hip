@@ -381,6 +381,11 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
 }
 
 #ifdef SGLK_PROBES
+static int g_qserve_mf = 0;  // (diagnostic: cap on the m-tiles per workgroup of the decode stream kernel)
+#else
+constexpr int g_qserve_mf = 0;
+#endif
+#ifdef SGLK_PROBES
 static int g_qserve_persist_rows = 128;
 #define kPersistRows g_qserve_persist_rows
 #else
@@ -396,9 +401,11 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   // at least four 64-deep steps); 16 waves (128 registers per lane) only with one m-tile and a 4-deep ring
   const int64_t pairs = cdiv(N, 64);
   // m-tiles per workgroup: 1 / 2 / 4 by the row count, fewer (the weights are then streamed once per group of m-tiles, the
-  // repeats from L2) when the launch would have under 128 workgroups - N = K = 4096, 64 rows: 24.9 us with 4 m-tiles on 64 workgroups
+  // repeats from L2) when the launch would have under 256 workgroups - N = K = 4096, 64 rows: 24.9 us with 4 m-tiles on 64
+  // workgroups, 16.8 with 2 on 128, 13.0 with 1 on 256; at N = 14336 one m-tile per workgroup is slower (30.0 against 26.2 us)
   int mf = M <= 16 ? 1 : M <= 32 ? 2 : 4;
-  while (mf > 1 && pairs * cdiv(M, 16 * mf) < 128) mf /= 2;
+  while (mf > 1 && pairs * cdiv(M, 16 * mf) < 256) mf /= 2;
+  if (g_qserve_mf > 0 && g_qserve_mf < mf) mf = g_qserve_mf;
   int ks = 1;
   while (ks < (M <= 16 ? 16 : 8) && pairs * cdiv(M, 16 * mf) * ks < 1536 && (K >> 6) >= 8 * ks) ks *= 2;
   const bool deep = (K >> 6) / ks >= 8 && ks <= 8;  // (ring no deeper than a wave's steps)
@@ -453,6 +460,7 @@ static int check(const char* op, const void* out, const void* a, const void* w, 
 
 #ifdef SGLK_PROBES
 extern "C" SGLK_API void sglk_debug_set_qserve_persist_rows(int rows) { sglk::g_qserve_persist_rows = rows; }
+extern "C" SGLK_API void sglk_debug_set_qserve_mf(int mf) { sglk::g_qserve_mf = mf; }
 #endif
 
 extern "C" int sglk_qserve_w4a8_per_chn_gemm(sglk_stream_t stream, void* out, const void* in_feats, const void* kernel,

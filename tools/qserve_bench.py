@@ -6,13 +6,29 @@ import sgl_kernel
 dev = "cuda"
 
 
+if os.environ.get("QSERVE_MF"):  # diagnostic build only (LD_PRELOAD=.../build/libsglk_probes.so)
+    import ctypes
+    ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
+                ).sglk_debug_set_qserve_mf(int(os.environ["QSERVE_MF"]))
+
+
 def timeit(f, it=30):
+    """device time per call: `it` calls in one HIP graph, median of three replays"""
     for _ in range(10): f()
-    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    st.record()
-    for _ in range(it): f()
-    en.record(); torch.cuda.synchronize()
-    return st.elapsed_time(en) / it
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(it): f()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record(); g.replay(); en.record(); torch.cuda.synchronize()
+        ts.append(st.elapsed_time(en) / it)
+    return sorted(ts)[1]
 
 
 for N, K in ((4096, 4096), (14336, 4096)):
