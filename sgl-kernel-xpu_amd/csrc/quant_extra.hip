@@ -80,15 +80,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void per_tensor_absmax_kernel(const T* __restrict__ x, float* __restrict__ s, int64_t n) {
   const int64_t nvec = n / 8, nchunk = (nvec + 1023) / 1024;
   float mx = 0.f;
-  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
-    Vec<T, 8> t[4];
+  for (int64_t c = blockIdx.x; c < nchunk; c += 2 * gridDim.x) {  // (two chunks per trip: eight loads in flight per lane)
+    Vec<T, 8> t[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t v = c * 1024 + j * 256 + threadIdx.x;
+    for (int j = 0; j < 8; ++j) {
+      const int64_t cc = j < 4 ? c : c + gridDim.x;
+      const int64_t v = cc * 1024 + (j & 3) * 256 + threadIdx.x;
       t[j] = load_vec<T, 8>(x + (v < nvec ? v : nvec - 1) * 8);  // (past the end: the last vector again - it counts anyway)
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
       for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf((float)t[j][e]));
   }
@@ -192,8 +193,12 @@ extern "C" int sglk_per_tensor_quant_fp8(sglk_stream_t stream, void* output_q, f
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+  // (the absmax pass ends in ONE atomic max per workgroup on ONE word: ~12 ns each, they serialise - 2048 workgroups spent
+  // 25 us there, more than both passes' bytes take; two workgroups per CU stream just as fast and leave 512 atomics that
+  // overlap the stream)
+  const int64_t ablocks = blocks < 2 * num_cus() ? blocks : 2 * num_cus();
   SGLK_DISPATCH_FLOAT(dtype, T, {
-    if (!is_static) per_tensor_absmax_kernel<T><<<(unsigned)blocks, 256, 0, st>>>((const T*)input, output_s, numel);
+    if (!is_static) per_tensor_absmax_kernel<T><<<(unsigned)ablocks, 256, 0, st>>>((const T*)input, output_s, numel);
     per_tensor_quant_fp8_kernel<T><<<(unsigned)blocks, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, numel,
                                                                      is_static ? 0 : 1);
   });
