@@ -294,13 +294,18 @@ SGLK_API int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const vo
  * fused form, kernels/moe/xe20/bf16/moe_mainloop.hpp:232-247). fused_act: 0 none, 1 silu, 2 gelu (tanh): W rows
  * [0, N/2) gate, [N/2, N) up, out [total_m, N/2] = T(act(gate + b) * (up + b)) from the fp32 accumulators;
  * 3 relu2: out [total_m, N] = T(max(x + b, 0)^2); 4 the DeepSeek-V4 clamped swiglu (reference silu_and_mul_clamp,
- * python/sgl_kernel/elementwise.py:231-255): gate = min(gate, act_limit), up = clamp(up, +-act_limit), silu(gate) * up. */
+ * python/sgl_kernel/elementwise.py:231-255): gate = min(gate, act_limit), up = clamp(up, +-act_limit), silu(gate) * up.
+ * row_map (may be NULL): int32 [total_m], the token gather of fused_experts (reference shuffle_rows,
+ * python/sgl_kernel/moe.py:739) folded into the GEMM: row r of the expert-contiguous problem reads
+ * activations[row_map[r]], activations is [src_rows, K] (src_rows * K < 2^32). A mapped call runs on the
+ * streaming (decode) kernels at every size. */
 SGLK_API int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, const void* activations,
                                            const void* packed_weights, const void* scales,
                                            const void* zeros, const float* bias,
                                            const int32_t* rows_per_expert, int64_t total_m,
                                            int64_t n_experts, int64_t N, int64_t K, int64_t group_size,
-                                           int is_int4, int dtype, int fused_act, float act_limit);
+                                           int is_int4, int dtype, int fused_act, float act_limit,
+                                           const int32_t* row_map, int64_t src_rows);
 
 /* ---- flash-attention forward ---------------------------------------------------
  * fwd (mha_fwd): reference src/sycl/flash_attention.cpp:1332-1435 (schema

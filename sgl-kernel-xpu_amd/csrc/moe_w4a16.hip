@@ -173,7 +173,11 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
                                                         const uint8_t* __restrict__ wq, const void* __restrict__ scales_,
                                                         const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
-                                                        int K, int group_shift, int probe, int fuse, float act_limit) {
+                                                        int K, int group_shift, int probe, int fuse, float act_limit,
+                                                        const int32_t* __restrict__ row_map) {
+  // row_map (may be null): activation row of expert-contiguous row r is act[row_map[r]] - the token gather of fused_experts
+  // (reference shuffle_rows, python/sgl_kernel/moe.py:739) folded into this kernel's staging loads: no [rows, K] copy of the
+  // tokens, one launch less per call at decode sizes.
   // fuse (the gate / up activation of fused_experts in this GEMM's epilogue, as moe_bf16.hip does for 16-bit weights;
   // reference python/sgl_kernel/moe.py:751-835 runs GEMM, then a separate act-and-mul over a [rows, 2I] intermediate):
   //   1 silu, 2 gelu (tanh form): W holds gate rows [0, N/2) then up rows [N/2, N); a workgroup takes BN/2 gate columns
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   // exposes a full memory latency per 128-deep block (that alone was 200 us of a K = 14336 decode GEMM).
   // (a scalar base per workgroup and 32-bit per-thread offsets: 64-bit per-thread row addresses of the large tiles were
   // spilled and reloaded inside the K loop)
-  const T* act_blk = act + (int64_t)m0 * K;
+  const T* act_blk = row_map ? act : act + (int64_t)m0 * K;
   constexpr int AL = MT * AS * 4 / WV;  // 16-byte chunks per thread and stage: chunk q = i * NT_ + tid of [BM][16 AS]
   static_assert(MT * AS * 4 % WV == 0, "stage chunks must divide over the threads");
   uint32_t aoff[AL];
@@ -266,7 +270,8 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   for (int i = 0; i < AL; ++i) {
     const int q = i * NT_ + tid;
     const int row = q / (16 * AS), c = q % (16 * AS);
-    aoff[i] = (uint32_t)((probe & 1) ? 0 : row < m_valid ? row : m_valid - 1) * (uint32_t)K + c * 8;
+    const int rc = (probe & 1) ? 0 : row < m_valid ? row : m_valid - 1;
+    aoff[i] = (uint32_t)(row_map ? row_map[m0 + rc] : rc) * (uint32_t)K + c * 8;
   }
   auto load_a = [&](int st, v4i (&r)[AL]) {  // stage st = blocks st * AS .. + AS - 1
 #pragma unroll
@@ -804,6 +809,7 @@ constexpr int g_w4_probe = 0, g_w4_mt = 0, g_w4_fp4hw = 1;
 
 // (the clamp bound of fused_act 4 rides beside the launch parameters: one value per call, set by the C-ABI entry)
 static thread_local float t_act_limit = 0.f;
+static thread_local const int32_t* t_row_map = nullptr;  // the token gather of the call (streaming kernels only)
 static thread_local int t_tail_flag = 0;  // kMoeTailFlag while the launches cover only the rows moe_persist.hip left over
 
 template <typename T, int MT, int NW, int PB, int FMT = 0, int WV = 4>
@@ -815,7 +821,7 @@ static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq,
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20_w4a16: problem too large for one launch");
   dim3 grid((unsigned)wgs);
   moe_w4a16_kernel<T, MT, NW, PB, FMT, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
-                                                             rows, E | t_tail_flag, N, K, group_shift, g_w4_probe, fuse, t_act_limit);
+                                                             rows, E | t_tail_flag, N, K, group_shift, g_w4_probe, fuse, t_act_limit, t_row_map);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
 }
 
@@ -928,15 +934,19 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
                                          int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
                                          int dtype) {
   return sglk_moe_grouped_mm_w4a16_act(stream, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m,
-                                       n_experts, N, K, group_size, is_int4, dtype, 0, 0.f);
+                                       n_experts, N, K, group_size, is_int4, dtype, 0, 0.f, nullptr, 0);
 }
 
 extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, const void* activations,
                                              const void* packed_weights, const void* scales, const void* zeros,
                                              const float* bias, const int32_t* rows_per_expert, int64_t total_m,
                                              int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
-                                             int dtype, int fused_act, float act_limit) {
+                                             int dtype, int fused_act, float act_limit, const int32_t* row_map,
+                                             int64_t src_rows) {
   using namespace sglk;
+  SGLK_REQUIRE(row_map == nullptr || (src_rows > 0 && src_rows * K < (1ll << 32)),
+               "moe_grouped_mm_nt_xe20_w4a16: a row map needs 0 < src_rows and src_rows * K < 2^32 (src_rows=%lld)",
+               (long long)src_rows);
   SGLK_REQUIRE(fused_act >= 0 && fused_act <= 4,
                "moe_grouped_mm_nt_xe20_w4a16: fused_act must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2) or 4 (clamped swiglu)");
   SGLK_REQUIRE(fused_act != 4 || act_limit > 0.f, "moe_grouped_mm_nt_xe20_w4a16: the clamped swiglu needs a positive limit");
@@ -963,7 +973,13 @@ extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, co
   if (total_m == 0) return SGLK_OK;
   const int gs = !is_int4 ? -1 : group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : 8;
   hipStream_t st = (hipStream_t)stream;
-  {
+  // (a row map is honoured by the streaming kernels' staging loads; the tile pipeline stages by LDS-DMA from expert-contiguous
+  // rows, so a mapped call stays on the streaming kernels at every size - fused_experts maps only below 96 rows per expert)
+  struct MapScope {
+    explicit MapScope(const int32_t* m) { t_row_map = m; }
+    ~MapScope() { t_row_map = nullptr; }
+  } map_scope(row_map);
+  if (row_map == nullptr) {
     if (int rc = moe_persist_try(st, out, activations, packed_weights, scales, is_int4 ? zeros : nullptr, gs, bias, rows_per_expert, total_m, (int)n_experts,
                                  (int)N, (int)K, 0, 0, dtype, is_int4 ? 1 : 2, fused_act, act_limit)) {
       if (rc < 0) return rc;

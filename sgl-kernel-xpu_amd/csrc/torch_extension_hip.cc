@@ -674,7 +674,8 @@ void apply_shuffle_mul_sum(const Tensor& input, Tensor& output, const Tensor& pe
 static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
                           const Tensor& scales, const std::optional<Tensor>& zeros,
                           const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
-                          bool is_int4, int64_t group_size, int64_t fused_act, double act_limit) {
+                          bool is_int4, int64_t group_size, int64_t fused_act, double act_limit,
+                          const std::optional<Tensor>& row_map = std::nullopt) {
   CHECK_GPU(output);
   CHECK_GPU(activations);
   CHECK_GPU(packed_weights);
@@ -688,7 +689,14 @@ static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tens
   TORCH_CHECK(output.dim() == 2, "output must be 2D [total_m, N]");
   TORCH_CHECK(activations.dim() == 2, "activations must be 2D [total_m, K]");
   TORCH_CHECK(rows_per_expert.dim() == 1, "rows_per_expert must be 1D [E]");
-  const int64_t total_m = activations.size(0), gemm_k = activations.size(1);
+  const int32_t* map_ptr = nullptr;
+  if (row_map.has_value()) {  // activations [tokens, K], row r of the grouped problem reads activations[row_map[r]]
+    CHECK_GPU(*row_map);
+    TORCH_CHECK(row_map->dim() == 1 && row_map->scalar_type() == at::kInt && row_map->is_contiguous(),
+                "row_map must be a contiguous 1D int32 tensor [total_m]");
+    map_ptr = row_map->data_ptr<int32_t>();
+  }
+  const int64_t total_m = map_ptr ? row_map->size(0) : activations.size(0), gemm_k = activations.size(1);
   TORCH_CHECK(packed_weights.dim() == 3, "packed_weights must be 3D [E, N, K/2]");
   const int64_t gemm_n = packed_weights.size(1);
   TORCH_CHECK(packed_weights.size(0) == n_experts, "packed_weights.size(0) must equal n_experts");
@@ -713,7 +721,7 @@ static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tens
   TORCH_CHECK(n_experts > 0, "n_experts must be positive");
   TORCH_CHECK(n_experts == rows_per_expert.size(0), "rows_per_expert must have n_experts elements");
   TORCH_CHECK(rows_per_expert.scalar_type() == at::kInt, "rows_per_expert must be int32");
-  TORCH_CHECK(output.size(0) == total_m, "output rows must match activations rows");
+  TORCH_CHECK(output.size(0) == total_m, map_ptr ? "output rows must match row_map's length" : "output rows must match activations rows");
   TORCH_CHECK(fused_act >= 0 && fused_act <= 4, "activation_type must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2) or 4 (clamped swiglu)");
   const bool gated = fused_act == 1 || fused_act == 2 || fused_act == 4;
   TORCH_CHECK(output.size(1) == (gated ? gemm_n / 2 : gemm_n), gated ? "output must have N / 2 columns (gate rows, then up rows in W)"
@@ -751,7 +759,8 @@ static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tens
                                           packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr, bias_ptr,
                                           rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
                                           group_size, is_int4 ? 1 : 0,
-                                          dtype_code(activations.scalar_type(), "activations"), (int)fused_act, (float)act_limit));
+                                          dtype_code(activations.scalar_type(), "activations"), (int)fused_act, (float)act_limit,
+                                          map_ptr, activations.size(0)));
 }
 
 void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
@@ -764,12 +773,15 @@ void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, con
 // authored (no reference op: the reference runs GEMM 1 and the gate / up activation as two launches,
 // python/sgl_kernel/moe.py:751-835): the same GEMM with the activation on its fp32 accumulators.
 // activation_type: 1 silu, 2 gelu (tanh), 4 clamped swiglu (act_limit) - output [total_m, N / 2]; 3 relu2 - output [total_m, N]
+// row_map (optional, int32 [total_m]): activations are the tokens [T, K] and row r reads activations[row_map[r]] - the
+// reference's shuffle_rows (python/sgl_kernel/moe.py:739) folded into the GEMM's staging loads
 void moe_grouped_mm_nt_w4a16_act(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
                                  const Tensor& scales, const std::optional<Tensor>& zeros,
                                  const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
-                                 bool is_int4, int64_t group_size, int64_t activation_type, double act_limit) {
+                                 bool is_int4, int64_t group_size, int64_t activation_type, double act_limit,
+                                 const std::optional<Tensor>& row_map) {
   moe_w4a16_impl(output, activations, packed_weights, scales, zeros, bias, rows_per_expert, n_experts, is_int4, group_size,
-                 activation_type, act_limit);
+                 activation_type, act_limit, row_map);
 }
 
 // ---- moe_grouped_mm_nt_xe20 (reference src/sycl/GroupGemmXe20.cpp:160-275) ---------------------------------
@@ -1651,7 +1663,7 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
   m.def(
       "moe_grouped_mm_nt_w4a16_act(Tensor! output, Tensor activations, Tensor packed_weights, Tensor scales, "
       "Tensor? zeros, Tensor? bias, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size, "
-      "int activation_type, float act_limit=0.0) -> ()");
+      "int activation_type, float act_limit=0.0, Tensor? row_map=None) -> ()");
   m.impl("moe_grouped_mm_nt_w4a16_act", c10::kCUDA, &moe_grouped_mm_nt_w4a16_act);
   m.def(
       "prepare_moe_input(Tensor topk_ids, Tensor! expert_offsets, Tensor? blockscale_offsets, Tensor! problem_sizes1,"

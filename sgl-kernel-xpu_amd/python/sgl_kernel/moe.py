@@ -284,8 +284,16 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
                                    scratch("problem_sizes1", (p.experts, 3), torch.int32),
                                    scratch("problem_sizes2", (p.experts, 3), torch.int32),
                                    src_rows, dst_rows, p.experts, p.hidden, p.topk)
-    x = scratch("input_A_shuffle", (p.rows, p.hidden))
-    _ops.scatter_tokens_to_experts.default(hidden_states.contiguous(), dst_rows, x)
+    # decode sizes with 4-bit weights: GEMM 1 gathers its rows through a_map itself (the streaming kernels' staging loads),
+    # no [rows, hidden] copy of the tokens and one launch less. From 96 rows per expert on the tile pipeline takes the
+    # GEMM, which stages expert-contiguous rows by LDS-DMA: the copy (reference shuffle_rows, moe.py:739) stays there.
+    gather_in_gemm1 = (p.four_bit and gemm1_alpha is None and w1_g_idx_perm is None and p.rows < 96 * p.experts
+                       and p.tokens * p.hidden < 2**32)
+    if gather_in_gemm1:
+        x = hidden_states.contiguous()
+    else:
+        x = scratch("input_A_shuffle", (p.rows, p.hidden))
+        _ops.scatter_tokens_to_experts.default(hidden_states.contiguous(), dst_rows, x)
     if w1_g_idx_perm is not None:
         x = _gather_channels_per_expert(x, w1_g_idx_perm, rows_per_expert, p.experts)
 
@@ -309,7 +317,7 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     else:
         fused = 4 if swiglu_limit is not None else {0: 1, 1: 2, 3: 3}[p.act_type]
         _ops.moe_grouped_mm_nt_w4a16_act(h, x, w1, w1_scale, w1_zp, b1, rows_per_expert, p.experts, p.int4, p.group1,
-                                         fused, float(swiglu_limit or 0.0))
+                                         fused, float(swiglu_limit or 0.0), src_rows if gather_in_gemm1 else None)
     if w2_g_idx_perm is not None:
         h = _gather_channels_per_expert(h, w2_g_idx_perm, rows_per_expert, p.experts)
 

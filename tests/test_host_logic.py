@@ -197,22 +197,31 @@ def test_fused_experts_plan_and_op_sequence(sglk, monkeypatch):
     b1 = torch.randn(4, 128, dtype=torch.bfloat16)
     out = moe.fused_experts(x, w1, w2, tw, ti, b1=b1, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, routed_scaling_factor=2.5)
     assert out.shape == x.shape and out is not x
-    # GEMM 1 carries the gate / up activation in its epilogue (authored op): no separate act-and-mul launch
-    assert rec.names() == ["prepare_moe_input", "scatter_tokens_to_experts", "moe_grouped_mm_nt_w4a16_act",
-                           "moe_grouped_mm_nt_xe20_w4a16", "apply_shuffle_mul_sum"]
+    # GEMM 1 carries the gate / up activation in its epilogue (authored op): no separate act-and-mul launch; at decode
+    # sizes (fewer than 96 rows per expert) it also gathers its rows through a_map: no scatter launch, the tokens go in as they are
+    assert rec.names() == ["prepare_moe_input", "moe_grouped_mm_nt_w4a16_act", "moe_grouped_mm_nt_xe20_w4a16",
+                           "apply_shuffle_mul_sum"]
     prep = rec.calls[0][1]
     assert prep[0].dtype == torch.int32 and prep[2] is None and prep[7:] == (4, 128, 2)  # ids int32, E, hidden, topk
-    g1, g2 = rec.calls[2][1], rec.calls[3][1]
-    assert g1[0].shape == (10, 64) and g1[1].shape == (10, 128)  # act(gate) * up: [T*k, I] from [T*k, H]
+    g1, g2 = rec.calls[1][1], rec.calls[2][1]
+    assert g1[0].shape == (10, 64) and g1[1].shape == (5, 128)  # act(gate) * up: [T*k, I] from the tokens [T, H]
     assert g1[5].dtype == torch.float32 and torch.equal(g1[5], b1.float())  # bf16 bias widened to fp32
-    assert g1[7:] == (4, True, 32, 1, 0.0) and g2[9] == 32  # E, is_int4, group size, silu, no clamp
+    assert g1[7:12] == (4, True, 32, 1, 0.0) and g2[9] == 32  # E, is_int4, group size, silu, no clamp
+    assert g1[12] is prep[5] and g1[12].shape == (10,) and g1[12].dtype == torch.int32  # the row map = prepare_moe_input's a_map
     assert g2[0].shape == (10, 128) and g2[1].shape == (10, 64) and g2[5] is None
-    comb = rec.calls[4][1]
-    assert comb[1] is out and comb[3] == 2.5 and comb[4] is tw
+    comb = rec.calls[3][1]
+    assert comb[1] is out and comb[3] == 2.5 and comb[4] is tw and comb[2] is prep[6]
     # DeepSeek-V4 clamp: activation 4 with its limit
     rec.calls.clear()
     moe.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, swiglu_limit=10)
-    assert rec.calls[2][1][10:] == (4, 10.0)
+    assert rec.calls[1][1][10:12] == (4, 10.0)
+    # from 96 rows per expert on (the tile pipeline's sizes) the tokens are copied expert-contiguous first, no map
+    rec.calls.clear()
+    xl, w1l, w2l, twl, til, s1l, s2l = _moe_case(T=192)
+    moe.fused_experts(xl, w1l, w2l, twl, til, use_int4_w4a16=True, w1_scale=s1l, w2_scale=s2l)
+    assert rec.names() == ["prepare_moe_input", "scatter_tokens_to_experts", "moe_grouped_mm_nt_w4a16_act",
+                           "moe_grouped_mm_nt_xe20_w4a16", "apply_shuffle_mul_sum"]
+    assert rec.calls[2][1][1].shape == (384, 128) and rec.calls[2][1][12] is None
     # gpt-oss swiglu (reference moe.py:692-697, :751-789): plain GEMM 1 to [rows, 2I], the interleaved-pairs op, GEMM 2
     rec.calls.clear()
     moe.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, gemm1_alpha=1.702, gemm1_limit=7.0)
@@ -229,7 +238,7 @@ def test_fused_experts_plan_and_op_sequence(sglk, monkeypatch):
     rec.calls.clear()
     x, w1, w2, tw, ti, s1, s2 = _moe_case(gated=False)
     out = moe.fused_experts(x, w1, w2, tw, ti, activation="relu2", inplace=True, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2)
-    assert out is x and rec.calls[2][1][0].shape == (10, 64) and rec.calls[2][1][10] == 3 and "silu_and_mul" not in rec.names()
+    assert out is x and rec.calls[1][1][0].shape == (10, 64) and rec.calls[1][1][10] == 3 and "silu_and_mul" not in rec.names()
     assert rec.calls[-1][1][3] == 1.0
     # 16-bit weights: the grouped GEMM's fused gate/up epilogue, GEMM 2 without it
     rec.calls.clear()

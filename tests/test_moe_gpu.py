@@ -240,6 +240,48 @@ def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit
     torch.testing.assert_close(out.cpu().float(), two.cpu().float(), rtol=5e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act_type", [1, 3, 4])
+@pytest.mark.parametrize("fmt", ["int4", "int4_zp", "mxfp4"])
+@pytest.mark.parametrize("rows,N,K,tokens", [([2] * 8, 256, 256, 3), ([0, 5, 17, 0, 1, 33, 0, 70], 416, 512, 40),
+                                             ([1] * 8, 4096, 1024, 1), ([3, 0, 16, 7], 208, 4096, 9),
+                                             ([130, 200, 112, 150], 512, 1024, 300)])
+def test_moe_grouped_mm_w4a16_row_map_is_the_gather(sglk, dev, dtype, act_type, fmt, rows, N, K, tokens):
+    """row_map of the authored op (the token gather of fused_experts, reference shuffle_rows, python/sgl_kernel/moe.py:739,
+    folded into GEMM 1's staging loads): the mapped call on the tokens equals, bit for bit, the plain call on the rows
+    gathered beforehand - at every size, also where the unmapped call would run on the tile pipeline (the last case: that
+    one is compared within the reference tolerance, the two pipelines round differently)."""
+    g = torch.Generator().manual_seed(sum(rows) + N + K + act_type)
+    E, total = len(rows), sum(rows)
+    x = (torch.randn(tokens, K, generator=g) * 0.1).to(dtype).to(dev)
+    row_map = torch.randint(0, tokens, (total,), generator=g, dtype=torch.int32).to(dev)
+    if fmt == "mxfp4":
+        packed = torch.randint(0, 256, (E, N, K // 2), generator=g, dtype=torch.uint8)
+        scales, zeros, gs, is_int4 = torch.randint(118, 126, (E, N, K // 32), generator=g, dtype=torch.uint8), None, 32, False
+    else:
+        gs, is_int4 = 128, True
+        packed, scales, zeros = make_int4(E, N, K, gs, dtype, fmt == "int4_zp", g)
+        packed = packed.view(torch.int8 if fmt == "int4_zp" else torch.uint8)
+    bias = (torch.randn(E, N, generator=g) * 0.05).to(dev) if N % 256 == 0 else None
+    d = lambda t: t.to(dev) if t is not None else None
+    rows_t = torch.tensor(rows, dtype=torch.int32, device=dev)
+    cols = N if act_type == 3 else N // 2
+    mapped = torch.full((total, cols), float("nan"), dtype=dtype, device=dev)
+    plain = torch.full((total, cols), float("nan"), dtype=dtype, device=dev)
+    op = torch.ops.sgl_kernel.moe_grouped_mm_nt_w4a16_act
+    op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25, row_map)
+    op(plain, x[row_map.long()].contiguous(), packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25)
+    assert torch.isfinite(mapped.float()).all()
+    if total < 96 * E:
+        assert torch.equal(mapped, plain)
+    else:
+        torch.testing.assert_close(mapped.float(), plain.float(), rtol=5e-2, atol=2e-2)
+    with pytest.raises(RuntimeError, match="row_map"):
+        op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25, row_map.long())
+    with pytest.raises(RuntimeError, match="row_map's length"):
+        op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25, row_map[:-1])
+
+
 def test_fused_experts_swiglu_limit(sglk, dev):
     """DeepSeek-V4 clamp (reference moe.py:699-709, tests/test_fused_experts_mxfp4_dsv4_shapes.py:59-61): with a limit no
     pre-activation reaches, the clamped layer equals the plain silu layer bit for bit; with inputs scaled up it equals the
