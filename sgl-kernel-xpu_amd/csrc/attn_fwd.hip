@@ -93,6 +93,7 @@ struct AttnParams {
   int splits;
   float scale;          // softmax scale
   float softcap;        // 0 = off
+  int probe;            // libsglk_probes.so only (0 in the release library): attn_prefill_kernel timing probes, garbage results
 };
 
 // DKP: head dim rounded up to 32 (k-steps of the QK product); the V/O side uses ceil(D/16) 16-wide tiles.
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
   // attention problem is cache position i + leftpad.
   int seqlen_k, k_begin = 0, cache_row = b, leftpad = 0;
   if (p.paged) {
-    if (p.kv_batch_idx != nullptr) cache_row = p.kv_batch_idx[b];
-    if (p.leftpad_k != nullptr) leftpad = p.leftpad_k[b];
+    if (p.kv_batch_idx != nullptr) cache_row = __builtin_amdgcn_readfirstlane(p.kv_batch_idx[b]);  // (uniform, and the
+    if (p.leftpad_k != nullptr) leftpad = __builtin_amdgcn_readfirstlane(p.leftpad_k[b]);          // compiler must know)
     seqlen_k = seq_k[b] - leftpad;
     seqlen_k = seqlen_k > 0 ? seqlen_k : 0;
   } else {
@@ -540,24 +541,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Prefill kernel (head dim 128, 16-bit KV, no softcap; everything else of the contract above): the kernel above gives a
+// Prefill kernel (head dims 64 / 128, 16-bit KV, no softcap; everything else of the contract above): the kernel above gives a
 // wave 16 packed rows and 32-token tiles, so every K / V fragment it reads from LDS feeds one MFMA and every tile costs
 // a barrier per 16 MFMAs of a wave: 267 TFLOP/s on the causal 16 x 4096 Llama-3-8B prefill (0.11 of the bf16 MFMA
-// peak), LDS-read bound. Here a workgroup is 8 waves x 32 packed rows = 256 rows and a tile is 64 tokens:
+// peak), LDS-read bound. Here a wave takes 32 packed rows and a tile is 64 tokens:
 //   * S^T = K . Q^T and O^T = V^T . P^T with v_mfma_f32_32x32x16: lane l owns query row l % 32 in BOTH products
-//     (score and output columns), so the running max / sum / rescale factors are per-lane scalars and P never moves
+//     (score and output columns), so the running reference / sum / rescale factors are per-lane scalars and P never moves
 //     between lanes: a lane's 16 scores of a 32-token block, taken 8 at a time, ARE its P operand for the k-slot
 //     order tau(s, u, e) = 32 (s / 2) + 16 (s % 2) + 8 (e / 4) + 4 u + e % 4 (u = lane / 32), and V^T is read in that
 //     token order with the hardware transpose read (4 tokens x 16 dims per 16 lanes);
 //   * per wave and tile 16 + 16 MFMAs of 32 cycles against 24 KiB of LDS reads (the 16-row kernel: 32 KiB for half the
-//     work); the row maximum costs one cross-lane exchange (lane ^ 32);
-//   * K / V tiles go global -> registers -> LDS (loads issued before the tile's MFMAs, written after them), two LDS
-//     buffers, one barrier per 64 tokens; LDS images are 256-byte rows with 16-byte chunk c of row r at c ^ (r & 15)
-//     for K (ds_read_b128 of 16 different rows is conflict-free) and c ^ ((r & 3) << 2) for V (the 4-row x 64-byte
-//     footprint of a transpose read covers all banks once);
+//     work);
+//   * K / V tiles go global -> LDS by LDS-DMA (round 4; see "staging" in the kernel), two LDS buffers, one barrier per 64
+//     tokens; LDS images are 256-byte rows with 16-byte chunk c of row r at c ^ (r & 15) for K (ds_read_b128 of 16 different
+//     rows is conflict-free) and c ^ ((r & 3) << 2) for V (the 4-row x 64-byte footprint of a transpose read covers all
+//     banks once);
 //   * causal / window masks only on tiles that are not fully visible to the wave's 32 rows; workgroups of later (longer)
-//     row blocks are dispatched first.
-constexpr int kPBlockM = 256, kPTile = 64;
+//     row blocks are dispatched first;
+//   * NW = 4 waves (128 rows) per workgroup, TWO workgroups per CU (round 4; 8 waves x 32 rows, one workgroup per CU, before:
+//     the staging registers the DMA freed - 32 per thread - were what kept a second workgroup out). One workgroup's Q
+//     loads, first tiles, barrier waits and output stores now run under the other's tiles: causal 16 x 4096 at d = 128
+//     879 - 886 -> 909 - 923 TFLOP/s, at d = 64 684 - 707 -> 827 - 835 (same box, interleaved runs); a launch of exactly one
+//     round of workgroups (q = 128 chunks over 4096 keys) loses 6 % - it has nothing to overlap and misses the phase skew the
+//     two waves of a SIMD had inside one workgroup.
+// Round 4, measured and dropped: the weights of a block formed in the gaps of the next block's MFMAs (840
+// against 910 TFLOP/s - a wave's vector and matrix instructions do not overlap on this part, interleaved or not, and
+// the interleaved form waits for every fragment read); the first fragments of a phase requested ahead of the scalar work
+// in front of it (d = 128 unchanged, d = 64 -15 %).
+constexpr int kPTile = 64;  // (a workgroup takes 32 NW packed rows)
 
 
 template <typename T>
@@ -578,16 +589,24 @@ struct Mfma32<f16> {
 // Head dim 64 (round 3; reference instantiations FMHAPrefillXe20.cmake): the same kernel with 128-byte LDS rows - 8 chunks per
 // row, one staging load per thread, tile and operand; K chunk c of row r at c ^ ((r >> 1) & 7) (rows two apart share their
 // banks), V chunk c at c ^ (((r >> 1) & 1) << 2); 8 + 8 MFMAs per wave and tile against the same softmax work.
-template <typename T, int D>
-__global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
                                                            const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                            const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
                                                            const int32_t* __restrict__ page_table) {
   using M = Mfma<T>;
   using M32 = Mfma32<T>;
   constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, TILE_BYTES = kPTile * ROWB;
-  constexpr int CPR = D / 8, NCH = CPR / 8, RPP = 512 / CPR;  // 16-byte chunks per row, staging loads per thread, rows per pass
+  constexpr int kPBlockM = 32 * NW, NTH = 64 * NW;
+  constexpr int CPR = D / 8, RPP = NTH / CPR, NCH = kPTile / RPP;  // 16-byte chunks per row, rows per pass, staging loads per thread
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][K tile, V tile]
+  // probe (diagnostic build): 64 no output stores, 128 no Q loads (the probes of the tile loop - no softmax, no MFMAs, no
+  // staging, no barrier, no fragment reads - were used once and removed: DESIGN 4.11)
+#ifdef SGLK_PROBES
+  const int probe = p.probe;
+#else
+  constexpr int probe = 0;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -606,8 +625,10 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   const int seqlen_q = cu_q[b + 1] - q_begin;
   int seqlen_k, k_begin = 0, cache_row = b, leftpad = 0;
   if (p.paged) {
-    if (p.kv_batch_idx != nullptr) cache_row = p.kv_batch_idx[b];
-    if (p.leftpad_k != nullptr) leftpad = p.leftpad_k[b];
+    // (loads through pointers inside the parameter struct are vector loads: without the readfirstlane the compiler treats
+    // everything derived from them - the tile range, the loop itself - as divergent)
+    if (p.kv_batch_idx != nullptr) cache_row = __builtin_amdgcn_readfirstlane(p.kv_batch_idx[b]);
+    if (p.leftpad_k != nullptr) leftpad = __builtin_amdgcn_readfirstlane(p.leftpad_k[b]);
     seqlen_k = seq_k[b] - leftpad;
     seqlen_k = seqlen_k > 0 ? seqlen_k : 0;
   } else {
@@ -642,9 +663,9 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
     kv_lo = lim > 0 ? lim : 0;
   }
   if (kv_hi < 0) kv_hi = 0;
-  int t_lo = kv_lo / kPTile, t_hi = (kv_hi + kPTile - 1) / kPTile;
+  int t_lo = __builtin_amdgcn_readfirstlane(kv_lo / kPTile), t_hi = __builtin_amdgcn_readfirstlane((kv_hi + kPTile - 1) / kPTile);
   if (t_hi < t_lo) t_hi = t_lo;
-  const int n_tiles = t_hi - t_lo;
+  const int n_tiles = t_hi - t_lo;  // (uniform, and the compiler has to know: the tile loop is then a scalar loop)
 
   // ---- Q^T fragments (B operand of K . Q^T): lane supplies q[row l31][16 ks + 8 u .. + 8)
   v8s qf[KS];
@@ -653,15 +674,28 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       v8s v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (row_ok) v = *reinterpret_cast<const v8s*>(qrow + 16 * ks + 8 * u);
+      if (row_ok && !(probe & 128)) v = *reinterpret_cast<const v8s*>(qrow + 16 * ks + 8 * u);
       qf[ks] = v;
     }
   }
 
-  // ---- staging: 16-byte chunk c = tid + 512 i (i = 0, 1) of a tile <-> (token row c / 16, chunk c % 16).
-  // One address formula for the three layouts (page * s0 + position-in-page * s1 + base), positions past the end clamped
-  // to the last key (their scores are masked, and a real V row times weight 0 is 0), so that a tile's loads are four
-  // unconditional instructions; the page ids of a tile are fetched one tile before its loads are issued.
+  // ---- staging by LDS-DMA (round 4; before: global -> registers -> ds_write, 32 staging registers per thread, which kept
+  // the kernel at one 8-wave workgroup per CU - nothing ran under a workgroup's Q loads, first tiles, barriers and output
+  // stores: with every phase of the loop switched off the launch still took 0.43 of its time). A tile is 2 x 64 rows of ROWB
+  // bytes = 1-KiB pieces of RP rows; wave w moves pieces w PPW .. w PPW + PPW - 1 of K and of V, one
+  // global_load_lds_dwordx4 each: lane -> (row r = lane / CPR of the piece, LDS chunk position c = lane % CPR), and since the
+  // DMA writes lanes to consecutive LDS addresses the swizzle sits on the GLOBAL side: the lane fetches chunk c ^ key(row).
+  // One address formula for the three layouts (page * s0 + position-in-page * s1 + base; page stride 0 and a dummy id
+  // source without a table); positions past the end are clamped to the last key (their scores are masked, and a real V row
+  // times weight 0 is 0). A tile that lies whole inside the sequence, with pieces that do not straddle pages, has one page id
+  // and one position for all the rows a wave moves: its address arithmetic is scalar and done once per operand, a piece is
+  // that SGPR base plus a loop-invariant 32-bit lane offset (the general form costs ~12 VALU instructions per piece; a base
+  // per piece cost the wave 121 scalar instructions per tile - its own issue time, 0.1 of the tile). Page ids are fetched a tile ahead by vector loads (a
+  // scalar load would share lgkmcnt with the LDS reads and turn their counted waits into full ones).
+  // The DMA instructions are asm text (an LDS-DMA the compiler can see makes it wait vmcnt(0) in front of every LDS read):
+  // their completion is the hand-written s_waitcnt vmcnt(0) in front of the tile barrier.
+  constexpr int RP = 1024 / ROWB, NPIECE = kPTile / RP, PPW = NPIECE / NW;  // rows per piece, pieces per tile, per wave
+  static_assert(PPW >= 1 && PPW * NW == NPIECE, "pieces must divide over the waves");
   const int32_t* table_b = page_table + (p.paged == 1 ? (int64_t)cache_row * p.table_stride : 0);
   const bool use_table = p.paged == 1;
   const int pos_mask = use_table ? (1 << p.page_shift) - 1 : -1;
@@ -674,48 +708,76 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
                                      : (int64_t)hk * (p.paged ? p.k_s2 : p.k_s1);
   const int64_t vbase = p.paged == 2 ? (int64_t)cache_row * p.v_s0 + (int64_t)hk * p.v_s2
                                      : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1);
-  const int srow = tid / CPR, sch = (tid % CPR) * 8;  // this thread's token rows srow (+ RPP) and chunk of a tile
   const int last_key = seqlen_k - 1;
-  struct Pages { int pg[NCH]; };
-  // (without a page table the fetch reads cu_q[b], a valid word, and the page stride below is 0: no branch, so that the
-  // loaded registers are not merged with constants behind a wait)
+  // (without a page table the fetch reads cu_q[b], a valid word, and the page stride is 0: no branch)
   const int32_t* pg_src = use_table ? table_b : cu_q + b;
-  auto fetch_pages = [&](int t) -> Pages {
-    Pages r;
+  const int prow = lane / CPR, pch = lane % CPR;  // this lane's row of a piece and its LDS chunk position
+  // global 16-byte chunk of the lane for piece i of this wave (K: the key depends on the piece's rows; V: it does not)
+  auto k_chunk = [&](int i) -> int {
+    const int row = RP * (wave * PPW + i) + prow;
+    return pch ^ (D == 128 ? (row & 15) : ((row >> 1) & 7));
+  };
+  const int v_chunk = pch ^ (D == 128 ? ((prow & 3) << 2) : (((prow >> 1) & 1) << 2));
+  // (fast tiles: the RP PPW consecutive rows a wave moves share their page, so one SGPR base serves the wave's pieces and the
+  // piece's row offset rides in the lane offset)
+  constexpr int WR = RP * PPW;  // rows of a tile moved by one wave
+  const bool wave_aligned = (!use_table || ((1 << p.page_shift) % WR == 0 && (pos_base & (WR - 1)) == 0)) &&
+                            kst < (1u << 22) && vst < (1u << 22);
+  auto tile_fast = [&](int t) -> bool { return wave_aligned && t * kPTile + kPTile - 1 <= last_key; };
+  uint32_t voff_k[PPW], voff_v[PPW];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      int pos = t * kPTile + srow + RPP * i;
+  for (int i = 0; i < PPW; ++i) {
+    voff_k[i] = ((uint32_t)(RP * i + prow) * kst) * 2u + (uint32_t)(k_chunk(i) << 4);
+    voff_v[i] = ((uint32_t)(RP * i + prow) * vst) * 2u + (uint32_t)(v_chunk << 4);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)SGLK_LDS(smem);
+  auto dma16 = [&](const char* src, uint32_t lds_dst) {  // per-lane 64-bit address
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_dst) : "memory", "m0");
+  };
+  auto dma16s = [&](uint32_t voff, const char* sbase, uint32_t lds_dst) {  // SGPR base + 32-bit lane offset
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory", "m0");
+  };
+  struct Pages { int pg[PPW]; };  // fast tiles: pg[0] = the id of the wave's rows; else: this lane's id of piece i
+  auto fetch_pages = [&](int t) -> Pages {
+    Pages r = {};
+    if (tile_fast(t)) {
+      r.pg[0] = pg_src[((t * kPTile + WR * wave + pos_base) >> pos_shift) + (lane >> 6)];  // (lane >> 6 = 0: a vector load)
+      return r;
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      int pos = t * kPTile + RP * (wave * PPW + i) + prow;
       pos = pos < last_key ? pos : last_key;
       r.pg[i] = pg_src[(pos + pos_base) >> pos_shift];
     }
     return r;
   };
-  auto issue_load = [&](int t, const Pages& pages, const char* cache, uint32_t s0, uint32_t st, int64_t base, v4i (&dst)[NCH]) {
+  // K and V pieces of tile t into buffer buf
+  auto stage_tile = [&](int t, int buf, const Pages& pages) {
+    const uint32_t kdst = lds0 + (uint32_t)(buf * TILE_BYTES + wave * PPW * 1024);
+    const uint32_t vdst = kdst + 2 * TILE_BYTES;
+    if (tile_fast(t)) {
+      const uint32_t pg = (uint32_t)__builtin_amdgcn_readfirstlane(pages.pg[0]);
+      const uint32_t cp = (uint32_t)((t * kPTile + WR * wave + pos_base) & pos_mask);
+      const char* kb_ = kcache + (int64_t)((uint64_t)pg * kpg + ((uint64_t)cp * kst + (uint64_t)kbase)) * 2;
+      const char* vb_ = vcache + (int64_t)((uint64_t)pg * vpg + ((uint64_t)cp * vst + (uint64_t)vbase)) * 2;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      int pos = t * kPTile + srow + RPP * i;
+      for (int i = 0; i < PPW; ++i) {
+        dma16s(voff_k[i], kb_, kdst + i * 1024);
+        dma16s(voff_v[i], vb_, vdst + i * 1024);
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      int pos = t * kPTile + RP * (wave * PPW + i) + prow;
       pos = pos < last_key ? pos : last_key;
       const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
-      const int64_t off = (int64_t)((uint64_t)(uint32_t)pages.pg[i] * s0 + ((uint64_t)cp * st + (uint64_t)(base + sch)));
-      dst[i] = *reinterpret_cast<const v4i*>(cache + off * 2);
-    }
-  };
-  auto write_k = [&](int buf, const v4i (&src)[NCH]) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + 512 * i;
-      const int row = c / CPR, ch = c % CPR;
-      const int key = D == 128 ? (row & 15) : ((row >> 1) & 7);
-      *reinterpret_cast<v4i*>(smem + buf * TILE_BYTES + row * ROWB + ((ch ^ key) << 4)) = src[i];
-    }
-  };
-  auto write_v = [&](int buf, const v4i (&src)[NCH]) {
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = tid + 512 * i;
-      const int row = c / CPR, ch = c % CPR;
-      const int key = D == 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2);
-      *reinterpret_cast<v4i*>(smem + (2 + buf) * TILE_BYTES + row * ROWB + ((ch ^ key) << 4)) = src[i];
+      const int64_t ko = (int64_t)((uint64_t)(uint32_t)pages.pg[i] * kpg + ((uint64_t)cp * kst + (uint64_t)kbase));
+      const int64_t vo = (int64_t)((uint64_t)(uint32_t)pages.pg[i] * vpg + ((uint64_t)cp * vst + (uint64_t)vbase));
+      dma16(kcache + ko * 2 + (k_chunk(i) << 4), kdst + i * 1024);
+      dma16(vcache + vo * 2 + (v_chunk << 4), vdst + i * 1024);
     }
   };
 
@@ -735,45 +797,32 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
   // Softmax reference m_ref (log2 units, per row): moved only when a tile's maximum passes it by more than kSlack
   // binades, so that the 64-register rescale of O^T is rare; weights are then at most 2^kSlack (exact arithmetic gives
   // the same result for any reference, the final normalisation divides it out).
-  constexpr float kSlack = 8.0f;
+  constexpr float kSlack = 8.0f;  // (256.0f below is 2^kSlack)
   float m_ref = -INFINITY, l_run = 0.f;
   const float log2e = 1.4426950408889634f;
   const float scale = p.scale, sc2 = scale * log2e;
 
-  // Schedule. Per wave and tile j: QK(j) (MFMA), softmax(j) (VALU), PV(j) (MFMA). The two waves of a SIMD (w, w + 4)
-  // take the workgroup's one barrier per tile at different places - waves 0..3 between softmax and PV, waves 4..7
-  // between QK and softmax - so that after every barrier one of them starts a matrix phase (PV(j), QK(j+1)) while the
-  // other starts its softmax: the matrix pipe and the VALU are shared by phase instead of both waves queueing for
-  // the same unit. Barrier j+1 is passed by everybody after QK(j) and before PV(j); K(j+1) and V(j) are written into
-  // their double buffers at the top of iteration j (between barriers j and j+1: K(j-1) and V(j-2) are dead by then,
-  // and the first readers come after barrier j+1); their global loads were issued one iteration earlier.
-  // (which two waves share a SIMD is the hardware's choice: the wave slot number HW_ID.wave_id tells them apart.
-  // Measured on the 16 x 4096 prefill, causal / full: this 817 / 942 TFLOP/s, waves 0..3 vs 4..7 809 / 917, even vs odd
-  // waves 777 / 872, no skew 783 / 900.)
-  const bool late_barrier = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) == 0;
-  v4i sk[NCH], sv[NCH];
-  Pages pg_v = {}, pg_k = {}, pg_pre = {};  // page ids of tiles t + 1, t + 2 and (in flight) t + 3
+  // Schedule. Per wave and tile j: QK(j) (MFMA), softmax(j) (VALU), PV(j) (MFMA), one workgroup barrier per tile. Up to
+  // round 3 a workgroup was 8 waves - two per SIMD, which took the barrier at different places (between QK and softmax /
+  // between softmax and PV, told apart by HW_ID.wave_id) so that one started a matrix phase while the other started its
+  // softmax: 817 / 942 TFLOP/s causal / full against 783 / 900 without the skew. With four waves a SIMD's two waves belong
+  // to two workgroups, which drift apart by themselves.
+  // Tile j lives in buffer j & 1. Iteration j: its pieces have landed (vmcnt(0)) and, behind the barrier, everybody's;
+  // everybody is also done with tile j - 1, whose buffer takes the pieces of tile j + 1 now - in flight for the whole of
+  // iteration j - with the page ids fetched in iteration j - 1; the ids of tile j + 2 are fetched next.
+  Pages pg_next = {};
   if (n_tiles > 0) {
-    pg_v = fetch_pages(t_lo);
-    pg_k = fetch_pages(t_lo + 1);
-    pg_pre = fetch_pages(t_lo + 2);
-    issue_load(t_lo, pg_v, kcache, kpg, kst, kbase, sk);
-    write_k(0, sk);
-    issue_load(t_lo + 1, pg_k, kcache, kpg, kst, kbase, sk);
-    issue_load(t_lo, pg_v, vcache, vpg, vst, vbase, sv);
-    pg_v = pg_k;
-    pg_k = pg_pre;
+    stage_tile(t_lo, 0, fetch_pages(t_lo));
+    if (n_tiles > 1) pg_next = fetch_pages(t_lo + 1);
   }
-  __syncthreads();
 
   for (int i = 0; i < n_tiles; ++i) {
     const int t = t_lo + i, buf = i & 1;
-    write_k(buf ^ 1, sk);
-    write_v(buf, sv);
-    issue_load(t + 2, pg_k, kcache, kpg, kst, kbase, sk);  // (past the end: clamped to the last key, never used)
-    issue_load(t + 1, pg_v, vcache, vpg, vst, vbase, sv);
-    pg_v = pg_k;
-    pg_k = fetch_pages(t + 3);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (i + 1 < n_tiles) {
+      stage_tile(t + 1, buf ^ 1, pg_next);
+      if (i + 2 < n_tiles) pg_next = fetch_pages(t + 2);
+    }
     const char* kb = smem + buf * TILE_BYTES;
     const char* vb = smem + (2 + buf) * TILE_BYTES;
 
@@ -805,13 +854,12 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
-    if (!late_barrier) lds_barrier();
 
     // ---- online softmax for row l31 (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each block)
     bool interior = wave_rows_ok && (t * kPTile + kPTile <= seqlen_k);
     if (p.causal_right >= 0) interior = interior && (t * kPTile + kPTile - 1 <= wave_qabs_lo + p.causal_right);
     if (p.window_left >= 0) interior = interior && (t * kPTile >= wave_qabs_hi - p.window_left);
-    if (!interior) {
+    if (__builtin_amdgcn_readfirstlane(interior ? 0 : 1)) {  // (uniform per wave)
       const int tb = t * kPTile + 4 * u;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
@@ -823,50 +871,72 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
         s1[v] = m1 ? -INFINITY : s1[v];
       }
     }
-    // (the VALU is this kernel's second bottleneck after the matrix pipe. Scores are scaled first: the maxima of products
-    // need no NaN canonicalisation (raw MFMA results get one v_max x, x each) and pair up into v_max3_f32. Scalar f32
-    // instructions on purpose - the file is built with -fno-slp-vectorize: next to MFMAs a v_pk_*_f32 costs more issue
-    // time than the two scalar instructions it replaces. No inline-asm VALU here: the hazard recogniser cannot see an
-    // asm read of a register an MFMA is still writing.)
-    float x0[16], x1[16];
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      x0[v] = s0[v] * sc2;  // -inf stays -inf (scale > 0)
-      x1[v] = s1[v] * sc2;
-    }
-    float mt = fmaxf(fmaxf(x0[0], x0[1]), x1[0]);
-    mt = fmaxf(mt, x1[1]);
-#pragma unroll
-    for (int v = 2; v < 16; v += 2) {
-      mt = fmaxf(fmaxf(mt, x0[v]), x0[v + 1]);
-      mt = fmaxf(fmaxf(mt, x1[v]), x1[v + 1]);
-    }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    if (__any(mt > m_ref + kSlack)) {  // (m_ref = -inf: any finite maximum moves it)
-      const float m_new = mt > m_ref + kSlack ? mt : m_ref;
-      const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
-      m_ref = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) o[db][v] *= alpha;
-    }
-    const float mneg = m_ref == -INFINITY ? 0.f : -m_ref;
+    // (Round 4: the weights are formed OPTIMISTICALLY against the running reference - y = s * scale - m_ref is one v_fma per
+    // score, no separate scaling product - and no maximum is taken in the common case (below); in the slow path the two
+    // lanes of a row exchange their maxima with v_permlane32_swap instead of a ds_bpermute (six VALU instructions of index
+    // arithmetic and an LDS round trip). 241 -> 153 vector instructions per tile with the scalar staging - and by itself that
+    // bought nothing at d = 128 (875 -> 881 TFLOP/s): the tile is not bound by its vector instruction count. Scalar f32
+    // instructions on purpose - the file is built with -fno-slp-vectorize: next to MFMAs a v_pk_*_f32 costs more issue time
+    // than the two scalar instructions it replaces. No inline-asm VALU on MFMA results: the hazard recogniser cannot see an
+    // asm read of a register an MFMA is still writing (the swap below reads VALU results).)
+    float mneg = m_ref == -INFINITY ? 0.f : -m_ref;
     float psum_a = 0.f, psum_b = 0.f;
     v8s pf[4];
+    auto weights = [&]() {
+      psum_a = 0.f;
+      psum_b = 0.f;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const float p0 = __builtin_amdgcn_exp2f(x0[v] + mneg);
-      const float p1 = __builtin_amdgcn_exp2f(x1[v] + mneg);
-      psum_a += p0;
-      psum_b += p1;
-      pf[v >> 3][v & 7] = M::cvt(p0);
-      pf[2 + (v >> 3)][v & 7] = M::cvt(p1);
+      for (int v = 0; v < 16; ++v) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[v], sc2, mneg));  // -inf stays -inf (scale > 0)
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[v], sc2, mneg));
+        psum_a += p0;
+        psum_b += p1;
+        pf[v >> 3][v & 7] = M::cvt(p0);
+        pf[2 + (v >> 3)][v & 7] = M::cvt(p1);
+      }
+    };
+    weights();
+    // No maximum in the common case: a lane whose 32 weights sum to at most 2^kSlack holds none above 2^kSlack, so its row
+    // does not ask for a new reference. Otherwise (or while a row has no reference yet: the sum then says nothing, the raw
+    // scores may all underflow) the wave takes the slow path - maxima, exchange, move, weights again.
+    if (__any(m_ref == -INFINITY || !(psum_a + psum_b <= 256.0f))) {
+      float x0[16], x1[16];  // (formed again, behind an opaque copy: kept from above they would cost the common path 32 registers)
+      float mneg_again = mneg;
+      asm volatile("" : "+v"(mneg_again));
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        x0[v] = __builtin_fmaf(s0[v], sc2, mneg_again);
+        x1[v] = __builtin_fmaf(s1[v], sc2, mneg_again);
+      }
+      float mt = fmaxf(fmaxf(x0[0], x0[1]), x1[0]);
+      mt = fmaxf(mt, x1[1]);
+#pragma unroll
+      for (int v = 2; v < 16; v += 2) {
+        mt = fmaxf(fmaxf(mt, x0[v]), x0[v + 1]);
+        mt = fmaxf(fmaxf(mt, x1[v]), x1[v + 1]);
+      }
+      {
+        float ma = mt, mb = mt;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma), "+v"(mb));
+        mt = fmaxf(ma, mb);  // (both halves of the wave now hold the row's maximum)
+      }
+      // mt is relative to the reference (absolute while there is none): move it when a tile passes it by kSlack binades
+      const bool moves = m_ref == -INFINITY ? mt > -INFINITY : mt > kSlack;
+      if (__any(moves)) {
+        const float m_new = moves ? (m_ref == -INFINITY ? mt : m_ref + mt) : m_ref;
+        const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
+        m_ref = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) o[db][v] *= alpha;
+        mneg = m_ref == -INFINITY ? 0.f : -m_ref;
+        weights();
+      }
     }
     const float psum = psum_a + psum_b;
     l_run += psum;
-    if (late_barrier) lds_barrier();
 
     // ---- O^T[dim, row] += V^T . P^T: k-slot order tau (see above): MFMA s4 takes tokens 32 (s4 / 2) + 16 (s4 % 2) + ...
     // MFMA m = 4 s4 + db (the four accumulators in turn); V^T fragments four MFMAs ahead
@@ -912,7 +982,7 @@ __global__ __launch_bounds__(512) void attn_prefill_kernel(AttnParams p, const T
     l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
   }
   const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
-  if (row_ok) {
+  if (row_ok && !(probe & 64)) {
     const int64_t tok = q_begin + my_qpos;
     T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)my_head * p.o_s1;
 #pragma unroll
@@ -982,8 +1052,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
   const int seqlen_q = cu_q[b + 1] - q_begin;
   int seqlen_k, k_begin = 0, cache_row = b, leftpad = 0;
   if (p.paged) {
-    if (p.kv_batch_idx != nullptr) cache_row = p.kv_batch_idx[b];
-    if (p.leftpad_k != nullptr) leftpad = p.leftpad_k[b];
+    if (p.kv_batch_idx != nullptr) cache_row = __builtin_amdgcn_readfirstlane(p.kv_batch_idx[b]);  // (uniform, and the
+    if (p.leftpad_k != nullptr) leftpad = __builtin_amdgcn_readfirstlane(p.leftpad_k[b]);          // compiler must know)
     seqlen_k = seq_k[b] - leftpad;
     seqlen_k = seqlen_k > 0 ? seqlen_k : 0;
   } else {
@@ -1025,7 +1095,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
     t_lo = a < t_hi ? a : t_hi;
     t_hi = e < t_hi ? e : t_hi;
   }
-  const int n_tiles = t_hi - t_lo;
+  t_lo = __builtin_amdgcn_readfirstlane(t_lo);  // (uniform, and the compiler has to know: the tile loop is then a scalar loop)
+  const int n_tiles = __builtin_amdgcn_readfirstlane(t_hi - t_lo);
   const int nw = n_tiles > wave ? (n_tiles - wave + NW - 1) / NW : 0;  // tiles of this wave: t_lo + wave + NW j
 
   const int pig = (0x2130 >> (4 * g4)) & 3;
@@ -1435,15 +1506,31 @@ static int launch(hipStream_t st, const AttnParams& p, const void* q, const void
   return SGLK_OK;
 }
 
+template <typename T, int D, int NW>
+static int launch_prefill_nw(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
+                             const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
+  constexpr int lds = 2 * 2 * kPTile * D * 2;  // 64 KiB (d = 64: 32 KiB)
+  static unsigned long long attr_done = 0;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D, NW>), lds, &attr_done, "fwd")) return rc;
+  dim3 grid((unsigned)cdiv(max_rows, 32 * NW), (unsigned)p.Hk, (unsigned)batch);
+  attn_prefill_kernel<T, D, NW><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  return check_launch("fwd(prefill)");
+}
+
+#ifdef SGLK_PROBES
+static int g_attn_prefill_waves = 0;  // 0: the policy below; 4 / 8: forced (sglk_debug_set_attn_prefill_waves)
+#else
+constexpr int g_attn_prefill_waves = 0;
+#endif
+
+// Four waves (128 rows) per workgroup, two workgroups per CU: see the kernel comment.
 template <typename T, int D>
 static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                           const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
-  constexpr int lds = 2 * 2 * kPTile * D * 2;  // 64 KiB (d = 64: 32 KiB)
-  static unsigned long long attr_done = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D>), lds, &attr_done, "fwd")) return rc;
-  dim3 grid((unsigned)cdiv(max_rows, kPBlockM), (unsigned)p.Hk, (unsigned)batch);
-  attn_prefill_kernel<T, D><<<grid, 512, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
-  return check_launch("fwd(prefill)");
+#ifdef SGLK_PROBES  // (the 8-wave form - one workgroup per CU - for A/B timing)
+  if (g_attn_prefill_waves == 8) return launch_prefill_nw<T, D, 8>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+#endif
+  return launch_prefill_nw<T, D, 4>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
 }
 
 template <typename T, int D, int KV8, int NW>
@@ -1465,8 +1552,10 @@ static int launch_decode_nw(hipStream_t st, const AttnParams& p, const void* q, 
 
 #ifdef SGLK_PROBES
 static int g_attn_decode_waves = 0;  // 0: the policy below; 4 / 8: forced (sglk_debug_set_attn_decode_waves)
+static int g_attn_prefill_probe = 0;  // attn_prefill_kernel's timing probes (sglk_debug_set_attn_prefill_probe)
 #else
 constexpr int g_attn_decode_waves = 0;
+constexpr int g_attn_prefill_probe = 0;
 #endif
 
 template <typename T, int D, int KV8>
@@ -1532,6 +1621,8 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
 // (256 tokens) per split. Prefill-sized problems never split.
 #ifdef SGLK_PROBES
 extern "C" SGLK_API void sglk_debug_set_attn_decode_waves(int w) { sglk::g_attn_decode_waves = w; }
+extern "C" SGLK_API void sglk_debug_set_attn_prefill_probe(int probe) { sglk::g_attn_prefill_probe = probe; }
+extern "C" SGLK_API void sglk_debug_set_attn_prefill_waves(int w) { sglk::g_attn_prefill_waves = w; }
 #endif
 
 extern "C" int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
@@ -1623,6 +1714,7 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
   p.splits = (int)num_splits;
   p.scale = softmax_scale;
   p.softcap = softcap;
+  p.probe = g_attn_prefill_probe;
   const int max_rows = (int)(max_seqlen_q * p.G);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16)

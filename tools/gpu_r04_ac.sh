@@ -1,0 +1,19 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/r04_ac
+mkdir -p $OUT
+export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
+cd $R
+for rep in 1 2; do
+for w in 8 4; do
+  echo "== waves $w"
+  ATTN_PREFILL_WAVES=$w LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_probes.so timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu
+done
+done | tee $OUT/prefill_waves.log
+for pr in 1 6 7 8 40 63; do
+  echo "== waves 4 probe $pr"
+  ATTN_PREFILL_ONLY=128 ATTN_PREFILL_WAVES=4 ATTN_PREFILL_PROBE=$pr LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_probes.so timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu
+done | tee -a $OUT/prefill_waves.log
+echo "== release"
+timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu | tee -a $OUT/prefill_waves.log
+timeout 1500 python3 -m pytest tests/test_attention_gpu.py tests/test_full_size_gpu.py -m gpu -q -x -n 4 2>&1 | tail -4
