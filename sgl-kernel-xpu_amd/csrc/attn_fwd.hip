@@ -589,15 +589,15 @@ struct Mfma32<f16> {
 // Head dim 64 (round 3; reference instantiations FMHAPrefillXe20.cmake): the same kernel with 128-byte LDS rows - 8 chunks per
 // row, one staging load per thread, tile and operand; K chunk c of row r at c ^ ((r >> 1) & 7) (rows two apart share their
 // banks), V chunk c at c ^ (((r >> 1) & 1) << 2); 8 + 8 MFMAs per wave and tile against the same softmax work.
-template <typename T, int D, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
+template <typename T, int D, int NW, int MB>  // NW waves of MB 32-row blocks
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
                                                            const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                            const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
                                                            const int32_t* __restrict__ page_table) {
   using M = Mfma<T>;
   using M32 = Mfma32<T>;
   constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, TILE_BYTES = kPTile * ROWB;
-  constexpr int kPBlockM = 32 * NW, NTH = 64 * NW;
+  constexpr int kPBlockM = 32 * MB * NW, NTH = 64 * NW;
   constexpr int CPR = D / 8, RPP = NTH / CPR, NCH = kPTile / RPP;  // 16-byte chunks per row, rows per pass, staging loads per thread
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][K tile, V tile]
   // probe (diagnostic build): 64 no output stores, 128 no Q loads (the probes of the tile loop - no softmax, no MFMAs, no
@@ -641,12 +641,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(
   const int row0 = (nblk - 1 - bx) * kPBlockM;  // longest rows first
   const int shift = seqlen_k - seqlen_q;
 
-  const int my_row = row0 + wave * 32 + l31;
-  const bool row_ok = my_row < rows_total;
-  const int my_qpos = row_ok ? my_row / G : 0;
-  const int my_head = hk * G + (row_ok ? my_row % G : 0);
-  const int q_abs = my_qpos + shift;
-  const int wrow_first = row0 + wave * 32, wrow_last = wrow_first + 31;
+  // (a lane owns row l31 of each of the wave's MB blocks)
+  int my_row[MB], my_qpos[MB], my_head[MB], q_abs[MB];
+  bool row_ok[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    my_row[mb] = row0 + wave * (32 * MB) + 32 * mb + l31;
+    row_ok[mb] = my_row[mb] < rows_total;
+    my_qpos[mb] = row_ok[mb] ? my_row[mb] / G : 0;
+    my_head[mb] = hk * G + (row_ok[mb] ? my_row[mb] % G : 0);
+    q_abs[mb] = my_qpos[mb] + shift;
+  }
+  const int wrow_first = row0 + wave * (32 * MB), wrow_last = wrow_first + 32 * MB - 1;
   const bool wave_rows_ok = wrow_last < rows_total;
   const int wave_qabs_lo = wrow_first / G + shift, wave_qabs_hi = (wrow_last < rows_total ? wrow_last : rows_total - 1) / G + shift;
 
@@ -668,14 +674,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(
   const int n_tiles = t_hi - t_lo;  // (uniform, and the compiler has to know: the tile loop is then a scalar loop)
 
   // ---- Q^T fragments (B operand of K . Q^T): lane supplies q[row l31][16 ks + 8 u .. + 8)
-  v8s qf[KS];
-  {
-    const T* qrow = q + (int64_t)(q_begin + my_qpos) * p.q_s0 + (int64_t)my_head * p.q_s1;
+  v8s qf[MB][KS];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const T* qrow = q + (int64_t)(q_begin + my_qpos[mb]) * p.q_s0 + (int64_t)my_head[mb] * p.q_s1;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       v8s v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (row_ok && !(probe & 128)) v = *reinterpret_cast<const v8s*>(qrow + 16 * ks + 8 * u);
-      qf[ks] = v;
+      if (row_ok[mb] && !(probe & 128)) v = *reinterpret_cast<const v8s*>(qrow + 16 * ks + 8 * u);
+      qf[mb][ks] = v;
     }
   }
 
@@ -789,16 +796,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(
   const int vlane_off = (4 * u + qq) * ROWB + 8 * (pp & 1);  // + token group offsets below; row & 3 == qq
   const int vchunk_lo = 2 * hh + (pp >> 1);                  // chunk = 4 db + vchunk_lo, swizzled with qq << 2
 
-  v16f o[DB];
+  v16f o[MB][DB];
 #pragma unroll
-  for (int db = 0; db < DB; ++db)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) o[db][v] = 0.f;
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) o[mb][db][v] = 0.f;
   // Softmax reference m_ref (log2 units, per row): moved only when a tile's maximum passes it by more than kSlack
   // binades, so that the 64-register rescale of O^T is rare; weights are then at most 2^kSlack (exact arithmetic gives
   // the same result for any reference, the final normalisation divides it out).
   constexpr float kSlack = 8.0f;  // (256.0f below is 2^kSlack)
-  float m_ref = -INFINITY, l_run = 0.f;
+  float m_ref[MB], l_run[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) { m_ref[mb] = -INFINITY; l_run[mb] = 0.f; }
   const float log2e = 1.4426950408889634f;
   const float scale = p.scale, sc2 = scale * log2e;
 
@@ -827,9 +838,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(
     const char* vb = smem + (2 + buf) * TILE_BYTES;
 
     // ---- S^T[token, row] = K . Q^T: two 32-token blocks; K fragments two k-steps ahead of their MFMAs
-    v16f s0, s1;
+    v16f s0[MB], s1[MB];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { s0[v] = 0.f; s1[v] = 0.f; }
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { s0[mb][v] = 0.f; s1[mb][v] = 0.f; }
     {
       v8s ka[2][2];
       auto read_k = [&](int ks, v8s (&dst)[2]) {
@@ -841,35 +854,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(
       read_k(1, ka[1]);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s0 = M32::run(ka[ks & 1][0], qf[ks], s0);
-        s1 = M32::run(ka[ks & 1][1], qf[ks], s1);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          s0[mb] = M32::run(ka[ks & 1][0], qf[mb][ks], s0[mb]);
+          s1[mb] = M32::run(ka[ks & 1][1], qf[mb][ks], s1[mb]);
+        }
         if (ks + 2 < KS) read_k(ks + 2, ka[ks & 1]);
       }
       // keep that order: the scheduler otherwise sinks every read below the MFMAs in front of it
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
       for (int ks = 0; ks < KS - 2; ++ks) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MB, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MB, 0);
     }
 
-    // ---- online softmax for row l31 (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each block)
+    // ---- online softmax for row l31 of each block (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each 32-token block)
     bool interior = wave_rows_ok && (t * kPTile + kPTile <= seqlen_k);
     if (p.causal_right >= 0) interior = interior && (t * kPTile + kPTile - 1 <= wave_qabs_lo + p.causal_right);
     if (p.window_left >= 0) interior = interior && (t * kPTile >= wave_qabs_hi - p.window_left);
     if (__builtin_amdgcn_readfirstlane(interior ? 0 : 1)) {  // (uniform per wave)
       const int tb = t * kPTile + 4 * u;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int k0 = tb + 8 * (v >> 2) + (v & 3), k1 = k0 + 32;
-        bool m0 = !row_ok || k0 >= seqlen_k, m1 = !row_ok || k1 >= seqlen_k;
-        if (p.causal_right >= 0) { m0 |= k0 > q_abs + p.causal_right; m1 |= k1 > q_abs + p.causal_right; }
-        if (p.window_left >= 0) { m0 |= k0 < q_abs - p.window_left; m1 |= k1 < q_abs - p.window_left; }
-        s0[v] = m0 ? -INFINITY : s0[v];
-        s1[v] = m1 ? -INFINITY : s1[v];
-      }
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int k0 = tb + 8 * (v >> 2) + (v & 3), k1 = k0 + 32;
+          bool m0 = !row_ok[mb] || k0 >= seqlen_k, m1 = !row_ok[mb] || k1 >= seqlen_k;
+          if (p.causal_right >= 0) { m0 |= k0 > q_abs[mb] + p.causal_right; m1 |= k1 > q_abs[mb] + p.causal_right; }
+          if (p.window_left >= 0) { m0 |= k0 < q_abs[mb] - p.window_left; m1 |= k1 < q_abs[mb] - p.window_left; }
+          s0[mb][v] = m0 ? -INFINITY : s0[mb][v];
+          s1[mb][v] = m1 ? -INFINITY : s1[mb][v];
+        }
     }
     // (Round 4: the weights are formed OPTIMISTICALLY against the running reference - y = s * scale - m_ref is one v_fma per
     // score, no separate scaling product - and no maximum is taken in the common case (below); in the slow path the two
@@ -879,67 +897,69 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(
     // instructions on purpose - the file is built with -fno-slp-vectorize: next to MFMAs a v_pk_*_f32 costs more issue time
     // than the two scalar instructions it replaces. No inline-asm VALU on MFMA results: the hazard recogniser cannot see an
     // asm read of a register an MFMA is still writing (the swap below reads VALU results).)
-    float mneg = m_ref == -INFINITY ? 0.f : -m_ref;
-    float psum_a = 0.f, psum_b = 0.f;
-    v8s pf[4];
-    auto weights = [&]() {
-      psum_a = 0.f;
-      psum_b = 0.f;
+    v8s pf[MB][4];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[v], sc2, mneg));  // -inf stays -inf (scale > 0)
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[v], sc2, mneg));
-        psum_a += p0;
-        psum_b += p1;
-        pf[v >> 3][v & 7] = M::cvt(p0);
-        pf[2 + (v >> 3)][v & 7] = M::cvt(p1);
-      }
-    };
-    weights();
-    // No maximum in the common case: a lane whose 32 weights sum to at most 2^kSlack holds none above 2^kSlack, so its row
-    // does not ask for a new reference. Otherwise (or while a row has no reference yet: the sum then says nothing, the raw
-    // scores may all underflow) the wave takes the slow path - maxima, exchange, move, weights again.
-    if (__any(m_ref == -INFINITY || !(psum_a + psum_b <= 256.0f))) {
-      float x0[16], x1[16];  // (formed again, behind an opaque copy: kept from above they would cost the common path 32 registers)
-      float mneg_again = mneg;
-      asm volatile("" : "+v"(mneg_again));
+    for (int mb = 0; mb < MB; ++mb) {
+      float mneg = m_ref[mb] == -INFINITY ? 0.f : -m_ref[mb];
+      float psum_a = 0.f, psum_b = 0.f;
+      auto weights = [&]() {
+        psum_a = 0.f;
+        psum_b = 0.f;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        x0[v] = __builtin_fmaf(s0[v], sc2, mneg_again);
-        x1[v] = __builtin_fmaf(s1[v], sc2, mneg_again);
-      }
-      float mt = fmaxf(fmaxf(x0[0], x0[1]), x1[0]);
-      mt = fmaxf(mt, x1[1]);
+        for (int v = 0; v < 16; ++v) {
+          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[mb][v], sc2, mneg));  // -inf stays -inf (scale > 0)
+          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[mb][v], sc2, mneg));
+          psum_a += p0;
+          psum_b += p1;
+          pf[mb][v >> 3][v & 7] = M::cvt(p0);
+          pf[mb][2 + (v >> 3)][v & 7] = M::cvt(p1);
+        }
+      };
+      weights();
+      // No maximum in the common case: a lane whose 32 weights sum to at most 2^kSlack holds none above 2^kSlack, so its row
+      // does not ask for a new reference. Otherwise (or while a row has no reference yet: the sum then says nothing, the raw
+      // scores may all underflow) the wave takes the slow path - maxima, exchange, move, weights again.
+      if (__any(m_ref[mb] == -INFINITY || !(psum_a + psum_b <= 256.0f))) {
+        float x0[16], x1[16];  // (formed again, behind an opaque copy: kept from above they would cost the common path 32 registers)
+        float mneg_again = mneg;
+        asm volatile("" : "+v"(mneg_again));
 #pragma unroll
-      for (int v = 2; v < 16; v += 2) {
-        mt = fmaxf(fmaxf(mt, x0[v]), x0[v + 1]);
-        mt = fmaxf(fmaxf(mt, x1[v]), x1[v + 1]);
-      }
-      {
-        float ma = mt, mb = mt;
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma), "+v"(mb));
-        mt = fmaxf(ma, mb);  // (both halves of the wave now hold the row's maximum)
-      }
-      // mt is relative to the reference (absolute while there is none): move it when a tile passes it by kSlack binades
-      const bool moves = m_ref == -INFINITY ? mt > -INFINITY : mt > kSlack;
-      if (__any(moves)) {
-        const float m_new = moves ? (m_ref == -INFINITY ? mt : m_ref + mt) : m_ref;
-        const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_ref - m_new);
-        m_ref = m_new;
-        l_run *= alpha;
+        for (int v = 0; v < 16; ++v) {
+          x0[v] = __builtin_fmaf(s0[mb][v], sc2, mneg_again);
+          x1[v] = __builtin_fmaf(s1[mb][v], sc2, mneg_again);
+        }
+        float mt = fmaxf(fmaxf(x0[0], x0[1]), x1[0]);
+        mt = fmaxf(mt, x1[1]);
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int v = 2; v < 16; v += 2) {
+          mt = fmaxf(fmaxf(mt, x0[v]), x0[v + 1]);
+          mt = fmaxf(fmaxf(mt, x1[v]), x1[v + 1]);
+        }
+        {
+          float ma = mt, mb_ = mt;
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma), "+v"(mb_));
+          mt = fmaxf(ma, mb_);  // (both halves of the wave now hold the row's maximum)
+        }
+        // mt is relative to the reference (absolute while there is none): move it when a tile passes it by kSlack binades
+        const bool moves = m_ref[mb] == -INFINITY ? mt > -INFINITY : mt > kSlack;
+        if (__any(moves)) {
+          const float m_new = moves ? (m_ref[mb] == -INFINITY ? mt : m_ref[mb] + mt) : m_ref[mb];
+          const float alpha = m_new == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m_ref[mb] - m_new);
+          m_ref[mb] = m_new;
+          l_run[mb] *= alpha;
 #pragma unroll
-          for (int v = 0; v < 16; ++v) o[db][v] *= alpha;
-        mneg = m_ref == -INFINITY ? 0.f : -m_ref;
-        weights();
+          for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o[mb][db][v] *= alpha;
+          mneg = m_ref[mb] == -INFINITY ? 0.f : -m_ref[mb];
+          weights();
+        }
       }
+      l_run[mb] += psum_a + psum_b;
     }
-    const float psum = psum_a + psum_b;
-    l_run += psum;
 
     // ---- O^T[dim, row] += V^T . P^T: k-slot order tau (see above): MFMA s4 takes tokens 32 (s4 / 2) + 16 (s4 % 2) + ...
-    // MFMA m = 4 s4 + db (the four accumulators in turn); V^T fragments four MFMAs ahead
+    // step m = 4 s4 + db (the four accumulators in turn), MB MFMAs per V^T fragment; fragments four steps ahead
     {
       v8s vf[4];
       auto read_v = [&](int m, v8s& dst) {
@@ -956,46 +976,49 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_prefill_kernel(
       for (int m = 0; m < 4; ++m) read_v(m, vf[m]);
 #pragma unroll
       for (int m = 0; m < NPV; ++m) {
-        o[m % DB] = M32::run(vf[m & 3], pf[m / DB], o[m % DB]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) o[mb][m % DB] = M32::run(vf[m & 3], pf[mb][m / DB], o[mb][m % DB]);
         if (m + 4 < NPV) read_v(m + 4, vf[m & 3]);
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
       for (int m = 0; m < NPV - 4; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MB, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * MB, 0);
     }
   }
-  const float m_run = m_ref == -INFINITY ? -INFINITY : m_ref * 0.6931471805599453f;  // the reference in natural-log units
 
   // ---- epilogue (as the kernel above; the two lanes of a row hold partial sums)
-  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float m_fin = m_run;
-  float lse_val = (l_tot > 0.f && m_fin != -INFINITY) ? m_fin + logf(l_tot) : -INFINITY;
-  if (p.sinks != nullptr && row_ok) {
-    const float sk = p.sinks[my_head];
-    const float m2 = fmaxf(m_fin, sk);
-    const float l2 = l_tot * __builtin_amdgcn_exp2f((m_fin - m2) * log2e) + __builtin_amdgcn_exp2f((sk - m2) * log2e);
-    lse_val = m2 + logf(l2);
-    l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
-  }
-  const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
-  if (row_ok && !(probe & 64)) {
-    const int64_t tok = q_begin + my_qpos;
-    T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)my_head * p.o_s1;
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {  // dims 32 db + 8 g + 4 u .. + 3
-        Vec<T, 4> ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (T)(o[db][4 * g + r] * inv_l);
-        store_vec<T, 4>(orow + 32 * db + 8 * g + 4 * u, ov);
-      }
+  for (int mb = 0; mb < MB; ++mb) {
+    const float m_fin = m_ref[mb] == -INFINITY ? -INFINITY : m_ref[mb] * 0.6931471805599453f;  // the reference in natural-log units
+    float l_tot = l_run[mb] + __shfl_xor(l_run[mb], 32, 64);
+    float lse_val = (l_tot > 0.f && m_fin != -INFINITY) ? m_fin + logf(l_tot) : -INFINITY;
+    if (p.sinks != nullptr && row_ok[mb]) {
+      const float sk = p.sinks[my_head[mb]];
+      const float m2 = fmaxf(m_fin, sk);
+      const float l2 = l_tot * __builtin_amdgcn_exp2f((m_fin - m2) * log2e) + __builtin_amdgcn_exp2f((sk - m2) * log2e);
+      lse_val = m2 + logf(l2);
+      l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
     }
-    if (u == 0) p.lse[(int64_t)my_head * p.total_q + tok] = lse_val;
+    const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
+    if (row_ok[mb] && !(probe & 64)) {
+      const int64_t tok = q_begin + my_qpos[mb];
+      T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)my_head[mb] * p.o_s1;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // dims 32 db + 8 g + 4 u .. + 3
+          Vec<T, 4> ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = (T)(o[mb][db][4 * g + r] * inv_l);
+          store_vec<T, 4>(orow + 32 * db + 8 * g + 4 * u, ov);
+        }
+      }
+      if (u == 0) p.lse[(int64_t)my_head[mb] * p.total_q + tok] = lse_val;
+    }
   }
 }
 
@@ -1506,19 +1529,19 @@ static int launch(hipStream_t st, const AttnParams& p, const void* q, const void
   return SGLK_OK;
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, int MB>
 static int launch_prefill_nw(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                              const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
   constexpr int lds = 2 * 2 * kPTile * D * 2;  // 64 KiB (d = 64: 32 KiB)
   static unsigned long long attr_done = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D, NW>), lds, &attr_done, "fwd")) return rc;
-  dim3 grid((unsigned)cdiv(max_rows, 32 * NW), (unsigned)p.Hk, (unsigned)batch);
-  attn_prefill_kernel<T, D, NW><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D, NW, MB>), lds, &attr_done, "fwd")) return rc;
+  dim3 grid((unsigned)cdiv(max_rows, 32 * MB * NW), (unsigned)p.Hk, (unsigned)batch);
+  attn_prefill_kernel<T, D, NW, MB><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   return check_launch("fwd(prefill)");
 }
 
 #ifdef SGLK_PROBES
-static int g_attn_prefill_waves = 0;  // 0: the policy below; 4 / 8: forced (sglk_debug_set_attn_prefill_waves)
+static int g_attn_prefill_waves = 0;  // 0: the policy below; 4 / 8: forced; 64: four waves of 64 rows (sglk_debug_set_attn_prefill_waves)
 #else
 constexpr int g_attn_prefill_waves = 0;
 #endif
@@ -1528,9 +1551,10 @@ template <typename T, int D>
 static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                           const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
 #ifdef SGLK_PROBES  // (the 8-wave form - one workgroup per CU - for A/B timing)
-  if (g_attn_prefill_waves == 8) return launch_prefill_nw<T, D, 8>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (g_attn_prefill_waves == 8) return launch_prefill_nw<T, D, 8, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if (g_attn_prefill_waves == 64) return launch_prefill_nw<T, D, 4, 2>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
 #endif
-  return launch_prefill_nw<T, D, 4>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  return launch_prefill_nw<T, D, 4, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
 }
 
 template <typename T, int D, int KV8, int NW>
