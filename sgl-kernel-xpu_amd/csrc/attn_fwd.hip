@@ -567,7 +567,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 // Round 4, measured and dropped: the weights of a block formed in the gaps of the next block's MFMAs (840
 // against 910 TFLOP/s - a wave's vector and matrix instructions do not overlap on this part, interleaved or not, and
 // the interleaved form waits for every fragment read); the first fragments of a phase requested ahead of the scalar work
-// in front of it (d = 128 unchanged, d = 64 -15 %).
+// in front of it (d = 128 unchanged, d = 64 -15 %); MB = 2 (64 rows per wave, one workgroup per CU, the compiler allocating the
+// 512 registers): 353 TFLOP/s - ~170 v_accvgpr moves per tile and nobody to overlap with; that form needs asm-owned AGPR
+// accumulators and a hand-placed schedule (mla_rows128x_kernel). MB = 2 stays instantiated in the diagnostic build only.
 constexpr int kPTile = 64;  // (a workgroup takes 32 NW packed rows)
 
 
@@ -1589,11 +1591,12 @@ constexpr int g_attn_prefill_probe = 0;
 template <typename T, int D, int KV8>
 static int launch_decode(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                          const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch) {
-  // eight waves where a tile is small (d = 64, fp8 cache at d <= 128); d = 256 needs the whole register file with four
+#ifdef SGLK_PROBES  // (eight waves, diagnostic build only: measured no faster, see the kernel comment; d = 256 needs the whole
+  // register file with four)
   if constexpr (D <= 128) {
-    const bool eight = g_attn_decode_waves == 8;  // (diagnostic build only: measured no faster, see the kernel comment)
-    if (eight) return launch_decode_nw<T, D, KV8, 8>(st, p, q, k, v, cu_q, seq_k, table, batch);
+    if (g_attn_decode_waves == 8) return launch_decode_nw<T, D, KV8, 8>(st, p, q, k, v, cu_q, seq_k, table, batch);
   }
+#endif
   return launch_decode_nw<T, D, KV8, 4>(st, p, q, k, v, cu_q, seq_k, table, batch);
 }
 
@@ -1601,8 +1604,8 @@ template <typename T>
 static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                         const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows, int kv8) {
   const int d = p.D;
-  // prefill-sized problems at head dim 128 (Llama-3 / BASELINE configs[2]): the 256-row kernel. A row block must be worth
-  // filling: at least 128 packed rows per (sequence, kv head) at the longest sequence.
+  // prefill-sized problems at head dim 128 / 64 (Llama-3 / BASELINE configs[2]): the 128-row-block kernel. A row block must be
+  // worth filling: at least 128 packed rows per (sequence, kv head) at the longest sequence.
   if (kv8 == 0 && (d == 128 || d == 64) && p.splits == 1 && p.softcap <= 0.f && max_rows >= 128 && p.q_s0 % 8 == 0 &&
       p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0)
     return d == 128 ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
