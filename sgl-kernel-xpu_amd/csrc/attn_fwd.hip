@@ -832,10 +832,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
   for (int i = 0; i < n_tiles; ++i) {
     const int t = t_lo + i, buf = i & 1;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (i + 1 < n_tiles) {
-      stage_tile(t + 1, buf ^ 1, pg_next);
-      if (i + 2 < n_tiles) pg_next = fetch_pages(t + 2);
-    }
+    auto stage_next = [&]() {
+      if (i + 1 < n_tiles) {
+        stage_tile(t + 1, buf ^ 1, pg_next);
+        if (i + 2 < n_tiles) pg_next = fetch_pages(t + 2);
+      }
+    };
+    const int dma_at = (probe >> 8) & 3;  // (diagnostic build: 0 behind the barrier, 1 behind QK, 2 behind the softmax)
+    if (dma_at == 0) stage_next();
     const char* kb = smem + buf * TILE_BYTES;
     const char* vb = smem + (2 + buf) * TILE_BYTES;
 
@@ -875,6 +879,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * kKA * MB, 0);
     }
+
+    if (dma_at == 1) stage_next();
 
     // ---- online softmax for row l31 of each block (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each 32-token block)
     bool interior = wave_rows_ok && (t * kPTile + kPTile <= seqlen_k);
@@ -962,6 +968,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
       }
       l_run[mb] += psum_a + psum_b;
     }
+
+    if (dma_at == 2) stage_next();
 
     // ---- O^T[dim, row] += V^T . P^T: k-slot order tau (see above): MFMA s4 takes tokens 32 (s4 / 2) + 16 (s4 % 2) + ...
     // step m = 4 s4 + db (the four accumulators in turn), MB MFMAs per V^T fragment; fragments four steps ahead
