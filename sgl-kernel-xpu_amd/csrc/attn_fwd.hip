@@ -94,6 +94,7 @@ struct AttnParams {
   float scale;          // softmax scale
   float softcap;        // 0 = off
   int probe;            // libsglk_probes.so only (0 in the release library): attn_prefill_kernel timing probes, garbage results
+  unsigned long long* stamps;  // libsglk_probes.so only: per-wave cycle sums of the prefill tile loop's segments, or null
 };
 
 // DKP: head dim rounded up to 32 (k-steps of the QK product); the V/O side uses ceil(D/16) 16-wide tiles.
@@ -790,6 +791,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
     }
   };
 
+  // Fast tiles, spread form: the bases now, piece j (K pieces first) wherever the caller puts it. Stamped (diagnostic build): the
+  // 8 pieces of a d = 128 tile issued back to back held the wave for ~1400 cycles per tile - an LDS-DMA instruction issues in
+  // ~170 cycles behind another one - a third of the stamped loop; between the softmax's vector instructions the pieces are
+  // ~145 cycles apart and the wave does not wait for them.
+  struct Spread { const char* kb; const char* vb; uint32_t kdst; };
+  auto spread_begin = [&](int t, int buf, const Pages& pages) -> Spread {
+    Spread r;
+    const uint32_t pg = (uint32_t)__builtin_amdgcn_readfirstlane(pages.pg[0]);
+    const uint32_t cp = (uint32_t)((t * kPTile + WR * wave + pos_base) & pos_mask);
+    r.kb = kcache + (int64_t)((uint64_t)pg * kpg + ((uint64_t)cp * kst + (uint64_t)kbase)) * 2;
+    r.vb = vcache + (int64_t)((uint64_t)pg * vpg + ((uint64_t)cp * vst + (uint64_t)vbase)) * 2;
+    r.kdst = lds0 + (uint32_t)(buf * TILE_BYTES + wave * PPW * 1024);
+    return r;
+  };
+  auto spread_piece = [&](const Spread& sp, int j) {  // j < 2 PPW
+    if (j < PPW) dma16s(voff_k[j], sp.kb, sp.kdst + j * 1024);
+    else dma16s(voff_v[j - PPW], sp.vb, sp.kdst + 2 * TILE_BYTES + (j - PPW) * 1024);
+  };
+
   // ---- per-lane LDS read offsets
   // K (A operand of K . Q^T): token row 32 beta + l31, chunk 2 ks + u at position chunk ^ (row & 15)
   const int krow_off = l31 * ROWB, kkey = D == 128 ? (l31 & 15) : ((l31 >> 1) & 7);  // (32 beta does not change the key)
@@ -829,19 +849,31 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
     if (n_tiles > 1) pg_next = fetch_pages(t_lo + 1);
   }
 
+#ifdef SGLK_PROBES
+  // in-kernel stamps (guide 7, 'In-kernel stamps'): cycle sums of the tile loop's segments in scalar registers, stored once by
+  // lane 0 of every wave. Read the SHARES: the fences forbid overlaps the real loop has.
+  unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_prev = 0;
+  const bool st_on = p.stamps != nullptr;
+#define PF_STAMP(k)                                                                            \
+  if (st_on) {                                                                                 \
+    unsigned long long now_;                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if ((k) >= 0) st_sum[(k) < 0 ? 0 : (k)] += now_ - st_prev;                                 \
+    st_prev = now_;                                                                            \
+  }
+#else
+#define PF_STAMP(k)
+#endif
   for (int i = 0; i < n_tiles; ++i) {
     const int t = t_lo + i, buf = i & 1;
+    PF_STAMP(-1)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    auto stage_next = [&]() {
-      if (i + 1 < n_tiles) {
-        stage_tile(t + 1, buf ^ 1, pg_next);
-        if (i + 2 < n_tiles) pg_next = fetch_pages(t + 2);
-      }
-    };
-    // where the next tile's DMA is issued: behind QK (1). Behind the barrier (probe 768 of the diagnostic build) measured
-    // 892 - 904 against 906 - 908 TFLOP/s at d = 128 and 830 against 840 at d = 64, behind the softmax (512) 896 - 902 / 814 - 832
-    const int dma_at = (probe >> 8) & 3 ? (probe >> 8) & 3 : 1;
-    if (dma_at == 3) stage_next();
+    PF_STAMP(0)
+    // the next tile's staging: a fast tile's pieces ride in the softmax of the wave's first row block (below); any other
+    // tile's go out together behind QK
+    const bool next_tile = i + 1 < n_tiles, spread = next_tile && tile_fast(t + 1);
     const char* kb = smem + buf * TILE_BYTES;
     const char* vb = smem + (2 + buf) * TILE_BYTES;
 
@@ -882,7 +914,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * kKA * MB, 0);
     }
 
-    if (dma_at == 1) stage_next();
+    PF_STAMP(1)
+    Spread sp = {};
+    if (spread) sp = spread_begin(t + 1, buf ^ 1, pg_next);
+    else if (next_tile) stage_tile(t + 1, buf ^ 1, pg_next);
+    if (next_tile && i + 2 < n_tiles) pg_next = fetch_pages(t + 2);
+    PF_STAMP(2)
 
     // ---- online softmax for row l31 of each block (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each 32-token block)
     bool interior = wave_rows_ok && (t * kPTile + kPTile <= seqlen_k);
@@ -910,25 +947,46 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
     // instructions on purpose - the file is built with -fno-slp-vectorize: next to MFMAs a v_pk_*_f32 costs more issue time
     // than the two scalar instructions it replaces. No inline-asm VALU on MFMA results: the hazard recogniser cannot see an
     // asm read of a register an MFMA is still writing (the swap below reads VALU results).)
-    v8s pf[MB][4];
+    typedef short v2s_ __attribute__((ext_vector_type(2)));
+    int pw[MB][16];  // rounded weights as dwords: block b, tokens 2 j, 2 j + 1 -> pw[8 b + j]; B fragment h = pw[4 h .. 4 h + 3]
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       float mneg = m_ref[mb] == -INFINITY ? 0.f : -m_ref[mb];
       float psum_a = 0.f, psum_b = 0.f;
-      auto weights = [&]() {
+      auto weights = [&](bool with_dma) {
         psum_a = 0.f;
         psum_b = 0.f;
+        // in steps of two tokens per block (14 vector instructions); with_dma: one DMA piece of the next tile behind every
+        // 8 / (2 PPW)-th step, the steps pinned where they are written (opaque copies of the reference in front, of the results
+        // behind: the optimiser would otherwise hoist all the fmas above the first piece and sink sums and roundings below the last)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[mb][v], sc2, mneg));  // -inf stays -inf (scale > 0)
-          const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[mb][v], sc2, mneg));
-          psum_a += p0;
-          psum_b += p1;
-          pf[mb][v >> 3][v & 7] = M::cvt(p0);
-          pf[mb][2 + (v >> 3)][v & 7] = M::cvt(p1);
+        for (int st = 0; st < 8; ++st) {
+          float mg = mneg;
+          if (with_dma) asm volatile("" : "+v"(mg));
+          const int v = 2 * st;
+          const float p0a = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[mb][v], sc2, mg));  // -inf stays -inf (scale > 0)
+          const float p0b = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[mb][v + 1], sc2, mg));
+          const float p1a = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[mb][v], sc2, mg));
+          const float p1b = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[mb][v + 1], sc2, mg));
+          psum_a += p0a;
+          psum_b += p1a;
+          psum_a += p0b;
+          psum_b += p1b;
+          const v2s_ r0 = {M::cvt(p0a), M::cvt(p0b)}, r1 = {M::cvt(p1a), M::cvt(p1b)};
+          int k0 = __builtin_bit_cast(int, r0), k1 = __builtin_bit_cast(int, r1);
+          if (with_dma) asm volatile("" : "+v"(k0), "+v"(k1), "+v"(psum_a), "+v"(psum_b));
+          pw[mb][st] = k0;
+          pw[mb][8 + st] = k1;
+          constexpr int kEvery = 8 / (2 * PPW);
+          if (mb == 0 && with_dma && st % kEvery == kEvery - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            spread_piece(sp, st / kEvery);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       };
-      weights();
+      if (spread) weights(true);
+      else weights(false);
       // No maximum in the common case: a lane whose 32 weights sum to at most 2^kSlack holds none above 2^kSlack, so its row
       // does not ask for a new reference. Otherwise (or while a row has no reference yet: the sum then says nothing, the raw
       // scores may all underflow) the wave takes the slow path - maxima, exchange, move, weights again.
@@ -965,13 +1023,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
 #pragma unroll
             for (int v = 0; v < 16; ++v) o[mb][db][v] *= alpha;
           mneg = m_ref[mb] == -INFINITY ? 0.f : -m_ref[mb];
-          weights();
+          weights(false);
         }
       }
       l_run[mb] += psum_a + psum_b;
     }
 
-    if (dma_at == 2) stage_next();
+    PF_STAMP(3)
 
     // ---- O^T[dim, row] += V^T . P^T: k-slot order tau (see above): MFMA s4 takes tokens 32 (s4 / 2) + 16 (s4 % 2) + ...
     // step m = 4 s4 + db (the four accumulators in turn), MB MFMAs per V^T fragment; fragments four steps ahead
@@ -993,7 +1051,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
 #pragma unroll
       for (int m = 0; m < NPV; ++m) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) o[mb][m % DB] = M32::run(vf[m % kVA], pf[mb][m / DB], o[mb][m % DB]);
+        for (int mb = 0; mb < MB; ++mb) {
+          const v4i w4 = {pw[mb][4 * (m / DB)], pw[mb][4 * (m / DB) + 1], pw[mb][4 * (m / DB) + 2], pw[mb][4 * (m / DB) + 3]};
+          o[mb][m % DB] = M32::run(vf[m % kVA], __builtin_bit_cast(v8s, w4), o[mb][m % DB]);
+        }
         if (m + kVA < NPV) read_v(m + kVA, vf[m % kVA]);
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * kVA, 0);
@@ -1004,7 +1065,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
       }
       __builtin_amdgcn_sched_group_barrier(0x008, kVA * MB, 0);
     }
+    PF_STAMP(4)
   }
+#ifdef SGLK_PROBES
+  if (st_on && lane == 0) {
+    unsigned long long* dst = p.stamps + ((int64_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * NW + wave) * 8;
+    for (int k = 0; k < 5; ++k) dst[k] = st_sum[k];
+    dst[5] = (unsigned long long)n_tiles;
+    dst[6] = (unsigned long long)bx;
+  }
+#endif
+#undef PF_STAMP
 
   // ---- epilogue (as the kernel above; the two lanes of a row hold partial sums)
 #pragma unroll
@@ -1593,9 +1664,11 @@ static int launch_decode_nw(hipStream_t st, const AttnParams& p, const void* q, 
 #ifdef SGLK_PROBES
 static int g_attn_decode_waves = 0;  // 0: the policy below; 4 / 8: forced (sglk_debug_set_attn_decode_waves)
 static int g_attn_prefill_probe = 0;  // attn_prefill_kernel's timing probes (sglk_debug_set_attn_prefill_probe)
+static unsigned long long* g_attn_prefill_stamps = nullptr;  // (sglk_debug_set_attn_prefill_stamps)
 #else
 constexpr int g_attn_decode_waves = 0;
 constexpr int g_attn_prefill_probe = 0;
+constexpr unsigned long long* g_attn_prefill_stamps = nullptr;
 #endif
 
 template <typename T, int D, int KV8>
@@ -1664,6 +1737,7 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
 extern "C" SGLK_API void sglk_debug_set_attn_decode_waves(int w) { sglk::g_attn_decode_waves = w; }
 extern "C" SGLK_API void sglk_debug_set_attn_prefill_probe(int probe) { sglk::g_attn_prefill_probe = probe; }
 extern "C" SGLK_API void sglk_debug_set_attn_prefill_waves(int w) { sglk::g_attn_prefill_waves = w; }
+extern "C" SGLK_API void sglk_debug_set_attn_prefill_stamps(unsigned long long* buf) { sglk::g_attn_prefill_stamps = buf; }
 #endif
 
 extern "C" int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
@@ -1756,6 +1830,7 @@ extern "C" int sglk_attn_fwd(sglk_stream_t stream, void* out, float* lse, const 
   p.scale = softmax_scale;
   p.softcap = softcap;
   p.probe = g_attn_prefill_probe;
+  p.stamps = g_attn_prefill_stamps;
   const int max_rows = (int)(max_seqlen_q * p.G);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16)

@@ -1,0 +1,14 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/r04_an
+mkdir -p $OUT
+export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
+cd $R
+for rep in 1 2; do
+echo "== release (DMA pieces spread into the softmax)"
+timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu
+echo "== old (DMA behind the barrier)"
+LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_old.so timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu
+done | tee $OUT/prefill.log
+LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_probes.so timeout 300 python3 tools/attn_prefill_stamps.py 2>&1 | grep -v amdgpu | tee $OUT/stamps.log
+timeout 1500 python3 -m pytest tests/test_attention_gpu.py tests/test_full_size_gpu.py tests/test_graph_capture_gpu.py tests/test_determinism_gpu.py -m gpu -q -x -n 4 2>&1 | tail -3
