@@ -562,9 +562,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 //   * NW = 4 waves (128 rows) per workgroup, TWO workgroups per CU (round 4; 8 waves x 32 rows, one workgroup per CU, before:
 //     the staging registers the DMA freed - 32 per thread - were what kept a second workgroup out). One workgroup's Q
 //     loads, first tiles, barrier waits and output stores now run under the other's tiles: causal 16 x 4096 at d = 128
-//     879 - 886 -> 909 - 923 TFLOP/s, at d = 64 684 - 707 -> 827 - 835 (same box, interleaved runs); a launch of exactly one
-//     round of workgroups (q = 128 chunks over 4096 keys) loses 6 % - it has nothing to overlap and misses the phase skew the
-//     two waves of a SIMD had inside one workgroup.
+//     879 - 886 -> 909 - 923 TFLOP/s, at d = 64 684 - 707 -> 827 - 835 (same box, interleaved runs), and with the DMA pieces
+//     between the softmax's steps (see "Spread" in the kernel) 944 - 955 / 838 - 857; a launch of exactly one round of
+//     workgroups (q = 128 chunks over 4096 keys) loses 3 % - it has nothing to overlap and misses the phase skew the two waves
+//     of a SIMD had inside one workgroup.
 // Round 4, measured and dropped: the weights of a block formed in the gaps of the next block's MFMAs (840
 // against 910 TFLOP/s - a wave's vector and matrix instructions do not overlap on this part, interleaved or not, and
 // the interleaved form waits for every fragment read); the first fragments of a phase requested ahead of the scalar work

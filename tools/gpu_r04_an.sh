@@ -1,13 +1,13 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/r04_an
+OUT=$R/gpurun_out/r04_ap
 mkdir -p $OUT
 export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
 cd $R
 for rep in 1 2; do
-echo "== release (DMA pieces spread into the softmax)"
+echo "== release (bases under the first K reads)"
 timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu
-echo "== old (DMA behind the barrier)"
+echo "== old (committed: spread DMA)"
 LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_old.so timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu
 done | tee $OUT/prefill.log
 LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_probes.so timeout 300 python3 tools/attn_prefill_stamps.py 2>&1 | grep -v amdgpu | tee $OUT/stamps.log
