@@ -1315,6 +1315,8 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
       X32_RD16(nq[0][1][0], nb2, 0);  X32_RD16(nq[0][1][1], nb3, 0);                                           \
       if (kDma) dma_piece(dL, kbL, sL, 0, 1);                                                                  \
     } else {                                                                                                   \
+      /* (round 4: with no two pieces back to back - the second of each pair moved behind the step's last MFMA - 0.2289 against */ \
+      /* 0.2268 ms, no gain: between 64-cycle MFMAs the pair's issue is covered)                                                   */ \
       /* (whole tiles: the block's last pieces go out two m-steps before its barrier: issued in the step in front of it */ \
       /* they were still in flight at the vmcnt(0) there: +54 us at the headline shape)                                  */ \
       if (kDma && MS == 4 && (mf) == 0) { dma_piece(dE, kbE, sE, 1, 1); dma_piece(dE, kbE, sE, 2, 0); }        \
