@@ -563,9 +563,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 //     the staging registers the DMA freed - 32 per thread - were what kept a second workgroup out). One workgroup's Q
 //     loads, first tiles, barrier waits and output stores now run under the other's tiles: causal 16 x 4096 at d = 128
 //     879 - 886 -> 909 - 923 TFLOP/s, at d = 64 684 - 707 -> 827 - 835 (same box, interleaved runs), and with the DMA pieces
-//     between the softmax's steps (see "Spread" in the kernel) 944 - 955 / 838 - 857; a launch of exactly one round of
-//     workgroups (q = 128 chunks over 4096 keys) loses 3 % - it has nothing to overlap and misses the phase skew the two waves
-//     of a SIMD had inside one workgroup.
+//     between the softmax's steps (see "Spread" in the kernel) and the matrix phases at priority 1: 944 - 958 / 838 - 857; a
+//     launch of exactly one round of workgroups (q = 128 chunks over 4096 keys: nothing to overlap, and no phase skew between
+//     the two waves of a SIMD) went 892 - 923 -> 853 - 860 -> 876 - 890 -> 935 over these steps.
 // Round 4, measured and dropped: the weights of a block formed in the gaps of the next block's MFMAs (840
 // against 910 TFLOP/s - a wave's vector and matrix instructions do not overlap on this part, interleaved or not, and
 // the interleaved form waits for every fragment read); the first fragments of a phase requested ahead of the scalar work
@@ -896,6 +896,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
       };
 #pragma unroll
       for (int ks = 0; ks < kKA; ++ks) read_k(ks, ka[ks]);
+      // (the matrix phases run at priority 1: the partner wave's softmax then takes the issue slots the MFMAs leave - 918 against
+      // 908 TFLOP/s at d = 128, interleaved runs of the diagnostic build)
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -913,6 +916,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * kKA * MB, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
 
     PF_STAMP(1)
@@ -1049,6 +1053,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
       constexpr int NPV = 4 * DB;
 #pragma unroll
       for (int m = 0; m < kVA; ++m) read_v(m, vf[m]);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int m = 0; m < NPV; ++m) {
 #pragma unroll
@@ -1065,6 +1070,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, kVA * MB, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     PF_STAMP(4)
   }
