@@ -152,6 +152,18 @@ def test_kvcache_paged_many_tiles(sglk, dev, causal, local, page, D):
               use_sink=causal, seed=D)
 
 
+@pytest.mark.parametrize("page", [8, 16, 32, 256])
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal,local", [(True, False), (False, True)])
+def test_prefill_kernel_page_sizes(sglk, dev, causal, local, D, page):
+    """prefill-sized row counts (the LDS-DMA kernel, round 4) over pages smaller than, equal to and larger than what one wave
+    stages per tile (16 rows): pages of 8 tokens take the per-lane address path (a wave's rows straddle pages), 16 and up the
+    scalar one; the ragged tails and the second sequence's 129 queries end inside tiles and pages."""
+    window = (150, 40) if local else (-1, -1)
+    run_paged(sglk, dev, torch.bfloat16 if D == 128 else torch.float16, [300, 129], [517, 640], 8, 2, D, page, causal=causal,
+              window=window, seed=D + page)
+
+
 @pytest.mark.parametrize("D,sq,sk", [(512, 3, 300), (512, 40, 130), (96, 17, 200), (192, 5, 77)])
 def test_kvcache_other_head_dims(sglk, dev, D, sq, sk):
     run_paged(sglk, dev, torch.bfloat16, [sq, 1], [sk, sk - 9], 8, 2, D, 64, causal=True, seed=D)
