@@ -1,0 +1,12 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/r04_az
+mkdir -p $OUT
+export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
+cd $R
+for rep in 1 2 3; do
+echo "== new (two-compare masks)"
+timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu
+echo "== old (committed)"
+LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_old.so timeout 300 python3 tools/attn_prefill_bench.py 2>&1 | grep -v amdgpu
+done | tee $OUT/prefill_mask.log
