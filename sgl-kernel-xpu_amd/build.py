@@ -121,7 +121,7 @@ def check_isa(verbose=True):
         return ["%s missing (build with this script first)" % path]
     text = open(path).read()
     found = 0
-    for name, body in _functions(text, r"mla_rows128x?_kernelI"):
+    for name, body in _functions(text, r"mla_rows128[xz]_kernelI"):
         found += 1
         in_asm = False
         for ln in body:

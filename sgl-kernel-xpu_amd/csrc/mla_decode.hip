@@ -202,7 +202,7 @@ struct MlaParams {
   void* out;                 // [B, H, 512] T
   float* ws_o;               // [B, splits, H, 512] fp32 (splits > 1)
   float* ws_lse;             // [B, splits, H]
-  uint32_t* ws_cnt;          // [B, 2] {tickets taken, partial results published}: zeroed by the host before every launch
+  unsigned long long* ws_cnt;  // [B, 2] {tickets taken, partial results published}: tagged words, see mla_cnt_up
   int64_t qn_sb, qn_sh, qp_sb, qp_sh;
   int64_t page_stride_bytes;
   int64_t table_stride;
@@ -599,481 +599,7 @@ __global__ __launch_bounds__(kThreads, 2) void mla_decode_kernel(MlaParams p, co
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// rows128 kernel: the same contract and LDS image as above for workgroups with 128 rows (decode with H > 64 -
-// DeepSeek-V3 has 128 heads - and every flash_mla_prefill). In the kernel above a wave that owns 16 rows pins
-// 72 (Q) + 128 (O) of its 256 registers and has no room to keep LDS reads in flight: its QK^T loop is read - wait -
-// MFMA (seen in the ISA), and every K / V fragment read from LDS feeds ONE MFMA, so the LDS pipe (2 x 1088 B per
-// token and 16 rows) bounds it at ~0.4 of the HBM roofline.
-// Here a workgroup is 4 waves, one per SIMD, 512 registers each. Wave w owns rows 32w .. 32w+31 (two 16-row
-// tiles): every K fragment and every transposed V fragment is read once and feeds TWO MFMAs (LDS read traffic
-// halves). O (2 x 32 tiles x 4 = 256 registers) lives in the FIXED registers a0..a255, named in the asm text; the
-// compiler never sees those values (check_isa in build.py verifies that it does not touch the AGPR file itself in this
-// kernel: under VGPR pressure it would park values there). Next to Q (144 VGPRs) the rings hold K fragments 2
-// k-steps ahead and V fragments 4 tiles ahead - all the registers there are (252 of 256 used).
-// One wave per SIMD has no other wave to overlap with, so the overlap is written out: iteration j runs QK^T of tile
-// j, then P.V of tile j-1 with the softmax of tile j as ~56 micro-ops between its MFMAs; page ids are looked up one
-// tile ahead; the max across lane groups uses v_permlane16/32_swap (VALU) instead of LDS shuffles.
-// All MFMAs and LDS reads are inline asm in program order with hand-counted waits. What the compiler would do for
-// real MFMA instructions is done by hand: s_nop after the last MFMA of a phase before its results are read, operand
-// registers kept reserved past the issue of their last MFMA, zeros and addresses materialised before the first read.
-// Online softmax with a lazy reference maximum: O (in AGPRs: a rescale costs 3 VALU instructions per register) is
-// rescaled only when a weight would pass 2^50 (bf16: the weights have fp32's exponent range and the reference is
-// set 2^50 above the tile maximum when it moves) or 2^8 (f16); the row sums add the ROUNDED weights, so numerator
-// and denominator round alike.
-// (The reference benchmark's q x 100 logits move a head's maximum by tens of binades at a time: with an exact
-// reference 76 of a split's 128 tiles would rescale, each costing about a tile's time.)
 constexpr int kThreads2 = 256;
-
-template <typename T>
-__global__ __launch_bounds__(kThreads2, 1) void mla_rows128_kernel(MlaParams p, const T* __restrict__ q_nope,
-                                                                   const T* __restrict__ q_pe,
-                                                                   const char* __restrict__ cache,
-                                                                   const int32_t* __restrict__ seq_lens,
-                                                                   const int32_t* __restrict__ page_table,
-                                                                   const int32_t* __restrict__ cu_seqlens_q) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  using M = Mfma<T>;
-  constexpr int kStages = 4;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x, b = blockIdx.y;
-  const int H = p.H;
-  const int l15 = lane & 15, g = lane >> 4;
-
-  // ---- rows (see the kernel above): row tile 2 wave + h
-  const int hp_mask = (1 << p.hp_shift) - 1;
-  int grp_tok[2], grp_head0[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    grp_tok[h] = ((wave * 2 + h) * 16) >> p.hp_shift;
-    grp_head0[h] = ((wave * 2 + h) * 16) & hp_mask;
-  }
-  int q_row0 = b, n_tok = 1, seq, kv_first;
-  if (cu_seqlens_q != nullptr) {
-    const int q0 = cu_seqlens_q[b], sq = cu_seqlens_q[b + 1] - q0, sk = seq_lens[b];
-    const int t0 = (int)blockIdx.z << (7 - p.hp_shift);
-    if (t0 >= sq) return;
-    const int tpw = 1 << (7 - p.hp_shift);
-    n_tok = (sq - t0) < tpw ? (sq - t0) : tpw;
-    q_row0 = q0 + t0;
-    kv_first = p.causal ? sk - sq + t0 + 1 : sk;
-    seq = p.causal ? sk - sq + t0 + n_tok : sk;
-  } else {
-    seq = seq_lens[b];
-    kv_first = seq;
-  }
-  bool active[2];
-  int kv_row[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    active[h] = grp_tok[h] < n_tok && grp_head0[h] < H;
-    kv_row[h] = (cu_seqlens_q != nullptr && p.causal && grp_tok[h] < n_tok) ? kv_first + grp_tok[h] : seq;
-  }
-  const bool work = (active[0] || active[1]) && p.probe != 1;  // (rows that are not stored still compute)
-  const int ntiles = (seq + kTile - 1) / kTile;
-  const int tps = (ntiles + p.splits - 1) / p.splits;
-  const int t_begin = split * tps;
-  const int t_end = (t_begin + tps < ntiles) ? (t_begin + tps) : ntiles;
-
-  const int32_t* table = page_table + (int64_t)b * p.table_stride;
-  const int page_mask = (1 << p.page_shift) - 1;
-
-  // ---- LDS-DMA of one tile (same image as above): wave w fills column block w (8 row groups) and rope rows 8w..8w+7
-  // Addresses: a scalar base per half tile (rows 0..15 / 16..31: the second half is another page when PAGE == 16)
-  // plus two loop-invariant per-lane offsets (the row-group dependence of the swizzle is an XOR on bits 4, 5), so
-  // that a tile costs a handful of scalar instructions instead of ~90 vector ones (64-bit adds, multiplies) on the
-  // critical path behind the barrier.
-  const uint32_t dma_lo0 = (uint32_t)((lane >> 4) * kRowBytes + wave * 256 + 16 * ((lane & 15) ^ ((lane >> 4) << 2)));
-  const uint32_t dma_ro = (uint32_t)((((wave & 1) * 8 + (lane >> 3)) * kRowBytes) + 1024 +
-                                     16 * ((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)));
-  auto stage_tile = [&](int t, int st, int pg0, int pg1) {
-    char* base = smem + st * kStageBytes;
-    const int tok0 = t * kTile;
-    const char* sA = cache + (int64_t)pg0 * p.page_stride_bytes + (int64_t)(tok0 & page_mask) * kRowBytes;
-    const char* sB = p.page_shift == 4 ? cache + (int64_t)pg1 * p.page_stride_bytes : sA + 16 * kRowBytes;
-#pragma unroll
-    for (int rg = 0; rg < 8; ++rg) {
-      const char* sbase = (rg < 4 ? sA : sB) + (rg & 3) * 4 * kRowBytes;
-      const char* src = sbase + (dma_lo0 ^ (uint32_t)((rg & 3) << 4));
-      __builtin_amdgcn_global_load_lds(SGLK_GLB(src), SGLK_LDS(base + wave * 8192 + rg * 1024), 16, 0, 0);
-    }
-    {
-      const char* src = (wave < 2 ? sA : sB) + dma_ro;
-      __builtin_amdgcn_global_load_lds(SGLK_GLB(src), SGLK_LDS(base + kMainBytes + wave * 1024), 16, 0, 0);
-    }
-  };
-
-  if (t_begin >= t_end) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (!active[h]) continue;
-      const int row0 = (wave * 2 + h) * 16;
-      for (int i = lane; i < 16 * kLatent; i += 64) {
-        const int head = row0 + i / kLatent, d = i % kLatent;  // (decode only: splits > 1 or an empty sequence)
-        if (head < H) {
-          if (p.splits == 1) ((T*)p.out)[((int64_t)(q_row0 + grp_tok[h]) * H + grp_head0[h] + i / kLatent) * kLatent + d] = (T)0.f;
-          else p.ws_o[(((int64_t)b * p.splits + split) * H + head) * kLatent + d] = 0.f;
-        }
-      }
-      if (p.splits > 1 && lane < 16 && row0 + lane < H)
-        p.ws_lse[((int64_t)b * p.splits + split) * H + row0 + lane] = -INFINITY;
-    }
-    return;
-  }
-
-  const int pig = (0x2130 >> (4 * g)) & 3;  // pi = (0,3,1,2)
-
-  // ---- Q^T fragments of both row tiles: 2 x 18 k-steps x 4 registers
-  v8s qf[2][18];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int head = grp_head0[h] + l15;
-    const bool ok = active[h] && head < H;
-    const int64_t qrow = q_row0 + (active[h] ? grp_tok[h] : 0);
-    const T* qn = q_nope + qrow * p.qn_sb + (int64_t)(ok ? head : 0) * p.qn_sh + 8 * pig;
-    const T* qp = q_pe + qrow * p.qp_sb + (int64_t)(ok ? head : 0) * p.qp_sh + 8 * pig;
-    const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < 18; ++ks) {
-      const T* src = ks < 16 ? qn + 32 * ks : qp + 32 * (ks - 16);
-      const v8s v = *reinterpret_cast<const v8s*>(src);
-      qf[h][ks] = ok ? v : zero;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q is in registers before any LDS-DMA is counted
-
-  // ---- per-lane LDS read offsets (same image and permutations as above)
-  const int tau = (l15 & 3) | (((l15 >> 2) & 1) << 3) | (((l15 >> 3) & 1) << 2);
-  const int kbase = 256 * tau + 16 * (pig ^ sw_main(tau));
-  const int rbase = kMainBytes + 128 * tau + 16 * (pig ^ ((tau >> 1) & 7));
-  int vbase0;
-  {
-    const int q = l15 >> 2, pp = l15 & 3;
-    const int r = 8 * (g & 1) + 4 * (g >> 1) + q;
-    vbase0 = 256 * r + 16 * ((pp >> 1) ^ sw_main(r)) + 8 * (pp & 1);
-  }
-
-  // O[row tile h][16-column tile nt] = a[(32 h + nt) 4 .. +3]; the clobbers tell the compiler that the kernel
-  // owns the whole AGPR file (it must not place anything there: checked in the ISA)
-  asm volatile("" ::: "a0", "a255");
-  float m_ref[2] = {-INFINITY, -INFINITY};  // reference maximum of head l15 of each row tile (lane groups agree)
-  float m_run[2] = {-INFINITY, -INFINITY};  // true running maximum of the same heads
-  float l_run[2] = {0.f, 0.f};              // sum of 2^(s - ref) over this lane's own tokens
-  // (ln: the lane id through an opaque copy, so that the addresses are recomputed where they are used instead of
-  //  being carried through the main loop: there is no register to spare there)
-  auto head_bcast = [&](int ln, float v, int r) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((ln & 48) | (4 * (ln >> 4) + r)) << 2, __builtin_bit_cast(int, v)));
-  };
-  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
-
-  const int n_my = t_end - t_begin;
-  // page ids of local tile j, looked up one iteration before the tile is staged (the scalar-load latency would
-  // otherwise sit between the barrier and the first LDS-DMA of every tile; a single wave per SIMD cannot hide it)
-  auto load_pages = [&](int j, int& pg0, int& pg1) {
-    const int tok0 = (t_begin + (j < n_my ? j : n_my - 1)) * kTile;
-    pg0 = table[tok0 >> p.page_shift];
-    pg1 = pg0;
-    if (p.page_shift == 4 && tok0 + 16 < seq) pg1 = table[(tok0 + 16) >> 4];
-  };
-  int pgn0, pgn1;
-  {
-    int a0, a1;
-    load_pages(0, a0, a1);
-    stage_tile(t_begin, 0, a0, a1);
-    if (n_my > 1) {
-      load_pages(1, a0, a1);
-      stage_tile(t_begin + 1, 1, a0, a1);
-    }
-  }
-  load_pages(2, pgn0, pgn1);
-
-  // ---- software pipeline over the tiles: iteration j runs QK^T of tile j, then P.V of tile j-1 with the softmax of
-  // tile j woven between its MFMAs (the VALU work hides behind the matrix pipe; a single wave per SIMD has no
-  // other wave to fill it). Iteration 0 accumulates P = 0 (O is zeroed after it), iteration n recomputes the last
-  // tile's scores and discards them. Ring: tiles j-1, j resident, j+1 in flight, j+2 issued after the barrier.
-  v8s pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
-  constexpr bool kWide = std::is_same<T, bf16>::value;  // weights with fp32's exponent range
-  constexpr float kLazy = kWide ? 50.0f : 8.0f;
-  const float head_raw = (kWide && p.scale_log2 > 0.f) ? 50.0f / p.scale_log2 : 0.f;  // 2^50 in units of the raw logits
-  for (int j = 0; j <= n_my; ++j) {
-    const bool commit = j < n_my;
-    const int jq = commit ? j : n_my - 1, jv = j > 0 ? j - 1 : 0;
-    if (j + 1 < n_my) wait_vmcnt<9>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // tile j landed for every wave; every wave is done with tile j-2
-    if (j + 2 < n_my) stage_tile(t_begin + j + 2, (j + 2) & 3, pgn0, pgn1);
-    if (work) {
-      const uint32_t sbq = lds_base + (uint32_t)((jq & 3) * kStageBytes), sbv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
-      const int t = t_begin + jq;
-      __builtin_amdgcn_sched_barrier(0);
-      // one base address per read kind; the chunk step of a read is an XOR on bits 5..7 (stage bases are multiples
-      // of 4 KiB, so the XOR commutes with the add) done right before the read goes out: 3 registers instead of 14
-      uint32_t ksum = sbq + (uint32_t)kbase, rsum = sbq + (uint32_t)rbase, vsum = sbv + (uint32_t)vbase0;
-      v4f s[2][2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) s[h][tt] = (v4f){0.f, 0.f, 0.f, 0.f};
-      // The compiler does not know that the asm statements below are MFMAs, and the hardware does not interlock a
-      // VALU write against the operands an MFMA issued just before is still reading. So: the zeros and all addresses
-      // are in their registers BEFORE the first read goes out (left alone, the compiler rematerialises a zero
-      // accumulator right in front of its first MFMA, into the registers of the K fragment of the MFMA one
-      // instruction earlier: seen, S off by 2^-12), and operand registers stay reserved past their last MFMA.
-      asm volatile("" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(ksum), "+v"(rsum), "+v"(vsum));
-      constexpr int kKD = 2, kKB = kKD + 1;
-      constexpr int kVD = 5, kVB = kVD + 1;
-      v8s kr[kKB][2];
-      v2i vb[kVB][2];
-#define SGLK_K_ISSUE(KS)                                                                                     \
-  do {                                                                                                       \
-    constexpr int o0_ = (KS) < 16 ? ((KS) >> 2) * 8192 : 0, o1_ = o0_ + ((KS) < 16 ? 4096 : 2048);           \
-    const uint32_t a_ = (KS) < 16 ? (ksum ^ (uint32_t)(((KS) & 3) << 6)) : (rsum ^ (uint32_t)(((KS) - 16) << 6)); \
-    /* the address is computed while the slot this read will overwrite is still reserved: its last MFMAs were */ \
-    /* issued just before, and the compiler would otherwise be free to put the address into those registers   */ \
-    if constexpr ((KS) >= kKB) asm volatile("" ::"v"(kr[(KS) % kKB][0]), "v"(kr[(KS) % kKB][1]), "v"(a_));   \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][0]) : "v"(a_), "i"(o0_) : "memory");  \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(KS) % kKB][1]) : "v"(a_), "i"(o1_) : "memory");  \
-  } while (0)
-#define SGLK_V_ISSUE(I)                                                                                      \
-  do {                                                                                                       \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                       \
-                 : "=v"(vb[(I) % kVB][0]) : "v"(vnext), "i"((((I) >> 3) * 8192)) : "memory");                \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                       \
-                 : "=v"(vb[(I) % kVB][1]) : "v"(vnext), "i"((((I) >> 3) * 8192 + 4096)) : "memory");         \
-    vnext = vsum ^ (uint32_t)((((I) + 1) & 7) << 5); /* address of the next fragment (the reads go out in order) */ \
-  } while (0)
-#define SGLK_K_WAIT(N, KS) \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(kr[(KS) % kKB][0]), "+v"(kr[(KS) % kKB][1])::"memory")
-#define SGLK_K_MMA(KS)                                                                                       \
-    M::acc_v(s[0][0], kr[(KS) % kKB][0], qf[0][KS]);                                                         \
-    M::acc_v(s[1][0], kr[(KS) % kKB][0], qf[1][KS]);                                                         \
-    M::acc_v(s[0][1], kr[(KS) % kKB][1], qf[0][KS]);                                                         \
-    M::acc_v(s[1][1], kr[(KS) % kKB][1], qf[1][KS]);
-#define SGLK_K_STEP(KS)                                                                                      \
-  {                                                                                                          \
-    SGLK_K_ISSUE((KS) + kKD);                                                                                \
-    SGLK_K_WAIT(4, KS);                                                                                      \
-    SGLK_K_MMA(KS)                                                                                           \
-  }
-      // ---- S^T[token, head] = K . Q^T of tile j: per k-step two K fragments (token tiles 0, 1), four MFMAs
-      uint32_t vnext = vsum;
-      SGLK_K_ISSUE(0); SGLK_K_ISSUE(1);
-      SGLK_K_STEP(0) SGLK_K_STEP(1) SGLK_K_STEP(2) SGLK_K_STEP(3) SGLK_K_STEP(4) SGLK_K_STEP(5)
-      SGLK_K_STEP(6) SGLK_K_STEP(7) SGLK_K_STEP(8) SGLK_K_STEP(9) SGLK_K_STEP(10) SGLK_K_STEP(11)
-      SGLK_K_STEP(12) SGLK_K_STEP(13) SGLK_K_STEP(14)
-      // the last three k-steps send out the first V fragments of tile j-1 (younger than the K reads still in flight:
-      // the counts below allow them to stay outstanding)
-      { SGLK_K_ISSUE(17); SGLK_V_ISSUE(0); SGLK_V_ISSUE(1); SGLK_K_WAIT(8, 15); SGLK_K_MMA(15) }
-      { SGLK_V_ISSUE(2); SGLK_V_ISSUE(3); SGLK_K_WAIT(10, 16); SGLK_K_MMA(16) }
-      { SGLK_V_ISSUE(4); SGLK_K_WAIT(10, 17); SGLK_K_MMA(17) }
-#undef SGLK_K_STEP
-#undef SGLK_K_MMA
-#undef SGLK_K_WAIT
-#undef SGLK_K_ISSUE
-      // S is read by the VALU from PV step 2 on (two steps = 4 MFMAs behind the last QK^T MFMA: more than the wait
-      // states an MFMA result needs); the K ring registers stay reserved up to here
-      asm volatile(""
-                   : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1])
-                   : "v"(kr[0][0]), "v"(kr[0][1]), "v"(kr[1][0]), "v"(kr[1][1]), "v"(kr[2][0]), "v"(kr[2][1]));
-      __builtin_amdgcn_sched_barrier(0);
-
-      // ---- O += P . V of tile j-1 (one transposed V fragment, two MFMAs per step) with the softmax of tile j
-      // behind the MFMAs of steps 2 .. 29
-      v8s pfn[2];
-      float mt[2], alpha[2], mneg[2], psum[2];  // (mt: tile maximum, then the new reference)
-      bool upd[2];
-      // one micro-op (a few dependent VALU instructions of one row tile) per MFMA slot, the two row tiles
-      // alternating, so that consecutive slots are independent and a dependent pair is >= 2 MFMAs apart: a single
-      // wave issues in order, and a dependent VALU chain between two MFMAs would leave the matrix pipe idle
-      auto sm_op = [&](auto nc) {
-        constexpr int n = decltype(nc)::value, h = n & 1, k = n >> 1;
-        if constexpr (k < 8) {  // keys past this row's horizon
-          constexpr int tt = k >> 2, r = k & 3;
-          if (t * kTile + 8 * (g & 1) + 4 * (g >> 1) + 16 * tt + r >= kv_row[h]) s[h][tt][r] = -INFINITY;
-        } else if constexpr (k == 8) {
-          mt[h] = fmaxf(fmaxf(s[h][0][0], s[h][0][1]), fmaxf(s[h][0][2], s[h][0][3]));
-        } else if constexpr (k == 9) {
-          mt[h] = fmaxf(mt[h], fmaxf(fmaxf(s[h][1][0], s[h][1][1]), fmaxf(s[h][1][2], s[h][1][3])));
-        } else if constexpr (k == 10) {
-          // maximum over the four lane groups of a head: VALU lane swaps, no LDS traffic. (inline asm: this
-          // compiler's __builtin_amdgcn_permlane16_swap / 32_swap drop the second result - probed,
-          // tools/permlane_probe.cpp. The s_nop covers the VALU-write -> permlane-swap wait states.)
-          float a0 = mt[h], a1 = mt[h];
-          asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));  // a0 = rows 0 0 2 2, a1 = rows 1 1 3 3
-          mt[h] = fmaxf(a0, a1);
-        } else if constexpr (k == 11) {
-          float c0 = mt[h], c1 = mt[h];
-          asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
-          mt[h] = fmaxf(c0, c1);
-        } else if constexpr (k == 12) {
-          // bf16 has fp32's exponent range, so the reference need not be the maximum: when it moves it is set 2^50
-          // ABOVE the tile maximum (weights start at 2^-50: normal numbers with the same relative precision) and it
-          // moves again only when a weight would pass 2^50: a window of 100 binades per move. The rescale factor
-          // 2^-(move) flushes to zero below 2^-126, i.e. for moves past 126 binades: by then every old weight is
-          // below 2^-26 of the new largest one. (With 90 + 60 the flush dropped weights that mattered: caught by the
-          // parity tests.) O and the row sums are
-          // fp32: 2^60 x 1M keys x |V| stays far below 2^127. f16 weights must stay in [2^-14, 2^16): no headroom,
-          // threshold 2^8. (first tile: ref = -inf; a NaN difference keeps the ref)
-          // A rescale touches the whole row tile's registers whichever head asked for it, so when one head's
-          // reference has to move every head of the row tile takes fresh headroom above its own running maximum:
-          // the heads stay synchronised and the number of rescales per row tile is set by its fastest-growing head,
-          // not by the sum over its 16 heads (simulated for the q x 100 logits: 9 instead of 16 per 128 tiles).
-          upd[h] = __any(commit && (mt[h] - m_ref[h]) * p.scale_log2 > kLazy);
-          m_run[h] = commit ? fmaxf(m_run[h], mt[h]) : m_run[h];
-          const float cand = m_run[h] + head_raw;  // (>= the old reference: that was an older maximum + headroom)
-          mt[h] = (upd[h] && cand > m_ref[h]) ? cand : m_ref[h];
-        } else if constexpr (k == 13) {
-          alpha[h] = upd[h] ? __builtin_amdgcn_exp2f((m_ref[h] - mt[h]) * p.scale_log2) : 1.0f;
-        } else if constexpr (k == 14) {
-          mneg[h] = -mt[h] * p.scale_log2;
-          m_ref[h] = mt[h];  // (the discarded last iteration never updates: upd is false there)
-          psum[h] = 0.f;
-        } else if constexpr (k < 23) {  // the weights overwrite the scores
-          constexpr int e = k - 15, tt = e >> 2, r = e & 3;
-          s[h][tt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[h][tt][r], p.scale_log2, mneg[h]));
-        } else if constexpr (k < 27) {
-          constexpr int pr = k - 23, tt = pr >> 1, r0 = (pr & 1) * 2;
-#pragma unroll
-          for (int r = r0; r < r0 + 2; ++r) {
-            pfn[h][tt * 4 + r] = M::cvt(s[h][tt][r]);
-            // the row sum takes the ROUNDED weights (the ones P . V uses): with a lazy reference the largest weight
-            // is no longer exactly 1, and numerator and denominator must round alike
-            psum[h] += M::back(pfn[h][tt * 4 + r]);
-          }
-        } else if constexpr (k == 27) {
-          l_run[h] = commit ? l_run[h] * alpha[h] + psum[h] : l_run[h];
-        }
-      };
-#define SGLK_V_WAIT(N, I) \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(vb[(I) % kVB][0]), "+v"(vb[(I) % kVB][1])::"memory")
-#define SGLK_V_STEP(G)                                                                                       \
-  {                                                                                                          \
-    if constexpr ((G) + kVD < 32) SGLK_V_ISSUE((G) + kVD);                                                   \
-    constexpr int ahead_ = (G) + kVD < 32 ? kVD : 31 - (G);                                                  \
-    if constexpr (ahead_ == 5) SGLK_V_WAIT(10, G);                                                           \
-    if constexpr (ahead_ == 4) SGLK_V_WAIT(8, G);                                                            \
-    if constexpr (ahead_ == 3) SGLK_V_WAIT(6, G);                                                            \
-    if constexpr (ahead_ == 2) SGLK_V_WAIT(4, G);                                                            \
-    if constexpr (ahead_ == 1) SGLK_V_WAIT(2, G);                                                            \
-    if constexpr (ahead_ == 0) SGLK_V_WAIT(0, G);                                                            \
-    v8s f_;                                                                                                  \
-    const v4s x0_ = __builtin_bit_cast(v4s, vb[(G) % kVB][0]), x1_ = __builtin_bit_cast(v4s, vb[(G) % kVB][1]); \
-    f_[0] = x0_[0]; f_[1] = x0_[1]; f_[2] = x0_[2]; f_[3] = x0_[3];                                          \
-    f_[4] = x1_[0]; f_[5] = x1_[1]; f_[6] = x1_[2]; f_[7] = x1_[3];                                          \
-    M::template acc_agpr<(G) * 4>(pf[0], f_);                                                                \
-    if constexpr ((G) >= 2 && (G) < 30) {                                                                    \
-      __builtin_amdgcn_sched_barrier(0);                                                                     \
-      sm_op(std::integral_constant<int, ((G) - 2) * 2>{});                                                   \
-      __builtin_amdgcn_sched_barrier(0);                                                                     \
-    }                                                                                                        \
-    M::template acc_agpr<(32 + (G)) * 4>(pf[1], f_);                                                         \
-    if constexpr ((G) >= 2 && (G) < 30) {                                                                    \
-      __builtin_amdgcn_sched_barrier(0);                                                                     \
-      sm_op(std::integral_constant<int, ((G) - 2) * 2 + 1>{});                                               \
-    }                                                                                                        \
-    /* the V fragment's registers stay reserved past the micro-op (the compiler would hand them to it: a VALU */ \
-    /* write into an operand of the MFMA issued just before)                                               */ \
-    asm volatile("" ::"v"(vb[(G) % kVB][0]), "v"(vb[(G) % kVB][1]));                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-  }
-      SGLK_V_STEP(0) SGLK_V_STEP(1) SGLK_V_STEP(2) SGLK_V_STEP(3) SGLK_V_STEP(4) SGLK_V_STEP(5)
-      SGLK_V_STEP(6) SGLK_V_STEP(7) SGLK_V_STEP(8) SGLK_V_STEP(9) SGLK_V_STEP(10) SGLK_V_STEP(11)
-      SGLK_V_STEP(12) SGLK_V_STEP(13) SGLK_V_STEP(14) SGLK_V_STEP(15) SGLK_V_STEP(16) SGLK_V_STEP(17)
-      SGLK_V_STEP(18) SGLK_V_STEP(19) SGLK_V_STEP(20) SGLK_V_STEP(21) SGLK_V_STEP(22) SGLK_V_STEP(23)
-      SGLK_V_STEP(24) SGLK_V_STEP(25) SGLK_V_STEP(26) SGLK_V_STEP(27) SGLK_V_STEP(28) SGLK_V_STEP(29)
-      SGLK_V_STEP(30) SGLK_V_STEP(31)
-#undef SGLK_V_STEP
-#undef SGLK_V_WAIT
-#undef SGLK_V_ISSUE
-      // the operands of the last PV MFMAs (P and the V ring) stay reserved until the matrix pipe has read them; the
-      // nops also cover the MFMA -> v_accvgpr_read wait states of the two blocks below
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::"v"(pf[0]), "v"(pf[1]), "v"(vb[0][0]), "v"(vb[0][1]), "v"(vb[1][0]),
-                   "v"(vb[1][1]), "v"(vb[2][0]), "v"(vb[2][1]), "v"(vb[3][0]), "v"(vb[3][1]), "v"(vb[4][0]), "v"(vb[4][1]),
-                   "v"(vb[5][0]), "v"(vb[5][1]));
-      __builtin_amdgcn_sched_barrier(0);
-      if (j == 0) {
-        // O[row tile h][16-column tile nt] = a[(32 h + nt) 4 .. +3]: start from zero (iteration 0 added 0 . V)
-        static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
-      } else {
-        // rare: a reference moved, rescale that row tile's O (AGPR -> VGPR -> AGPR) before the next tile's P . V
-        if (upd[0]) {
-          int ln = lane;
-          asm volatile("" : "+v"(ln));
-          const v4f a0 = {head_bcast(ln, alpha[0], 0), head_bcast(ln, alpha[0], 1), head_bcast(ln, alpha[0], 2), head_bcast(ln, alpha[0], 3)};
-          static_for<0, 16>([&](auto ic) { agpr_scale8<decltype(ic)::value * 8>(a0); });
-          asm volatile("s_nop 7");
-        }
-        if (upd[1]) {
-          int ln = lane;
-          asm volatile("" : "+v"(ln));
-          const v4f a1 = {head_bcast(ln, alpha[1], 0), head_bcast(ln, alpha[1], 1), head_bcast(ln, alpha[1], 2), head_bcast(ln, alpha[1], 3)};
-          static_for<16, 32>([&](auto ic) { agpr_scale8<decltype(ic)::value * 8>(a1); });
-          asm volatile("s_nop 7");
-        }
-      }
-      if (commit) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) pf[h] = pfn[h];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // next tile's page ids: the scalar loads go out at the END of the iteration, so that they are not outstanding
-    // (on the same counter) while the hand-counted LDS waits of the phases above run
-    load_pages(j + 3, pgn0, pgn1);
-  }
-
-  // ---- epilogue: normalise by the row sums and write. O tile nt: lane holds dim 16 nt + l15, heads 4g + r
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");  // the last MFMA results are read from the AGPRs below
-  int le = threadIdx.x & 63;
-  asm volatile("" : "+v"(le));  // (everything the stores need is derived here, after the loop)
-  const int l15e = le & 15, ge = le >> 4;
-  static_for<0, 2>([&](auto hc) {
-    constexpr int h = decltype(hc)::value;
-    if (!active[h] || p.probe == 1) return;
-    float l_tot = l_run[h] + __shfl_xor(l_run[h], 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
-    const float inv_l = 1.0f / l_tot;
-    const v4f i4 = {head_bcast(le, inv_l, 0), head_bcast(le, inv_l, 1), head_bcast(le, inv_l, 2), head_bcast(le, inv_l, 3)};
-    const int row0 = (wave * 2 + h) * 16;
-    if (p.splits == 1) {
-      T* out = (T*)p.out + (int64_t)(q_row0 + grp_tok[h]) * H * kLatent;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int head = grp_head0[h] + 4 * ge + r;
-        (void)head;
-      }
-      static_for<0, 32>([&](auto ic) {
-        constexpr int nt = decltype(ic)::value;
-        const v4f v = agpr_read4<(h * 32 + nt) * 4>();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int head = grp_head0[h] + 4 * ge + r;
-          if (head < H) out[(int64_t)head * kLatent + nt * 16 + l15e] = (T)(v[r] * i4[r]);
-        }
-      });
-    } else {
-      float* wo = p.ws_o + ((int64_t)b * p.splits + split) * H * kLatent;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int head = row0 + 4 * ge + r;
-        (void)head;
-      }
-      static_for<0, 32>([&](auto ic) {
-        constexpr int nt = decltype(ic)::value;
-        const v4f v = agpr_read4<(h * 32 + nt) * 4>();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int head = row0 + 4 * ge + r;
-          if (head < H) wo[(int64_t)head * kLatent + nt * 16 + l15e] = v[r] * i4[r];
-        }
-      });
-      if (le < 16 && row0 + le < H)
-        p.ws_lse[((int64_t)b * p.splits + split) * H + row0 + le] = m_ref[h] * p.scale_log2 + log2f(l_tot);
-    }
-  });
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // rows128 kernel, 32x32x16 form (round 3). Same contract, launch geometry, LDS image and DMA ring as the kernel above;
@@ -1176,52 +702,77 @@ template <int kOrd>
 __host__ __device__ constexpr int pv_ss(int m) {
   return kOrd == 0 ? (m & 1) : kOrd == 1 ? ((m >> 2) & 1) : ((m >> 1) & 1);
 }
-__global__ void mla_zero_counters_kernel(uint32_t* __restrict__ cnt, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) cnt[i] = 0u;
-}
-
 // ---- split KV merged inside the kernel (rows128x kernel). The workgroup of a batch element that finishes LAST merges the
 // splits itself: no second launch, and its own partial result never leaves the registers. Every workgroup takes a ticket
 // when its tile loop is done; all but the last publish O / l (fp32, write-through stores) and their log2-sum-exp, then
 // count themselves in; the last one waits until the others - which took their tickets before it, so they are running their
 // epilogues - are counted in, and adds the partial results IN SPLIT ORDER (its own at its place): the sum does not depend
 // on who came last. Hand-off as cdna_hip_programming.md guideline 16: sc1 payload stores, every storing wave drains,
-// barrier, one agent-scope add; consumer: one lane polls relaxed, one agent acquire, barrier, loads. The two counters of a
-// batch element are zeroed by a memset node in front of every launch.
-typedef __attribute__((address_space(1))) uint32_t mla_gu32;
+// barrier, one agent-scope add; consumer: one lane polls relaxed, one agent acquire, barrier, loads.
+//
+// The two counters of a batch element need NO launch and no memset in front of the kernel (round 4 spent 4.8 us per call
+// on a zeroing kernel; a memset node replayed from a captured graph did not even work). Each is a 64-bit word
+// {48-bit tag, 16-bit count}, changed only by compare-and-swap: a word whose tag is not kCntTag - a fresh torch.empty
+// workspace, or memory the allocator lent to somebody else in between - counts as zero, so the first arriver initialises
+// it on the fly; the ticket word wraps to zero with the last ticket and the merger stores a zero count into the published
+// word when it has seen everybody, so that the words a finished call leaves behind read zero for ANY split count of the
+// next call. (A word of garbage that happens to carry the tag: 2^-48 per word. One workspace serves one call at a time.)
+typedef __attribute__((address_space(1))) unsigned long long mla_gu64;
+constexpr unsigned long long kCntTag = 0x5fa3c96d17b4ull;  // 48 bits
+__device__ __forceinline__ uint32_t mla_cnt_of(unsigned long long w) { return (w >> 16) == kCntTag ? (uint32_t)(w & 0xffffu) : 0u; }
+// count one up (wrapping to zero at `wrap`, 0 = never) and return the count found
+__device__ __forceinline__ uint32_t mla_cnt_up(mla_gu64* w, uint32_t wrap) {
+  unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    const uint32_t cnt = mla_cnt_of(old);
+    uint32_t nxt = cnt + 1;
+    if (wrap != 0u && nxt >= wrap) nxt = 0u;
+    const unsigned long long want = (kCntTag << 16) | nxt;
+    if (__hip_atomic_compare_exchange_strong(w, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      return cnt;
+  }
+}
 __device__ __forceinline__ bool mla_take_ticket(const MlaParams& p, int b, char* smem, int tid) {
-  mla_gu32* cnt = (mla_gu32*)(p.ws_cnt + 2 * (int64_t)b);
+  mla_gu64* cnt = (mla_gu64*)p.ws_cnt + 2 * (int64_t)b;
   uint32_t* lds_word = reinterpret_cast<uint32_t*>(smem);
   __builtin_amdgcn_s_barrier();  // (every wave has left the tile loop: the stages are free)
-  if (tid == 0) *lds_word = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) *lds_word = mla_cnt_up(cnt, (uint32_t)p.splits);
   __syncthreads();
   return (int)(*lds_word) == p.splits - 1;
 }
 __device__ __forceinline__ void mla_count_in(const MlaParams& p, int b, int tid) {
-  mla_gu32* cnt = (mla_gu32*)(p.ws_cnt + 2 * (int64_t)b);
+  mla_gu64* cnt = (mla_gu64*)p.ws_cnt + 2 * (int64_t)b;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every storing wave, in front of the barrier)
   __builtin_amdgcn_s_barrier();
-  if (tid == 0) __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) mla_cnt_up(cnt + 1, 0u);
 }
-__device__ __forceinline__ void mla_wait_others(const MlaParams& p, int b, int tid) {
-  mla_gu32* cnt = (mla_gu32*)(p.ws_cnt + 2 * (int64_t)b);
+// false = the others did not show up within the bound (a lost workgroup, or a second call sharing this workspace): the
+// caller then writes NaN instead of merging stale partial results
+__device__ __forceinline__ bool mla_wait_others(const MlaParams& p, int b, char* smem, int tid) {
+  mla_gu64* cnt = (mla_gu64*)p.ws_cnt + 2 * (int64_t)b;
+  uint32_t* lds_word = reinterpret_cast<uint32_t*>(smem) + 1;  // (not the ticket's word: a slow wave may still be reading that)
   if (tid == 0) {
-    // (bounded: a spin that never ends would take the device with it; an exhausted one shows up as a wrong result)
+    // (bounded: a spin that never ends would take the device with it)
+    uint32_t seen = 0u;
     for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
-      if ((int)__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.splits - 1) break;
+      seen = mla_cnt_of(__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if ((int)seen >= p.splits - 1) break;
       __builtin_amdgcn_s_sleep(8);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // everybody is counted in and nobody touches the word again in this call: leave a zero count for the next one
+    __hip_atomic_store(cnt + 1, kCntTag << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *lds_word = (int)seen >= p.splits - 1 ? 1u : 0u;
   }
   __syncthreads();
+  return *lds_word != 0u;
 }
 // The last workgroup's merge for the row of lane (l31, u): out = sum_s w_s O_s / sum_s w_s, w_s = 2^(lse_s - max lse), s in
 // split order. OWN: this workgroup's O^T sits unnormalised in a0..a255 (x inv_l), log2-sum-exp my_lse; otherwise it had no keys.
 template <typename T, typename M, bool OWN>
 __device__ __forceinline__ void mla_merge_splits(const MlaParams& p, int b, int split, int H, bool ok, int hrow, T* out,
-                                                 int u, float my_lse, float inv_l) {
+                                                 int u, float my_lse, float inv_l, bool all_in) {
   const float* lse_b = p.ws_lse + (int64_t)b * p.splits * H + hrow;
   const float* wo_b = p.ws_o + ((int64_t)b * p.splits * H + hrow) * kLatent + 4 * u;
   float mx = my_lse;
@@ -1232,7 +783,8 @@ __device__ __forceinline__ void mla_merge_splits(const MlaParams& p, int b, int 
     const float l2 = s2 == split ? my_lse : lse_b[(int64_t)s2 * H];
     if (l2 != -INFINITY) wsum += exp2f(l2 - mx);
   }
-  const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+  // (all_in false: a partial result never arrived - NaN rows instead of a silently wrong sum)
+  const float inv = !all_in ? __builtin_nanf("") : wsum > 0.f ? 1.0f / wsum : 0.f;
   static_for<0, 8>([&](auto cc) {  // 8 chunks of 8 register groups (32 accumulators of this lane's row)
     constexpr int c0 = decltype(cc)::value * 8;
     v4f acc[8];
@@ -1363,10 +915,10 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
                              __HIP_MEMORY_SCOPE_AGENT);
         mla_count_in(p, b, tid);
       } else {
-        mla_wait_others(p, b, tid);
+        const bool all_in = mla_wait_others(p, b, smem, tid);
         const int hrow = ok ? my_head : 0;
         T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + hrow) * kLatent + 4 * u;
-        mla_merge_splits<T, M, false>(p, b, split, H, ok, hrow, out, u, -INFINITY, 0.f);
+        mla_merge_splits<T, M, false>(p, b, split, H, ok, hrow, out, u, -INFINITY, 0.f, all_in);
       }
     }
     return;
@@ -1771,10 +1323,638 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
                            __HIP_MEMORY_SCOPE_AGENT);
       mla_count_in(p, b, tid);
     } else {
-      mla_wait_others(p, b, tid);
+      const bool all_in = mla_wait_others(p, b, smem, tid);
       const int hrow = ok ? my_head : 0;
       T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + hrow) * kLatent + 4 * u;
-      mla_merge_splits<T, M, true>(p, b, split, H, ok, hrow, out, u, my_lse, inv_l);
+      mla_merge_splits<T, M, true>(p, b, split, H, ok, hrow, out, u, my_lse, inv_l, all_in);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  write_stamps();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rows128z kernel (round 5): the rows128x kernel's arithmetic, registers, LDS image and merge, with the tile loop re-cut around
+// what round 5's in-kernel stamps showed (per 32-token tile, one wave per SIMD: 2176 cycles of MFMA, ~4000 spent):
+//   * phase-start bubbles (~250 cycles each): every phase began with ~13 address instructions and the latency of its first
+//     fragment reads. Now the P.V fragments of tile j-1 are requested in the last three MFMA gaps of QK^T(j) (K reads are asm
+//     with hand-counted waits too, so the two rings share one counter), the 16 + 16 per-tile address registers are gone (one
+//     stage-relative base per operand and a v_xor per chunk pair / dim-tile column, computed in the gaps that use them), and
+//     the QK^T phase, which cannot start its reads before the tile barrier, fills that latency with the tile's rope DMA piece;
+//   * LDS-DMA pieces (9 per wave and tile) cost ~60 cycles each in the QK^T gaps, ~240 cycles of barrier skew and a block of
+//     64-bit vector address arithmetic: all four waves issued their piece in the same gap and queued for the CU's one
+//     vector-memory path. Now the pieces sit in the P.V gaps (which carry no softmax exponentials), wave w in the gaps
+//     m % 4 == w - at most one wave issues at a time - with scalar bases (`global_load_lds_dwordx4 voff, s[base]`) and
+//     loop-invariant lane offsets;
+//   * page ids: a 64-entry window of the page table lives in one VGPR (lane = entry), a tile's ids are two v_readlane; the
+//     window is re-fetched (asm load, in front of the iteration's nine pieces, so that the next iteration's counted vmcnt
+//     covers it) once per 32 - 128 tiles: no scalar load shares lgkmcnt with the LDS reads;
+//   * softmax micro-ops re-cut so that no instruction directly follows its producer (fma, fma | exp, cvt | exp, dot2).
+template <typename T, bool kStamp = false, int kProbe = 0>
+__global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p, const T* __restrict__ q_nope,
+                                                                    const T* __restrict__ q_pe,
+                                                                    const char* __restrict__ cache,
+                                                                    const int32_t* __restrict__ seq_lens,
+                                                                    const int32_t* __restrict__ page_table,
+                                                                    const int32_t* __restrict__ cu_seqlens_q) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using M = Mfma32<T>;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x, b = blockIdx.y;
+  const int H = p.H;
+  const int l31 = lane & 31, u = lane >> 5;
+
+  // ---- this lane's row: (token slot, head) of workgroup row 32 wave + l31
+  const int hp_mask = (1 << p.hp_shift) - 1;
+  const int row = wave * 32 + l31;
+  const int my_tok = row >> p.hp_shift, my_head = row & hp_mask;
+  int q_row0 = b, n_tok = 1, seq, kv_first;
+  if (cu_seqlens_q != nullptr) {
+    const int q0 = cu_seqlens_q[b], sq = cu_seqlens_q[b + 1] - q0, sk = seq_lens[b];
+    const int t0 = (int)blockIdx.z << (7 - p.hp_shift);
+    if (t0 >= sq) return;
+    const int tpw = 1 << (7 - p.hp_shift);
+    n_tok = (sq - t0) < tpw ? (sq - t0) : tpw;
+    q_row0 = q0 + t0;
+    kv_first = p.causal ? sk - sq + t0 + 1 : sk;
+    seq = p.causal ? sk - sq + t0 + n_tok : sk;
+  } else {
+    seq = seq_lens[b];
+    kv_first = seq;
+  }
+  if (seq < 0) seq = 0;
+  seq = __builtin_amdgcn_readfirstlane(seq);
+  kv_first = __builtin_amdgcn_readfirstlane(kv_first);
+  const bool ok = my_tok < n_tok && my_head < H;
+  const bool work = __any(ok) && p.probe != 1;
+  // the same, recomputed from a laundered thread id where it is needed after the prologue (the mask path, the epilogue): the
+  // compiler otherwise carries these lane values across the tile loop - in registers it does not have (it parked them in
+  // a0..a5, the accumulators this kernel owns: check_isa caught it)
+  struct RowId {
+    int u, my_tok, my_head;
+    bool ok;
+  };
+  auto row_id = [&]() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    RowId r;
+    const int ln = t & 63, r_row = wave * 32 + (ln & 31);
+    r.u = ln >> 5;
+    r.my_tok = r_row >> p.hp_shift;
+    r.my_head = r_row & hp_mask;
+    r.ok = r.my_tok < n_tok && r.my_head < H;
+    return r;
+  };
+  const int ntiles = (seq + kTile - 1) / kTile;
+  const int tps = (ntiles + p.splits - 1) / p.splits;
+  const int t_begin = split * tps;
+  const int t_end = (t_begin + tps < ntiles) ? (t_begin + tps) : ntiles;
+  const int n_my = t_end - t_begin;
+
+  const int32_t* table = page_table + (int64_t)b * p.table_stride;
+  const int page_mask = (1 << p.page_shift) - 1;
+
+  // ---- nothing to do for this split (decode only: an empty sequence, or more splits than tiles)
+  if (n_my <= 0) {
+    if (ok) {
+      if (p.splits == 1) {
+        T* out = (T*)p.out + ((int64_t)(q_row0 + my_tok) * H + my_head) * kLatent;
+        for (int d = u * 256; d < u * 256 + 256; ++d) out[d] = (T)0.f;
+      }
+    }
+    if (p.splits > 1) {  // (no keys here: a log2-sum-exp of -inf takes part in the merge, no O - see mla_take_ticket)
+      if (!mla_take_ticket(p, b, smem, tid)) {
+        if (ok && u == 0)
+          __hip_atomic_store(p.ws_lse + ((int64_t)b * p.splits + split) * H + my_head, -INFINITY, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        mla_count_in(p, b, tid);
+      } else {
+        const bool all_in = mla_wait_others(p, b, smem, tid);
+        const int hrow = ok ? my_head : 0;
+        T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + hrow) * kLatent + 4 * u;
+        mla_merge_splits<T, M, false>(p, b, split, H, ok, hrow, out, u, -INFINITY, 0.f, all_in);
+      }
+    }
+    return;
+  }
+
+  // ---- page-table window: lane L holds table[win0 + L] (entries past the sequence's last page: the last page)
+  const int last_entry = (seq - 1) >> p.page_shift;
+  auto tile_of = [&](int j) { return t_begin + (j < n_my ? j : n_my - 1); };
+  int win0 = (tile_of(0) * kTile) >> p.page_shift;
+  int v_ids;
+  auto ids_fetch = [&]() {  // asm: the compiler must not count this load (it would drain the DMA ring in front of the first use)
+    int e = win0 + lane;
+    e = e < last_entry ? e : last_entry;
+    const uint32_t off = (uint32_t)e * 4u;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v_ids) : "v"(off), "s"(table) : "memory");
+  };
+  ids_fetch();
+  // page ids of tile t (both 16-token halves; for pages of 32 tokens and more both name the same page)
+  auto ids_of = [&](int t, int& pg0, int& pg1) {
+    const int tok0 = t * kTile;
+    const int e0 = tok0 >> p.page_shift;
+    const int e1 = (tok0 + 16 < seq) ? ((tok0 + 16) >> p.page_shift) : e0;
+    pg0 = __builtin_amdgcn_readlane(v_ids, e0 - win0);
+    pg1 = __builtin_amdgcn_readlane(v_ids, e1 - win0);
+  };
+  // moves the window when tile t's entries do not lie in it (t: the tile whose ids the NEXT iteration reads)
+  auto ids_advance = [&](int t) {
+    const int tok0 = t * kTile;
+    const int e0 = tok0 >> p.page_shift;
+    const int e1 = (tok0 + 16) >> p.page_shift;
+    if (e1 - win0 >= 64) {
+      win0 = e0;
+      ids_fetch();
+    }
+  };
+
+  // ---- Q^T fragments (B operand of K . Q^T): lane supplies q[row][16 ks + 8 u .. + 8). The 32 fragments of the latent part
+  // stay in registers (128); the four rope fragments sit in the 16 KiB of LDS the four stages leave free - each lane reads
+  // back what it wrote, so no barrier - and come in through the K ring's counter: 16 registers the tile loop needs for the
+  // P.V fragments it now requests while the QK^T phase still runs (with all of Q in registers the compiler parked ten
+  // values in a0..a9, the accumulators this kernel owns).
+  constexpr int kQpeOff = 4 * kStageBytes;
+  v8s qf[32];
+  const uint32_t qpe_addr = (uint32_t)(uintptr_t)SGLK_LDS(smem) + (uint32_t)(kQpeOff + wave * 4096 + lane * 16);
+  {
+    const int64_t qrow = q_row0 + (ok ? my_tok : 0);
+    const T* qn = q_nope + qrow * p.qn_sb + (int64_t)(ok ? my_head : 0) * p.qn_sh + 8 * u;
+    const T* qp = q_pe + qrow * p.qp_sb + (int64_t)(ok ? my_head : 0) * p.qp_sh + 8 * u;
+    const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+      const v8s v = *reinterpret_cast<const v8s*>(qn + 16 * ks);
+      qf[ks] = ok ? v : zero;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const v8s v = *reinterpret_cast<const v8s*>(qp + 16 * ks);
+      *reinterpret_cast<v8s*>(smem + kQpeOff + wave * 4096 + ks * 1024 + lane * 16) = ok ? v : zero;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(v_ids)::"memory");  // Q and the page ids are in place before any LDS-DMA is counted
+
+  // ---- LDS-DMA of one tile: wave w fills column block w (eight 1-KiB pieces of four rows each) and rope rows 8w .. 8w+7.
+  // Global side: a scalar base (the tile's first row / its 17th) + a loop-invariant lane offset; the swizzle of the LDS
+  // image sits in the lane offset (the DMA writes consecutive LDS addresses).
+  const uint32_t dma_lo0 = (uint32_t)((lane >> 4) * kRowBytes + wave * 256 + 16 * ((lane & 15) ^ ((lane >> 4) << 2)));
+  uint32_t dvo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dvo[r] = (dma_lo0 ^ (uint32_t)(r << 4)) + (uint32_t)(r * 4 * kRowBytes);
+  const uint32_t dro = (uint32_t)((((wave & 1) * 8 + (lane >> 3)) * kRowBytes) + 1024 +
+                                  16 * ((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)));
+  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
+  // (the DMA instructions are asm text: an LDS-DMA the compiler can see makes it wait vmcnt(0) in front of the next LDS
+  //  read it can see - any read may alias the DMA's LDS write - which would empty the ring once per tile)
+  auto dma_s = [&](const char* sbase, uint32_t voff, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory", "m0");
+  };
+  struct TileSrc {
+    const char* sA;  // rows 0..15 of the tile
+    const char* sB;  // rows 16..31
+    uint32_t dst;    // this wave's column block in the tile's stage
+    uint32_t rdst;   // this wave's rope rows
+  };
+  auto tile_src = [&](int t, int st, int pg0, int pg1) {
+    TileSrc s;
+    const int tok0 = t * kTile;
+    s.sA = cache + (int64_t)pg0 * p.page_stride_bytes + (int64_t)(tok0 & page_mask) * kRowBytes;
+    s.sB = p.page_shift == 4 ? cache + (int64_t)pg1 * p.page_stride_bytes : s.sA + 16 * kRowBytes;
+    s.dst = lds_base + (uint32_t)(st * kStageBytes + wave * 8192);
+    s.rdst = lds_base + (uint32_t)(st * kStageBytes + kMainBytes + wave * 1024);
+    return s;
+  };
+  auto dma_piece = [&](const TileSrc& s, auto ic) {  // piece 0..7: a row group of the column block; 8: the rope rows
+    constexpr int rg = decltype(ic)::value;
+    if constexpr (kProbe != 4 && kProbe != 5) {
+      if constexpr (rg < 8) dma_s(rg < 4 ? s.sA : s.sB, dvo[rg & 3], s.dst + (uint32_t)(rg * 1024));
+      else dma_s(wave < 2 ? s.sA : s.sB, dro, s.rdst);
+    }
+  };
+  auto stage_tile = [&](int t, int st, int pg0, int pg1) {
+    const TileSrc s = tile_src(t, st, pg0, pg1);
+    static_for<0, 9>([&](auto ic) { dma_piece(s, ic); });
+  };
+
+  // ---- per-lane LDS read offsets inside a stage
+  // K row read, k-step ks: block ks / 8, chunk 2 (ks % 8) + u of token row l31  ->  kbase ^ (32 (ks % 8)) + 8192 (ks / 8)
+  const uint32_t kbase = (uint32_t)(256 * l31 + 16 * (u ^ sw_main(l31)));
+  const uint32_t rbase = (uint32_t)(kMainBytes + 128 * l31 + 16 * (u ^ ((l31 >> 1) & 7)));  // rope: ^ (32 (ks - 32))
+  // V^T transposed read of dim tile dt, k-step s, token half e (tokens 16 s + 8 e + 4 u + qq, dims 32 dt + 16 hh + 4 pp ..):
+  //   8192 (dt / 4) + 4096 s + 2048 e + (vbase ^ (64 (dt % 4)) ^ (32 e))
+  const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, hh = (lane >> 4) & 1;
+  const uint32_t vbase = (uint32_t)(256 * (4 * u + qq) + 8 * (pp & 1) + 16 * ((qq << 2) | ((2 * hh + (pp >> 1)) ^ u)));
+
+  // O^T tile dt = a[16 dt .. 16 dt + 15], named only in asm text; the clobbers tell the compiler that the kernel owns the
+  // whole AGPR file (build.py check_isa verifies that it places nothing there)
+  asm volatile("" ::: "a0", "a255");
+  static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
+
+  // Lazy reference: see mla_rows128x_kernel
+  constexpr bool kWide = std::is_same<T, bf16>::value;
+  constexpr float kLazy = kWide ? 90.0f : 8.0f, kHead = kWide ? 100.0f : 0.0f;
+  const float sl2 = p.scale_log2;
+  const float head_raw = (kWide && sl2 > 0.f) ? kHead / sl2 : 0.f;  // 2^kHead in units of the raw logits
+  float m_ref = -INFINITY, m_run = -INFINITY, l_run = 0.f;
+
+  // Every tile slot past the split's last tile re-loads the last tile into a stage nobody reads (two duplicates per split):
+  // the DMA needs no condition and every tile-landed wait is the same vmcnt(9).
+  {
+    int a0, a1;
+    ids_of(tile_of(0), a0, a1);
+    stage_tile(tile_of(0), 0, a0, a1);
+    ids_of(tile_of(1), a0, a1);
+    stage_tile(tile_of(1), 1, a0, a1);
+  }
+
+  float mt = 0.f, mb = 0.f, alpha = 1.0f, mneg = 0.f, psum = 0.f;
+  bool upd = false;
+  v8s pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+
+  // second half of the softmax of the tile whose raw logits are in sp (reference mneg, fixed by the first half), as micro-ops
+  // for the QK^T gaps 1 .. 27. Pair pr = weights 2 pr, 2 pr + 1: gap 3 pr + 1 both multiply-adds, gap 3 pr + 2 the first
+  // exponential and the PREVIOUS pair's rounding, gap 3 pr + 3 the second exponential and the previous pair's row-sum step:
+  // no instruction directly follows its producer (a dependent pair waits out the VALU latency: stamps, round 5).
+  int pk_prev = 0;
+  auto exp_op = [&](auto kc, v16f& sp) {
+    constexpr int k = decltype(kc)::value;  // gap - 1
+    constexpr int pr = k / 3, r = k % 3;
+    if constexpr (pr < 8 && r == 0) {
+      float y0 = __builtin_fmaf(sp[2 * pr], sl2, mneg), y1 = __builtin_fmaf(sp[2 * pr + 1], sl2, mneg);
+      asm volatile("" : "+v"(y0), "+v"(y1));
+      sp[2 * pr] = y0;
+      sp[2 * pr + 1] = y1;
+    }
+    if constexpr (pr < 8 && r == 1) {
+      float e = __builtin_amdgcn_exp2f(sp[2 * pr]);
+      asm volatile("" : "+v"(e));
+      sp[2 * pr] = e;
+    }
+    if constexpr (pr < 8 && r == 2) {
+      float e = __builtin_amdgcn_exp2f(sp[2 * pr + 1]);
+      asm volatile("" : "+v"(e));
+      sp[2 * pr + 1] = e;
+    }
+    // the previous pair (pq): rounded and packed one gap after its second exponential, added to the row sum a gap later
+    if constexpr (k >= 4 && k <= 25 && r == 1) {
+      constexpr int pq = pr - 1;
+      int pk = M::pack(sp[2 * pq], sp[2 * pq + 1]);
+      asm volatile("" : "+v"(pk));
+      pk_prev = pk;
+      pf[pq >> 2][2 * (pq & 3)] = (short)(pk & 0xffff);
+      pf[pq >> 2][2 * (pq & 3) + 1] = (short)((unsigned)pk >> 16);
+    }
+    if constexpr (k >= 5 && k <= 26 && r == 2) {
+      psum = M::add2(pk_prev, psum);  // the row sum takes the ROUNDED weights (numerator and denominator round alike)
+      asm volatile("" : "+v"(psum));
+    }
+    if constexpr (k == 27) {
+      l_run += psum;
+      asm volatile("" : "+v"(l_run));
+    }
+  };
+  constexpr int kExpOps = 28;
+  // first half: row maximum of the raw logits in sc, then the lazy reference: see mla_rows128x_kernel
+  auto max_op = [&](auto kc, v16f& sc) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k == 0) {
+      mt = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+      mb = fmaxf(fmaxf(sc[3], sc[4]), sc[5]);
+    } else if constexpr (k == 1) {
+      mt = fmaxf(fmaxf(mt, sc[6]), sc[7]);
+      mb = fmaxf(fmaxf(mb, sc[8]), sc[9]);
+    } else if constexpr (k == 2) {
+      mt = fmaxf(fmaxf(mt, sc[10]), sc[11]);
+      mb = fmaxf(fmaxf(mb, sc[12]), sc[13]);
+    } else if constexpr (k == 3) {
+      mt = fmaxf(fmaxf(mt, sc[14]), sc[15]);
+      mt = fmaxf(mt, mb);
+    } else if constexpr (k == 4) {  // the other 16 tokens of this row live in lane ^ 32
+      float c0 = mt, c1 = mt;
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
+      mt = fmaxf(c0, c1);
+    } else if constexpr (k == 5) {
+      upd = __any((mt - m_ref) * sl2 > kLazy);  // (first tile: +inf; nothing but masked keys so far: NaN -> false)
+      m_run = fmaxf(m_run, mt);
+    } else if constexpr (k == 6) {
+      const float cand = upd ? m_run + head_raw : -INFINITY;  // (selects, no branch in the MFMA stream)
+      const float m_new = fmaxf(m_ref, cand);
+      alpha = m_new > m_ref ? __builtin_amdgcn_exp2f((m_ref - m_new) * sl2 * 0.5f) : 1.0f;  // (the factor's square root)
+      m_ref = m_new;
+    } else if constexpr (k == 7) {
+      mneg = m_ref == -INFINITY ? 0.f : -m_ref * sl2;
+      l_run = l_run * alpha * alpha;
+      psum = 0.f;
+    }
+    asm volatile("" : "+v"(mt), "+v"(mb), "+v"(alpha), "+v"(mneg), "+v"(l_run), "+v"(m_ref), "+v"(m_run));
+  };
+  constexpr int kMaxOps = 8;
+
+  // ---- rings. K: fragment n + 3 is requested in the gap behind MFMA n; V^T: four fragments (eight transposed reads) ahead,
+  // the first three requested in the last three gaps of the QK^T phase in front (kPre).
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  constexpr int kKA = 3, kVA = 4;
+  v2i vlo[kVA], vhi[kVA];
+  uint32_t vb[2];  // stage-relative bases of the tile whose P . V comes next (token halves e = 0, 1)
+  uint32_t va0 = 0, va1 = 0;
+  // order of the 32 P.V MFMAs: m -> column x = m / 8 of the dim tiles (dt % 4), then dt / 4 = (m % 8) / 2, k-step m % 2: the
+  // two address registers of a column serve eight MFMAs, everything else is an immediate
+  // (a capture-less lambda behind a macro: clang rejects asm outputs that name captured arrays inside nested generic lambdas)
+  auto v_issue_ = [](auto mc, v2i& lo, v2i& hi, uint32_t& a0, uint32_t& a1, const uint32_t b0, const uint32_t b1) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int q = m & 7, c = (q >> 1) * 8192 + (q & 1) * 4096;
+    if constexpr ((m & 7) == 0) {  // (first use of column x: its two addresses)
+      constexpr uint32_t xo = (uint32_t)((m >> 3) << 6);
+      a0 = b0 ^ xo;
+      a1 = b1 ^ xo;
+      asm volatile("" : "+v"(a0), "+v"(a1));
+    }
+    if constexpr (kProbe != 1 && kProbe != 3 && kProbe != 5) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(c));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(c));
+    }
+  };
+#define SGLK_V_ISSUE(M_) v_issue_(std::integral_constant<int, (M_)>{}, vlo[(M_) % kVA], vhi[(M_) % kVA], va0, va1, vb[0], vb[1])
+
+  // ---- S^T of tile j (raw logits) in VGPRs: asm MFMAs behind hand-counted waits, asm K reads. k-step order n -> chunk pair
+  // n / 4 of column block n % 4 (n < 32: one address serves four reads), then the four rope steps.
+  // The first MFMA takes the constant 0 as its addend: no VALU write feeds an asm MFMA (the hazard recogniser cannot see one).
+  auto qk_tile = [&](int j, v16f& s, auto with_exp, v16f& sp, const TileSrc& nxt, int jv) {
+    constexpr bool kExp = decltype(with_exp)::value;
+    const uint32_t sb = lds_base + (uint32_t)((j & 3) * kStageBytes);
+    uint32_t kbs = kbase + sb, rbs = rbase + sb;  // (stage bases are multiples of 256: the xor of bits 5..7 commutes with the add)
+    asm volatile("" : "+v"(kbs), "+v"(rbs));
+    v4i kr[kKA], qr[4];  // (K ring of three; the four rope fragments of Q, read from LDS with their K fragments)
+    uint32_t ka = kbs;
+    // (capture-less, behind a macro: see v_issue_)
+    auto k_issue_ = [](auto nc, v4i& kslot, v4i& qslot, uint32_t& ka_, const uint32_t kbs_, const uint32_t rbs_,
+                       const uint32_t qpe_) {
+      constexpr int n = decltype(nc)::value;
+      if constexpr (n < 32) {
+        if constexpr ((n & 3) == 0 && n > 0) {
+          ka_ = kbs_ ^ (uint32_t)((n >> 2) << 5);
+          asm volatile("" : "+v"(ka_));
+        }
+        if constexpr (kProbe != 2 && kProbe != 3 && kProbe != 5)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kslot) : "v"(ka_), "i"((n & 3) * 8192));
+      } else {
+        uint32_t ra = rbs_ ^ (uint32_t)((n - 32) << 5);
+        if constexpr (kProbe != 2 && kProbe != 3 && kProbe != 5) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(kslot) : "v"(ra));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qslot) : "v"(qpe_), "i"((n - 32) * 1024));
+        }
+      }
+    };
+#define SGLK_K_ISSUE(N_) k_issue_(std::integral_constant<int, (N_)>{}, kr[(N_) % kKA], qr[(N_) & 3], ka, kbs, rbs, qpe_addr)
+    SGLK_K_ISSUE(0);
+    SGLK_K_ISSUE(1);
+    SGLK_K_ISSUE(2);
+    // under the latency of the first fragments: the rope piece of tile j + 2
+    if constexpr (kExp) dma_piece(nxt, std::integral_constant<int, 8>{});
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 36>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      constexpr int ks = n < 32 ? 8 * (n & 3) + (n >> 2) : 0;  // the Q fragment that goes with K fragment n (rope: from LDS)
+      // reads younger than step n's at this point: those of the steps n+1, n+2 (one each, two for a rope step: K and Q) and
+      // the V^T reads of the gaps 33, 34 (two each)
+      constexpr int r1 = n + 1 > 35 ? 0 : n + 1 >= 32 ? 2 : 1, r2 = n + 2 > 35 ? 0 : n + 2 >= 32 ? 2 : 1;
+      constexpr int younger = r1 + r2 + (kExp ? (n == 34 ? 2 : n == 35 ? 4 : 0) : 0);
+      constexpr int wcnt = (kProbe == 2 || kProbe == 3 || kProbe == 5) ? 0 : younger;
+      const v8s kf = __builtin_bit_cast(v8s, kr[n % kKA]);
+      const v8s qb = n < 32 ? qf[ks] : __builtin_bit_cast(v8s, qr[n & 3]);
+      if constexpr (n == 0) {
+        if constexpr (std::is_same<T, bf16>::value)
+          asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf), "v"(qb), "i"(wcnt));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf), "v"(qb), "i"(wcnt));
+      } else {
+        if constexpr (std::is_same<T, bf16>::value)
+          asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "v"(qb), "i"(wcnt));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "v"(qb), "i"(wcnt));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kExp && n >= 1 && n - 1 < kExpOps && kProbe != 6) exp_op(std::integral_constant<int, n - 1>{}, sp);
+      // (the slot stays reserved up to its refill: the MFMA issued just before is still reading it)
+      asm volatile("" ::"v"(kr[n % kKA]));
+      if constexpr (n >= 32) asm volatile("" ::"v"(qr[n & 3]));
+      if constexpr (n + kKA < 36) SGLK_K_ISSUE(n + kKA);
+      if constexpr (kExp) {  // P . V of tile jv comes next: its bases, then its first four fragments
+        if constexpr (n == 31) {
+          const uint32_t sv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
+          vb[0] = vbase + sv;
+          vb[1] = (vb[0] ^ 32u) + 2048u;
+          asm volatile("" : "+v"(vb[0]), "+v"(vb[1]));
+        }
+        if constexpr (n == 33) SGLK_V_ISSUE(0);
+        if constexpr (n == 34) SGLK_V_ISSUE(1);
+        if constexpr (n == 35) SGLK_V_ISSUE(2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("" : "+v"(s));
+#pragma unroll
+    for (int i = 0; i < kKA; ++i) asm volatile("" ::"v"(kr[i]));  // (the ring stays reserved past the last MFMAs)
+#undef SGLK_K_ISSUE
+  };
+  auto mask_tile = [&](int j, v16f& s) {  // (rare, uniform: keys past a row's horizon)
+    const int t = t_begin + j;
+    if (t * kTile + kTile > kv_first || t * kTile + kTile > seq) {
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s));  // (asm MFMA result -> VALU read wait states)
+      const RowId r = row_id();  // (recomputed here: nothing lane-dependent of the epilogue stays live across the tile loop)
+      const int kv_row = (cu_seqlens_q != nullptr && p.causal && r.my_tok < n_tok) ? kv_first + r.my_tok : seq;  // the row's horizon
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        if (t * kTile + (v & 3) + 8 * (v >> 2) + 4 * r.u >= kv_row) s[v] = -INFINITY;
+    }
+  };
+
+  // ---- O^T += V^T . P^T of tile jv: asm MFMAs on the fixed accumulators and asm transposed reads in program order with
+  // hand-counted waits. kPre: the first four fragments were requested by the QK^T phase in front. kSlot >= 0: this wave's
+  // DMA pieces 0..7 of the tile after next go out in the gaps m % 4 == kSlot (wave w: slot w - one wave at a time on the
+  // CU's vector-memory path).
+  auto pv_tile = [&](int jv, auto pre, auto with_max, v16f& sc, auto slot, const TileSrc& nxt) {
+    constexpr bool kPre = decltype(pre)::value, kMax = decltype(with_max)::value;
+    constexpr int kSlot = decltype(slot)::value;
+    if constexpr (!kPre) {
+      const uint32_t sv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
+      vb[0] = vbase + sv;
+      vb[1] = (vb[0] ^ 32u) + 2048u;
+      asm volatile("" : "+v"(vb[0]), "+v"(vb[1]));
+      static_for<0, kVA>([&](auto mc) { constexpr int m0 = decltype(mc)::value; SGLK_V_ISSUE(m0); });
+    } else {
+      SGLK_V_ISSUE(3);  // (three fragments came with the QK^T phase: its K ring was still live there)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 32>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int q = m & 7, dt = (m >> 3) + 4 * (q >> 1), ss = q & 1;
+      constexpr int ahead = (32 - m < kVA ? 32 - m : kVA) - 1;  // fragments issued after this one
+      // (the two halves are coalesced into the 4-register operand in place - no copy may sit between the reads and the
+      //  wait the MFMA statement starts with; the ISA shows none)
+      const v8s f = __builtin_bit_cast(v8s, __builtin_shufflevector(vlo[m % kVA], vhi[m % kVA], 0, 1, 2, 3));
+      constexpr int wcnt = (kProbe == 1 || kProbe == 3 || kProbe == 5) ? 0 : 2 * ahead;
+      M::template wait_acc_agpr<dt * 16, wcnt>(f, pf[ss]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kMax && m >= 2 && m - 2 < kMaxOps && kProbe != 6) max_op(std::integral_constant<int, m - 2>{}, sc);
+      // the fragment's registers stay reserved past the micro-op (a VALU write into an operand of the MFMA issued just
+      // before is not interlocked); the refill of this slot lands tens of cycles later
+      asm volatile("" ::"v"(f));
+      if constexpr (m + kVA < 32) SGLK_V_ISSUE(m + kVA);
+      if constexpr (kSlot >= 0 && (m & 3) == kSlot) dma_piece(nxt, std::integral_constant<int, (m >> 2)>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // the operands of the last MFMAs stay reserved until the matrix pipe has read them
+    asm volatile("" ::"v"(pf[0]), "v"(pf[1]));
+#pragma unroll
+    for (int i = 0; i < kVA; ++i) asm volatile("" ::"v"(vlo[i]), "v"(vhi[i]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#undef SGLK_V_ISSUE
+
+  unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+  auto stamp = [&](int k) {
+    if constexpr (kStamp) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      st_sum[k] += now - st_t;
+      st_t = now;
+    }
+  };
+  unsigned long long clk0 = 0, rt0 = 0;
+  if constexpr (kStamp) {
+    st_t = __builtin_amdgcn_s_memtime();
+    clk0 = st_t;
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
+  // One iteration: tile j's QK^T (+ exponentials of tile j-1 from s_prv, + the first V^T reads of tile j-1), then P.V of
+  // tile j-1 (+ maxima of tile j in s_cur, + the DMA pieces of tile j+2).
+  auto iter = [&](int j, v16f& s_cur, v16f& s_prv) {
+    stamp(8);
+    asm volatile("s_waitcnt vmcnt(9)" : "+v"(v_ids)::"memory");  // tile j landed; so has a window fetched an iteration ago
+    stamp(0);
+    __builtin_amdgcn_s_barrier();  // tile j landed for every wave; every wave is done with tile j-2
+    stamp(1);
+    int pga, pgb;
+    ids_of(tile_of(j + 2), pga, pgb);
+    ids_advance(tile_of(j + 3));  // (in front of this iteration's nine pieces)
+    const TileSrc nxt = tile_src(tile_of(j + 2), (j + 2) & 3, pga, pgb);
+    stamp(2);
+    if (work) {
+      qk_tile(j, s_cur, std::true_type{}, s_prv, nxt, j - 1);  // + exponentials of tile j-1 -> pf
+      mask_tile(j, s_cur);
+      __builtin_amdgcn_sched_barrier(0);
+      stamp(3);
+      // + row maxima / reference of tile j; the slot of this wave's DMA pieces is a template parameter: four copies
+      if (wave == 0) pv_tile(j - 1, std::true_type{}, std::true_type{}, s_cur, std::integral_constant<int, 0>{}, nxt);
+      else if (wave == 1) pv_tile(j - 1, std::true_type{}, std::true_type{}, s_cur, std::integral_constant<int, 1>{}, nxt);
+      else if (wave == 2) pv_tile(j - 1, std::true_type{}, std::true_type{}, s_cur, std::integral_constant<int, 2>{}, nxt);
+      else pv_tile(j - 1, std::true_type{}, std::true_type{}, s_cur, std::integral_constant<int, 3>{}, nxt);
+      stamp(4);
+      if (upd) {  // rare: the reference moved, rescale O (AGPR -> VGPR -> AGPR) before the next P . V
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");  // (MFMA -> v_accvgpr_read wait states)
+        static_for<0, 32>([&](auto ic) { agpr_scale8_sq<decltype(ic)::value * 8>(alpha); });
+        asm volatile("s_nop 7");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      static_for<0, 9>([&](auto ic) { dma_piece(nxt, ic); });
+    }
+  };
+  v16f s_a, s_b;
+  {  // tile 0: nothing to overlap with
+    stamp(5);
+    asm volatile("s_waitcnt vmcnt(9)" : "+v"(v_ids)::"memory");
+    __builtin_amdgcn_s_barrier();
+    int pga, pgb;
+    ids_of(tile_of(2), pga, pgb);
+    ids_advance(tile_of(3));
+    const TileSrc nxt = tile_src(tile_of(2), 2, pga, pgb);
+    static_for<0, 9>([&](auto ic) { dma_piece(nxt, ic); });
+    if (work) {
+      qk_tile(0, s_b, std::false_type{}, s_b, nxt, 0);
+      mask_tile(0, s_b);
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s_b));  // (asm MFMA result -> VALU read wait states)
+      static_for<0, kMaxOps>([&](auto kc) { max_op(kc, s_b); });  // (O is zero: nothing to rescale)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  int j = 1;
+  for (; j + 1 < n_my; j += 2) {  // (two tiles per trip: the logits of the tile in flight and of the one before swap roles)
+    iter(j, s_a, s_b);
+    iter(j + 1, s_b, s_a);
+  }
+  const bool odd_tail = j < n_my;
+  if (odd_tail) iter(j, s_a, s_b);
+  if (work) {
+    if (odd_tail) static_for<0, kExpOps>([&](auto kc) { exp_op(kc, s_a); });
+    else static_for<0, kExpOps>([&](auto kc) { exp_op(kc, s_b); });
+    __builtin_amdgcn_sched_barrier(0);
+    v16f dummy;
+    TileSrc none = {};
+    pv_tile(n_my - 1, std::false_type{}, std::false_type{}, dummy, std::integral_constant<int, -1>{}, none);
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");  // (MFMA -> v_accvgpr_read wait states of the epilogue)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the duplicate tiles: no LDS-DMA may be in flight when the workgroup ends)
+  stamp(4);
+#ifdef SGLK_PROBES
+  auto write_stamps = [&]() {
+    if constexpr (kStamp) {
+      stamp(6);
+      if (lane == 0) {
+        unsigned long long* d = g_mla_stamps + (((size_t)b * p.splits + split) * 4 + wave) % 4096 * 16;
+        for (int k = 0; k < 12; ++k) d[k] = st_sum[k];
+        d[12] = __builtin_amdgcn_s_memtime() - clk0;       // shader cycles of the whole tile loop + epilogue
+        d[13] = __builtin_amdgcn_s_memrealtime() - rt0;    // the same in 100 MHz ticks
+        d[15] = (unsigned long long)n_my;
+      }
+    }
+  };
+#else
+  auto write_stamps = [&]() {};
+#endif
+
+  // ---- epilogue: O^T tile dt, register v: dim 32 dt + 8 (v / 4) + 4 u + v % 4 of this lane's row
+  if (p.probe == 1) return;
+  const RowId rid = row_id();
+  const bool ok2 = rid.ok;
+  const int u2 = rid.u, tok2 = rid.my_tok, head2 = rid.my_head;
+  float c0 = l_run, c1 = l_run;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));
+  const float l_tot = c0 + c1;
+  const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if (p.splits == 1) {
+    T* out = (T*)p.out + ((int64_t)(q_row0 + (ok2 ? tok2 : 0)) * H + (ok2 ? head2 : 0)) * kLatent + 4 * u2;
+    static_for<0, 64>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;  // dim tile i / 4, register group i % 4
+      const v4f v = agpr_read4<i * 4>();
+      const int lo = M::pack(v[0] * inv_l, v[1] * inv_l), hi = M::pack(v[2] * inv_l, v[3] * inv_l);
+      if (ok2) *reinterpret_cast<v2i*>(out + 32 * (i >> 2) + 8 * (i & 3)) = (v2i){lo, hi};
+    });
+  } else {
+    const float my_lse = l_tot > 0.f ? m_ref * sl2 + log2f(l_tot) : -INFINITY;
+    if (!mla_take_ticket(p, b, smem, tid)) {
+      float* wo = p.ws_o + (((int64_t)b * p.splits + split) * H + (ok2 ? head2 : 0)) * kLatent + 4 * u2;
+      static_for<0, 64>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const v4f v = agpr_read4<i * 4>();
+        const v4f w = {v[0] * inv_l, v[1] * inv_l, v[2] * inv_l, v[3] * inv_l};
+        float* const dst = wo + 32 * (i >> 2) + 8 * (i & 3);
+        if (ok2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+      });
+      if (ok2 && u2 == 0)
+        __hip_atomic_store(p.ws_lse + ((int64_t)b * p.splits + split) * H + head2, my_lse, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      mla_count_in(p, b, tid);
+    } else {
+      const bool all_in = mla_wait_others(p, b, smem, tid);
+      const int hrow = ok2 ? head2 : 0;
+      T* out = (T*)p.out + ((int64_t)(q_row0 + (ok2 ? tok2 : 0)) * H + hrow) * kLatent + 4 * u2;
+      mla_merge_splits<T, M, true>(p, b, split, H, ok2, hrow, out, u2, my_lse, inv_l, all_in);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1821,98 +2001,37 @@ static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nop
   return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
 }
 
-template <typename T>
-static int launch_rows128(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
-                          const void* cache, const int32_t* seq_lens, const int32_t* page_table,
-                          const int32_t* cu_seqlens_q = nullptr, int token_blocks = 1) {
-  static unsigned long long attr_done = 0;
-  constexpr int lds = 4 * kStageBytes;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128_kernel<T>), lds, &attr_done, "flash_mla_decode"))
-    return rc;
-  mla_rows128_kernel<T><<<dim3(p.splits, B, token_blocks), kThreads2, lds, st>>>(
-      p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
-  return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
-}
-
-template <typename T, int KA, int VA>
-static int launch_rows128x_v(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
-                             const void* cache, const int32_t* seq_lens, const int32_t* page_table,
-                             const int32_t* cu_seqlens_q, int token_blocks) {
-  static unsigned long long attr_done = 0;
-  constexpr int lds = 4 * kStageBytes;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, KA, VA>), lds, &attr_done,
-                               "flash_mla_decode"))
-    return rc;
-  mla_rows128x_kernel<T, KA, VA><<<dim3(p.splits, B, token_blocks), kThreads2, lds, st>>>(
-      p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
-  return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");
-}
 #ifdef SGLK_PROBES
-static int g_mla_variant = 0;  // ring depths of the rows128x kernel (kbench)
+static int g_mla_variant = 0;  // kbench: 50 = the round-4 tile loop, 90 = the same with stamps, 70 + probe = stamped round-5 loop
 #endif
 template <typename T>
 static int launch_rows128x(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
                            const void* cache, const int32_t* seq_lens, const int32_t* page_table,
                            const int32_t* cu_seqlens_q = nullptr, int token_blocks = 1) {
+  const dim3 grid(p.splits, B, token_blocks);
+  constexpr int ldsx = 4 * kStageBytes, ldsz = 4 * kStageBytes + 16384;  // (z: + the rope part of Q = all 160 KiB)
+#define SGLK_MLA_LAUNCH(KERNEL, lds)                                                                                      \
+  {                                                                                                                    \
+    static unsigned long long attr = 0;                                                                                \
+    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&KERNEL), lds, &attr, "flash_mla_decode")) return rc;   \
+    KERNEL<<<grid, kThreads2, lds, st>>>(p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, \
+                                         cu_seqlens_q);                                                                \
+    return check_launch(cu_seqlens_q ? "flash_mla_prefill" : "flash_mla_decode");                                      \
+  }
 #ifdef SGLK_PROBES
-#define SGLK_V(KA, VA) return launch_rows128x_v<T, KA, VA>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table, cu_seqlens_q, token_blocks)
   if constexpr (std::is_same<T, bf16>::value) {
-    if (g_mla_variant == 1) SGLK_V(5, 5);
-    if (g_mla_variant == 2) SGLK_V(6, 6);
-    if (g_mla_variant == 3) SGLK_V(4, 6);
-    if (g_mla_variant == 4) SGLK_V(6, 4);
-    if (g_mla_variant == 5) SGLK_V(2, 2);
-#define SGLK_STAMPED(PR)                                                                                               \
-  if (g_mla_variant == 90 + PR) {                                                                                      \
-    static unsigned long long attr2 = 0;                                                                               \
-    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 3, 4, true, PR>), 4 * kStageBytes, \
-                                 &attr2, "flash_mla_decode"))                                                          \
-      return rc;                                                                                                       \
-    mla_rows128x_kernel<T, 3, 4, true, PR><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(        \
-        p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);                   \
-    return check_launch("flash_mla_decode");                                                                           \
+    if (g_mla_variant == 50) SGLK_MLA_LAUNCH((mla_rows128x_kernel<T, 3, 4>), ldsx)
+    if (g_mla_variant == 90) SGLK_MLA_LAUNCH((mla_rows128x_kernel<T, 3, 4, true>), ldsx)
+    if (g_mla_variant == 94) SGLK_MLA_LAUNCH((mla_rows128x_kernel<T, 3, 4, true, 4>), ldsx)
+    if (g_mla_variant == 70) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0>), ldsz)
+    if (g_mla_variant == 73) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 3>), ldsz)
+    if (g_mla_variant == 74) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 4>), ldsz)
+    if (g_mla_variant == 75) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 5>), ldsz)
+    if (g_mla_variant == 76) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 6>), ldsz)
   }
-    SGLK_STAMPED(0) SGLK_STAMPED(1) SGLK_STAMPED(2) SGLK_STAMPED(3) SGLK_STAMPED(4) SGLK_STAMPED(5) SGLK_STAMPED(6)
-    SGLK_STAMPED(9) SGLK_STAMPED(10) SGLK_STAMPED(11) SGLK_STAMPED(13) SGLK_STAMPED(14) SGLK_STAMPED(15) SGLK_STAMPED(18) SGLK_STAMPED(19) SGLK_STAMPED(20) SGLK_STAMPED(21)
-#undef SGLK_STAMPED
-#define SGLK_STAMPED_ORD(V, ORD)                                                                                       \
-  if (g_mla_variant == 90 + V) {                                                                                       \
-    static unsigned long long attr2 = 0;                                                                               \
-    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 3, 4, true, 0, ORD>),           \
-                                 4 * kStageBytes, &attr2, "flash_mla_decode"))                                         \
-      return rc;                                                                                                       \
-    mla_rows128x_kernel<T, 3, 4, true, 0, ORD><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(    \
-        p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);                   \
-    return check_launch("flash_mla_decode");                                                                           \
-  }
-    SGLK_STAMPED_ORD(7, 1) SGLK_STAMPED_ORD(8, 2)
-    if (g_mla_variant == 90 + 16 || g_mla_variant == 90 + 17) {  // deeper rings
-      static unsigned long long attr4 = 0, attr5 = 0;
-      if (g_mla_variant == 90 + 16) {
-        if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 6, 4, true>), 4 * kStageBytes, &attr4, "mla")) return rc;
-        mla_rows128x_kernel<T, 6, 4, true><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(
-            p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
-      } else {
-        if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 2, 2, true>), 4 * kStageBytes, &attr5, "mla")) return rc;
-        mla_rows128x_kernel<T, 2, 2, true><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(
-            p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
-      }
-      return check_launch("flash_mla_decode");
-    }
-    if (g_mla_variant == 90 + 12) {  // DMA as a block in front of QK^T
-      static unsigned long long attr3 = 0;
-      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&mla_rows128x_kernel<T, 3, 4, true, 0, 0, false>),
-                                   4 * kStageBytes, &attr3, "flash_mla_decode"))
-        return rc;
-      mla_rows128x_kernel<T, 3, 4, true, 0, 0, false><<<dim3(p.splits, B, token_blocks), kThreads2, 4 * kStageBytes, st>>>(
-          p, (const T*)q_nope, (const T*)q_pe, (const char*)cache, seq_lens, page_table, cu_seqlens_q);
-      return check_launch("flash_mla_decode");
-    }
-#undef SGLK_STAMPED_ORD
-  }
-#undef SGLK_V
 #endif
-  return launch_rows128x_v<T, 3, 4>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table, cu_seqlens_q, token_blocks);
+  SGLK_MLA_LAUNCH((mla_rows128z_kernel<T>), ldsz)
+#undef SGLK_MLA_LAUNCH
 }
 
 // Diagnostic build only (-DSGLK_PROBES, tools/kbench): force the number of waves per 16-head group (0 = automatic;
@@ -1935,8 +2054,6 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
   int rc;
   if (ngroups > 4 && g_mla_waves_per_group == 0) {
     rc = launch_rows128x<T>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table);
-  } else if (ngroups > 4 && g_mla_waves_per_group == 10) {  // (hook: the 16x16x32 form of round 2, for A/B timing)
-    rc = launch_rows128<T>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table);
   } else
   switch (w) {
     case 8: rc = launch_w<T, 8>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
@@ -1954,8 +2071,9 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
 }
 
 }  // namespace
-// bytes of the merge counters in front of the workspace: 8 per batch element, padded to 256 (keeps what follows aligned)
-static inline int64_t mla_counter_bytes(int64_t batch) { return (batch * 8 + 255) / 256 * 256; }
+// bytes of the merge counters in front of the workspace: two 8-byte words per batch element, padded to 256 (keeps what
+// follows aligned)
+static inline int64_t mla_counter_bytes(int64_t batch) { return (batch * 16 + 255) / 256 * 256; }
 }  // namespace sglk
 
 #ifdef SGLK_PROBES
@@ -1984,7 +2102,7 @@ extern "C" int64_t sglk_mla_decode_workspace_size(int64_t max_seq_len, int64_t b
                                                   int64_t num_kv_splits) {
   if (num_kv_splits < 1) num_kv_splits = sglk_mla_decode_auto_splits(batch, max_seq_len);
   if (num_kv_splits == 1) return 0;
-  // {ticket, published} counters of the in-kernel merge (a block of their own at the start: the host zeroes exactly it), then
+  // {ticket, published} counter words of the in-kernel merge (a block of their own at the start), then
   // fp32 partial O and the log2-sum-exps
   return sglk::mla_counter_bytes(batch) + batch * num_kv_splits * num_heads * (sglk::kLatent + 1) * 4;
 }
@@ -2012,6 +2130,7 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   int64_t splits = num_kv_splits < 1 ? sglk_mla_decode_auto_splits(batch, max_seq) : num_kv_splits;
   const int64_t max_tiles = (max_seq + 31) / 32;
   if (splits > max_tiles) splits = max_tiles;
+  SGLK_REQUIRE(splits <= 32768, "flash_mla_decode: at most 32768 KV splits, got %lld", (long long)splits);
   if (splits > 1) {
     const int64_t need = mla_counter_bytes(batch) + batch * splits * num_heads * (kLatent + 1) * 4;
     SGLK_REQUIRE(workspace != nullptr && workspace_bytes >= need,
@@ -2021,7 +2140,7 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   }
   MlaParams p;
   p.out = out;
-  p.ws_cnt = (uint32_t*)workspace;
+  p.ws_cnt = (unsigned long long*)workspace;  // (no zeroing: the words initialise themselves, see mla_cnt_up)
   p.ws_o = workspace ? (float*)((char*)workspace + mla_counter_bytes(batch)) : nullptr;
   p.ws_lse = p.ws_o ? p.ws_o + batch * splits * num_heads * kLatent : nullptr;
   p.qn_sb = q_nope_stride_b;
@@ -2038,14 +2157,6 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   p.probe = g_mla_probe;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  if (splits > 1) {
-    // the merge counters are zeroed in front of every launch - by a kernel, not hipMemsetAsync: replayed from a captured
-    // graph (tests/test_graph_capture_gpu.py) the memset node left the counters of the capture-time warm-up in place, no
-    // workgroup drew the last ticket and the output was never written
-    const int nwords = (int)(mla_counter_bytes(batch) / 4);
-    mla_zero_counters_kernel<<<(nwords + 255) / 256, 256, 0, st>>>((uint32_t*)workspace, nwords);
-    if (int rc = check_launch("flash_mla_decode(counters)")) return rc;
-  }
   if (dtype == SGLK_BF16) return launch<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
   return launch<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
 }
@@ -2100,11 +2211,6 @@ extern "C" int sglk_flash_mla_prefill(sglk_stream_t stream, void* out, const voi
     if (dtype == SGLK_BF16)
       return launch_w<bf16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
     return launch_w<f16, 1>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
-  }
-  if (g_mla_waves_per_group == 10) {
-    if (dtype == SGLK_BF16)
-      return launch_rows128<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
-    return launch_rows128<f16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);
   }
   if (dtype == SGLK_BF16)
     return launch_rows128x<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens_k, page_table, cu_seqlens_q, token_blocks);

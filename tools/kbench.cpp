@@ -702,7 +702,7 @@ int main(int argc, char** argv) {
         std::vector<int> probes;
         { std::string e = getenv("MLA_STAMPS"); size_t pos = 0; while (pos < e.size()) { probes.push_back(atoi(e.c_str() + pos)); pos = e.find(',', pos); if (pos == std::string::npos) break; ++pos; } }
         for (int prb : probes) {
-          sglk_debug_set_mla_variant(90 + prb);
+          sglk_debug_set_mla_variant(prb);  // 90 / 94: the round-4 loop (94: no DMA), 70 + probe: the round-5 loop
           for (int i = 0; i < 20; ++i) run();
           HIP_CHECK(hipDeviceSynchronize());
           std::vector<unsigned long long> st(16 * 4 * 4096);
@@ -710,7 +710,7 @@ int main(int argc, char** argv) {
           const int nw = (int)std::min<int64_t>(4096, B * (splits > 0 ? splits : 1) * 4);
           double sum[14] = {0}, tiles = 0;
           for (int i = 0; i < nw; i += 4) { for (int k = 0; k < 14; ++k) sum[k] += (double)st[i * 16 + k]; tiles += (double)st[i * 16 + 15]; }
-          printf("probe %2d: landed-wait %.0f barrier %.0f DMA-issue %.0f QK %.0f PV %.0f tail %.0f | per launch: prologue %.0f epilogue %.0f\n",
+          printf("variant %2d: landed-wait %.0f barrier %.0f DMA-issue %.0f QK %.0f PV %.0f tail %.0f | per launch: prologue %.0f epilogue %.0f\n",
                  prb, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[8] / tiles,
                  sum[5] / (nw / 4), sum[6] / (nw / 4));
           printf("          in-kernel clock %.0f MHz (%.0f cycles in %.1f us per workgroup)\n", sum[12] / sum[13] * 100.0,
@@ -721,29 +721,16 @@ int main(int argc, char** argv) {
         if (ai >= argc) break;
         continue;
       }
-      if (getenv("MLA_VARIANTS")) {  // interleaved rounds of the ring-depth variants of the rows128x kernel
-        const int nv = atoi(getenv("MLA_VARIANTS"));
+      if (getenv("MLA_AB")) {  // interleaved rounds of the round-4 tile loop (variant 50) and the current one
         for (int round = 0; round < 3; ++round)
-          for (int v = 0; v <= nv; ++v) {
+          for (int v : {50, 0}) {
             sglk_debug_set_mla_variant(v);
             const double m = time_ms(run, 60, 30, &all);
-            printf("mla[variant %d] B=%lld S=%lld H=%lld splits=%lld median %.4f ms min %.4f -> %.1f GB/s, %.1f TFLOP/s\n", v,
-                   (long long)B, (long long)S, (long long)H, (long long)splits, m, all[0], bytes / m / 1e6,
-                   2.0 * B * H * S * 1088 / m / 1e9);
-          }
-        if (ws) HIP_CHECK(hipFree(ws));
-        if (ai >= argc) break;
-        continue;
-      }
-      if (getenv("MLA_AB")) {  // interleaved rounds of the round-2 (16x16x32, hook 10) and the current rows128 kernel
-        for (int round = 0; round < 3; ++round)
-          for (int w : {10, 0}) {
-            sglk_debug_set_mla_waves_per_group(w);
-            const double m = time_ms(run, 60, 30, &all);
             printf("mla[%s] B=%lld S=%lld H=%lld splits=%lld median %.4f ms min %.4f -> %.1f GB/s, %.1f TFLOP/s\n",
-                   w == 10 ? "r2 16x16" : "r3 32x32", (long long)B, (long long)S, (long long)H, (long long)splits, m, all[0],
+                   v == 50 ? "r4 loop" : "r5 loop", (long long)B, (long long)S, (long long)H, (long long)splits, m, all[0],
                    bytes / m / 1e6, 2.0 * B * H * S * 1088 / m / 1e9);
           }
+        sglk_debug_set_mla_variant(0);
         if (ws) HIP_CHECK(hipFree(ws));
         if (ai >= argc) break;
         continue;
