@@ -158,7 +158,7 @@ __device__ __forceinline__ v4f agpr_read4() {
   return (v4f){t0, t1, t2, t3};
 }
 
-// a[R .. R+7] *= f * f (one scalar factor, applied as two multiplies: the rescale factor 2^-(move) of the rows128x kernel
+// a[R .. R+7] *= f * f (one scalar factor, applied as two multiplies: the rescale factor 2^-(move) of the rows128z kernel
 // spans up to ~2^-220, which a single fp32 factor cannot hold)
 template <int R>
 __device__ __forceinline__ void agpr_scale8_sq(float f) {
@@ -688,21 +688,8 @@ struct Mfma32<f16> {
 __device__ unsigned long long g_mla_stamps[16 * 4 * 4096];
 #endif
 // kProbe (diagnostic build, garbage results): 1 = P.V without its LDS reads, 2 = QK^T without its LDS reads, 3 = both,
-// 4 = no DMA, 5 = no reads and no DMA, 6 = no softmax micro-ops, 9 = P.V as 32 bare MFMAs (no reads, no waits, no
-// micro-ops, no fences), 10 = 9 + the fences, 11 = 10 + the wait statements, 13 = QK^T accumulates into a0..a15
-// order of the 32 P.V MFMAs of a tile: step m -> (dim tile, k-step). kOrd 0: the two k-steps of a dim tile back to back
-// (the second takes the first's result through the pipeline's own forwarding); 1: four accumulators in rotation; 2: two
-// in rotation (the first version: a dependent MFMA that is not issued directly behind its producer waits for the
-// producer's write-back, ~100 cycles after its issue - 52 cycles per MFMA, found with the in-kernel stamps)
-template <int kOrd>
-__host__ __device__ constexpr int pv_dt(int m) {
-  return kOrd == 0 ? (m >> 1) : kOrd == 1 ? 4 * (m >> 3) + (m & 3) : 2 * (m >> 2) + (m & 1);
-}
-template <int kOrd>
-__host__ __device__ constexpr int pv_ss(int m) {
-  return kOrd == 0 ? (m & 1) : kOrd == 1 ? ((m >> 2) & 1) : ((m >> 1) & 1);
-}
-// ---- split KV merged inside the kernel (rows128x kernel). The workgroup of a batch element that finishes LAST merges the
+// 4 = no DMA, 5 = no reads and no DMA, 6 = no softmax micro-ops
+// ---- split KV merged inside the kernel (rows128z kernel). The workgroup of a batch element that finishes LAST merges the
 // splits itself: no second launch, and its own partial result never leaves the registers. Every workgroup takes a ticket
 // when its tile loop is done; all but the last publish O / l (fp32, write-through stores) and their log2-sum-exp, then
 // count themselves in; the last one waits until the others - which took their tickets before it, so they are running their
@@ -768,13 +755,50 @@ __device__ __forceinline__ bool mla_wait_others(const MlaParams& p, int b, char*
   __syncthreads();
   return *lds_word != 0u;
 }
+// ---- epilogue of the rows128 kernel. A lane owns ROW 32 wave + l31 and, of that row, the dims 32 dt + 8 g + 4 u .. + 4 of
+// register group i = 4 dt + g (64 groups of four accumulators). Stored as they lie, every instruction touches 32 rows - round
+// 4's tail did, and was store-ISSUE-bound: 64 row-per-lane stores cost a wave ~37k cycles, the publishing and the merging
+// workgroup of a batch element one after the other ~45 us of a 320-us launch (in-kernel stamps, round 5). Now
+//   * partial results travel in FRAGMENT ORDER: group i of wave w, lane L at float4 index ((w 64 + i) 64 + L) of the split's
+//     slab - one contiguous KiB per store / load instruction, the merging lane reads exactly what its twin wrote;
+//   * the final rows go through LDS (the stages are free by then): a wave writes its 32 rows x 512 16-bit values row-major
+//     (row stride 1040 B: the 16 lanes of a ds_write_b64 group hit 16 different bank pairs), reads them back a row per
+//     instruction and stores one contiguous KiB per row.
+constexpr int kOutOff = 1024;        // (the ticket words live in the first bytes)
+constexpr int kOutRow = 1040;        // bytes per row in the LDS staging area
+constexpr int kOutWave = 32 * kOutRow;
+__device__ __forceinline__ int64_t mla_slab_f4(const MlaParams& p, int b, int split, int wave) {  // float4 index of a wave's slab
+  return (((int64_t)b * p.splits + split) * 4 + wave) * 64 * 64;
+}
+// the 16-bit values of register group i of this lane's row -> the wave's staging area
+template <typename M>
+__device__ __forceinline__ void mla_stage_group(char* smem, int wave, int l31, int u, int i, const v4f& v) {
+  const int lo = M::pack(v[0], v[1]), hi = M::pack(v[2], v[3]);
+  *reinterpret_cast<v2i*>(smem + kOutOff + wave * kOutWave + l31 * kOutRow + (32 * (i >> 2) + 8 * (i & 3) + 4 * u) * 2) =
+      (v2i){lo, hi};
+}
+// the wave's 32 staged rows -> out (row r of the workgroup = token slot r >> hp_shift, head r & hp_mask)
+template <typename T>
+__device__ __forceinline__ void mla_flush_rows(const MlaParams& p, char* smem, int wave, int lane, int q_row0, int n_tok) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  const int hp_mask = (1 << p.hp_shift) - 1;
+  const char* src = smem + kOutOff + wave * kOutWave + lane * 16;
+#pragma unroll 8
+  for (int k = 0; k < 32; ++k) {
+    const int r = wave * 32 + k, tok = r >> p.hp_shift, head = r & hp_mask;
+    const v4i v = *reinterpret_cast<const v4i*>(src + k * kOutRow);
+    if (tok < n_tok && head < p.H)
+      *reinterpret_cast<v4i*>((T*)p.out + ((int64_t)(q_row0 + tok) * p.H + head) * kLatent + lane * 8) = v;
+  }
+}
 // The last workgroup's merge for the row of lane (l31, u): out = sum_s w_s O_s / sum_s w_s, w_s = 2^(lse_s - max lse), s in
-// split order. OWN: this workgroup's O^T sits unnormalised in a0..a255 (x inv_l), log2-sum-exp my_lse; otherwise it had no keys.
+// split order. OWN: this workgroup's O^T sits unnormalised in a0..a255 (x inv_l), log2-sum-exp my_lse; otherwise it had no
+// keys. The merged rows are left in the wave's LDS staging area (mla_flush_rows stores them).
 template <typename T, typename M, bool OWN>
-__device__ __forceinline__ void mla_merge_splits(const MlaParams& p, int b, int split, int H, bool ok, int hrow, T* out,
-                                                 int u, float my_lse, float inv_l, bool all_in) {
+__device__ __forceinline__ void mla_merge_splits(const MlaParams& p, int b, int split, int H, int hrow, char* smem, int wave,
+                                                 int lane, float my_lse, float inv_l, bool all_in) {
+  const int l31 = lane & 31, u = lane >> 5;
   const float* lse_b = p.ws_lse + (int64_t)b * p.splits * H + hrow;
-  const float* wo_b = p.ws_o + ((int64_t)b * p.splits * H + hrow) * kLatent + 4 * u;
   float mx = my_lse;
   for (int s2 = 0; s2 < p.splits; ++s2)
     if (s2 != split) mx = fmaxf(mx, lse_b[(int64_t)s2 * H]);
@@ -804,10 +828,10 @@ __device__ __forceinline__ void mla_merge_splits(const MlaParams& p, int b, int 
           });
         }
       } else {
-        const float* src = wo_b + (int64_t)s2 * H * kLatent;
+        const v4f* src = reinterpret_cast<const v4f*>(p.ws_o) + mla_slab_f4(p, b, s2, wave) + (int64_t)c0 * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const v4f v = *reinterpret_cast<const v4f*>(src + 32 * ((c0 + k) >> 2) + 8 * ((c0 + k) & 3));
+          const v4f v = src[k * 64];
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[k][e] += w * v[e];
         }
@@ -815,526 +839,14 @@ __device__ __forceinline__ void mla_merge_splits(const MlaParams& p, int b, int 
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int lo = M::pack(acc[k][0] * inv, acc[k][1] * inv), hi = M::pack(acc[k][2] * inv, acc[k][3] * inv);
-      if (ok) *reinterpret_cast<v2i*>(out + 32 * ((c0 + k) >> 2) + 8 * ((c0 + k) & 3)) = (v2i){lo, hi};
+      const v4f o = {acc[k][0] * inv, acc[k][1] * inv, acc[k][2] * inv, acc[k][3] * inv};
+      mla_stage_group<M>(smem, wave, l31, u, c0 + k, o);
     }
   });
 }
 
-template <typename T, int kKA, int kVA, bool kStamp = false, int kProbe = 0, int kOrd = 0, bool kDmaQK = true>
-__global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p, const T* __restrict__ q_nope,
-                                                                    const T* __restrict__ q_pe,
-                                                                    const char* __restrict__ cache,
-                                                                    const int32_t* __restrict__ seq_lens,
-                                                                    const int32_t* __restrict__ page_table,
-                                                                    const int32_t* __restrict__ cu_seqlens_q) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  using M = Mfma32<T>;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x, b = blockIdx.y;
-  const int H = p.H;
-  const int l31 = lane & 31, u = lane >> 5;
-
-  // ---- this lane's row: (token slot, head) of workgroup row 32 wave + l31
-  const int hp_mask = (1 << p.hp_shift) - 1;
-  const int row = wave * 32 + l31;
-  const int my_tok = row >> p.hp_shift, my_head = row & hp_mask;
-  int q_row0 = b, n_tok = 1, seq, kv_first;
-  if (cu_seqlens_q != nullptr) {
-    const int q0 = cu_seqlens_q[b], sq = cu_seqlens_q[b + 1] - q0, sk = seq_lens[b];
-    const int t0 = (int)blockIdx.z << (7 - p.hp_shift);
-    if (t0 >= sq) return;
-    const int tpw = 1 << (7 - p.hp_shift);
-    n_tok = (sq - t0) < tpw ? (sq - t0) : tpw;
-    q_row0 = q0 + t0;
-    kv_first = p.causal ? sk - sq + t0 + 1 : sk;
-    seq = p.causal ? sk - sq + t0 + n_tok : sk;
-  } else {
-    seq = seq_lens[b];
-    kv_first = seq;
-  }
-  if (seq < 0) seq = 0;
-  const bool ok = my_tok < n_tok && my_head < H;
-  const int kv_row = (cu_seqlens_q != nullptr && p.causal && my_tok < n_tok) ? kv_first + my_tok : seq;  // this row's horizon
-  const bool work = __any(ok) && p.probe != 1;
-  const int ntiles = (seq + kTile - 1) / kTile;
-  const int tps = (ntiles + p.splits - 1) / p.splits;
-  const int t_begin = split * tps;
-  const int t_end = (t_begin + tps < ntiles) ? (t_begin + tps) : ntiles;
-  const int n_my = t_end - t_begin;
-
-  const int32_t* table = page_table + (int64_t)b * p.table_stride;
-  const int page_mask = (1 << p.page_shift) - 1;
-
-  // ---- LDS-DMA of one tile (as in the kernel above): wave w fills column block w and rope rows 8w .. 8w+7
-  const uint32_t dma_lo0 = (uint32_t)((lane >> 4) * kRowBytes + wave * 256 + 16 * ((lane & 15) ^ ((lane >> 4) << 2)));
-  const uint32_t dma_ro = (uint32_t)((((wave & 1) * 8 + (lane >> 3)) * kRowBytes) + 1024 +
-                                     16 * ((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)));
-  // (the DMA instructions are asm text: an LDS-DMA the compiler can see makes it wait vmcnt(0) in front of the next LDS
-  //  read it can see - any read may alias the DMA's LDS write - which would empty the ring once per tile)
-  auto dma16 = [&](const char* src, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_dst) : "memory", "m0");
-  };
-  auto stage_tile = [&](int t, int st, int pg0, int pg1) {
-    const uint32_t base = (uint32_t)(uintptr_t)SGLK_LDS(smem) + (uint32_t)(st * kStageBytes);
-    const int tok0 = t * kTile;
-    const char* sA = cache + (int64_t)pg0 * p.page_stride_bytes + (int64_t)(tok0 & page_mask) * kRowBytes;
-    const char* sB = p.page_shift == 4 ? cache + (int64_t)pg1 * p.page_stride_bytes : sA + 16 * kRowBytes;
-#pragma unroll
-    for (int rg = 0; rg < 8; ++rg) {
-      const char* sbase = (rg < 4 ? sA : sB) + (rg & 3) * 4 * kRowBytes;
-      dma16(sbase + (dma_lo0 ^ (uint32_t)((rg & 3) << 4)), base + (uint32_t)(wave * 8192 + rg * 1024));
-    }
-    dma16((wave < 2 ? sA : sB) + dma_ro, base + (uint32_t)(kMainBytes + wave * 1024));
-  };
-  // page ids of local tile j (clamped to the last one): two unconditional scalar loads - for pages of 32 tokens and more
-  // both name the same page - so that nothing waits on them where they are issued
-  auto load_pages = [&](int j, int& pg0, int& pg1) {
-    const int tok0 = (t_begin + (j < n_my ? j : n_my - 1)) * kTile;
-    const int i0 = tok0 >> p.page_shift;
-    const int i1 = (tok0 + 16 < seq) ? ((tok0 + 16) >> p.page_shift) : i0;
-    pg0 = table[i0];
-    pg1 = table[i1];
-  };
-
-  // ---- nothing to do for this split (decode only: an empty sequence, or more splits than tiles)
-  if (n_my <= 0) {
-    if (ok) {
-      if (p.splits == 1) {
-        T* out = (T*)p.out + ((int64_t)(q_row0 + my_tok) * H + my_head) * kLatent;
-        for (int d = u * 256; d < u * 256 + 256; ++d) out[d] = (T)0.f;
-      }
-    }
-    if (p.splits > 1) {  // (no keys here: a log2-sum-exp of -inf takes part in the merge, no O - see mla_take_ticket)
-      if (!mla_take_ticket(p, b, smem, tid)) {
-        if (ok && u == 0)
-          __hip_atomic_store(p.ws_lse + ((int64_t)b * p.splits + split) * H + my_head, -INFINITY, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        mla_count_in(p, b, tid);
-      } else {
-        const bool all_in = mla_wait_others(p, b, smem, tid);
-        const int hrow = ok ? my_head : 0;
-        T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + hrow) * kLatent + 4 * u;
-        mla_merge_splits<T, M, false>(p, b, split, H, ok, hrow, out, u, -INFINITY, 0.f, all_in);
-      }
-    }
-    return;
-  }
-
-  // ---- Q^T fragments (B operand of K . Q^T): lane supplies q[row][16 ks + 8 u .. + 8)
-  v8s qf[36];
-  {
-    const int64_t qrow = q_row0 + (ok ? my_tok : 0);
-    const T* qn = q_nope + qrow * p.qn_sb + (int64_t)(ok ? my_head : 0) * p.qn_sh + 8 * u;
-    const T* qp = q_pe + qrow * p.qp_sb + (int64_t)(ok ? my_head : 0) * p.qp_sh + 8 * u;
-    const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < 36; ++ks) {
-      const T* src = ks < 32 ? qn + 16 * ks : qp + 16 * (ks - 32);
-      const v8s v = *reinterpret_cast<const v8s*>(src);
-      qf[ks] = ok ? v : zero;
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q is in registers before any LDS-DMA is counted
-
-  // ---- per-lane LDS read offsets inside a stage
-  // K row read, k-step ks: block ks / 8, chunk 2 (ks % 8) + u of token row l31  ->  kbase ^ (32 (ks % 8)) + 8192 (ks / 8)
-  const uint32_t kbase = (uint32_t)(256 * l31 + 16 * (u ^ sw_main(l31)));
-  const uint32_t rbase = (uint32_t)(kMainBytes + 128 * l31 + 16 * (u ^ ((l31 >> 1) & 7)));  // rope: ^ (32 (ks - 32))
-  // V^T transposed read of dim tile dt, k-step s, token half e (tokens 16 s + 8 e + 4 u + qq, dims 32 dt + 16 hh + 4 pp ..):
-  //   8192 (dt / 4) + 4096 s + 2048 e + (vbase ^ (64 (dt % 4)) ^ (32 e))
-  const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, hh = (lane >> 4) & 1;
-  const uint32_t vbase = (uint32_t)(256 * (4 * u + qq) + 8 * (pp & 1) + 16 * ((qq << 2) | ((2 * hh + (pp >> 1)) ^ u)));
-
-  // O^T tile dt = a[16 dt .. 16 dt + 15], named only in asm text; the clobbers tell the compiler that the kernel owns the
-  // whole AGPR file (build.py check_isa verifies that it places nothing there)
-  asm volatile("" ::: "a0", "a255");
-  static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
-
-  // Lazy reference (the idea of the kernel above, wider here): bf16 weights have fp32's exponent range, so the reference
-  // need not be the maximum. When it moves it is set 2^kHead ABOVE the row's running maximum (weights restart at 2^-kHead)
-  // and it moves again only when a weight would pass 2^kLazy: kHead + kLazy = 190 binades of growth per move (100 in the
-  // kernel above; the reference benchmark's q x 100 logits grow by ~220 binades over a split, and every move of any of
-  // a wave's 32 rows costs the wave - and, through the tile barrier, the workgroup - a 768-instruction pass over O).
-  // Range: 2^kLazy x keys x |V| stays below 2^127 for a million keys and |V| < 2^16; a weight 2^-24 below the largest
-  // one is still >= 2^-124 (normal); the rescale factor 2^-(move), down to ~2^-220, is applied as two multiplies by its
-  // square root. f16 weights must stay in [2^-14, 2^16): threshold 2^8, no headroom.
-  constexpr bool kWide = std::is_same<T, bf16>::value;
-  constexpr float kLazy = kWide ? 90.0f : 8.0f, kHead = kWide ? 100.0f : 0.0f;
-  const float sl2 = p.scale_log2;
-  const float head_raw = (kWide && sl2 > 0.f) ? kHead / sl2 : 0.f;  // 2^kHead in units of the raw logits
-  float m_ref = -INFINITY, m_run = -INFINITY, l_run = 0.f;
-
-  // Every tile slot past the split's last tile re-loads the last tile into a stage nobody reads (two duplicates per split):
-  // the DMA needs no condition and every tile-landed wait is the same vmcnt(9).
-  auto tile_of = [&](int j) { return t_begin + (j < n_my ? j : n_my - 1); };
-  int pgn0, pgn1;
-  {
-    int a0, a1;
-    load_pages(0, a0, a1);
-    stage_tile(tile_of(0), 0, a0, a1);
-    load_pages(1, a0, a1);
-    stage_tile(tile_of(1), 1, a0, a1);
-  }
-  load_pages(2, pgn0, pgn1);
-
-  // ---- The tile pipeline (per wave; one wave per SIMD has nobody to overlap with, so the overlap is written out):
-  //   iteration j:  QK^T(j)   with the second half of softmax(j-1) - exponentials, rounding, row sum - in its MFMA gaps
-  //                 P.V(j-1)  with the first half of softmax(j)    - row maximum, reference decision   - in its MFMA gaps
-  // so that an MFMA gap carries at most ~3 vector instructions (a 32-cycle MFMA holds the issue port for 8 cycles: more
-  // than ~24 cycles of other issue per gap is paid in full; measured with in-kernel stamps on the first version, which
-  // had the whole softmax and two address adds per read in the P.V gaps: 77 cycles per P.V MFMA).
-  // State carried between phases: s_prev = raw logits of tile j-1 (exponentiated in place during QK^T(j)), mneg = the
-  // reference they are taken against, pf = the rounded weights (B operand of P.V), alpha / upd = the pending rescale.
-  typedef const v8s __attribute__((address_space(3))) * lds_v8s;
-  const uint32_t lds_base = (uint32_t)(uintptr_t)SGLK_LDS(smem);
-  float mt = 0.f, mb = 0.f, alpha = 1.0f, mneg = 0.f, psum = 0.f;
-  bool upd = false;
-  v8s pf[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
-
-  // second half of the softmax of the tile whose raw logits are in sp (reference mneg, fixed by the first half)
-  auto exp_op = [&](auto kc, v16f& sp) {
-    constexpr int k = decltype(kc)::value;
-    // (each micro-op ends in an empty volatile asm on its result: the optimiser would otherwise sink the whole chain
-    //  to its first use behind the MFMA loop - a sched_barrier only binds the machine scheduler)
-    // slots 3 p, 3 p + 1: weights 2 p, 2 p + 1 (one multiply-add and one exponential each); slot 3 p + 2: the pair is
-    // rounded, packed and added to the row sum. One slot per MFMA gap: <= ~15 cycles of issue next to the K read.
-    constexpr int pr = k / 3, r = k % 3;
-    if constexpr (k < 24 && r < 2) {
-      float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sp[2 * pr + r], sl2, mneg));
-      asm volatile("" : "+v"(e));
-      sp[2 * pr + r] = e;
-    } else if constexpr (k < 24) {
-      int pk = M::pack(sp[2 * pr], sp[2 * pr + 1]);
-      psum = M::add2(pk, psum);  // the row sum takes the ROUNDED weights (numerator and denominator round alike)
-      asm volatile("" : "+v"(pk), "+v"(psum));
-      pf[pr >> 2][2 * (pr & 3)] = (short)(pk & 0xffff);
-      pf[pr >> 2][2 * (pr & 3) + 1] = (short)((unsigned)pk >> 16);
-    } else if constexpr (k == 24) {
-      l_run += psum;
-      asm volatile("" : "+v"(l_run));
-    }
-  };
-  constexpr int kExpOps = 25;
-  // first half: row maximum of the raw logits in sc, then the lazy reference (see the kernel above): it moves only when a
-  // weight would pass 2^kLazy, then to 2^50 (bf16) above the running maximum; all rows of the wave move together (one
-  // rescale pass serves them all). Leaves alpha / upd for the rescale of O and takes l_run to the new reference.
-  auto max_op = [&](auto kc, v16f& sc) {
-    constexpr int k = decltype(kc)::value;
-    if constexpr (k == 0) {
-      mt = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-      mb = fmaxf(fmaxf(sc[3], sc[4]), sc[5]);
-    } else if constexpr (k == 1) {
-      mt = fmaxf(fmaxf(mt, sc[6]), sc[7]);
-      mb = fmaxf(fmaxf(mb, sc[8]), sc[9]);
-    } else if constexpr (k == 2) {
-      mt = fmaxf(fmaxf(mt, sc[10]), sc[11]);
-      mb = fmaxf(fmaxf(mb, sc[12]), sc[13]);
-    } else if constexpr (k == 3) {
-      mt = fmaxf(fmaxf(mt, sc[14]), sc[15]);
-      mt = fmaxf(mt, mb);
-    } else if constexpr (k == 4) {  // the other 16 tokens of this row live in lane ^ 32
-      float c0 = mt, c1 = mt;
-      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));  // c0 = low half twice, c1 = high half twice
-      mt = fmaxf(c0, c1);
-    } else if constexpr (k == 5) {
-      upd = __any((mt - m_ref) * sl2 > kLazy);  // (first tile: +inf; nothing but masked keys so far: NaN -> false)
-      m_run = fmaxf(m_run, mt);
-    } else if constexpr (k == 6) {
-      const float cand = upd ? m_run + head_raw : -INFINITY;  // (selects, no branch in the MFMA stream)
-      const float m_new = fmaxf(m_ref, cand);
-      alpha = m_new > m_ref ? __builtin_amdgcn_exp2f((m_ref - m_new) * sl2 * 0.5f) : 1.0f;  // (the factor's square root)
-      m_ref = m_new;
-    } else if constexpr (k == 7) {
-      mneg = m_ref == -INFINITY ? 0.f : -m_ref * sl2;
-      l_run = l_run * alpha * alpha;
-      psum = 0.f;
-    }
-    asm volatile("" : "+v"(mt), "+v"(mb), "+v"(alpha), "+v"(mneg), "+v"(l_run), "+v"(m_ref), "+v"(m_run));  // (as above)
-  };
-  constexpr int kMaxOps = 8;
-
-  // ---- S^T of tile j (raw logits) in VGPRs (asm MFMAs: left to itself the compiler puts this accumulator into a0..a15),
-  // K fragments kKA k-steps ahead, in program order. The first MFMA takes the constant 0 as its addend: no VALU write
-  // feeds an asm MFMA (the hazard recogniser cannot see one).
-  auto qk_tile = [&](int j, v16f& s, auto with_exp, v16f& sp, auto&& dma_piece) {
-    constexpr bool kExp = decltype(with_exp)::value;
-    const uint32_t sb = lds_base + (uint32_t)((j & 3) * kStageBytes);
-    uint32_t kb = kbase, rb = rbase;
-    asm volatile("" : "+v"(kb), "+v"(rb));  // (derive the chunk addresses here, not across the whole loop)
-    v8s kr[kKA];
-    // eight base addresses (chunk pair ks % 8 of the stage), pinned in registers: the column block ks / 8 is then an
-    // immediate of the read (left alone the compiler adds stage + block in an SGPR and spends a v_add per read)
-    uint32_t ka[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      ka[i] = sb + (kb ^ (uint32_t)(i << 5));
-      asm volatile("" : "+v"(ka[i]));
-    }
-    auto k_addr = [&](int ks) -> uint32_t {
-      return ks < 32 ? ka[ks & 7] + (uint32_t)((ks >> 3) * 8192) : sb + (rb ^ (uint32_t)((ks - 32) << 5));
-    };
-#pragma unroll
-    for (int ks = 0; ks < kKA; ++ks) kr[ks] = *(lds_v8s)(uintptr_t)k_addr(ks);
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<0, 36>([&](auto kc) {
-      constexpr int ks = decltype(kc)::value;
-      if constexpr (kProbe == 13) M::template acc_agpr<0>(kr[ks % kKA], qf[ks]);  // (is an AGPR accumulator cheaper to fill around?)
-      else if constexpr (kProbe == 14) M::template acc_agpr<16 * (ks & 3)>(kr[ks % kKA], qf[ks]);  // (four independent chains?)
-      else if constexpr (kProbe == 15) M::template acc_agpr<16 * (ks & 1)>(kr[ks % kKA], qf[ks]);  // (two?)
-      else if constexpr (ks == 0) M::first_v(s, kr[ks % kKA], qf[ks]);
-      else M::acc_v(s, kr[ks % kKA], qf[ks]);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kDmaQK && kExp && (ks & 3) == 2) dma_piece(std::integral_constant<int, (ks >> 2)>{});
-      if constexpr (kExp && ks >= 1 && ks - 1 < kExpOps && kProbe != 6) exp_op(std::integral_constant<int, ks - 1>{}, sp);
-      if constexpr (ks + kKA < 36 && kProbe != 2 && kProbe != 3 && kProbe != 5) {
-        // (the slot stays reserved up to its refill: the MFMA issued just before is still reading it, and the compiler
-        //  would otherwise be free to put a temporary there)
-        asm volatile("" ::"v"(kr[ks % kKA]));
-        kr[ks % kKA] = *(lds_v8s)(uintptr_t)k_addr(ks + kKA);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    asm volatile("" : "+v"(s));
-#pragma unroll
-    for (int i = 0; i < kKA; ++i) asm volatile("" ::"v"(kr[i]));  // (the ring stays reserved past the last MFMAs)
-  };
-  auto mask_tile = [&](int j, v16f& s) {  // (rare, uniform: keys past a row's horizon)
-    const int t = t_begin + j;
-    if (t * kTile + kTile > kv_first || t * kTile + kTile > seq) {
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s));  // (asm MFMA result -> VALU read wait states)
-#pragma unroll
-      for (int v = 0; v < 16; ++v)
-        if (t * kTile + (v & 3) + 8 * (v >> 2) + 4 * u >= kv_row) s[v] = -INFINITY;
-    }
-  };
-
-  // ---- O^T += V^T . P^T of tile jv: asm MFMAs on the fixed accumulators and asm transposed reads (the compiler cannot
-  // fold an immediate offset into the read intrinsic: two address adds per read), in program order with hand-counted waits,
-  // V^T fragments kVA steps ahead; step m = (dim tile pv_dt(m), k-step pv_ss(m)). Eight base addresses per tile (token
-  // half e x dim tile % 4), everything else is an immediate.
-  auto pv_tile = [&](int jv, auto with_max, v16f& sc) {
-    constexpr bool kMax = decltype(with_max)::value;
-    const uint32_t sb = lds_base + (uint32_t)((jv & 3) * kStageBytes);
-    uint32_t vb0 = vbase;
-    asm volatile("" : "+v"(vb0));
-    const uint32_t vb1 = (vb0 ^ 32u) + 2048u;
-    uint32_t va[2][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      va[0][x] = sb + (vb0 ^ (uint32_t)(x << 6));
-      va[1][x] = sb + (vb1 ^ (uint32_t)(x << 6));
-    }
-    v2i vlo[kVA], vhi[kVA];
-    auto v_issue = [](auto mc, v2i& lo, v2i& hi, const uint32_t a0, const uint32_t a1) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int dt = pv_dt<kOrd>(m), ss = pv_ss<kOrd>(m), c = (dt >> 2) * 8192 + ss * 4096;
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "i"(c));
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "i"(c));
-    };
-#define SGLK_V_ISSUE(M_) v_issue(std::integral_constant<int, (M_)>{}, vlo[(M_) % kVA], vhi[(M_) % kVA], \
-                                 va[0][pv_dt<kOrd>(M_) & 3], va[1][pv_dt<kOrd>(M_) & 3])
-    static_for<0, kVA>([&](auto mc) { constexpr int m0 = decltype(mc)::value; SGLK_V_ISSUE(m0); });
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<0, 32>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int dt = pv_dt<kOrd>(m), ss = pv_ss<kOrd>(m);
-      constexpr int ahead = (32 - m < kVA ? 32 - m : kVA) - 1;  // fragments issued after this one
-      if constexpr (kProbe == 21 && (m & 7) == 7) asm volatile("s_waitcnt lgkmcnt(0)");
-      // (the two halves are coalesced into the 4-register operand in place - no copy may sit between the reads and the
-      //  wait the MFMA statement starts with; the ISA shows none)
-      const v8s f = __builtin_bit_cast(v8s, __builtin_shufflevector(vlo[m % kVA], vhi[m % kVA], 0, 1, 2, 3));
-      constexpr int wcnt = (kProbe == 1 || kProbe == 3 || kProbe == 5 || kProbe == 11) ? 0 : kProbe >= 9 ? 15 : 2 * ahead;
-      M::template wait_acc_agpr<dt * 16, wcnt>(f, pf[ss]);
-      if constexpr (kProbe != 9) __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kProbe == 18 || kProbe == 19 || kProbe == 20) {  // (how many independent VALU fillers hide in a gap?)
-        float d0 = (float)m, d1 = d0, d2 = d0, d3 = d0;
-        constexpr int reps = kProbe == 18 ? 1 : kProbe == 19 ? 2 : 3;
-#pragma unroll
-        for (int r = 0; r < reps; ++r)
-          asm volatile("v_add_f32 %0, %0, %0\n\tv_add_f32 %1, %1, %1\n\tv_add_f32 %2, %2, %2\n\tv_add_f32 %3, %3, %3"
-                       : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-      }
-      if constexpr (kProbe == 21) {  // (two LDS reads per gap, never waited for)
-        v2i x0, x1;
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=v"(x0), "=v"(x1) : "v"(va[0][0]));
-      }
-      if constexpr (kMax && m >= 2 && m - 2 < kMaxOps && kProbe != 6 && kProbe < 9) max_op(std::integral_constant<int, m - 2>{}, sc);
-      // the fragment's registers stay reserved past the micro-op (a VALU write into an operand of the MFMA issued just
-      // before is not interlocked); the refill of this slot lands tens of cycles later
-      asm volatile("" ::"v"(f));
-      if constexpr (m + kVA < 32 && kProbe != 1 && kProbe != 3 && kProbe != 5 && kProbe < 9) SGLK_V_ISSUE(m + kVA);
-      if constexpr (kProbe != 9) __builtin_amdgcn_sched_barrier(0);
-    });
-#undef SGLK_V_ISSUE
-    // the operands of the last MFMAs stay reserved until the matrix pipe has read them; the nops also cover the
-    // MFMA -> v_accvgpr_read wait states of the rescale / the epilogue
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::"v"(pf[0]), "v"(pf[1]));
-#pragma unroll
-    for (int i = 0; i < kVA; ++i) asm volatile("" ::"v"(vlo[i]), "v"(vhi[i]));
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
-  auto stamp = [&](int k) {
-    if constexpr (kStamp) {
-      const unsigned long long now = __builtin_amdgcn_s_memtime();
-      st_sum[k] += now - st_t;
-      st_t = now;
-    }
-  };
-  unsigned long long clk0 = 0, rt0 = 0;
-  if constexpr (kStamp) {
-    st_t = __builtin_amdgcn_s_memtime();
-    clk0 = st_t;
-    rt0 = __builtin_amdgcn_s_memrealtime();
-  }
-  // One iteration: tile j's QK^T (+ exponentials of tile j-1 from s_prv), then P.V of tile j-1 (+ maxima of tile j in
-  // s_cur). The page ids of tile j+3 are requested before the DMA of tile j+2 is issued and awaited behind it, the DMA
-  // instructions themselves go out in the gaps of the QK^T MFMAs (each costs its wave ~60 cycles of issue: ~570 cycles
-  // per tile as a block in front of the MFMAs).
-  auto iter = [&](int j, v16f& s_cur, v16f& s_prv) {
-    stamp(8);
-    wait_vmcnt<9>();
-    stamp(0);
-    __builtin_amdgcn_s_barrier();  // tile j landed for every wave; every wave is done with tile j-2
-    stamp(1);
-    const int pga = pgn0, pgb = pgn1;  // tile j+2
-    load_pages(j + 3, pgn0, pgn1);
-    constexpr bool do_dma = kProbe != 4 && kProbe != 5;
-    const uint32_t dbase = lds_base + (uint32_t)(((j + 2) & 3) * kStageBytes);
-    const int dtok0 = tile_of(j + 2) * kTile;
-    const char* sA = cache + (int64_t)pga * p.page_stride_bytes + (int64_t)(dtok0 & page_mask) * kRowBytes;
-    const char* sB = p.page_shift == 4 ? cache + (int64_t)pgb * p.page_stride_bytes : sA + 16 * kRowBytes;
-    auto dma_piece = [&](auto ic) {  // piece 0..7: row group of this wave's column block; 8: its rope rows
-      constexpr int rg = decltype(ic)::value;
-      if constexpr (do_dma) {
-        if constexpr (rg < 8)
-          dma16((rg < 4 ? sA : sB) + (rg & 3) * 4 * kRowBytes + (dma_lo0 ^ (uint32_t)((rg & 3) << 4)),
-                dbase + (uint32_t)(wave * 8192 + rg * 1024));
-        else
-          dma16((wave < 2 ? sA : sB) + dma_ro, dbase + (uint32_t)(kMainBytes + wave * 1024));
-      }
-    };
-    if constexpr (!kDmaQK) static_for<0, 9>([&](auto ic) { dma_piece(ic); });
-    stamp(2);
-    if (work) {
-      qk_tile(j, s_cur, std::true_type{}, s_prv, dma_piece);  // + exponentials of tile j-1 -> pf
-    } else {
-      if constexpr (kDmaQK) static_for<0, 9>([&](auto ic) { dma_piece(ic); });
-    }
-    // (the page ids count as used here on every path: no scalar load is outstanding - on the LDS reads' counter - in the
-    //  P.V phase below, and the QK^T phase of the next tile starts without one)
-    asm volatile("" ::"s"(pgn0), "s"(pgn1));
-    if (work) {
-      mask_tile(j, s_cur);
-      __builtin_amdgcn_sched_barrier(0);
-      stamp(3);
-      pv_tile(j - 1, std::true_type{}, s_cur);  // + row maxima / reference of tile j
-      stamp(4);
-      if (upd) {  // rare: the reference moved, rescale O (AGPR -> VGPR -> AGPR) before the next P . V
-        static_for<0, 32>([&](auto ic) { agpr_scale8_sq<decltype(ic)::value * 8>(alpha); });
-        asm volatile("s_nop 7");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  v16f s_a, s_b;
-  {  // tile 0: nothing to overlap with
-    stamp(5);
-    wait_vmcnt<9>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::"s"(pgn0), "s"(pgn1));
-    if constexpr (kProbe != 4 && kProbe != 5) stage_tile(tile_of(2), 2, pgn0, pgn1);
-    load_pages(3, pgn0, pgn1);
-    asm volatile("" ::"s"(pgn0), "s"(pgn1));
-    if (work) {
-      auto no_dma = [](auto) {};
-      qk_tile(0, s_b, std::false_type{}, s_b, no_dma);
-      mask_tile(0, s_b);
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s_b));  // (asm MFMA result -> VALU read wait states)
-      static_for<0, kMaxOps>([&](auto kc) { max_op(kc, s_b); });  // (O is zero: nothing to rescale)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  int j = 1;
-  for (; j + 1 < n_my; j += 2) {  // (two tiles per trip: the logits of the tile in flight and of the one before swap roles)
-    iter(j, s_a, s_b);
-    iter(j + 1, s_b, s_a);
-  }
-  const bool odd_tail = j < n_my;
-  if (odd_tail) iter(j, s_a, s_b);
-  if (work) {
-    if (odd_tail) static_for<0, kExpOps>([&](auto kc) { exp_op(kc, s_a); });
-    else static_for<0, kExpOps>([&](auto kc) { exp_op(kc, s_b); });
-    __builtin_amdgcn_sched_barrier(0);
-    v16f dummy;
-    pv_tile(n_my - 1, std::false_type{}, dummy);
-  }
-  wait_vmcnt<0>();  // (the duplicate tiles: no LDS-DMA may be in flight when the workgroup ends and its LDS is handed on)
-  stamp(4);
-#ifdef SGLK_PROBES
-  auto write_stamps = [&]() {
-    if constexpr (kStamp) {
-      stamp(6);
-      if (lane == 0) {
-        unsigned long long* d = g_mla_stamps + (((size_t)b * p.splits + split) * 4 + wave) % 4096 * 16;
-        for (int k = 0; k < 12; ++k) d[k] = st_sum[k];
-        d[12] = __builtin_amdgcn_s_memtime() - clk0;       // shader cycles of the whole tile loop + epilogue
-        d[13] = __builtin_amdgcn_s_memrealtime() - rt0;    // the same in 100 MHz ticks
-        d[15] = (unsigned long long)n_my;
-      }
-    }
-  };
-#else
-  auto write_stamps = [&]() {};
-#endif
-
-  // ---- epilogue: O^T tile dt, register v: dim 32 dt + 8 (v / 4) + 4 u + v % 4 of this lane's row
-  if (p.probe == 1) return;
-  float c0 = l_run, c1 = l_run;
-  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));
-  const float l_tot = c0 + c1;
-  const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (p.splits == 1) {
-    T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + (ok ? my_head : 0)) * kLatent + 4 * u;
-    static_for<0, 64>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;  // dim tile i / 4, register group i % 4
-      const v4f v = agpr_read4<i * 4>();
-      const int lo = M::pack(v[0] * inv_l, v[1] * inv_l), hi = M::pack(v[2] * inv_l, v[3] * inv_l);
-      if (ok) *reinterpret_cast<v2i*>(out + 32 * (i >> 2) + 8 * (i & 3)) = (v2i){lo, hi};
-    });
-  } else {
-    const float my_lse = l_tot > 0.f ? m_ref * sl2 + log2f(l_tot) : -INFINITY;
-    if (!mla_take_ticket(p, b, smem, tid)) {
-      float* wo = p.ws_o + (((int64_t)b * p.splits + split) * H + (ok ? my_head : 0)) * kLatent + 4 * u;
-      static_for<0, 64>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const v4f v = agpr_read4<i * 4>();
-        const v4f w = {v[0] * inv_l, v[1] * inv_l, v[2] * inv_l, v[3] * inv_l};
-        float* const dst = wo + 32 * (i >> 2) + 8 * (i & 3);
-        if (ok) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
-      });
-      if (ok && u == 0)
-        __hip_atomic_store(p.ws_lse + ((int64_t)b * p.splits + split) * H + my_head, my_lse, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      mla_count_in(p, b, tid);
-    } else {
-      const bool all_in = mla_wait_others(p, b, smem, tid);
-      const int hrow = ok ? my_head : 0;
-      T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + hrow) * kLatent + 4 * u;
-      mla_merge_splits<T, M, true>(p, b, split, H, ok, hrow, out, u, my_lse, inv_l, all_in);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  write_stamps();
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// rows128z kernel (round 5): the rows128x kernel's arithmetic, registers, LDS image and merge, with the tile loop re-cut around
+// rows128z kernel (round 5): round 3's 32x32x16 arithmetic, registers, LDS image and merge, with the tile loop re-cut around
 // what round 5's in-kernel stamps showed (per 32-token tile, one wave per SIMD: 2176 cycles of MFMA, ~4000 spent):
 //   * phase-start bubbles (~250 cycles each): every phase began with ~13 address instructions and the latency of its first
 //     fragment reads. Now the P.V fragments of tile j-1 are requested in the last three MFMA gaps of QK^T(j) (K reads are asm
@@ -1350,7 +862,7 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128x_kernel(MlaParams p,
 //     window is re-fetched (asm load, in front of the iteration's nine pieces, so that the next iteration's counted vmcnt
 //     covers it) once per 32 - 128 tiles: no scalar load shares lgkmcnt with the LDS reads;
 //   * softmax micro-ops re-cut so that no instruction directly follows its producer (fma, fma | exp, cvt | exp, dot2).
-template <typename T, bool kStamp = false, int kProbe = 0>
+template <typename T, bool kStamp = false, int kProbe = 0, int kKA = 3, int kVA = 4>
 __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p, const T* __restrict__ q_nope,
                                                                     const T* __restrict__ q_pe,
                                                                     const char* __restrict__ cache,
@@ -1433,9 +945,8 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
         mla_count_in(p, b, tid);
       } else {
         const bool all_in = mla_wait_others(p, b, smem, tid);
-        const int hrow = ok ? my_head : 0;
-        T* out = (T*)p.out + ((int64_t)(q_row0 + (ok ? my_tok : 0)) * H + hrow) * kLatent + 4 * u;
-        mla_merge_splits<T, M, false>(p, b, split, H, ok, hrow, out, u, -INFINITY, 0.f, all_in);
+        mla_merge_splits<T, M, false>(p, b, split, H, ok ? my_head : 0, smem, wave, lane, -INFINITY, 0.f, all_in);
+        mla_flush_rows<T>(p, smem, wave, lane, q_row0, n_tok);
       }
     }
     return;
@@ -1445,31 +956,37 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   const int last_entry = (seq - 1) >> p.page_shift;
   auto tile_of = [&](int j) { return t_begin + (j < n_my ? j : n_my - 1); };
   int win0 = (tile_of(0) * kTile) >> p.page_shift;
-  int v_ids;
-  auto ids_fetch = [&]() {  // asm: the compiler must not count this load (it would drain the DMA ring in front of the first use)
+  // (asm: the compiler must not count this load - it would drain the DMA ring in front of the first use - and the register
+  //  is an IN-OUT operand of every statement that touches it: the load lands long after its statement, so the value must
+  //  never be copied in between. `go` = 0 skips the load inside the statement: no branch merge, no phi, no copy)
+  int v_ids = 0;
+  auto ids_fetch = [&](int go) {
     int e = win0 + lane;
     e = e < last_entry ? e : last_entry;
     const uint32_t off = (uint32_t)e * 4u;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v_ids) : "v"(off), "s"(table) : "memory");
+    asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\tglobal_load_dword %0, %1, %2\n1:"
+                 : "+v"(v_ids)
+                 : "v"(off), "s"(table), "s"(go)
+                 : "memory", "scc");
   };
-  ids_fetch();
-  // page ids of tile t (both 16-token halves; for pages of 32 tokens and more both name the same page)
+  ids_fetch(1);
+  // page ids of tile t (both 16-token halves; only 16-token pages give them different ones). Scalar work is issue time of
+  // the one wave a SIMD has: 32-bit index arithmetic, a 32 x 32 -> 64-bit product per page (the host checks the stride)
+  const bool two_pages = p.page_shift == 4;
+  const uint32_t stride32 = (uint32_t)p.page_stride_bytes;
   auto ids_of = [&](int t, int& pg0, int& pg1) {
     const int tok0 = t * kTile;
-    const int e0 = tok0 >> p.page_shift;
-    const int e1 = (tok0 + 16 < seq) ? ((tok0 + 16) >> p.page_shift) : e0;
-    pg0 = __builtin_amdgcn_readlane(v_ids, e0 - win0);
-    pg1 = __builtin_amdgcn_readlane(v_ids, e1 - win0);
+    const int i0 = (tok0 >> p.page_shift) - win0;
+    pg0 = __builtin_amdgcn_readlane(v_ids, i0);
+    pg1 = pg0;
+    if (two_pages) pg1 = __builtin_amdgcn_readlane(v_ids, (tok0 + 16 < seq) ? i0 + 1 : i0);
   };
   // moves the window when tile t's entries do not lie in it (t: the tile whose ids the NEXT iteration reads)
   auto ids_advance = [&](int t) {
-    const int tok0 = t * kTile;
-    const int e0 = tok0 >> p.page_shift;
-    const int e1 = (tok0 + 16) >> p.page_shift;
-    if (e1 - win0 >= 64) {
-      win0 = e0;
-      ids_fetch();
-    }
+    const int e0 = (t * kTile) >> p.page_shift;
+    const int go = __builtin_amdgcn_readfirstlane((e0 + 1 - win0 >= 64) ? 1 : 0);
+    win0 = go ? e0 : win0;
+    ids_fetch(go);
   };
 
   // ---- Q^T fragments (B operand of K . Q^T): lane supplies q[row][16 ks + 8 u .. + 8). The 32 fragments of the latent part
@@ -1523,8 +1040,8 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   auto tile_src = [&](int t, int st, int pg0, int pg1) {
     TileSrc s;
     const int tok0 = t * kTile;
-    s.sA = cache + (int64_t)pg0 * p.page_stride_bytes + (int64_t)(tok0 & page_mask) * kRowBytes;
-    s.sB = p.page_shift == 4 ? cache + (int64_t)pg1 * p.page_stride_bytes : s.sA + 16 * kRowBytes;
+    s.sA = cache + ((uint64_t)(uint32_t)pg0 * stride32 + (uint32_t)((tok0 & page_mask) * kRowBytes));
+    s.sB = two_pages ? cache + (uint64_t)(uint32_t)pg1 * stride32 : s.sA + 16 * kRowBytes;
     s.dst = lds_base + (uint32_t)(st * kStageBytes + wave * 8192);
     s.rdst = lds_base + (uint32_t)(st * kStageBytes + kMainBytes + wave * 1024);
     return s;
@@ -1555,7 +1072,14 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   asm volatile("" ::: "a0", "a255");
   static_for<0, 64>([&](auto ic) { agpr_zero4<decltype(ic)::value * 4>(); });
 
-  // Lazy reference: see mla_rows128x_kernel
+  // Lazy reference (the idea of the 16-row kernel above, wider here): bf16 weights have fp32's exponent range, so the
+  // reference need not be the maximum. When it moves it is set 2^kHead ABOVE the row's running maximum (weights restart at
+  // 2^-kHead) and it moves again only when a weight would pass 2^kLazy: kHead + kLazy = 190 binades of growth per move (100
+  // in the kernel above; the reference benchmark's q x 100 logits grow by ~220 binades over a split, and every move of any
+  // of a wave's 32 rows costs the wave - and, through the tile barrier, the workgroup - a 768-instruction pass over O).
+  // Range: 2^kLazy x keys x |V| stays below 2^127 for a million keys and |V| < 2^16; a weight 2^-24 below the largest
+  // one is still >= 2^-124 (normal); the rescale factor 2^-(move), down to ~2^-220, is applied as two multiplies by its
+  // square root. f16 weights must stay in [2^-14, 2^16): threshold 2^8, no headroom.
   constexpr bool kWide = std::is_same<T, bf16>::value;
   constexpr float kLazy = kWide ? 90.0f : 8.0f, kHead = kWide ? 100.0f : 0.0f;
   const float sl2 = p.scale_log2;
@@ -1619,7 +1143,9 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
     }
   };
   constexpr int kExpOps = 28;
-  // first half: row maximum of the raw logits in sc, then the lazy reference: see mla_rows128x_kernel
+  // first half: row maximum of the raw logits in sc, then the lazy reference: it moves only when a weight would pass
+  // 2^kLazy, then to 2^kHead above the running maximum; all rows of the wave move together (one rescale pass serves them
+  // all). Leaves alpha / upd for the rescale of O and takes l_run to the new reference.
   auto max_op = [&](auto kc, v16f& sc) {
     constexpr int k = decltype(kc)::value;
     if constexpr (k == 0) {
@@ -1658,7 +1184,7 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   // ---- rings. K: fragment n + 3 is requested in the gap behind MFMA n; V^T: four fragments (eight transposed reads) ahead,
   // the first three requested in the last three gaps of the QK^T phase in front (kPre).
   typedef int v4i __attribute__((ext_vector_type(4)));
-  constexpr int kKA = 3, kVA = 4;
+  static_assert(kKA >= 2 && kKA <= 6 && kVA >= 3 && kVA <= 8, "ring depths");
   v2i vlo[kVA], vhi[kVA];
   uint32_t vb[2];  // stage-relative bases of the tile whose P . V comes next (token halves e = 0, 1)
   uint32_t va0 = 0, va1 = 0;
@@ -1689,7 +1215,7 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
     const uint32_t sb = lds_base + (uint32_t)((j & 3) * kStageBytes);
     uint32_t kbs = kbase + sb, rbs = rbase + sb;  // (stage bases are multiples of 256: the xor of bits 5..7 commutes with the add)
     asm volatile("" : "+v"(kbs), "+v"(rbs));
-    v4i kr[kKA], qr[4];  // (K ring of three; the four rope fragments of Q, read from LDS with their K fragments)
+    v4i kr[kKA], qr[4];  // (K ring; the four rope fragments of Q, read from LDS with their K fragments)
     uint32_t ka = kbs;
     // (capture-less, behind a macro: see v_issue_)
     auto k_issue_ = [](auto nc, v4i& kslot, v4i& qslot, uint32_t& ka_, const uint32_t kbs_, const uint32_t rbs_,
@@ -1711,9 +1237,7 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
       }
     };
 #define SGLK_K_ISSUE(N_) k_issue_(std::integral_constant<int, (N_)>{}, kr[(N_) % kKA], qr[(N_) & 3], ka, kbs, rbs, qpe_addr)
-    SGLK_K_ISSUE(0);
-    SGLK_K_ISSUE(1);
-    SGLK_K_ISSUE(2);
+    static_for<0, kKA>([&](auto nc) { constexpr int n0 = decltype(nc)::value; SGLK_K_ISSUE(n0); });
     // under the latency of the first fragments: the rope piece of tile j + 2
     if constexpr (kExp) dma_piece(nxt, std::integral_constant<int, 8>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -1722,8 +1246,10 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
       constexpr int ks = n < 32 ? 8 * (n & 3) + (n >> 2) : 0;  // the Q fragment that goes with K fragment n (rope: from LDS)
       // reads younger than step n's at this point: those of the steps n+1, n+2 (one each, two for a rope step: K and Q) and
       // the V^T reads of the gaps 33, 34 (two each)
-      constexpr int r1 = n + 1 > 35 ? 0 : n + 1 >= 32 ? 2 : 1, r2 = n + 2 > 35 ? 0 : n + 2 >= 32 ? 2 : 1;
-      constexpr int younger = r1 + r2 + (kExp ? (n == 34 ? 2 : n == 35 ? 4 : 0) : 0);
+      constexpr int last = n + kKA - 1 < 35 ? n + kKA - 1 : 35;  // steps n+1 .. last are in flight behind step n
+      constexpr int n_lat = last - n, n_rope = last >= 32 ? last - (n + 1 > 32 ? n + 1 : 32) + 1 : 0;
+      constexpr int younger = n_lat + (n_rope > 0 ? n_rope : 0) + (kExp ? (n == 34 ? 2 : n == 35 ? 4 : 0) : 0);
+      static_assert(younger <= 15, "lgkmcnt is a 4-bit field");
       constexpr int wcnt = (kProbe == 2 || kProbe == 3 || kProbe == 5) ? 0 : younger;
       const v8s kf = __builtin_bit_cast(v8s, kr[n % kKA]);
       const v8s qb = n < 32 ? qf[ks] : __builtin_bit_cast(v8s, qr[n & 3]);
@@ -1787,8 +1313,8 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
       vb[1] = (vb[0] ^ 32u) + 2048u;
       asm volatile("" : "+v"(vb[0]), "+v"(vb[1]));
       static_for<0, kVA>([&](auto mc) { constexpr int m0 = decltype(mc)::value; SGLK_V_ISSUE(m0); });
-    } else {
-      SGLK_V_ISSUE(3);  // (three fragments came with the QK^T phase: its K ring was still live there)
+    } else {  // (three fragments came with the QK^T phase: its K ring was still live there)
+      static_for<3, kVA>([&](auto mc) { constexpr int m0 = decltype(mc)::value; SGLK_V_ISSUE(m0); });
     }
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 32>([&](auto mc) {
@@ -1848,7 +1374,7 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
       qk_tile(j, s_cur, std::true_type{}, s_prv, nxt, j - 1);  // + exponentials of tile j-1 -> pf
       mask_tile(j, s_cur);
       __builtin_amdgcn_sched_barrier(0);
-      stamp(3);
+      // (no stamp between the phases: s_memtime is a scalar memory read, its wait would drain the V^T reads in flight here)
       // + row maxima / reference of tile j; the slot of this wave's DMA pieces is a template parameter: four copies
       if (wave == 0) pv_tile(j - 1, std::true_type{}, std::true_type{}, s_cur, std::integral_constant<int, 0>{}, nxt);
       else if (wave == 1) pv_tile(j - 1, std::true_type{}, std::true_type{}, s_cur, std::integral_constant<int, 1>{}, nxt);
@@ -1918,43 +1444,42 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   auto write_stamps = [&]() {};
 #endif
 
-  // ---- epilogue: O^T tile dt, register v: dim 32 dt + 8 (v / 4) + 4 u + v % 4 of this lane's row
+  // ---- epilogue: O^T tile dt, register v: dim 32 dt + 8 (v / 4) + 4 u + v % 4 of this lane's row (see mla_stage_group)
   if (p.probe == 1) return;
   const RowId rid = row_id();
-  const bool ok2 = rid.ok;
-  const int u2 = rid.u, tok2 = rid.my_tok, head2 = rid.my_head;
+  const int l31b = lane & 31;
   float c0 = l_run, c1 = l_run;
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c0), "+v"(c1));
   const float l_tot = c0 + c1;
   const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   if (p.splits == 1) {
-    T* out = (T*)p.out + ((int64_t)(q_row0 + (ok2 ? tok2 : 0)) * H + (ok2 ? head2 : 0)) * kLatent + 4 * u2;
+    __syncthreads();  // (every wave has left the tile loop and drained its DMA: the stages are free)
     static_for<0, 64>([&](auto ic) {
       constexpr int i = decltype(ic)::value;  // dim tile i / 4, register group i % 4
       const v4f v = agpr_read4<i * 4>();
-      const int lo = M::pack(v[0] * inv_l, v[1] * inv_l), hi = M::pack(v[2] * inv_l, v[3] * inv_l);
-      if (ok2) *reinterpret_cast<v2i*>(out + 32 * (i >> 2) + 8 * (i & 3)) = (v2i){lo, hi};
+      const v4f o = {v[0] * inv_l, v[1] * inv_l, v[2] * inv_l, v[3] * inv_l};
+      mla_stage_group<M>(smem, wave, l31b, rid.u, i, o);
     });
+    mla_flush_rows<T>(p, smem, wave, lane, q_row0, n_tok);
   } else {
     const float my_lse = l_tot > 0.f ? m_ref * sl2 + log2f(l_tot) : -INFINITY;
     if (!mla_take_ticket(p, b, smem, tid)) {
-      float* wo = p.ws_o + (((int64_t)b * p.splits + split) * H + (ok2 ? head2 : 0)) * kLatent + 4 * u2;
+      v4f* wo = reinterpret_cast<v4f*>(p.ws_o) + mla_slab_f4(p, b, split, wave) + lane;  // fragment order: see above
       static_for<0, 64>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const v4f v = agpr_read4<i * 4>();
         const v4f w = {v[0] * inv_l, v[1] * inv_l, v[2] * inv_l, v[3] * inv_l};
-        float* const dst = wo + 32 * (i >> 2) + 8 * (i & 3);
-        if (ok2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+        v4f* const dst = wo + i * 64;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
       });
-      if (ok2 && u2 == 0)
-        __hip_atomic_store(p.ws_lse + ((int64_t)b * p.splits + split) * H + head2, my_lse, __ATOMIC_RELAXED,
+      if (rid.ok && rid.u == 0)
+        __hip_atomic_store(p.ws_lse + ((int64_t)b * p.splits + split) * H + rid.my_head, my_lse, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       mla_count_in(p, b, tid);
     } else {
       const bool all_in = mla_wait_others(p, b, smem, tid);
-      const int hrow = ok2 ? head2 : 0;
-      T* out = (T*)p.out + ((int64_t)(q_row0 + (ok2 ? tok2 : 0)) * H + hrow) * kLatent + 4 * u2;
-      mla_merge_splits<T, M, true>(p, b, split, H, ok2, hrow, out, u2, my_lse, inv_l, all_in);
+      mla_merge_splits<T, M, true>(p, b, split, H, rid.ok ? rid.my_head : 0, smem, wave, lane, my_lse, inv_l, all_in);
+      mla_flush_rows<T>(p, smem, wave, lane, q_row0, n_tok);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2002,14 +1527,14 @@ static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nop
 }
 
 #ifdef SGLK_PROBES
-static int g_mla_variant = 0;  // kbench: 50 = the round-4 tile loop, 90 = the same with stamps, 70 + probe = stamped round-5 loop
+static int g_mla_variant = 0;  // kbench: 70 + probe = the tile loop with in-kernel stamps
 #endif
 template <typename T>
 static int launch_rows128x(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
                            const void* cache, const int32_t* seq_lens, const int32_t* page_table,
                            const int32_t* cu_seqlens_q = nullptr, int token_blocks = 1) {
   const dim3 grid(p.splits, B, token_blocks);
-  constexpr int ldsx = 4 * kStageBytes, ldsz = 4 * kStageBytes + 16384;  // (z: + the rope part of Q = all 160 KiB)
+  constexpr int ldsz = 4 * kStageBytes + 16384;  // (the four stages + the rope part of Q = all 160 KiB)
 #define SGLK_MLA_LAUNCH(KERNEL, lds)                                                                                      \
   {                                                                                                                    \
     static unsigned long long attr = 0;                                                                                \
@@ -2020,14 +1545,25 @@ static int launch_rows128x(hipStream_t st, const MlaParams& p, int B, const void
   }
 #ifdef SGLK_PROBES
   if constexpr (std::is_same<T, bf16>::value) {
-    if (g_mla_variant == 50) SGLK_MLA_LAUNCH((mla_rows128x_kernel<T, 3, 4>), ldsx)
-    if (g_mla_variant == 90) SGLK_MLA_LAUNCH((mla_rows128x_kernel<T, 3, 4, true>), ldsx)
-    if (g_mla_variant == 94) SGLK_MLA_LAUNCH((mla_rows128x_kernel<T, 3, 4, true, 4>), ldsx)
     if (g_mla_variant == 70) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0>), ldsz)
     if (g_mla_variant == 73) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 3>), ldsz)
     if (g_mla_variant == 74) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 4>), ldsz)
     if (g_mla_variant == 75) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 5>), ldsz)
     if (g_mla_variant == 76) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 6>), ldsz)
+    if (g_mla_variant == 170) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 5, 4>), ldsz)  // deeper fragment rings
+    if (g_mla_variant == 171) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 5, 6>), ldsz)
+    if (g_mla_variant == 172) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 3, 6>), ldsz)
+    if (g_mla_variant == 173) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 4, 5>), ldsz)
+    if (g_mla_variant == 203) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 3>), ldsz)  // probes without stamps: wall time
+    if (g_mla_variant == 204) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 4>), ldsz)
+    if (g_mla_variant == 205) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 5>), ldsz)
+    if (g_mla_variant == 206) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 6>), ldsz)
+    if (g_mla_variant == 270) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 5, 4>), ldsz)
+    if (g_mla_variant == 271) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 5, 6>), ldsz)
+    if (g_mla_variant == 272) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 3, 6>), ldsz)
+    if (g_mla_variant == 273) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 4, 5>), ldsz)
+    if (g_mla_variant == 274) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 6, 6>), ldsz)
+    if (g_mla_variant == 276) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 2, 3>), ldsz)
   }
 #endif
   SGLK_MLA_LAUNCH((mla_rows128z_kernel<T>), ldsz)
@@ -2062,7 +1598,7 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
     default: rc = launch_w<T, 1>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
   }
   if (rc) return rc;
-  const bool merged_in_kernel = ngroups > 4 && g_mla_waves_per_group == 0;  // (the rows128x kernel merges its splits itself)
+  const bool merged_in_kernel = ngroups > 4 && g_mla_waves_per_group == 0;  // (the rows128z kernel merges its splits itself)
   if (p.splits > 1 && !merged_in_kernel) {
     mla_reduce_kernel<T><<<dim3(p.H, B), 128, 0, st>>>((T*)p.out, p.ws_o, p.ws_lse, p.H, p.splits);
     return check_launch("flash_mla_decode(reduce)");
@@ -2074,6 +1610,8 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
 // bytes of the merge counters in front of the workspace: two 8-byte words per batch element, padded to 256 (keeps what
 // follows aligned)
 static inline int64_t mla_counter_bytes(int64_t batch) { return (batch * 16 + 255) / 256 * 256; }
+// rows of partial O per (batch element, split): the rows128 kernel (H > 64) stores whole 128-row fragment slabs
+static inline int64_t mla_ws_rows(int64_t H) { return H > 64 ? 128 : H; }
 }  // namespace sglk
 
 #ifdef SGLK_PROBES
@@ -2104,7 +1642,7 @@ extern "C" int64_t sglk_mla_decode_workspace_size(int64_t max_seq_len, int64_t b
   if (num_kv_splits == 1) return 0;
   // {ticket, published} counter words of the in-kernel merge (a block of their own at the start), then
   // fp32 partial O and the log2-sum-exps
-  return sglk::mla_counter_bytes(batch) + batch * num_kv_splits * num_heads * (sglk::kLatent + 1) * 4;
+  return sglk::mla_counter_bytes(batch) + batch * num_kv_splits * (sglk::mla_ws_rows(num_heads) * sglk::kLatent + num_heads) * 4;
 }
 
 extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void* q_nope, const void* q_pe,
@@ -2125,6 +1663,8 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
                    q_pe_stride_h % 8 == 0 && (uintptr_t)q_nope % 16 == 0 && (uintptr_t)q_pe % 16 == 0 &&
                    (uintptr_t)cache % 16 == 0 && cache_page_stride % 8 == 0,
                "flash_mla_decode: q and cache rows must be 16-byte aligned");
+  SGLK_REQUIRE(cache_page_stride > 0 && cache_page_stride * 2 < (int64_t)1 << 32,
+               "flash_mla_decode: a page stride must be below 4 GiB, got %lld elements", (long long)cache_page_stride);
   if (batch == 0) return SGLK_OK;
   const int64_t max_seq = pages_per_seq * page_size;
   int64_t splits = num_kv_splits < 1 ? sglk_mla_decode_auto_splits(batch, max_seq) : num_kv_splits;
@@ -2132,7 +1672,7 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   if (splits > max_tiles) splits = max_tiles;
   SGLK_REQUIRE(splits <= 32768, "flash_mla_decode: at most 32768 KV splits, got %lld", (long long)splits);
   if (splits > 1) {
-    const int64_t need = mla_counter_bytes(batch) + batch * splits * num_heads * (kLatent + 1) * 4;
+    const int64_t need = mla_counter_bytes(batch) + batch * splits * (mla_ws_rows(num_heads) * kLatent + num_heads) * 4;
     SGLK_REQUIRE(workspace != nullptr && workspace_bytes >= need,
                  "flash_mla_decode: workspace too small: %lld bytes given, %lld needed for %lld splits",
                  (long long)workspace_bytes, (long long)need, (long long)splits);
@@ -2142,7 +1682,7 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   p.out = out;
   p.ws_cnt = (unsigned long long*)workspace;  // (no zeroing: the words initialise themselves, see mla_cnt_up)
   p.ws_o = workspace ? (float*)((char*)workspace + mla_counter_bytes(batch)) : nullptr;
-  p.ws_lse = p.ws_o ? p.ws_o + batch * splits * num_heads * kLatent : nullptr;
+  p.ws_lse = p.ws_o ? p.ws_o + batch * splits * mla_ws_rows(num_heads) * kLatent : nullptr;
   p.qn_sb = q_nope_stride_b;
   p.qn_sh = q_nope_stride_h;
   p.qp_sb = q_pe_stride_b;
@@ -2185,6 +1725,8 @@ extern "C" int sglk_flash_mla_prefill(sglk_stream_t stream, void* out, const voi
                    q_pe_stride_h % 8 == 0 && (uintptr_t)q_nope % 16 == 0 && (uintptr_t)q_pe % 16 == 0 &&
                    (uintptr_t)cache % 16 == 0 && cache_page_stride % 8 == 0,
                "flash_mla_prefill: q and cache rows must be 16-byte aligned");
+  SGLK_REQUIRE(cache_page_stride > 0 && cache_page_stride * 2 < (int64_t)1 << 32,
+               "flash_mla_prefill: a page stride must be below 4 GiB, got %lld elements", (long long)cache_page_stride);
   if (batch == 0 || max_seqlen_q <= 0) return SGLK_OK;
   MlaParams p;
   p.out = out;

@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b) {
 // (Measured and dropped: a wave-step of the four consecutive blocks of ONE 32-column group - 2 KiB contiguous, 128 deep, twice
 // the workgroups - needs two MFMAs per row set, each with half of the row slots zeroed, and four activation loads per step:
 // 11.3 against 7.8 us at N = 14336, K = 4096, one row.)
-template <bool GROUP, int MF, int KS, int KD>
+template <bool GROUP, int MF, int KS, int KD, bool A16 = false>
 __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
     f16* __restrict__ out, const int8_t* __restrict__ a, const uint8_t* __restrict__ w,
     const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales_i8, const f16* __restrict__ wscales,
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
   for (int mf = 0; mf < MF; ++mf) {
     int m = m0 + mf * 16 + j;
     m = m < M ? m : M - 1;
-    al[mf] = a + (int64_t)m * lda + q1 * 32 + p * 8;
+    al[mf] = a + (int64_t)m * lda + q1 * 32 + (A16 ? p * 16 : p * 8);
   }
   const int8_t* s8 = GROUP ? scales_i8 + n32c * 32 + c * 4 : nullptr;
   const int8_t* z8 = GROUP ? zeros + n32c * 32 + c * 4 : nullptr;
@@ -105,8 +105,14 @@ __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
     wd[1] = *reinterpret_cast<const v4i*>(wl + (int64_t)ks * 1024 + 16);
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-      af[mf][0] = *reinterpret_cast<const v2i*>(al[mf] + ks * 64);
-      af[mf][1] = *reinterpret_cast<const v2i*>(al[mf] + ks * 64 + 16);
+      if constexpr (A16) {  // one 16-byte load per lane: the lanes p = 0 / 1 of a row exchange halves in front of the MFMAs
+        const v4i t = *reinterpret_cast<const v4i*>(al[mf] + ks * 64);
+        af[mf][0] = (v2i){t[0], t[1]};
+        af[mf][1] = (v2i){t[2], t[3]};
+      } else {
+        af[mf][0] = *reinterpret_cast<const v2i*>(al[mf] + ks * 64);
+        af[mf][1] = *reinterpret_cast<const v2i*>(al[mf] + ks * 64 + 16);
+      }
     }
     if constexpr (GROUP) {
       const int64_t g = ks >> 1;
@@ -154,6 +160,13 @@ __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
       }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
+        if constexpr (A16) {
+          // lane p = 0 holds bytes 0..15 of the row's 32-byte k block, lane p = 1 (16 lanes on) bytes 16..31; the MFMA wants
+          // {0..7, 16..23} from p = 0 and {8..15, 24..31} from p = 1: v_permlane16_swap exchanges the odd 16-lane rows of its
+          // first operand (p = 1's low half) with the even rows of its second (p = 0's high half)
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
+                       : "+v"(aq_[u][mf][0][0]), "+v"(aq_[u][mf][0][1]), "+v"(aq_[u][mf][1][0]), "+v"(aq_[u][mf][1][1]));
+        }
         const v4i bop = {aq_[u][mf][0][0], aq_[u][mf][0][1], aq_[u][mf][1][0], aq_[u][mf][1][1]};
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[mf][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop[t], bop, acc[mf][t], 0, 0, 0);
@@ -382,8 +395,10 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
 
 #ifdef SGLK_PROBES
 static int g_qserve_mf = 0;  // (diagnostic: cap on the m-tiles per workgroup of the decode stream kernel)
+static int g_qserve_cfg = 0; // (diagnostic: forced stream configuration 1000 mf + 100 log2(ks) + 10 kd + a16, e.g. 4341)
 #else
 constexpr int g_qserve_mf = 0;
+constexpr int g_qserve_cfg = 0;
 #endif
 #ifdef SGLK_PROBES
 static int g_qserve_persist_rows = 128;
@@ -409,23 +424,44 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   int ks = 1;
   while (ks < (M <= 16 ? 16 : 8) && pairs * cdiv(M, 16 * mf) * ks < 1536 && (K >> 6) >= 8 * ks) ks *= 2;
   const bool deep = (K >> 6) / ks >= 8 && ks <= 8;  // (ring no deeper than a wave's steps)
-#define SGLK_GO_STREAM(MF, KS, KD)                                                                               \
+#define SGLK_GO_STREAM_A(MF, KS, KD, A16)                                                                        \
   {                                                                                                              \
     constexpr int lds = (KS - 1) * MF * 4 * 64 * 16;                                                             \
     static unsigned long long attr_done = 0;                                                                     \
     if (lds > 64 * 1024)                                                                                         \
-      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&qserve_w4a8_stream_kernel<GROUP, MF, KS, KD>), lds,   \
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&qserve_w4a8_stream_kernel<GROUP, MF, KS, KD, A16>), lds, \
                                    &attr_done, "qserve_w4a8"))                                                   \
         return rc;                                                                                               \
-    qserve_w4a8_stream_kernel<GROUP, MF, KS, KD><<<dim3((unsigned)pairs, (unsigned)cdiv(M, 16 * MF)), 64 * KS, lds, st>>>( \
+    qserve_w4a8_stream_kernel<GROUP, MF, KS, KD, A16><<<dim3((unsigned)pairs, (unsigned)cdiv(M, 16 * MF)), 64 * KS, lds, st>>>( \
         (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,          \
         (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc); \
   }
+#define SGLK_GO_STREAM(MF, KS, KD) SGLK_GO_STREAM_A(MF, KS, KD, false)
 #define SGLK_GO_STREAM_KS(MF, KD)                                                                                \
   {                                                                                                              \
     if (ks == 1) SGLK_GO_STREAM(MF, 1, KD) else if (ks == 2) SGLK_GO_STREAM(MF, 2, KD) else if (ks == 4) SGLK_GO_STREAM(MF, 4, KD) \
     else SGLK_GO_STREAM(MF, 8, KD)                                                                               \
   }
+#ifdef SGLK_PROBES
+  if (g_qserve_cfg != 0 && M <= 64) {
+    switch (g_qserve_cfg) {
+      case 4320: SGLK_GO_STREAM_A(4, 8, 2, false) break;
+      case 4321: SGLK_GO_STREAM_A(4, 8, 2, true) break;
+      case 4340: SGLK_GO_STREAM_A(4, 8, 4, false) break;
+      case 4341: SGLK_GO_STREAM_A(4, 8, 4, true) break;
+      case 4241: SGLK_GO_STREAM_A(4, 4, 4, true) break;
+      case 4281: SGLK_GO_STREAM_A(4, 4, 8, true) break;
+      case 2341: SGLK_GO_STREAM_A(2, 8, 4, true) break;
+      case 2381: SGLK_GO_STREAM_A(2, 8, 8, true) break;
+      case 2441: SGLK_GO_STREAM_A(2, 16, 4, true) break;
+      case 2340: SGLK_GO_STREAM_A(2, 8, 4, false) break;
+      case 1441: SGLK_GO_STREAM_A(1, 16, 4, true) break;
+      case 1381: SGLK_GO_STREAM_A(1, 8, 8, true) break;
+      default: break;
+    }
+    return check_launch("qserve_w4a8(cfg)");
+  }
+#endif
   if (M <= 64) {
     if (mf == 1) {
       if (ks == 16) SGLK_GO_STREAM(1, 16, 4) else if (deep) SGLK_GO_STREAM_KS(1, 8) else SGLK_GO_STREAM_KS(1, 4)
@@ -440,6 +476,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   }
 #undef SGLK_GO_STREAM_KS
 #undef SGLK_GO_STREAM
+#undef SGLK_GO_STREAM_A
   return check_launch(GROUP ? "qserve_w4a8_per_group_gemm" : "qserve_w4a8_per_chn_gemm");
 }
 
@@ -461,6 +498,7 @@ static int check(const char* op, const void* out, const void* a, const void* w, 
 #ifdef SGLK_PROBES
 extern "C" SGLK_API void sglk_debug_set_qserve_persist_rows(int rows) { sglk::g_qserve_persist_rows = rows; }
 extern "C" SGLK_API void sglk_debug_set_qserve_mf(int mf) { sglk::g_qserve_mf = mf; }
+extern "C" SGLK_API void sglk_debug_set_qserve_cfg(int cfg) { sglk::g_qserve_cfg = cfg; }
 #endif
 
 extern "C" int sglk_qserve_w4a8_per_chn_gemm(sglk_stream_t stream, void* out, const void* in_feats, const void* kernel,

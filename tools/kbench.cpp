@@ -707,15 +707,34 @@ int main(int argc, char** argv) {
           HIP_CHECK(hipDeviceSynchronize());
           std::vector<unsigned long long> st(16 * 4 * 4096);
           sglk_debug_get_mla_stamps(st.data(), (int)st.size());
-          const int nw = (int)std::min<int64_t>(4096, B * (splits > 0 ? splits : 1) * 4);
-          double sum[14] = {0}, tiles = 0;
-          for (int i = 0; i < nw; i += 4) { for (int k = 0; k < 14; ++k) sum[k] += (double)st[i * 16 + k]; tiles += (double)st[i * 16 + 15]; }
-          printf("variant %2d: landed-wait %.0f barrier %.0f DMA-issue %.0f QK %.0f PV %.0f tail %.0f | per launch: prologue %.0f epilogue %.0f\n",
-                 prb, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[8] / tiles,
-                 sum[5] / (nw / 4), sum[6] / (nw / 4));
-          printf("          in-kernel clock %.0f MHz (%.0f cycles in %.1f us per workgroup)\n", sum[12] / sum[13] * 100.0,
-                 sum[12] / (nw / 4), sum[13] / (nw / 4) / 100.0);
+          const int nw = (int)std::min<int64_t>(4096, B * (splits > 0 ? splits : 2) * 4);
+          for (int w = 0; w < 4; ++w) {  // per wave: the barrier wait of one is the others' extra work
+            double sum[14] = {0}, tiles = 0;
+            for (int i = w; i < nw; i += 4) { for (int k = 0; k < 14; ++k) sum[k] += (double)st[i * 16 + k]; tiles += (double)st[i * 16 + 15]; }
+            printf("variant %2d wave %d: landed-wait %.0f barrier %.0f DMA-setup %.0f QK+PV %.0f tail %.0f = %.0f per tile | per launch: prologue %.0f epilogue %.0f\n",
+                   prb, w, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, (sum[3] + sum[4]) / tiles, sum[8] / tiles,
+                   (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[8]) / tiles, sum[5] / (nw / 4), sum[6] / (nw / 4));
+            if (w == 3)
+              printf("          in-kernel clock %.0f MHz (%.0f cycles in %.1f us per workgroup)\n", sum[12] / sum[13] * 100.0,
+                     sum[12] / (nw / 4), sum[13] / (nw / 4) / 100.0);
+          }
         }
+        sglk_debug_set_mla_variant(0);
+        if (ws) HIP_CHECK(hipFree(ws));
+        if (ai >= argc) break;
+        continue;
+      }
+      if (getenv("MLA_TIME_VARIANTS")) {  // interleaved rounds of the listed variants (0 = the release configuration)
+        std::vector<int> vs;
+        { std::string e = getenv("MLA_TIME_VARIANTS"); size_t pos = 0; while (pos < e.size()) { vs.push_back(atoi(e.c_str() + pos)); pos = e.find(',', pos); if (pos == std::string::npos) break; ++pos; } }
+        for (int round = 0; round < 3; ++round)
+          for (int v : vs) {
+            sglk_debug_set_mla_variant(v);
+            const double m = time_ms(run, 60, 30, &all);
+            printf("mla[variant %3d] B=%lld S=%lld H=%lld splits=%lld median %.4f ms min %.4f -> %.1f GB/s, %.1f TFLOP/s\n", v,
+                   (long long)B, (long long)S, (long long)H, (long long)splits, m, all[0], bytes / m / 1e6,
+                   2.0 * B * H * S * 1088 / m / 1e9);
+          }
         sglk_debug_set_mla_variant(0);
         if (ws) HIP_CHECK(hipFree(ws));
         if (ai >= argc) break;

@@ -6,6 +6,10 @@ import sgl_kernel
 dev = "cuda"
 
 
+_probes = None
+if os.environ.get("QSERVE_CFGS"):  # diagnostic build only (LD_PRELOAD=.../build/libsglk_probes.so): forced stream configurations
+    import ctypes
+    _probes = ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so"))
 if os.environ.get("QSERVE_MF"):  # diagnostic build only (LD_PRELOAD=.../build/libsglk_probes.so)
     import ctypes
     ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
@@ -46,3 +50,17 @@ for N, K in ((4096, 4096), (14336, 4096)):
         ms2 = timeit(lambda: sgl_kernel.qserve_w4a8_per_group_gemm(a, w, z8, s8, ws, sa, out))
         print(f"N={N} K={K} M={M}: per_chn {ms*1e3:.1f} us {2.0*M*N*K/ms/1e9:.1f} TOP/s weights {N*K/2/ms/1e6:.0f} GB/s | "
               f"per_group {ms2*1e3:.1f} us {2.0*M*N*K/ms2/1e9:.1f} TOP/s")
+        if _probes is not None and M <= 64:
+            ref_c = torch.empty_like(out); ref_g = torch.empty_like(out)
+            sgl_kernel.qserve_w4a8_per_chn_gemm(a, w, ws, sa, wz, ssum, ref_c)
+            sgl_kernel.qserve_w4a8_per_group_gemm(a, w, z8, s8, ws, sa, ref_g)
+            for cfg in [int(c) for c in os.environ["QSERVE_CFGS"].split(",")]:
+                _probes.sglk_debug_set_qserve_cfg(cfg)
+                o1 = torch.empty_like(out); o2 = torch.empty_like(out)
+                sgl_kernel.qserve_w4a8_per_chn_gemm(a, w, ws, sa, wz, ssum, o1)
+                sgl_kernel.qserve_w4a8_per_group_gemm(a, w, z8, s8, ws, sa, o2)
+                same = bool(torch.equal(o1, ref_c)) and bool(torch.equal(o2, ref_g))
+                t1 = timeit(lambda: sgl_kernel.qserve_w4a8_per_chn_gemm(a, w, ws, sa, wz, ssum, out))
+                t2 = timeit(lambda: sgl_kernel.qserve_w4a8_per_group_gemm(a, w, z8, s8, ws, sa, out))
+                print(f"    cfg {cfg}: per_chn {t1*1e3:.1f} us | per_group {t2*1e3:.1f} us | bit-identical to the default path: {same}")
+                _probes.sglk_debug_set_qserve_cfg(0)
