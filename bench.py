@@ -35,8 +35,8 @@ PEAK_FP8_TFLOPS = 5000.0  # MI355X_MICROARCH.md: dense FP8 MFMA peak (MX K=128 f
 PEAK_HBM_GBS = 8000.0
 GEMM_KERNEL = ("gemm_fp8bw_x32_kernel<bf16> (ONE launch: per workgroup three 256-row tiles, then one 128-row half "
                "tile of the last partial round on a three-stage LDS ring)")
-PMC_FILE = os.path.join("profiles", "r04", "bench_pmc.json")
-MLA_PMC_FILE = os.path.join("profiles", "r04", "mla_pmc.json")
+PMC_FILE = os.path.join("profiles", "r05", "bench_pmc.json")
+MLA_PMC_FILE = os.path.join("profiles", "r05", "mla_pmc.json")
 CLOCK_RAMP_S = 0.15  # untimed steady-state run of the step before the W warm-up steps
 REPS = 3             # repetitions of the timed region (each: ramp, W warm-up steps, exactly K timed steps)
 BUILD_DIR = os.path.join(ROOT, "sgl-kernel-xpu_amd", "build")
@@ -72,7 +72,7 @@ def mla_pmc_traffic_bytes():
     try:
         with open(os.path.join(ROOT, MLA_PMC_FILE)) as f:
             pmc = json.load(f)
-        ks = [v for name, v in pmc.items() if name.startswith("mla_") or "mla_rows128x" in name or "mla_reduce" in name]
+        ks = [v for name, v in pmc.items() if name.startswith("mla_") or "mla_rows128" in name or "mla_reduce" in name]
         return int(sum(2 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"] for k in ks) * 1024) if ks else None
     except Exception:
         return None
@@ -123,6 +123,47 @@ def mfma_ceiling(dev):
             "frac_of_nominal": round(tflops / PEAK_FP8_TFLOPS, 4)}
 
 
+def mfma_ceiling_bf16(dev, waves):
+    """The same for the bf16 kernels: a register-only v_mfma_f32_32x32x16_bf16 stream on random operands, `waves` waves per
+    workgroup (4 = one per SIMD as flash_mla_decode's 128-row kernel, 8 = two as the prefill / MoE kernels), one workgroup
+    per CU, behind its own clock ramp; median of 20 launches. TFLOP/s, or None without the library."""
+    import ctypes
+
+    try:
+        lib = ctypes.CDLL(os.path.join(BUILD_DIR, "libsglk_ceiling.so"))
+        fn, flop = lib.sglk_bench_mfma_ceiling_bf16, lib.sglk_bench_mfma_ceiling_bf16_flop
+    except (OSError, AttributeError):
+        return None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    flop.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    flop.restype = ctypes.c_double
+    blocks = torch.cuda.get_device_properties(dev).multi_processor_count
+    iters = 3000 if waves == 4 else 1500  # ~0.2 - 0.3 ms per launch
+    g = torch.Generator(device="cpu").manual_seed(9)
+    src = torch.randint(0, 2 ** 31 - 1, (16384,), generator=g, dtype=torch.int32).to(dev)
+    dst = torch.empty(blocks * 512, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        rc = fn(stream, src.data_ptr(), dst.data_ptr(), blocks, waves, iters)
+        if rc:
+            raise RuntimeError("bf16 mfma ceiling launch failed: %d" % rc)
+
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < CLOCK_RAMP_S:
+        for _ in range(50):
+            run()
+        torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b_ in ev:
+        a.record()
+        run()
+        b_.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
+    return round(flop(blocks, waves, iters) / (ms[len(ms) // 2] * 1e-3) / 1e12, 1)
+
+
 def gemm_clock(q, b, s, sb, dev):
     """Median shader clock (MHz) and shader cycles per K block of the whole-tile phase of the GEMM, from the stamps the
     workgroups of the DIAGNOSTIC build of the library write (build/libsglk_probes.so, build.py --probes; the release
@@ -152,6 +193,9 @@ def gemm_clock(q, b, s, sb, dev):
         for _ in range(50):
             run()
         torch.cuda.synchronize()
+    # (a workgroup writes its whole-tile record at index blockIdx.x and its half-tile record at blockIdx.x + 256: the grid is
+    #  one workgroup per CU, at most 256 on this part - sized for that, and checked)
+    assert torch.cuda.get_device_properties(dev).multi_processor_count <= 256, "stamp buffer is sized for <= 256 workgroups"
     buf = torch.zeros(512 * 4, dtype=torch.int32, device=dev)
     arm(buf.data_ptr())
     try:
@@ -217,6 +261,7 @@ def cpu_baseline(seconds_budget=20.0):
 def side_metrics(sgl_kernel, dev):
     """HBM-bound companions of the path (BASELINE configs[0] shapes), reported as extra evidence."""
     out = {}
+    eager_legs = []  # (timing mode is kept apart from the metrics: legs whose graph capture failed are listed at the end)
 
     def timeit(fn, iters=30):
         """Device time per call: `iters` calls captured into ONE HIP graph and one replay of it timed with events (the
@@ -240,7 +285,6 @@ def side_metrics(sgl_kernel, dev):
             graph.replay()
             en.record()
             torch.cuda.synchronize()
-            out["_timing"] = "device time per call: N calls in one HIP graph, one replay timed"
             del graph
             return st.elapsed_time(en) / iters
         except Exception:
@@ -250,7 +294,7 @@ def side_metrics(sgl_kernel, dev):
             fn()
         en.record()
         torch.cuda.synchronize()
-        out["_timing"] = "eager loop (graph capture failed)"
+        eager_legs.append(len(out))
         return st.elapsed_time(en) / iters
 
     x = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
@@ -417,6 +461,16 @@ def side_metrics(sgl_kernel, dev):
     out["fwd_prefill_causal_bs16_h32_kv8_d64_seq4096_TFLOPs"] = round(4.0 * bs * hq * 64 * seq * seq / 2 / ms / 1e9, 1)
     out["fwd_prefill_causal_bs16_h32_kv8_d64_seq4096_ms"] = round(ms, 4)
     del kc64, vc64, qp64
+    # prefill at head dim 256 (Gemma; reference instantiation FMHAPrefillXe20.cmake:30-54), 16 q heads / 8 kv heads: still on the
+    # general 16-row kernel (the 128-row-block kernel's LDS images are built for d <= 128) - reported so that the gap shows
+    kc256 = torch.randn(n_pages, page, hk, 256, device=dev, dtype=torch.bfloat16)
+    vc256 = torch.randn(n_pages, page, hk, 256, device=dev, dtype=torch.bfloat16)
+    qp256 = torch.randn(bs * seq, 16, 256, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: flash_attn_with_kvcache(qp256, kc256, vc256, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                max_seqlen_q=seq, causal=True), iters=5)
+    out["fwd_prefill_causal_bs16_h16_kv8_d256_seq4096_TFLOPs"] = round(4.0 * bs * 16 * 256 * seq * seq / 2 / ms / 1e9, 1)
+    out["fwd_prefill_causal_bs16_h16_kv8_d256_seq4096_ms"] = round(ms, 4)
+    del kc256, vc256, qp256
     # decode at the other head dims / an fp8 KV cache the reference instantiates (FMHADecodeXe20.cmake:13-16, :62-111)
     for dd, kvdt in ((64, torch.bfloat16), (256, torch.bfloat16), (128, FP8)):
         npg = bs * seq // page
@@ -480,10 +534,12 @@ def side_metrics(sgl_kernel, dev):
         ms = timeit(lambda: sgl_kernel.fused_experts(xx, w1, w2, tw, ti, use_mxfp4_w4a16=True, w1_scale=s1m, w2_scale=s2m),
                     iters=40 if T <= 256 else 8)
         out[f"fused_experts_mxfp4_mixtral_T{T}_ms"] = round(ms, 4)
+    out["timing"] = ("device time per call: N calls in one HIP graph, one replay timed"
+                     + ("; graph capture failed, eager loop timed instead, for %d leg(s)" % len(eager_legs) if eager_legs else ""))
     return out
 
 
-def roofline_extra(ex):
+def roofline_extra(ex, bf16_ceiling=None):
     """Fraction of the bounding roofline per extra leg (MI355X_MICROARCH.md peaks: HBM 8 TB/s, bf16 MFMA 2.5 PFLOP/s,
     fp8 / int8 MFMA 5 P): {leg: {"bound", "achieved", "peak", "unit", "frac"}}. Latency-bound legs (routing) carry no
     fraction."""
@@ -491,6 +547,11 @@ def roofline_extra(ex):
 
     def put(leg, bound, achieved, peak, unit):
         out[leg] = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": round(achieved / peak, 4)}
+        if bound == "mfma" and peak == 2500.0 and bf16_ceiling:
+            # next to the nominal peak: the same-run register-only bf16 MFMA stream at two waves per SIMD (what the matrix
+            # pipes deliver on this device at the clock it holds under them)
+            out[leg]["ceiling_measured"] = bf16_ceiling
+            out[leg]["frac_of_ceiling_measured"] = round(achieved / bf16_ceiling, 4)
 
     for k, v in ex.items():
         if k.endswith("_GBs") and "weight" not in k and "fp8_blockwise_gemm" not in k:
@@ -635,9 +696,8 @@ def mla_roofline(sgl_kernel, dev, heads=128):
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b_) for a, b_ in ev)
     avg_eager = sum(ms) / len(ms)
-    # The op is two launches (the 2-us kernel that zeroes the merge counters, then the decode kernel): timed eagerly the pair
-    # carries the host's launch gap. Device time per call = `iters` calls captured in ONE HIP graph, median of five replays
-    # (events on the launch stream); the eager per-call average is reported next to it.
+    # Device time per call = `iters` calls captured in ONE HIP graph, median of five replays (events on the launch stream: an
+    # eager loop of 0.3-ms calls still carries the host's launch gaps); the eager per-call average is reported next to it.
     avg, how = avg_eager, "eager: HIP events around every call"
     try:
         graph = torch.cuda.CUDAGraph()
@@ -665,7 +725,7 @@ def mla_roofline(sgl_kernel, dev, heads=128):
     nbytes = qq.numel() * 2 + cache.numel() * 2 + table.numel() * 4 + seq_lens.numel() * 4 + bs * heads * 512 * 2
     return {
         "bound": "hbm",
-        "kernel": "mla_rows128x_kernel<bf16> (32x32x16 MFMA, row per lane; the split merge inside the kernel, + a counter-zeroing launch)" if heads > 64 else "mla_decode_kernel<bf16> (+ mla_reduce_kernel)",
+        "kernel": "mla_rows128z_kernel<bf16> (32x32x16 MFMA, row per lane; the split merge inside the kernel, ONE launch)" if heads > 64 else "mla_decode_kernel<bf16> (+ mla_reduce_kernel)",
         "workload": f"flash_mla_decode bs={bs} seq={seq} heads={heads} kv_lora=512 rope=64 page={page} bf16",
         "achieved": round(nbytes / avg / 1e6, 1),
         "peak": PEAK_HBM_GBS,
@@ -673,6 +733,7 @@ def mla_roofline(sgl_kernel, dev, heads=128):
         "frac": round(nbytes / avg / 1e6 / PEAK_HBM_GBS, 4),
         "bytes": nbytes,
         "traffic": mla_pmc_traffic_bytes(),
+        "traffic_source": MLA_PMC_FILE + " (rocprofv3 PMC passes of this round's kernel, not this run)",
         "kernel_ms_avg": round(avg, 4),
         "timing": how,
         "eager_ms_avg": round(avg_eager, 4),
@@ -797,6 +858,7 @@ def main(argv=None):
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP8_TFLOPS, 4),
             "traffic": pmc_traffic_bytes(),
+            "traffic_source": PMC_FILE + " (rocprofv3 PMC passes of this round's kernel, not this run)",
             "kernel_ms_avg": round(gemm_avg_ms, 4),          # median over the repetitions of the per-repetition mean
             "kernel_ms_median": round(gemm_med_ms, 4),
             "kernel_ms_min": round(gemm_min_ms, 4),
@@ -804,6 +866,7 @@ def main(argv=None):
             # same process, same device: what a register-only stream of the GEMM's own MFMA reaches on random operands -
             # the clock the part holds under full matrix load sets it, not the nominal 2.4 GHz
             "ceiling_measured": ceiling,
+            "ceiling_tflops": ceiling and ceiling["tflops"],  # (scalar copy: nested objects do not survive every log)
             "frac_of_ceiling_measured": ceiling and round(achieved / ceiling["tflops"], 4),
             # the kernel's own s_memtime / s_memrealtime stamps (DIAGNOSTIC build of the library, untimed launches after
             # the timed region): the shader clock the part sustains under this kernel, and the matrix-pipe share of a
@@ -818,10 +881,22 @@ def main(argv=None):
         if world == 1:
             del x, b, sb, q, s
             # the "GB/s (flash decode)" half of the metric: its own roofline entry, measured in the same run
-            result["roofline_flash_decode"] = mla_roofline(sgl_kernel, dev)
+            fd = mla_roofline(sgl_kernel, dev)
+            # same-run bf16 matrix ceilings (register-only 32x32x16 streams): what the 128-row MLA kernel (one wave per SIMD)
+            # and the two-waves-per-SIMD kernels (fwd prefill, MoE tile pipeline) could reach on this device under load
+            c4, c8 = mfma_ceiling_bf16(dev, 4), mfma_ceiling_bf16(dev, 8)
+            fd["bf16_ceiling_tflops_1_wave_per_simd"] = c4
+            fd["frac_of_bf16_ceiling_measured"] = c4 and round(fd["tflops"] / c4, 4)
+            result["roofline_flash_decode"] = fd
+            # scalar copies at the top level of `roofline` (the second half of the metric must survive a flattened log)
+            result["roofline"]["flash_decode_frac"] = fd["frac"]
+            result["roofline"]["flash_decode_GBs"] = fd["achieved"]
+            result["roofline"]["flash_decode_ms"] = fd["kernel_ms_avg"]
+            result["roofline"]["bf16_ceiling_tflops_1_wave_per_simd"] = c4
+            result["roofline"]["bf16_ceiling_tflops_2_waves_per_simd"] = c8
         if world == 1 and not args.no_extra:
             result["extra"] = side_metrics(sgl_kernel, dev)
-            result["roofline_extra"] = roofline_extra(result["extra"])
+            result["roofline_extra"] = roofline_extra(result["extra"], result["roofline"].get("bf16_ceiling_tflops_2_waves_per_simd"))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)

@@ -59,6 +59,12 @@ SGLK_API const char* sglk_last_error(void);
 /* Library version string, and the gfx arch the code objects were built for. */
 SGLK_API const char* sglk_version(void);
 SGLK_API const char* sglk_arch(void);
+/* ABI revision of this header. It is raised whenever an entry point changes its parameter list or a workspace its layout or
+ * size (5: sglk_moe_grouped_mm_w4a16_act takes row_map / src_rows; the flash_mla_decode workspace holds 16-byte merge
+ * counters and, above 64 heads, 128-row fragment slabs). A caller built against another revision must not call in: compare
+ * sglk_abi_version() with the SGLK_ABI_VERSION it was compiled with. */
+#define SGLK_ABI_VERSION 5
+SGLK_API int sglk_abi_version(void);
 
 /* Row addressing of a 2-D / 3-D last-dim-contiguous tensor:
  * offset(row) = (row / inner_size) * outer_stride + (row % inner_size) * inner_stride.

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Prefill kernel (head dims 64 / 128, 16-bit KV, no softcap; everything else of the contract above): the kernel above gives a
+// Prefill kernel (head dims 64 / 128, 16-bit KV; everything else of the contract above, softcap included): the kernel above gives a
 // wave 16 packed rows and 32-token tiles, so every K / V fragment it reads from LDS feeds one MFMA and every tile costs
 // a barrier per 16 MFMAs of a wave: 267 TFLOP/s on the causal 16 x 4096 Llama-3-8B prefill (0.11 of the bf16 MFMA
 // peak), LDS-read bound. Here a wave takes 32 packed rows and a tile is 64 tokens:
@@ -601,6 +601,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
   using M = Mfma<T>;
   using M32 = Mfma32<T>;
   constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, TILE_BYTES = kPTile * ROWB;
+  static_assert(D == 64 || D == 128, "the LDS images and the transposed V reads are built for rows of at most 256 bytes");
   constexpr int kPBlockM = 32 * MB * NW, NTH = 64 * NW;
   constexpr int CPR = D / 8, RPP = NTH / CPR, NCH = kPTile / RPP;  // 16-byte chunks per row, rows per pass, staging loads per thread
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][K tile, V tile]
@@ -926,6 +927,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
     if (next_tile && i + 2 < n_tiles) pg_next = fetch_pages(t + 2);
     PF_STAMP(2)
 
+    // ---- softcap (Gemma-2; round 5 - before, a capped prefill fell through to the general kernel): the raw score s becomes
+    // s'' = (cap / scale) tanh(s scale / cap), so that the weights below (y = s'' scale log2e - reference) need nothing else;
+    // tanh(x) = 1 - 2 / (exp(2 x) + 1) as one exp2, one rcp, two fmas per score (saturates correctly at +-inf). In front of the
+    // masks: a masked score must stay -inf.
+    if (p.softcap > 0.f) {  // (uniform)
+      const float c1 = 2.0f * sc2 / p.softcap, c2 = p.softcap / scale;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const float e0 = __builtin_amdgcn_exp2f(s0[mb][v] * c1), e1 = __builtin_amdgcn_exp2f(s1[mb][v] * c1);
+          s0[mb][v] = c2 - 2.0f * c2 * __builtin_amdgcn_rcpf(e0 + 1.0f);
+          s1[mb][v] = c2 - 2.0f * c2 * __builtin_amdgcn_rcpf(e1 + 1.0f);
+        }
+    }
     // ---- online softmax for row l31 of each block (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each 32-token block)
     bool interior = wave_rows_ok && (t * kPTile + kPTile <= seqlen_k);
     if (p.causal_right >= 0) interior = interior && (t * kPTile + kPTile - 1 <= wave_qabs_lo + p.causal_right);
@@ -1353,10 +1369,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
         const int blk = v_piece >> 4, ch = v_piece & 15;  // 128-dim column block, 16-byte chunk inside it
         *reinterpret_cast<v4i*>(vb + blk * (kTile * 256) + row * 256 + ((ch ^ sw_main(row)) << 4)) = vr.v[i];
       } else {  // 16 fp8 -> two chunks of 8 elements
-        const int blk = v_piece >> 3, ch = (v_piece & 7) * 2;
+        // (the eight lanes of a ds_write_b128 group hold pieces 0..7 of ONE row: written "even chunk, then odd chunk" they hit
+        //  chunks 0, 2, .., 14 - and chunks c, c + 8 share their 16 banks: SQ_LDS_BANK_CONFLICT 0.34 of the LDS cycles, round 4.
+        //  The upper four lanes of a group - pieces 4..7, or at d = 64 the next token's pieces 0..3, whose swizzle key has the
+        //  same parity - write their odd chunk first: every instruction covers all eight residues)
+        const int blk = v_piece >> 3, ch = (v_piece & 7) * 2, first = (lane >> 2) & 1;
         char* rowp = vb + blk * (kTile * 256) + row * 256;
-        *reinterpret_cast<v4i*>(rowp + ((ch ^ sw_main(row)) << 4)) = widen8(vr.v[i][0], vr.v[i][1]);
-        *reinterpret_cast<v4i*>(rowp + (((ch + 1) ^ sw_main(row)) << 4)) = widen8(vr.v[i][2], vr.v[i][3]);
+        const v4i w0 = widen8(vr.v[i][0], vr.v[i][1]), w1 = widen8(vr.v[i][2], vr.v[i][3]);
+        *reinterpret_cast<v4i*>(rowp + (((ch + first) ^ sw_main(row)) << 4)) = first ? w1 : w0;
+        *reinterpret_cast<v4i*>(rowp + (((ch + 1 - first) ^ sw_main(row)) << 4)) = first ? w0 : w1;
       }
     }
     issue_v(tile_of(j + 1), page_v, vr);
@@ -1696,7 +1717,10 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
   const int d = p.D;
   // prefill-sized problems at head dim 128 / 64 (Llama-3 / BASELINE configs[2]): the 128-row-block kernel. A row block must be
   // worth filling: at least 128 packed rows per (sequence, kv head) at the longest sequence.
-  if (kv8 == 0 && (d == 128 || d == 64) && p.splits == 1 && p.softcap <= 0.f && max_rows >= 128 && p.q_s0 % 8 == 0 &&
+  // (softcap - Gemma-2 - runs on this kernel since round 5. d = 256 does not yet: the LDS images and the transposed V reads are
+  //  built for 256-byte rows; instantiated at D = 256 the kernel compiles into the whole register file and computes garbage -
+  //  tests/test_attention_gpu.py::test_kvcache_paged caught it. It needs the decode kernel's 128-dim column blocks.)
+  if (kv8 == 0 && (d == 128 || d == 64) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 &&
       p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0)
     return d == 128 ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
                     : launch_prefill<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);

@@ -1099,7 +1099,7 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nkb = K / BK;  // >= 2
-  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 14);
+  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 15);
   // LDS stage of this phase: a rows [64 MS][128 B], b^T rows [256][128 B], 256 row scales (+ 1 KiB spare). Whole tiles: two
   // stages of 66 KiB. Half tiles: THREE stages of 50 KiB - with 1024 cycles of MFMAs per K block and the block's data
   // requested one block ahead, the half-tile loop ran at the latency of its LDS-DMA (2450 shader cycles per block,
@@ -1222,8 +1222,51 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
 
   // stores: lane (i, h) owns row wm * 32 MS + 32 mf + i, columns wn * 64 + 32 nf + 16 h .. + 15
   const uint32_t orow_off = (uint32_t)(((int64_t)(wm * (MS * 32) + li) * ldc + wn * 64 + lh * 8) * (int64_t)sizeof(OutT));
+  // Whole tiles (round 5): the rows leave through LDS. Stored as the lanes hold them, an instruction writes 32 bytes of each
+  // of 32 rows - a quarter of 32 different 128-byte lines, and a row-per-lane store is priced per line it touches (the MLA
+  // epilogue of this round: 58k -> 23k cycles when its instructions went from 32 rows to one contiguous KiB). Here 16 rows of
+  // the wave's 64 columns (16 x 128 B) are staged in the 18 KiB the two whole-tile stages leave of the kernel's LDS
+  // (2304 B per wave, row stride 144 B: the eight lanes of a ds_write_b128 group hit eight different bank quads) and read
+  // back a row per eight lanes: a store instruction then writes eight whole lines.
+  constexpr bool kStaged = MS == 4 && PROBE != 15 && sizeof(OutT) == 2;
   auto store_frag = [&](const TileDesc& d, const float (&accm)[2][16], int mf) {
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
+    if constexpr (kStaged) {
+      static_assert(2 * kStg + 8 * 2304 <= 3 * (kStageBytes - kTileBytes / 2), "the staging rows fit behind the two whole-tile stages");
+      // (addresses from a laundered lane id, formed here: the K loop has no register to carry them - 256 per wave, all taken)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int li2 = ln & 31, lh2 = ln >> 5;
+      const uint32_t stg_w = lds_base + (uint32_t)(2 * kStg + wave * 2304 + (li2 & 15) * 144 + lh2 * 16);
+      const uint32_t stg_r = lds_base + (uint32_t)(2 * kStg + wave * 2304 + (ln >> 3) * 144 + (ln & 7) * 16);
+      const uint32_t vo2 = (wn * 64 + (ln & 7) * 8 < d.ncols)
+                               ? (uint32_t)(((int64_t)(wm * (MS * 32) + (ln >> 3)) * ldc + wn * 64 + (ln & 7) * 8) * (int64_t)sizeof(OutT))
+                               : 0x80000000u;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+          for (int hv = 0; hv < 2; ++hv) {
+            Vec<OutT, 8> v;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (OutT)accm[nf][hv * 8 + c];
+            const v4i dq = __builtin_bit_cast(v4i, v);
+            if ((li2 >> 4) == half)  // (this half's sixteen rows: 32 lanes write their 16-byte piece)
+              asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(stg_w), "v"(dq), "n"(nf * 64 + hv * 32) : "memory");
+          }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+          v4i rr;
+          if (r2 == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rr) : "v"(stg_r) : "memory");
+          else asm volatile("ds_read_b128 %0, %1 offset:1152\n\ts_waitcnt lgkmcnt(0)" : "=v"(rr) : "v"(stg_r) : "memory");
+          const int soff2 = __builtin_amdgcn_readfirstlane((mf * 32 + half * 16 + r2 * 8) * (int)ldc * (int)sizeof(OutT));
+          __builtin_amdgcn_raw_buffer_store_b128(rr, ro, (int)vo2, soff2, 0);
+          asm volatile("s_nop 4" ::"v"(rr));  // (store data is read for a few cycles after issue)
+        }
+      }
+      return;
+    }
     const int soff = __builtin_amdgcn_readfirstlane(mf * 32 * (int)ldc * (int)sizeof(OutT));
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
@@ -1930,6 +1973,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 34: SGLK_GO_X32(12); break;                                                                       \
       case 35: SGLK_GO_X32(13); break;                                                                       \
       case 36: SGLK_GO_X32(14); break;                                                                       \
+      case 37: SGLK_GO_X32(15); break;  /* round 4's direct row-per-lane stores */                           \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \

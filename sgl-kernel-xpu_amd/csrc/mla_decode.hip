@@ -1028,8 +1028,12 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   // (the DMA instructions are asm text: an LDS-DMA the compiler can see makes it wait vmcnt(0) in front of the next LDS
   //  read it can see - any read may alias the DMA's LDS write - which would empty the ring once per tile)
   auto dma_s = [&](const char* sbase, uint32_t voff, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory", "m0");
+    if constexpr (kProbe == 7)  // (cache policy probe: non-temporal loads for a cache that is read once)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+                   : "memory", "m0");
+    else
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+                   : "memory", "m0");
   };
   struct TileSrc {
     const char* sA;  // rows 0..15 of the tile
@@ -1527,7 +1531,7 @@ static int launch_w(hipStream_t st, const MlaParams& p, int B, const void* q_nop
 }
 
 #ifdef SGLK_PROBES
-static int g_mla_variant = 0;  // kbench: 70 + probe = the tile loop with in-kernel stamps
+static int g_mla_variant = 0;  // kbench: 70 + probe = the tile loop with in-kernel stamps, 200 + probe = without (wall time)
 #endif
 template <typename T>
 static int launch_rows128x(hipStream_t st, const MlaParams& p, int B, const void* q_nope, const void* q_pe,
@@ -1550,20 +1554,11 @@ static int launch_rows128x(hipStream_t st, const MlaParams& p, int B, const void
     if (g_mla_variant == 74) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 4>), ldsz)
     if (g_mla_variant == 75) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 5>), ldsz)
     if (g_mla_variant == 76) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 6>), ldsz)
-    if (g_mla_variant == 170) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 5, 4>), ldsz)  // deeper fragment rings
-    if (g_mla_variant == 171) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 5, 6>), ldsz)
-    if (g_mla_variant == 172) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 3, 6>), ldsz)
-    if (g_mla_variant == 173) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 4, 5>), ldsz)
     if (g_mla_variant == 203) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 3>), ldsz)  // probes without stamps: wall time
     if (g_mla_variant == 204) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 4>), ldsz)
     if (g_mla_variant == 205) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 5>), ldsz)
     if (g_mla_variant == 206) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 6>), ldsz)
-    if (g_mla_variant == 270) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 5, 4>), ldsz)
-    if (g_mla_variant == 271) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 5, 6>), ldsz)
-    if (g_mla_variant == 272) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 3, 6>), ldsz)
-    if (g_mla_variant == 273) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 4, 5>), ldsz)
-    if (g_mla_variant == 274) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 6, 6>), ldsz)
-    if (g_mla_variant == 276) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 2, 3>), ldsz)
+    if (g_mla_variant == 207) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 7>), ldsz)
   }
 #endif
   SGLK_MLA_LAUNCH((mla_rows128z_kernel<T>), ldsz)

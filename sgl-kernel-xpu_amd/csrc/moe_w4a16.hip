@@ -878,7 +878,9 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   const bool narrow = !gated_epi && gp == 7 && K % 1024 == 0 && (est_row_blocks * cdiv(N, 128) <= 384 || g_w4_mt == 11);
   if (small) {
     // fewer workgroups than CUs even with 64-column tiles, long K: four waves split K (see moe_w4a16_ksplit_kernel)
-    const bool ksplit = fuse == 0 && (group_shift == 7 || fp4hw) && K % 2048 == 0 && ((K >= 8192 && avg <= 10 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
+    // (not with a row_map: the K-split kernel reads expert-contiguous rows - a mapped call with fused_act = 0 computed on the
+    //  wrong rows and read past the [src_rows, K] activations)
+    const bool ksplit = t_row_map == nullptr && fuse == 0 && (group_shift == 7 || fp4hw) && K % 2048 == 0 && ((K >= 8192 && avg <= 10 && est_row_blocks * cdiv(N, 64) <= 1024) || g_w4_mt == 12) && g_w4_mt != 11 && g_w4_mt != 1 && g_w4_mt != 13;
     if (ksplit) {
       const int64_t wgs = moe_tile_launch_size(total_m, E, 16, cdiv(N, 32));
       if (wgs < ((int64_t)1 << 31)) {

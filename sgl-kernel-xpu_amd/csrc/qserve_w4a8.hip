@@ -58,13 +58,21 @@ __device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b) {
 // (Measured and dropped: a wave-step of the four consecutive blocks of ONE 32-column group - 2 KiB contiguous, 128 deep, twice
 // the workgroups - needs two MFMAs per row set, each with half of the row slots zeroed, and four activation loads per step:
 // 11.3 against 7.8 us at N = 14336, K = 4096, one row.)
-template <bool GROUP, int MF, int KS, int KD, bool A16 = false>
+// Round 5 (17 - 64 rows were at 0.14 of HBM, 26 us for the 29 MB of a 14336 x 4096 layer):
+//   * the B operand as ONE 16-byte load per lane and m-tile instead of two 8-byte loads: lane p = 0 takes bytes 0..15 of the
+//     row's 32-byte k block, lane p = 1 (16 lanes on) bytes 16..31, and two v_permlane16_swap exchange the halves so that
+//     p = 0 holds {0..7, 16..23} and p = 1 {8..15, 24..31}, the k order of the A operand (26.1 -> 17.0 us at 64 rows);
+//   * separate ring depths: KD steps of weights (a wave's whole k range when it has at most eight steps: the weight stream
+//     is one round trip), KA steps of activations (L2-resident, 16 registers per step and m-tile group);
+//   * the K-split reduction and the stores are spread over all waves (each takes the output tiles t = wave, wave + KS, ..
+//     and adds the KS int32 partial sums, 16-byte LDS accesses) instead of wave 0 doing 448 ds_read_b32 and every store.
+template <bool GROUP, int MF, int KS, int KD, int KA, bool IL = true>
 __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
     f16* __restrict__ out, const int8_t* __restrict__ a, const uint8_t* __restrict__ w,
     const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales_i8, const f16* __restrict__ wscales,
     const f16* __restrict__ ascales, const f16* __restrict__ w_szs, const f16* __restrict__ a_ssums, int M, int N,
     int K, int64_t lda, int64_t ldc) {
-  typedef int v2i __attribute__((ext_vector_type(2)));
+  static_assert(KD % KA == 0, "the activation ring divides the weight ring");
   typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
   for (int mf = 0; mf < MF; ++mf) {
     int m = m0 + mf * 16 + j;
     m = m < M ? m : M - 1;
-    al[mf] = a + (int64_t)m * lda + q1 * 32 + (A16 ? p * 16 : p * 8);
+    al[mf] = a + (int64_t)m * lda + q1 * 32 + p * 16;
   }
   const int8_t* s8 = GROUP ? scales_i8 + n32c * 32 + c * 4 : nullptr;
   const int8_t* z8 = GROUP ? zeros + n32c * 32 + c * 4 : nullptr;
@@ -95,33 +103,38 @@ __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
   const int nks_all = K >> 6;
   const int nks = nks_all > wave ? (nks_all - wave + KS - 1) / KS : 0;  // this wave's steps ks = wave + KS i
   v4i wq_[KD][2];
-  v2i aq_[KD][MF][2];
+  v4i aq_[KA][MF];
   uint32_t sq_[KD][2];
-  auto load_step = [&](int i, v4i (&wd)[2], v2i (&af)[MF][2], uint32_t (&sz)[2]) {
+  auto step_of = [&](int i) {
     i = i < nks ? i : nks - 1;
     int ks = wave + KS * (i > 0 ? i : 0);
-    ks = ks < nks_all ? ks : nks_all - 1;  // (a wave without steps loads the last one; nothing is accumulated)
+    return ks < nks_all ? ks : nks_all - 1;  // (a wave without steps loads the last one; nothing is accumulated)
+  };
+  auto load_w = [&](int i, v4i (&wd)[2], uint32_t (&sz)[2]) {
+    const int ks = step_of(i);
     wd[0] = *reinterpret_cast<const v4i*>(wl + (int64_t)ks * 1024);
     wd[1] = *reinterpret_cast<const v4i*>(wl + (int64_t)ks * 1024 + 16);
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      if constexpr (A16) {  // one 16-byte load per lane: the lanes p = 0 / 1 of a row exchange halves in front of the MFMAs
-        const v4i t = *reinterpret_cast<const v4i*>(al[mf] + ks * 64);
-        af[mf][0] = (v2i){t[0], t[1]};
-        af[mf][1] = (v2i){t[2], t[3]};
-      } else {
-        af[mf][0] = *reinterpret_cast<const v2i*>(al[mf] + ks * 64);
-        af[mf][1] = *reinterpret_cast<const v2i*>(al[mf] + ks * 64 + 16);
-      }
-    }
     if constexpr (GROUP) {
       const int64_t g = ks >> 1;
       sz[0] = *reinterpret_cast<const uint32_t*>(s8 + g * N);
       sz[1] = *reinterpret_cast<const uint32_t*>(z8 + g * N);
     }
   };
+  auto load_a = [&](int i, v4i (&af)[MF]) {
+    const int ks = step_of(i);
 #pragma unroll
-  for (int d = 0; d < KD; ++d) load_step(d, wq_[d], aq_[d], sq_[d]);
+    for (int mf = 0; mf < MF; ++mf) af[mf] = *reinterpret_cast<const v4i*>(al[mf] + ks * 64);
+  };
+  // (a wave's loads return in issue order: the first steps' activations go out WITH their weights, not behind the whole ring)
+#pragma unroll
+  for (int d = 0; d < KD; ++d) {
+    load_w(d, wq_[d], sq_[d]);
+    if (IL && d < KA) load_a(d, aq_[d]);
+  }
+  if constexpr (!IL) {  // (probe: all weights first)
+#pragma unroll
+    for (int d = 0; d < KA; ++d) load_a(d, aq_[d]);
+  }
   for (int ks0 = 0; ks0 < nks; ks0 += KD) {
 #pragma unroll
     for (int u = 0; u < KD; ++u) {
@@ -158,67 +171,62 @@ __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
         }
         wop[t] = (v4i){(int)d4[0], (int)d4[1], (int)d4[2], (int)d4[3]};
       }
+      const int ua = u % KA;  // (u is an unrolled loop counter: a constant after unrolling)
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        if constexpr (A16) {
-          // lane p = 0 holds bytes 0..15 of the row's 32-byte k block, lane p = 1 (16 lanes on) bytes 16..31; the MFMA wants
-          // {0..7, 16..23} from p = 0 and {8..15, 24..31} from p = 1: v_permlane16_swap exchanges the odd 16-lane rows of its
-          // first operand (p = 1's low half) with the even rows of its second (p = 0's high half)
-          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
-                       : "+v"(aq_[u][mf][0][0]), "+v"(aq_[u][mf][0][1]), "+v"(aq_[u][mf][1][0]), "+v"(aq_[u][mf][1][1]));
-        }
-        const v4i bop = {aq_[u][mf][0][0], aq_[u][mf][0][1], aq_[u][mf][1][0], aq_[u][mf][1][1]};
+        // lanes p = 0 / 1 of a row exchange halves: v_permlane16_swap swaps the odd 16-lane rows of its first operand (p = 1's
+        // bytes 16..23) with the even rows of its second (p = 0's bytes 8..15)
+        v4i bop = aq_[ua][mf];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
+                     : "+v"(bop[0]), "+v"(bop[1]), "+v"(bop[2]), "+v"(bop[3]));
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[mf][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wop[t], bop, acc[mf][t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      load_step(ks0 + u + KD, wq_[u], aq_[u], sq_[u]);
+      load_w(ks0 + u + KD, wq_[u], sq_[u]);
+      load_a(ks0 + u + KA, aq_[ua]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 
+  // ---- K-split reduction (int32: exact in any order) and epilogue, spread over the waves: output tile ti = 4 mf + t goes to
+  // wave ti % KS. Lane (column m = j of the m fragment; MFMA rows 4 kg + r = block kg / 2, byte row 4 (kg % 2) + r): weight row
+  // t of that block's 8 t + c, i.e. columns n = 32 (2 pair + kg / 2) + 8 t + 4 (kg % 2) + r, r = 0..3 consecutive.
+  extern __shared__ __attribute__((aligned(16))) int red[];  // [KS][MF * 4][64 lanes] x v4i
+  v4i* red4 = reinterpret_cast<v4i*>(red);
   if constexpr (KS > 1) {
-    // (dword r of a lane at stride 64: every LDS access is 64 consecutive dwords)
-    extern __shared__ int red[];  // [KS - 1][MF][4][4][64 lanes]
-    if (wave > 0) {
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) red[(((((wave - 1) * MF + mf) * 4 + t) * 4 + r) << 6) + lane] = acc[mf][t][r];
-    }
+      for (int t = 0; t < 4; ++t)
+        if ((mf * 4 + t) % KS != wave) red4[((wave * MF + mf) * 4 + t) * 64 + lane] = acc[mf][t];  // (the owner keeps its own)
     __syncthreads();
-    if (wave > 0) return;
-#pragma nounroll
-    for (int w2 = 0; w2 < KS - 1; ++w2) {
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mf][t][r] += red[((((w2 * MF + mf) * 4 + t) * 4 + r) << 6) + lane];
-        }
-    }
   }
-
-  // ---- epilogue: lane (column m = j of the m fragment; MFMA rows 4 kg + r = block kg / 2, byte row 4 (kg % 2) + r):
-  // weight row t of that block's 8 t + c, i.e. columns n = 32 (2 pair + kg / 2) + 8 t + 4 (kg % 2) + r, r = 0..3 consecutive
   const int nblk = pair * 2 + (kg >> 1);
   if (nblk * 32 >= N) return;
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
-    const int m = m0 + mf * 16 + j;
-    if (m >= M) continue;
-    const float sa = (float)ascales[m];
-    const float asum = GROUP ? 0.f : (float)a_ssums[m];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+      if ((mf * 4 + t) % KS != wave) continue;
+      v4i sum = acc[mf][t];
+      if constexpr (KS > 1) {
+#pragma unroll
+        for (int w2 = 0; w2 < KS; ++w2)
+          if (w2 != wave) {
+            const v4i o = red4[((w2 * MF + mf) * 4 + t) * 64 + lane];
+            sum[0] += o[0]; sum[1] += o[1]; sum[2] += o[2]; sum[3] += o[3];
+          }
+      }
+      const int m = m0 + mf * 16 + j;
+      if (m >= M) continue;
+      const float sa = (float)ascales[m];
+      const float asum = GROUP ? 0.f : (float)a_ssums[m];
       const int n = nblk * 32 + t * 8 + (kg & 1) * 4;
       Vec<f16, 4> o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = (float)acc[mf][t][r] * sa * (float)wscales[n + r];
+        float v = (float)sum[r] * sa * (float)wscales[n + r];
         if constexpr (!GROUP) v -= asum * (float)w_szs[n + r];
         o[r] = (f16)v;
       }
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void qserve_w4a8_tile_kernel(
 
 #ifdef SGLK_PROBES
 static int g_qserve_mf = 0;  // (diagnostic: cap on the m-tiles per workgroup of the decode stream kernel)
-static int g_qserve_cfg = 0; // (diagnostic: forced stream configuration 1000 mf + 100 log2(ks) + 10 kd + a16, e.g. 4341)
+static int g_qserve_cfg = 0; // (diagnostic: forced stream configuration 10000 mf + 1000 log2(ks) + 10 kd + ka)
 #else
 constexpr int g_qserve_mf = 0;
 constexpr int g_qserve_cfg = 0;
@@ -419,54 +427,61 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   // repeats from L2) when the launch would have under 256 workgroups - N = K = 4096, 64 rows: 24.9 us with 4 m-tiles on 64
   // workgroups, 16.8 with 2 on 128, 13.0 with 1 on 256; at N = 14336 one m-tile per workgroup is slower (30.0 against 26.2 us)
   int mf = M <= 16 ? 1 : M <= 32 ? 2 : 4;
-  while (mf > 1 && pairs * cdiv(M, 16 * mf) < 256) mf /= 2;
+  // (round 5, with the 16-byte activation loads: N = 14336 keeps four m-tiles on 224 workgroups - 14.8 us at 64 rows against 19 with
+  //  two m-tiles on 448; N = 4096 goes down to one m-tile on 256 workgroups - 8.8 against 14.0 us)
+  while (mf > 1 && pairs * cdiv(M, 16 * mf) < 192) mf /= 2;
   if (g_qserve_mf > 0 && g_qserve_mf < mf) mf = g_qserve_mf;
   int ks = 1;
   while (ks < (M <= 16 ? 16 : 8) && pairs * cdiv(M, 16 * mf) * ks < 1536 && (K >> 6) >= 8 * ks) ks *= 2;
   const bool deep = (K >> 6) / ks >= 8 && ks <= 8;  // (ring no deeper than a wave's steps)
-#define SGLK_GO_STREAM_A(MF, KS, KD, A16)                                                                        \
+#define SGLK_GO_STREAM(MF, KS, KD, KA) SGLK_GO_STREAM_IL(MF, KS, KD, KA, true)
+#define SGLK_GO_STREAM_IL(MF, KS, KD, KA, IL)                                                                    \
   {                                                                                                              \
-    constexpr int lds = (KS - 1) * MF * 4 * 64 * 16;                                                             \
+    constexpr int lds = KS > 1 ? KS * MF * 4 * 64 * 16 : 0;                                                      \
     static unsigned long long attr_done = 0;                                                                     \
     if (lds > 64 * 1024)                                                                                         \
-      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&qserve_w4a8_stream_kernel<GROUP, MF, KS, KD, A16>), lds, \
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&qserve_w4a8_stream_kernel<GROUP, MF, KS, KD, KA, IL>), lds, \
                                    &attr_done, "qserve_w4a8"))                                                   \
         return rc;                                                                                               \
-    qserve_w4a8_stream_kernel<GROUP, MF, KS, KD, A16><<<dim3((unsigned)pairs, (unsigned)cdiv(M, 16 * MF)), 64 * KS, lds, st>>>( \
+    qserve_w4a8_stream_kernel<GROUP, MF, KS, KD, KA, IL><<<dim3((unsigned)pairs, (unsigned)cdiv(M, 16 * MF)), 64 * KS, lds, st>>>( \
         (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,          \
         (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc); \
   }
-#define SGLK_GO_STREAM(MF, KS, KD) SGLK_GO_STREAM_A(MF, KS, KD, false)
-#define SGLK_GO_STREAM_KS(MF, KD)                                                                                \
+#define SGLK_GO_STREAM_KS(MF, KD, KA)                                                                            \
   {                                                                                                              \
-    if (ks == 1) SGLK_GO_STREAM(MF, 1, KD) else if (ks == 2) SGLK_GO_STREAM(MF, 2, KD) else if (ks == 4) SGLK_GO_STREAM(MF, 4, KD) \
-    else SGLK_GO_STREAM(MF, 8, KD)                                                                               \
+    if (ks == 1) SGLK_GO_STREAM(MF, 1, KD, KA) else if (ks == 2) SGLK_GO_STREAM(MF, 2, KD, KA)                   \
+    else if (ks == 4) SGLK_GO_STREAM(MF, 4, KD, KA) else SGLK_GO_STREAM(MF, 8, KD, KA)                           \
   }
 #ifdef SGLK_PROBES
-  if (g_qserve_cfg != 0 && M <= 64) {
+  if (g_qserve_cfg != 0 && M <= 64) {  // forced configuration: 10000 mf + 1000 log2(ks) + 10 kd + ka
     switch (g_qserve_cfg) {
-      case 4320: SGLK_GO_STREAM_A(4, 8, 2, false) break;
-      case 4321: SGLK_GO_STREAM_A(4, 8, 2, true) break;
-      case 4340: SGLK_GO_STREAM_A(4, 8, 4, false) break;
-      case 4341: SGLK_GO_STREAM_A(4, 8, 4, true) break;
-      case 4241: SGLK_GO_STREAM_A(4, 4, 4, true) break;
-      case 4281: SGLK_GO_STREAM_A(4, 4, 8, true) break;
-      case 2341: SGLK_GO_STREAM_A(2, 8, 4, true) break;
-      case 2381: SGLK_GO_STREAM_A(2, 8, 8, true) break;
-      case 2441: SGLK_GO_STREAM_A(2, 16, 4, true) break;
-      case 2340: SGLK_GO_STREAM_A(2, 8, 4, false) break;
-      case 1441: SGLK_GO_STREAM_A(1, 16, 4, true) break;
-      case 1381: SGLK_GO_STREAM_A(1, 8, 8, true) break;
-      default: break;
+      case 43082: SGLK_GO_STREAM(4, 8, 8, 2) break;
+      case 43042: SGLK_GO_STREAM(4, 8, 4, 2) break;
+      case 43022: SGLK_GO_STREAM(4, 8, 2, 2) break;
+      case 143022: SGLK_GO_STREAM_IL(4, 8, 2, 2, false) break;
+      case 123044: SGLK_GO_STREAM_IL(2, 8, 4, 4, false) break;
+      case 43084: SGLK_GO_STREAM(4, 8, 8, 4) break;
+      case 42082: SGLK_GO_STREAM(4, 4, 8, 2) break;
+      case 23084: SGLK_GO_STREAM(2, 8, 8, 4) break;
+      case 23044: SGLK_GO_STREAM(2, 8, 4, 4) break;
+      case 23082: SGLK_GO_STREAM(2, 8, 8, 2) break;
+      case 24044: SGLK_GO_STREAM(2, 16, 4, 4) break;
+      case 13088: SGLK_GO_STREAM(1, 8, 8, 8) break;
+      case 13084: SGLK_GO_STREAM(1, 8, 8, 4) break;
+      case 14044: SGLK_GO_STREAM(1, 16, 4, 4) break;
+      case 14042: SGLK_GO_STREAM(1, 16, 4, 2) break;
+      default: return SGLK_OK;
     }
     return check_launch("qserve_w4a8(cfg)");
   }
 #endif
   if (M <= 64) {
     if (mf == 1) {
-      if (ks == 16) SGLK_GO_STREAM(1, 16, 4) else if (deep) SGLK_GO_STREAM_KS(1, 8) else SGLK_GO_STREAM_KS(1, 4)
-    } else if (mf == 2) SGLK_GO_STREAM_KS(2, 4)
-    else SGLK_GO_STREAM_KS(4, 2)
+      // (ring depths from the round-5 sweep at N = 4096 / 14336, K = 4096, 1 - 64 rows: shallow activation rings win everywhere, a
+      //  weight ring over a wave's whole k range does not - 16.1 us at (4 m-tiles, 8 waves, 8, 2) against 14.8 at (4, 8, 2, 2))
+      if (ks == 16) SGLK_GO_STREAM(1, 16, 4, 2) else if (deep) SGLK_GO_STREAM_KS(1, 8, 4) else SGLK_GO_STREAM_KS(1, 4, 2)
+    } else if (mf == 2) SGLK_GO_STREAM_KS(2, 4, 4)
+    else SGLK_GO_STREAM_KS(4, 2, 2)
   } else if (M > kPersistRows && qserve_w4a8_persist(st, GROUP, out, a, w, zeros, scales_i8, wscales, ascales, w_szs, a_ssums, M, N, K,
                                                    lda, ldc)) {
   } else {
@@ -476,7 +491,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   }
 #undef SGLK_GO_STREAM_KS
 #undef SGLK_GO_STREAM
-#undef SGLK_GO_STREAM_A
+#undef SGLK_GO_STREAM_IL
   return check_launch(GROUP ? "qserve_w4a8_per_group_gemm" : "qserve_w4a8_per_chn_gemm");
 }
 
@@ -518,6 +533,9 @@ extern "C" int sglk_qserve_w4a8_per_group_gemm(sglk_stream_t stream, void* out, 
                                                int64_t ldc) {
   using namespace sglk;
   if (int rc = check("qserve_w4a8_per_group_gemm", out, in_feats, kernel, M, N, K, lda, ldc, 128)) return rc;
+  // (the decode kernel reads a lane's four group scales / zero terms as one dword)
+  SGLK_REQUIRE((uintptr_t)scales_i8 % 4 == 0 && (uintptr_t)zeros % 4 == 0,
+               "qserve_w4a8_per_group_gemm: scales_i8 and zeros must be 4-byte aligned");
   if (M == 0) return SGLK_OK;
   return launch<true>((hipStream_t)stream, out, in_feats, kernel, zeros, scales_i8, wscales, ascales, nullptr, nullptr, M, N,
                       K, lda, ldc);

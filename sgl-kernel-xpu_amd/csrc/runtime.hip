@@ -52,4 +52,5 @@ extern "C" {
 const char* sglk_last_error(void) { return sglk::g_err; }
 const char* sglk_version(void) { return "0.1.0"; }
 const char* sglk_arch(void) { return "gfx950"; }
+int sglk_abi_version(void) { return SGLK_ABI_VERSION; }
 }

@@ -37,6 +37,9 @@ def test_identity_and_error_reporting():
     lib.sglk_last_error.restype = ctypes.c_char_p
     assert lib.sglk_arch() == b"gfx950"
     assert re.match(rb"\d+\.\d+\.\d+", lib.sglk_version())
+    # the ABI revision the library was built with is the one the header declares
+    m = re.search(r"#define SGLK_ABI_VERSION (\d+)", open(HEADER).read())
+    assert m and lib.sglk_abi_version() == int(m.group(1))
     # bad arguments are rejected before any device work: K not a multiple of 128
     i64 = ctypes.c_int64
     rc = lib.sglk_fp8_blockwise_scaled_mm(None, None, None, None, None, None, i64(4), i64(128), i64(100),

@@ -282,6 +282,36 @@ def test_moe_grouped_mm_w4a16_row_map_is_the_gather(sglk, dev, dtype, act_type, 
         op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25, row_map[:-1])
 
 
+@pytest.mark.parametrize("fmt", ["int4", "int4_zp", "mxfp4"])
+def test_moe_grouped_mm_w4a16_row_map_without_activation_on_the_k_split_shape(sglk, dev, fmt):
+    """fused_act = 0 with a row_map at the shape the K-split kernel takes (few rows per expert, K = 8192, groups of 128): that
+    kernel reads expert-contiguous rows, so a mapped call must not be routed to it (round 4 did: wrong rows, reads past the
+    [src_rows, K] activations). The mapped call equals the plain call on the gathered rows bit for bit."""
+    dtype, rows, N, K, tokens = torch.bfloat16, [3, 0, 5, 1, 2, 0, 4, 1], 256, 8192, 6
+    g = torch.Generator().manual_seed(77)
+    E, total = len(rows), sum(rows)
+    x = (torch.randn(tokens, K, generator=g) * 0.1).to(dtype).to(dev)
+    row_map = torch.randint(0, tokens, (total,), generator=g, dtype=torch.int32).to(dev)
+    if fmt == "mxfp4":
+        packed = torch.randint(0, 256, (E, N, K // 2), generator=g, dtype=torch.uint8)
+        scales, zeros, gs, is_int4 = torch.randint(118, 126, (E, N, K // 32), generator=g, dtype=torch.uint8), None, 32, False
+    else:
+        gs, is_int4 = 128, True
+        packed, scales, zeros = make_int4(E, N, K, gs, dtype, fmt == "int4_zp", g)
+        packed = packed.view(torch.int8 if fmt == "int4_zp" else torch.uint8)
+    d = lambda t: t.to(dev) if t is not None else None
+    rows_t = torch.tensor(rows, dtype=torch.int32, device=dev)
+    mapped = torch.full((total, N), float("nan"), dtype=dtype, device=dev)
+    plain = torch.full((total, N), float("nan"), dtype=dtype, device=dev)
+    op = torch.ops.sgl_kernel.moe_grouped_mm_nt_w4a16_act
+    op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), None, rows_t, E, is_int4, gs, 0, 0.0, row_map)
+    gathered = x[row_map.long()].contiguous()
+    op(plain, gathered, packed.to(dev), scales.to(dev), d(zeros), None, rows_t, E, is_int4, gs, 0, 0.0)
+    assert torch.isfinite(mapped.float()).all()
+    # (the plain call may run on the K-split kernel, whose four waves add their K quarters in another order: tolerance there)
+    torch.testing.assert_close(mapped.float(), plain.float(), rtol=2e-2, atol=2e-2)
+
+
 def test_fused_experts_swiglu_limit(sglk, dev):
     """DeepSeek-V4 clamp (reference moe.py:699-709, tests/test_fused_experts_mxfp4_dsv4_shapes.py:59-61): with a limit no
     pre-activation reaches, the clamped layer equals the plain silu layer bit for bit; with inputs scaled up it equals the

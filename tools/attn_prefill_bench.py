@@ -13,7 +13,7 @@ if os.environ.get("ATTN_PREFILL_WAVES"):
     import ctypes
     ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
                 ).sglk_debug_set_attn_prefill_waves(int(os.environ["ATTN_PREFILL_WAVES"]))
-ONLY = os.environ.get("ATTN_PREFILL_ONLY")  # "128": the d = 128 causal leg alone
+ONLY = os.environ.get("ATTN_PREFILL_ONLY")  # "128" / "64" / "256" / "chunk" / "softcap": that leg alone (one rocprofv3 run per shape)
 bs, hq, hk, seq, page = 16, 32, 8, 4096, 64
 n_pages = bs * seq // page
 pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, seq // page)
@@ -23,15 +23,21 @@ def timeit(f, warm, it):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(it): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / it * 1e3
-for d in ((128,) if ONLY == "128" else (128, 64)):
+for d in ((128,) if ONLY in ("128", "chunk", "softcap") else (64,) if ONLY == "64" else (256,) if ONLY == "256" else (128, 64, 256)):
+    hq = 16 if d == 256 else 32  # (d = 256: 16 q heads / 8 kv heads)
     kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
     vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
     qp = torch.randn(bs * seq, hq, d, device=dev, dtype=torch.bfloat16)
     cu = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * seq
-    ms = timeit(lambda: flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
-                                                max_seqlen_q=seq, causal=True), 5, 10)
-    print(f"prefill causal d={d}: {ms:.3f} ms  {4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9:.1f} TFLOP/s")
-    if d == 128 and ONLY is None:
+    if ONLY not in ("chunk", "softcap"):
+        ms = timeit(lambda: flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                    max_seqlen_q=seq, causal=True), 5, 10)
+        print(f"prefill causal d={d}: {ms:.3f} ms  {4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9:.1f} TFLOP/s")
+    if d == 128 and ONLY in (None, "softcap"):
+        ms = timeit(lambda: flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                    max_seqlen_q=seq, causal=True, softcap=50.0), 5, 10)
+        print(f"prefill causal d={d} softcap 50: {ms:.3f} ms  {4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9:.1f} TFLOP/s")
+    if d == 128 and ONLY in (None, "chunk"):
         qc = torch.randn(bs * 128, hq, d, device=dev, dtype=torch.bfloat16)
         cuc = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * 128
         ms = timeit(lambda: flash_attn_with_kvcache(qc, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cuc,

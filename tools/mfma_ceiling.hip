@@ -41,3 +41,39 @@ extern "C" __attribute__((visibility("default"))) int sglk_bench_mfma_ceiling(vo
 extern "C" __attribute__((visibility("default"))) double sglk_bench_mfma_ceiling_flop(int blocks, int iters) {
   return (double)blocks * 8.0 * 8.0 * iters * 2.0 * 32 * 32 * 64;
 }
+
+// The same for the bf16 kernels (flash_mla_decode, fwd prefill, the MoE tile pipeline): v_mfma_f32_32x32x16_bf16 on random
+// bf16 operands (exponent bits masked so that nothing is NaN / Inf), `waves` waves per workgroup (4 = one per SIMD as in
+// mla_rows128z_kernel, 8 = two as in the prefill / MoE kernels), one workgroup per CU.
+typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void mfma_ceiling_bf16_kernel(const int* __restrict__ src, float* __restrict__ dst, int iters) {
+  v4i_t a[4], b[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      a[i][j] = src[(threadIdx.x * 4 + j + i * 4096) & 16383] & 0xBFFFBFFF;
+      b[i][j] = src[(threadIdx.x * 4 + j + i * 4096 + 777) & 16383] & 0xBFFFBFFF;
+    }
+  v16f_t acc[4] = {};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf_t, b[n]),
+                                                         __builtin_bit_cast(v8bf_t, a[u + 2 * (it & 1)]), acc[n], 0, 0, 0);
+  }
+  float s = 0;
+  for (int n = 0; n < 4; ++n)
+    for (int r = 0; r < 16; ++r) s += acc[n][r];
+  dst[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+extern "C" __attribute__((visibility("default"))) int sglk_bench_mfma_ceiling_bf16(void* stream, const void* src, void* dst,
+                                                                                   int blocks, int waves, int iters) {
+  mfma_ceiling_bf16_kernel<<<blocks, 64 * waves, 0, (hipStream_t)stream>>>((const int*)src, (float*)dst, iters);
+  return (int)hipGetLastError();
+}
+// waves x 8 MFMAs per iteration x 2 * 32 * 32 * 16 FLOP
+extern "C" __attribute__((visibility("default"))) double sglk_bench_mfma_ceiling_bf16_flop(int blocks, int waves, int iters) {
+  return (double)blocks * waves * 8.0 * iters * 2.0 * 32 * 32 * 16;
+}
