@@ -461,8 +461,8 @@ def side_metrics(sgl_kernel, dev):
     out["fwd_prefill_causal_bs16_h32_kv8_d64_seq4096_TFLOPs"] = round(4.0 * bs * hq * 64 * seq * seq / 2 / ms / 1e9, 1)
     out["fwd_prefill_causal_bs16_h32_kv8_d64_seq4096_ms"] = round(ms, 4)
     del kc64, vc64, qp64
-    # prefill at head dim 256 (Gemma; reference instantiation FMHAPrefillXe20.cmake:30-54), 16 q heads / 8 kv heads: still on the
-    # general 16-row kernel (the 128-row-block kernel's LDS images are built for d <= 128) - reported so that the gap shows
+    # prefill at head dim 256 (Gemma; reference instantiation FMHAPrefillXe20.cmake:30-54), 16 q heads / 8 kv heads: on the
+    # 128-row-block kernel since round 5 (before: the general 16-row kernel, 192 TFLOP/s)
     kc256 = torch.randn(n_pages, page, hk, 256, device=dev, dtype=torch.bfloat16)
     vc256 = torch.randn(n_pages, page, hk, 256, device=dev, dtype=torch.bfloat16)
     qp256 = torch.randn(bs * seq, 16, 256, device=dev, dtype=torch.bfloat16)

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p, const T* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Prefill kernel (head dims 64 / 128, 16-bit KV; everything else of the contract above, softcap included): the kernel above gives a
+// Prefill kernel (head dims 64 / 128 / 256, 16-bit KV; everything else of the contract above, softcap included): the kernel above gives a
 // wave 16 packed rows and 32-token tiles, so every K / V fragment it reads from LDS feeds one MFMA and every tile costs
 // a barrier per 16 MFMAs of a wave: 267 TFLOP/s on the causal 16 x 4096 Llama-3-8B prefill (0.11 of the bf16 MFMA
 // peak), LDS-read bound. Here a wave takes 32 packed rows and a tile is 64 tokens:
@@ -594,14 +594,14 @@ struct Mfma32<f16> {
 // row, one staging load per thread, tile and operand; K chunk c of row r at c ^ ((r >> 1) & 7) (rows two apart share their
 // banks), V chunk c at c ^ (((r >> 1) & 1) << 2); 8 + 8 MFMAs per wave and tile against the same softmax work.
 template <typename T, int D, int NW, int MB>  // NW waves of MB 32-row blocks
-__global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
+__global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
                                                            const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                            const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
                                                            const int32_t* __restrict__ page_table) {
   using M = Mfma<T>;
   using M32 = Mfma32<T>;
   constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, TILE_BYTES = kPTile * ROWB;
-  static_assert(D == 64 || D == 128, "the LDS images and the transposed V reads are built for rows of at most 256 bytes");
+  static_assert(D == 64 || D == 128 || D == 256, "head dims with a power-of-two number of 16-byte chunks per row");
   constexpr int kPBlockM = 32 * MB * NW, NTH = 64 * NW;
   constexpr int CPR = D / 8, RPP = NTH / CPR, NCH = kPTile / RPP;  // 16-byte chunks per row, rows per pass, staging loads per thread
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][K tile, V tile]
@@ -727,9 +727,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
   // global 16-byte chunk of the lane for piece i of this wave (K: the key depends on the piece's rows; V: it does not)
   auto k_chunk = [&](int i) -> int {
     const int row = RP * (wave * PPW + i) + prow;
-    return pch ^ (D == 128 ? (row & 15) : ((row >> 1) & 7));
+    return pch ^ (D >= 128 ? (row & 15) : ((row >> 1) & 7));
   };
-  const int v_chunk = pch ^ (D == 128 ? ((prow & 3) << 2) : (((prow >> 1) & 1) << 2));
+  // (V: the key is (row & 3) << 2 - at d = 128 a piece is four rows and the key a lane constant; at d = 256 a piece is two rows
+  //  and the key depends on the piece's parity)
+  auto v_chunk = [&](int i) -> int {
+    const int row = RP * (wave * PPW + i) + prow;
+    return pch ^ (D >= 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2));
+  };
   // (fast tiles: the RP PPW consecutive rows a wave moves share their page, so one SGPR base serves the wave's pieces and the
   // piece's row offset rides in the lane offset)
   constexpr int WR = RP * PPW;  // rows of a tile moved by one wave
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     voff_k[i] = ((uint32_t)(RP * i + prow) * kst) * 2u + (uint32_t)(k_chunk(i) << 4);
-    voff_v[i] = ((uint32_t)(RP * i + prow) * vst) * 2u + (uint32_t)(v_chunk << 4);
+    voff_v[i] = ((uint32_t)(RP * i + prow) * vst) * 2u + (uint32_t)(v_chunk(i) << 4);
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)SGLK_LDS(smem);
   auto dma16 = [&](const char* src, uint32_t lds_dst) {  // per-lane 64-bit address
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
       const int64_t ko = (int64_t)((uint64_t)(uint32_t)pages.pg[i] * kpg + ((uint64_t)cp * kst + (uint64_t)kbase));
       const int64_t vo = (int64_t)((uint64_t)(uint32_t)pages.pg[i] * vpg + ((uint64_t)cp * vst + (uint64_t)vbase));
       dma16(kcache + ko * 2 + (k_chunk(i) << 4), kdst + i * 1024);
-      dma16(vcache + vo * 2 + (v_chunk << 4), vdst + i * 1024);
+      dma16(vcache + vo * 2 + (v_chunk(i) << 4), vdst + i * 1024);
     }
   };
 
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
 
   // ---- per-lane LDS read offsets
   // K (A operand of K . Q^T): token row 32 beta + l31, chunk 2 ks + u at position chunk ^ (row & 15)
-  const int krow_off = l31 * ROWB, kkey = D == 128 ? (l31 & 15) : ((l31 >> 1) & 7);  // (32 beta does not change the key)
+  const int krow_off = l31 * ROWB, kkey = D >= 128 ? (l31 & 15) : ((l31 >> 1) & 7);  // (32 beta does not change the key)
   // V^T (A operand of V^T . P^T) by transpose reads: 16 lanes fetch 4 tokens x 16 dims; lane -> (token qq, 4-dim quad pp)
   const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, hh = (lane >> 4) & 1;
   const int vlane_off = (4 * u + qq) * ROWB + 8 * (pp & 1);  // + token group offsets below; row & 3 == qq
@@ -998,11 +1003,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
           if (with_dma) asm volatile("" : "+v"(k0), "+v"(k1), "+v"(psum_a), "+v"(psum_b));
           pw[mb][st] = k0;
           pw[mb][8 + st] = k1;
-          constexpr int kEvery = 8 / (2 * PPW);
-          if (mb == 0 && with_dma && st % kEvery == kEvery - 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            spread_piece(sp, st / kEvery);
-            __builtin_amdgcn_sched_barrier(0);
+          constexpr int kNP = 2 * PPW;  // pieces of a tile per wave: 4 / 8 / 16 at d = 64 / 128 / 256, over the eight steps
+          if (mb == 0 && with_dma) {
+            if constexpr (kNP >= 8) {
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int q_ = 0; q_ < kNP / 8; ++q_) spread_piece(sp, st * (kNP / 8) + q_);
+              __builtin_amdgcn_sched_barrier(0);
+            } else if (st % (8 / kNP) == 8 / kNP - 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              spread_piece(sp, st / (8 / kNP));
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
       };
@@ -1059,7 +1071,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1) ? 2 : 1) void attn_pr
       v8s vf[kVA];
       auto read_v = [&](int m, v8s& dst) {
         const int s4 = m / DB, db = m % DB;
-        const int chunk = ((4 * db + vchunk_lo) ^ ((D == 128 ? qq : (qq >> 1)) << 2)) << 4;
+        const int chunk = ((4 * db + vchunk_lo) ^ ((D >= 128 ? qq : (qq >> 1)) << 2)) << 4;
         const char* a = vb + (32 * (s4 >> 1) + 16 * (s4 & 1)) * ROWB + vlane_off + chunk;
         const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a));
         const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a + 8 * ROWB));
@@ -1717,13 +1729,15 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
   const int d = p.D;
   // prefill-sized problems at head dim 128 / 64 (Llama-3 / BASELINE configs[2]): the 128-row-block kernel. A row block must be
   // worth filling: at least 128 packed rows per (sequence, kv head) at the longest sequence.
-  // (softcap - Gemma-2 - runs on this kernel since round 5. d = 256 does not yet: the LDS images and the transposed V reads are
-  //  built for 256-byte rows; instantiated at D = 256 the kernel compiles into the whole register file and computes garbage -
-  //  tests/test_attention_gpu.py::test_kvcache_paged caught it. It needs the decode kernel's 128-dim column blocks.)
-  if (kv8 == 0 && (d == 128 || d == 64) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 &&
+  // (softcap - Gemma-2 - and d = 256 - Gemma; reference instantiation FMHAPrefillXe20.cmake:30-54 - run on this kernel since
+  //  round 5; before, both fell through to the general 16-row kernel at ~0.08 - 0.11 of the bf16 peak. d = 256: 128 KiB of LDS and
+  //  the whole register file, one workgroup per CU; 512-byte rows keep the d = 128 swizzle keys - (row & 15) for K, (row & 3) << 2
+  //  for V - on the low bits of the 32 chunks of a row.)
+  if (kv8 == 0 && (d == 128 || d == 64 || d == 256) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 &&
       p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0)
-    return d == 128 ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
-                    : launch_prefill<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+    return d == 128  ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
+           : d == 64 ? launch_prefill<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
+                     : launch_prefill<T, 256>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
   // decode-sized problems at head dims 64 / 128 / 256 (16-bit or fp8 cache): every sequence has at most 16 packed rows per
   // kv head; a tile within one page
   if ((d == 64 || d == 128 || d == 256) && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) &&

@@ -1222,13 +1222,13 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
 
   // stores: lane (i, h) owns row wm * 32 MS + 32 mf + i, columns wn * 64 + 32 nf + 16 h .. + 15
   const uint32_t orow_off = (uint32_t)(((int64_t)(wm * (MS * 32) + li) * ldc + wn * 64 + lh * 8) * (int64_t)sizeof(OutT));
-  // Whole tiles (round 5): the rows leave through LDS. Stored as the lanes hold them, an instruction writes 32 bytes of each
-  // of 32 rows - a quarter of 32 different 128-byte lines, and a row-per-lane store is priced per line it touches (the MLA
-  // epilogue of this round: 58k -> 23k cycles when its instructions went from 32 rows to one contiguous KiB). Here 16 rows of
-  // the wave's 64 columns (16 x 128 B) are staged in the 18 KiB the two whole-tile stages leave of the kernel's LDS
-  // (2304 B per wave, row stride 144 B: the eight lanes of a ds_write_b128 group hit eight different bank quads) and read
-  // back a row per eight lanes: a store instruction then writes eight whole lines.
-  constexpr bool kStaged = MS == 4 && PROBE != 15 && sizeof(OutT) == 2;
+  // (Round 5, measured and left as probe 15 / kbench variant 37: the rows of a whole tile staged through LDS - 16 rows of the
+  // wave's 64 columns in the 18 KiB the two whole-tile stages leave free, row stride 144 B, read back a row per eight lanes - so
+  // that a store instruction writes eight whole 128-byte lines instead of a quarter of 32. The MLA epilogue of this round gained
+  // 2.5x from that change; here it is a wash - 0.2395 against 0.2396 ms at (4096, 14336, 4096), 0.5026 / 0.5046 at 8192^3,
+  // interleaved on one box - the stores ride under the next tile's MFMAs either way, and the staged form costs the prologues
+  // three spilled registers. The release kernel keeps the direct stores.)
+  constexpr bool kStaged = MS == 4 && PROBE == 15 && sizeof(OutT) == 2;
   auto store_frag = [&](const TileDesc& d, const float (&accm)[2][16], int mf) {
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(d.po, d.nrec_o);
     if constexpr (kStaged) {
@@ -1973,7 +1973,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 34: SGLK_GO_X32(12); break;                                                                       \
       case 35: SGLK_GO_X32(13); break;                                                                       \
       case 36: SGLK_GO_X32(14); break;                                                                       \
-      case 37: SGLK_GO_X32(15); break;  /* round 4's direct row-per-lane stores */                           \
+      case 37: SGLK_GO_X32(15); break;  /* whole-tile stores staged through LDS */                             \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
