@@ -155,7 +155,7 @@ def check_isa(verbose=True):
     else:
         text = open(path).read()
         n = 0
-        for name, body in _functions(text, r"(gemm_8bit_persist_kernelI|gemm_fp8bw_x32_kernelI)"):
+        for name, body in _functions(text, r"(gemm_8bit_persist2?_kernelI|gemm_fp8bw_x32_kernelI)"):
             n += 1
             # A scratch access is vector-memory traffic: inside a K loop it sits in the hand-counted vmcnt window (the waits
             # stay safe - "all but the N youngest" only ever waits for more - but every block then drains what it should

@@ -434,9 +434,12 @@ struct TileDesc {
 // MFMAs of a tile chain into its accumulators (int8: two K = 64 MFMAs per fragment pair), no promotion FMAs, no scale
 // DMA; the first K block of the next tile fetches the finished tile's row scales, column scales and bias at its top and
 // applies them in the stores (the oracle's rounding order). Requires sb and bias 16-byte aligned as well.
+// (a PHASE of a kernel: the units of one kind - MS = 8 whole tiles or MS = 4 half tiles - of this workgroup, prologue to final
+//  stores and drain; smem = the workgroup's kStages * kStageBytes of LDS. The kernels below run one phase, or - round 5 - the whole
+//  tiles and then the half tiles of the last partial round in ONE launch, as gemm_fp8bw_x32_kernel does since round 4.)
 template <typename OutT, int MODE, bool HW_SCALE, int PROBE, int MS>  // MS m-steps per K block: 8 = 256-row tiles, 4 = 128-row half tiles
-__global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
-    OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+__device__ __forceinline__ void gemm_8bit_persist_phase(
+    char* smem, OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
     int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m,
     int tiles_n, int all_halves, uint32_t* __restrict__ stamps, const void* __restrict__ x0,
@@ -445,7 +448,6 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
   constexpr bool kW4 = MODE == MODE_W4A8_CHN || MODE == MODE_W4A8_GRP, kGrp = MODE == MODE_W4A8_GRP;
   constexpr bool kI8 = MODE == MODE_INT8_ROWCOL || kW4;
   using AccT = typename std::conditional<kI8, v4i, v4f>::type;
-  __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1066,6 +1068,38 @@ __global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
 #undef SGLK_RD4
 #undef SGLK_RDW
 #undef SGLK_FRAG
+}
+
+template <typename OutT, int MODE, bool HW_SCALE, int PROBE, int MS>
+__global__ __launch_bounds__(512) void gemm_8bit_persist_kernel(
+    OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+    const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
+    int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m,
+    int tiles_n, int all_halves, uint32_t* __restrict__ stamps, const void* __restrict__ x0,
+    const void* __restrict__ x1) {
+  __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
+  gemm_8bit_persist_phase<OutT, MODE, HW_SCALE, PROBE, MS>(smem, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, sa_sm, sa_sk,
+                                                             sb_sk, sb_sn, tiles_m, tiles_n, all_halves, stamps, x0, x1);
+}
+
+// ONE launch for a problem whose last round of 256-row tiles is only partly filled (round 5; the fp8 block-scale kernel has
+// run this way since round 4: one launch instead of a launch of whole tiles, a pipeline drain and a second launch of half
+// tiles): a persistent workgroup runs its whole tiles (MS = 8), then - when its XCD's last round fits twice - one 128-row
+// half tile of that round (MS = 4). Used by fp8_scaled_mm, int8_scaled_mm and the QServe W4A8 modes.
+template <typename OutT, int MODE, bool HW_SCALE, int PROBE>
+__global__ __launch_bounds__(512) void gemm_8bit_persist2_kernel(
+    OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+    const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
+    int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m,
+    int tiles_n, uint32_t* __restrict__ stamps, const void* __restrict__ x0, const void* __restrict__ x1) {
+  __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
+  gemm_8bit_persist_phase<OutT, MODE, HW_SCALE, PROBE, 8>(smem, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, sa_sm, sa_sk,
+                                                            sb_sk, sb_sn, tiles_m, tiles_n, 0, stamps, x0, x1);
+  // (the phase has drained its own LDS reads and DMA; no wave may start the next prologue's DMA while another still reads
+  //  the stages)
+  asm volatile("s_barrier" ::: "memory");
+  gemm_8bit_persist_phase<OutT, MODE, HW_SCALE, PROBE, 4>(smem, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, sa_sm, sa_sk,
+                                                            sb_sk, sb_sn, tiles_m, tiles_n, 0, stamps, x0, x1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1940,6 +1974,11 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
         (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
         ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 1, g_gemm_stamps, nullptr, nullptr);                                     \
   } else {                                                                                                   \
+    if (tail_halves && P == 0)                                                                               \
+      gemm_8bit_persist2_kernel<OutT, MODE, H, 0><<<pgrid, 512, 0, st>>>(                                    \
+          (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
+          ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, g_gemm_stamps, nullptr, nullptr);            \
+    else {                                                                                                   \
     gemm_8bit_persist_kernel<OutT, MODE, H, P, 8><<<pgrid, 512, 0, st>>>(                                 \
         (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
         ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps, nullptr, nullptr);                                     \
@@ -1947,6 +1986,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       gemm_8bit_persist_kernel<OutT, MODE, H, P, 4><<<pgrid, 512, 0, st>>>(                               \
           (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (const OutT*)bias, (int)M, (int)N, (int)K, lda, \
           ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n, 0, g_gemm_stamps, nullptr, nullptr);                                   \
+    }                                                                                                        \
   }
 // (blockwise: the 32 x 32 x 64 schedule; the 16 x 16 x 128 one stays for the row / column scale modes and as probe 22)
 #define SGLK_GO_X32(P)                                                                                       \
@@ -2057,9 +2097,13 @@ int qserve_w4a8_persist(hipStream_t st, bool group, void* out, const void* a, co
 #define SGLK_GO_W4M(MODE)                                                                                    \
   if (all_halves) {                                                                                          \
     SGLK_GO_W4(MODE, 4, hgrid, 1);                                                                           \
+  } else if (tail_halves) { /* whole tiles, then the half tiles of the last partial round: one launch (round 5) */ \
+    gemm_8bit_persist2_kernel<f16, MODE, true, 0><<<pgrid, 512, 0, st>>>(                                    \
+        (f16*)out, (const uint8_t*)a, (const uint8_t*)w, (const float*)ascales, (const float*)wscales,       \
+        (const f16*)w_szs, (int)M, (int)N, (int)K, lda, 0, ldc, 0, 0, 0, 0, tiles_m, tiles_n, nullptr,        \
+        group ? scales_i8 : a_ssums, zeros);                                                                 \
   } else {                                                                                                   \
     SGLK_GO_W4(MODE, 8, pgrid, 0);                                                                           \
-    if (tail_halves) SGLK_GO_W4(MODE, 4, pgrid, 0);                                                          \
   }
   if (group) {
     SGLK_GO_W4M(MODE_W4A8_GRP)
