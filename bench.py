@@ -461,6 +461,20 @@ def side_metrics(sgl_kernel, dev):
     out["fwd_prefill_causal_bs16_h32_kv8_d64_seq4096_TFLOPs"] = round(4.0 * bs * hq * 64 * seq * seq / 2 / ms / 1e9, 1)
     out["fwd_prefill_causal_bs16_h32_kv8_d64_seq4096_ms"] = round(ms, 4)
     del kc64, vc64, qp64
+    # the same d = 128 prefill with a softcap (Gemma-2) and over an fp8 e4m3 cache (reference tests/test_flash_attention.py:
+    # 1691-1704): both on the 128-row-block kernel since round 5
+    kcb = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+    vcb = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+    qpb = torch.randn(bs * seq, hq, d, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: flash_attn_with_kvcache(qpb, kcb, vcb, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                max_seqlen_q=seq, causal=True, softcap=50.0), iters=5)
+    out["fwd_prefill_causal_softcap_bs16_h32_kv8_d128_seq4096_TFLOPs"] = round(4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9, 1)
+    kc8, vc8, one = kcb.to(FP8), vcb.to(FP8), torch.ones(1, device=dev)
+    del kcb, vcb
+    ms = timeit(lambda: flash_attn_with_kvcache(qpb, kc8, vc8, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                max_seqlen_q=seq, causal=True, k_descale=one, v_descale=one), iters=5)
+    out["fwd_prefill_causal_fp8kv_bs16_h32_kv8_d128_seq4096_TFLOPs"] = round(4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9, 1)
+    del kc8, vc8, qpb
     # prefill at head dim 256 (Gemma; reference instantiation FMHAPrefillXe20.cmake:30-54), 16 q heads / 8 kv heads: on the
     # 128-row-block kernel since round 5 (before: the general 16-row kernel, 192 TFLOP/s)
     kc256 = torch.randn(n_pages, page, hk, 256, device=dev, dtype=torch.bfloat16)

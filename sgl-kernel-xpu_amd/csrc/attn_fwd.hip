@@ -593,7 +593,7 @@ struct Mfma32<f16> {
 // Head dim 64 (round 3; reference instantiations FMHAPrefillXe20.cmake): the same kernel with 128-byte LDS rows - 8 chunks per
 // row, one staging load per thread, tile and operand; K chunk c of row r at c ^ ((r >> 1) & 7) (rows two apart share their
 // banks), V chunk c at c ^ (((r >> 1) & 1) << 2); 8 + 8 MFMAs per wave and tile against the same softmax work.
-template <typename T, int D, int NW, int MB>  // NW waves of MB 32-row blocks
+template <typename T, int D, int NW, int MB, int KV8 = 0>  // NW waves of MB 32-row blocks; KV8: 0 16-bit cache, 1 e4m3, 2 e5m2
 __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
                                                            const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                            const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
@@ -817,6 +817,74 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
     else dma16s(voff_v[j - PPW], sp.vb, sp.kdst + 2 * TILE_BYTES + (j - PPW) * 1024);
   };
 
+  // ---- fp8 cache (round 5; reference tests/test_flash_attention.py:1691-1704 - before, an fp8 prefill ran on the general 16-row
+  // kernel): the LDS images stay 16-bit, so everything below the staging is unchanged. LDS-DMA cannot widen: a tile goes global ->
+  // registers (16 bytes = 16 elements per lane and load, a tile ahead) -> v_cvt_scalef32_pk_* -> two ds_write_b128 into the
+  // swizzled image behind the P . V phase. A wave stages rows 16 wave .. + 15 of K and of V. The K descale rides in the softmax
+  // scale, the V descale in the final normalisation (as in the decode kernel).
+  constexpr int C16 = D / 16;             // 16-byte pieces per fp8 row
+  constexpr int RPL = 64 / C16;           // rows per load instruction
+  constexpr int NL8 = KV8 ? 16 / RPL : 1; // loads per operand, wave and tile
+  struct Regs8 {
+    v4i k[NL8], v[NL8];
+  };
+  auto widen8 = [&](int lo, int hi) -> v4i {  // 8 bytes -> 8 elements of T (exact), unit scale
+    typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 v2h_ __attribute__((ext_vector_type(2)));
+    v4i r = {0, 0, 0, 0};
+    const int x[2] = {lo, hi};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if constexpr (std::is_same<T, bf16>::value && KV8 == 1) {
+        r[2 * h] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(x[h], 1.0f, false));
+        r[2 * h + 1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(x[h], 1.0f, true));
+      } else if constexpr (std::is_same<T, bf16>::value && KV8 == 2) {
+        r[2 * h] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(x[h], 1.0f, false));
+        r[2 * h + 1] = __builtin_bit_cast(int, (v2bf_)__builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(x[h], 1.0f, true));
+      } else if constexpr (KV8 == 1) {
+        r[2 * h] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x[h], 1.0f, false));
+        r[2 * h + 1] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_fp8(x[h], 1.0f, true));
+      } else if constexpr (KV8 == 2) {
+        r[2 * h] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(x[h], 1.0f, false));
+        r[2 * h + 1] = __builtin_bit_cast(int, (v2h_)__builtin_amdgcn_cvt_scalef32_pk_f16_bf8(x[h], 1.0f, true));
+      }
+    }
+    return r;
+  };
+  auto issue8 = [&](int t, Regs8& r) {
+#pragma unroll
+    for (int j = 0; j < NL8; ++j) {
+      int pos = t * kPTile + 16 * wave + RPL * j + lane / C16;
+      pos = pos < last_key ? pos : last_key;
+      const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
+      const uint32_t pg = (uint32_t)pg_src[(pos + pos_base) >> pos_shift];
+      const int64_t ko = (int64_t)((uint64_t)pg * kpg + ((uint64_t)cp * kst + (uint64_t)kbase));  // (fp8: elements = bytes)
+      const int64_t vo = (int64_t)((uint64_t)pg * vpg + ((uint64_t)cp * vst + (uint64_t)vbase));
+      r.k[j] = *reinterpret_cast<const v4i*>(kcache + ko + 16 * (lane % C16));
+      r.v[j] = *reinterpret_cast<const v4i*>(vcache + vo + 16 * (lane % C16));
+    }
+  };
+  auto write8 = [&](int buf, const Regs8& r) {
+    char* kbw = smem + buf * TILE_BYTES;
+    char* vbw = smem + (2 + buf) * TILE_BYTES;
+    // (the eight lanes of a ds_write_b128 group hold eight pieces of one row - or four of each of two rows whose keys have the
+    //  same parity: the upper four write their odd chunk first, so that every instruction covers all eight chunk residues)
+    const int first = (lane >> 2) & 1;
+#pragma unroll
+    for (int j = 0; j < NL8; ++j) {
+      const int row = 16 * wave + RPL * j + lane / C16, ch = 2 * (lane % C16);
+      const int kk = D >= 128 ? (row & 15) : ((row >> 1) & 7), vk = D >= 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2);
+      const v4i k0 = widen8(r.k[j][0], r.k[j][1]), k1 = widen8(r.k[j][2], r.k[j][3]);
+      const v4i v0 = widen8(r.v[j][0], r.v[j][1]), v1 = widen8(r.v[j][2], r.v[j][3]);
+      char* kr_ = kbw + row * ROWB;
+      char* vr_ = vbw + row * ROWB;
+      *reinterpret_cast<v4i*>(kr_ + (((ch + first) ^ kk) << 4)) = first ? k1 : k0;
+      *reinterpret_cast<v4i*>(kr_ + (((ch + 1 - first) ^ kk) << 4)) = first ? k0 : k1;
+      *reinterpret_cast<v4i*>(vr_ + (((ch + first) ^ vk) << 4)) = first ? v1 : v0;
+      *reinterpret_cast<v4i*>(vr_ + (((ch + 1 - first) ^ vk) << 4)) = first ? v0 : v1;
+    }
+  };
+
   // ---- per-lane LDS read offsets
   // K (A operand of K . Q^T): token row 32 beta + l31, chunk 2 ks + u at position chunk ^ (row & 15)
   const int krow_off = l31 * ROWB, kkey = D >= 128 ? (l31 & 15) : ((l31 >> 1) & 7);  // (32 beta does not change the key)
@@ -840,7 +908,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) { m_ref[mb] = -INFINITY; l_run[mb] = 0.f; }
   const float log2e = 1.4426950408889634f;
-  const float scale = p.scale, sc2 = scale * log2e;
+  const float kd8 = (KV8 != 0 && p.k_descale) ? p.k_descale[0] : 1.f, vd8 = (KV8 != 0 && p.v_descale) ? p.v_descale[0] : 1.f;
+  const float scale = p.scale * kd8, sc2 = scale * log2e;  // (fp8 cache: the K descale multiplies every logit)
 
   // Schedule. Per wave and tile j: QK(j) (MFMA), softmax(j) (VALU), PV(j) (MFMA), one workgroup barrier per tile. Up to
   // round 3 a workgroup was 8 waves - two per SIMD, which took the barrier at different places (between QK and softmax /
@@ -851,9 +920,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
   // everybody is also done with tile j - 1, whose buffer takes the pieces of tile j + 1 now - in flight for the whole of
   // iteration j - with the page ids fetched in iteration j - 1; the ids of tile j + 2 are fetched next.
   Pages pg_next = {};
+  Regs8 r8 = {};
   if (n_tiles > 0) {
-    stage_tile(t_lo, 0, fetch_pages(t_lo));
-    if (n_tiles > 1) pg_next = fetch_pages(t_lo + 1);
+    if constexpr (KV8 != 0) {
+      issue8(t_lo, r8);
+      write8(0, r8);
+    } else {
+      stage_tile(t_lo, 0, fetch_pages(t_lo));
+      if (n_tiles > 1) pg_next = fetch_pages(t_lo + 1);
+    }
   }
 
 #ifdef SGLK_PROBES
@@ -876,11 +951,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
   for (int i = 0; i < n_tiles; ++i) {
     const int t = t_lo + i, buf = i & 1;
     PF_STAMP(-1)
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (KV8 != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the image was written by ds_write)
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     PF_STAMP(0)
     // the next tile's staging: a fast tile's pieces ride in the softmax of the wave's first row block (below); any other
     // tile's go out together behind QK
-    const bool next_tile = i + 1 < n_tiles, spread = next_tile && tile_fast(t + 1);
+    const bool next_tile = i + 1 < n_tiles, spread = KV8 == 0 && next_tile && tile_fast(t + 1);
     const char* kb = smem + buf * TILE_BYTES;
     const char* vb = smem + (2 + buf) * TILE_BYTES;
 
@@ -927,9 +1003,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
 
     PF_STAMP(1)
     Spread sp = {};
-    if (spread) sp = spread_begin(t + 1, buf ^ 1, pg_next);
-    else if (next_tile) stage_tile(t + 1, buf ^ 1, pg_next);
-    if (next_tile && i + 2 < n_tiles) pg_next = fetch_pages(t + 2);
+    if constexpr (KV8 != 0) {
+      if (next_tile) issue8(t + 1, r8);  // (widened and written behind the P . V phase)
+    } else {
+      if (spread) sp = spread_begin(t + 1, buf ^ 1, pg_next);
+      else if (next_tile) stage_tile(t + 1, buf ^ 1, pg_next);
+      if (next_tile && i + 2 < n_tiles) pg_next = fetch_pages(t + 2);
+    }
     PF_STAMP(2)
 
     // ---- softcap (Gemma-2; round 5 - before, a capped prefill fell through to the general kernel): the raw score s becomes
@@ -1100,6 +1180,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
       __builtin_amdgcn_sched_group_barrier(0x008, kVA * MB, 0);
       __builtin_amdgcn_s_setprio(0);
     }
+    if constexpr (KV8 != 0) {
+      if (next_tile) write8(buf ^ 1, r8);  // (buffer buf ^ 1 was last read in the iteration before: free since this one's barrier)
+    }
     PF_STAMP(4)
   }
 #ifdef SGLK_PROBES
@@ -1125,7 +1208,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
       lse_val = m2 + logf(l2);
       l_tot = (m_fin == -INFINITY) ? INFINITY : l_tot + __builtin_amdgcn_exp2f((sk - m_fin) * log2e);
     }
-    const float inv_l = (l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f;
+    const float inv_l = ((l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f) * vd8;  // (fp8 cache: x the V descale)
     if (row_ok[mb] && !(probe & 64)) {
       const int64_t tok = q_begin + my_qpos[mb];
       T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)my_head[mb] * p.o_s1;
@@ -1656,14 +1739,14 @@ static int launch(hipStream_t st, const AttnParams& p, const void* q, const void
   return SGLK_OK;
 }
 
-template <typename T, int D, int NW, int MB>
+template <typename T, int D, int NW, int MB, int KV8 = 0>
 static int launch_prefill_nw(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                              const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
   constexpr int lds = 2 * 2 * kPTile * D * 2;  // 64 KiB (d = 64: 32 KiB)
   static unsigned long long attr_done = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D, NW, MB>), lds, &attr_done, "fwd")) return rc;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D, NW, MB, KV8>), lds, &attr_done, "fwd")) return rc;
   dim3 grid((unsigned)cdiv(max_rows, 32 * MB * NW), (unsigned)p.Hk, (unsigned)batch);
-  attn_prefill_kernel<T, D, NW, MB><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  attn_prefill_kernel<T, D, NW, MB, KV8><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   return check_launch("fwd(prefill)");
 }
 
@@ -1674,14 +1757,16 @@ constexpr int g_attn_prefill_waves = 0;
 #endif
 
 // Four waves (128 rows) per workgroup, two workgroups per CU: see the kernel comment.
-template <typename T, int D>
+template <typename T, int D, int KV8 = 0>
 static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                           const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
 #ifdef SGLK_PROBES  // (the 8-wave form - one workgroup per CU - for A/B timing)
-  if (g_attn_prefill_waves == 8) return launch_prefill_nw<T, D, 8, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
-  if (g_attn_prefill_waves == 64) return launch_prefill_nw<T, D, 4, 2>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  if constexpr (KV8 == 0) {
+    if (g_attn_prefill_waves == 8) return launch_prefill_nw<T, D, 8, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+    if (g_attn_prefill_waves == 64) return launch_prefill_nw<T, D, 4, 2>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  }
 #endif
-  return launch_prefill_nw<T, D, 4, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  return launch_prefill_nw<T, D, 4, 1, KV8>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
 }
 
 template <typename T, int D, int KV8, int NW>
@@ -1738,6 +1823,17 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
     return d == 128  ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
            : d == 64 ? launch_prefill<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
                      : launch_prefill<T, 256>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  // (an fp8 cache at prefill sizes - the reference tests it, tests/test_flash_attention.py:1691-1704 - on the same kernel since
+  //  round 5: registers instead of LDS-DMA, widened on the way into the 16-bit LDS images; rows are fetched in 16-byte pieces)
+  if (kv8 != 0 && (d == 128 || d == 64) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 && p.o_s0 % 4 == 0 &&
+      p.o_s1 % 4 == 0 && p.k_s0 % 16 == 0 && p.k_s1 % 16 == 0 && p.k_s2 % 16 == 0 && p.v_s0 % 16 == 0 && p.v_s1 % 16 == 0 &&
+      p.v_s2 % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0) {
+    if (d == 128)
+      return kv8 == 1 ? launch_prefill<T, 128, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
+                      : launch_prefill<T, 128, 2>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+    return kv8 == 1 ? launch_prefill<T, 64, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
+                    : launch_prefill<T, 64, 2>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  }
   // decode-sized problems at head dims 64 / 128 / 256 (16-bit or fp8 cache): every sequence has at most 16 packed rows per
   // kv head; a tile within one page
   if ((d == 64 || d == 128 || d == 256) && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) &&

@@ -334,13 +334,15 @@ def test_missing_max_seqlen_q_is_safe(sglk, dev):
 # ---------------------------------------------------------------------- fp8 KV cache (reference :1697-1830)
 @pytest.mark.parametrize("fp8_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("heads", [(8, 8), (8, 2)])
-@pytest.mark.parametrize("D", [128, 256])
+@pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("page", [64, 128])
-@pytest.mark.parametrize("sq", [1, 32, 64])
+@pytest.mark.parametrize("sq", [1, 32, 64, 200])
 @pytest.mark.parametrize("sk", [256, 512])
 @pytest.mark.parametrize("causal", [False, True])
 def test_fp8_kvcache(sglk, dev, fp8_dtype, heads, D, page, sq, sk, causal):
-    """bf16 q against an fp8 paged KV cache with per-tensor descales (scalar and expanded-scalar layouts)."""
+    """bf16 q against an fp8 paged KV cache with per-tensor descales (scalar and expanded-scalar layouts). 64 queries x 4 q
+    heads per kv head and 200 queries reach the 128-row-block prefill kernel at d = 64 / 128 (fp8 staging through registers,
+    round 5; reference tests/test_flash_attention.py:1691-1704), the rest the decode and the general kernels."""
     Hq, Hk = heads
     b = 3
     g = torch.Generator().manual_seed(D + page + sq + sk)

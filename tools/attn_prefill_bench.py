@@ -23,13 +23,13 @@ def timeit(f, warm, it):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(it): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / it * 1e3
-for d in ((128,) if ONLY in ("128", "chunk", "softcap") else (64,) if ONLY == "64" else (256,) if ONLY == "256" else (128, 64, 256)):
+for d in ((128,) if ONLY in ("128", "chunk", "softcap", "fp8") else (64,) if ONLY == "64" else (256,) if ONLY == "256" else (128, 64, 256)):
     hq = 16 if d == 256 else 32  # (d = 256: 16 q heads / 8 kv heads)
     kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
     vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
     qp = torch.randn(bs * seq, hq, d, device=dev, dtype=torch.bfloat16)
     cu = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * seq
-    if ONLY not in ("chunk", "softcap"):
+    if ONLY not in ("chunk", "softcap", "fp8"):
         ms = timeit(lambda: flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
                                                     max_seqlen_q=seq, causal=True), 5, 10)
         print(f"prefill causal d={d}: {ms:.3f} ms  {4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9:.1f} TFLOP/s")
@@ -37,6 +37,13 @@ for d in ((128,) if ONLY in ("128", "chunk", "softcap") else (64,) if ONLY == "6
         ms = timeit(lambda: flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
                                                     max_seqlen_q=seq, causal=True, softcap=50.0), 5, 10)
         print(f"prefill causal d={d} softcap 50: {ms:.3f} ms  {4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9:.1f} TFLOP/s")
+    if d == 128 and ONLY in (None, "fp8"):
+        k8, v8 = kc.to(torch.float8_e4m3fn), vc.to(torch.float8_e4m3fn)
+        one = torch.ones(1, device=dev)
+        ms = timeit(lambda: flash_attn_with_kvcache(qp, k8, v8, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                    max_seqlen_q=seq, causal=True, k_descale=one, v_descale=one), 5, 10)
+        print(f"prefill causal d={d} fp8 e4m3 KV: {ms:.3f} ms  {4.0 * bs * hq * d * seq * seq / 2 / ms / 1e9:.1f} TFLOP/s")
+        del k8, v8
     if d == 128 and ONLY in (None, "chunk"):
         qc = torch.randn(bs * 128, hq, d, device=dev, dtype=torch.bfloat16)
         cuc = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * 128
