@@ -283,6 +283,7 @@ extern "C" int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* 
   if (int rc = moe_persist_try(st, out, activations, weights, nullptr, nullptr, 0, bias, rows_per_expert, total_m, (int)n_experts, (int)N,
                                (int)K, ldb, weight_stride_e, dtype, 0, fused_act, 0.f)) {
     if (rc < 0) return rc;
+    if (rc == 3) return SGLK_OK;  // (the tile pipeline took the remainders too)
     t_tail_flag = rc == 2 ? kMoeTailFlag128 : kMoeTailFlag;  // the experts' last rows (at most 128 each) on the streaming kernel
     const int64_t tail_m = std::min<int64_t>(total_m, (rc == 2 ? 64 : 128) * n_experts);
     rc = dtype == SGLK_BF16 ? dispatch<bf16>(st, out, activations, weights, bias, rows_per_expert, tail_m, (int)n_experts, (int)N,

@@ -60,6 +60,7 @@ struct MpParams {
   int blocks128;        // MS = 2 launch: 0 = only the <= 128-row remainders of 256-row blocks; 1 = all rows in 128-row blocks
                         // (remainders of at most 64 rows excepted: the caller's streaming kernels take them); 2 = the same
                         // blocks as 128 x 512 tiles (WIDE)
+  int own_rem;          // 128-row blocks: 1 = a remainder of 1 .. 64 rows is a (partly empty) block of this launch too: no tail launch
   const int32_t* rows;  // [E]
   int E, N, K, fuse;    // fuse: 0 none, 1 silu, 2 gelu (tanh), 3 relu2, 4 clamped swiglu (1, 2, 4 gated: N = gate + up rows)
   float act_limit;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // row blocks of an expert with r rows in THIS launch
   const bool b128 = (MS == 2 && p.blocks128 != 0) || WIDE;
   auto blocks_of = [&](int r) -> int {
-    if (b128) return (r >> 7) + ((r & 127) > 64 ? 1 : 0);
+    if (b128) return (r >> 7) + ((r & 127) > (p.own_rem ? 0 : 64) ? 1 : 0);
     const int full = r >> 8, tail = r & 255;
     return MS == 4 ? full + (tail > 128 ? 1 : 0) : ((tail > 0 && tail <= 128) ? 1 : 0);
   };
@@ -795,7 +796,8 @@ static int launch_persist(hipStream_t st, const MpParams& p) {
 
 // Called by sglk_moe_grouped_mm / sglk_moe_grouped_mm_w4a16_act. Returns 0 when the shape does not qualify (the caller goes
 // on with its streaming kernels), 1 after launching 256-row blocks (the caller runs the tails in kMoeTailFlag mode), 2 after
-// launching 128-row blocks (kMoeTailFlag128), a negative error code on failure.
+// launching 128-row blocks (kMoeTailFlag128), 3 after launching 128-row blocks that cover every row (no tails), a negative error
+// code on failure.
 int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const void* zeros,
                     int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
@@ -821,6 +823,12 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
   // its down projection - 8 column blocks x 8 row blocks = 64 tiles of 224 K blocks - stays on the 128 x 256 tiles: 128 of them)
   const int64_t wide_tiles = (total_m / 128) * ((Nout + (gated ? 255 : 511)) / (gated ? 256 : 512));
   p.blocks128 = !blocks128 ? 0 : wide_tiles >= 192 ? 2 : 1;
+  // Round 5: when even the worst case of 128 x 256 tiles - every expert with a remainder block - fits ONE round of the CUs, the
+  // remainders of 1 .. 64 rows run here as partly empty blocks on CUs that would idle, instead of a tail launch that streams those
+  // experts' weights a second time (Mixtral down projection at 512 tokens: 128 - 256 tiles of 224 K blocks on 256 CUs; the tail
+  // launch cost ~60 us of the layer's 750).
+  const int64_t nb_cols = gated ? (Nout + 127) / 128 : (N + 255) / 256;
+  p.own_rem = (p.blocks128 == 1 && (total_m / 128 + E) * nb_cols <= (int64_t)num_cus()) ? 1 : 0;
   p.stamps = g_mp_stamps;
   p.prio47 = g_mp_prio47;
   p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.bias = bias;  p.gshift = group_shift;  p.rows = rows;
@@ -839,7 +847,7 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
          : fmt == 1 ? launch_persist<bf16, 1>(st, p) : launch_persist<bf16, 0>(st, p);
   else
     rc = fmt == 3 ? launch_persist<f16, 3>(st, p) : fmt == 1 ? launch_persist<f16, 1>(st, p) : launch_persist<f16, 0>(st, p);
-  return rc ? rc : (blocks128 ? 2 : 1);
+  return rc ? rc : (blocks128 ? (p.own_rem ? 3 : 2) : 1);
 }
 
 }  // namespace sglk

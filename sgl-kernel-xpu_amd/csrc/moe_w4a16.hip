@@ -985,6 +985,7 @@ extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, co
     if (int rc = moe_persist_try(st, out, activations, packed_weights, scales, is_int4 ? zeros : nullptr, gs, bias, rows_per_expert, total_m, (int)n_experts,
                                  (int)N, (int)K, 0, 0, dtype, is_int4 ? 1 : 2, fused_act, act_limit)) {
       if (rc < 0) return rc;
+      if (rc == 3) return SGLK_OK;  // (the tile pipeline took the remainders too)
       // the experts' last rows (at most 128 each) on the streaming kernels, sized for the worst case
       t_tail_flag = rc == 2 ? kMoeTailFlag128 : kMoeTailFlag;
       const int64_t tail_m = std::min<int64_t>(total_m, (rc == 2 ? 64 : 128) * n_experts);

@@ -23,6 +23,9 @@ for T in (int(x) for x in (sys.argv[1:] or ["1", "16", "64", "256", "2048"])):
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / n * 1e3
     print(f"fused_experts T={T}: {ms:.3f} ms  {2.0*T*topk*3*Hd*I/ms/1e9:.1f} TFLOP/s  weights {(w1.numel()+w2.numel())/ms/1e6:.0f} GB/s")
 
+if os.environ.get("MOE_BENCH_INT4_ONLY"):
+    sys.exit(0)
+
 # 16-bit weights (moe_grouped_mm_nt_xe20)
 del w1, w2, s1, s2
 w1b = (torch.randn(E, 2 * I, Hd, device=dev) * 0.02).to(torch.bfloat16)
