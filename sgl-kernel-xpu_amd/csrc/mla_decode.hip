@@ -211,6 +211,7 @@ struct MlaParams {
   // head slots; decode: hp_shift = 7 (one token, row = head)
   int hp_shift, causal;
   int probe;  // timing probe: 1 = stream the cache through LDS, compute nothing (garbage results)
+  int q16;    // host only, rows128z kernel: QK^T on the 16-wide MFMA shape (launches that fill the chip for long: see S4)
   float scale_log2;
 };
 
@@ -862,7 +863,37 @@ __device__ __forceinline__ void mla_merge_splits(const MlaParams& p, int b, int 
 //     window is re-fetched (asm load, in front of the iteration's nine pieces, so that the next iteration's counted vmcnt
 //     covers it) once per 32 - 128 tiles: no scalar load shares lgkmcnt with the LDS reads;
 //   * softmax micro-ops re-cut so that no instruction directly follows its producer (fma, fma | exp, cvt | exp, dot2).
-template <typename T, bool kStamp = false, int kProbe = 0, int kKA = 3, int kVA = 4>
+//
+// kQ16 (round 5, second half): QK^T on v_mfma_f32_16x16x32 instead of 32x32x16. Same FLOP, same LDS bytes, twice the
+// instructions - and the part holds a higher clock under them: a register-only stream of the 16-wide shape delivers
+// 1.87 - 1.94 PFLOP/s against 1.64 - 1.70 for the 32-wide one on random bf16 operands, 1.47 - 1.59 against 1.37 - 1.48 with
+// every operand re-read from LDS (tools/mfma_shape_probe.py; MI355X_MICROARCH.md, DVFS give-back item 7). The wave's 32 rows
+// are two 16-row blocks rb, the tile's 32 tokens two 16-token blocks tb; a K fragment (16 tokens x 32 k, one ds_read_b128:
+// MFMA row i = token 4 g(i >> 2) + (i & 3), g = (0, 2, 3, 1), which keeps the reads conflict-free on the unchanged image)
+// feeds the two MFMAs of its row blocks. The accumulator of block (tb, rb) leaves lane (j, kg) with row 16 rb + j and the
+// tokens 16 tb + 4 g(kg) + 0..3; eight v_permlane16_swap (odd 16-lane rows of the rb = 0 registers <-> even rows of the
+// rb = 1 registers) hand every lane the 16 tokens of ROW lane & 31 - the ownership the softmax, P.V and the epilogue were
+// written for. Only the order of a lane's tokens differs, which the transposed V reads follow (token half e swapped for
+// the upper 32 lanes).
+struct S4 {
+  v4f q[4];  // before the swap: block (tb, rb) = q[2 tb + rb]; after: weights 8 tb + 4 h + r = q[2 tb + h][r]
+};
+template <int I>
+__device__ __forceinline__ float sget(const v16f& s) { return s[I]; }
+template <int I>
+__device__ __forceinline__ void sset(v16f& s, float x) { s[I] = x; }
+template <int I>
+__device__ __forceinline__ float sget(const S4& s) { return s.q[I >> 2][I & 3]; }
+template <int I>
+__device__ __forceinline__ void sset(S4& s, float x) { s.q[I >> 2][I & 3] = x; }
+__device__ __forceinline__ void s_pin(v16f& s) { asm volatile("" : "+v"(s)); }
+__device__ __forceinline__ void s_pin(S4& s) { asm volatile("" : "+v"(s.q[0]), "+v"(s.q[1]), "+v"(s.q[2]), "+v"(s.q[3])); }
+// (asm MFMA result -> VALU read wait states)
+__device__ __forceinline__ void s_settle(v16f& s) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s)); }
+__device__ __forceinline__ void s_settle(S4& s) {
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s.q[0]), "+v"(s.q[1]), "+v"(s.q[2]), "+v"(s.q[3]));
+}
+template <typename T, bool kStamp = false, int kProbe = 0, int kKA = 3, int kVA = 4, bool kQ16 = false>
 __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p, const T* __restrict__ q_nope,
                                                                     const T* __restrict__ q_pe,
                                                                     const char* __restrict__ cache,
@@ -997,7 +1028,31 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   constexpr int kQpeOff = 4 * kStageBytes;
   v8s qf[32];
   const uint32_t qpe_addr = (uint32_t)(uintptr_t)SGLK_LDS(smem) + (uint32_t)(kQpeOff + wave * 4096 + lane * 16);
-  {
+  if constexpr (kQ16) {
+    // 16-wide shape: lane (j, kg) supplies q[row 16 rb + j][32 ks + 8 kg .. + 8) of both row blocks: qf[16 rb + ks] for the
+    // latent k-steps, LDS slot 2 (ks - 16) + rb for the two rope steps
+    const int j16 = lane & 15, kg = lane >> 4;
+    const v8s zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int r2 = wave * 32 + 16 * rb + j16;
+      const int tok2 = r2 >> p.hp_shift, head2 = r2 & hp_mask;
+      const bool ok2 = tok2 < n_tok && head2 < H;
+      const int64_t qrow = q_row0 + (ok2 ? tok2 : 0);
+      const T* qn = q_nope + qrow * p.qn_sb + (int64_t)(ok2 ? head2 : 0) * p.qn_sh + 8 * kg;
+      const T* qp = q_pe + qrow * p.qp_sb + (int64_t)(ok2 ? head2 : 0) * p.qp_sh + 8 * kg;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const v8s v = *reinterpret_cast<const v8s*>(qn + 32 * ks);
+        qf[16 * rb + ks] = ok2 ? v : zero;
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const v8s v = *reinterpret_cast<const v8s*>(qp + 32 * k2);
+        *reinterpret_cast<v8s*>(smem + kQpeOff + wave * 4096 + (2 * k2 + rb) * 1024 + lane * 16) = ok2 ? v : zero;
+      }
+    }
+  } else {
     const int64_t qrow = q_row0 + (ok ? my_tok : 0);
     const T* qn = q_nope + qrow * p.qn_sb + (int64_t)(ok ? my_head : 0) * p.qn_sh + 8 * u;
     const T* qp = q_pe + qrow * p.qp_sb + (int64_t)(ok ? my_head : 0) * p.qp_sh + 8 * u;
@@ -1064,12 +1119,21 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
 
   // ---- per-lane LDS read offsets inside a stage
   // K row read, k-step ks: block ks / 8, chunk 2 (ks % 8) + u of token row l31  ->  kbase ^ (32 (ks % 8)) + 8192 (ks / 8)
-  const uint32_t kbase = (uint32_t)(256 * l31 + 16 * (u ^ sw_main(l31)));
-  const uint32_t rbase = (uint32_t)(kMainBytes + 128 * l31 + 16 * (u ^ ((l31 >> 1) & 7)));  // rope: ^ (32 (ks - 32))
+  // kQ16: K fragment of k-step ks = 4 cb + ks', token block tb: lane (i, kg) reads chunk 4 ks' + kg of token 16 tb + tau(i),
+  // tau(i) = 4 g(i >> 2) + (i & 3)  ->  kbase ^ (64 ks') + 8192 cb + 4096 tb; rope step k2: rbase ^ (64 k2) + 2048 tb
+  const int i16k = lane & 15, kgk = lane >> 4, g16 = (0x78 >> (2 * (i16k >> 2))) & 3, tau16 = 4 * g16 + (i16k & 3);
+  const uint32_t kbase = kQ16 ? (uint32_t)(256 * tau16 + 16 * (4 * (i16k & 3) + (kgk ^ g16)))
+                              : (uint32_t)(256 * l31 + 16 * (u ^ sw_main(l31)));
+  const uint32_t rbase = kQ16 ? (uint32_t)(kMainBytes + 128 * tau16 + 16 * (kgk ^ ((tau16 >> 1) & 7)))
+                              : (uint32_t)(kMainBytes + 128 * l31 + 16 * (u ^ ((l31 >> 1) & 7)));  // rope: ^ (32 (ks - 32))
   // V^T transposed read of dim tile dt, k-step s, token half e (tokens 16 s + 8 e + 4 u + qq, dims 32 dt + 16 hh + 4 pp ..):
   //   8192 (dt / 4) + 4096 s + 2048 e + (vbase ^ (64 (dt % 4)) ^ (32 e))
   const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, hh = (lane >> 4) & 1;
   const uint32_t vbase = (uint32_t)(256 * (4 * u + qq) + 8 * (pp & 1) + 16 * ((qq << 2) | ((2 * hh + (pp >> 1)) ^ u)));
+  // token halves e = 0 / 1 of a k-step, relative to the stage. kQ16: behind the row swap a lane holds its tokens in the order
+  // 16 tb + {0..3, 8..11} (lanes 0..31) / 16 tb + {12..15, 4..7} (lanes 32..63): the upper lanes fetch half 1 first
+  const uint32_t vbase1 = (vbase ^ 32u) + 2048u;
+  const uint32_t vbA = (kQ16 && u) ? vbase1 : vbase, vbB = (kQ16 && u) ? vbase : vbase1;
 
   // O^T tile dt = a[16 dt .. 16 dt + 15], named only in asm text; the clobbers tell the compiler that the kernel owns the
   // whole AGPR file (build.py check_isa verifies that it places nothing there)
@@ -1109,60 +1173,81 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   // exponential and the PREVIOUS pair's rounding, gap 3 pr + 3 the second exponential and the previous pair's row-sum step:
   // no instruction directly follows its producer (a dependent pair waits out the VALU latency: stamps, round 5).
   int pk_prev = 0;
-  auto exp_op = [&](auto kc, v16f& sp) {
+  // the pieces: multiply-adds of pair pr, one exponential, rounding + packing of pair pq, its row-sum step, the tile's sum
+  auto e_fma = [&](auto prc, auto& sp) {
+    constexpr int pr = decltype(prc)::value;
+    float y0 = __builtin_fmaf(sget<2 * pr>(sp), sl2, mneg), y1 = __builtin_fmaf(sget<2 * pr + 1>(sp), sl2, mneg);
+    asm volatile("" : "+v"(y0), "+v"(y1));
+    sset<2 * pr>(sp, y0);
+    sset<2 * pr + 1>(sp, y1);
+  };
+  auto e_exp = [&](auto ic, auto& sp) {
+    constexpr int i = decltype(ic)::value;
+    float e = __builtin_amdgcn_exp2f(sget<i>(sp));
+    asm volatile("" : "+v"(e));
+    sset<i>(sp, e);
+  };
+  auto e_pack = [&](auto pqc, auto& sp) {
+    constexpr int pq = decltype(pqc)::value;
+    int pk = M::pack(sget<2 * pq>(sp), sget<2 * pq + 1>(sp));
+    asm volatile("" : "+v"(pk));
+    pk_prev = pk;
+    pf[pq >> 2][2 * (pq & 3)] = (short)(pk & 0xffff);
+    pf[pq >> 2][2 * (pq & 3) + 1] = (short)((unsigned)pk >> 16);
+  };
+  auto e_add = [&]() {
+    psum = M::add2(pk_prev, psum);  // the row sum takes the ROUNDED weights (numerator and denominator round alike)
+    asm volatile("" : "+v"(psum));
+  };
+  auto e_fin = [&]() {
+    l_run += psum;
+    asm volatile("" : "+v"(l_run));
+  };
+  auto exp_op = [&](auto kc, auto& sp) {
     constexpr int k = decltype(kc)::value;  // gap - 1
     constexpr int pr = k / 3, r = k % 3;
-    if constexpr (pr < 8 && r == 0) {
-      float y0 = __builtin_fmaf(sp[2 * pr], sl2, mneg), y1 = __builtin_fmaf(sp[2 * pr + 1], sl2, mneg);
-      asm volatile("" : "+v"(y0), "+v"(y1));
-      sp[2 * pr] = y0;
-      sp[2 * pr + 1] = y1;
-    }
-    if constexpr (pr < 8 && r == 1) {
-      float e = __builtin_amdgcn_exp2f(sp[2 * pr]);
-      asm volatile("" : "+v"(e));
-      sp[2 * pr] = e;
-    }
-    if constexpr (pr < 8 && r == 2) {
-      float e = __builtin_amdgcn_exp2f(sp[2 * pr + 1]);
-      asm volatile("" : "+v"(e));
-      sp[2 * pr + 1] = e;
-    }
+    if constexpr (pr < 8 && r == 0) e_fma(std::integral_constant<int, pr>{}, sp);
+    if constexpr (pr < 8 && r == 1) e_exp(std::integral_constant<int, 2 * pr>{}, sp);
+    if constexpr (pr < 8 && r == 2) e_exp(std::integral_constant<int, 2 * pr + 1>{}, sp);
     // the previous pair (pq): rounded and packed one gap after its second exponential, added to the row sum a gap later
-    if constexpr (k >= 4 && k <= 25 && r == 1) {
-      constexpr int pq = pr - 1;
-      int pk = M::pack(sp[2 * pq], sp[2 * pq + 1]);
-      asm volatile("" : "+v"(pk));
-      pk_prev = pk;
-      pf[pq >> 2][2 * (pq & 3)] = (short)(pk & 0xffff);
-      pf[pq >> 2][2 * (pq & 3) + 1] = (short)((unsigned)pk >> 16);
-    }
-    if constexpr (k >= 5 && k <= 26 && r == 2) {
-      psum = M::add2(pk_prev, psum);  // the row sum takes the ROUNDED weights (numerator and denominator round alike)
-      asm volatile("" : "+v"(psum));
-    }
-    if constexpr (k == 27) {
-      l_run += psum;
-      asm volatile("" : "+v"(l_run));
-    }
+    if constexpr (k >= 4 && k <= 25 && r == 1) e_pack(std::integral_constant<int, pr - 1>{}, sp);
+    if constexpr (k >= 5 && k <= 26 && r == 2) e_add();
+    if constexpr (k == 27) e_fin();
   };
   constexpr int kExpOps = 28;
+  // kQ16: the same pieces over the gaps of the 16-wide QK^T phase (an MFMA of that shape leaves 8 of its 16 cycles to the
+  // vector issue: one exponential, or two 4-cycle instructions, per gap). Only the gap behind the MFMA of row block 0 of a
+  // fragment carries vector work (h = 0; the other one has the K read): fragment n = 4 pr + 1 + ph - ph 0 the multiply-adds
+  // of pair pr, ph 1 / 2 its exponentials, ph 3 the row-sum step of pair pr - 1 and the rounding of pair pr.
+  auto exp_gap16 = [&](auto nc, auto hc, auto& sp) {
+    constexpr int n = decltype(nc)::value, h = decltype(hc)::value;
+    if constexpr (n >= 1 && h == 0) {
+      constexpr int pr = (n - 1) / 4, ph = (n - 1) % 4;
+      if constexpr (pr < 8 && ph == 0) e_fma(std::integral_constant<int, pr>{}, sp);
+      if constexpr (pr < 8 && ph == 1) e_exp(std::integral_constant<int, 2 * pr>{}, sp);
+      if constexpr (pr < 8 && ph == 2) e_exp(std::integral_constant<int, 2 * pr + 1>{}, sp);
+      if constexpr (pr >= 1 && pr < 8 && ph == 3) e_add();
+      if constexpr (pr < 8 && ph == 3) e_pack(std::integral_constant<int, pr>{}, sp);
+      if constexpr (n == 33) e_add();
+      if constexpr (n == 34) e_fin();
+    }
+  };
   // first half: row maximum of the raw logits in sc, then the lazy reference: it moves only when a weight would pass
   // 2^kLazy, then to 2^kHead above the running maximum; all rows of the wave move together (one rescale pass serves them
   // all). Leaves alpha / upd for the rescale of O and takes l_run to the new reference.
-  auto max_op = [&](auto kc, v16f& sc) {
+  auto max_op = [&](auto kc, auto& sc) {
     constexpr int k = decltype(kc)::value;
     if constexpr (k == 0) {
-      mt = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-      mb = fmaxf(fmaxf(sc[3], sc[4]), sc[5]);
+      mt = fmaxf(fmaxf(sget<0>(sc), sget<1>(sc)), sget<2>(sc));
+      mb = fmaxf(fmaxf(sget<3>(sc), sget<4>(sc)), sget<5>(sc));
     } else if constexpr (k == 1) {
-      mt = fmaxf(fmaxf(mt, sc[6]), sc[7]);
-      mb = fmaxf(fmaxf(mb, sc[8]), sc[9]);
+      mt = fmaxf(fmaxf(mt, sget<6>(sc)), sget<7>(sc));
+      mb = fmaxf(fmaxf(mb, sget<8>(sc)), sget<9>(sc));
     } else if constexpr (k == 2) {
-      mt = fmaxf(fmaxf(mt, sc[10]), sc[11]);
-      mb = fmaxf(fmaxf(mb, sc[12]), sc[13]);
+      mt = fmaxf(fmaxf(mt, sget<10>(sc)), sget<11>(sc));
+      mb = fmaxf(fmaxf(mb, sget<12>(sc)), sget<13>(sc));
     } else if constexpr (k == 3) {
-      mt = fmaxf(fmaxf(mt, sc[14]), sc[15]);
+      mt = fmaxf(fmaxf(mt, sget<14>(sc)), sget<15>(sc));
       mt = fmaxf(mt, mb);
     } else if constexpr (k == 4) {  // the other 16 tokens of this row live in lane ^ 32
       float c0 = mt, c1 = mt;
@@ -1183,6 +1268,15 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
     }
     asm volatile("" : "+v"(mt), "+v"(mb), "+v"(alpha), "+v"(mneg), "+v"(l_run), "+v"(m_ref), "+v"(m_run));
   };
+  // kQ16: the row swap in front of the maxima - two v_permlane16_swap per step (see S4): odd 16-lane rows of the rb = 0
+  // register <-> even rows of the rb = 1 register
+  auto swap_op = [&](auto kc, S4& sc) {
+    constexpr int k = decltype(kc)::value;  // 0..3: registers r = 2 (k & 1), + 1 of token block k >> 1
+    constexpr int tb = k >> 1, r0 = 2 * (k & 1);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
+                 : "+v"(sc.q[2 * tb][r0]), "+v"(sc.q[2 * tb][r0 + 1]), "+v"(sc.q[2 * tb + 1][r0]), "+v"(sc.q[2 * tb + 1][r0 + 1]));
+  };
+  constexpr int kSwapOps = kQ16 ? 4 : 0;
   constexpr int kMaxOps = 8;
 
   // ---- rings. K: fragment n + 3 is requested in the gap behind MFMA n; V^T: four fragments (eight transposed reads) ahead,
@@ -1277,8 +1371,8 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
       if constexpr (kExp) {  // P . V of tile jv comes next: its bases, then its first four fragments
         if constexpr (n == 31) {
           const uint32_t sv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
-          vb[0] = vbase + sv;
-          vb[1] = (vb[0] ^ 32u) + 2048u;
+          vb[0] = vbA + sv;
+          vb[1] = vbB + sv;
           asm volatile("" : "+v"(vb[0]), "+v"(vb[1]));
         }
         if constexpr (n == 33) SGLK_V_ISSUE(0);
@@ -1292,15 +1386,134 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
     for (int i = 0; i < kKA; ++i) asm volatile("" ::"v"(kr[i]));  // (the ring stays reserved past the last MFMAs)
 #undef SGLK_K_ISSUE
   };
-  auto mask_tile = [&](int j, v16f& s) {  // (rare, uniform: keys past a row's horizon)
+  // ---- kQ16: the same phase on v_mfma_f32_16x16x32 (see S4). Fragment n < 32: k-step 4 cb + ks' with ks' = n / 8,
+  // cb = (n / 2) % 4, token block n % 2 - one address (kbs ^ 64 ks') serves eight reads; n >= 32: rope step (n - 32) / 2,
+  // token block n % 2, the two rope fragments of Q (row blocks 0, 1) requested in front of the step's first K fragment.
+  auto qk_tile16 = [&](int j, S4& s, auto with_exp, S4& sp, const TileSrc& nxt, int jv) {
+    constexpr bool kExp = decltype(with_exp)::value;
+    const uint32_t sb = lds_base + (uint32_t)((j & 3) * kStageBytes);
+    uint32_t kbs = kbase + sb, rbs = rbase + sb;
+    asm volatile("" : "+v"(kbs), "+v"(rbs));
+    v4i kr[kKA], qr[4];
+    uint32_t ka = kbs;
+    auto k_issue_ = [](auto nc, v4i& kslot, v4i& q0, v4i& q1, uint32_t& ka_, const uint32_t kbs_, const uint32_t rbs_,
+                       const uint32_t qpe_) {
+      constexpr int n = decltype(nc)::value;
+      if constexpr (n < 32) {
+        if constexpr ((n & 7) == 0 && n > 0) {
+          ka_ = kbs_ ^ (uint32_t)((n >> 3) << 6);
+          asm volatile("" : "+v"(ka_));
+        }
+        if constexpr (kProbe != 2 && kProbe != 3 && kProbe != 5)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kslot) : "v"(ka_), "i"(((n >> 1) & 3) * 8192 + (n & 1) * 4096));
+      } else {
+        constexpr int k2 = (n - 32) >> 1;
+        uint32_t ra = rbs_ ^ (uint32_t)(k2 << 6);
+        if constexpr (kProbe != 2 && kProbe != 3 && kProbe != 5) {
+          if constexpr ((n & 1) == 0) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q0) : "v"(qpe_), "i"((2 * k2) * 1024));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q1) : "v"(qpe_), "i"((2 * k2 + 1) * 1024));
+          }
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kslot) : "v"(ra), "i"((n & 1) * 2048));
+        }
+      }
+    };
+#define SGLK_K_ISSUE(N_) \
+  k_issue_(std::integral_constant<int, (N_)>{}, kr[(N_) % kKA], qr[(N_) & 2], qr[((N_) & 2) + 1], ka, kbs, rbs, qpe_addr)
+    static_for<0, kKA>([&](auto nc) { constexpr int n0 = decltype(nc)::value; SGLK_K_ISSUE(n0); });
+    // under the latency of the first fragments: the rope piece of tile j + 2
+    if constexpr (kExp) dma_piece(nxt, std::integral_constant<int, 8>{});
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 36>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      constexpr int tb = n & 1;
+      constexpr int ks = n < 32 ? 4 * ((n >> 1) & 3) + (n >> 3) : 0;  // the latent k-step of fragment n
+      constexpr int k2 = n < 32 ? 0 : (n - 32) >> 1;
+      // LDS reads younger than fragment n's at this point: the fragments n+1 .. last (one read each, plus the two Q reads in
+      // front of the fragments 32 and 34) and the V^T reads requested behind the fragments 33, 34 (two each)
+      constexpr int last = n + kKA - 1 < 35 ? n + kKA - 1 : 35;
+      constexpr int younger = (last - n) + ((n + 1 <= 32 && 32 <= last) ? 2 : 0) + ((n + 1 <= 34 && 34 <= last) ? 2 : 0) +
+                              (kExp ? (n == 34 ? 2 : n == 35 ? 4 : 0) : 0);
+      static_assert(younger <= 15, "lgkmcnt is a 4-bit field");
+      constexpr int wcnt = (kProbe == 2 || kProbe == 3 || kProbe == 5) ? 0 : younger;
+      const v8s kf = __builtin_bit_cast(v8s, kr[n % kKA]);
+      const v8s qb0 = n < 32 ? qf[ks] : __builtin_bit_cast(v8s, qr[2 * k2]);
+      const v8s qb1 = n < 32 ? qf[16 + ks] : __builtin_bit_cast(v8s, qr[2 * k2 + 1]);
+      // (the first MFMA of a block takes the constant 0 as its addend: no VALU write feeds an asm MFMA)
+      if constexpr (n < 2) {
+        if constexpr (std::is_same<T, bf16>::value)
+          asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s.q[2 * tb]) : "v"(kf), "v"(qb0), "i"(wcnt));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(s.q[2 * tb]) : "v"(kf), "v"(qb0), "i"(wcnt));
+      } else {
+        if constexpr (std::is_same<T, bf16>::value)
+          asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s.q[2 * tb]) : "v"(kf), "v"(qb0), "i"(wcnt));
+        else
+          asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(s.q[2 * tb]) : "v"(kf), "v"(qb0), "i"(wcnt));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kExp && kProbe != 6) exp_gap16(nc, std::integral_constant<int, 0>{}, sp);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (n < 2) {
+        if constexpr (std::is_same<T, bf16>::value)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s.q[2 * tb + 1]) : "v"(kf), "v"(qb1));
+        else
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(s.q[2 * tb + 1]) : "v"(kf), "v"(qb1));
+      } else {
+        if constexpr (std::is_same<T, bf16>::value)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s.q[2 * tb + 1]) : "v"(kf), "v"(qb1));
+        else
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(s.q[2 * tb + 1]) : "v"(kf), "v"(qb1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kExp && kProbe != 6) exp_gap16(nc, std::integral_constant<int, 1>{}, sp);
+      // (the slot stays reserved up to its refill: the MFMA issued just before is still reading it)
+      asm volatile("" ::"v"(kr[n % kKA]));
+      if constexpr (n >= 32) asm volatile("" ::"v"(qr[2 * k2]), "v"(qr[2 * k2 + 1]));
+      if constexpr (n + kKA < 36) SGLK_K_ISSUE(n + kKA);
+      if constexpr (kExp) {  // P . V of tile jv comes next: its bases, then its first three fragments
+        if constexpr (n == 31) {
+          const uint32_t sv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
+          vb[0] = vbA + sv;
+          vb[1] = vbB + sv;
+          asm volatile("" : "+v"(vb[0]), "+v"(vb[1]));
+        }
+        if constexpr (n == 33) SGLK_V_ISSUE(0);
+        if constexpr (n == 34) SGLK_V_ISSUE(1);
+        if constexpr (n == 35) SGLK_V_ISSUE(2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    s_pin(s);
+#pragma unroll
+    for (int i = 0; i < kKA; ++i) asm volatile("" ::"v"(kr[i]));  // (the ring stays reserved past the last MFMAs)
+#undef SGLK_K_ISSUE
+  };
+  auto mask_tile = [&](int j, auto& s) {  // (rare, uniform: keys past a row's horizon)
     const int t = t_begin + j;
     if (t * kTile + kTile > kv_first || t * kTile + kTile > seq) {
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s));  // (asm MFMA result -> VALU read wait states)
-      const RowId r = row_id();  // (recomputed here: nothing lane-dependent of the epilogue stays live across the tile loop)
-      const int kv_row = (cu_seqlens_q != nullptr && p.causal && r.my_tok < n_tok) ? kv_first + r.my_tok : seq;  // the row's horizon
+      s_settle(s);
+      if constexpr (kQ16) {  // (in front of the row swap: block (tb, rb), register r = token 16 tb + 4 g(kg) + r of row 16 rb + j)
+        int tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));
+        const int ln = tl & 63, gk = (0x78 >> (2 * (ln >> 4))) & 3;
 #pragma unroll
-      for (int v = 0; v < 16; ++v)
-        if (t * kTile + (v & 3) + 8 * (v >> 2) + 4 * r.u >= kv_row) s[v] = -INFINITY;
+        for (int rb = 0; rb < 2; ++rb) {
+          const int r_tok = (wave * 32 + 16 * rb + (ln & 15)) >> p.hp_shift;
+          const int kv_row = (cu_seqlens_q != nullptr && p.causal && r_tok < n_tok) ? kv_first + r_tok : seq;
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (t * kTile + 16 * tb + 4 * gk + r >= kv_row) s.q[2 * tb + rb][r] = -INFINITY;
+        }
+      } else {
+        const RowId r = row_id();  // (recomputed here: nothing lane-dependent of the epilogue stays live across the tile loop)
+        const int kv_row = (cu_seqlens_q != nullptr && p.causal && r.my_tok < n_tok) ? kv_first + r.my_tok : seq;  // the row's horizon
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          if (t * kTile + (v & 3) + 8 * (v >> 2) + 4 * r.u >= kv_row) s[v] = -INFINITY;
+      }
     }
   };
 
@@ -1308,13 +1521,13 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   // hand-counted waits. kPre: the first four fragments were requested by the QK^T phase in front. kSlot >= 0: this wave's
   // DMA pieces 0..7 of the tile after next go out in the gaps m % 4 == kSlot (wave w: slot w - one wave at a time on the
   // CU's vector-memory path).
-  auto pv_tile = [&](int jv, auto pre, auto with_max, v16f& sc, auto slot, const TileSrc& nxt) {
+  auto pv_tile = [&](int jv, auto pre, auto with_max, auto& sc, auto slot, const TileSrc& nxt) {
     constexpr bool kPre = decltype(pre)::value, kMax = decltype(with_max)::value;
     constexpr int kSlot = decltype(slot)::value;
     if constexpr (!kPre) {
       const uint32_t sv = lds_base + (uint32_t)((jv & 3) * kStageBytes);
-      vb[0] = vbase + sv;
-      vb[1] = (vb[0] ^ 32u) + 2048u;
+      vb[0] = vbA + sv;
+      vb[1] = vbB + sv;
       asm volatile("" : "+v"(vb[0]), "+v"(vb[1]));
       static_for<0, kVA>([&](auto mc) { constexpr int m0 = decltype(mc)::value; SGLK_V_ISSUE(m0); });
     } else {  // (three fragments came with the QK^T phase: its K ring was still live there)
@@ -1329,9 +1542,18 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
       //  wait the MFMA statement starts with; the ISA shows none)
       const v8s f = __builtin_bit_cast(v8s, __builtin_shufflevector(vlo[m % kVA], vhi[m % kVA], 0, 1, 2, 3));
       constexpr int wcnt = (kProbe == 1 || kProbe == 3 || kProbe == 5) ? 0 : 2 * ahead;
-      M::template wait_acc_agpr<dt * 16, wcnt>(f, pf[ss]);
+      if constexpr (kProbe == 8) {  // (timing probe, garbage results: the phase's FLOP on the 16-wide shape - two MFMAs per fragment)
+        asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(f), "v"(pf[ss]),
+                     "i"(dt * 16), "i"(dt * 16 + 3), "i"(wcnt));
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(f), "v"(pf[ss]), "i"(dt * 16 + 8), "i"(dt * 16 + 11));
+      } else {
+        M::template wait_acc_agpr<dt * 16, wcnt>(f, pf[ss]);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (kMax && m >= 2 && m - 2 < kMaxOps && kProbe != 6) max_op(std::integral_constant<int, m - 2>{}, sc);
+      if constexpr (kMax && kProbe != 6) {  // (kQ16: the row swap of the tile's raw logits first)
+        if constexpr (kQ16 && m >= 2 && m - 2 < kSwapOps) swap_op(std::integral_constant<int, m - 2>{}, sc);
+        if constexpr (m >= 2 + kSwapOps && m - 2 - kSwapOps < kMaxOps) max_op(std::integral_constant<int, m - 2 - kSwapOps>{}, sc);
+      }
       // the fragment's registers stay reserved past the micro-op (a VALU write into an operand of the MFMA issued just
       // before is not interlocked); the refill of this slot lands tens of cycles later
       asm volatile("" ::"v"(f));
@@ -1363,7 +1585,7 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   }
   // One iteration: tile j's QK^T (+ exponentials of tile j-1 from s_prv, + the first V^T reads of tile j-1), then P.V of
   // tile j-1 (+ maxima of tile j in s_cur, + the DMA pieces of tile j+2).
-  auto iter = [&](int j, v16f& s_cur, v16f& s_prv) {
+  auto iter = [&](int j, auto& s_cur, auto& s_prv) {
     stamp(8);
     asm volatile("s_waitcnt vmcnt(9)" : "+v"(v_ids)::"memory");  // tile j landed; so has a window fetched an iteration ago
     stamp(0);
@@ -1375,7 +1597,9 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
     const TileSrc nxt = tile_src(tile_of(j + 2), (j + 2) & 3, pga, pgb);
     stamp(2);
     if (work) {
-      qk_tile(j, s_cur, std::true_type{}, s_prv, nxt, j - 1);  // + exponentials of tile j-1 -> pf
+      // + exponentials of tile j-1 -> pf
+      if constexpr (kQ16) qk_tile16(j, s_cur, std::true_type{}, s_prv, nxt, j - 1);
+      else qk_tile(j, s_cur, std::true_type{}, s_prv, nxt, j - 1);
       mask_tile(j, s_cur);
       __builtin_amdgcn_sched_barrier(0);
       // (no stamp between the phases: s_memtime is a scalar memory read, its wait would drain the V^T reads in flight here)
@@ -1395,7 +1619,7 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
       static_for<0, 9>([&](auto ic) { dma_piece(nxt, ic); });
     }
   };
-  v16f s_a, s_b;
+  typename std::conditional<kQ16, S4, v16f>::type s_a, s_b;
   {  // tile 0: nothing to overlap with
     stamp(5);
     asm volatile("s_waitcnt vmcnt(9)" : "+v"(v_ids)::"memory");
@@ -1406,9 +1630,14 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
     const TileSrc nxt = tile_src(tile_of(2), 2, pga, pgb);
     static_for<0, 9>([&](auto ic) { dma_piece(nxt, ic); });
     if (work) {
-      qk_tile(0, s_b, std::false_type{}, s_b, nxt, 0);
+      if constexpr (kQ16) qk_tile16(0, s_b, std::false_type{}, s_b, nxt, 0);
+      else qk_tile(0, s_b, std::false_type{}, s_b, nxt, 0);
       mask_tile(0, s_b);
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s_b));  // (asm MFMA result -> VALU read wait states)
+      s_settle(s_b);  // (asm MFMA result -> VALU read wait states)
+      if constexpr (kQ16) {
+        static_for<0, kSwapOps>([&](auto kc) { swap_op(kc, s_b); });
+        asm volatile("s_nop 1");
+      }
       static_for<0, kMaxOps>([&](auto kc) { max_op(kc, s_b); });  // (O is zero: nothing to rescale)
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1559,9 +1788,15 @@ static int launch_rows128x(hipStream_t st, const MlaParams& p, int B, const void
     if (g_mla_variant == 205) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 5>), ldsz)
     if (g_mla_variant == 206) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 6>), ldsz)
     if (g_mla_variant == 207) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 7>), ldsz)
+    if (g_mla_variant == 208) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 8, 3, 4, true>), ldsz)   // + P.V FLOP on 16x16x32 (garbage)
+    if (g_mla_variant == 216) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 3, 4, true>), ldsz)   // QK^T on 16x16x32
+    if (g_mla_variant == 232) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 3, 4, false>), ldsz)  // QK^T on 32x32x16
+    if (g_mla_variant == 86) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 3, 4, true>), ldsz)     // stamped, 16-wide
+    if (g_mla_variant == 87) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, true, 0, 3, 4, false>), ldsz)    // stamped, 32-wide
   }
 #endif
-  SGLK_MLA_LAUNCH((mla_rows128z_kernel<T>), ldsz)
+  if (p.q16) SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 3, 4, true>), ldsz)
+  SGLK_MLA_LAUNCH((mla_rows128z_kernel<T, false, 0, 3, 4, false>), ldsz)
 #undef SGLK_MLA_LAUNCH
 }
 
@@ -1690,6 +1925,10 @@ extern "C" int sglk_flash_mla_decode(sglk_stream_t stream, void* out, const void
   p.hp_shift = 7;
   p.causal = 0;
   p.probe = g_mla_probe;
+  // QK^T on the 16-wide MFMA shape where the launch keeps every CU busy for long (the part then holds a higher clock under
+  // it: bs 128 x 8192 -2.7 %, bs 256 x 2048 -5 %, H = 96 -3 %); short launches are issue-bound, not power-bound, and lose
+  // ~1 % to its narrower gaps (bs 32 x 8192, bs 64 x 4096, bs 128 x 1024): from 48 tiles per CU on
+  p.q16 = batch * max_tiles >= 48 * (int64_t)num_cus() ? 1 : 0;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SGLK_BF16) return launch<bf16>(st, p, (int)batch, q_nope, q_pe, cache, seq_lens, page_table);
@@ -1742,6 +1981,9 @@ extern "C" int sglk_flash_mla_prefill(sglk_stream_t stream, void* out, const voi
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   const int tpw = 1 << (7 - p.hp_shift);
   const int token_blocks = (int)((max_seqlen_q + tpw - 1) / tpw);
+  // (QK^T on the 16-wide MFMA shape once the grid fills the chip: 16 x 512 over 4096 keys 7.19 - 7.30 ms against 7.38 - 7.66,
+  //  8 x 128 over 8192 1.815 against 1.873, 4 x 64 over 2048 0.133 against 0.136; on 96 - 128 workgroups it loses 1 - 4 %)
+  p.q16 = batch * token_blocks >= (int64_t)num_cus() ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   // 128 rows per workgroup either way: the rows128 kernel (the hook value 1 selects the 8-wave kernel instead)
   if (g_mla_waves_per_group == 1) {

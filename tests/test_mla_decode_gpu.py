@@ -12,7 +12,7 @@ from oracle import mla as omla
 pytestmark = pytest.mark.gpu
 
 
-def run_case(sglk, dev, dtype, seqs, page, H, splits, seed=42, q_scale=100.0, contiguous_q=False):
+def run_case(sglk, dev, dtype, seqs, page, H, splits, seed=42, q_scale=100.0, contiguous_q=False, table_tokens=0):
     g = torch.Generator().manual_seed(seed)
     bs = len(seqs)
     seq_lens = torch.tensor(seqs, dtype=torch.int32)
@@ -20,7 +20,9 @@ def run_case(sglk, dev, dtype, seqs, page, H, splits, seed=42, q_scale=100.0, co
     pack = 128 // page
     block_num = (block_num + pack - 1) // pack * pack
     q = (torch.randn(bs, H, 576, generator=g) * q_scale).to(dtype)
-    table = torch.randint(0, bs * block_num, (bs, block_num), generator=g, dtype=torch.int32)
+    # table_tokens: a page table wider than any sequence (the launch is sized - splits, and for H > 64 the MFMA shape of
+    # QK^T - by the table's width, the work by seq_lens)
+    table = torch.randint(0, bs * block_num, (bs, max(block_num, (table_tokens + 127) // 128 * pack)), generator=g, dtype=torch.int32)
     cache = torch.randn(bs * block_num, page, 576, generator=g).to(dtype)
     scale = (128 + 64) ** -0.5
     ref = omla.mla_decode(q, cache, scale, table, seq_lens)
@@ -32,7 +34,7 @@ def run_case(sglk, dev, dtype, seqs, page, H, splits, seed=42, q_scale=100.0, co
         q_nope = torch.empty((H, bs, 512), dtype=dtype, device=dev).transpose(0, 1)
         q_nope.copy_(qd[:, :, :512])
     q_pe = qd[:, :, 512:].clone()
-    ws_size = sglk.flash_mla_get_workspace_size(block_num * page, bs, H, page, num_kv_splits=splits)
+    ws_size = sglk.flash_mla_get_workspace_size(table.shape[1] * page, bs, H, page, num_kv_splits=splits)
     ws = torch.empty(ws_size, device=dev, dtype=torch.uint8)
     out = sglk.flash_mla_decode(q_nope, q_pe, cache.to(dev), seq_lens.to(dev), table.to(dev), ws, scale, splits)
     assert out.shape == (bs, H, 512) and out.dtype == dtype
@@ -102,6 +104,19 @@ def test_running_max_rescale_is_forced(sglk, dev):
         out = sglk.flash_mla_decode(q[..., :512].to(dev), q[..., 512:].to(dev).contiguous(), cache.to(dev),
                                     seq_lens.to(dev), table.to(dev), ws, scale, splits)
         torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mean", [128, 1024])
+@pytest.mark.parametrize("bs", [1, 4])
+@pytest.mark.parametrize("page", [16, 32, 64, 128])
+@pytest.mark.parametrize("H", [96, 128])
+def test_wide_table_16_wide_qk(sglk, dev, dtype, mean, bs, page, H):
+    """H > 64 launches that keep every CU busy for long (>= 48 tiles per CU by the table's width) run QK^T on
+    v_mfma_f32_16x16x32 (csrc/mla_decode.hip, S4): the reference grid's varlen cases behind a page table of 400k tokens -
+    ragged tails, every page size, empty splits, both dtypes on that path."""
+    idx = (mean // 128) + bs + (page // 16) + (H // 16) + (dtype == torch.float16)
+    run_case(sglk, dev, dtype, seqs_for(mean, bs, True, idx), page, H, [-1, 1, 3][idx % 3], seed=idx, table_tokens=400_000 // bs * 1)
 
 
 def test_full_size_config_sampled(sglk, dev):

@@ -59,6 +59,16 @@ def test_mla_prefill_head_counts(sglk, dev, H):
     run_case(sglk, dev, torch.bfloat16, 64, H, [37, 5, 64], [300, 5, 64], seed=H)
 
 
+@pytest.mark.parametrize("H", [16, 32, 64, 100, 128])
+def test_mla_prefill_16_wide_qk_head_slots(sglk, dev, H):
+    """grids of at least one workgroup per CU run QK^T on v_mfma_f32_16x16x32 (csrc/mla_decode.hip, S4): every (token slot,
+    head) row layout of a 128-row workgroup on that path, ragged q, unaligned k, causal and not"""
+    tpw = 128 // (16 if H <= 16 else 32 if H <= 32 else 64 if H <= 64 else 128)
+    sq = 64 * tpw + 3
+    run_case(sglk, dev, [torch.bfloat16, torch.float16][H // 16 % 2], 64, H, [sq, sq - 5, sq, 7], [sq + 190, sq + 64, sq, 333], seed=H)
+    run_case(sglk, dev, torch.bfloat16, 16, H, [sq, sq, 9, sq], [sq + 50, sq + 17, 100, sq + 1], causal=False, seed=H + 1)
+
+
 def test_mla_prefill_non_causal(sglk, dev):
     run_case(sglk, dev, torch.float16, 32, 16, [33, 7], [137, 71], causal=False)
     run_case(sglk, dev, torch.bfloat16, 128, 64, [5], [1000], causal=False)
