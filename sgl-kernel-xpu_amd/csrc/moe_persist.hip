@@ -61,6 +61,7 @@ struct MpParams {
                         // (remainders of at most 64 rows excepted: the caller's streaming kernels take them); 2 = the same
                         // blocks as 128 x 512 tiles (WIDE)
   int own_rem;          // 128-row blocks: 1 = a remainder of 1 .. 64 rows is a (partly empty) block of this launch too: no tail launch
+  int64_t total_m;      // KSPL > 1: rows of the whole problem = rows of one fp32 slab of `out`
   const int32_t* rows;  // [E]
   int E, N, K, fuse;    // fuse: 0 none, 1 silu, 2 gelu (tanh), 3 relu2, 4 clamped swiglu (1, 2, 4 gated: N = gate + up rows)
   float act_limit;
@@ -96,16 +97,22 @@ struct MpTile {
 // fragments past them (the m-steps of the 256-row form): the same 32 MFMAs per wave, K block and barrier, the same register
 // budget, the same LDS reads per MFMA as a 256 x 256 tile. Stage: a 16 KiB + b 64 KiB, two stages = all 160 KiB of LDS.
 // Gated epilogues: n-fragments 0, 1 of a wave are gate columns, 2, 3 the up columns that go with them.
-template <typename T, int FMT, int MS, bool BIAS = false, bool WIDE = false>
+// KSPL = 2 (128-row blocks of a projection with few column blocks and a long K - the Mixtral down projection at 512 tokens is
+// 128 tiles of 224 K blocks on 256 CUs): a unit is (tile, half of K); both halves store their fp32 accumulators - no
+// activation, the bias in half 0 - into slab `half` of out = float [2][total_m][N]; the consumer (apply_shuffle_mul_sum's
+// split form, moe_routing.hip) adds the two slabs - a two-term fp32 sum is the same in either order - and rounds once.
+template <typename T, int FMT, int MS, bool BIAS = false, bool WIDE = false, int KSPL = 1>
 __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   static_assert(!WIDE || MS == 4, "the wide tile streams four weight fragments per K block");
+  static_assert(KSPL == 1 || (MS == 2 && !WIDE && !BIAS), "the K split exists for the 128-row blocks");
+  constexpr int OES = KSPL > 1 ? 4 : 2;  // bytes per output element
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][a tile, b tile]
   constexpr bool W4 = FMT != 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int K = p.K, N = p.N;
-  const int nkb = K >> 6;  // >= 2
+  const int nkb = (K >> 6) / KSPL;  // K blocks of a unit, >= 2 (three stages: >= 3)
   // (an opaque scalar: left as an expression the compiler re-evaluates `fuse` with a branch ladder at every use inside the K loop)
   const bool gated = __builtin_amdgcn_readfirstlane((int)(p.fuse == 1 || p.fuse == 2 || p.fuse == 4)) != 0;
   const int Nout = gated ? N >> 1 : N;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     else if (prio47_ == 3) __builtin_amdgcn_s_setprio(3);
   }
   const uint64_t st_c0 = stamps_ ? __builtin_amdgcn_s_memtime() : 0, st_r0 = stamps_ ? __builtin_amdgcn_s_memrealtime() : 0;
-  const int nt = MB * NB;
+  const int nt = MB * NB * KSPL;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int q8 = nt >> 3, rem = nt & 7;
   const int run_first = xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8;
@@ -170,7 +177,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   auto describe = [&](int unit) -> MpTile {  // unit >= n_units: the null tile
     MpTile d;
     const bool live = unit < n_units;
-    const int tile = live ? run_first + slot + unit * slots : 0;
+    const int unit_id = live ? run_first + slot + unit * slots : 0;
+    const int tile = unit_id / KSPL, kh = unit_id - tile * KSPL;  // (the halves of a tile are neighbours: one XCD)
     const int mblk = tile / NB, cb = tile - mblk * NB;
     // (expert, block of its rows) of row block mblk: lanes = experts, wave prefix sums (moe_tiles.h)
     int e = 0, row0 = 0, rows_e = 0, blk = 0, base_b = 0, base_r = 0;
@@ -201,19 +209,24 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     const int c0 = gated ? cb * (kRowsB / 2) : cb * kRowsB;          // first output column (gated: = first gate row)
     const int cols = gated ? (Nout - c0 < kRowsB / 2 ? Nout - c0 : kRowsB / 2) : (N - c0 < kRowsB ? N - c0 : kRowsB);
     d.ncols = cols;
-    d.pa = (const char*)p.act + (int64_t)m0 * a_row;
-    d.pb = (const char*)p.w + (int64_t)e * b_exp + (int64_t)c0 * b_row;
-    d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + c0) * kgroups * kSB : nullptr;
-    d.pz = FMT == 3 ? (const char*)p.zeros + ((int64_t)e * N + c0) * kgroups * 2 : nullptr;
-    d.po = (char*)p.out + ((int64_t)m0 * Nout + c0) * 2;
+    // (K split: the unit's K range starts k0 elements into every row; k0 is a multiple of the scale group, host-checked)
+    const int k0 = kh * nkb * 64;
+    const uint32_t koff_a = (uint32_t)k0 * 2u, koff_b = W4 ? (uint32_t)(k0 >> 1) : (uint32_t)k0 * 2u;
+    const uint32_t koff_s = W4 ? (uint32_t)(k0 >> gshift) * (uint32_t)kSB : 0u, koff_z = (uint32_t)(k0 >> gshift) * 2u;
+    d.pa = (const char*)p.act + (int64_t)m0 * a_row + koff_a;
+    d.pb = (const char*)p.w + (int64_t)e * b_exp + (int64_t)c0 * b_row + koff_b;
+    d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + c0) * kgroups * kSB + koff_s : nullptr;
+    d.pz = FMT == 3 ? (const char*)p.zeros + ((int64_t)e * N + c0) * kgroups * 2 + koff_z : nullptr;
+    d.po = (char*)p.out + (((int64_t)kh * p.total_m + m0) * Nout + c0) * OES;
     d.pbs = BIAS ? (const char*)(p.bias + (int64_t)e * N + c0) : nullptr;
     d.nrec_bs = (live && BIAS) ? (uint32_t)((N - c0) * 4) : 0u;
-    d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * a_row + (int64_t)K * 2) : 0u;
+    d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * a_row + (int64_t)K * 2) - koff_a : 0u;
     // (b: the resource spans the expert's rows from the tile's first one to row N - 1: weight rows past N read zeros)
-    d.nrec_b = live ? (uint32_t)((int64_t)(N - c0) * b_row) : 0u;
-    d.nrec_o = live ? (uint32_t)(((int64_t)(rows_a - 1) * Nout + cols) * 2) : 0u;
+    d.nrec_b = live ? (uint32_t)((int64_t)(N - c0) * b_row) - koff_b : 0u;
+    d.nrec_o = live ? (uint32_t)(((int64_t)(rows_a - 1) * Nout + cols) * OES) : 0u;
     // (weight rows past N of an edge tile: their scales lie past the tensor too - out of range, read as zero)
-    d.nrec_s = (live && W4) ? (uint32_t)((int64_t)(N - c0) * kgroups * kSB) : 0u;
+    // (FMT 3 reads scales and zero points - both two bytes per group - under this one range)
+    d.nrec_s = (live && W4) ? (uint32_t)((int64_t)(N - c0) * kgroups * kSB) - koff_s : 0u;
     return d;
   };
   auto pick = [](bool c, const MpTile& x, const MpTile& y) -> MpTile {
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // (wide tile: row wm * 64 + 32 hf + i of held fragment hf; columns wn * 128 + 32 nf + 16 h .. of streamed fragment nf,
   // gated wn * 64 + 32 nf + 16 h .. for nf = 0, 1)
   const uint32_t orow_off = WIDE ? (uint32_t)(((int64_t)(wm * 64 + li) * Nout + (gated ? wn * 64 : wn * 128) + lh * 16) * 2)
-                                 : (uint32_t)(((int64_t)(wm * (MS * 32) + li) * Nout + (gated ? wn * 32 : wn * 64) + lh * 16) * 2);
+                                 : (uint32_t)(((int64_t)(wm * (MS * 32) + li) * Nout + (gated ? wn * 32 : wn * 64) + lh * 16) * OES);
   auto act_mul = [&](float x, float y) -> float {
     if (p.fuse == 4) {
       x = fminf(x, p.act_limit);
@@ -387,7 +400,23 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   };
   auto store_frag = [&](const MpTile& d, const v16f (&accm)[2], int mf) {
     const __amdgpu_buffer_rsrc_t ro = mp_rsrc(d.po, d.nrec_o);
-    const int soff = __builtin_amdgcn_readfirstlane(mf * 32 * Nout * 2);
+    const int soff = __builtin_amdgcn_readfirstlane(mf * 32 * Nout * OES);
+    if constexpr (KSPL > 1) {  // the fp32 accumulators as they are: 64 bytes per lane and n-fragment
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int col = wn * 64 + nf * 32 + lh * 16 + q4 * 4;
+          const uint32_t vo = col < d.ncols ? orow_off + (uint32_t)((nf * 32 + q4 * 4) * 4) : 0x80000000u;
+          // (through float temporaries: __builtin_bit_cast on a vector-element lvalue read element 0 for every index)
+          const float f0 = accm[nf][q4 * 4], f1 = accm[nf][q4 * 4 + 1], f2 = accm[nf][q4 * 4 + 2], f3 = accm[nf][q4 * 4 + 3];
+          const v4i data = {(int)__float_as_uint(f0), (int)__float_as_uint(f1), (int)__float_as_uint(f2), (int)__float_as_uint(f3)};
+          __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, 0);
+          asm volatile("s_nop 4" ::"v"(data));
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
       if (gated && nf == 1) break;
@@ -748,6 +777,7 @@ constexpr int g_mp_prio47 = 0;
 #ifdef SGLK_PROBES
 static int g_mp_own_tails = 0;
 static int g_mp_wide = 1;
+static int g_mp_splitk = 1;  // (sglk_debug_set_moe_splitk: 0 = the K split of the down projection off, for A / B timing)
 #else
 constexpr int g_mp_own_tails = 0;
 constexpr int g_mp_wide = 1;
@@ -832,6 +862,7 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
   p.stamps = g_mp_stamps;
   p.prio47 = g_mp_prio47;
   p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.bias = bias;  p.gshift = group_shift;  p.rows = rows;
+  p.total_m = total_m;
   p.E = E;  p.N = N;  p.K = K;  p.fuse = fuse;  p.act_limit = act_limit;  p.ldb = ldb;  p.stride_e = stride_e;
   int rc;
   const int fmt = w4 == 1 && zeros != nullptr ? 3 : w4;
@@ -850,9 +881,69 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
   return rc ? rc : (blocks128 ? (p.own_rem ? 3 : 2) : 1);
 }
 
+// ---- K split of the 128-row blocks (4-bit weights, no bias, no activation: the down projection of fused_experts) ----
+// Applies when the 128 x 256 tiles of the FULL 128-row blocks are at most ~5/8 of the CUs, so that two units per tile fit one
+// round (an expert's remainder of more than 64 rows is a block too: up to E more row blocks, i.e. a second round of half-length
+// units at worst - never more K blocks per CU than without the split), K halves are whole scale groups and at least four K
+// blocks long. Remainders of 1 .. 64 rows stay with the caller's streaming kernels (kMoeTailFlag128) and go to `out`.
+bool moe_persist_splitk_applies(int64_t total_m, int E, int N, int K, int group_shift, int w4, int dtype) {
+#ifdef SGLK_PROBES
+  if (g_mp_splitk == 0) return false;
+#endif
+  if (num_cus() % 8 != 0 || E <= 0) return false;
+  if (total_m < (int64_t)kMinAvgRows128 * E || total_m >= (int64_t)kMinAvgRows * E) return false;  // the 128-row-block regime
+  if (w4 != 1 && w4 != 2) return false;
+  if (w4 == 2 && dtype != SGLK_BF16) return false;
+  const int gsh = w4 == 2 ? 5 : group_shift;
+  if (K % 128 != 0 || (K / 2) % (1 << gsh) != 0 || K / 128 < 4) return false;
+  if (N % 8 != 0) return false;
+  const int64_t nb_cols = (N + 255) / 256;
+  return (total_m / 128) * nb_cols * 8 <= (int64_t)num_cus() * 5;
+}
+
+// Launches the split form over the full 128-row blocks; returns 0 when it does not apply, 2 when launched (the caller runs the
+// remainders of 1 .. 64 rows in kMoeTailFlag128 mode into its 16-bit `out`), a negative error code on failure.
+int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const void* w, const void* scales, const void* zeros,
+                           int group_shift, const int32_t* rows, int64_t total_m, int E, int N, int K, int dtype, int w4) {
+  if (!moe_persist_splitk_applies(total_m, E, N, K, group_shift, w4, dtype)) return 0;
+  if ((uintptr_t)ws % 16 != 0 || (uintptr_t)act % 16 != 0 || (uintptr_t)w % 16 != 0) return 0;
+  const int64_t b_row = K / 2;
+  if ((int64_t)N * b_row >= (1ll << 32) || 264ll * K * 2 >= (1ll << 32) || 256ll * N * 4 + 1024 >= (1ll << 31) ||
+      (w4 == 1 && (group_shift < 5 || group_shift > 8 || (uintptr_t)scales % 2 != 0 || (uintptr_t)zeros % 2 != 0 ||
+                   (int64_t)N * (K >> group_shift) * 2 >= (1ll << 31))) ||
+      (w4 == 2 && (int64_t)N * (K / 32) >= (1ll << 31)))
+    return 0;
+  MpParams p;
+  p.blocks128 = 1;
+  p.own_rem = 0;
+  p.stamps = g_mp_stamps;
+  p.prio47 = g_mp_prio47;
+  p.out = ws;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.bias = nullptr;  p.gshift = group_shift;  p.rows = rows;
+  p.total_m = total_m;
+  p.E = E;  p.N = N;  p.K = K;  p.fuse = 0;  p.act_limit = 0.f;  p.ldb = 0;  p.stride_e = 0;
+  constexpr int kLds2 = 3 * (kTile / 2 + kTile);
+  const int fmt = w4 == 1 && zeros != nullptr ? 3 : w4;
+#define MP_GO_SPLIT(TT, FF)                                                                                         \
+  {                                                                                                                 \
+    static unsigned long long attr_done = 0;                                                                        \
+    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<TT, FF, 2, false, false, 2>), kLds2, \
+                                 &attr_done, "moe_persist"))                                                        \
+      return rc;                                                                                                    \
+    moe_persist_kernel<TT, FF, 2, false, false, 2><<<(unsigned)num_cus(), 512, kLds2, st>>>(p);                     \
+  }
+  if (dtype == SGLK_BF16) {
+    if (fmt == 3) MP_GO_SPLIT(bf16, 3) else if (fmt == 2) MP_GO_SPLIT(bf16, 2) else MP_GO_SPLIT(bf16, 1)
+  } else {
+    if (fmt == 3) MP_GO_SPLIT(f16, 3) else MP_GO_SPLIT(f16, 1)
+  }
+#undef MP_GO_SPLIT
+  return 2;
+}
+
 }  // namespace sglk
 
 #ifdef SGLK_PROBES
+extern "C" SGLK_API void sglk_debug_set_moe_splitk(int on) { sglk::g_mp_splitk = on; }
 // Diagnostic build only. Clock stamps of the tile pipeline: 256 x 4 uint32, one record per workgroup of the last launch
 // {shader cycles, 100 MHz ticks, K blocks, m-steps}, followed by 256 x 8 x 2 uint32: per wave the shader cycles spent in
 // front of the K blocks' barriers waiting for its own LDS-DMA / LDS data, and at the barriers themselves (5120 uint32).

@@ -294,6 +294,64 @@ __global__ __launch_bounds__(256) void shuffle_mul_sum_kernel(const T* __restric
   }
 }
 
+// The same combine behind a down projection whose K range was split in two (moe_persist.hip, KSPL = 2): source row r of a full
+// 128-row block is T(ws[0][r] + ws[1][r]) - the one rounding the GEMM's own store would have made - and a row of an expert's
+// remainder of 1 .. 64 rows (the streaming kernels' share) is y[r]. Which one: from rows_per_expert, as the GEMM's tile walk does.
+template <typename T, typename W>
+__global__ __launch_bounds__(256) void shuffle_mul_sum_splitk_kernel(const T* __restrict__ y, const float* __restrict__ ws,
+                                                                     T* __restrict__ out, const int32_t* __restrict__ perm,
+                                                                     const W* __restrict__ factors,
+                                                                     const int32_t* __restrict__ rows_per_expert, int E,
+                                                                     int64_t total_m, int topk, int hidden, float rsf,
+                                                                     bool use_rsf) {
+  constexpr int V = 4;  // 16 bytes of fp32 per lane and slab
+  const int64_t tok = blockIdx.x;
+  __shared__ int s_tail[16];  // per top-k slot: 1 = the row is in y
+  if ((int)threadIdx.x < topk) {
+    const int src = perm[tok * topk + threadIdx.x];
+    int base = 0, tail = 0;
+    for (int e = 0; e < E; ++e) {
+      const int r = rows_per_expert[e];
+      if (src >= base && src < base + r) {
+        const int rem = r & 127;
+        tail = (rem >= 1 && rem <= 64 && src - base >= r - rem) ? 1 : 0;
+        break;
+      }
+      base += r;
+    }
+    s_tail[threadIdx.x] = tail;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x * V; c < hidden; c += 256 * V) {
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    for (int j = 0; j < topk; ++j) {
+      const int64_t src = perm[tok * topk + j];
+      const float w = factors ? (float)factors[tok * topk + j] : 1.0f;
+      Vec<T, V> x;
+      if (s_tail[j]) {
+        x = load_vec<T, V>(y + src * hidden + c);
+      } else {
+        const Vec<float, V> p0 = load_vec<float, V>(ws + src * hidden + c);
+        const Vec<float, V> p1 = load_vec<float, V>(ws + (total_m + src) * hidden + c);
+#pragma unroll
+        for (int i = 0; i < V; ++i) x[i] = (T)__fadd_rn(p0[i], p1[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float t = __fmul_rn((float)x[i], w);
+        if (use_rsf) t = __fmul_rn(t, rsf);
+        acc[i] = __fadd_rn(acc[i], t);
+      }
+    }
+    Vec<T, V> o;
+#pragma unroll
+    for (int i = 0; i < V; ++i) o[i] = (T)acc[i];
+    store_vec<T, V>(out + tok * hidden + c, o);
+  }
+}
+
 template <typename IdT>
 static int align_launch(hipStream_t st, const void* ids, int32_t* sorted, int32_t* eids, int32_t* total,
                         int32_t* cumsum, int num_experts, int block_size, int64_t numel, bool pad) {
@@ -405,4 +463,35 @@ extern "C" int sglk_apply_shuffle_mul_sum(sglk_stream_t stream, const void* inpu
     }
   });
   return check_launch("apply_shuffle_mul_sum");
+}
+
+extern "C" int sglk_apply_shuffle_mul_sum_splitk(sglk_stream_t stream, const void* y, const float* ws, void* output,
+                                                 const int32_t* permutation, const void* factors,
+                                                 const int32_t* rows_per_expert, int64_t n_experts, int64_t total_m,
+                                                 int64_t tokens, int64_t topk, int64_t hidden, float routed_scaling_factor,
+                                                 int dtype, int factors_dtype) {
+  using namespace sglk;
+  SGLK_REQUIRE(topk > 0 && topk <= 16, "apply_shuffle_mul_sum_splitk: topk must be in [1, 16]");
+  SGLK_REQUIRE(hidden > 0 && hidden % 8 == 0, "apply_shuffle_mul_sum_splitk: hidden size must be a positive multiple of 8");
+  SGLK_REQUIRE(n_experts > 0 && n_experts < (1ll << 20) && total_m >= 0 && total_m < (1ll << 31),
+               "apply_shuffle_mul_sum_splitk: bad n_experts / total_m");
+  SGLK_REQUIRE((uintptr_t)y % 16 == 0 && (uintptr_t)ws % 16 == 0 && (uintptr_t)output % 16 == 0,
+               "apply_shuffle_mul_sum_splitk: y, ws and output must be 16-byte aligned");
+  if (tokens == 0) return SGLK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool use_rsf = routed_scaling_factor != 1.0f;
+  SGLK_DISPATCH_HALF(dtype, T, {
+    if (factors == nullptr) {
+      shuffle_mul_sum_splitk_kernel<T, T><<<(unsigned)tokens, 256, 0, st>>>(
+          (const T*)y, ws, (T*)output, permutation, nullptr, rows_per_expert, (int)n_experts, total_m, (int)topk, (int)hidden,
+          routed_scaling_factor, use_rsf);
+    } else {
+      SGLK_DISPATCH_FLOAT(factors_dtype, W, {
+        shuffle_mul_sum_splitk_kernel<T, W><<<(unsigned)tokens, 256, 0, st>>>(
+            (const T*)y, ws, (T*)output, permutation, (const W*)factors, rows_per_expert, (int)n_experts, total_m, (int)topk,
+            (int)hidden, routed_scaling_factor, use_rsf);
+      });
+    }
+  });
+  return check_launch("apply_shuffle_mul_sum_splitk");
 }

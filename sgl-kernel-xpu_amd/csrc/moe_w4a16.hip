@@ -47,6 +47,10 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
                     int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
                     int fuse, float act_limit);
+// moe_persist.hip: the K split of the 128-row blocks into fp32 slabs (returns 2 after launching, 0 if it does not apply)
+int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const void* w, const void* scales, const void* zeros,
+                           int group_shift, const int32_t* rows, int64_t total_m, int E, int N, int K, int dtype, int w4);
+bool moe_persist_splitk_applies(int64_t total_m, int E, int N, int K, int group_shift, int w4, int dtype);
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -939,12 +943,44 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
                                        n_experts, N, K, group_size, is_int4, dtype, 0, 0.f, nullptr, 0);
 }
 
+static int w4a16_run(sglk_stream_t stream, void* out, const void* activations, const void* packed_weights, const void* scales,
+                     const void* zeros, const float* bias, const int32_t* rows_per_expert, int64_t total_m, int64_t n_experts,
+                     int64_t N, int64_t K, int64_t group_size, int is_int4, int dtype, int fused_act, float act_limit,
+                     const int32_t* row_map, int64_t src_rows, float* split_ws, int* split_used);
+
 extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, const void* activations,
                                              const void* packed_weights, const void* scales, const void* zeros,
                                              const float* bias, const int32_t* rows_per_expert, int64_t total_m,
                                              int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
                                              int dtype, int fused_act, float act_limit, const int32_t* row_map,
                                              int64_t src_rows) {
+  return w4a16_run(stream, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m, n_experts, N, K,
+                   group_size, is_int4, dtype, fused_act, act_limit, row_map, src_rows, nullptr, nullptr);
+}
+
+extern "C" int sglk_moe_grouped_mm_w4a16_splitk(sglk_stream_t stream, void* out, float* ws, const void* activations,
+                                                const void* packed_weights, const void* scales, const void* zeros,
+                                                const int32_t* rows_per_expert, int64_t total_m, int64_t n_experts,
+                                                int64_t N, int64_t K, int64_t group_size, int is_int4, int dtype,
+                                                int* split_used) {
+  SGLK_REQUIRE(split_used != nullptr, "moe_grouped_mm_nt_w4a16_splitk: split_used must not be NULL");
+  *split_used = 0;
+  return w4a16_run(stream, out, activations, packed_weights, scales, zeros, nullptr, rows_per_expert, total_m, n_experts, N, K,
+                   group_size, is_int4, dtype, 0, 0.f, nullptr, 0, ws, split_used);
+}
+
+extern "C" int sglk_moe_w4a16_splitk_applies(int64_t total_m, int64_t n_experts, int64_t N, int64_t K, int64_t group_size,
+                                             int is_int4, int dtype) {
+  if (total_m <= 0 || n_experts <= 0 || N <= 0 || K <= 0 || N >= (1ll << 31) || K >= (1ll << 31) || n_experts >= (1ll << 20)) return 0;
+  const int gs = !is_int4 ? 5 : group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : group_size == 256 ? 8 : -1;
+  if (gs < 0) return 0;
+  return sglk::moe_persist_splitk_applies(total_m, (int)n_experts, (int)N, (int)K, gs, is_int4 ? 1 : 2, dtype) ? 1 : 0;
+}
+
+static int w4a16_run(sglk_stream_t stream, void* out, const void* activations, const void* packed_weights, const void* scales,
+                     const void* zeros, const float* bias, const int32_t* rows_per_expert, int64_t total_m, int64_t n_experts,
+                     int64_t N, int64_t K, int64_t group_size, int is_int4, int dtype, int fused_act, float act_limit,
+                     const int32_t* row_map, int64_t src_rows, float* split_ws, int* split_used) {
   using namespace sglk;
   SGLK_REQUIRE(row_map == nullptr || (src_rows > 0 && src_rows * K < (1ll << 32)),
                "moe_grouped_mm_nt_xe20_w4a16: a row map needs 0 < src_rows and src_rows * K < 2^32 (src_rows=%lld)",
@@ -981,6 +1017,24 @@ extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, co
     explicit MapScope(const int32_t* m) { t_row_map = m; }
     ~MapScope() { t_row_map = nullptr; }
   } map_scope(row_map);
+  if (row_map == nullptr && split_ws != nullptr && bias == nullptr && fused_act == 0) {
+    // the K split of the down projection: the full 128-row blocks as fp32 partial sums in split_ws, remainders of 1 .. 64 rows
+    // on the streaming kernels into `out`
+    int rc = moe_persist_splitk_try(st, split_ws, activations, packed_weights, scales, is_int4 ? zeros : nullptr, gs, rows_per_expert,
+                                    total_m, (int)n_experts, (int)N, (int)K, dtype, is_int4 ? 1 : 2);
+    if (rc < 0) return rc;
+    if (rc == 2) {
+      *split_used = 1;
+      t_tail_flag = kMoeTailFlag128;
+      const int64_t tail_m = std::min<int64_t>(total_m, 64 * n_experts);
+      rc = dtype == SGLK_BF16 ? dispatch<bf16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, tail_m,
+                                               (int)n_experts, (int)N, (int)K, gs, fused_act)
+                              : dispatch<f16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, tail_m,
+                                              (int)n_experts, (int)N, (int)K, gs, fused_act);
+      t_tail_flag = 0;
+      return rc;
+    }
+  }
   if (row_map == nullptr) {
     if (int rc = moe_persist_try(st, out, activations, packed_weights, scales, is_int4 ? zeros : nullptr, gs, bias, rows_per_expert, total_m, (int)n_experts,
                                  (int)N, (int)K, 0, 0, dtype, is_int4 ? 1 : 2, fused_act, act_limit)) {

@@ -671,11 +671,12 @@ void apply_shuffle_mul_sum(const Tensor& input, Tensor& output, const Tensor& pe
                                        (float)routed_scaling_factor, dtype_code(input.scalar_type(), "input"), fdt));
 }
 
-static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
+// split_ws != nullptr: the K-split form (sglk_moe_grouped_mm_w4a16_splitk); returns whether the split was used
+static bool moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
                           const Tensor& scales, const std::optional<Tensor>& zeros,
                           const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
                           bool is_int4, int64_t group_size, int64_t fused_act, double act_limit,
-                          const std::optional<Tensor>& row_map = std::nullopt) {
+                          const std::optional<Tensor>& row_map = std::nullopt, Tensor* split_ws = nullptr) {
   CHECK_GPU(output);
   CHECK_GPU(activations);
   CHECK_GPU(packed_weights);
@@ -755,12 +756,78 @@ static void moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tens
     zeros_al = zeros->clone();
     zeros_ptr = zeros_al.data_ptr();
   }
+  if (split_ws != nullptr) {
+    CHECK_GPU(*split_ws);
+    TORCH_CHECK(split_ws->scalar_type() == at::kFloat && split_ws->is_contiguous() && split_ws->numel() >= 2 * total_m * gemm_n,
+                "moe_grouped_mm_nt_w4a16_splitk: ws must be a contiguous float32 tensor of at least 2 * total_m * N elements");
+    TORCH_CHECK(!bias.has_value() && fused_act == 0 && map_ptr == nullptr, "moe_grouped_mm_nt_w4a16_splitk: no bias, activation or row map");
+    int used = 0;
+    SGLK_CALL(sglk_moe_grouped_mm_w4a16_splitk(stream_of(activations), output.data_ptr(), split_ws->data_ptr<float>(),
+                                               activations.data_ptr(), packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr,
+                                               rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k, group_size,
+                                               is_int4 ? 1 : 0, dtype_code(activations.scalar_type(), "activations"), &used));
+    return used != 0;
+  }
   SGLK_CALL(sglk_moe_grouped_mm_w4a16_act(stream_of(activations), output.data_ptr(), activations.data_ptr(),
                                           packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr, bias_ptr,
                                           rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
                                           group_size, is_int4 ? 1 : 0,
                                           dtype_code(activations.scalar_type(), "activations"), (int)fused_act, (float)act_limit,
                                           map_ptr, activations.size(0)));
+  return false;
+}
+
+// authored (no reference op): the down projection of fused_experts with the K range of its tiles split in two where that
+// projection has fewer tiles than the GPU has CUs (include/sglk.h: sglk_moe_grouped_mm_w4a16_splitk). Returns True when the
+// split was used - the result is then in ws (two fp32 partial sums per row) except for the experts' remainders of 1 .. 64 rows,
+// which are in output, and apply_shuffle_mul_sum_splitk reads both - and False when output holds the whole product.
+bool moe_grouped_mm_nt_w4a16_splitk(Tensor& output, Tensor& ws, const Tensor& activations, const Tensor& packed_weights,
+                                    const Tensor& scales, const std::optional<Tensor>& zeros, const Tensor& rows_per_expert,
+                                    int64_t n_experts, bool is_int4, int64_t group_size) {
+  return moe_w4a16_impl(output, activations, packed_weights, scales, zeros, std::nullopt, rows_per_expert, n_experts, is_int4,
+                        group_size, 0, 0.0, std::nullopt, &ws);
+}
+
+// host-only: would moe_grouped_mm_nt_w4a16_splitk split this shape? (so that fused_experts allocates ws only then)
+bool moe_w4a16_splitk_applies(int64_t total_m, int64_t n_experts, int64_t n, int64_t k, int64_t group_size, bool is_int4,
+                              bool is_bf16) {
+  return sglk_moe_w4a16_splitk_applies(total_m, n_experts, n, k, group_size, is_int4 ? 1 : 0, is_bf16 ? SGLK_BF16 : SGLK_F16) != 0;
+}
+
+void apply_shuffle_mul_sum_splitk(const Tensor& y, const Tensor& ws, Tensor& output, const Tensor& permutation,
+                                  const Tensor& rows_per_expert, double routed_scaling_factor,
+                                  const std::optional<Tensor>& factors) {
+  CHECK_GPU(y);
+  CHECK_GPU(ws);
+  CHECK_GPU(output);
+  CHECK_GPU(permutation);
+  CHECK_GPU(rows_per_expert);
+  TORCH_CHECK(y.dim() == 2 && output.dim() == 2 && y.is_contiguous() && output.is_contiguous(),
+              "apply_shuffle_mul_sum_splitk: y and output must be contiguous 2-D tensors");
+  TORCH_CHECK(y.scalar_type() == output.scalar_type() && y.size(1) == output.size(1),
+              "apply_shuffle_mul_sum_splitk: y and output must share dtype and hidden size");
+  TORCH_CHECK(ws.scalar_type() == at::kFloat && ws.is_contiguous() && ws.numel() >= 2 * y.numel(),
+              "apply_shuffle_mul_sum_splitk: ws must be a contiguous float32 tensor [2, rows, hidden]");
+  TORCH_CHECK(permutation.scalar_type() == at::kInt && permutation.is_contiguous(),
+              "apply_shuffle_mul_sum_splitk: permutation must be a contiguous int32 tensor");
+  TORCH_CHECK(rows_per_expert.scalar_type() == at::kInt && rows_per_expert.is_contiguous() && rows_per_expert.dim() == 1,
+              "apply_shuffle_mul_sum_splitk: rows_per_expert must be a contiguous 1-D int32 tensor");
+  const int64_t m = output.size(0);
+  if (m == 0) return;
+  const int64_t topk = permutation.numel() / m;
+  const void* fptr = nullptr;
+  int fdt = SGLK_F32;
+  if (factors.has_value()) {
+    CHECK_GPU(*factors);
+    TORCH_CHECK(factors->is_contiguous() && factors->numel() >= m * topk, "apply_shuffle_mul_sum_splitk: bad factors tensor");
+    fptr = factors->data_ptr();
+    fdt = dtype_code(factors->scalar_type(), "factors");
+  }
+  const c10::OptionalDeviceGuard guard(y.device());
+  SGLK_CALL(sglk_apply_shuffle_mul_sum_splitk(stream_of(y), y.data_ptr(), ws.data_ptr<float>(), output.data_ptr(),
+                                              permutation.data_ptr<int32_t>(), fptr, rows_per_expert.data_ptr<int32_t>(),
+                                              rows_per_expert.numel(), y.size(0), m, topk, output.size(1),
+                                              (float)routed_scaling_factor, dtype_code(y.scalar_type(), "y"), fdt));
 }
 
 void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
@@ -1665,6 +1732,16 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
       "Tensor? zeros, Tensor? bias, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size, "
       "int activation_type, float act_limit=0.0, Tensor? row_map=None) -> ()");
   m.impl("moe_grouped_mm_nt_w4a16_act", c10::kCUDA, &moe_grouped_mm_nt_w4a16_act);
+  m.def(
+      "moe_grouped_mm_nt_w4a16_splitk(Tensor! output, Tensor! ws, Tensor activations, Tensor packed_weights, Tensor scales, "
+      "Tensor? zeros, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size) -> bool");
+  m.impl("moe_grouped_mm_nt_w4a16_splitk", c10::kCUDA, &moe_grouped_mm_nt_w4a16_splitk);
+  m.def("moe_w4a16_splitk_applies(int total_m, int n_experts, int n, int k, int group_size, bool is_int4, bool is_bf16) -> bool",
+        &moe_w4a16_splitk_applies);
+  m.def(
+      "apply_shuffle_mul_sum_splitk(Tensor y, Tensor ws, Tensor! output, Tensor permutation, Tensor rows_per_expert, float "
+      "routed_scaling_factor, Tensor? factors) -> ()");
+  m.impl("apply_shuffle_mul_sum_splitk", c10::kCUDA, &apply_shuffle_mul_sum_splitk);
   m.def(
       "prepare_moe_input(Tensor topk_ids, Tensor! expert_offsets, Tensor? blockscale_offsets, Tensor! problem_sizes1,"
       " Tensor! problem_sizes2, Tensor! input_permutation, Tensor! output_permutation, int num_experts, int n, int k)"

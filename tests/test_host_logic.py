@@ -56,8 +56,9 @@ def test_out_of_scope_names_raise_on_call_only(sglk):
 class _Recorder:
     """Stands in for torch.ops.sgl_kernel: records (op name, args) and returns what a caller needs to go on."""
 
-    def __init__(self):
+    def __init__(self, answers=None):
         self.calls = []
+        self.answers = answers or {}
 
     def __getattr__(self, name):
         rec = self
@@ -67,6 +68,8 @@ class _Recorder:
                 rec.calls.append((name, a, k))
                 if name == "swiglu_gpt_oss_sigmoid_alpha":  # (the one op of these wrappers whose result is used)
                     return a[0].new_empty(a[0].shape[0], a[0].shape[1] // 2)
+                if name in rec.answers:  # (host-side predicates: moe_w4a16_splitk_applies, moe_grouped_mm_nt_w4a16_splitk)
+                    return rec.answers[name]
                 return 0
 
             default = property(lambda self_: self_)
@@ -187,6 +190,35 @@ def _moe_case(dtype=torch.bfloat16, T=5, H=128, I=64, E=4, k=2, four_bit=True, g
     return x, w1, w2, tw, ti, s1, s2
 
 
+@pytest.mark.parametrize("applies,used", [(True, True), (True, False), (False, False)])
+def test_fused_experts_down_projection_k_split_sequence(sglk, monkeypatch, applies, used):
+    """96 .. 191 rows per expert, 4-bit weights, no b2: the down projection asks for its K split; when the op says it split, the
+    combine is the split form reading the workspace, otherwise the plain sequence - and the plain GEMM is not run twice."""
+    from sgl_kernel import moe
+
+    rec = _Recorder({"moe_w4a16_splitk_applies": applies, "moe_grouped_mm_nt_w4a16_splitk": used})
+    monkeypatch.setattr(moe, "_ops", rec)
+    monkeypatch.setattr(moe, "is_xe2_arch", lambda: True)
+    x, w1, w2, tw, ti, s1, s2 = _moe_case(T=256, E=4, k=2)  # 512 rows: 128 per expert
+    out = moe.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2, routed_scaling_factor=2.5)
+    head = ["prepare_moe_input", "scatter_tokens_to_experts", "moe_grouped_mm_nt_w4a16_act", "moe_w4a16_splitk_applies"]
+    if applies and used:
+        assert rec.names() == head + ["moe_grouped_mm_nt_w4a16_splitk", "apply_shuffle_mul_sum_splitk"]
+        gemm, comb = rec.calls[4][1], rec.calls[5][1]
+        assert gemm[1].shape == (2, 512, 128) and gemm[1].dtype == torch.float32 and gemm[0].shape == (512, 128)
+        assert comb[0] is gemm[0] and comb[1] is gemm[1] and comb[2] is out and comb[5] == 2.5 and comb[6] is tw
+        assert comb[4] is rec.calls[0][1][1]  # rows_per_expert of prepare_moe_input
+    elif applies:  # (the op ran the plain GEMM itself and said so)
+        assert rec.names() == head + ["moe_grouped_mm_nt_w4a16_splitk", "apply_shuffle_mul_sum"]
+    else:
+        assert rec.names() == head + ["moe_grouped_mm_nt_xe20_w4a16", "apply_shuffle_mul_sum"]
+    assert rec.calls[3][1] == (512, 4, 128, 64, 32, True, True)  # rows, E, N = hidden, K = inter, group, int4, bf16
+    # a bias on the down projection keeps the plain sequence (the split form has no bias path)
+    rec.calls.clear()
+    moe.fused_experts(x, w1, w2, tw, ti, b2=torch.zeros(4, 128), use_int4_w4a16=True, w1_scale=s1, w2_scale=s2)
+    assert "moe_w4a16_splitk_applies" not in rec.names() and rec.names()[-2:] == ["moe_grouped_mm_nt_xe20_w4a16", "apply_shuffle_mul_sum"]
+
+
 def test_fused_experts_plan_and_op_sequence(sglk, monkeypatch):
     from sgl_kernel import moe
 
@@ -219,8 +251,9 @@ def test_fused_experts_plan_and_op_sequence(sglk, monkeypatch):
     rec.calls.clear()
     xl, w1l, w2l, twl, til, s1l, s2l = _moe_case(T=192)
     moe.fused_experts(xl, w1l, w2l, twl, til, use_int4_w4a16=True, w1_scale=s1l, w2_scale=s2l)
+    # (96 .. 191 rows per expert: the down projection also asks whether its K split applies; the recorder says no)
     assert rec.names() == ["prepare_moe_input", "scatter_tokens_to_experts", "moe_grouped_mm_nt_w4a16_act",
-                           "moe_grouped_mm_nt_xe20_w4a16", "apply_shuffle_mul_sum"]
+                           "moe_w4a16_splitk_applies", "moe_grouped_mm_nt_xe20_w4a16", "apply_shuffle_mul_sum"]
     assert rec.calls[2][1][1].shape == (384, 128) and rec.calls[2][1][12] is None
     # gpt-oss swiglu (reference moe.py:692-697, :751-789): plain GEMM 1 to [rows, 2I], the interleaved-pairs op, GEMM 2
     rec.calls.clear()

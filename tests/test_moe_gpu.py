@@ -282,6 +282,97 @@ def test_moe_grouped_mm_w4a16_row_map_is_the_gather(sglk, dev, dtype, act_type, 
         op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25, row_map[:-1])
 
 
+def _tail_rows_mask(rows):
+    """rows of an expert's remainder of 1 .. 64 rows behind its last full 128-row block (the streaming kernels' share)"""
+    m = []
+    for r in rows:
+        rem = r % 128
+        t = rem if 1 <= rem <= 64 else 0
+        m += [False] * (r - t) + [True] * t
+    return torch.tensor(m, dtype=torch.bool)
+
+
+@pytest.mark.parametrize("fmt,dtype", [("int4", torch.bfloat16), ("int4", torch.float16), ("int4_zp", torch.bfloat16),
+                                       ("int4_zp", torch.float16), ("mxfp4", torch.bfloat16)])
+@pytest.mark.parametrize("rows,N,K,gs", [([128] * 8, 512, 1024, 128),
+                                         ([124, 106, 126, 146, 137, 133, 124, 128], 512, 1024, 128),
+                                         ([130, 200, 112, 150], 200, 1280, 128),   # edge column block, 72-row remainder block
+                                         ([191, 96, 129, 64 + 128], 256, 2048, 64),
+                                         ([97] * 16, 256, 512, 32),                # K / 2 = four K blocks: the shortest unit
+                                         ([130, 200, 112, 150], 512, 1280, 256)])  # K / 2 is not whole groups: no split
+def test_moe_grouped_mm_w4a16_splitk(sglk, dev, fmt, dtype, rows, N, K, gs):
+    """The down projection's K split (moe_persist.hip, KSPL = 2): full 128-row blocks as two fp32 partial sums in ws, remainders
+    of 1 .. 64 rows in out; bf16(ws[0] + ws[1]) against the oracle at the reference's tolerance and against the unsplit op."""
+    g = torch.Generator().manual_seed(N + K + gs + len(rows))
+    E, total = len(rows), sum(rows)
+    act = (torch.randn(total, K, generator=g) * 0.1).to(dtype)
+    if fmt == "mxfp4":
+        if gs != 128:
+            pytest.skip("mxfp4 has one group size")
+        gs = 32
+        packed = torch.randint(0, 256, (E, N, K // 2), generator=g, dtype=torch.uint8)
+        scales, zeros, is_int4 = torch.randint(118, 126, (E, N, K // 32), generator=g, dtype=torch.uint8), None, False
+    else:
+        packed, scales, zeros = make_int4(E, N, K, gs, dtype, fmt == "int4_zp", g)
+        is_int4 = True
+    d = lambda t: t.to(dev) if t is not None else None
+    rows_t = torch.tensor(rows, dtype=torch.int32, device=dev)
+    op = torch.ops.sgl_kernel
+    applies = op.moe_w4a16_splitk_applies(total, E, N, K, gs, is_int4, dtype == torch.bfloat16)
+    assert applies == ((K // 2) % gs == 0)
+    y = torch.full((total, N), float("nan"), dtype=dtype, device=dev)
+    ws = torch.full((2, total, N), float("nan"), dtype=torch.float32, device=dev)
+    used = op.moe_grouped_mm_nt_w4a16_splitk(y, ws, act.to(dev), packed.to(dev), scales.to(dev), d(zeros), rows_t, E, is_int4, gs)
+    assert used == applies
+    plain = torch.full((total, N), float("nan"), dtype=dtype, device=dev)
+    op.moe_grouped_mm_nt_xe20_w4a16(plain, act.to(dev), packed.to(dev), scales.to(dev), d(zeros), None, rows_t, E, is_int4, gs)
+    if not used:
+        assert torch.equal(y, plain), "without the split the call is the plain op"
+        assert torch.isnan(ws).all(), "... and does not touch ws"
+        return
+    tail = _tail_rows_mask(rows)
+    assert torch.isnan(y.cpu()[~tail].float()).all(), "rows of the split blocks are not written to out"
+    assert torch.isnan(ws.cpu()[:, tail]).all(), "remainder rows are not written to ws"
+    got = torch.where(tail[:, None], y.cpu().float(), (ws[0] + ws[1]).to(dtype).cpu().float())
+    assert torch.isfinite(got).all()
+    if fmt == "mxfp4":
+        ref = omoe.moe_grouped_mm_w4a16(act, packed, scales, None, None, rows_t.cpu(), 32, mxfp4=True)
+    else:
+        ref = omoe.moe_grouped_mm_w4a16(act, packed, scales, zeros, None, rows_t.cpu(), gs)
+    torch.testing.assert_close(got.to(dtype), ref, rtol=5e-2, atol=2e-2)  # reference tolerance (tests/test_moe_gemm.py:386)
+    # rows of the split blocks: the same tile arithmetic in another summation order - tight. (The remainders run on the streaming
+    # kernels, which keep the codes exact and scale in fp32, while the unsplit call may take them into the tile pipeline, which
+    # rounds code * scale once as the reference does - INTEGRATION.md note 16: those rows have the oracle check above.)
+    torch.testing.assert_close(got[~tail], plain.cpu().float()[~tail], rtol=1e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,topk,hidden", [([128] * 8, 2, 512), ([124, 106, 126, 146, 137, 133, 124, 128], 2, 4096),
+                                              ([130, 200, 112, 150, 0, 64, 65, 1], 6, 136)])
+def test_apply_shuffle_mul_sum_splitk(sglk, dev, dt, rows, topk, hidden):
+    """out[t] = T(sum_j T(x[perm[t, j]]) * w[t, j] * rsf), x[r] = y[r] for an expert's remainder of 1 .. 64 rows and
+    T(ws[0][r] + ws[1][r]) otherwise: bit-exact against that definition."""
+    g = torch.Generator().manual_seed(sum(rows) + hidden)
+    total = sum(rows)
+    total -= total % topk
+    rows = list(rows)
+    rows[0] -= sum(rows) - total
+    tokens = total // topk
+    y = torch.randn(total, hidden, generator=g).to(dt)
+    ws = torch.randn(2, total, hidden, generator=g)
+    perm = torch.randperm(total, generator=g).to(torch.int32).view(tokens, topk)
+    w = torch.rand(tokens, topk, generator=g)
+    out = torch.empty(tokens, hidden, dtype=dt, device=dev)
+    torch.ops.sgl_kernel.apply_shuffle_mul_sum_splitk(y.to(dev), ws.to(dev), out, perm.to(dev),
+                                                      torch.tensor(rows, dtype=torch.int32, device=dev), 2.5, w.to(dev))
+    tail = _tail_rows_mask(rows)
+    x = torch.where(tail[:, None], y.float(), (ws[0] + ws[1]).to(dt).float())
+    acc = torch.zeros(tokens, hidden)
+    for j in range(topk):
+        acc = acc + (x[perm[:, j].long()] * w[:, j:j + 1]) * 2.5
+    assert torch.equal(out.cpu(), acc.to(dt))
+
+
 @pytest.mark.parametrize("fmt", ["int4", "int4_zp", "mxfp4"])
 def test_moe_grouped_mm_w4a16_row_map_without_activation_on_the_k_split_shape(sglk, dev, fmt):
     """fused_act = 0 with a row_map at the shape the K-split kernel takes (few rows per expert, K = 8192, groups of 128): that

@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu
 import sgl_kernel
 dev = "cuda"
 E, Hd, I, gs, topk = 8, 4096, 14336, 128, 2
+if os.environ.get("MOE_SPLITK"):  # diagnostic build only (LD_PRELOAD=.../build/libsglk_probes.so): 0 = the down projection's K split off
+    import ctypes
+    ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
+                ).sglk_debug_set_moe_splitk(int(os.environ["MOE_SPLITK"]))
 w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
 w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
 s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01

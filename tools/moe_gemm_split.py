@@ -43,6 +43,8 @@ def clock_of(f):
             f"{wv[:, 4:, 0].mean().item():.0f}, barrier wait {wv[:, :4, 1].mean().item():.0f} / {wv[:, 4:, 1].mean().item():.0f}")
 
 
+if os.environ.get("MOE_WIDE"):  # 0: the 128-row blocks as 128 x 256 tiles (MS = 2) instead of 128 x 512
+    lib.sglk_debug_set_moe_persist_wide(int(os.environ["MOE_WIDE"]))
 if os.environ.get("MOE_PRIO"):
     lib.sglk_debug_set_moe_prio(int(os.environ["MOE_PRIO"]))
 for T in (int(a) for a in (sys.argv[1:] or ["2048"])):
