@@ -235,6 +235,191 @@ __global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream_kernel(
   }
 }
 
+// 17 - 64 rows, wide N (round 5, second form): the stream above was bound by what its workgroups pull through L2 -> L1, not by HBM:
+// with four 16-row m-tiles a wave fetches 4 KiB of activations per 2 KiB of weights, every one of the 224 workgroups the whole
+// [64 x K] activation matrix - 57 MB beside the 29 MB of weights of a 14336 x 4096 layer. Here the SAME 32 contiguous bytes per
+// lane feed v_mfma_i32_32x32x32_i8 instead: a wave covers FOUR neighbouring 32-column blocks (128 columns) x one 32-deep k block
+// per step, the m-tiles are 32 rows - 2 KiB of activations per 2 KiB of weights, and half as many workgroups (each reads the
+// activation matrix once: 29 MB).
+//   lane = (c = lane % 8, r2 = lane / 8 % 4, h = lane / 32): MFMA row i = 8 r2 + c, k half h; the lane loads bytes [32 h, 32 h + 32)
+//   of byte row c of block (4 quad + r2, k block ks): chunks e = 2 h, 2 h + 1, i.e. k = {8 h .. 8 h + 7} and {16 + 8 h ..} of the
+//   rows c, 8 + c (low nibbles) and 16 + c, 24 + c (high nibbles); MFMA t multiplies weight rows 8 t + c of the four blocks with
+//   A = {X[b], Y[b], X[2 + b], Y[2 + b]} (b = t % 2, nibble t / 2) as above; B = 16 bytes [16 h, 16 h + 16) of activation row
+//   32 mf + lane % 32 with the halves exchanged between lanes l and l + 32 (v_permlane32_swap): {8 h .., 16 + 8 h ..}.
+//   Accumulator register r of tile (mf, t): MFMA row 8 (r / 4) + 4 h + r % 4 = block r / 4, byte row 4 h + r % 4, i.e. output
+//   columns 32 (4 quad + r / 4) + 8 t + 4 h + (0..3): four consecutive fp16 per store.
+// A workgroup = 8 waves on one 128-column quad, wave w takes the 32-deep steps w, w + 8, ..; the int32 partial sums meet in LDS
+// in two passes of 128 KiB (tiles 0..3, then 4..7: tile ti belongs to wave ti).
+typedef int v16i __attribute__((ext_vector_type(16)));
+template <bool GROUP, int MF2, int KD, int KA, int KS = 8>
+__global__ __launch_bounds__(64 * KS) void qserve_w4a8_stream32_kernel(
+    f16* __restrict__ out, const int8_t* __restrict__ a, const uint8_t* __restrict__ w,
+    const int8_t* __restrict__ zeros, const int8_t* __restrict__ scales_i8, const f16* __restrict__ wscales,
+    const f16* __restrict__ ascales, const f16* __restrict__ w_szs, const f16* __restrict__ a_ssums, int M, int N,
+    int K, int64_t lda, int64_t ldc) {
+  static_assert(KD % KA == 0, "the activation ring divides the weight ring");
+  static_assert(KS == 8 || KS == 16, "8 or 16 waves split K");
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int quad = blockIdx.x;
+  const int m0 = blockIdx.y * (32 * MF2);
+  const int c = lane & 7, r2 = (lane >> 3) & 3, h = lane >> 5, i32 = lane & 31;
+  const int n32 = quad * 4 + r2;
+  const int n32c = n32 * 32 < N ? n32 : quad * 4;  // (a block past N re-reads the quad's first one and is not stored)
+
+  const uint8_t* wl = w + (int64_t)n32c * (K >> 5) * 512 + c * 64 + h * 32;
+  const int8_t* al[MF2];
+#pragma unroll
+  for (int mf = 0; mf < MF2; ++mf) {
+    int m = m0 + mf * 32 + i32;
+    m = m < M ? m : M - 1;
+    al[mf] = a + (int64_t)m * lda + h * 16;
+  }
+  const int8_t* s8 = GROUP ? scales_i8 + n32c * 32 + c * 4 : nullptr;
+  const int8_t* z8 = GROUP ? zeros + n32c * 32 + c * 4 : nullptr;
+
+  v16i acc[MF2][4];
+#pragma unroll
+  for (int mf = 0; mf < MF2; ++mf)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mf][t][r] = 0;
+
+  const int nks_all = K >> 5;                                            // 32-deep steps
+  const int nks = nks_all > wave ? (nks_all - wave + KS - 1) / KS : 0;   // this wave's steps ks = wave + KS i
+  v4i wq_[KD][2];
+  v4i aq_[KA][MF2];
+  uint32_t sq_[KD][2];
+  auto step_of = [&](int i) {
+    i = i < nks ? i : nks - 1;
+    int ks = wave + KS * (i > 0 ? i : 0);
+    return ks < nks_all ? ks : nks_all - 1;
+  };
+  auto load_w = [&](int i, v4i (&wd)[2], uint32_t (&sz)[2]) {
+    const int ks = step_of(i);
+    wd[0] = *reinterpret_cast<const v4i*>(wl + (int64_t)ks * 512);
+    wd[1] = *reinterpret_cast<const v4i*>(wl + (int64_t)ks * 512 + 16);
+    if constexpr (GROUP) {
+      const int64_t g = ks >> 2;
+      sz[0] = *reinterpret_cast<const uint32_t*>(s8 + g * N);
+      sz[1] = *reinterpret_cast<const uint32_t*>(z8 + g * N);
+    }
+  };
+  auto load_a = [&](int i, v4i (&af)[MF2]) {
+    const int ks = step_of(i);
+#pragma unroll
+    for (int mf = 0; mf < MF2; ++mf) af[mf] = *reinterpret_cast<const v4i*>(al[mf] + ks * 32);
+  };
+#pragma unroll
+  for (int d = 0; d < KD; ++d) {
+    load_w(d, wq_[d], sq_[d]);
+    if (d < KA) load_a(d, aq_[d]);
+  }
+  for (int ks0 = 0; ks0 < nks; ks0 += KD) {
+#pragma unroll
+    for (int u = 0; u < KD; ++u) {
+      const uint32_t keep = ks0 + u < nks ? 0xffffffffu : 0u;
+      uint32_t lo[2][4], hi[2][4];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t wd = (uint32_t)wq_[u][x][e] & keep;
+          lo[x][e] = wd & 0x0f0f0f0fu;
+          hi[x][e] = (wd >> 4) & 0x0f0f0f0fu;
+        }
+      v4i wop[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int b = t & 1;
+        uint32_t d4[4] = {t < 2 ? lo[0][b] : hi[0][b], t < 2 ? lo[1][b] : hi[1][b], t < 2 ? lo[0][2 + b] : hi[0][2 + b],
+                          t < 2 ? lo[1][2 + b] : hi[1][2 + b]};
+        if constexpr (GROUP) {
+          const uint32_t sv = (sq_[u][0] >> (8 * t)) & 0xffu;
+          const uint32_t zv = ((sq_[u][1] >> (8 * t)) & 0xffu) ^ 0x80u;
+          const uint32_t smul = sv | (sv << 16);
+          const uint32_t z2 = zv | (zv << 8);
+          const uint32_t zadd = (z2 | (z2 << 16)) & keep;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            d4[e] = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, d4[e]) * __builtin_bit_cast(u16x2, smul) +
+                                                         __builtin_bit_cast(u16x2, zadd))) ^ (0x80808080u & keep);
+        }
+        wop[t] = (v4i){(int)d4[0], (int)d4[1], (int)d4[2], (int)d4[3]};
+      }
+      const int ua = u % KA;
+#pragma unroll
+      for (int mf = 0; mf < MF2; ++mf) {
+        // lanes l and l + 32 of a row exchange halves: v_permlane32_swap swaps the upper 32 lanes of its first operand (h = 1's
+        // bytes 16..23) with the lower 32 lanes of its second (h = 0's bytes 8..15)
+        v4i bop = aq_[ua][mf];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3"
+                     : "+v"(bop[0]), "+v"(bop[1]), "+v"(bop[2]), "+v"(bop[3]));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mf][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wop[t], bop, acc[mf][t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(ks0 + u + KD, wq_[u], sq_[u]);
+      load_a(ks0 + u + KA, aq_[ua]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- K-split reduction in passes of TPP tiles (128 KiB of LDS: 4 tiles of 8 waves, 2 of 16; tile (mf, t) belongs to wave
+  // (4 mf + t) % KS) and epilogue
+  extern __shared__ __attribute__((aligned(16))) int red[];  // [KS][TPP tiles][4 register groups][64 lanes] x v4i = 128 KiB
+  v4i* red4 = reinterpret_cast<v4i*>(red);
+  constexpr int TPP = 32 / KS;
+#pragma unroll
+  for (int mf = 0; mf < MF2; ++mf) {
+#pragma unroll
+    for (int t0 = 0; t0 < 4; t0 += TPP) {
+      if (mf > 0 || t0 > 0) __syncthreads();  // (the owners of the pass before are done reading)
+#pragma unroll
+      for (int tt = 0; tt < TPP; ++tt) {
+        const int t = t0 + tt;
+        if ((mf * 4 + t) % KS != wave) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            red4[((wave * TPP + tt) * 4 + q) * 64 + lane] =
+                (v4i){acc[mf][t][4 * q], acc[mf][t][4 * q + 1], acc[mf][t][4 * q + 2], acc[mf][t][4 * q + 3]};
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int tt = 0; tt < TPP; ++tt) {
+        const int t = t0 + tt;
+        if ((mf * 4 + t) % KS != wave) continue;
+        const int m = m0 + mf * 32 + i32;
+        const float sa = m < M ? (float)ascales[m] : 0.f;
+        const float asum = (GROUP || m >= M) ? 0.f : (float)a_ssums[m];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // register group q = column block q of the quad
+          v4i sum = (v4i){acc[mf][t][4 * q], acc[mf][t][4 * q + 1], acc[mf][t][4 * q + 2], acc[mf][t][4 * q + 3]};
+#pragma unroll
+          for (int w2 = 0; w2 < KS; ++w2)
+            if (w2 != wave) {
+              const v4i o = red4[((w2 * TPP + tt) * 4 + q) * 64 + lane];
+              sum[0] += o[0]; sum[1] += o[1]; sum[2] += o[2]; sum[3] += o[3];
+            }
+          const int n = (quad * 4 + q) * 32 + t * 8 + h * 4;
+          if (m >= M || n >= N) continue;
+          Vec<f16, 4> o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = (float)sum[r] * sa * (float)wscales[n + r];
+            if constexpr (!GROUP) v -= asum * (float)w_szs[n + r];
+            o[r] = (f16)v;
+          }
+          store_vec<f16, 4>(out + (int64_t)m * ldc + n, o);
+        }
+      }
+    }
+  }
+}
+
 // Many rows (M > 64): a 128 x 128 tile per workgroup, 4 waves as 2 (m) x 2 (n), a wave owns 64 rows x two 32-column
 // weight blocks = 4 x 4 MFMA tiles. The activation tile [128 rows][64 B] of a k step is staged ONCE per workgroup in LDS
 // (two 64-deep steps per stage: global -> registers two stages ahead -> LDS one stage ahead, two buffers, one LDS-only
@@ -452,8 +637,20 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
     if (ks == 1) SGLK_GO_STREAM(MF, 1, KD, KA) else if (ks == 2) SGLK_GO_STREAM(MF, 2, KD, KA)                   \
     else if (ks == 4) SGLK_GO_STREAM(MF, 4, KD, KA) else SGLK_GO_STREAM(MF, 8, KD, KA)                           \
   }
+#define SGLK_GO_STREAM32(MF2, KD, KA) SGLK_GO_STREAM32_KS(MF2, KD, KA, 8)
+#define SGLK_GO_STREAM32_KS(MF2, KD, KA, KS)                                                                     \
+  {                                                                                                              \
+    constexpr int lds = 8 * 4 * 4 * 64 * 16;                                                                     \
+    static unsigned long long attr_done = 0;                                                                     \
+    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&qserve_w4a8_stream32_kernel<GROUP, MF2, KD, KA, KS>), lds, &attr_done, \
+                                 "qserve_w4a8"))                                                                 \
+      return rc;                                                                                                 \
+    qserve_w4a8_stream32_kernel<GROUP, MF2, KD, KA, KS><<<dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, 32 * MF2)), 64 * KS, lds, st>>>( \
+        (f16*)out, (const int8_t*)a, (const uint8_t*)w, (const int8_t*)zeros, (const int8_t*)scales_i8,          \
+        (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc); \
+  }
 #ifdef SGLK_PROBES
-  if (g_qserve_cfg != 0 && M <= 64) {  // forced configuration: 10000 mf + 1000 log2(ks) + 10 kd + ka
+  if (g_qserve_cfg > 1 && M <= 64) {  // forced configuration: 10000 mf + 1000 log2(ks) + 10 kd + ka (1: the stream kernel where the 32x32x32 form is the default)
     switch (g_qserve_cfg) {
       case 43082: SGLK_GO_STREAM(4, 8, 8, 2) break;
       case 43042: SGLK_GO_STREAM(4, 8, 4, 2) break;
@@ -470,12 +667,32 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
       case 13084: SGLK_GO_STREAM(1, 8, 8, 4) break;
       case 14044: SGLK_GO_STREAM(1, 16, 4, 4) break;
       case 14042: SGLK_GO_STREAM(1, 16, 4, 2) break;
+      case 320022: SGLK_GO_STREAM32(2, 2, 2) break;
+      case 320042: SGLK_GO_STREAM32(2, 4, 2) break;
+      case 320044: SGLK_GO_STREAM32(2, 4, 4) break;
+      case 320082: SGLK_GO_STREAM32(2, 8, 2) break;
+      case 320084: SGLK_GO_STREAM32(2, 8, 4) break;
+      case 311011: SGLK_GO_STREAM32_KS(1, 1, 1, 16) break;
+      case 311022: SGLK_GO_STREAM32_KS(1, 2, 2, 16) break;
+      case 311021: SGLK_GO_STREAM32_KS(1, 2, 1, 16) break;
+      case 310022: SGLK_GO_STREAM32(1, 2, 2) break;
+      case 310021: SGLK_GO_STREAM32(1, 2, 1) break;
+      case 310011: SGLK_GO_STREAM32(1, 1, 1) break;
+      case 310042: SGLK_GO_STREAM32(1, 4, 2) break;
+      case 310044: SGLK_GO_STREAM32(1, 4, 4) break;
+      case 310084: SGLK_GO_STREAM32(1, 8, 4) break;
       default: return SGLK_OK;
     }
     return check_launch("qserve_w4a8(cfg)");
   }
 #endif
-  if (M <= 64) {
+  // 33 - 64 rows at wide N (round 5): the 32x32x32 form, one 32-row m-tile per workgroup - at 14336 x 4096 and 64 rows 12.4 us
+  // per channel / 13.4 per group against 14.5 / 15.1 for the stream above (48 rows: 12.1 / 13.1 against 13.2 / 13.5); two m-tiles
+  // per workgroup (half the workgroups, the weights streamed once) lose to it - 18 us: 112 CUs then carry all the int8 MFMAs;
+  // up to 32 rows and at narrow N (under 192 workgroups) the stream above stays faster (N = 4096, 64 rows: 8.6 against 11.6 us)
+  if (M > 40 && M <= 64 && cdiv(N, 128) * cdiv(M, 32) >= 192 && g_qserve_cfg != 1) {
+    SGLK_GO_STREAM32(1, 1, 1)
+  } else if (M <= 64) {
     if (mf == 1) {
       // (ring depths from the round-5 sweep at N = 4096 / 14336, K = 4096, 1 - 64 rows: shallow activation rings win everywhere, a
       //  weight ring over a wave's whole k range does not - 16.1 us at (4 m-tiles, 8 waves, 8, 2) against 14.8 at (4, 8, 2, 2))
@@ -490,6 +707,8 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
         (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc);
   }
 #undef SGLK_GO_STREAM_KS
+#undef SGLK_GO_STREAM32
+#undef SGLK_GO_STREAM32_KS
 #undef SGLK_GO_STREAM
 #undef SGLK_GO_STREAM_IL
   return check_launch(GROUP ? "qserve_w4a8_per_group_gemm" : "qserve_w4a8_per_chn_gemm");

@@ -55,6 +55,28 @@ def test_per_group(sglk, dev, M, N, K):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("M", [33, 48, 64])
+@pytest.mark.parametrize("N,K", [(12320, 512), (14336, 384), (12288, 128)])
+def test_wide_n_33_to_64_rows(sglk, dev, M, N, K):
+    """33 - 64 rows at N >= 12288: qserve_w4a8_stream32_kernel (v_mfma_i32_32x32x32_i8, four 32-column blocks per wave, K split
+    over eight waves - with K = 128 half of them have no step, with K = 384 half have one more than the others; N = 12320 ends in
+    a quad with one real block). Integer accumulation exact: per group against the oracle at 1 fp16 ulp, per channel with the
+    exact row sums."""
+    a, b = make(M, N, K, M + N + K)
+    a_q, a_scale = oq.sym_quantize(a)
+    b_q, b_scale, b_zero = oq.asym_quantize_u4(b)
+    w, ws, wsz = oq.per_chn_inputs(b_q, b_scale, b_zero)
+    a_sum_q = (a_q.float().sum(dim=-1, keepdim=True) * a_scale.float()).to(torch.float16)
+    out = sglk.qserve_w4a8_per_chn_gemm(a_q.to(dev), w.to(dev), ws.to(dev), a_scale.to(dev), wsz.to(dev), a_sum_q.to(dev))
+    ref = oq.w4a8_per_chn_gemm(a_q, b_q, a_scale, b_scale, b_zero)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=2e-3, atol=2e-3)
+    b_q, chn, s8, z8 = oq.progressive_group_quantize(b)
+    w, ws, s8f, z8f = oq.per_group_inputs(b_q, chn, s8, z8)
+    out = sglk.qserve_w4a8_per_group_gemm(a_q.to(dev), w.to(dev), z8f.to(dev), s8f.to(dev), ws.to(dev), a_scale.to(dev))
+    ref = oq.w4a8_per_group_gemm(a_q, b_q, a_scale, chn, s8, z8)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-5)
+
+
 def test_golden_vectors(sglk, dev):
     g = load_golden("qserve_w4a8")
     for c in g["chn"]:
