@@ -315,10 +315,11 @@ SGLK_API int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, cons
 
 /* authored (no reference op): the DOWN projection of fused_experts (no bias, no activation) with the K range of every
  * 128 x 256 tile split over two workgroups, for the row counts at which that projection has fewer tiles than the GPU has CUs
- * (Mixtral: hidden 4096 = 16 column blocks x 8 row blocks of 224 K blocks at 512 tokens). When the split is used
- * (*split_used = 1) the rows of every full 128-row block of an expert - and of a remainder of more than 64 rows - are in
- * ws = float [2][total_m][N] as two fp32 partial sums (their sum, rounded once, is the GEMM's value), and only the rows of an
- * expert's remainder of 1 .. 64 rows are in out; sglk_apply_shuffle_mul_sum_splitk consumes both. When it is not used
+ * (Mixtral: hidden 4096 = 16 column blocks x 8 row blocks of 224 K blocks at 512 tokens and again, with 256-row blocks, at
+ * 1024). When the split is used (*split_used = the row block, 128 or 256) the rows of every full row block of an expert - and
+ * of a remainder of more than half a block - are in ws = float [2][total_m][N] as two fp32 partial sums (their sum, rounded
+ * once, is the GEMM's value), and only the rows of an expert's remainder of 1 .. block / 2 rows are in out;
+ * sglk_apply_shuffle_mul_sum_splitk consumes both. When it is not used
  * (*split_used = 0: shape outside the regime, see sglk_moe_w4a16_splitk_applies) the call is sglk_moe_grouped_mm_w4a16
  * without a bias and ws is not touched. The reference picks a tile policy per average row count instead
  * (src/sycl/GroupGemmW4A16Xe20.cpp:266-277). */
@@ -327,14 +328,17 @@ SGLK_API int sglk_moe_grouped_mm_w4a16_splitk(sglk_stream_t stream, void* out, f
                                               const int32_t* rows_per_expert, int64_t total_m, int64_t n_experts,
                                               int64_t N, int64_t K, int64_t group_size, int is_int4, int dtype,
                                               int* split_used);
-/* host-only: 1 when sglk_moe_grouped_mm_w4a16_splitk would split this shape (so that the caller can skip allocating ws) */
+/* host-only: the row block (128 / 256) sglk_moe_grouped_mm_w4a16_splitk would split this shape with, 0 when it would not
+ * (so that the caller can skip allocating ws) */
 SGLK_API int sglk_moe_w4a16_splitk_applies(int64_t total_m, int64_t n_experts, int64_t N, int64_t K, int64_t group_size,
                                            int is_int4, int dtype);
 /* apply_shuffle_mul_sum behind a split down projection: source row r is T(ws[0][r] + ws[1][r]) unless it lies in its
- * expert's remainder of 1 .. 64 rows (from rows_per_expert [n_experts], expert-contiguous rows), then it is y[r]. */
+ * expert's remainder of 1 .. block_rows / 2 rows (from rows_per_expert [n_experts], expert-contiguous rows; block_rows =
+ * *split_used of the GEMM call), then it is y[r]. */
 SGLK_API int sglk_apply_shuffle_mul_sum_splitk(sglk_stream_t stream, const void* y, const float* ws, void* output,
                                                const int32_t* permutation, const void* factors,
-                                               const int32_t* rows_per_expert, int64_t n_experts, int64_t total_m,
+                                               const int32_t* rows_per_expert, int64_t n_experts, int64_t block_rows,
+                                               int64_t total_m,
                                                int64_t tokens, int64_t topk, int64_t hidden,
                                                float routed_scaling_factor, int dtype, int factors_dtype);
 

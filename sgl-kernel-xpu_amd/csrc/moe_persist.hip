@@ -104,7 +104,7 @@ struct MpTile {
 template <typename T, int FMT, int MS, bool BIAS = false, bool WIDE = false, int KSPL = 1>
 __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   static_assert(!WIDE || MS == 4, "the wide tile streams four weight fragments per K block");
-  static_assert(KSPL == 1 || (MS == 2 && !WIDE && !BIAS), "the K split exists for the 128-row blocks");
+  static_assert(KSPL == 1 || (!WIDE && !BIAS), "the K split exists for the 128 x 256 and 256 x 256 tiles without a bias");
   constexpr int OES = KSPL > 1 ? 4 : 2;  // bytes per output element
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 stages][a tile, b tile]
   constexpr bool W4 = FMT != 0;
@@ -405,14 +405,18 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const int col = wn * 64 + nf * 32 + lh * 16 + q4 * 4;
-          const uint32_t vo = col < d.ncols ? orow_off + (uint32_t)((nf * 32 + q4 * 4) * 4) : 0x80000000u;
-          // (through float temporaries: __builtin_bit_cast on a vector-element lvalue read element 0 for every index)
-          const float f0 = accm[nf][q4 * 4], f1 = accm[nf][q4 * 4 + 1], f2 = accm[nf][q4 * 4 + 2], f3 = accm[nf][q4 * 4 + 3];
-          const v4i data = {(int)__float_as_uint(f0), (int)__float_as_uint(f1), (int)__float_as_uint(f2), (int)__float_as_uint(f3)};
-          __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, 0);
-          asm volatile("s_nop 4" ::"v"(data));
+        for (int hv = 0; hv < 2; ++hv) {  // (N is a multiple of 8: one range decision - one offset register - per eight columns)
+          const int col = wn * 64 + nf * 32 + lh * 16 + hv * 8;
+          const uint32_t vo = col < d.ncols ? orow_off + (uint32_t)((nf * 32 + hv * 8) * 4) : 0x80000000u;
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {
+            // (through float temporaries: __builtin_bit_cast on a vector-element lvalue read element 0 for every index)
+            const int j = hv * 8 + q2 * 4;
+            const float f0 = accm[nf][j], f1 = accm[nf][j + 1], f2 = accm[nf][j + 2], f3 = accm[nf][j + 3];
+            const v4i data = {(int)__float_as_uint(f0), (int)__float_as_uint(f1), (int)__float_as_uint(f2), (int)__float_as_uint(f3)};
+            __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)(vo + (uint32_t)(q2 * 16)), soff, 0);
+            asm volatile("s_nop 4" ::"v"(data));
+          }
         }
       }
       return;
@@ -881,31 +885,35 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
   return rc ? rc : (blocks128 ? (p.own_rem ? 3 : 2) : 1);
 }
 
-// ---- K split of the 128-row blocks (4-bit weights, no bias, no activation: the down projection of fused_experts) ----
-// Applies when the 128 x 256 tiles of the FULL 128-row blocks are at most ~5/8 of the CUs, so that two units per tile fit one
-// round (an expert's remainder of more than 64 rows is a block too: up to E more row blocks, i.e. a second round of half-length
-// units at worst - never more K blocks per CU than without the split), K halves are whole scale groups and at least four K
-// blocks long. Remainders of 1 .. 64 rows stay with the caller's streaming kernels (kMoeTailFlag128) and go to `out`.
-bool moe_persist_splitk_applies(int64_t total_m, int E, int N, int K, int group_shift, int w4, int dtype) {
+// ---- K split of the 128- / 256-row blocks (4-bit weights, no bias, no activation: the down projection of fused_experts) ----
+// Applies when the tiles of the FULL row blocks (128 x 256 below an average of 192 rows per expert, 256 x 256 from there) are
+// at most 9/16 of the CUs, so that two units per tile fit one round (an expert's remainder of more than half a block is a block
+// too: up to E more row blocks, i.e. a second round of half-length units at worst - never more K blocks per CU than without the
+// split), K halves are whole scale groups and at least four K blocks long. Remainders of up to half a block stay with the
+// caller's streaming kernels (kMoeTailFlag128 / kMoeTailFlag) and go to `out`. Returns the row block (128 / 256) or 0.
+int moe_persist_splitk_applies(int64_t total_m, int E, int N, int K, int group_shift, int w4, int dtype) {
 #ifdef SGLK_PROBES
-  if (g_mp_splitk == 0) return false;
+  if (g_mp_splitk == 0) return 0;
 #endif
-  if (num_cus() % 8 != 0 || E <= 0) return false;
-  if (total_m < (int64_t)kMinAvgRows128 * E || total_m >= (int64_t)kMinAvgRows * E) return false;  // the 128-row-block regime
-  if (w4 != 1 && w4 != 2) return false;
-  if (w4 == 2 && dtype != SGLK_BF16) return false;
+  if (num_cus() % 8 != 0 || E <= 0) return 0;
+  if (total_m < (int64_t)kMinAvgRows128 * E) return 0;  // (below: the streaming kernels)
+  const int block = total_m < (int64_t)kMinAvgRows * E ? 128 : 256;
+  if (w4 != 1 && w4 != 2) return 0;
+  if (w4 == 2 && dtype != SGLK_BF16) return 0;
   const int gsh = w4 == 2 ? 5 : group_shift;
-  if (K % 128 != 0 || (K / 2) % (1 << gsh) != 0 || K / 128 < 4) return false;
-  if (N % 8 != 0) return false;
+  if (K % 128 != 0 || (K / 2) % (1 << gsh) != 0 || K / 128 < 4) return 0;
+  if (N % 8 != 0) return 0;
   const int64_t nb_cols = (N + 255) / 256;
-  return (total_m / 128) * nb_cols * 8 <= (int64_t)num_cus() * 5;
+  return (total_m / block) * nb_cols * 16 <= (int64_t)num_cus() * 9 ? block : 0;
 }
 
-// Launches the split form over the full 128-row blocks; returns 0 when it does not apply, 2 when launched (the caller runs the
-// remainders of 1 .. 64 rows in kMoeTailFlag128 mode into its 16-bit `out`), a negative error code on failure.
+// Launches the split form over the full row blocks; returns 0 when it does not apply, 2 after launching 128-row blocks (the caller
+// runs the remainders of 1 .. 64 rows in kMoeTailFlag128 mode into its 16-bit `out`), 1 after launching 256-row blocks (remainders
+// of 1 .. 128 rows, kMoeTailFlag), a negative error code on failure.
 int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const void* w, const void* scales, const void* zeros,
                            int group_shift, const int32_t* rows, int64_t total_m, int E, int N, int K, int dtype, int w4) {
-  if (!moe_persist_splitk_applies(total_m, E, N, K, group_shift, w4, dtype)) return 0;
+  const int block = moe_persist_splitk_applies(total_m, E, N, K, group_shift, w4, dtype);
+  if (block == 0) return 0;
   if ((uintptr_t)ws % 16 != 0 || (uintptr_t)act % 16 != 0 || (uintptr_t)w % 16 != 0) return 0;
   const int64_t b_row = K / 2;
   if ((int64_t)N * b_row >= (1ll << 32) || 264ll * K * 2 >= (1ll << 32) || 256ll * N * 4 + 1024 >= (1ll << 31) ||
@@ -914,7 +922,7 @@ int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const voi
       (w4 == 2 && (int64_t)N * (K / 32) >= (1ll << 31)))
     return 0;
   MpParams p;
-  p.blocks128 = 1;
+  p.blocks128 = block == 128 ? 1 : 0;
   p.own_rem = 0;
   p.stamps = g_mp_stamps;
   p.prio47 = g_mp_prio47;
@@ -925,11 +933,18 @@ int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const voi
   const int fmt = w4 == 1 && zeros != nullptr ? 3 : w4;
 #define MP_GO_SPLIT(TT, FF)                                                                                         \
   {                                                                                                                 \
-    static unsigned long long attr_done = 0;                                                                        \
-    if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<TT, FF, 2, false, false, 2>), kLds2, \
-                                 &attr_done, "moe_persist"))                                                        \
-      return rc;                                                                                                    \
-    moe_persist_kernel<TT, FF, 2, false, false, 2><<<(unsigned)num_cus(), 512, kLds2, st>>>(p);                     \
+    static unsigned long long attr_done = 0, attr_done4 = 0;                                                        \
+    if (block == 128) {                                                                                             \
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<TT, FF, 2, false, false, 2>), kLds2, \
+                                   &attr_done, "moe_persist"))                                                      \
+        return rc;                                                                                                  \
+      moe_persist_kernel<TT, FF, 2, false, false, 2><<<(unsigned)num_cus(), 512, kLds2, st>>>(p);                   \
+    } else {                                                                                                        \
+      if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&moe_persist_kernel<TT, FF, 4, false, false, 2>), 2 * kStage, \
+                                   &attr_done4, "moe_persist"))                                                     \
+        return rc;                                                                                                  \
+      moe_persist_kernel<TT, FF, 4, false, false, 2><<<(unsigned)num_cus(), 512, 2 * kStage, st>>>(p);              \
+    }                                                                                                               \
   }
   if (dtype == SGLK_BF16) {
     if (fmt == 3) MP_GO_SPLIT(bf16, 3) else if (fmt == 2) MP_GO_SPLIT(bf16, 2) else MP_GO_SPLIT(bf16, 1)
@@ -937,7 +952,7 @@ int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const voi
     if (fmt == 3) MP_GO_SPLIT(f16, 3) else MP_GO_SPLIT(f16, 1)
   }
 #undef MP_GO_SPLIT
-  return 2;
+  return block == 128 ? 2 : 1;
 }
 
 }  // namespace sglk

@@ -295,15 +295,16 @@ __global__ __launch_bounds__(256) void shuffle_mul_sum_kernel(const T* __restric
 }
 
 // The same combine behind a down projection whose K range was split in two (moe_persist.hip, KSPL = 2): source row r of a full
-// 128-row block is T(ws[0][r] + ws[1][r]) - the one rounding the GEMM's own store would have made - and a row of an expert's
-// remainder of 1 .. 64 rows (the streaming kernels' share) is y[r]. Which one: from rows_per_expert, as the GEMM's tile walk does.
+// row block (block = 128 or 256 rows) is T(ws[0][r] + ws[1][r]) - the one rounding the GEMM's own store would have made - and a
+// row of an expert's remainder of 1 .. block / 2 rows (the streaming kernels' share) is y[r]. Which one: from rows_per_expert, as
+// the GEMM's tile walk does.
 template <typename T, typename W>
 __global__ __launch_bounds__(256) void shuffle_mul_sum_splitk_kernel(const T* __restrict__ y, const float* __restrict__ ws,
                                                                      T* __restrict__ out, const int32_t* __restrict__ perm,
                                                                      const W* __restrict__ factors,
                                                                      const int32_t* __restrict__ rows_per_expert, int E,
-                                                                     int64_t total_m, int topk, int hidden, float rsf,
-                                                                     bool use_rsf) {
+                                                                     int block, int64_t total_m, int topk, int hidden,
+                                                                     float rsf, bool use_rsf) {
   constexpr int V = 4;  // 16 bytes of fp32 per lane and slab
   const int64_t tok = blockIdx.x;
   __shared__ int s_tail[16];  // per top-k slot: 1 = the row is in y
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(256) void shuffle_mul_sum_splitk_kernel(const T* __
     for (int e = 0; e < E; ++e) {
       const int r = rows_per_expert[e];
       if (src >= base && src < base + r) {
-        const int rem = r & 127;
-        tail = (rem >= 1 && rem <= 64 && src - base >= r - rem) ? 1 : 0;
+        const int rem = r & (block - 1);
+        tail = (rem >= 1 && rem <= block / 2 && src - base >= r - rem) ? 1 : 0;
         break;
       }
       base += r;
@@ -467,10 +468,11 @@ extern "C" int sglk_apply_shuffle_mul_sum(sglk_stream_t stream, const void* inpu
 
 extern "C" int sglk_apply_shuffle_mul_sum_splitk(sglk_stream_t stream, const void* y, const float* ws, void* output,
                                                  const int32_t* permutation, const void* factors,
-                                                 const int32_t* rows_per_expert, int64_t n_experts, int64_t total_m,
-                                                 int64_t tokens, int64_t topk, int64_t hidden, float routed_scaling_factor,
-                                                 int dtype, int factors_dtype) {
+                                                 const int32_t* rows_per_expert, int64_t n_experts, int64_t block_rows,
+                                                 int64_t total_m, int64_t tokens, int64_t topk, int64_t hidden,
+                                                 float routed_scaling_factor, int dtype, int factors_dtype) {
   using namespace sglk;
+  SGLK_REQUIRE(block_rows == 128 || block_rows == 256, "apply_shuffle_mul_sum_splitk: block_rows must be 128 or 256");
   SGLK_REQUIRE(topk > 0 && topk <= 16, "apply_shuffle_mul_sum_splitk: topk must be in [1, 16]");
   SGLK_REQUIRE(hidden > 0 && hidden % 8 == 0, "apply_shuffle_mul_sum_splitk: hidden size must be a positive multiple of 8");
   SGLK_REQUIRE(n_experts > 0 && n_experts < (1ll << 20) && total_m >= 0 && total_m < (1ll << 31),
@@ -483,13 +485,13 @@ extern "C" int sglk_apply_shuffle_mul_sum_splitk(sglk_stream_t stream, const voi
   SGLK_DISPATCH_HALF(dtype, T, {
     if (factors == nullptr) {
       shuffle_mul_sum_splitk_kernel<T, T><<<(unsigned)tokens, 256, 0, st>>>(
-          (const T*)y, ws, (T*)output, permutation, nullptr, rows_per_expert, (int)n_experts, total_m, (int)topk, (int)hidden,
-          routed_scaling_factor, use_rsf);
+          (const T*)y, ws, (T*)output, permutation, nullptr, rows_per_expert, (int)n_experts, (int)block_rows, total_m, (int)topk,
+          (int)hidden, routed_scaling_factor, use_rsf);
     } else {
       SGLK_DISPATCH_FLOAT(factors_dtype, W, {
         shuffle_mul_sum_splitk_kernel<T, W><<<(unsigned)tokens, 256, 0, st>>>(
-            (const T*)y, ws, (T*)output, permutation, (const W*)factors, rows_per_expert, (int)n_experts, total_m, (int)topk,
-            (int)hidden, routed_scaling_factor, use_rsf);
+            (const T*)y, ws, (T*)output, permutation, (const W*)factors, rows_per_expert, (int)n_experts, (int)block_rows, total_m,
+            (int)topk, (int)hidden, routed_scaling_factor, use_rsf);
       });
     }
   });

@@ -50,7 +50,7 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
 // moe_persist.hip: the K split of the 128-row blocks into fp32 slabs (returns 2 after launching, 0 if it does not apply)
 int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const void* w, const void* scales, const void* zeros,
                            int group_shift, const int32_t* rows, int64_t total_m, int E, int N, int K, int dtype, int w4);
-bool moe_persist_splitk_applies(int64_t total_m, int E, int N, int K, int group_shift, int w4, int dtype);
+int moe_persist_splitk_applies(int64_t total_m, int E, int N, int K, int group_shift, int w4, int dtype);
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -974,7 +974,7 @@ extern "C" int sglk_moe_w4a16_splitk_applies(int64_t total_m, int64_t n_experts,
   if (total_m <= 0 || n_experts <= 0 || N <= 0 || K <= 0 || N >= (1ll << 31) || K >= (1ll << 31) || n_experts >= (1ll << 20)) return 0;
   const int gs = !is_int4 ? 5 : group_size == 32 ? 5 : group_size == 64 ? 6 : group_size == 128 ? 7 : group_size == 256 ? 8 : -1;
   if (gs < 0) return 0;
-  return sglk::moe_persist_splitk_applies(total_m, (int)n_experts, (int)N, (int)K, gs, is_int4 ? 1 : 2, dtype) ? 1 : 0;
+  return sglk::moe_persist_splitk_applies(total_m, (int)n_experts, (int)N, (int)K, gs, is_int4 ? 1 : 2, dtype);
 }
 
 static int w4a16_run(sglk_stream_t stream, void* out, const void* activations, const void* packed_weights, const void* scales,
@@ -1023,10 +1023,10 @@ static int w4a16_run(sglk_stream_t stream, void* out, const void* activations, c
     int rc = moe_persist_splitk_try(st, split_ws, activations, packed_weights, scales, is_int4 ? zeros : nullptr, gs, rows_per_expert,
                                     total_m, (int)n_experts, (int)N, (int)K, dtype, is_int4 ? 1 : 2);
     if (rc < 0) return rc;
-    if (rc == 2) {
-      *split_used = 1;
-      t_tail_flag = kMoeTailFlag128;
-      const int64_t tail_m = std::min<int64_t>(total_m, 64 * n_experts);
+    if (rc > 0) {
+      *split_used = rc == 2 ? 128 : 256;
+      t_tail_flag = rc == 2 ? kMoeTailFlag128 : kMoeTailFlag;
+      const int64_t tail_m = std::min<int64_t>(total_m, (rc == 2 ? 64 : 128) * n_experts);
       rc = dtype == SGLK_BF16 ? dispatch<bf16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, tail_m,
                                                (int)n_experts, (int)N, (int)K, gs, fused_act)
                               : dispatch<f16>(st, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, tail_m,

@@ -671,8 +671,8 @@ void apply_shuffle_mul_sum(const Tensor& input, Tensor& output, const Tensor& pe
                                        (float)routed_scaling_factor, dtype_code(input.scalar_type(), "input"), fdt));
 }
 
-// split_ws != nullptr: the K-split form (sglk_moe_grouped_mm_w4a16_splitk); returns whether the split was used
-static bool moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
+// split_ws != nullptr: the K-split form (sglk_moe_grouped_mm_w4a16_splitk); returns the row block of the split (0: not split)
+static int64_t moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
                           const Tensor& scales, const std::optional<Tensor>& zeros,
                           const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
                           bool is_int4, int64_t group_size, int64_t fused_act, double act_limit,
@@ -766,7 +766,7 @@ static bool moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tens
                                                activations.data_ptr(), packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr,
                                                rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k, group_size,
                                                is_int4 ? 1 : 0, dtype_code(activations.scalar_type(), "activations"), &used));
-    return used != 0;
+    return used;
   }
   SGLK_CALL(sglk_moe_grouped_mm_w4a16_act(stream_of(activations), output.data_ptr(), activations.data_ptr(),
                                           packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr, bias_ptr,
@@ -774,28 +774,29 @@ static bool moe_w4a16_impl(Tensor& output, const Tensor& activations, const Tens
                                           group_size, is_int4 ? 1 : 0,
                                           dtype_code(activations.scalar_type(), "activations"), (int)fused_act, (float)act_limit,
                                           map_ptr, activations.size(0)));
-  return false;
+  return 0;
 }
 
 // authored (no reference op): the down projection of fused_experts with the K range of its tiles split in two where that
-// projection has fewer tiles than the GPU has CUs (include/sglk.h: sglk_moe_grouped_mm_w4a16_splitk). Returns True when the
-// split was used - the result is then in ws (two fp32 partial sums per row) except for the experts' remainders of 1 .. 64 rows,
-// which are in output, and apply_shuffle_mul_sum_splitk reads both - and False when output holds the whole product.
-bool moe_grouped_mm_nt_w4a16_splitk(Tensor& output, Tensor& ws, const Tensor& activations, const Tensor& packed_weights,
+// projection has fewer tiles than the GPU has CUs (include/sglk.h: sglk_moe_grouped_mm_w4a16_splitk). Returns the row block
+// (128 / 256) when the split was used - the result is then in ws (two fp32 partial sums per row) except for the experts'
+// remainders of up to half a block, which are in output, and apply_shuffle_mul_sum_splitk reads both - and 0 when output holds
+// the whole product.
+int64_t moe_grouped_mm_nt_w4a16_splitk(Tensor& output, Tensor& ws, const Tensor& activations, const Tensor& packed_weights,
                                     const Tensor& scales, const std::optional<Tensor>& zeros, const Tensor& rows_per_expert,
                                     int64_t n_experts, bool is_int4, int64_t group_size) {
   return moe_w4a16_impl(output, activations, packed_weights, scales, zeros, std::nullopt, rows_per_expert, n_experts, is_int4,
                         group_size, 0, 0.0, std::nullopt, &ws);
 }
 
-// host-only: would moe_grouped_mm_nt_w4a16_splitk split this shape? (so that fused_experts allocates ws only then)
-bool moe_w4a16_splitk_applies(int64_t total_m, int64_t n_experts, int64_t n, int64_t k, int64_t group_size, bool is_int4,
+// host-only: the row block moe_grouped_mm_nt_w4a16_splitk would split this shape with, 0 = not (fused_experts allocates ws only then)
+int64_t moe_w4a16_splitk_applies(int64_t total_m, int64_t n_experts, int64_t n, int64_t k, int64_t group_size, bool is_int4,
                               bool is_bf16) {
-  return sglk_moe_w4a16_splitk_applies(total_m, n_experts, n, k, group_size, is_int4 ? 1 : 0, is_bf16 ? SGLK_BF16 : SGLK_F16) != 0;
+  return sglk_moe_w4a16_splitk_applies(total_m, n_experts, n, k, group_size, is_int4 ? 1 : 0, is_bf16 ? SGLK_BF16 : SGLK_F16);
 }
 
 void apply_shuffle_mul_sum_splitk(const Tensor& y, const Tensor& ws, Tensor& output, const Tensor& permutation,
-                                  const Tensor& rows_per_expert, double routed_scaling_factor,
+                                  const Tensor& rows_per_expert, int64_t block_rows, double routed_scaling_factor,
                                   const std::optional<Tensor>& factors) {
   CHECK_GPU(y);
   CHECK_GPU(ws);
@@ -826,7 +827,7 @@ void apply_shuffle_mul_sum_splitk(const Tensor& y, const Tensor& ws, Tensor& out
   const c10::OptionalDeviceGuard guard(y.device());
   SGLK_CALL(sglk_apply_shuffle_mul_sum_splitk(stream_of(y), y.data_ptr(), ws.data_ptr<float>(), output.data_ptr(),
                                               permutation.data_ptr<int32_t>(), fptr, rows_per_expert.data_ptr<int32_t>(),
-                                              rows_per_expert.numel(), y.size(0), m, topk, output.size(1),
+                                              rows_per_expert.numel(), block_rows, y.size(0), m, topk, output.size(1),
                                               (float)routed_scaling_factor, dtype_code(y.scalar_type(), "y"), fdt));
 }
 
@@ -1734,13 +1735,13 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
   m.impl("moe_grouped_mm_nt_w4a16_act", c10::kCUDA, &moe_grouped_mm_nt_w4a16_act);
   m.def(
       "moe_grouped_mm_nt_w4a16_splitk(Tensor! output, Tensor! ws, Tensor activations, Tensor packed_weights, Tensor scales, "
-      "Tensor? zeros, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size) -> bool");
+      "Tensor? zeros, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size) -> int");
   m.impl("moe_grouped_mm_nt_w4a16_splitk", c10::kCUDA, &moe_grouped_mm_nt_w4a16_splitk);
-  m.def("moe_w4a16_splitk_applies(int total_m, int n_experts, int n, int k, int group_size, bool is_int4, bool is_bf16) -> bool",
+  m.def("moe_w4a16_splitk_applies(int total_m, int n_experts, int n, int k, int group_size, bool is_int4, bool is_bf16) -> int",
         &moe_w4a16_splitk_applies);
   m.def(
-      "apply_shuffle_mul_sum_splitk(Tensor y, Tensor ws, Tensor! output, Tensor permutation, Tensor rows_per_expert, float "
-      "routed_scaling_factor, Tensor? factors) -> ()");
+      "apply_shuffle_mul_sum_splitk(Tensor y, Tensor ws, Tensor! output, Tensor permutation, Tensor rows_per_expert, int "
+      "block_rows, float routed_scaling_factor, Tensor? factors) -> ()");
   m.impl("apply_shuffle_mul_sum_splitk", c10::kCUDA, &apply_shuffle_mul_sum_splitk);
   m.def(
       "prepare_moe_input(Tensor topk_ids, Tensor! expert_offsets, Tensor? blockscale_offsets, Tensor! problem_sizes1,"

@@ -324,18 +324,20 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     # ---- GEMM 2 and the weighted combine over the top-k slots
     y = scratch("intermediate_cache3", (p.rows, p.hidden))
     rsf = 1.0 if routed_scaling_factor is None else routed_scaling_factor
-    # 4-bit weights, 96 .. 191 rows per expert: the down projection has fewer 128 x 256 tiles than the GPU has CUs (Mixtral at 512
-    # tokens: 128 tiles of 224 K blocks on 256 CUs), so the K range of every tile is split over two workgroups; the two fp32
+    # 4-bit weights, from 96 rows per expert: where the down projection has fewer tiles than the GPU has CUs (Mixtral at 512 tokens:
+    # 128 tiles of 128 x 256 and 224 K blocks on 256 CUs; at 1024 tokens 128 tiles of 256 x 256), the K range of every tile is
+    # split over two workgroups; the two fp32
     # partial sums go to a workspace and the combine below adds them (a two-term sum: the same in either order) and rounds once,
     # as the GEMM's own store would have (the reference picks a tile policy per average row count, GroupGemmW4A16Xe20.cpp:266-277)
     # (the op answers for the tile counts and the group alignment; the row-count regime is checked here so that other sizes make
     # no extra call)
-    if (p.four_bit and b2 is None and p.hidden % 8 == 0 and 96 * p.experts <= p.rows < 192 * p.experts
+    if (p.four_bit and b2 is None and p.hidden % 8 == 0 and 96 * p.experts <= p.rows
             and _ops.moe_w4a16_splitk_applies(p.rows, p.experts, p.hidden, p.inter, p.group2, p.int4, dt == torch.bfloat16)):
         ws = scratch("splitk_partials", (2, p.rows, p.hidden), torch.float32)
-        if _ops.moe_grouped_mm_nt_w4a16_splitk(y, ws, h.contiguous(), w2, w2_scale, w2_zp, rows_per_expert, p.experts, p.int4,
-                                               p.group2):
-            _ops.apply_shuffle_mul_sum_splitk.default(y, ws, result, dst_rows, rows_per_expert, rsf, topk_weights)
+        block = _ops.moe_grouped_mm_nt_w4a16_splitk(y, ws, h.contiguous(), w2, w2_scale, w2_zp, rows_per_expert, p.experts,
+                                                     p.int4, p.group2)
+        if block:  # (the row block of the split: 128 or 256; 0 = the op ran the plain GEMM into y)
+            _ops.apply_shuffle_mul_sum_splitk.default(y, ws, result, dst_rows, rows_per_expert, block, rsf, topk_weights)
             return result
     else:
         grouped_mm(y, h.contiguous(), w2, w2_scale, w2_zp, b2, p.group2)

@@ -190,10 +190,11 @@ def _moe_case(dtype=torch.bfloat16, T=5, H=128, I=64, E=4, k=2, four_bit=True, g
     return x, w1, w2, tw, ti, s1, s2
 
 
-@pytest.mark.parametrize("applies,used", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("applies,used", [(128, 128), (256, 256), (128, 0), (0, 0)])
 def test_fused_experts_down_projection_k_split_sequence(sglk, monkeypatch, applies, used):
-    """96 .. 191 rows per expert, 4-bit weights, no b2: the down projection asks for its K split; when the op says it split, the
-    combine is the split form reading the workspace, otherwise the plain sequence - and the plain GEMM is not run twice."""
+    """From 96 rows per expert, 4-bit weights, no b2: the down projection asks for its K split; when the op says it split (by
+    returning its row block), the combine is the split form reading the workspace with that block, otherwise the plain sequence -
+    and the plain GEMM is not run twice."""
     from sgl_kernel import moe
 
     rec = _Recorder({"moe_w4a16_splitk_applies": applies, "moe_grouped_mm_nt_w4a16_splitk": used})
@@ -206,7 +207,7 @@ def test_fused_experts_down_projection_k_split_sequence(sglk, monkeypatch, appli
         assert rec.names() == head + ["moe_grouped_mm_nt_w4a16_splitk", "apply_shuffle_mul_sum_splitk"]
         gemm, comb = rec.calls[4][1], rec.calls[5][1]
         assert gemm[1].shape == (2, 512, 128) and gemm[1].dtype == torch.float32 and gemm[0].shape == (512, 128)
-        assert comb[0] is gemm[0] and comb[1] is gemm[1] and comb[2] is out and comb[5] == 2.5 and comb[6] is tw
+        assert comb[0] is gemm[0] and comb[1] is gemm[1] and comb[2] is out and comb[5:7] == (used, 2.5) and comb[7] is tw
         assert comb[4] is rec.calls[0][1][1]  # rows_per_expert of prepare_moe_input
     elif applies:  # (the op ran the plain GEMM itself and said so)
         assert rec.names() == head + ["moe_grouped_mm_nt_w4a16_splitk", "apply_shuffle_mul_sum"]

@@ -282,12 +282,12 @@ def test_moe_grouped_mm_w4a16_row_map_is_the_gather(sglk, dev, dtype, act_type, 
         op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25, row_map[:-1])
 
 
-def _tail_rows_mask(rows):
-    """rows of an expert's remainder of 1 .. 64 rows behind its last full 128-row block (the streaming kernels' share)"""
+def _tail_rows_mask(rows, block=128):
+    """rows of an expert's remainder of 1 .. block / 2 rows behind its last full row block (the streaming kernels' share)"""
     m = []
     for r in rows:
-        rem = r % 128
-        t = rem if 1 <= rem <= 64 else 0
+        rem = r % block
+        t = rem if 1 <= rem <= block // 2 else 0
         m += [False] * (r - t) + [True] * t
     return torch.tensor(m, dtype=torch.bool)
 
@@ -299,7 +299,10 @@ def _tail_rows_mask(rows):
                                          ([130, 200, 112, 150], 200, 1280, 128),   # edge column block, 72-row remainder block
                                          ([191, 96, 129, 64 + 128], 256, 2048, 64),
                                          ([97] * 16, 256, 512, 32),                # K / 2 = four K blocks: the shortest unit
-                                         ([130, 200, 112, 150], 512, 1280, 256)])  # K / 2 is not whole groups: no split
+                                         ([130, 200, 112, 150], 512, 1280, 256),   # K / 2 is not whole groups: no split
+                                         # from an average of 192 rows per expert: 256-row blocks, remainders of up to 128 rows
+                                         ([256] * 8, 512, 1024, 128), ([300, 200, 513, 256], 512, 1280, 128),
+                                         ([236, 276, 250, 291, 232, 251, 269, 243], 200, 1024, 64)])
 def test_moe_grouped_mm_w4a16_splitk(sglk, dev, fmt, dtype, rows, N, K, gs):
     """The down projection's K split (moe_persist.hip, KSPL = 2): full 128-row blocks as two fp32 partial sums in ws, remainders
     of 1 .. 64 rows in out; bf16(ws[0] + ws[1]) against the oracle at the reference's tolerance and against the unsplit op."""
@@ -319,7 +322,7 @@ def test_moe_grouped_mm_w4a16_splitk(sglk, dev, fmt, dtype, rows, N, K, gs):
     rows_t = torch.tensor(rows, dtype=torch.int32, device=dev)
     op = torch.ops.sgl_kernel
     applies = op.moe_w4a16_splitk_applies(total, E, N, K, gs, is_int4, dtype == torch.bfloat16)
-    assert applies == ((K // 2) % gs == 0)
+    assert applies == (0 if (K // 2) % gs else 128 if total < 192 * E else 256)
     y = torch.full((total, N), float("nan"), dtype=dtype, device=dev)
     ws = torch.full((2, total, N), float("nan"), dtype=torch.float32, device=dev)
     used = op.moe_grouped_mm_nt_w4a16_splitk(y, ws, act.to(dev), packed.to(dev), scales.to(dev), d(zeros), rows_t, E, is_int4, gs)
@@ -330,7 +333,7 @@ def test_moe_grouped_mm_w4a16_splitk(sglk, dev, fmt, dtype, rows, N, K, gs):
         assert torch.equal(y, plain), "without the split the call is the plain op"
         assert torch.isnan(ws).all(), "... and does not touch ws"
         return
-    tail = _tail_rows_mask(rows)
+    tail = _tail_rows_mask(rows, used)
     assert torch.isnan(y.cpu()[~tail].float()).all(), "rows of the split blocks are not written to out"
     assert torch.isnan(ws.cpu()[:, tail]).all(), "remainder rows are not written to ws"
     got = torch.where(tail[:, None], y.cpu().float(), (ws[0] + ws[1]).to(dtype).cpu().float())
@@ -347,9 +350,10 @@ def test_moe_grouped_mm_w4a16_splitk(sglk, dev, fmt, dtype, rows, N, K, gs):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("block", [128, 256])
 @pytest.mark.parametrize("rows,topk,hidden", [([128] * 8, 2, 512), ([124, 106, 126, 146, 137, 133, 124, 128], 2, 4096),
-                                              ([130, 200, 112, 150, 0, 64, 65, 1], 6, 136)])
-def test_apply_shuffle_mul_sum_splitk(sglk, dev, dt, rows, topk, hidden):
+                                              ([130, 200, 112, 150, 0, 64, 65, 1], 6, 136), ([300, 129, 513, 256, 128], 2, 256)])
+def test_apply_shuffle_mul_sum_splitk(sglk, dev, dt, block, rows, topk, hidden):
     """out[t] = T(sum_j T(x[perm[t, j]]) * w[t, j] * rsf), x[r] = y[r] for an expert's remainder of 1 .. 64 rows and
     T(ws[0][r] + ws[1][r]) otherwise: bit-exact against that definition."""
     g = torch.Generator().manual_seed(sum(rows) + hidden)
@@ -364,8 +368,8 @@ def test_apply_shuffle_mul_sum_splitk(sglk, dev, dt, rows, topk, hidden):
     w = torch.rand(tokens, topk, generator=g)
     out = torch.empty(tokens, hidden, dtype=dt, device=dev)
     torch.ops.sgl_kernel.apply_shuffle_mul_sum_splitk(y.to(dev), ws.to(dev), out, perm.to(dev),
-                                                      torch.tensor(rows, dtype=torch.int32, device=dev), 2.5, w.to(dev))
-    tail = _tail_rows_mask(rows)
+                                                      torch.tensor(rows, dtype=torch.int32, device=dev), block, 2.5, w.to(dev))
+    tail = _tail_rows_mask(rows, block)
     x = torch.where(tail[:, None], y.float(), (ws[0] + ws[1]).to(dt).float())
     acc = torch.zeros(tokens, hidden)
     for j in range(topk):

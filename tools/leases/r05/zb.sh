@@ -10,6 +10,6 @@ tail -6 $OUT/pytest.log
 for rep in 1 2; do
   for k in 1 0; do
     echo "== MOE_SPLITK=$k"
-    MOE_SPLITK=$k MOE_BENCH_INT4_ONLY=1 LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_probes.so timeout 300 python3 tools/moe_bench.py 384 448 512 576 2>&1 | grep "fused_experts T"
+    MOE_SPLITK=$k MOE_BENCH_INT4_ONLY=1 LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_probes.so timeout 300 python3 tools/moe_bench.py 512 768 1024 1536 2>&1 | grep "fused_experts T"
   done
 done | tee $OUT/moe.log
