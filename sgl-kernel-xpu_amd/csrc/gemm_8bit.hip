@@ -428,6 +428,7 @@ struct TileDesc {
   int ncols;                                // valid columns of the tile (<= BN)
   int wrows;                                // rows per wm half of the wave grid: 128 (256-row tile) or 64 (128-row half tile)
   int m0, n0;                               // first row / column (row / column scale modes: the epilogue's scales and bias)
+  int rev;                                  // (diagnostic build, probe 16) 1: the tile walks its K blocks from the last to the first
 };
 
 // MODE_FP8_ROWCOL / MODE_INT8_ROWCOL (fp8_scaled_mm / int8_scaled_mm): the same pipeline without the block scales - the
@@ -524,6 +525,7 @@ __device__ __forceinline__ void gemm_8bit_persist_phase(
     int nblk = (n0 + wn * 64) >> 7;
     nblk = nblk < nblk_max ? nblk : nblk_max;
     d.sbw = kBW ? sb + (int64_t)nblk * sb_sn : sb;
+    d.rev = 0;
     return d;
   };
   auto pick = [](bool c, const TileDesc& x, const TileDesc& y) -> TileDesc {  // scalar selects
@@ -533,6 +535,7 @@ __device__ __forceinline__ void gemm_8bit_persist_phase(
     d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_s = c ? x.nrec_s : y.nrec_s;
     d.nrec_o = c ? x.nrec_o : y.nrec_o;  d.ncols = c ? x.ncols : y.ncols;  d.wrows = c ? x.wrows : y.wrows;
     d.m0 = c ? x.m0 : y.m0;  d.n0 = c ? x.n0 : y.n0;
+    d.rev = 0;
     return d;
   };
 
@@ -1133,7 +1136,7 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nkb = K / BK;  // >= 2
-  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 15);
+  constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 19);
   // LDS stage of this phase: a rows [64 MS][128 B], b^T rows [256][128 B], 256 row scales (+ 1 KiB spare). Whole tiles: two
   // stages of 66 KiB. Half tiles: THREE stages of 50 KiB - with 1024 cycles of MFMAs per K block and the block's data
   // requested one block ahead, the half-tile loop ran at the latency of its LDS-DMA (2450 shader cycles per block,
@@ -1196,6 +1199,9 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
     int nblk = (n0 + wn * 64) >> 7;
     nblk = nblk < nblk_max ? nblk : nblk_max;
     d.sbw = sb + (int64_t)nblk * sb_sn;
+    // (probe 16: consecutive units of a workgroup share their a panel - the tile index advances by the slot count, a multiple of
+    //  the group of four m-tiles; odd units walk K backwards, so the panel's last blocks are re-read while the XCD's L2 holds them)
+    d.rev = (PROBE == 16) ? (unit & 1) : 0;
     return d;
   };
   auto pick = [](bool c, const TileDesc& x, const TileDesc& y) -> TileDesc {  // scalar selects
@@ -1205,6 +1211,7 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
     d.nrec_a = c ? x.nrec_a : y.nrec_a;  d.nrec_b = c ? x.nrec_b : y.nrec_b;  d.nrec_s = c ? x.nrec_s : y.nrec_s;
     d.nrec_o = c ? x.nrec_o : y.nrec_o;  d.ncols = c ? x.ncols : y.ncols;  d.wrows = c ? x.wrows : y.wrows;
     d.m0 = c ? x.m0 : y.m0;  d.n0 = c ? x.n0 : y.n0;
+    d.rev = c ? x.rev : y.rev;
     return d;
   };
 
@@ -1221,7 +1228,7 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
   const uint32_t voff_s = (uint32_t)tid * (uint32_t)sa_sm * 4u;
   // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = rows of b^T (sub 0, 1 each); (part 0, sub 2) = row scales
   auto dma_piece = [&](const TileDesc& d, int kb_, int s, int part, int sub) {
-    const int kb = PROBE == 4 ? 0 : kb_;
+    const int kb = PROBE == 4 ? 0 : (PROBE == 16 && d.rev) ? nkb - 1 - kb_ : kb_;
     char* base = smem + s * kStg;
     if (sub == 2) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(d.ps, d.nrec_s), SGLK_LDS(base + kOffS + wave * 256), 4,
@@ -1325,7 +1332,11 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mf][nf][r] = 0.f;
 
-#define X32_RD16(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+// (diagnostic build, garbage results: probe 17 = no promotion FMAs, 18 = no LDS fragment reads, 19 = neither - what each costs
+//  under the power cap: time x in-kernel clock, kbench gemm with GEMM_CLOCK=1)
+#define X32_RD16(dst, addr, imm)                                                                   \
+  if constexpr (PROBE != 18 && PROBE != 19) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm)); \
+  else asm volatile("" : "=v"(dst))
 #define X32_RD4(dst, addr, imm) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define X32_FRAG(lo, hi) __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)
 // first / second MFMA of a 32 x 32 partial (K halves s = 0, 1)
@@ -1339,6 +1350,7 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
                : "v"(X32_FRAG(nq[nf][1][0], nq[nf][1][1])), "v"(X32_FRAG(mq[1][0], mq[1][1])), "v"(one_e8m0));
 // acc[row][nf][:] += cur[:] * sc
 #define X32_PROMOTE(row, nf, cur)                                                                              \
+  if constexpr (PROBE != 17 && PROBE != 19)                                                                    \
   _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                                            \
       asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[row][nf][r_]) : "v"(cur[r_]), "v"(sc));
 
@@ -1448,7 +1460,7 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
     }                                                                                                          \
     if constexpr (MS == 4) { X32_STEP(0, STORE, false) X32_STEP(1, STORE, false) X32_STEP(2, STORE, false) }   \
     else { X32_STEP(0, STORE, false) }                                                                         \
-    float sbv_next = d1.sbw[(int64_t)kb1 * sb_sk];                                                             \
+    float sbv_next = d1.sbw[(int64_t)((PROBE == 16 && d1.rev) ? nkb - 1 - kb1 : kb1) * sb_sk];                  \
     /* (round 3, probe 15 - counted vmcnt at the store block's barrier of whole tiles so that the stores get one more K block */ \
     /* before anything waits - changed nothing, 0.2376 against 0.2378 ms: the 33 MB burst takes four K blocks to drain)          */ \
     /* Half tiles, three stages: vmcnt retires in issue order; younger than block + 1's pieces are the 3 pieces issued behind    */ \
@@ -1503,7 +1515,7 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
     dma_piece(cur_t, 0, 0, part, 1);
   }
   dma_piece(cur_t, 0, 0, 0, 2);
-  sbv = cur_t.sbw[0];
+  sbv = cur_t.sbw[(PROBE == 16 && cur_t.rev) ? (int64_t)(nkb - 1) * sb_sk : 0];
   if constexpr (NST == 3) {  // all of block 1 and the a pieces + row scales of block 2 go out before anything waits
     if (kDma) {
       dma_piece(cur_t, 1, 1, 0, 0);  dma_piece(cur_t, 1, 1, 0, 1);
@@ -2014,6 +2026,10 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       case 35: SGLK_GO_X32(13); break;                                                                       \
       case 36: SGLK_GO_X32(14); break;                                                                       \
       case 37: SGLK_GO_X32(15); break;  /* whole-tile stores staged through LDS */                             \
+      case 38: SGLK_GO_X32(16); break;  /* odd units of a workgroup walk K backwards (shared a panel from L2) */    \
+      case 39: SGLK_GO_X32(17); break;  /* no promotion FMAs */                                                \
+      case 40: SGLK_GO_X32(18); break;  /* no LDS fragment reads */                                            \
+      case 41: SGLK_GO_X32(19); break;  /* neither */                                                          \
       case 0: SGLK_GO_VAR(V, H, 0); break;                                                                   \
       case 1: SGLK_GO_VAR(V, H, 1); break;                                                                   \
       case 8: SGLK_GO_VAR(V, H, 8); break;                                                                   \
