@@ -485,6 +485,16 @@ def side_metrics(sgl_kernel, dev):
     out["fwd_prefill_causal_bs16_h16_kv8_d256_seq4096_TFLOPs"] = round(4.0 * bs * 16 * 256 * seq * seq / 2 / ms / 1e9, 1)
     out["fwd_prefill_causal_bs16_h16_kv8_d256_seq4096_ms"] = round(ms, 4)
     del kc256, vc256, qp256
+    # head dims 96 / 192 (reference instantiations FMHAPrefillXe20.cmake:30-54) inside the 128 / 256 LDS images of the same kernel
+    # since round 5 (before: the general 16-row kernel)
+    for dd, hqd in ((96, 32), (192, 16)):
+        kcd = torch.randn(n_pages, page, hk, dd, device=dev, dtype=torch.bfloat16)
+        vcd = torch.randn(n_pages, page, hk, dd, device=dev, dtype=torch.bfloat16)
+        qpd = torch.randn(bs * seq, hqd, dd, device=dev, dtype=torch.bfloat16)
+        ms = timeit(lambda: flash_attn_with_kvcache(qpd, kcd, vcd, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu,
+                                                    max_seqlen_q=seq, causal=True), iters=5)
+        out[f"fwd_prefill_causal_bs16_h{hqd}_kv8_d{dd}_seq4096_TFLOPs"] = round(4.0 * bs * hqd * dd * seq * seq / 2 / ms / 1e9, 1)
+        del kcd, vcd, qpd
     # decode at the other head dims / an fp8 KV cache the reference instantiates (FMHADecodeXe20.cmake:13-16, :62-111)
     for dd, kvdt in ((64, torch.bfloat16), (256, torch.bfloat16), (128, FP8)):
         npg = bs * seq // page

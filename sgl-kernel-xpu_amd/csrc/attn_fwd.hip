@@ -593,7 +593,11 @@ struct Mfma32<f16> {
 // Head dim 64 (round 3; reference instantiations FMHAPrefillXe20.cmake): the same kernel with 128-byte LDS rows - 8 chunks per
 // row, one staging load per thread, tile and operand; K chunk c of row r at c ^ ((r >> 1) & 7) (rows two apart share their
 // banks), V chunk c at c ^ (((r >> 1) & 1) << 2); 8 + 8 MFMAs per wave and tile against the same softmax work.
-template <typename T, int D, int NW, int MB, int KV8 = 0>  // NW waves of MB 32-row blocks; KV8: 0 16-bit cache, 1 e4m3, 2 e5m2
+// Head dims 96 / 192 (round 5; reference instantiations FMHAPrefillXe20.cmake:30-54): DA = the head dim, D = 128 / 256 the LDS
+// image it lives in - 12 (24) of a row's 16 (32) chunk positions are real, the others are filled with a second copy of real chunks
+// (the DMA lane fetches chunk c - (D - DA) / 8 instead: no read past a row's end) and never read: Q K^T runs DA / 16 k-steps, P V
+// DA / 32 dim blocks - three quarters of the matrix work of the image's size.
+template <typename T, int D, int NW, int MB, int KV8 = 0, int DA = D>  // NW waves of MB 32-row blocks; KV8: 0 16-bit cache, 1 e4m3, 2 e5m2
 __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) void attn_prefill_kernel(AttnParams p, const T* __restrict__ q,
                                                            const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                            const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
@@ -602,6 +606,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
   using M32 = Mfma32<T>;
   constexpr int KS = D / 16, DB = D / 32, ROWB = D * 2, TILE_BYTES = kPTile * ROWB;
   static_assert(D == 64 || D == 128 || D == 256, "head dims with a power-of-two number of 16-byte chunks per row");
+  static_assert(DA == D || (KV8 == 0 && DA % 32 == 0 && DA < D && 2 * DA > D), "a head dim inside the next image size");
+  constexpr int KSA = DA / 16, DBA = DA / 32;  // k-steps of Q K^T and dim blocks of P V that are real
   constexpr int kPBlockM = 32 * MB * NW, NTH = 64 * NW;
   constexpr int CPR = D / 8, RPP = NTH / CPR, NCH = kPTile / RPP;  // 16-byte chunks per row, rows per pass, staging loads per thread
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2][K tile, V tile]
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
   for (int mb = 0; mb < MB; ++mb) {
     const T* qrow = q + (int64_t)(q_begin + my_qpos[mb]) * p.q_s0 + (int64_t)my_head[mb] * p.q_s1;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KSA; ++ks) {
       v8s v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (row_ok[mb] && !(probe & 128)) v = *reinterpret_cast<const v8s*>(qrow + 16 * ks + 8 * u);
       qf[mb][ks] = v;
@@ -727,13 +733,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
   // global 16-byte chunk of the lane for piece i of this wave (K: the key depends on the piece's rows; V: it does not)
   auto k_chunk = [&](int i) -> int {
     const int row = RP * (wave * PPW + i) + prow;
-    return pch ^ (D >= 128 ? (row & 15) : ((row >> 1) & 7));
+    const int c = pch ^ (D >= 128 ? (row & 15) : ((row >> 1) & 7));
+    return c < DA / 8 ? c : c - (D - DA) / 8;  // (DA < D: the positions past the row's end take a second copy of real chunks)
   };
   // (V: the key is (row & 3) << 2 - at d = 128 a piece is four rows and the key a lane constant; at d = 256 a piece is two rows
   //  and the key depends on the piece's parity)
   auto v_chunk = [&](int i) -> int {
     const int row = RP * (wave * PPW + i) + prow;
-    return pch ^ (D >= 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2));
+    const int c = pch ^ (D >= 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2));
+    return c < DA / 8 ? c : c - (D - DA) / 8;
   };
   // (fast tiles: the RP PPW consecutive rows a wave moves share their page, so one SGPR base serves the wave's pieces and the
   // piece's row offset rides in the lane offset)
@@ -982,18 +990,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
       // 908 TFLOP/s at d = 128, interleaved runs of the diagnostic build)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < KSA; ++ks) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           s0[mb] = M32::run(ka[ks % kKA][0], qf[mb][ks], s0[mb]);
           s1[mb] = M32::run(ka[ks % kKA][1], qf[mb][ks], s1[mb]);
         }
-        if (ks + kKA < KS) read_k(ks + kKA, ka[ks % kKA]);
+        if (ks + kKA < KSA) read_k(ks + kKA, ka[ks % kKA]);
       }
       // keep that order: the scheduler otherwise sinks every read below the MFMAs in front of it
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * kKA, 0);
 #pragma unroll
-      for (int ks = 0; ks < KS - kKA; ++ks) {
+      for (int ks = 0; ks < KSA - kKA; ++ks) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * MB, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
@@ -1132,7 +1140,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
           m_ref[mb] = m_new;
           l_run[mb] *= alpha;
 #pragma unroll
-          for (int db = 0; db < DB; ++db)
+          for (int db = 0; db < DBA; ++db)
 #pragma unroll
             for (int v = 0; v < 16; ++v) o[mb][db][v] *= alpha;
           mneg = m_ref[mb] == -INFINITY ? 0.f : -m_ref[mb];
@@ -1150,7 +1158,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
       constexpr int kVA = 4;  // V^T fragments in flight (steps ahead)
       v8s vf[kVA];
       auto read_v = [&](int m, v8s& dst) {
-        const int s4 = m / DB, db = m % DB;
+        const int s4 = m / DBA, db = m % DBA;
         const int chunk = ((4 * db + vchunk_lo) ^ ((D >= 128 ? qq : (qq >> 1)) << 2)) << 4;
         const char* a = vb + (32 * (s4 >> 1) + 16 * (s4 & 1)) * ROWB + vlane_off + chunk;
         const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)SGLK_LDS(a));
@@ -1158,7 +1166,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
         dst[0] = v0[0]; dst[1] = v0[1]; dst[2] = v0[2]; dst[3] = v0[3];
         dst[4] = v1[0]; dst[5] = v1[1]; dst[6] = v1[2]; dst[7] = v1[3];
       };
-      constexpr int NPV = 4 * DB;
+      constexpr int NPV = 4 * DBA;
 #pragma unroll
       for (int m = 0; m < kVA; ++m) read_v(m, vf[m]);
       __builtin_amdgcn_s_setprio(1);
@@ -1166,8 +1174,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
       for (int m = 0; m < NPV; ++m) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const v4i w4 = {pw[mb][4 * (m / DB)], pw[mb][4 * (m / DB) + 1], pw[mb][4 * (m / DB) + 2], pw[mb][4 * (m / DB) + 3]};
-          o[mb][m % DB] = M32::run(vf[m % kVA], __builtin_bit_cast(v8s, w4), o[mb][m % DB]);
+          const v4i w4 = {pw[mb][4 * (m / DBA)], pw[mb][4 * (m / DBA) + 1], pw[mb][4 * (m / DBA) + 2], pw[mb][4 * (m / DBA) + 3]};
+          o[mb][m % DBA] = M32::run(vf[m % kVA], __builtin_bit_cast(v8s, w4), o[mb][m % DBA]);
         }
         if (m + kVA < NPV) read_v(m + kVA, vf[m % kVA]);
       }
@@ -1213,7 +1221,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
       const int64_t tok = q_begin + my_qpos[mb];
       T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)my_head[mb] * p.o_s1;
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
+      for (int db = 0; db < DBA; ++db) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {  // dims 32 db + 8 g + 4 u .. + 3
           Vec<T, 4> ov;
@@ -1739,14 +1747,14 @@ static int launch(hipStream_t st, const AttnParams& p, const void* q, const void
   return SGLK_OK;
 }
 
-template <typename T, int D, int NW, int MB, int KV8 = 0>
+template <typename T, int D, int NW, int MB, int KV8 = 0, int DA = D>
 static int launch_prefill_nw(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                              const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
   constexpr int lds = 2 * 2 * kPTile * D * 2;  // 64 KiB (d = 64: 32 KiB)
   static unsigned long long attr_done = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D, NW, MB, KV8>), lds, &attr_done, "fwd")) return rc;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D, NW, MB, KV8, DA>), lds, &attr_done, "fwd")) return rc;
   dim3 grid((unsigned)cdiv(max_rows, 32 * MB * NW), (unsigned)p.Hk, (unsigned)batch);
-  attn_prefill_kernel<T, D, NW, MB, KV8><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  attn_prefill_kernel<T, D, NW, MB, KV8, DA><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   return check_launch("fwd(prefill)");
 }
 
@@ -1757,9 +1765,10 @@ constexpr int g_attn_prefill_waves = 0;
 #endif
 
 // Four waves (128 rows) per workgroup, two workgroups per CU: see the kernel comment.
-template <typename T, int D, int KV8 = 0>
+template <typename T, int D, int KV8 = 0, int DA = D>
 static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                           const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows) {
+  if constexpr (DA != D) return launch_prefill_nw<T, D, 4, 1, KV8, DA>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
 #ifdef SGLK_PROBES  // (the 8-wave form - one workgroup per CU - for A/B timing)
   if constexpr (KV8 == 0) {
     if (g_attn_prefill_waves == 8) return launch_prefill_nw<T, D, 8, 1>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
@@ -1823,6 +1832,13 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
     return d == 128  ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
            : d == 64 ? launch_prefill<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
                      : launch_prefill<T, 256>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
+  // (head dims 96 / 192 - the reference builds both, FMHAPrefillXe20.cmake:30-54 - inside the 128 / 256 images since round 5; the
+  //  DMA fetches whole 16-byte chunks of 192- / 384-byte rows: row strides and bases must be multiples of 8 elements)
+  if (kv8 == 0 && (d == 96 || d == 192) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 && p.q_s1 % 8 == 0 &&
+      p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0 && p.k_s0 % 8 == 0 && p.k_s1 % 8 == 0 && p.k_s2 % 8 == 0 && p.v_s0 % 8 == 0 &&
+      p.v_s1 % 8 == 0 && p.v_s2 % 8 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)q % 16 == 0)
+    return d == 96 ? launch_prefill<T, 128, 0, 96>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
+                   : launch_prefill<T, 256, 0, 192>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
   // (an fp8 cache at prefill sizes - the reference tests it, tests/test_flash_attention.py:1691-1704 - on the same kernel since
   //  round 5: registers instead of LDS-DMA, widened on the way into the 16-bit LDS images; rows are fetched in 16-byte pieces)
   if (kv8 != 0 && (d == 128 || d == 64) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 && p.o_s0 % 4 == 0 &&

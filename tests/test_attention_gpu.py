@@ -153,7 +153,7 @@ def test_kvcache_paged_many_tiles(sglk, dev, causal, local, page, D):
 
 
 @pytest.mark.parametrize("page", [8, 16, 32, 256])
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 96, 128, 192])  # (96 / 192: inside the 128 / 256 LDS images, round 5)
 @pytest.mark.parametrize("causal,local", [(True, False), (False, True)])
 def test_prefill_kernel_page_sizes(sglk, dev, causal, local, D, page):
     """prefill-sized row counts (the LDS-DMA kernel, round 4) over pages smaller than, equal to and larger than what one wave
@@ -233,6 +233,15 @@ def test_varlen(sglk, dev, heads, causal, local, D, sq, sk):
     """the reference's ragged grid (tests/test_flash_attention.py:1912-1947: head layouts x masks x d x 20 length pairs; the
     2048 x 2048 pair is test_varlen_2048 below); its softcap axis (0 / 15) alternates over the grid instead of doubling it"""
     run_varlen(sglk, dev, heads, causal, local, D, sq, sk)
+
+
+@pytest.mark.parametrize("heads", [(16, 16), (16, 4), (16, 1)])
+@pytest.mark.parametrize("causal,local", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("sq,sk", [(128, 128), (113, 203), (256, 512), (307, 256), (640, 128), (1023, 1024)])
+def test_varlen_d96(sglk, dev, heads, causal, local, sq, sk):
+    """head dim 96 (reference FMHAPrefillXe20.cmake:30-54) at prefill row counts: the 128-row-block kernel with 192-byte rows inside
+    the d = 128 LDS image (d = 192 inside the d = 256 one is part of test_varlen's grid)"""
+    run_varlen(sglk, dev, heads, causal, local, 96, sq, sk)
 
 
 @pytest.mark.parametrize("causal,local", [(False, False), (True, False), (False, True)])

@@ -23,8 +23,9 @@ def timeit(f, warm, it):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(it): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / it * 1e3
-for d in ((128,) if ONLY in ("128", "chunk", "softcap", "fp8") else (64,) if ONLY == "64" else (256,) if ONLY == "256" else (128, 64, 256)):
-    hq = 16 if d == 256 else 32  # (d = 256: 16 q heads / 8 kv heads)
+for d in ((128,) if ONLY in ("128", "chunk", "softcap", "fp8") else (64,) if ONLY == "64" else (256,) if ONLY == "256" else
+          (96, 192) if ONLY == "96" else (128, 64, 256)):
+    hq = 16 if d >= 192 else 32  # (d = 192 / 256: 16 q heads / 8 kv heads)
     kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
     vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
     qp = torch.randn(bs * seq, hq, d, device=dev, dtype=torch.bfloat16)
