@@ -1260,13 +1260,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
 // against 35.9 with an fp8 cache, 55.2 against 53.0 at d = 128 (round 4, interleaved runs of the diagnostic build) - the
 // stream itself runs at 5.8 - 6.5 TB/s, what the short legs feel are ~12 us of fixed cost (first-tile latency chain, the
 // wave merge, the partial results and the reduce launch).
-template <typename T, int D, int KV8, int NW>
+// Head dims 96 / 192 (round 5; the reference's paged decode builds them, FMHADecodeXe20.cmake:13-16): DA = the head dim inside the
+// d = 128 / 256 form - DA / 32 k-steps of K (loaded straight into registers: nothing extra is fetched), DA / 16 output tiles, and a V
+// image whose rows keep 16 (32) chunk positions of which 12 (24) are real: the lanes of the other positions fetch a second copy of
+// real chunks (no read past a row's end), an eighth more HBM bytes than the rows hold.
+template <typename T, int D, int KV8, int NW, int DA = D>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void attn_decode_kernel(AttnParams p, const T* __restrict__ q,
                                                              const char* __restrict__ kcache, const char* __restrict__ vcache,
                                                              const int32_t* __restrict__ cu_q, const int32_t* __restrict__ seq_k,
                                                              const int32_t* __restrict__ page_table) {
   using M = Mfma<T>;
-  constexpr int KS = D / 32, NT = D / 16, NB = (D + 127) / 128, VIMG = NB * kTile * 256;  // V image of a tile: NB x 8 KiB
+  static_assert(DA == D || (DA % 32 == 0 && DA < D && 2 * DA > D), "a head dim inside the next form");
+  constexpr int KS = DA / 32, NT = DA / 16, NB = (D + 127) / 128, VIMG = NB * kTile * 256;  // V image of a tile: NB x 8 KiB
   constexpr int ES = KV8 ? 1 : 2;  // bytes per cache element
   static_assert(D == 64 || D == 128 || D == 256, "decode kernel: head dims 64, 128, 256");
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [4 waves][2] V images; the merge reuses them
@@ -1383,6 +1388,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
     v4i v[NVL];
   };
   const int v_piece = lane % CPR, v_tok = lane / CPR;  // this lane's piece of the row, its token within a load
+  constexpr int CPRA = DA * ES / 16;                   // real pieces of a row; the positions past them re-fetch real ones
+  const int v_src = v_piece < CPRA ? v_piece : v_piece - (CPR - CPRA);
   auto issue_k = [&](int t, int page, KRegs& r) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1401,7 +1408,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
       pos = pos < last_key ? pos : last_key;
       const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
       const int64_t off = (int64_t)((uint64_t)(uint32_t)page * vpg + ((uint64_t)cp * vst + (uint64_t)vbase_row));
-      r.v[i] = *reinterpret_cast<const v4i*>(vcache + off * ES + 16 * v_piece);
+      r.v[i] = *reinterpret_cast<const v4i*>(vcache + off * ES + 16 * v_src);
     }
   };
   // fp8: 8 bytes -> 8 elements of T (exact), one v_cvt_scalef32_pk_* per pair, unit scale
@@ -1638,7 +1645,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + l15] = (T)(o[nt][e] * i4[e]);
     } else {
-      float* orow = p.part_o + (((int64_t)split * p.total_q + tok) * p.Hq + head) * D;
+      float* orow = p.part_o + (((int64_t)split * p.total_q + tok) * p.Hq + head) * DA;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) orow[nt * 16 + l15] = o[nt][e] * i4[e];
     }
@@ -1778,14 +1785,14 @@ static int launch_prefill(hipStream_t st, const AttnParams& p, const void* q, co
   return launch_prefill_nw<T, D, 4, 1, KV8>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
 }
 
-template <typename T, int D, int KV8, int NW>
+template <typename T, int D, int KV8, int NW, int DA = D>
 static int launch_decode_nw(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
                             const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch) {
   constexpr int lds = NW * 2 * ((D + 127) / 128) * kTile * 256;  // four waves: 64 KiB (d = 256: 128 KiB); eight: 128 KiB
   static unsigned long long attr_done = 0;
-  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_decode_kernel<T, D, KV8, NW>), lds, &attr_done, "fwd")) return rc;
+  if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_decode_kernel<T, D, KV8, NW, DA>), lds, &attr_done, "fwd")) return rc;
   dim3 grid((unsigned)(p.Hk * p.splits), (unsigned)batch);
-  attn_decode_kernel<T, D, KV8, NW><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
+  attn_decode_kernel<T, D, KV8, NW, DA><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   if (int rc = check_launch("fwd(decode)")) return rc;
   if (p.splits > 1) {
     attn_reduce_kernel<T><<<dim3(p.Hq, p.total_q), 128, 0, st>>>((T*)p.out, p.lse, p.part_o, p.part_lse, p.sinks,
@@ -1864,6 +1871,19 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
     if (d == 128) SGLK_DEC_GO(128);
     SGLK_DEC_GO(256);
 #undef SGLK_DEC_GO
+  }
+  // (head dims 96 / 192 - the reference's paged decode builds them, FMHADecodeXe20.cmake:13-16 - inside the 128 / 256 forms of the
+  //  same kernel since round 5; 16-byte loads of 192- / 384-byte rows: strides and bases in whole chunks)
+  if ((d == 96 || d == 192) && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) && p.leftpad_k == nullptr &&
+      p.q_s0 % 8 == 0 && p.q_s1 % 8 == 0 && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
+      p.k_s0 % 16 == 0 && p.k_s1 % 16 == 0 && p.k_s2 % 16 == 0 && p.v_s0 % 16 == 0 && p.v_s1 % 16 == 0 && p.v_s2 % 16 == 0) {
+#define SGLK_DEC_GO_A(DD, DA_)                                                                                  \
+  return kv8 == 0   ? launch_decode_nw<T, DD, 0, 4, DA_>(st, p, q, k, v, cu_q, seq_k, table, batch)             \
+         : kv8 == 1 ? launch_decode_nw<T, DD, 1, 4, DA_>(st, p, q, k, v, cu_q, seq_k, table, batch)             \
+                    : launch_decode_nw<T, DD, 2, 4, DA_>(st, p, q, k, v, cu_q, seq_k, table, batch)
+    if (d == 96) SGLK_DEC_GO_A(128, 96);
+    SGLK_DEC_GO_A(256, 192);
+#undef SGLK_DEC_GO_A
   }
   if (kv8 != 0) {  // fp8 KV cache: built for the head dims the reference exercises (and 64)
 #define SGLK_FP8_GO(DKP)                                                                              \

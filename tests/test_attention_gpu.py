@@ -189,6 +189,24 @@ def test_decode(sglk, dev, heads, local, page, D, batch, seqlen_k):
                   use_sink=((seqlen_k + (D >> 6) + Hk + int(local)) % 2 == 0), num_splits=splits, seed=seqlen_k)
 
 
+@pytest.mark.parametrize("page", [64, 128])
+@pytest.mark.parametrize("heads", [(16, 4), (8, 1), (32, 8)])
+@pytest.mark.parametrize("local", [False, True])
+@pytest.mark.parametrize("D", [96, 192])
+@pytest.mark.parametrize("batch,seqlen_k", [(1, 1), (4, 65), (1, 129), (4, 1024), (1, 4033), (2, 4097)])
+def test_decode_d96_d192(sglk, dev, heads, local, page, D, batch, seqlen_k):
+    """head dims 96 / 192 of the reference's paged decode (FMHADecodeXe20.cmake:13-16) on the independent-wave decode kernel inside
+    its d = 128 / 256 forms (round 5): a slice of the decode grid above, every case at three split counts"""
+    Hq, Hk = heads
+    g = torch.Generator().manual_seed(seqlen_k + D)
+    seqs_k = torch.randint(max(1, seqlen_k - 30), seqlen_k + 1, (batch,), generator=g).tolist()
+    seqs_k[0] = seqlen_k
+    window = (seqlen_k // 3, 0) if local else (-1, -1)
+    for splits in (0, 1, 5):
+        run_paged(sglk, dev, torch.bfloat16 if D == 96 else torch.float16, [1] * batch, seqs_k, Hq, Hk, D, page, window=window,
+                  use_sink=((seqlen_k + Hk + int(local)) % 2 == 0), num_splits=splits, seed=seqlen_k)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("heads,sq", [((16, 16), 1), ((16, 16), 5), ((16, 4), 4), ((16, 2), 2), ((32, 2), 1), ((8, 1), 2)])
 @pytest.mark.parametrize("feature", ["plain", "causal", "local", "softcap", "sinks", "causal+sinks"])
