@@ -229,6 +229,15 @@ SGLK_API int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* ac
                                  const float* bias, const int32_t* rows_per_expert, int64_t total_m,
                                  int64_t n_experts, int64_t N, int64_t K, int64_t ldb, int64_t weight_stride_e,
                                  int dtype, int fused_act);
+/* moe_grouped_mm_nt_xe20 with activation_type 2 (swiglu_gpt_oss) and fuse_act = true: reference
+ * kernels/moe/xe20/bf16/moe_kernel.hpp:109-125 (gate = weight rows 0, 2, 4, .., up = rows 1, 3, 5, .. - INTERLEAVED - and the
+ * bias likewise, :138-146) and common/activation.hpp:31-42: out [total_m, N/2],
+ *   out[m, n] = T(g * sigmoid(alpha * g) * (u + 1)),  g = min(x[m, 2n], limit),  u = clamp(x[m, 2n + 1], -limit, limit),
+ * x = A W^T + bias on the fp32 accumulators. Other parameters as sglk_moe_grouped_mm. */
+SGLK_API int sglk_moe_grouped_mm_swiglu(sglk_stream_t stream, void* out, const void* activations, const void* weights,
+                                        const float* bias, const int32_t* rows_per_expert, int64_t total_m,
+                                        int64_t n_experts, int64_t N, int64_t K, int64_t ldb, int64_t weight_stride_e,
+                                        int dtype, float alpha, float limit);
 
 /* ---- MLA prefill ------------------------------------------------------------
  * flash_mla_prefill: reference src/sycl/mla_prefill.cpp (schema src/torch_extension_sycl.cc:379-383;
@@ -313,6 +322,15 @@ SGLK_API int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, cons
                                            int is_int4, int dtype, int fused_act, float act_limit,
                                            const int32_t* row_map, int64_t src_rows);
 
+/* authored: the same gpt-oss swiglu epilogue on the 4-bit grouped GEMM (the reference runs its W4A16 GEMM 1 unfused and
+ * calls swiglu_gpt_oss_sigmoid_alpha on the [rows, 2I] product, python/sgl_kernel/moe.py:748-789): gate = weight row 2n,
+ * up = row 2n + 1, out [total_m, N/2]; other parameters as sglk_moe_grouped_mm_w4a16_act. */
+SGLK_API int sglk_moe_grouped_mm_w4a16_swiglu(sglk_stream_t stream, void* out, const void* activations,
+                                              const void* packed_weights, const void* scales, const void* zeros,
+                                              const float* bias, const int32_t* rows_per_expert, int64_t total_m,
+                                              int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
+                                              int dtype, float alpha, float limit, const int32_t* row_map,
+                                              int64_t src_rows);
 /* authored (no reference op): the DOWN projection of fused_experts (no bias, no activation) with the K range of every
  * 128 x 256 tile split over two workgroups, for the row counts at which that projection has fewer tiles than the GPU has CUs
  * (Mixtral: hidden 4096 = 16 column blocks x 8 row blocks of 224 K blocks at 512 tokens and again, with 256-row blocks, at

@@ -176,10 +176,12 @@ def moe_grouped_mm(act, weights, bias, rows_per_expert):
     return out
 
 
-def moe_grouped_mm_fused(act, weights, bias, rows_per_expert, activation):
+def moe_grouped_mm_fused(act, weights, bias, rows_per_expert, activation, alpha=1.702, limit=7.0):
     """moe_grouped_mm_nt_xe20 with fuse_act (reference kernels/moe/xe20/bf16/moe_mainloop.hpp:232-247, :375-390,
     common/activation.hpp:31-50): the activation works on the fp32 accumulators (+ bias), one rounding to T.
-    silu / gelu: weights hold gate rows then up rows, out [rows, N/2]; relu2: out [rows, N] = max(x, 0)^2."""
+    silu / gelu: weights hold gate rows then up rows, out [rows, N/2]; relu2: out [rows, N] = max(x, 0)^2;
+    swiglu_gpt_oss: gate = weight rows 0, 2, 4, .., up = rows 1, 3, 5, .. (moe_kernel.hpp:109-125; bias likewise, :138-146),
+    out = min(gate, limit) * sigmoid(alpha * that) * (clamp(up, +-limit) + 1) (common/activation.hpp:35-41)."""
     T = act.dtype
     n = weights.shape[1]
     out = torch.empty(act.shape[0], n if activation == "relu2" else n // 2, dtype=T)
@@ -191,6 +193,9 @@ def moe_grouped_mm_fused(act, weights, bias, rows_per_expert, activation):
                 o = o + bias[e].float()
             if activation == "relu2":
                 o = torch.square(torch.relu(o))
+            elif activation == "swiglu_gpt_oss":
+                gt, up = o[:, 0::2].clamp(max=limit), o[:, 1::2].clamp(min=-limit, max=limit)
+                o = gt * (1.0 / (1.0 + torch.exp(-(gt * alpha)))) * (up + 1.0)
             else:
                 g, u = o[:, : n // 2], o[:, n // 2:]
                 if activation == "silu":

@@ -26,10 +26,11 @@ namespace sglk {
 int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const void* zeros,
                     int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
-                    int fuse, float act_limit);
+                    int fuse, float act_limit, float act_alpha = 0.f);
 namespace {
 
 static thread_local int t_tail_flag = 0;  // kMoeTailFlag while the launch covers only the rows moe_persist.hip left over
+static thread_local float t_act_alpha = 0.f, t_act_limit = 0.f;  // the gpt-oss swiglu's parameters of the running call
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -47,12 +48,18 @@ __device__ __forceinline__ v4f mma16<f16>(const v4i& a, const v4i& b, const v4f&
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
 }
 
-enum { FUSE_NONE = 0, FUSE_SILU = 1, FUSE_GELU = 2, FUSE_RELU2 = 3 };
+// FUSE_SWIGLU (5, the numbering of the W4A16 op, where 4 is the clamped swiglu): the gpt-oss swiglu of the reference's fused
+// epilogue (kernels/moe/xe20/common/activation.hpp:31-42; moe_kernel.hpp:109-125: gate = weight rows 0, 2, 4, .., up = rows 1, 3,
+// 5, .. - INTERLEAVED, bias likewise): out[m, n] = g * sigmoid(alpha g) * (u + 1), g = min(x[2 n], limit), u = clamp(x[2 n + 1]).
+enum { FUSE_NONE = 0, FUSE_SILU = 1, FUSE_GELU = 2, FUSE_RELU2 = 3, FUSE_SWIGLU = 5 };
 
 template <int FUSE>
-__device__ __forceinline__ float gated_act(float x, float y) {
+__device__ __forceinline__ float gated_act(float x, float y, float alpha, float limit) {
   if constexpr (FUSE == FUSE_SILU) {
     return (x / (1.0f + expf(-x))) * y;
+  } else if constexpr (FUSE == FUSE_SWIGLU) {
+    const float gate = fminf(x, limit), up = fmaxf(-limit, fminf(y, limit));
+    return gate * (1.0f / (1.0f + expf(-(gate * alpha)))) * (up + 1.0f);
   } else {
     const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     return (x * (0.5f * (1.0f + tanhf(inner)))) * y;
@@ -63,7 +70,7 @@ template <typename T, int MT, int NW, int FUSE, int WV = 4>  // WV waves per wor
 __global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, const T* __restrict__ act,
                                                        const T* __restrict__ w, const float* __restrict__ bias,
                                                        const int32_t* __restrict__ rows_per_expert, int E, int N, int K,
-                                                       int64_t ldb, int64_t w_stride_e) {
+                                                       int64_t ldb, int64_t w_stride_e, float act_alpha, float act_limit) {
   constexpr int BM = 16 * MT;
   constexpr int BN = 16 * NW * WV;
   constexpr int NT_ = 64 * WV;       // threads
@@ -76,7 +83,8 @@ __global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, 
   const int l15 = lane & 15, g = lane >> 4;
 
   // ---- which (expert, block of its rows, column block): see moe_tiles.h
-  constexpr bool kGated = FUSE == FUSE_SILU || FUSE == FUSE_GELU;
+  constexpr bool kGated = FUSE == FUSE_SILU || FUSE == FUSE_GELU || FUSE == FUSE_SWIGLU;
+  constexpr bool kPairs = FUSE == FUSE_SWIGLU;  // gate / up rows interleaved (2 n, 2 n + 1) instead of halves (n, N / 2 + n)
   static_assert(!kGated || NW == 2, "the gated epilogue pairs the two n tiles of a wave");
   const int Nh = N >> 1;  // gated: output width; gate rows [0, Nh), up rows [Nh, N)
   const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, kGated ? (Nh + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN);
@@ -88,8 +96,8 @@ __global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, 
   uint32_t woff[NW];  // element offset of this lane's row and k group
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
-    int n = kGated ? n_base + l15 + nt * Nh : n_base + nt * 16 + l15;
-    const int lim = kGated ? (nt + 1) * Nh : N;
+    int n = kPairs ? 2 * (n_base + l15) + nt : kGated ? n_base + l15 + nt * Nh : n_base + nt * 16 + l15;
+    const int lim = kPairs ? N : kGated ? (nt + 1) * Nh : N;
     n = n < lim ? n : lim - 1;
     woff[nt] = (uint32_t)n * (uint32_t)ldb + 8 * g;
   }
@@ -188,13 +196,15 @@ __global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, 
   if constexpr (kGated) {
     const int n = n_base + l15;
     if (n < Nh) {
-      const float bg = bias ? bias[(int64_t)e * N + n] : 0.f, bu = bias ? bias[(int64_t)e * N + Nh + n] : 0.f;
+      const float bg = bias ? bias[(int64_t)e * N + (kPairs ? 2 * n : n)] : 0.f,
+                  bu = bias ? bias[(int64_t)e * N + (kPairs ? 2 * n + 1 : Nh + n)] : 0.f;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = mt * 16 + 4 * g + r;
-          if (row < m_valid) out[(int64_t)(m0 + row) * Nh + n] = (T)gated_act<FUSE>(acc[mt][0][r] + bg, acc[mt][1][r] + bu);
+          if (row < m_valid)
+            out[(int64_t)(m0 + row) * Nh + n] = (T)gated_act<FUSE>(acc[mt][0][r] + bg, acc[mt][1][r] + bu, act_alpha, act_limit);
         }
       }
     }
@@ -225,16 +235,17 @@ template <typename T, int MT, int NW, int WV = 4>
 static int launch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
                   int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
   constexpr int BM = 16 * MT, BN = 16 * NW * WV;
-  const bool gated = fuse == FUSE_SILU || fuse == FUSE_GELU;
+  const bool gated = fuse == FUSE_SILU || fuse == FUSE_GELU || fuse == FUSE_SWIGLU;
   const int64_t wgs = moe_tile_launch_size(total_m, E, BM, gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN));
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20: problem too large for one launch");
   dim3 grid((unsigned)wgs);
 #define SGLK_GO(F) \
-  moe_bf16_kernel<T, MT, NW, F, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E | t_tail_flag, N, K, ldb, w_stride_e)
+  moe_bf16_kernel<T, MT, NW, F, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const T*)w, bias, rows, E | t_tail_flag, N, K, ldb, w_stride_e, t_act_alpha, t_act_limit)
   switch (fuse) {
     case FUSE_SILU: SGLK_GO(FUSE_SILU); break;
     case FUSE_GELU: SGLK_GO(FUSE_GELU); break;
     case FUSE_RELU2: SGLK_GO(FUSE_RELU2); break;
+    case FUSE_SWIGLU: SGLK_GO(FUSE_SWIGLU); break;
     default: SGLK_GO(FUSE_NONE); break;
   }
 #undef SGLK_GO
@@ -265,23 +276,47 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* w, c
 }  // namespace
 }  // namespace sglk
 
+static int moe_bf16_run(sglk_stream_t stream, void* out, const void* activations, const void* weights, const float* bias,
+                        const int32_t* rows_per_expert, int64_t total_m, int64_t n_experts, int64_t N, int64_t K, int64_t ldb,
+                        int64_t weight_stride_e, int dtype, int fused_act, float act_alpha, float act_limit);
+
 extern "C" int sglk_moe_grouped_mm(sglk_stream_t stream, void* out, const void* activations, const void* weights,
                                    const float* bias, const int32_t* rows_per_expert, int64_t total_m,
                                    int64_t n_experts, int64_t N, int64_t K, int64_t ldb, int64_t weight_stride_e,
                                    int dtype, int fused_act) {
   using namespace sglk;
+  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 3, "moe_grouped_mm_nt_xe20: fused_act must be 0 (none), 1 (silu), 2 (gelu) or 3 (relu2)");
+  return moe_bf16_run(stream, out, activations, weights, bias, rows_per_expert, total_m, n_experts, N, K, ldb, weight_stride_e, dtype,
+                      fused_act, 0.f, 0.f);
+}
+
+extern "C" int sglk_moe_grouped_mm_swiglu(sglk_stream_t stream, void* out, const void* activations, const void* weights,
+                                          const float* bias, const int32_t* rows_per_expert, int64_t total_m,
+                                          int64_t n_experts, int64_t N, int64_t K, int64_t ldb, int64_t weight_stride_e,
+                                          int dtype, float alpha, float limit) {
+  using namespace sglk;
+  SGLK_REQUIRE(limit > 0.f, "moe_grouped_mm_nt_xe20: the gpt-oss swiglu needs a positive gemm1_limit");
+  return moe_bf16_run(stream, out, activations, weights, bias, rows_per_expert, total_m, n_experts, N, K, ldb, weight_stride_e, dtype,
+                      5, alpha, limit);
+}
+
+static int moe_bf16_run(sglk_stream_t stream, void* out, const void* activations, const void* weights, const float* bias,
+                        const int32_t* rows_per_expert, int64_t total_m, int64_t n_experts, int64_t N, int64_t K, int64_t ldb,
+                        int64_t weight_stride_e, int dtype, int fused_act, float act_alpha, float act_limit) {
+  using namespace sglk;
+  t_act_alpha = act_alpha;
+  t_act_limit = act_limit;
   SGLK_REQUIRE(dtype == SGLK_BF16 || dtype == SGLK_F16, "moe_grouped_mm_nt_xe20: activations and weights must be bfloat16 or half");
   SGLK_REQUIRE(n_experts > 0 && N > 0 && K > 0, "moe_grouped_mm_nt_xe20: bad shape");
   SGLK_REQUIRE(K % 8 == 0 && ldb % 8 == 0 && weight_stride_e % 8 == 0, "moe_grouped_mm_nt_xe20: K and the weight strides must be multiples of 8");
   SGLK_REQUIRE((uintptr_t)activations % 16 == 0 && (uintptr_t)weights % 16 == 0,
                "moe_grouped_mm_nt_xe20: activations and weights must be 16-byte aligned");
   SGLK_REQUIRE(N * ldb < (1ll << 32), "moe_grouped_mm_nt_xe20: one expert's weights must stay below 4 Gi elements");
-  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 3, "moe_grouped_mm_nt_xe20: fused_act must be 0 (none), 1 (silu), 2 (gelu) or 3 (relu2)");
-  SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2) || N % 2 == 0, "moe_grouped_mm_nt_xe20: a gated epilogue needs an even N");
+  SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2 || fused_act == 5) || N % 2 == 0, "moe_grouped_mm_nt_xe20: a gated epilogue needs an even N");
   if (total_m == 0) return SGLK_OK;
   hipStream_t st = (hipStream_t)stream;
   if (int rc = moe_persist_try(st, out, activations, weights, nullptr, nullptr, 0, bias, rows_per_expert, total_m, (int)n_experts, (int)N,
-                               (int)K, ldb, weight_stride_e, dtype, 0, fused_act, 0.f)) {
+                               (int)K, ldb, weight_stride_e, dtype, 0, fused_act, act_limit, act_alpha)) {
     if (rc < 0) return rc;
     if (rc == 3) return SGLK_OK;  // (the tile pipeline took the remainders too)
     t_tail_flag = rc == 2 ? kMoeTailFlag128 : kMoeTailFlag;  // the experts' last rows (at most 128 each) on the streaming kernel

@@ -64,7 +64,11 @@ struct MpParams {
   int64_t total_m;      // KSPL > 1: rows of the whole problem = rows of one fp32 slab of `out`
   const int32_t* rows;  // [E]
   int E, N, K, fuse;    // fuse: 0 none, 1 silu, 2 gelu (tanh), 3 relu2, 4 clamped swiglu (1, 2, 4 gated: N = gate + up rows)
-  float act_limit;
+  // The gpt-oss swiglu (the callers' code 5) arrives as fuse 4 with pairs = 1 (gate = weight row 2 n, up = row 2 n + 1 -
+  // interleaved; bias likewise), act_kneg = -log2(e) * alpha and act_yadd = 1: min(gate, limit) * sigmoid(alpha gate) *
+  // (clamp(up) + 1) is the clamped swiglu with two more constants (the other gated forms: act_kneg = -log2(e), act_yadd = 0).
+  int pairs;
+  float act_limit, act_kneg, act_yadd;
   int64_t ldb, stride_e;  // 16-bit weights: row stride / expert stride in elements
 };
 
@@ -115,6 +119,10 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   const int nkb = (K >> 6) / KSPL;  // K blocks of a unit, >= 2 (three stages: >= 3)
   // (an opaque scalar: left as an expression the compiler re-evaluates `fuse` with a branch ladder at every use inside the K loop)
   const bool gated = __builtin_amdgcn_readfirstlane((int)(p.fuse == 1 || p.fuse == 2 || p.fuse == 4)) != 0;
+  // (gpt-oss swiglu: the tile's gate / up weight rows are 2 n / 2 n + 1 instead of n / N / 2 + n - a row scale of 2 on the weight
+  //  side, used by the set-up code below and nothing else: the LDS slots, the fragments and the store block are those of the
+  //  other gated epilogues)
+  const int rmul = p.pairs ? 2 : 1;
   const int Nout = gated ? N >> 1 : N;
   constexpr int kRowsA = WIDE ? 128 : MS * 64;  // activation rows and weight rows (LDS slots) of a tile
   constexpr int kRowsB = WIDE ? 512 : 256;
@@ -214,19 +222,20 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
     const uint32_t koff_a = (uint32_t)k0 * 2u, koff_b = W4 ? (uint32_t)(k0 >> 1) : (uint32_t)k0 * 2u;
     const uint32_t koff_s = W4 ? (uint32_t)(k0 >> gshift) * (uint32_t)kSB : 0u, koff_z = (uint32_t)(k0 >> gshift) * 2u;
     d.pa = (const char*)p.act + (int64_t)m0 * a_row + koff_a;
-    d.pb = (const char*)p.w + (int64_t)e * b_exp + (int64_t)c0 * b_row + koff_b;
-    d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + c0) * kgroups * kSB + koff_s : nullptr;
-    d.pz = FMT == 3 ? (const char*)p.zeros + ((int64_t)e * N + c0) * kgroups * 2 + koff_z : nullptr;
+    const int w0 = c0 << p.pairs;  // the tile's first weight row
+    d.pb = (const char*)p.w + (int64_t)e * b_exp + (int64_t)w0 * b_row + koff_b;
+    d.ps = W4 ? (const char*)p.scales + ((int64_t)e * N + w0) * kgroups * kSB + koff_s : nullptr;
+    d.pz = FMT == 3 ? (const char*)p.zeros + ((int64_t)e * N + w0) * kgroups * 2 + koff_z : nullptr;
     d.po = (char*)p.out + (((int64_t)kh * p.total_m + m0) * Nout + c0) * OES;
-    d.pbs = BIAS ? (const char*)(p.bias + (int64_t)e * N + c0) : nullptr;
-    d.nrec_bs = (live && BIAS) ? (uint32_t)((N - c0) * 4) : 0u;
+    d.pbs = BIAS ? (const char*)(p.bias + (int64_t)e * N + w0) : nullptr;
+    d.nrec_bs = (live && BIAS) ? (uint32_t)((N - w0) * 4) : 0u;
     d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * a_row + (int64_t)K * 2) - koff_a : 0u;
     // (b: the resource spans the expert's rows from the tile's first one to row N - 1: weight rows past N read zeros)
-    d.nrec_b = live ? (uint32_t)((int64_t)(N - c0) * b_row) - koff_b : 0u;
+    d.nrec_b = live ? (uint32_t)((int64_t)(N - w0) * b_row) - koff_b : 0u;
     d.nrec_o = live ? (uint32_t)(((int64_t)(rows_a - 1) * Nout + cols) * OES) : 0u;
     // (weight rows past N of an edge tile: their scales lie past the tensor too - out of range, read as zero)
     // (FMT 3 reads scales and zero points - both two bytes per group - under this one range)
-    d.nrec_s = (live && W4) ? (uint32_t)((int64_t)(N - c0) * kgroups * kSB) - koff_s : 0u;
+    d.nrec_s = (live && W4) ? (uint32_t)((int64_t)(N - w0) * kgroups * kSB) - koff_s : 0u;
     return d;
   };
   auto pick = [](bool c, const MpTile& x, const MpTile& y) -> MpTile {
@@ -242,7 +251,8 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   // gated: its first 32 slots are gate rows c0 + 32 wn .., its last 32 the up rows N/2 further on
   // (wide tile: 128 slots per wave, its first 64 gate rows c0 + 64 wn .., its last 64 the up rows)
   auto wrow_of = [&](int s) -> int {
-    return gated ? ((s / kSW) * (kSW / 2) + (s & (kSW / 2 - 1)) + ((s & (kSW / 2)) ? Nout : 0)) : s;
+    const int gi = (s / kSW) * (kSW / 2) + (s & (kSW / 2 - 1));  // gate index of the slot inside the tile
+    return !gated ? s : rmul == 2 ? 2 * gi + ((s & (kSW / 2)) ? 1 : 0) : gi + ((s & (kSW / 2)) ? Nout : 0);
   };
 
   const uint32_t lds_base = (uint32_t)(uintptr_t)MP_LDS(smem);
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   for (int par = 0; par < 2; ++par) {
     const uint32_t ch = (uint32_t)(((lane & 7) ^ ((par * 4 + (lane >> 4)) & 7)) << 4);
     voff_a[par] = (uint32_t)(lane >> 3) * (uint32_t)a_row + ch;
-    voff_b[par] = (uint32_t)(lane >> 3) * (uint32_t)b_row + ch;
+    voff_b[par] = (uint32_t)(lane >> 3) * (uint32_t)(b_row * rmul) + ch;  // (gpt-oss: a piece's 8 slots are every other weight row)
   }
   // one 1-KiB piece per call: part 0, 1 = rows of a, part 2, 3 = weight rows (16-bit weights only), sub 0, 1 each.
   // The piece's row offset inside its tile is a per-wave constant (scalar registers, set once).
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   const int pslot = (tid >> 5) * 16 + 2 * (tid & 7) + ((tid >> 3) & 1), phalf = (tid >> 4) & 1;
   const uint32_t pvoff_w = (uint32_t)wrow_of(pslot) * (uint32_t)b_row + (uint32_t)phalf * 16u;
   // (slot + 256 is weight row + 256 - gated: + 128, the same half of the next-but-one wave column: a scalar byte offset)
-  const int prow2 = gated ? 128 : 256;
+  const int prow2 = gated ? 128 * rmul : 256;
   // (the thread's 32 codes lie in ONE scale group: group (64 kb + 32 half) >> gshift of the row)
   const uint32_t pvoff_s = (uint32_t)wrow_of(pslot) * (uint32_t)kgroups * (uint32_t)kSB +
                            (uint32_t)((phalf * 32) >> gshift) * (uint32_t)kSB;
@@ -384,13 +394,13 @@ __global__ __launch_bounds__(512) void moe_persist_kernel(MpParams p) {
   auto act_mul = [&](float x, float y) -> float {
     if (p.fuse == 4) {
       x = fminf(x, p.act_limit);
-      y = fminf(fmaxf(y, -p.act_limit), p.act_limit);
+      y = fminf(fmaxf(y, -p.act_limit), p.act_limit) + p.act_yadd;
     }
     // (hardware exp2 / reciprocal, ~1 ulp each: the libm forms are ~40 instructions per element, and the 64 elements per
     // lane and m-step of the store block - straight-line code - then thrash the instruction cache once per tile)
     float a;
     if (p.fuse == 1 || p.fuse == 4) {
-      a = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));  // x * sigmoid(x)
+      a = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(p.act_kneg * x));  // x * sigmoid(k x), k = 1 or alpha
     } else {
       const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
       // 0.5 (1 + tanh(u)) = 1 / (1 + exp(-2 u))
@@ -835,8 +845,8 @@ static int launch_persist(hipStream_t st, const MpParams& p) {
 int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const void* zeros,
                     int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
-                    int fuse, float act_limit) {
-  const bool gated = fuse == 1 || fuse == 2 || fuse == 4;
+                    int fuse, float act_limit, float act_alpha) {
+  const bool gated = fuse == 1 || fuse == 2 || fuse == 4 || fuse == 5;
   const int Nout = gated ? N / 2 : N;
   if (total_m < (int64_t)kMinAvgRows128 * E || num_cus() % 8 != 0 || (uintptr_t)bias % 4 != 0) return 0;
   const bool blocks128 = total_m < (int64_t)kMinAvgRows * E;
@@ -867,7 +877,9 @@ int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, c
   p.prio47 = g_mp_prio47;
   p.out = out;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.bias = bias;  p.gshift = group_shift;  p.rows = rows;
   p.total_m = total_m;
-  p.E = E;  p.N = N;  p.K = K;  p.fuse = fuse;  p.act_limit = act_limit;  p.ldb = ldb;  p.stride_e = stride_e;
+  p.E = E;  p.N = N;  p.K = K;  p.fuse = fuse == 5 ? 4 : fuse;  p.pairs = fuse == 5 ? 1 : 0;  p.act_limit = act_limit;
+  p.act_kneg = -1.4426950408889634f * (fuse == 5 ? act_alpha : 1.0f);  p.act_yadd = fuse == 5 ? 1.0f : 0.0f;
+  p.ldb = ldb;  p.stride_e = stride_e;
   int rc;
   const int fmt = w4 == 1 && zeros != nullptr ? 3 : w4;
   if (bias != nullptr) {
@@ -928,7 +940,7 @@ int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const voi
   p.prio47 = g_mp_prio47;
   p.out = ws;  p.act = act;  p.w = w;  p.scales = scales;  p.zeros = zeros;  p.bias = nullptr;  p.gshift = group_shift;  p.rows = rows;
   p.total_m = total_m;
-  p.E = E;  p.N = N;  p.K = K;  p.fuse = 0;  p.act_limit = 0.f;  p.ldb = 0;  p.stride_e = 0;
+  p.E = E;  p.N = N;  p.K = K;  p.fuse = 0;  p.pairs = 0;  p.act_limit = 0.f;  p.act_kneg = 0.f;  p.act_yadd = 0.f;  p.ldb = 0;  p.stride_e = 0;
   constexpr int kLds2 = 3 * (kTile / 2 + kTile);
   const int fmt = w4 == 1 && zeros != nullptr ? 3 : w4;
 #define MP_GO_SPLIT(TT, FF)                                                                                         \

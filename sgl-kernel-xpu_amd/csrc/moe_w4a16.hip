@@ -46,7 +46,7 @@ namespace sglk {
 int moe_persist_try(hipStream_t st, void* out, const void* act, const void* w, const void* scales, const void* zeros,
                     int group_shift, const float* bias,
                     const int32_t* rows, int64_t total_m, int E, int N, int K, int64_t ldb, int64_t stride_e, int dtype, int w4,
-                    int fuse, float act_limit);
+                    int fuse, float act_limit, float act_alpha = 0.f);
 // moe_persist.hip: the K split of the 128-row blocks into fp32 slabs (returns 2 after launching, 0 if it does not apply)
 int moe_persist_splitk_try(hipStream_t st, float* ws, const void* act, const void* w, const void* scales, const void* zeros,
                            int group_shift, const int32_t* rows, int64_t total_m, int E, int N, int K, int dtype, int w4);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
                                                         const void* __restrict__ zeros_, const float* __restrict__ bias,
                                                         const int32_t* __restrict__ rows_per_expert, int E, int N,
                                                         int K, int group_shift, int probe, int fuse, float act_limit,
-                                                        const int32_t* __restrict__ row_map) {
+                                                        const int32_t* __restrict__ row_map, float act_alpha) {
   // row_map (may be null): activation row of expert-contiguous row r is act[row_map[r]] - the token gather of fused_experts
   // (reference shuffle_rows, python/sgl_kernel/moe.py:739) folded into this kernel's staging loads: no [rows, K] copy of the
   // tokens, one launch less per call at decode sizes.
@@ -224,7 +224,10 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   // (64-row tiles of a projection with more k than columns: the column blocks of a row block run together and share its
   // activations in L2 - 731 against 755 us for the Mixtral down projection at 512 rows per expert; the gate / up projection
   // measured the other way round, 1609 against 1706 us. Probe 512 flips the choice.)
-  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4);
+  // fuse 5: the gpt-oss swiglu (reference kernels/moe/xe20/common/activation.hpp:31-42, moe_kernel.hpp:109-125 - the fused form of
+  // the reference's 16-bit GEMM): gate = weight row 2 n, up = row 2 n + 1 (INTERLEAVED), bias likewise
+  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4 || fuse == 5);
+  const bool pairs = fuse == 5;
   const int Nh = N >> 1;  // gated: output width
   const int col_blocks = gated ? (Nh + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN;
   const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, col_blocks, MT >= 4 && ((N < K) != ((probe & 512) != 0)));
@@ -236,7 +239,12 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
     if (!gated) return n_base + nt * 16 + l15;
     constexpr int H2 = NW >= 2 ? NW / 2 : 1;
     const int ng = tile.col_block * (BN / 2) + wave * (H2 * 16) + (nt % H2) * 16 + l15;  // gate column = output column
+    if (pairs) return 2 * ng + (nt < H2 ? 0 : 1);
     return nt < H2 ? ng : Nh + ng;
+  };
+  auto out_col_of = [&](int nt) -> int {  // output column of gate tile nt (nt < NW / 2)
+    constexpr int H2 = NW >= 2 ? NW / 2 : 1;
+    return tile.col_block * (BN / 2) + wave * (H2 * 16) + (nt % H2) * 16 + l15;
   };
   const int n_lim = gated ? Nh : N;  // valid gate / plain columns
 
@@ -545,9 +553,10 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
       constexpr int H2 = NW / 2;
 #pragma unroll
       for (int nt = 0; nt < H2; ++nt) {
-        const int n = col_of(nt);  // gate column = output column
+        const int n = out_col_of(nt);  // gate column = output column
         if (n >= Nh) continue;
-        const float bg = bias ? bias[(int64_t)e * N + n] : 0.f, bu = bias ? bias[(int64_t)e * N + Nh + n] : 0.f;
+        const float bg = bias ? bias[(int64_t)e * N + (pairs ? 2 * n : n)] : 0.f,
+                    bu = bias ? bias[(int64_t)e * N + (pairs ? 2 * n + 1 : Nh + n)] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -559,7 +568,11 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
               y = fminf(fmaxf(y, -act_limit), act_limit);
             }
             float a;
-            if (fuse == 1 || fuse == 4) {
+            if (fuse == 5) {
+              x = fminf(x, act_limit);
+              y = fmaxf(-act_limit, fminf(y, act_limit)) + 1.0f;
+              a = x * (1.0f / (1.0f + expf(-(x * act_alpha))));
+            } else if (fuse == 1 || fuse == 4) {
               a = x / (1.0f + expf(-x));
             } else {
               const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -812,7 +825,7 @@ constexpr int g_w4_probe = 0, g_w4_mt = 0, g_w4_fp4hw = 1;
 #endif
 
 // (the clamp bound of fused_act 4 rides beside the launch parameters: one value per call, set by the C-ABI entry)
-static thread_local float t_act_limit = 0.f;
+static thread_local float t_act_limit = 0.f, t_act_alpha = 0.f;
 static thread_local const int32_t* t_row_map = nullptr;  // the token gather of the call (streaming kernels only)
 static thread_local int t_tail_flag = 0;  // kMoeTailFlag while the launches cover only the rows moe_persist.hip left over
 
@@ -820,12 +833,12 @@ template <typename T, int MT, int NW, int PB, int FMT = 0, int WV = 4>
 static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift, int fuse) {
   constexpr int BM = 16 * MT, BN = 16 * NW * WV;
-  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4);
+  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4 || fuse == 5);
   const int64_t wgs = moe_tile_launch_size(total_m, E, BM, gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN));
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20_w4a16: problem too large for one launch");
   dim3 grid((unsigned)wgs);
   moe_w4a16_kernel<T, MT, NW, PB, FMT, WV><<<grid, 64 * WV, 0, st>>>((T*)out, (const T*)act, (const uint8_t*)wq, scales, zeros, bias,
-                                                             rows, E | t_tail_flag, N, K, group_shift, g_w4_probe, fuse, t_act_limit, t_row_map);
+                                                             rows, E | t_tail_flag, N, K, group_shift, g_w4_probe, fuse, t_act_limit, t_row_map, t_act_alpha);
   return check_launch("moe_grouped_mm_nt_xe20_w4a16");
 }
 
@@ -873,7 +886,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
   // (a narrow projection keeps the 16-row tile up to an average of 20 rows: ragged counts around 16 - 64 tokens, top-2 of 8 -
   // 81 us against 96 us with the 32-row tile for the down projection; the gate / up projection measured 151 against 145)
-  const bool gated_epi = fuse == 1 || fuse == 2 || fuse == 4;  // (needs the two-tile wave: no 16-column wave tiles, no K split)
+  const bool gated_epi = fuse == 1 || fuse == 2 || fuse == 4 || fuse == 5;  // (needs the two-tile wave: no 16-column wave tiles, no K split)
   const bool narrow16 = !gated_epi && gp == 7 && K % 1024 == 0 &&
                         std::max<int64_t>(std::min<int64_t>(pol_m, E), pol_m / 16) * cdiv(N, 128) <= 384;
   const bool small = avg <= 10 || (narrow16 && avg <= 20 && g_w4_mt == 0);
@@ -946,7 +959,7 @@ extern "C" int sglk_moe_grouped_mm_w4a16(sglk_stream_t stream, void* out, const 
 static int w4a16_run(sglk_stream_t stream, void* out, const void* activations, const void* packed_weights, const void* scales,
                      const void* zeros, const float* bias, const int32_t* rows_per_expert, int64_t total_m, int64_t n_experts,
                      int64_t N, int64_t K, int64_t group_size, int is_int4, int dtype, int fused_act, float act_limit,
-                     const int32_t* row_map, int64_t src_rows, float* split_ws, int* split_used);
+                     const int32_t* row_map, int64_t src_rows, float* split_ws, int* split_used, float act_alpha = 0.f);
 
 extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, const void* activations,
                                              const void* packed_weights, const void* scales, const void* zeros,
@@ -956,6 +969,15 @@ extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, co
                                              int64_t src_rows) {
   return w4a16_run(stream, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m, n_experts, N, K,
                    group_size, is_int4, dtype, fused_act, act_limit, row_map, src_rows, nullptr, nullptr);
+}
+
+extern "C" int sglk_moe_grouped_mm_w4a16_swiglu(sglk_stream_t stream, void* out, const void* activations,
+                                                const void* packed_weights, const void* scales, const void* zeros,
+                                                const float* bias, const int32_t* rows_per_expert, int64_t total_m,
+                                                int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
+                                                int dtype, float alpha, float limit, const int32_t* row_map, int64_t src_rows) {
+  return w4a16_run(stream, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m, n_experts, N, K,
+                   group_size, is_int4, dtype, 5, limit, row_map, src_rows, nullptr, nullptr, alpha);
 }
 
 extern "C" int sglk_moe_grouped_mm_w4a16_splitk(sglk_stream_t stream, void* out, float* ws, const void* activations,
@@ -980,16 +1002,19 @@ extern "C" int sglk_moe_w4a16_splitk_applies(int64_t total_m, int64_t n_experts,
 static int w4a16_run(sglk_stream_t stream, void* out, const void* activations, const void* packed_weights, const void* scales,
                      const void* zeros, const float* bias, const int32_t* rows_per_expert, int64_t total_m, int64_t n_experts,
                      int64_t N, int64_t K, int64_t group_size, int is_int4, int dtype, int fused_act, float act_limit,
-                     const int32_t* row_map, int64_t src_rows, float* split_ws, int* split_used) {
+                     const int32_t* row_map, int64_t src_rows, float* split_ws, int* split_used, float act_alpha) {
   using namespace sglk;
   SGLK_REQUIRE(row_map == nullptr || (src_rows > 0 && src_rows * K < (1ll << 32)),
                "moe_grouped_mm_nt_xe20_w4a16: a row map needs 0 < src_rows and src_rows * K < 2^32 (src_rows=%lld)",
                (long long)src_rows);
-  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 4,
-               "moe_grouped_mm_nt_xe20_w4a16: fused_act must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2) or 4 (clamped swiglu)");
-  SGLK_REQUIRE(fused_act != 4 || act_limit > 0.f, "moe_grouped_mm_nt_xe20_w4a16: the clamped swiglu needs a positive limit");
+  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 5,
+               "moe_grouped_mm_nt_xe20_w4a16: fused_act must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2), 4 (clamped swiglu) or 5 "
+               "(gpt-oss swiglu)");
+  SGLK_REQUIRE((fused_act != 4 && fused_act != 5) || act_limit > 0.f,
+               "moe_grouped_mm_nt_xe20_w4a16: the clamped / gpt-oss swiglu needs a positive limit");
   t_act_limit = act_limit;
-  SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2 || fused_act == 4) || N % 16 == 0,
+  t_act_alpha = act_alpha;
+  SGLK_REQUIRE(!(fused_act == 1 || fused_act == 2 || fused_act == 4 || fused_act == 5) || N % 16 == 0,
                "moe_grouped_mm_nt_xe20_w4a16: a gated epilogue needs N (gate + up rows) to be a multiple of 16");
   SGLK_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256,
                "group_size must be 32, 64, 128 or 256; got %lld", (long long)group_size);
@@ -1037,7 +1062,7 @@ static int w4a16_run(sglk_stream_t stream, void* out, const void* activations, c
   }
   if (row_map == nullptr) {
     if (int rc = moe_persist_try(st, out, activations, packed_weights, scales, is_int4 ? zeros : nullptr, gs, bias, rows_per_expert, total_m, (int)n_experts,
-                                 (int)N, (int)K, 0, 0, dtype, is_int4 ? 1 : 2, fused_act, act_limit)) {
+                                 (int)N, (int)K, 0, 0, dtype, is_int4 ? 1 : 2, fused_act, act_limit, act_alpha)) {
       if (rc < 0) return rc;
       if (rc == 3) return SGLK_OK;  // (the tile pipeline took the remainders too)
       // the experts' last rows (at most 128 each) on the streaming kernels, sized for the worst case

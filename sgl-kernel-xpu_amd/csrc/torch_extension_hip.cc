@@ -676,7 +676,7 @@ static int64_t moe_w4a16_impl(Tensor& output, const Tensor& activations, const T
                           const Tensor& scales, const std::optional<Tensor>& zeros,
                           const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
                           bool is_int4, int64_t group_size, int64_t fused_act, double act_limit,
-                          const std::optional<Tensor>& row_map = std::nullopt, Tensor* split_ws = nullptr) {
+                          const std::optional<Tensor>& row_map = std::nullopt, Tensor* split_ws = nullptr, double act_alpha = 0.0) {
   CHECK_GPU(output);
   CHECK_GPU(activations);
   CHECK_GPU(packed_weights);
@@ -723,8 +723,9 @@ static int64_t moe_w4a16_impl(Tensor& output, const Tensor& activations, const T
   TORCH_CHECK(n_experts == rows_per_expert.size(0), "rows_per_expert must have n_experts elements");
   TORCH_CHECK(rows_per_expert.scalar_type() == at::kInt, "rows_per_expert must be int32");
   TORCH_CHECK(output.size(0) == total_m, map_ptr ? "output rows must match row_map's length" : "output rows must match activations rows");
-  TORCH_CHECK(fused_act >= 0 && fused_act <= 4, "activation_type must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2) or 4 (clamped swiglu)");
-  const bool gated = fused_act == 1 || fused_act == 2 || fused_act == 4;
+  TORCH_CHECK(fused_act >= 0 && fused_act <= 5,
+              "activation_type must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2), 4 (clamped swiglu) or 5 (gpt-oss swiglu)");
+  const bool gated = fused_act == 1 || fused_act == 2 || fused_act == 4 || fused_act == 5;
   TORCH_CHECK(output.size(1) == (gated ? gemm_n / 2 : gemm_n), gated ? "output must have N / 2 columns (gate rows, then up rows in W)"
                                                                      : "output must have N columns");
   TORCH_CHECK(gemm_n % 8 == 0, "N must be divisible by 8");
@@ -767,6 +768,14 @@ static int64_t moe_w4a16_impl(Tensor& output, const Tensor& activations, const T
                                                rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k, group_size,
                                                is_int4 ? 1 : 0, dtype_code(activations.scalar_type(), "activations"), &used));
     return used;
+  }
+  if (fused_act == 5) {
+    SGLK_CALL(sglk_moe_grouped_mm_w4a16_swiglu(stream_of(activations), output.data_ptr(), activations.data_ptr(),
+                                               packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr, bias_ptr,
+                                               rows_per_expert.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k, group_size,
+                                               is_int4 ? 1 : 0, dtype_code(activations.scalar_type(), "activations"),
+                                               (float)act_alpha, (float)act_limit, map_ptr, activations.size(0)));
+    return 0;
   }
   SGLK_CALL(sglk_moe_grouped_mm_w4a16_act(stream_of(activations), output.data_ptr(), activations.data_ptr(),
                                           packed_weights.data_ptr(), scales_al.data_ptr(), zeros_ptr, bias_ptr,
@@ -840,16 +849,18 @@ void moe_grouped_mm_nt_xe20_w4a16(Tensor& output, const Tensor& activations, con
 
 // authored (no reference op: the reference runs GEMM 1 and the gate / up activation as two launches,
 // python/sgl_kernel/moe.py:751-835): the same GEMM with the activation on its fp32 accumulators.
-// activation_type: 1 silu, 2 gelu (tanh), 4 clamped swiglu (act_limit) - output [total_m, N / 2]; 3 relu2 - output [total_m, N]
+// activation_type: 1 silu, 2 gelu (tanh), 4 clamped swiglu (act_limit) - output [total_m, N / 2]; 3 relu2 - output [total_m, N];
+// 5 the gpt-oss swiglu (act_alpha, act_limit; gate / up rows INTERLEAVED in the weights as the reference's fused 16-bit GEMM takes
+// them, kernels/moe/xe20/bf16/moe_kernel.hpp:109-125) - output [total_m, N / 2]
 // row_map (optional, int32 [total_m]): activations are the tokens [T, K] and row r reads activations[row_map[r]] - the
 // reference's shuffle_rows (python/sgl_kernel/moe.py:739) folded into the GEMM's staging loads
 void moe_grouped_mm_nt_w4a16_act(Tensor& output, const Tensor& activations, const Tensor& packed_weights,
                                  const Tensor& scales, const std::optional<Tensor>& zeros,
                                  const std::optional<Tensor>& bias, const Tensor& rows_per_expert, int64_t n_experts,
                                  bool is_int4, int64_t group_size, int64_t activation_type, double act_limit,
-                                 const std::optional<Tensor>& row_map) {
+                                 const std::optional<Tensor>& row_map, double act_alpha) {
   moe_w4a16_impl(output, activations, packed_weights, scales, zeros, bias, rows_per_expert, n_experts, is_int4, group_size,
-                 activation_type, act_limit, row_map);
+                 activation_type, act_limit, row_map, nullptr, act_alpha);
 }
 
 // ---- moe_grouped_mm_nt_xe20 (reference src/sycl/GroupGemmXe20.cpp:160-275) ---------------------------------
@@ -857,8 +868,6 @@ void moe_grouped_mm_nt_w4a16_act(Tensor& output, const Tensor& activations, cons
 void moe_grouped_mm_nt_xe20(Tensor& output, const Tensor& activations, const Tensor& weights, const std::optional<Tensor>& bias,
                             const Tensor& total_rows_for_experts, int64_t n_experts, int64_t activation_type, bool fuse_act,
                             double gemm1_alpha, double gemm1_limit) {
-  (void)gemm1_alpha;
-  (void)gemm1_limit;
   CHECK_GPU(output);
   CHECK_GPU(activations);
   CHECK_GPU(weights);
@@ -889,11 +898,17 @@ void moe_grouped_mm_nt_xe20(Tensor& output, const Tensor& activations, const Ten
   }
   const c10::OptionalDeviceGuard guard(activations.device());
   const int dt = dtype_code(activations.scalar_type(), "activations");
-  // fused epilogue codes of the C-ABI: 0 none, 1 silu (gated), 2 gelu (gated), 3 relu2
+  // fused epilogue codes of the C-ABI: 0 none, 1 silu (gated), 2 gelu (gated), 3 relu2; the gpt-oss swiglu (activation_type 2:
+  // gate / up rows interleaved, reference moe_kernel.hpp:109-125) has its own entry point with alpha and limit
   int fused = 0;
-  if (fuse_act) {
-    TORCH_CHECK(activation_type != 2, "moe_grouped_mm_nt_xe20: the gpt-oss clamped swiglu epilogue (activation_type 2) is outside this build");
-    fused = activation_type == 0 ? 1 : activation_type == 1 ? 2 : 3;
+  if (fuse_act) fused = activation_type == 0 ? 1 : activation_type == 1 ? 2 : activation_type == 2 ? 5 : 3;
+  if (fused == 5) {
+    TORCH_CHECK(gemm_n % 2 == 0 && output.size(1) == gemm_n / 2, "output must have half the number of columns as activations");
+    TORCH_CHECK(gemm1_limit > 0.0, "moe_grouped_mm_nt_xe20: gemm1_limit must be positive");
+    SGLK_CALL(sglk_moe_grouped_mm_swiglu(stream_of(activations), output.data_ptr(), activations.data_ptr(), weights.data_ptr(),
+                                         bias_ptr, total_rows_for_experts.data_ptr<int32_t>(), total_m, n_experts, gemm_n, gemm_k,
+                                         weights.stride(1), weights.stride(0), dt, (float)gemm1_alpha, (float)gemm1_limit));
+    return;
   }
   if (fused == 1 || fused == 2) {
     TORCH_CHECK(gemm_n % 2 == 0 && output.size(1) == gemm_n / 2, "output must have half the number of columns as activations");
@@ -1731,7 +1746,7 @@ TORCH_LIBRARY_FRAGMENT(sgl_kernel, m) {
   m.def(
       "moe_grouped_mm_nt_w4a16_act(Tensor! output, Tensor activations, Tensor packed_weights, Tensor scales, "
       "Tensor? zeros, Tensor? bias, Tensor rows_per_expert, int n_experts, bool is_int4, int group_size, "
-      "int activation_type, float act_limit=0.0, Tensor? row_map=None) -> ()");
+      "int activation_type, float act_limit=0.0, Tensor? row_map=None, float act_alpha=0.0) -> ()");
   m.impl("moe_grouped_mm_nt_w4a16_act", c10::kCUDA, &moe_grouped_mm_nt_w4a16_act);
   m.def(
       "moe_grouped_mm_nt_w4a16_splitk(Tensor! output, Tensor! ws, Tensor activations, Tensor packed_weights, Tensor scales, "

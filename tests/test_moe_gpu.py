@@ -184,7 +184,7 @@ def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
         assert (near_exact | torch.isclose(o, ref.float(), rtol=1e-2, atol=2e-3)).all()
 
 
-@pytest.mark.parametrize("act_type", [1, 2, 3, 4])  # silu, gelu (tanh), relu2, DeepSeek-V4 clamped swiglu
+@pytest.mark.parametrize("act_type", [1, 2, 3, 4, 5])  # silu, gelu (tanh), relu2, DeepSeek-V4 clamped swiglu, gpt-oss swiglu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("gs,explicit_zero", [(128, False), (32, True), (64, False)])
 @pytest.mark.parametrize("rows,N,K", [([2] * 8, 256, 256), ([0, 5, 17, 0, 1, 33, 0, 129], 416, 512),
@@ -206,8 +206,9 @@ def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit
     wq = packed.view(torch.int8 if explicit_zero else torch.uint8).to(dev)
     d = lambda t: t.to(dev) if t is not None else None
     limit = 0.25  # (small enough that the clamp of act_type 4 bites on these inputs)
+    alpha = 1.702
     torch.ops.sgl_kernel.moe_grouped_mm_nt_w4a16_act(out, act.to(dev), wq, scales.to(dev), d(zeros), d(bias), rows_t.to(dev),
-                                                     E, True, gs, act_type, limit)
+                                                     E, True, gs, act_type, limit, None, alpha)
     codes = omoe.unpack_int4(packed, signed=zeros is None).float()
     z = zeros.float().repeat_interleave(gs, dim=-1) if zeros is not None else 0.0
     w_exact = (codes - z) * scales.float().repeat_interleave(gs, dim=-1)
@@ -222,6 +223,10 @@ def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit
     elif act_type == 4:  # reference silu_and_mul_clamp: gate = min(gate, limit), up = clamp(up, +-limit)
         ref = torch.nn.functional.silu(x[:, :N // 2].clamp(max=limit)) * x[:, N // 2:].clamp(-limit, limit)
         assert (x[:, :N // 2] > limit).any() and (x[:, N // 2:].abs() > limit).any()
+    elif act_type == 5:  # gate = weight rows 0, 2, .., up = rows 1, 3, .. (reference moe_kernel.hpp:109-125, activation.hpp:35-41)
+        gt, up = x[:, 0::2].clamp(max=limit), x[:, 1::2].clamp(-limit, limit)
+        ref = gt * torch.sigmoid(alpha * gt) * (up + 1.0)
+        assert (x[:, 0::2] > limit).any() and (x[:, 1::2].abs() > limit).any()
     else:
         ref = torch.relu(x) ** 2
     torch.testing.assert_close(out.cpu().float(), ref.to(dtype).float(), rtol=1e-2, atol=2e-3)
@@ -232,6 +237,8 @@ def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit
     if act_type == 4:
         guf = gu.float()
         two = torch.nn.functional.silu(guf[:, :N // 2].clamp(max=limit)) * guf[:, N // 2:].clamp(-limit, limit)
+    elif act_type == 5:  # (the reference's W4A16 route: swiglu_gpt_oss_sigmoid_alpha on the rounded [rows, 2I] product)
+        two = torch.ops.sgl_kernel.swiglu_gpt_oss_sigmoid_alpha(gu, alpha, limit)
     elif gated:
         two = torch.empty(total, N // 2, dtype=dtype, device=dev)
         (torch.ops.sgl_kernel.silu_and_mul if act_type == 1 else torch.ops.sgl_kernel.gelu_tanh_and_mul)(two, gu)
@@ -241,7 +248,7 @@ def test_moe_grouped_mm_w4a16_fused_act(sglk, dev, act_type, dtype, gs, explicit
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("act_type", [1, 3, 4])
+@pytest.mark.parametrize("act_type", [1, 3, 4, 5])
 @pytest.mark.parametrize("fmt", ["int4", "int4_zp", "mxfp4"])
 @pytest.mark.parametrize("rows,N,K,tokens", [([2] * 8, 256, 256, 3), ([0, 5, 17, 0, 1, 33, 0, 70], 416, 512, 40),
                                              ([1] * 8, 4096, 1024, 1), ([3, 0, 16, 7], 208, 4096, 9),
@@ -269,8 +276,9 @@ def test_moe_grouped_mm_w4a16_row_map_is_the_gather(sglk, dev, dtype, act_type, 
     mapped = torch.full((total, cols), float("nan"), dtype=dtype, device=dev)
     plain = torch.full((total, cols), float("nan"), dtype=dtype, device=dev)
     op = torch.ops.sgl_kernel.moe_grouped_mm_nt_w4a16_act
-    op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25, row_map)
-    op(plain, x[row_map.long()].contiguous(), packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25)
+    op(mapped, x, packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25, row_map, 1.702)
+    op(plain, x[row_map.long()].contiguous(), packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25,
+       None, 1.702)
     assert torch.isfinite(mapped.float()).all()
     if total < 96 * E:
         assert torch.equal(mapped, plain)
@@ -669,12 +677,14 @@ def _check_fused_act_16bit(sglk, dev, g, rows, N, K):
     w = (torch.randn(E, N, K, generator=g) * 0.1).to(dt)
     r = torch.tensor(rows, dtype=torch.int32)
     bias = torch.randn(E, N, generator=g) * 0.01
-    for act_type, name in ((0, "silu"), (1, "gelu"), (3, "relu2")):
+    # (swiglu_gpt_oss - activation_type 2 with fuse_act, gate / up rows interleaved, reference moe_kernel.hpp:109-125 - with a limit
+    #  small enough to bite on these inputs)
+    for act_type, name in ((0, "silu"), (1, "gelu"), (3, "relu2"), (2, "swiglu_gpt_oss")):
         for b in (None, bias):
             out = torch.full((sum(rows), N if name == "relu2" else N // 2), float("nan"), dtype=dt, device=dev)
             torch.ops.sgl_kernel.moe_grouped_mm_nt_xe20(out, act.to(dev), w.to(dev), b.to(dev) if b is not None else None,
-                                                       r.to(dev), E, act_type, True, 1.702, 7.0)
-            ref = omoe.moe_grouped_mm_fused(act, w, b, r, name)
+                                                       r.to(dev), E, act_type, True, 1.702, 0.4)
+            ref = omoe.moe_grouped_mm_fused(act, w, b, r, name, 1.702, 0.4)
             torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=1e-2, atol=1e-3)
 
 
@@ -762,9 +772,11 @@ def test_fused_experts_gpt_oss_swiglu_reference_inputs(sglk, dev, T, topk, E, H,
 
 @pytest.mark.parametrize("explicit_zero", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fused_experts_int4_gpt_oss_swiglu(sglk, dev, explicit_zero, dtype):
-    g = torch.Generator().manual_seed(5 + explicit_zero)
-    T, E, topk, H, I, gs = 40, 8, 2, 512, 256, 64
+@pytest.mark.parametrize("T", [40, 260, 520])  # (decode: the reference's sequence; 65 rows per expert: the swiglu in GEMM 1's epilogue on
+                                               #  the streaming kernels with the gather; 130: on the tile pipeline, K split in GEMM 2)
+def test_fused_experts_int4_gpt_oss_swiglu(sglk, dev, explicit_zero, dtype, T):
+    g = torch.Generator().manual_seed(5 + explicit_zero + T)
+    E, topk, H, I, gs = 8, 2, 512, 256, 64
     x = torch.randn(T, H, generator=g).to(dtype)
     w1, s1, z1 = make_int4(E, 2 * I, H, gs, dtype, explicit_zero, g)
     w2, s2, z2 = make_int4(E, H, I, gs, dtype, explicit_zero, g)
