@@ -23,7 +23,7 @@ for s in $SETS; do
     prefill_64) ATTN_PREFILL_ONLY=64 tools/gpu_prof.sh attn_prefill_d64 python3 $R/tools/attn_prefill_bench.py ;;
     prefill_chunk) ATTN_PREFILL_ONLY=chunk tools/gpu_prof.sh attn_prefill_chunk128 python3 $R/tools/attn_prefill_bench.py ;;
     prefill_softcap) ATTN_PREFILL_ONLY=softcap tools/gpu_prof.sh attn_prefill_softcap python3 $R/tools/attn_prefill_bench.py ;;
-    moe) tools/gpu_prof.sh moe python3 $R/tools/moe_bench.py 64 512 2048 ;;
+    moe) MOE_BENCH_INT4_ONLY=1 tools/gpu_prof.sh moe python3 $R/tools/moe_bench.py 64 512 2048 ;;
   esac
 done > $R/gpurun_out/r05/prof_all.log 2>&1
 ls $R/gpurun_out/r05/prof/digest
