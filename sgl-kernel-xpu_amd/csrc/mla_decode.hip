@@ -953,8 +953,17 @@ __global__ __launch_bounds__(kThreads2, 1) void mla_rows128z_kernel(MlaParams p,
   };
   const int ntiles = (seq + kTile - 1) / kTile;
   const int tps = (ntiles + p.splits - 1) / p.splits;
-  const int t_begin = split * tps;
-  const int t_end = (t_begin + tps < ntiles) ? (t_begin + tps) : ntiles;
+  int t_begin = split * tps;
+  int t_end = (t_begin + tps < ntiles) ? (t_begin + tps) : ntiles;
+#ifdef SGLK_PROBES
+  // (probe 9: two splits of unequal length - the first one tile shorter: it finishes first, publishes while the second still
+  //  streams, and the second, the merger, finds the partial result waiting)
+  if (p.probe == 9 && p.splits == 2 && tps >= 16) {
+    const int cut = tps - 1;
+    t_begin = split ? cut : 0;
+    t_end = split ? ntiles : cut;
+  }
+#endif
   const int n_my = t_end - t_begin;
 
   const int32_t* table = page_table + (int64_t)b * p.table_stride;
