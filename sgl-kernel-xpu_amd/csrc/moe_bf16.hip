@@ -83,8 +83,10 @@ __global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, 
   const int l15 = lane & 15, g = lane >> 4;
 
   // ---- which (expert, block of its rows, column block): see moe_tiles.h
-  constexpr bool kGated = FUSE == FUSE_SILU || FUSE == FUSE_GELU || FUSE == FUSE_SWIGLU;
-  constexpr bool kPairs = FUSE == FUSE_SWIGLU;  // gate / up rows interleaved (2 n, 2 n + 1) instead of halves (n, N / 2 + n)
+  constexpr bool kGated = FUSE == FUSE_SILU || FUSE == FUSE_GELU;
+  // gpt-oss: gate / up are weight rows 2 n, 2 n + 1 - on the PLAIN tile layout (16 consecutive rows per wave tile: a pair sits in
+  // neighbouring lanes, the epilogue fetches the partner's accumulator from lane l15 ^ 1; see moe_w4a16.hip)
+  constexpr bool kPairs = FUSE == FUSE_SWIGLU;
   static_assert(!kGated || NW == 2, "the gated epilogue pairs the two n tiles of a wave");
   const int Nh = N >> 1;  // gated: output width; gate rows [0, Nh), up rows [Nh, N)
   const MoeTile tile = find_moe_tile(rows_per_expert, E, BM, kGated ? (Nh + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN);
@@ -96,8 +98,8 @@ __global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, 
   uint32_t woff[NW];  // element offset of this lane's row and k group
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt) {
-    int n = kPairs ? 2 * (n_base + l15) + nt : kGated ? n_base + l15 + nt * Nh : n_base + nt * 16 + l15;
-    const int lim = kPairs ? N : kGated ? (nt + 1) * Nh : N;
+    int n = kGated ? n_base + l15 + nt * Nh : n_base + nt * 16 + l15;
+    const int lim = kGated ? (nt + 1) * Nh : N;
     n = n < lim ? n : lim - 1;
     woff[nt] = (uint32_t)n * (uint32_t)ldb + 8 * g;
   }
@@ -196,8 +198,7 @@ __global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, 
   if constexpr (kGated) {
     const int n = n_base + l15;
     if (n < Nh) {
-      const float bg = bias ? bias[(int64_t)e * N + (kPairs ? 2 * n : n)] : 0.f,
-                  bu = bias ? bias[(int64_t)e * N + (kPairs ? 2 * n + 1 : Nh + n)] : 0.f;
+      const float bg = bias ? bias[(int64_t)e * N + n] : 0.f, bu = bias ? bias[(int64_t)e * N + Nh + n] : 0.f;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -220,6 +221,11 @@ __global__ __launch_bounds__(64 * WV) void moe_bf16_kernel(T* __restrict__ out, 
         for (int r = 0; r < 4; ++r) {
           const int row = mt * 16 + 4 * g + r;
           float v = acc[mt][nt][r] + bv;
+          if constexpr (kPairs) {  // even lane: gate (row n), its right neighbour: up (row n + 1); N even: both or neither in range
+            const float other = __shfl_xor(v, 1, 64);
+            if (!(l15 & 1) && row < m_valid) out[(int64_t)(m0 + row) * Nh + (n >> 1)] = (T)gated_act<FUSE>(v, other, act_alpha, act_limit);
+            continue;
+          }
           if constexpr (FUSE == FUSE_RELU2) {
             v = fmaxf(v, 0.f);
             v = v * v;
@@ -235,7 +241,7 @@ template <typename T, int MT, int NW, int WV = 4>
 static int launch(hipStream_t st, void* out, const void* act, const void* w, const float* bias, const int32_t* rows,
                   int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
   constexpr int BM = 16 * MT, BN = 16 * NW * WV;
-  const bool gated = fuse == FUSE_SILU || fuse == FUSE_GELU || fuse == FUSE_SWIGLU;
+  const bool gated = fuse == FUSE_SILU || fuse == FUSE_GELU;  // (the gpt-oss swiglu runs on the plain layout)
   const int64_t wgs = moe_tile_launch_size(total_m, E, BM, gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN));
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20: problem too large for one launch");
   dim3 grid((unsigned)wgs);

@@ -225,8 +225,12 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
   // activations in L2 - 731 against 755 us for the Mixtral down projection at 512 rows per expert; the gate / up projection
   // measured the other way round, 1609 against 1706 us. Probe 512 flips the choice.)
   // fuse 5: the gpt-oss swiglu (reference kernels/moe/xe20/common/activation.hpp:31-42, moe_kernel.hpp:109-125 - the fused form of
-  // the reference's 16-bit GEMM): gate = weight row 2 n, up = row 2 n + 1 (INTERLEAVED), bias likewise
-  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4 || fuse == 5);
+  // the reference's 16-bit GEMM): gate = weight row 2 n, up = row 2 n + 1 (INTERLEAVED), bias likewise. Here it runs on the PLAIN
+  // tile layout - a wave tile is 16 consecutive weight rows, i.e. eight (gate, up) pairs in neighbouring lanes - and the epilogue
+  // fetches the partner's accumulator from lane l15 ^ 1. (First form: the gated layout with the row map 2 n / 2 n + 1 - a load
+  // instruction then touches 16 rows 4 KiB apart: 172 us against 132 for the split-halves silu at 64 Mixtral tokens, and the
+  // decode-sized tile forms of the plain GEMM - 64-column workgroups, 16-column wave tiles - were out of reach.)
+  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4);
   const bool pairs = fuse == 5;
   const int Nh = N >> 1;  // gated: output width
   const int col_blocks = gated ? (Nh + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN;
@@ -239,7 +243,6 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
     if (!gated) return n_base + nt * 16 + l15;
     constexpr int H2 = NW >= 2 ? NW / 2 : 1;
     const int ng = tile.col_block * (BN / 2) + wave * (H2 * 16) + (nt % H2) * 16 + l15;  // gate column = output column
-    if (pairs) return 2 * ng + (nt < H2 ? 0 : 1);
     return nt < H2 ? ng : Nh + ng;
   };
   auto out_col_of = [&](int nt) -> int {  // output column of gate tile nt (nt < NW / 2)
@@ -555,8 +558,7 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
       for (int nt = 0; nt < H2; ++nt) {
         const int n = out_col_of(nt);  // gate column = output column
         if (n >= Nh) continue;
-        const float bg = bias ? bias[(int64_t)e * N + (pairs ? 2 * n : n)] : 0.f,
-                    bu = bias ? bias[(int64_t)e * N + (pairs ? 2 * n + 1 : Nh + n)] : 0.f;
+        const float bg = bias ? bias[(int64_t)e * N + n] : 0.f, bu = bias ? bias[(int64_t)e * N + Nh + n] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -568,11 +570,7 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
               y = fminf(fmaxf(y, -act_limit), act_limit);
             }
             float a;
-            if (fuse == 5) {
-              x = fminf(x, act_limit);
-              y = fmaxf(-act_limit, fminf(y, act_limit)) + 1.0f;
-              a = x * (1.0f / (1.0f + expf(-(x * act_alpha))));
-            } else if (fuse == 1 || fuse == 4) {
+            if (fuse == 1 || fuse == 4) {
               a = x / (1.0f + expf(-x));
             } else {
               const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -596,6 +594,14 @@ __global__ __launch_bounds__(64 * WV, (MT <= 2 ? 2 : 1)) void moe_w4a16_kernel(T
       for (int r = 0; r < 4; ++r) {
         const int row = mt * 16 + 4 * g + r;
         float v = acc[mt][nt][r] + bv;
+        if (pairs) {  // even lane: gate (weight row n), its right neighbour: up (row n + 1); N is even, so both or neither is in range
+          const float other = __shfl_xor(v, 1, 64);
+          if (!(l15 & 1) && row < m_valid) {
+            const float gt = fminf(v, act_limit), up = fmaxf(-act_limit, fminf(other, act_limit)) + 1.0f;
+            out[(int64_t)(m0 + row) * Nh + (n >> 1)] = (T)(gt * (1.0f / (1.0f + expf(-(gt * act_alpha)))) * up);
+          }
+          continue;
+        }
         if (fuse == 3) {
           v = fmaxf(v, 0.f);
           v = v * v;
@@ -833,7 +839,7 @@ template <typename T, int MT, int NW, int PB, int FMT = 0, int WV = 4>
 static int launch_pb(hipStream_t st, void* out, const void* act, const void* wq, const void* scales, const void* zeros,
                   const float* bias, const int32_t* rows, int64_t total_m, int E, int N, int K, int group_shift, int fuse) {
   constexpr int BM = 16 * MT, BN = 16 * NW * WV;
-  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4 || fuse == 5);
+  const bool gated = NW >= 2 && (fuse == 1 || fuse == 2 || fuse == 4);  // (5, the gpt-oss swiglu, runs on the plain layout)
   const int64_t wgs = moe_tile_launch_size(total_m, E, BM, gated ? cdiv(N / 2, BN / 2) : cdiv(N, BN));
   if (wgs >= ((int64_t)1 << 31)) return fail(SGLK_EINVAL, "moe_grouped_mm_nt_xe20_w4a16: problem too large for one launch");
   dim3 grid((unsigned)wgs);
@@ -886,7 +892,7 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* wq, 
   // workgroups with an 8-deep weight ring instead - twice the workgroups, the same bytes in flight per wave
   // (a narrow projection keeps the 16-row tile up to an average of 20 rows: ragged counts around 16 - 64 tokens, top-2 of 8 -
   // 81 us against 96 us with the 32-row tile for the down projection; the gate / up projection measured 151 against 145)
-  const bool gated_epi = fuse == 1 || fuse == 2 || fuse == 4 || fuse == 5;  // (needs the two-tile wave: no 16-column wave tiles, no K split)
+  const bool gated_epi = fuse == 1 || fuse == 2 || fuse == 4;  // (needs the two-tile wave: no 16-column wave tiles, no K split)
   const bool narrow16 = !gated_epi && gp == 7 && K % 1024 == 0 &&
                         std::max<int64_t>(std::min<int64_t>(pol_m, E), pol_m / 16) * cdiv(N, 128) <= 384;
   const bool small = avg <= 10 || (narrow16 && avg <= 20 && g_w4_mt == 0);

@@ -287,12 +287,8 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     # decode sizes with 4-bit weights: GEMM 1 gathers its rows through a_map itself (the streaming kernels' staging loads),
     # no [rows, hidden] copy of the tokens and one launch less. From 96 rows per expert on the tile pipeline takes the
     # GEMM, which stages expert-contiguous rows by LDS-DMA: the copy (reference shuffle_rows, moe.py:739) stays there.
-    # gpt-oss swiglu with 4-bit weights: in GEMM 1's epilogue from an average of 48 rows per expert on (measured, Mixtral-sized
-    # experts: 272 against 286 us at 64 rows per expert, 1.80 against 1.94 ms at 1024; at 16 rows per expert the plain GEMM's
-    # narrower decode tiles win - 137 us for GEMM + swiglu op against 172 fused - so decode sizes keep the reference's sequence)
-    swiglu_in_gemm1 = gemm1_alpha is not None and (not p.four_bit or p.rows >= 48 * p.experts)
-    gather_in_gemm1 = (p.four_bit and (gemm1_alpha is None or swiglu_in_gemm1) and w1_g_idx_perm is None
-                       and p.rows < 96 * p.experts and p.tokens * p.hidden < 2**32)
+    gather_in_gemm1 = (p.four_bit and w1_g_idx_perm is None and p.rows < 96 * p.experts
+                       and p.tokens * p.hidden < 2**32)
     if gather_in_gemm1:
         x = hidden_states.contiguous()
     else:
@@ -310,17 +306,12 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     # ---- GEMM 1 with the gate / up activation (or relu2) on its fp32 accumulators, in the epilogue: no [rows, 2I]
     # intermediate, no separate act-and-mul launch (the reference runs them as two launches, moe.py:751-835)
     h = scratch("intermediate_cache1_fused", (p.rows, p.inter))
-    if gemm1_alpha is not None and not swiglu_in_gemm1:
-        # gpt-oss at decode sizes with 4-bit weights: the reference's own sequence (moe.py:748-789) - plain GEMM 1 to [rows, 2I],
-        # then its op on the (gate, up) pairs of the rounded product
-        full = scratch("intermediate_cache1", (p.rows, 2 * p.inter))
-        grouped_mm(full, x, w1, w1_scale, w1_zp, b1, p.group1)
-        h = _ops.swiglu_gpt_oss_sigmoid_alpha(full, float(gemm1_alpha), float(gemm1_limit))
-    elif gemm1_alpha is not None:
+    if gemm1_alpha is not None:
         # gpt-oss: the rows of w1 are (gate, up) PAIRS; the swiglu runs in the GEMM's epilogue on the fp32 accumulators, as the
         # reference's fused 16-bit GEMM does it (moe_grouped_mm_nt_xe20 with activation_type 2 and fuse_act, moe.py:830-846;
         # kernels/moe/xe20/bf16/moe_kernel.hpp:109-125) - for 4-bit weights too, where the reference writes [rows, 2I] and calls
-        # swiglu_gpt_oss_sigmoid_alpha on it (moe.py:748-789): no [rows, 2I] round trip through HBM, one launch less
+        # swiglu_gpt_oss_sigmoid_alpha on it (moe.py:748-789): no [rows, 2I] round trip through HBM, one launch less (graph-timed,
+        # Mixtral-sized experts, GEMM 1 alone: 111 against 123 us at 16 tokens, 135 / 137 at 64, 362 / 381 at 512, 1.80 / 1.94 ms at 4096)
         if p.four_bit:
             _ops.moe_grouped_mm_nt_w4a16_act(h, x, w1, w1_scale, w1_zp, b1, rows_per_expert, p.experts, p.int4, p.group1, 5,
                                              float(gemm1_limit), src_rows if gather_in_gemm1 else None, float(gemm1_alpha))
