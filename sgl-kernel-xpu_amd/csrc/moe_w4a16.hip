@@ -973,6 +973,9 @@ extern "C" int sglk_moe_grouped_mm_w4a16_act(sglk_stream_t stream, void* out, co
                                              int64_t n_experts, int64_t N, int64_t K, int64_t group_size, int is_int4,
                                              int dtype, int fused_act, float act_limit, const int32_t* row_map,
                                              int64_t src_rows) {
+  // (5, the gpt-oss swiglu, needs its alpha: sglk_moe_grouped_mm_w4a16_swiglu)
+  SGLK_REQUIRE(fused_act >= 0 && fused_act <= 4,
+               "moe_grouped_mm_nt_xe20_w4a16: fused_act must be 0 (none), 1 (silu), 2 (gelu), 3 (relu2) or 4 (clamped swiglu)");
   return w4a16_run(stream, out, activations, packed_weights, scales, zeros, bias, rows_per_expert, total_m, n_experts, N, K,
                    group_size, is_int4, dtype, fused_act, act_limit, row_map, src_rows, nullptr, nullptr);
 }

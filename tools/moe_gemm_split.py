@@ -45,6 +45,8 @@ def clock_of(f):
 
 if os.environ.get("MOE_WIDE"):  # 0: the 128-row blocks as 128 x 256 tiles (MS = 2) instead of 128 x 512
     lib.sglk_debug_set_moe_persist_wide(int(os.environ["MOE_WIDE"]))
+if os.environ.get("MOE_W4_MT"):  # forced tile form of the streaming kernels (12: the K-split kernel, 11: 64-column workgroups, ...)
+    lib.sglk_debug_set_w4a16_probe(0, int(os.environ["MOE_W4_MT"]))
 if os.environ.get("MOE_PRIO"):
     lib.sglk_debug_set_moe_prio(int(os.environ["MOE_PRIO"]))
 for T in (int(a) for a in (sys.argv[1:] or ["2048"])):
