@@ -143,3 +143,34 @@ def test_qserve_is_deterministic(sglk, dev, M):
     out = _repeat_equal(lambda: sglk.qserve_w4a8_per_group_gemm(*args), f"qserve per-group M={M}")
     ref = oq.w4a8_per_group_gemm(a_q, b_q, a_scale, chn, s8, z8)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("T", [512, 1024])
+def test_fused_experts_k_split_is_deterministic_and_capturable(sglk, dev, T):
+    """fused_experts in the row-count range where the down projection's K range is split over two workgroups per tile (round 5:
+    two fp32 slabs, the combine adds them - a two-term sum, the same in either order): bit-identical over 200 runs, and the same
+    bits from a HIP graph replay (the split decision is host-side, the workspace comes from the scratch cache: nothing in the
+    sequence synchronises or allocates during capture once warmed up)."""
+    from test_moe_gpu import make_int4
+    E, k, H, I, gs, dt = 8, 2, 1024, 1024, 128, torch.bfloat16
+    g = torch.Generator().manual_seed(T)
+    x = (torch.randn(T, H, generator=g) * 0.1).to(dt).to(dev)
+    w1, s1, _ = make_int4(E, 2 * I, H, gs, dt, False, g)
+    w2, s2, _ = make_int4(E, H, I, gs, dt, False, g)
+    w1, w2, s1, s2 = w1.view(torch.int8).to(dev), w2.view(torch.int8).to(dev), s1.to(dev), s2.to(dev)
+    tw = torch.rand(T, k, generator=g).to(dev)
+    ids = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)]).to(torch.int32).to(dev)
+    assert torch.ops.sgl_kernel.moe_w4a16_splitk_applies(T * k, E, H, I, gs, True, True) in (128, 256)
+    run = lambda: sglk.fused_experts(x, w1, w2, tw, ids, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2)
+    first = _repeat_equal(run, f"fused_experts T={T} (K split)")
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            captured = run()
+    torch.cuda.current_stream().wait_stream(side)
+    captured.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured.view(torch.int16), first.view(torch.int16)), "graph replay differs from the eager run"
