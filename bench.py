@@ -362,7 +362,7 @@ def side_metrics(sgl_kernel, dev):
     out["qserve_w4a8_per_chn_M4096_TOPs"] = round(2.0 * M * N * K / ms / 1e9, 1)
     ms = timeit(lambda: sgl_kernel.qserve_w4a8_per_group_gemm(ai, wq, z8, s8, ws16, sa16, qo), iters=30)
     out["qserve_w4a8_per_group_M4096_TOPs"] = round(2.0 * M * N * K / ms / 1e9, 1)
-    for m in (1, 64):
+    for m in (1, 64, 128):  # (128 rows: on the 32x32x32 stream kernel since round 5 - 56 us on the 128 x 128 tile kernel before)
         ms = timeit(lambda: sgl_kernel.qserve_w4a8_per_group_gemm(ai[:m], wq, z8, s8, ws16, sa16[:m], qo[:m]), iters=50)
         out[f"qserve_w4a8_per_group_M{m}_us"] = round(ms * 1e3, 1)
         out[f"qserve_w4a8_per_group_M{m}_weight_GBs"] = round(N * K / 2 / ms / 1e6, 1)
@@ -580,7 +580,7 @@ def roofline_extra(ex, bf16_ceiling=None):
     for k, v in ex.items():
         if k.endswith("_GBs") and "weight" not in k and "fp8_blockwise_gemm" not in k:
             put(k[:-4], "hbm", v, PEAK_HBM_GBS, "GB/s")
-        elif k.endswith("_weight_GBs") and ("_T1_" in k or "_T32_" in k or "_T64_" in k or "_M1_" in k or "_M16_" in k or "_M64_" in k):
+        elif k.endswith("_weight_GBs") and ("_T1_" in k or "_T32_" in k or "_T64_" in k or "_M1_" in k or "_M16_" in k or "_M64_" in k or "_M128_" in k):
             put(k[:-4], "hbm", v, PEAK_HBM_GBS, "GB/s")  # few rows: the weight stream bounds the GEMM
         elif k.endswith("_TFLOPs"):
             if k.startswith("fp8_scaled_mm"):

@@ -20,6 +20,8 @@
 // int8 in registers (packed multiply by the small group scale, carry-free packed add of zs8) before the MFMA, so
 // both variants accumulate over all of K without rescaling.
 // (That lane map is what the tile kernels below use; the decode kernel reads the same bytes another way, see there.)
+#include <algorithm>
+
 #include "common.h"
 
 namespace sglk {
@@ -650,7 +652,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
         (const f16*)wscales, (const f16*)ascales, (const f16*)w_szs, (const f16*)a_ssums, (int)M, (int)N, (int)K, lda, ldc); \
   }
 #ifdef SGLK_PROBES
-  if (g_qserve_cfg > 1 && M <= 64) {  // forced configuration: 10000 mf + 1000 log2(ks) + 10 kd + ka (1: the stream kernel where the 32x32x32 form is the default)
+  if (g_qserve_cfg > 1 && (M <= 64 || (g_qserve_cfg >= 300000 && M <= 512))) {  // forced configuration: 10000 mf + 1000 log2(ks) + 10 kd + ka (1: the stream kernel where the 32x32x32 form is the default)
     switch (g_qserve_cfg) {
       case 43082: SGLK_GO_STREAM(4, 8, 8, 2) break;
       case 43042: SGLK_GO_STREAM(4, 8, 4, 2) break;
@@ -690,7 +692,23 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   // per channel / 13.4 per group against 14.5 / 15.1 for the stream above (48 rows: 12.1 / 13.1 against 13.2 / 13.5); two m-tiles
   // per workgroup (half the workgroups, the weights streamed once) lose to it - 18 us: 112 CUs then carry all the int8 MFMAs;
   // up to 32 rows and at narrow N (under 192 workgroups) the stream above stays faster (N = 4096, 64 rows: 8.6 against 11.6 us)
-  if (M > 40 && M <= 64 && cdiv(N, 128) * cdiv(M, 32) >= 192 && g_qserve_cfg != 1) {
+  // 65 - 512 rows (round 5, late): the same kernel with M / 32 (one m-tile per workgroup) or M / 64 (two) workgroup rows, each
+  // streaming the weights (the repeats come from L2 / the Infinity Cache). Before, 65 - 128 rows ran on the 128 x 128 tile kernel
+  // below and 129+ on the persistent pipeline, whose floor is ~38 - 55 us whatever the size: 14336 x 4096 at 65 / 128 / 256 rows
+  // 39 - 56 -> 19.3 / 19.8 / 37 us, 4096 x 4096 at 65 / 128 / 256 / 512 rows 38 - 53 -> 11.3 / 11.6 / 12.3 / 19.7 us, outputs
+  // bit-identical. A round of one-m-tile workgroups takes ~12 us, of two-m-tile ones ~19 us (K = 4096); the form with the smaller
+  // estimate runs when it beats the other paths' floor - always up to 128 rows, up to ~36 us above.
+  bool stream32 = false, two_tiles = false;
+  if (M > 64 && M <= 512 && g_qserve_cfg != 1) {
+    const int64_t quads = cdiv(N, 128), cus = num_cus() > 0 ? num_cus() : 256;
+    const int64_t e1 = cdiv(quads * cdiv(M, 32), cus) * 12, e2 = cdiv(quads * cdiv(M, 64), cus) * 19;
+    const int64_t kscale = K > 4096 ? (K + 4095) / 4096 : 1;  // (the estimates are for K = 4096)
+    stream32 = M <= 128 || std::min(e1, e2) * kscale <= (GROUP ? 46 : 38);  // (the persistent pipeline per group: ~53 us)
+    two_tiles = e2 < e1;
+  }
+  if (stream32) {
+    if (two_tiles) SGLK_GO_STREAM32(2, 2, 2) else SGLK_GO_STREAM32(1, 1, 1)
+  } else if (M > 40 && M <= 64 && cdiv(N, 128) * cdiv(M, 32) >= 192 && g_qserve_cfg != 1) {
     SGLK_GO_STREAM32(1, 1, 1)
   } else if (M <= 64) {
     if (mf == 1) {
