@@ -91,6 +91,7 @@ struct AttnParams {
   int causal_right;     // window right (>= 0 active, < 0 unlimited)
   int window_left;      // >= 0 active, < 0 unlimited
   int splits;
+  int row_groups;       // decode kernel: 16-row groups of packed rows per (sequence, kv head), one workgroup each (1 .. 4)
   float scale;          // softmax scale
   float softcap;        // 0 = off
   int probe;            // libsglk_probes.so only (0 in the release library): attn_prefill_kernel timing probes, garbage results
@@ -1036,7 +1037,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
         }
     }
     // ---- online softmax for row l31 of each block (this lane: tokens 8 (v / 4) + 4 u + v % 4 of each 32-token block)
-    bool interior = wave_rows_ok && (t * kPTile + kPTile <= seqlen_k);
+    // (rows past the block's last one take part with q = 0 - finite scores, finite weights, sums that are never stored - so a
+    //  ragged row count does not send every tile of the wave down the masked path: 124 packed rows ran 1.6 x slower than 128)
+    bool interior = t * kPTile + kPTile <= seqlen_k;
     if (p.causal_right >= 0) interior = interior && (t * kPTile + kPTile - 1 <= wave_qabs_lo + p.causal_right);
     if (p.window_left >= 0) interior = interior && (t * kPTile >= wave_qabs_hi - p.window_left);
     if (__builtin_amdgcn_readfirstlane(interior ? 0 : 1)) {  // (uniform per wave)
@@ -1286,7 +1289,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
   }
   const int hk = wg % p.Hk;
   const int split = (wg / p.Hk) % p.splits;
-  const int b = wg / (p.Hk * p.splits);
+  // 17 - 64 packed rows (speculative decoding, short chunks; round 5 - they ran on the general kernel at a quarter of this kernel's
+  // rate): row_groups workgroups per (sequence, kv head, split), 16 rows each, every one streaming the split's keys (the repeats
+  // come from L2: the groups of a (sequence, head) are neighbours in the launch)
+  const int rg = (wg / (p.Hk * p.splits)) % p.row_groups;
+  const int b = wg / (p.Hk * p.splits * p.row_groups);
   const int G = p.G;
 
   const int q_begin = cu_q[b];
@@ -1301,20 +1308,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
     k_begin = seq_k[b];
     seqlen_k = seq_k[b + 1] - k_begin;
   }
-  const int rows_total = seqlen_q * G;  // <= 16
-  if (rows_total <= 0) return;
+  const int rows_total = seqlen_q * G;  // <= 16 row_groups
   // the host picked this kernel from the caller's max_seqlen_q: a sequence with more rows than that promise would be
   // written only in part. Fail the launch loudly instead of returning garbage rows.
-  if (rows_total > kRowsPerWave) __builtin_trap();
+  if (rows_total > kRowsPerWave * p.row_groups) __builtin_trap();
+  const int r0 = rg * kRowsPerWave;  // first packed row of this workgroup
+  if (rows_total <= r0) return;
   const int shift = seqlen_k - seqlen_q;
 
-  const int my_row = l15;
+  const int my_row = r0 + l15;
   const bool row_ok = my_row < rows_total;
   const int my_qpos = row_ok ? my_row / G : 0;
   const int my_head = hk * G + (row_ok ? my_row % G : 0);
   const int q_abs = my_qpos + shift;
-  const bool wave_rows_ok = rows_total == kRowsPerWave;
-  const int wave_qabs_lo = shift, wave_qabs_hi = (rows_total - 1) / G + shift;
+  const bool wave_rows_ok = r0 + kRowsPerWave <= rows_total;
+  const int wave_qabs_lo = r0 / G + shift;
+  const int wave_qabs_hi = ((r0 + kRowsPerWave <= rows_total ? r0 + kRowsPerWave : rows_total) - 1) / G + shift;
 
   int kv_hi = seqlen_k;
   if (p.causal_right >= 0) {
@@ -1493,7 +1502,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
     issue_v(tile_of(j + 1), page_v, vr);
     issue_k(tile_of(j + 2), page_k, kr);
     const int tb = t * kTile + 8 * (g4 & 1) + 4 * (g4 >> 1);
-    bool interior = p.softcap <= 0.f && wave_rows_ok && (t * kTile + kTile <= seqlen_k);
+    // (rows past the last one have q = 0: finite scores and weights, results never stored - no reason for the masked path)
+    bool interior = p.softcap <= 0.f && (t * kTile + kTile <= seqlen_k);
     if (p.causal_right >= 0) interior = interior && (t * kTile + kTile - 1 <= wave_qabs_lo + p.causal_right);
     if (p.window_left >= 0) interior = interior && (t * kTile >= wave_qabs_hi - p.window_left);
     float m_new, m_use, alpha, psum = 0.f;
@@ -1636,7 +1646,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
   const v4f i4 = *reinterpret_cast<const v4f*>(xch + 4 * g4);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int row = 4 * g4 + e;
+    const int row = r0 + 4 * g4 + e;
     if (row >= rows_total) continue;
     const int qpos = row / G, head = hk * G + row % G;
     const int64_t tok = q_begin + qpos;
@@ -1791,7 +1801,7 @@ static int launch_decode_nw(hipStream_t st, const AttnParams& p, const void* q, 
   constexpr int lds = NW * 2 * ((D + 127) / 128) * kTile * 256;  // four waves: 64 KiB (d = 256: 128 KiB); eight: 128 KiB
   static unsigned long long attr_done = 0;
   if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_decode_kernel<T, D, KV8, NW, DA>), lds, &attr_done, "fwd")) return rc;
-  dim3 grid((unsigned)(p.Hk * p.splits), (unsigned)batch);
+  dim3 grid((unsigned)(p.Hk * p.splits * p.row_groups), (unsigned)batch);
   attn_decode_kernel<T, D, KV8, NW, DA><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
   if (int rc = check_launch("fwd(decode)")) return rc;
   if (p.splits > 1) {
@@ -1824,9 +1834,15 @@ static int launch_decode(hipStream_t st, const AttnParams& p, const void* q, con
   return launch_decode_nw<T, D, KV8, 4>(st, p, q, k, v, cu_q, seq_k, table, batch);
 }
 
+// the decode kernel takes up to four 16-row groups of packed rows per (sequence, kv head)
+constexpr int kDecodeRowsMax = 4 * kRowsPerWave;
+
 template <typename T>
-static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, const void* k, const void* v,
+static int dispatch_dim(hipStream_t st, const AttnParams& p_in, const void* q, const void* k, const void* v,
                         const int32_t* cu_q, const int32_t* seq_k, const int32_t* table, int batch, int max_rows, int kv8) {
+  AttnParams p = p_in;
+  p.row_groups = max_rows <= kDecodeRowsMax ? (max_rows + kRowsPerWave - 1) / kRowsPerWave : 1;
+  if (p.row_groups < 1) p.row_groups = 1;
   const int d = p.D;
   // prefill-sized problems at head dim 128 / 64 (Llama-3 / BASELINE configs[2]): the 128-row-block kernel. A row block must be
   // worth filling: at least 128 packed rows per (sequence, kv head) at the longest sequence.
@@ -1834,21 +1850,26 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
   //  round 5; before, both fell through to the general 16-row kernel at ~0.08 - 0.11 of the bf16 peak. d = 256: 128 KiB of LDS and
   //  the whole register file, one workgroup per CU; 512-byte rows keep the d = 128 swizzle keys - (row & 15) for K, (row & 3) << 2
   //  for V - on the low bits of the 32 chunks of a row.)
-  if (kv8 == 0 && (d == 128 || d == 64 || d == 256) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 &&
+  // (round 5, late: from 65 packed rows on - below, the decode kernel takes 16-row groups - and whatever num_splits says: the
+  //  kernel does not split, it writes out and lse itself; 65 .. 127 rows and explicit split counts fell through to the general
+  //  16-row kernel before - bs16 x 4096 keys at 31 query tokens 210 us, at 32 tokens 101 us)
+  const bool prefill_rows = max_rows > kDecodeRowsMax;
+  if (prefill_rows) p.splits = 1;
+  if (kv8 == 0 && (d == 128 || d == 64 || d == 256) && prefill_rows && p.q_s0 % 8 == 0 &&
       p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0)
     return d == 128  ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
            : d == 64 ? launch_prefill<T, 64>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
                      : launch_prefill<T, 256>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
   // (head dims 96 / 192 - the reference builds both, FMHAPrefillXe20.cmake:30-54 - inside the 128 / 256 images since round 5; the
   //  DMA fetches whole 16-byte chunks of 192- / 384-byte rows: row strides and bases must be multiples of 8 elements)
-  if (kv8 == 0 && (d == 96 || d == 192) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 && p.q_s1 % 8 == 0 &&
+  if (kv8 == 0 && (d == 96 || d == 192) && prefill_rows && p.q_s0 % 8 == 0 && p.q_s1 % 8 == 0 &&
       p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0 && p.k_s0 % 8 == 0 && p.k_s1 % 8 == 0 && p.k_s2 % 8 == 0 && p.v_s0 % 8 == 0 &&
       p.v_s1 % 8 == 0 && p.v_s2 % 8 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 && (uintptr_t)q % 16 == 0)
     return d == 96 ? launch_prefill<T, 128, 0, 96>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)
                    : launch_prefill<T, 256, 0, 192>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows);
   // (an fp8 cache at prefill sizes - the reference tests it, tests/test_flash_attention.py:1691-1704 - on the same kernel since
   //  round 5: registers instead of LDS-DMA, widened on the way into the 16-bit LDS images; rows are fetched in 16-byte pieces)
-  if (kv8 != 0 && (d == 128 || d == 64) && p.splits == 1 && max_rows >= 128 && p.q_s0 % 8 == 0 && p.o_s0 % 4 == 0 &&
+  if (kv8 != 0 && (d == 128 || d == 64) && prefill_rows && p.q_s0 % 8 == 0 && p.o_s0 % 4 == 0 &&
       p.o_s1 % 4 == 0 && p.k_s0 % 16 == 0 && p.k_s1 % 16 == 0 && p.k_s2 % 16 == 0 && p.v_s0 % 16 == 0 && p.v_s1 % 16 == 0 &&
       p.v_s2 % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0) {
     if (d == 128)
@@ -1859,7 +1880,7 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
   }
   // decode-sized problems at head dims 64 / 128 / 256 (16-bit or fp8 cache): every sequence has at most 16 packed rows per
   // kv head; a tile within one page
-  if ((d == 64 || d == 128 || d == 256) && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) &&
+  if ((d == 64 || d == 128 || d == 256) && max_rows <= kDecodeRowsMax && (p.paged != 1 || p.page_shift >= 5) &&
       p.leftpad_k == nullptr && p.q_s0 % 8 == 0 &&
       (kv8 == 0 || (p.k_s0 % 16 == 0 && p.k_s1 % 16 == 0 && p.k_s2 % 16 == 0 && p.v_s0 % 16 == 0 && p.v_s1 % 16 == 0 &&
                     p.v_s2 % 16 == 0 && (uintptr_t)v % 16 == 0))) {  // (fp8: V rows are fetched in 16-byte pieces)
@@ -1874,7 +1895,7 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p, const void* q, cons
   }
   // (head dims 96 / 192 - the reference's paged decode builds them, FMHADecodeXe20.cmake:13-16 - inside the 128 / 256 forms of the
   //  same kernel since round 5; 16-byte loads of 192- / 384-byte rows: strides and bases in whole chunks)
-  if ((d == 96 || d == 192) && max_rows <= kRowsPerWave && (p.paged != 1 || p.page_shift >= 5) && p.leftpad_k == nullptr &&
+  if ((d == 96 || d == 192) && max_rows <= kDecodeRowsMax && (p.paged != 1 || p.page_shift >= 5) && p.leftpad_k == nullptr &&
       p.q_s0 % 8 == 0 && p.q_s1 % 8 == 0 && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
       p.k_s0 % 16 == 0 && p.k_s1 % 16 == 0 && p.k_s2 % 16 == 0 && p.v_s0 % 16 == 0 && p.v_s1 % 16 == 0 && p.v_s2 % 16 == 0) {
 #define SGLK_DEC_GO_A(DD, DA_)                                                                                  \
@@ -1919,8 +1940,9 @@ extern "C" SGLK_API void sglk_debug_set_attn_prefill_stamps(unsigned long long* 
 
 extern "C" int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
                                          int64_t max_seqlen_k) {
-  const int64_t wgs = batch * num_heads_k * ((max_rows_per_kv_head + 63) / 64);
-  const int64_t target = max_rows_per_kv_head <= 16 ? 256 : 512;
+  // (up to 64 packed rows: the decode kernel, one workgroup per 16-row group)
+  const int64_t wgs = batch * num_heads_k * (max_rows_per_kv_head <= 64 ? (max_rows_per_kv_head + 15) / 16 : (max_rows_per_kv_head + 63) / 64);
+  const int64_t target = max_rows_per_kv_head <= 64 ? 256 : 512;
   if (wgs >= target * 3 / 4) return 1;
   const int64_t tiles = (max_seqlen_k + 31) / 32;
   int64_t s = target / (wgs > 0 ? wgs : 1);

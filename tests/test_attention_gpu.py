@@ -353,9 +353,12 @@ def test_missing_max_seqlen_q_is_safe(sglk, dev):
     args = (q.to(dev), k.to(dev), v.to(dev), cu_q.to(dev), cu_k.to(dev))
     good = sglk.flash_attn_varlen_func(*args, 20, 200, causal=True)
     lazy = sglk.flash_attn_varlen_func(*args, 0, 200, causal=True)
-    assert torch.equal(good, lazy)
+    # (since round 5 the two bounds pick different kernels - 40 packed rows: the decode kernel's 16-row groups; 80: the 128-row-block
+    #  kernel - so the two results agree to rounding, not bit for bit)
+    torch.testing.assert_close(good.float(), lazy.float(), rtol=2e-2, atol=2e-2)
     ref, _ = oa.attention_ragged(q, [k[:100], k[100:]], [v[:100], v[100:]], cu_q, 128 ** -0.5, causal=True)
     torch.testing.assert_close(lazy.float().cpu(), ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(good.float().cpu(), ref, rtol=2e-2, atol=2e-2)
 
 
 # ---------------------------------------------------------------------- fp8 KV cache (reference :1697-1830)
