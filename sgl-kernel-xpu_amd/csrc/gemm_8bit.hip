@@ -1935,7 +1935,14 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   {
     // (up to 512 rows also when the tile kernel would have few units: M = 256, N = 4096, K = 14336 is 32 units of 128 x
     // 256 - 134 us there, 51 us here; from ~96 units on the tile kernel wins)
-    const bool few = M <= 128 || (M <= 512 && cdiv(M, 128) * cdiv(N, 256) <= 80);
+    // (round 5, late - a row sweep across this boundary: the block-scale mode's weight stream pays its promotion FMAs per row
+    //  set, 17 us + 0.23 us per row at N = 14336, K = 4096 against ~33 us for the tile pipeline from 65 rows on; and at N = 4096,
+    //  K = 14336 its stacked 64-row workgroups took 133 - 167 us at 257 - 512 rows against ~88 us for the half tiles. The row / column
+    //  scale modes keep the wider range: 22 us at 128 rows against 40 us for their tile pipeline.)
+    const bool wide_n = cdiv(N, 256) >= 32;
+    const bool few = MODE == MODE_BLOCKWISE
+                         ? (M <= 72 || (!wide_n && (M <= 128 || (M <= 256 && cdiv(M, 128) * cdiv(N, 256) <= 80))))
+                         : (M <= 128 || (M <= 512 && cdiv(M, 128) * cdiv(N, 256) <= 80));
     if ((few && g_gemm_variant == 4) || g_gemm_variant == 5 || g_gemm_variant == 7) {
 #define SGLK_GO_SKINNY_(MF, KS, LA)                                                                          \
   {                                                                                                          \
