@@ -796,12 +796,16 @@ static int g_mp_splitk = 1;  // (sglk_debug_set_moe_splitk: 0 = the K split of t
 constexpr int g_mp_own_tails = 0;
 constexpr int g_mp_wide = 1;
 #endif
-constexpr int kMinAvgRows128 = 96;  // ... and with 128-row blocks
+// (round 5, late - a token sweep of fused_experts across these boundaries: 383 tokens on the streaming kernels 645 us against 552 at
+//  384 on the tiles, whose time is flat in the row count - the boundary moved from 96 to 88; and 129 - 191 rows per expert on 128-row
+//  blocks left EVERY expert a remainder for the streaming launches - 640 / 704 / 767 tokens 0.98 / 1.07 / 1.06 ms against 0.73 / 0.745 /
+//  0.76 on 256-row blocks, one partly filled block per expert: 256-row blocks now start at an average of 152 rows, not 192)
+constexpr int kMinAvgRows128 = 88;  // ... and with 128-row blocks
 #ifdef SGLK_PROBES
-static int g_mp_min_avg_rows = 192;
+static int g_mp_min_avg_rows = 152;
 #define kMinAvgRows g_mp_min_avg_rows
 #else
-constexpr int kMinAvgRows = 192;  // average rows per expert from which the tile pipeline takes over with 256-row blocks
+constexpr int kMinAvgRows = 152;  // average rows per expert from which the tile pipeline takes over with 256-row blocks
 #endif
 
 

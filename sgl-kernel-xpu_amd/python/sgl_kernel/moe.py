@@ -139,6 +139,11 @@ _ACTIVATIONS = {
 }
 
 
+# average rows per expert from which the grouped GEMMs run on the tile pipeline (csrc/moe_persist.hip: kMinAvgRows128), which stages
+# expert-contiguous rows: below it GEMM 1 gathers its rows itself, from it on the tokens are copied expert-contiguous first
+_TILE_PIPELINE_MIN_ROWS = 88
+
+
 @dataclass(frozen=True)
 class _Plan:
     tokens: int
@@ -285,9 +290,9 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
                                    scratch("problem_sizes2", (p.experts, 3), torch.int32),
                                    src_rows, dst_rows, p.experts, p.hidden, p.topk)
     # decode sizes with 4-bit weights: GEMM 1 gathers its rows through a_map itself (the streaming kernels' staging loads),
-    # no [rows, hidden] copy of the tokens and one launch less. From 96 rows per expert on the tile pipeline takes the
+    # no [rows, hidden] copy of the tokens and one launch less. From 88 rows per expert on the tile pipeline takes the
     # GEMM, which stages expert-contiguous rows by LDS-DMA: the copy (reference shuffle_rows, moe.py:739) stays there.
-    gather_in_gemm1 = (p.four_bit and w1_g_idx_perm is None and p.rows < 96 * p.experts
+    gather_in_gemm1 = (p.four_bit and w1_g_idx_perm is None and p.rows < _TILE_PIPELINE_MIN_ROWS * p.experts
                        and p.tokens * p.hidden < 2**32)
     if gather_in_gemm1:
         x = hidden_states.contiguous()
@@ -329,14 +334,14 @@ def fused_experts(hidden_states: torch.Tensor, w1: torch.Tensor, w2: torch.Tenso
     # ---- GEMM 2 and the weighted combine over the top-k slots
     y = scratch("intermediate_cache3", (p.rows, p.hidden))
     rsf = 1.0 if routed_scaling_factor is None else routed_scaling_factor
-    # 4-bit weights, from 96 rows per expert: where the down projection has fewer tiles than the GPU has CUs (Mixtral at 512 tokens:
+    # 4-bit weights, from 88 rows per expert: where the down projection has fewer tiles than the GPU has CUs (Mixtral at 512 tokens:
     # 128 tiles of 128 x 256 and 224 K blocks on 256 CUs; at 1024 tokens 128 tiles of 256 x 256), the K range of every tile is
     # split over two workgroups; the two fp32
     # partial sums go to a workspace and the combine below adds them (a two-term sum: the same in either order) and rounds once,
     # as the GEMM's own store would have (the reference picks a tile policy per average row count, GroupGemmW4A16Xe20.cpp:266-277)
     # (the op answers for the tile counts and the group alignment; the row-count regime is checked here so that other sizes make
     # no extra call)
-    if (p.four_bit and b2 is None and p.hidden % 8 == 0 and 96 * p.experts <= p.rows
+    if (p.four_bit and b2 is None and p.hidden % 8 == 0 and _TILE_PIPELINE_MIN_ROWS * p.experts <= p.rows
             and _ops.moe_w4a16_splitk_applies(p.rows, p.experts, p.hidden, p.inter, p.group2, p.int4, dt == torch.bfloat16)):
         ws = scratch("splitk_partials", (2, p.rows, p.hidden), torch.float32)
         block = _ops.moe_grouped_mm_nt_w4a16_splitk(y, ws, h.contiguous(), w2, w2_scale, w2_zp, rows_per_expert, p.experts,

@@ -178,7 +178,7 @@ def test_moe_grouped_mm_w4a16(sglk, dev, explicit_zero, dtype, gs, rows, N, K):
     # every element is tight against one of the two definitions - the oracle's for the tile pipeline's rows)
     o = out.cpu().float()
     near_exact = torch.isclose(o, exact.to(dtype).float(), rtol=1e-2, atol=2e-3)
-    if sum(rows) < 96 * E:
+    if sum(rows) < 88 * E:
         assert near_exact.all(), "the streaming kernels keep the codes exact"
     else:
         assert (near_exact | torch.isclose(o, ref.float(), rtol=1e-2, atol=2e-3)).all()
@@ -280,7 +280,7 @@ def test_moe_grouped_mm_w4a16_row_map_is_the_gather(sglk, dev, dtype, act_type, 
     op(plain, x[row_map.long()].contiguous(), packed.to(dev), scales.to(dev), d(zeros), bias, rows_t, E, is_int4, gs, act_type, 0.25,
        None, 1.702)
     assert torch.isfinite(mapped.float()).all()
-    if total < 96 * E:
+    if total < 88 * E:
         assert torch.equal(mapped, plain)
     else:
         torch.testing.assert_close(mapped.float(), plain.float(), rtol=5e-2, atol=2e-2)
@@ -330,7 +330,7 @@ def test_moe_grouped_mm_w4a16_splitk(sglk, dev, fmt, dtype, rows, N, K, gs):
     rows_t = torch.tensor(rows, dtype=torch.int32, device=dev)
     op = torch.ops.sgl_kernel
     applies = op.moe_w4a16_splitk_applies(total, E, N, K, gs, is_int4, dtype == torch.bfloat16)
-    assert applies == (0 if (K // 2) % gs else 128 if total < 192 * E else 256)
+    assert applies == (0 if (K // 2) % gs else 128 if total < 152 * E else 256)
     y = torch.full((total, N), float("nan"), dtype=dtype, device=dev)
     ws = torch.full((2, total, N), float("nan"), dtype=torch.float32, device=dev)
     used = op.moe_grouped_mm_nt_w4a16_splitk(y, ws, act.to(dev), packed.to(dev), scales.to(dev), d(zeros), rows_t, E, is_int4, gs)

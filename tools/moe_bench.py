@@ -9,6 +9,10 @@ if os.environ.get("MOE_SPLITK"):  # diagnostic build only (LD_PRELOAD=.../build/
     import ctypes
     ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
                 ).sglk_debug_set_moe_splitk(int(os.environ["MOE_SPLITK"]))
+if os.environ.get("MOE_MIN_ROWS"):  # diagnostic build only: average rows per expert from which the tile pipeline uses 256-row blocks
+    import ctypes
+    ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
+                ).sglk_debug_set_moe_persist_min_rows(int(os.environ["MOE_MIN_ROWS"]))
 w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
 w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
 s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01

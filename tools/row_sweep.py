@@ -59,3 +59,46 @@ else:
         by = 2.0 * bs * seq * hk * d * 2
         fl = 4.0 * bs * hq * d * q * seq
         print(f"fwd bs16 seq4096 h32/8 d128, {q} query tokens per sequence ({q * hq // hk} packed rows): {t:.1f} us  {by / t / 1e6:.0f} GB/s  {fl / t / 1e6:.0f} TFLOP/s")
+if what == "moe":
+    E, Hd, I, gs, topk = 8, 4096, 14336, 128, 2
+    w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
+    w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
+    s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01
+    s2 = torch.rand(E, Hd, I // gs, device=dev).to(torch.bfloat16) * 0.01
+    for T in (1, 2, 4, 8, 16, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320, 383, 384, 448, 512, 640, 767, 768, 1024, 1280, 1536, 2048):
+        x = torch.randn(T, Hd, device=dev, dtype=torch.bfloat16) * 0.1
+        logits = torch.randn(T, E, device=dev, dtype=torch.bfloat16)
+        tw = torch.empty(T, topk, device=dev, dtype=torch.float32)
+        ti = torch.empty(T, topk, device=dev, dtype=torch.int32)
+        sgl_kernel.topk_softmax(tw, ti, logits, True)
+        t = timeit(lambda: sgl_kernel.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2), it=10)
+        print(f"fused_experts int4 Mixtral T={T}: {t:.0f} us  ({t / T:.2f} us per token)")
+if what == "mla":
+    from sgl_kernel.attention import flash_mla_decode, flash_mla_get_workspace_size
+    page = 64
+    for H in (8, 16, 32, 64, 65, 96, 128):
+        for bs, seq in ((1, 8192), (4, 8192), (16, 8192), (32, 8192), (64, 8192), (128, 8192), (128, 1024), (128, 2048), (256, 2048)):
+            n_pages = bs * seq // page
+            cache = torch.randn(n_pages, page, 576, device=dev, dtype=torch.bfloat16)
+            qn = torch.randn(bs, H, 512, device=dev, dtype=torch.bfloat16)
+            qp = torch.randn(bs, H, 64, device=dev, dtype=torch.bfloat16)
+            lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+            table = torch.arange(n_pages, device=dev, dtype=torch.int32).view(bs, -1)
+            ws = torch.empty(flash_mla_get_workspace_size(seq, bs, H, page, -1), device=dev, dtype=torch.uint8)
+            t = timeit(lambda: flash_mla_decode(qn, qp, cache, lens, table, ws, 0.1, -1), it=10)
+            by = bs * seq * 576 * 2
+            print(f"flash_mla_decode H={H} bs={bs} seq={seq}: {t:.1f} us  {by / t / 1e6:.2f} TB/s")
+            del cache
+if what == "fwdbs":
+    hq, hk, page, d = 32, 8, 64, 128
+    for bs, seq in ((1, 4096), (2, 4096), (4, 4096), (8, 4096), (16, 4096), (32, 4096), (64, 4096), (128, 4096), (256, 2048), (16, 512), (16, 1024), (16, 16384), (1, 65536)):
+        n_pages = bs * seq // page
+        kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+        vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+        pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, seq // page)
+        lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+        qq = torch.randn(bs, 1, hq, d, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: flash_attn_with_kvcache(qq, kc, vc, cache_seqlens=lens, page_table=pt, causal=True))
+        by = 2.0 * bs * seq * hk * d * 2
+        print(f"fwd decode bs={bs} seq={seq}: {t:.1f} us  {by / t / 1e6:.2f} TB/s")
+        del kc, vc
