@@ -1827,7 +1827,13 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
   int w = ngroups <= 1 ? 8 : ngroups <= 2 ? 4 : ngroups <= 4 ? 2 : 1;
   if (g_mla_waves_per_group > 0 && g_mla_waves_per_group <= w) w = g_mla_waves_per_group;
   int rc;
-  if (ngroups > 4 && g_mla_waves_per_group == 0) {
+  // More than 64 heads: the rows128z kernel - while a batch element has at most four splits. Its merge is ONE workgroup per
+  // batch element adding the other splits' 256-KiB partial results one after the other: fine for 2 .. 4 splits (batch >= 64),
+  // ruinous for the 16 .. 64 splits a small batch gets - a batch-size sweep (round 5, late) found bs 1 / 4 / 16 x 8192 keys x 128 heads
+  // at 520 / 587 / 186 us against 61 / 69 / 85 us for the 8-wave kernel below with its parallel reduce launch (bs 32: 149 / 128; bs 64:
+  // 178 / 207; bs 128: 301 / 376).
+  const bool rows128 = ngroups > 4 && g_mla_waves_per_group == 0 && p.splits <= 4;
+  if (rows128) {
     rc = launch_rows128x<T>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table);
   } else
   switch (w) {
@@ -1837,7 +1843,7 @@ static int launch(hipStream_t st, const MlaParams& p, int B, const void* q_nope,
     default: rc = launch_w<T, 1>(st, p, B, q_nope, q_pe, cache, seq_lens, page_table); break;
   }
   if (rc) return rc;
-  const bool merged_in_kernel = ngroups > 4 && g_mla_waves_per_group == 0;  // (the rows128z kernel merges its splits itself)
+  const bool merged_in_kernel = rows128;  // (the rows128z kernel merges its splits itself)
   if (p.splits > 1 && !merged_in_kernel) {
     mla_reduce_kernel<T><<<dim3(p.H, B), 128, 0, st>>>((T*)p.out, p.ws_o, p.ws_lse, p.H, p.splits);
     return check_launch("flash_mla_decode(reduce)");

@@ -102,3 +102,12 @@ if what == "fwdbs":
         by = 2.0 * bs * seq * hk * d * 2
         print(f"fwd decode bs={bs} seq={seq}: {t:.1f} us  {by / t / 1e6:.2f} TB/s")
         del kc, vc
+if what == "elem":
+    for rows in (1, 16, 64, 256, 1024, 4096, 16384):
+        for hidden in (1024, 2048, 4096, 4104, 5120, 7168, 8192, 16384):
+            x = torch.randn(rows, hidden, device=dev, dtype=torch.bfloat16)
+            w = torch.ones(hidden, device=dev, dtype=torch.bfloat16)
+            r = torch.randn(rows, hidden, device=dev, dtype=torch.bfloat16)
+            t1 = timeit(lambda: sgl_kernel.rmsnorm(x, w, 1e-6))
+            t2 = timeit(lambda: sgl_kernel.fused_add_rmsnorm(x, r, w, 1e-6))
+            print(f"rows={rows} hidden={hidden}: rmsnorm {t1:.1f} us {rows * hidden * 4 / t1 / 1e6:.2f} TB/s | fused_add_rmsnorm {t2:.1f} us {rows * hidden * 8 / t2 / 1e6:.2f} TB/s")
