@@ -18,12 +18,16 @@ namespace {
 constexpr float kFp8Max = 448.0f;
 
 // ---- per token ---------------------------------------------------------------------------------------------------
-// one wave per row; V elements per access (8, 4, 2 or 1: the widest that divides the row length keeps rows aligned)
-template <typename T, int V>
+// TPR threads per row - one wave (four rows per workgroup) or the whole 256-thread workgroup; V elements per access (8, 4, 2 or 1:
+// the widest that divides the row length keeps rows aligned). A lane keeps 8 vectors in registers: a wave covers 4096 elements
+// without a second read of the row, a workgroup 16384. (Round 5, late - a size sweep: one wave per row took 10.5 - 12 us for 1 .. 256
+// rows of 14336 elements, two passes of 28 serial loads, where the group quantiser takes 2.4 - 3.8: rows longer than a wave's cache,
+// and calls with too few rows to fill the chip with waves, now get a workgroup per row.)
+template <typename T, int V, int TPR>
 __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(const T* __restrict__ x, uint8_t* __restrict__ q,
                                                                   float* __restrict__ s, int64_t rows, int64_t cols) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = TPR == 64 ? (threadIdx.x & 63) : threadIdx.x;
+  const int64_t row = TPR == 64 ? (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) : (int64_t)blockIdx.x;
   if (row >= rows) return;
   const T* xr = x + row * cols;
   uint8_t* qr = q + row * cols;
@@ -33,19 +37,25 @@ __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(const T* __res
   float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < kCache; ++i) {
-    const int64_t v = lane + 64 * i;
+    const int64_t v = lane + TPR * i;
     if (v < nvec) {
       cache[i] = load_vec<T, V>(xr + v * V);
 #pragma unroll
       for (int e = 0; e < V; ++e) mx = fmaxf(mx, fabsf((float)cache[i][e]));
     }
   }
-  for (int64_t v = lane + 64 * kCache; v < nvec; v += 64) {
+  for (int64_t v = lane + TPR * kCache; v < nvec; v += TPR) {
     const Vec<T, V> t = load_vec<T, V>(xr + v * V);
 #pragma unroll
     for (int e = 0; e < V; ++e) mx = fmaxf(mx, fabsf((float)t[e]));
   }
   mx = wave_max(mx);
+  if constexpr (TPR == 256) {  // (the maximum of exact values: the order of the reduction cannot change it)
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  }
   const float scale = mx / kFp8Max;
   const float inv = scale == 0.f ? 0.f : 1.0f / scale;
   if (lane == 0) s[row] = scale;
@@ -66,10 +76,10 @@ __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(const T* __res
   };
 #pragma unroll
   for (int i = 0; i < kCache; ++i) {
-    const int64_t v = lane + 64 * i;
+    const int64_t v = lane + TPR * i;
     if (v < nvec) quant(cache[i], v);
   }
-  for (int64_t v = lane + 64 * kCache; v < nvec; v += 64) quant(load_vec<T, V>(xr + v * V), v);
+  for (int64_t v = lane + TPR * kCache; v < nvec; v += TPR) quant(load_vec<T, V>(xr + v * V), v);
 }
 
 // ---- per tensor --------------------------------------------------------------------------------------------------
@@ -168,16 +178,20 @@ extern "C" int sglk_per_token_quant_fp8(sglk_stream_t stream, void* output_q, fl
   SGLK_REQUIRE(rows >= 0 && cols > 0, "sgl_per_token_quant_fp8: bad shape");
   if (rows == 0) return SGLK_OK;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)cdiv(rows, 4);
+  // one wave per row only for rows a wave's register cache covers AND enough of them to fill the chip with waves
+  const bool wave_rows = rows >= 2048;
   const int v = (cols % 8 == 0 && (uintptr_t)input % 16 == 0 && (uintptr_t)output_q % 8 == 0) ? 8
                 : (cols % 4 == 0 && (uintptr_t)input % 8 == 0 && (uintptr_t)output_q % 4 == 0) ? 4
                 : (cols % 2 == 0 && (uintptr_t)input % 4 == 0 && (uintptr_t)output_q % 2 == 0) ? 2 : 1;
+  const bool one_wave = wave_rows && cols / v <= 64 * 8;
+  const unsigned grid = one_wave ? (unsigned)cdiv(rows, 4) : (unsigned)rows;
+#define SGLK_PTQ_GO(V_)                                                                                               \
+  if (one_wave) per_token_quant_fp8_kernel<T, V_, 64><<<grid, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, rows, cols); \
+  else per_token_quant_fp8_kernel<T, V_, 256><<<grid, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, rows, cols);
   SGLK_DISPATCH_FLOAT(dtype, T, {
-    if (v == 8) per_token_quant_fp8_kernel<T, 8><<<grid, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, rows, cols);
-    else if (v == 4) per_token_quant_fp8_kernel<T, 4><<<grid, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, rows, cols);
-    else if (v == 2) per_token_quant_fp8_kernel<T, 2><<<grid, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, rows, cols);
-    else per_token_quant_fp8_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)input, (uint8_t*)output_q, output_s, rows, cols);
+    if (v == 8) { SGLK_PTQ_GO(8) } else if (v == 4) { SGLK_PTQ_GO(4) } else if (v == 2) { SGLK_PTQ_GO(2) } else { SGLK_PTQ_GO(1) }
   });
+#undef SGLK_PTQ_GO
   return check_launch("sgl_per_token_quant_fp8");
 }
 

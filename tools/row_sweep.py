@@ -111,3 +111,18 @@ if what == "elem":
             t1 = timeit(lambda: sgl_kernel.rmsnorm(x, w, 1e-6))
             t2 = timeit(lambda: sgl_kernel.fused_add_rmsnorm(x, r, w, 1e-6))
             print(f"rows={rows} hidden={hidden}: rmsnorm {t1:.1f} us {rows * hidden * 4 / t1 / 1e6:.2f} TB/s | fused_add_rmsnorm {t2:.1f} us {rows * hidden * 8 / t2 / 1e6:.2f} TB/s")
+if what == "elem2":
+    FP8 = torch.float8_e4m3fn
+    for rows in (1, 16, 64, 256, 1024, 4096):
+        for hidden in (4096, 14336):
+            x2 = torch.randn(rows, 2 * hidden, device=dev, dtype=torch.bfloat16)
+            o = torch.empty(rows, hidden, device=dev, dtype=torch.bfloat16)
+            t1 = timeit(lambda: torch.ops.sgl_kernel.silu_and_mul(o, x2))
+            x = torch.randn(rows, hidden, device=dev, dtype=torch.bfloat16)
+            q = torch.empty(rows, hidden, device=dev, dtype=FP8)
+            s = torch.empty(hidden // 128, rows, device=dev, dtype=torch.float32).t()
+            t2 = timeit(lambda: sgl_kernel.sgl_per_token_group_quant_8bit(x, q, s, 128, 1e-10, -448.0, 448.0, False, enable_v2=False))
+            qt = torch.empty(rows, hidden, device=dev, dtype=FP8)
+            st = torch.empty(rows, 1, device=dev, dtype=torch.float32)
+            t3 = timeit(lambda: sgl_kernel.sgl_per_token_quant_fp8(x, qt, st))
+            print(f"rows={rows} hidden={hidden}: silu_and_mul {t1:.1f} us | per_token_group_quant_8bit {t2:.1f} us | per_token_quant_fp8 {t3:.1f} us")
