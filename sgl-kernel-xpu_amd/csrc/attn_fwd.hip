@@ -631,7 +631,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
     if ((total & 7) == 0) wg = (wg & 7) * (total >> 3) + (wg >> 3);
   }
   const int bx = wg % gridDim.x;
-  const int hk = (wg / gridDim.x) % gridDim.y, b = wg / (gridDim.x * gridDim.y), G = p.G;
+  // (grid.y = kv heads x KV splits - round 5, late: a chunk of a single long sequence is a handful of row blocks, bs 1 x 128 queries
+  //  over 32768 keys ran 654 us on 32 workgroups; a split writes its normalised partial result and log-sum-exp for the reduce
+  //  kernel exactly as the decode kernel does)
+  const int hk = ((wg / gridDim.x) % gridDim.y) % p.Hk, split = ((wg / gridDim.x) % gridDim.y) / p.Hk;
+  const int b = wg / (gridDim.x * gridDim.y), G = p.G;
 
   const int q_begin = cu_q[b];
   const int seqlen_q = cu_q[b + 1] - q_begin;
@@ -683,6 +687,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
   if (kv_hi < 0) kv_hi = 0;
   int t_lo = __builtin_amdgcn_readfirstlane(kv_lo / kPTile), t_hi = __builtin_amdgcn_readfirstlane((kv_hi + kPTile - 1) / kPTile);
   if (t_hi < t_lo) t_hi = t_lo;
+  if (p.splits > 1) {
+    const int per = (t_hi - t_lo + p.splits - 1) / p.splits;
+    const int a = t_lo + split * per, e = a + per;
+    t_lo = a < t_hi ? a : t_hi;
+    t_hi = e < t_hi ? e : t_hi;
+  }
   const int n_tiles = t_hi - t_lo;  // (uniform, and the compiler has to know: the tile loop is then a scalar loop)
 
   // ---- Q^T fragments (B operand of K . Q^T): lane supplies q[row l31][16 ks + 8 u .. + 8)
@@ -1212,7 +1222,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
     const float m_fin = m_ref[mb] == -INFINITY ? -INFINITY : m_ref[mb] * 0.6931471805599453f;  // the reference in natural-log units
     float l_tot = l_run[mb] + __shfl_xor(l_run[mb], 32, 64);
     float lse_val = (l_tot > 0.f && m_fin != -INFINITY) ? m_fin + logf(l_tot) : -INFINITY;
-    if (p.sinks != nullptr && row_ok[mb]) {
+    const bool final_pass = p.splits == 1;  // (a split leaves the sink term to the reduce kernel)
+    if (final_pass && p.sinks != nullptr && row_ok[mb]) {
       const float sk = p.sinks[my_head[mb]];
       const float m2 = fmaxf(m_fin, sk);
       const float l2 = l_tot * __builtin_amdgcn_exp2f((m_fin - m2) * log2e) + __builtin_amdgcn_exp2f((sk - m2) * log2e);
@@ -1222,18 +1233,33 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && MB == 1 && D <= 128) ? 2 : 1) 
     const float inv_l = ((l_tot > 0.f && l_tot < INFINITY) ? 1.0f / l_tot : 0.f) * vd8;  // (fp8 cache: x the V descale)
     if (row_ok[mb] && !(probe & 64)) {
       const int64_t tok = q_begin + my_qpos[mb];
-      T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)my_head[mb] * p.o_s1;
+      if (final_pass) {
+        T* orow = (T*)p.out + tok * p.o_s0 + (int64_t)my_head[mb] * p.o_s1;
 #pragma unroll
-      for (int db = 0; db < DBA; ++db) {
+        for (int db = 0; db < DBA; ++db) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // dims 32 db + 8 g + 4 u .. + 3
-          Vec<T, 4> ov;
+          for (int g = 0; g < 4; ++g) {  // dims 32 db + 8 g + 4 u .. + 3
+            Vec<T, 4> ov;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ov[r] = (T)(o[mb][db][4 * g + r] * inv_l);
-          store_vec<T, 4>(orow + 32 * db + 8 * g + 4 * u, ov);
+            for (int r = 0; r < 4; ++r) ov[r] = (T)(o[mb][db][4 * g + r] * inv_l);
+            store_vec<T, 4>(orow + 32 * db + 8 * g + 4 * u, ov);
+          }
         }
+        if (u == 0) p.lse[(int64_t)my_head[mb] * p.total_q + tok] = lse_val;
+      } else {
+        float* orow = p.part_o + (((int64_t)split * p.total_q + tok) * p.Hq + my_head[mb]) * DA;
+#pragma unroll
+        for (int db = 0; db < DBA; ++db) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            Vec<float, 4> ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = o[mb][db][4 * g + r] * inv_l;
+            store_vec<float, 4>(orow + 32 * db + 8 * g + 4 * u, ov);
+          }
+        }
+        if (u == 0) p.part_lse[((int64_t)split * p.Hq + my_head[mb]) * p.total_q + tok] = lse_val;
       }
-      if (u == 0) p.lse[(int64_t)my_head[mb] * p.total_q + tok] = lse_val;
     }
   }
 }
@@ -1770,9 +1796,15 @@ static int launch_prefill_nw(hipStream_t st, const AttnParams& p, const void* q,
   constexpr int lds = 2 * 2 * kPTile * D * 2;  // 64 KiB (d = 64: 32 KiB)
   static unsigned long long attr_done = 0;
   if (int rc = set_max_dyn_lds(reinterpret_cast<const void*>(&attn_prefill_kernel<T, D, NW, MB, KV8, DA>), lds, &attr_done, "fwd")) return rc;
-  dim3 grid((unsigned)cdiv(max_rows, 32 * MB * NW), (unsigned)p.Hk, (unsigned)batch);
+  dim3 grid((unsigned)cdiv(max_rows, 32 * MB * NW), (unsigned)(p.Hk * p.splits), (unsigned)batch);
   attn_prefill_kernel<T, D, NW, MB, KV8, DA><<<grid, 64 * NW, lds, st>>>(p, (const T*)q, (const char*)k, (const char*)v, cu_q, seq_k, table);
-  return check_launch("fwd(prefill)");
+  if (int rc = check_launch("fwd(prefill)")) return rc;
+  if (p.splits > 1) {
+    attn_reduce_kernel<T><<<dim3(p.Hq, p.total_q), 128, 0, st>>>((T*)p.out, p.lse, p.part_o, p.part_lse, p.sinks,
+                                                                  p.splits, p.total_q, p.Hq, p.D, p.o_s0, p.o_s1);
+    return check_launch("fwd(reduce)");
+  }
+  return SGLK_OK;
 }
 
 #ifdef SGLK_PROBES
@@ -1854,7 +1886,6 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p_in, const void* q, c
   //  kernel does not split, it writes out and lse itself; 65 .. 127 rows and explicit split counts fell through to the general
   //  16-row kernel before - bs16 x 4096 keys at 31 query tokens 210 us, at 32 tokens 101 us)
   const bool prefill_rows = max_rows > kDecodeRowsMax;
-  if (prefill_rows) p.splits = 1;
   if (kv8 == 0 && (d == 128 || d == 64 || d == 256) && prefill_rows && p.q_s0 % 8 == 0 &&
       p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0)
     return d == 128  ? launch_prefill<T, 128>(st, p, q, k, v, cu_q, seq_k, table, batch, max_rows)

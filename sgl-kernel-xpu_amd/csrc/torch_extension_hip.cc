@@ -1064,11 +1064,16 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mha_fwd(
   }
   if (batch <= 0 || total_q == 0) return {out, lse, out_accum, lse_accum};
 
-  // num_kv_splits (reference flash_attention.cpp:426-470): -1 or 1 = off, 0 = auto (decode only), > 1 = as given
+  // num_kv_splits (reference flash_attention.cpp:426-470): -1 or 1 = off, 0 = auto, > 1 = as given. The reference splits
+  // automatically only at decode; here "auto" also covers the launches that would leave most of the GPU idle otherwise - a
+  // chunk of one long sequence (bs 1, 128 queries over 32768 keys: 32 workgroups, 654 us; with 8 splits 115) - as long as the
+  // fp32 partial results stay small
   int64_t splits = 1;
   if (num_kv_splits > 1) splits = num_kv_splits;
-  else if (num_kv_splits == 0 && max_seqlen_q == 1)
+  else if (num_kv_splits == 0) {
     splits = sglk_attn_auto_splits(batch, num_heads_k, max_seqlen_q * (num_heads / num_heads_k), seqlen_k_max);
+    while (splits > 1 && splits * total_q * num_heads * head_size_v * 4 > (int64_t(256) << 20)) --splits;
+  }
   float* po = nullptr;
   float* pl = nullptr;
   if (splits > 1) {

@@ -8,4 +8,4 @@ export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
 cd $R
 timeout 1500 python3 -m pytest tests/test_attention_gpu.py tests/test_full_size_gpu.py tests/test_determinism_gpu.py tests/test_graph_capture_gpu.py -m gpu -q > $OUT/pytest.log 2>&1
 tail -6 $OUT/pytest.log
-timeout 300 python3 tools/row_sweep.py fwd 2>&1 | grep "fwd bs" | tee $OUT/sweep.log
+timeout 300 python3 tools/row_sweep.py fwd 2>&1 | grep "fwd bs" | tee $OUT/sweep.log; timeout 300 python3 tools/row_sweep.py prefill1 2>&1 | grep "fwd chunk" | tee -a $OUT/sweep.log

@@ -126,3 +126,30 @@ if what == "elem2":
             st = torch.empty(rows, 1, device=dev, dtype=torch.float32)
             t3 = timeit(lambda: sgl_kernel.sgl_per_token_quant_fp8(x, qt, st))
             print(f"rows={rows} hidden={hidden}: silu_and_mul {t1:.1f} us | per_token_group_quant_8bit {t2:.1f} us | per_token_quant_fp8 {t3:.1f} us")
+if what == "prefill1":
+    hq, hk, page, d = 32, 8, 64, 128
+    for bs, q, ctx in ((1, 128, 4096), (1, 128, 32768), (1, 512, 4096), (1, 512, 32768), (1, 2048, 2048), (1, 2048, 32768), (1, 8192, 8192),
+                       (2, 128, 32768), (4, 128, 32768), (4, 512, 8192)):
+        n_pages = bs * ctx // page
+        kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+        vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+        pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, ctx // page)
+        lens = torch.full((bs,), ctx, device=dev, dtype=torch.int32)
+        qq = torch.randn(bs * q, hq, d, device=dev, dtype=torch.bfloat16)
+        cu = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * q
+        t = timeit(lambda: flash_attn_with_kvcache(qq, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu, max_seqlen_q=q,
+                                                   causal=True), it=10)
+        fl = 4.0 * bs * hq * d * q * (ctx - q / 2)
+        print(f"fwd chunk prefill bs={bs} q={q} ctx={ctx}: {t:.0f} us  {fl / t / 1e6:.0f} TFLOP/s")
+        del kc, vc
+if what == "sample":
+    V = 128256
+    for bs in (1, 8, 64, 256):
+        probs = torch.softmax(torch.randn(bs, V, device=dev), dim=-1)
+        k = torch.full((bs,), 50, device=dev, dtype=torch.int32)
+        pp = torch.full((bs,), 0.9, device=dev, dtype=torch.float32)
+        t1 = timeit(lambda: sgl_kernel.top_k_renorm_prob(probs, k), it=10)
+        t2 = timeit(lambda: sgl_kernel.top_p_renorm_prob(probs, pp), it=10)
+        t3 = timeit(lambda: sgl_kernel.top_k_top_p_sampling_from_probs(probs, k, pp), it=10)
+        t4 = timeit(lambda: sgl_kernel.min_p_sampling_from_probs(probs, pp * 0.1), it=10)
+        print(f"sampling vocab {V} bs={bs}: top_k_renorm {t1:.0f} us | top_p_renorm {t2:.0f} us | top_k_top_p_sampling {t3:.0f} us | min_p_sampling {t4:.0f} us")
