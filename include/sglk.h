@@ -504,6 +504,21 @@ SGLK_API int sglk_min_p_sampling_from_probs(sglk_stream_t stream, int32_t* outpu
                                             const int64_t* indices, const float* min_p_arr, float min_p_val,
                                             int64_t batch, int64_t vocab, uint64_t philox_seed,
                                             uint64_t philox_offset);
+/* The same two draws for a launch RECORDED INTO A HIP GRAPH: the generator state lives on the device (what torch's
+ * PhiloxCudaState carries while a stream is capturing) - seed = *philox_seed_ptr, offset = *philox_offset_ptr +
+ * offset_intragraph, read by the kernel at replay, so that every replay draws fresh numbers. The reference reads its
+ * generator on the host at each call (TopKTopPSamplingFromProbs.cpp / MinPSamplingFromProbs.cpp:270-275) and has no
+ * counterpart; results equal the scalar entries' at the same (seed, offset). */
+SGLK_API int sglk_top_k_top_p_sampling_from_probs_graph(sglk_stream_t stream, int32_t* output, const float* probs,
+                                                        const int64_t* indices, const int32_t* top_k_arr,
+                                                        int64_t top_k_val, const float* top_p_arr, float top_p_val,
+                                                        int use_top_k, int64_t batch, int64_t vocab,
+                                                        const int64_t* philox_seed_ptr, const int64_t* philox_offset_ptr,
+                                                        uint64_t offset_intragraph);
+SGLK_API int sglk_min_p_sampling_from_probs_graph(sglk_stream_t stream, int32_t* output, const float* probs,
+                                                  const int64_t* indices, const float* min_p_arr, float min_p_val,
+                                                  int64_t batch, int64_t vocab, const int64_t* philox_seed_ptr,
+                                                  const int64_t* philox_offset_ptr, uint64_t offset_intragraph);
 
 #ifdef __cplusplus
 }

@@ -19,8 +19,10 @@
 //   * the first pass's histogram serves both the top-k and the top-p select (no prefix yet); 12 bits there spread
 //     a softmax's few exponent values over many bins (LDS atomic conflicts);
 //   * the draw: u64 from Philox4x32-10(seed; offset, row), target = floor(u * Z / 2^64) in fixed point, thread chunk
-//     sums + one block scan locate the chunk, its owner walks it.
-// Rows of 128k-152k fp32 probabilities (0.5 MB) are re-read from L2 by the 5-7 passes; the op is latency-bound.
+//     the waves own consecutive ranges of the row: wave totals locate the wave, the masses of its runs of 64 quads + one block scan
+//     locate the run, one wave scans it.
+// Rows of 128k-152k fp32 probabilities (0.5 MB) are re-read from L2 by 2 (min-p) to 5 (top-k renorm) passes, each with eight 16-byte
+// loads per thread in flight; the two criteria of the joint filter share every pass (count and mass histograms of one read).
 #include <math.h>
 
 #include "common.h"
@@ -45,6 +47,8 @@ struct SampleParams {
   int V;
   int use_k, use_p, use_minp, do_sample;
   uint64_t seed, offset;
+  const int64_t* seed_ptr;    // generator state resident on the device (a launch recorded into a HIP graph): seed = *seed_ptr,
+  const int64_t* offset_ptr;  // offset = *offset_ptr + offset; NULL: the scalars above
 };
 
 __device__ __forceinline__ uint32_t key_of(float x) { return x > 0.f ? __float_as_uint(x) : 0u; }  // (NaN, negatives -> 0)
@@ -88,9 +92,13 @@ __device__ __forceinline__ V block_suffix_sum(V v, V* red, V& total) {
   return s + after;
 }
 
+constexpr int kU = 8;         // 16-byte loads a thread has in flight per step of a row pass
+constexpr int kBlocks = 1024;  // draw: the row is cut into <= 1024 runs of quads whose masses one block scan orders
+
 struct Shared {
   uint32_t cnt[kBins1];
   unsigned long long mass[kBins1];
+  unsigned long long bsum[kBlocks];
   unsigned long long red64[16];
   uint32_t red32[16];
   // select state: [0] = count criterion, [1] = mass criterion
@@ -102,22 +110,113 @@ struct Shared {
   int pick_found;
   float fmax_;
   int out_idx;
+  int pick_block;
+  unsigned long long pick_before;
 };
 
-// Histogram of digit (key >> shift) & (nb - 1) over the row's elements whose bits above (shift + bits) equal `prefix`
-__device__ void build_hist(Shared& s, const float* row, int V, uint32_t prefix, int shift, int bits, bool match_all) {
+// A row as aligned 16-byte quads: quad qi holds the row's elements 4 * qi - mis + {0, 1, 2, 3}; the first and the last quad may
+// reach up to three floats outside the row (never outside their own aligned 16 bytes, which hold at least one row element).
+struct RowQuads {
+  const float4* q;
+  int mis, V, nq;
+  __device__ RowQuads(const float* row, int V_) {
+    mis = (int)((reinterpret_cast<uintptr_t>(row) >> 2) & 3);
+    q = reinterpret_cast<const float4*>(row - mis);
+    V = V_;
+    nq = (V_ + mis + 3) >> 2;
+  }
+};
+
+// f(qi, i0, x[4]) for every quad of the row (i0 = the row index of x[0]; may be < 0 or i0 + j >= V at the two ends), kU loads per
+// thread issued before the first is used: a pass is bound by the CU's L2 read rate, not by kU-fold load latency.
+template <typename F>
+__device__ __forceinline__ void scan_quads(const RowQuads& r, F&& f) {
+  for (int q0 = 0; q0 < r.nq; q0 += kU * kT) {
+    float4 v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int qi = q0 + u * kT + (int)threadIdx.x;
+      v[u] = r.q[qi < r.nq ? qi : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int qi = q0 + u * kT + (int)threadIdx.x;
+      const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      f(qi, qi * 4 - r.mis, x);
+    }
+  }
+}
+
+// f(i, x) for every element of the row (order unspecified)
+template <typename F>
+__device__ __forceinline__ void scan_row(const RowQuads& r, F&& f) {
+  scan_quads(r, [&](int qi, int i0, const float (&x)[4]) {
+    if (qi >= r.nq) return;
+    if (i0 >= 0 && i0 + 4 <= r.V) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f(i0 + j, x[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((unsigned)(i0 + j) < (unsigned)r.V) f(i0 + j, x[j]);
+    }
+  });
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// One pass over the row for one radix digit: the COUNT histogram of the count criterion's candidates (elements under its prefix) and
+// the MASS histogram of the mass criterion's, both in the same read of the row (pass 0: no prefix yet, every element is a candidate).
+// A single CU's VALU bounds these passes (4 cycles per wave instruction: ~1000 cycles per instruction and element of a 128k row), so
+// the common case is decided per quad in a few instructions: zeros (a row that went through a top-k renorm is nearly all zeros)
+// carry no mass and can only be the count criterion's pivot when the positive elements run out - which the select reports as
+// `exhausted`, with the same outcome: keep everything; under a prefix, candidates are a range of the raw float bits.
+__device__ void build_hist(Shared& s, const RowQuads& r, bool act0, bool act1, uint32_t pre0, uint32_t pre1, int shift, int bits,
+                           bool match_all) {
   const int nb = 1 << bits;
   for (int i = threadIdx.x; i < nb; i += kT) { s.cnt[i] = 0; s.mass[i] = 0ull; }
   __syncthreads();
-  for (int i = threadIdx.x; i < V; i += kT) {
-    const float x = row[i];
+  const int hs = shift + bits;  // (pass 0: hs = 32, match_all)
+  const uint32_t span = match_all ? 0u : 1u << hs;
+  const uint32_t lo0 = match_all ? 0u : (pre0 >> hs) << hs, lo1 = match_all ? 0u : (pre1 >> hs) << hs;
+  auto add = [&](float x, bool c0, bool c1) {
     const uint32_t key = key_of(x);
-    if (match_all || (key >> (shift + bits)) == (prefix >> (shift + bits))) {
-      const uint32_t d = (key >> shift) & (uint32_t)(nb - 1);
-      atomicAdd(&s.cnt[d], 1u);
-      atomicAdd(&s.mass[d], fix_of(x));
+    if (key == 0) return;
+    const uint32_t d = (key >> shift) & (uint32_t)(nb - 1);
+    if (c0) atomicAdd(&s.cnt[d], 1u);
+    if (c1) atomicAdd(&s.mass[d], fix_of(x));
+  };
+  scan_quads(r, [&](int qi, int i0, const float (&xin)[4]) {
+    if (qi >= r.nq) return;
+    float x[4] = {xin[0], xin[1], xin[2], xin[3]};
+    if (i0 < 0 || i0 + 4 > r.V) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((unsigned)(i0 + j) >= (unsigned)r.V) x[j] = 0.f;
     }
-  }
+    if (match_all) {
+      if (!(x[0] > 0.f || x[1] > 0.f || x[2] > 0.f || x[3] > 0.f)) return;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) add(x[j], act0, act1);
+    } else {
+      bool c0[4], c1[4], any = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t bts = __float_as_uint(x[j]);  // (negative floats: bits >= 2^31, never inside [lo, lo + span))
+        c0[j] = act0 && bts - lo0 < span;
+        c1[j] = act1 && bts - lo1 < span;
+        any = any || c0[j] || c1[j];
+      }
+      if (!any) return;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0[j] || c1[j]) add(x[j], c0[j], c1[j]);
+    }
+  });
   __syncthreads();
 }
 
@@ -169,13 +268,15 @@ __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
   const int V = p.V;
   const int64_t src_row = p.indices ? p.indices[b] : b;
   const float* row = p.probs + src_row * (int64_t)V;
+  const RowQuads r(row, V);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   uint32_t thr = 0;  // keep key >= thr
   if (p.use_minp) {
     float m = 0.f;
-    for (int i = threadIdx.x; i < V; i += kT) m = fmaxf(m, row[i]);
+    scan_row(r, [&](int, float x) { m = fmaxf(m, x); });
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) s.red32[threadIdx.x >> 6] = __float_as_uint(m);
+    if (lane == 0) s.red32[wave] = __float_as_uint(m);
     __syncthreads();
     if (threadIdx.x == 0) {
       float mm = 0.f;
@@ -208,65 +309,167 @@ __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
     __syncthreads();
     const int shifts[3] = {20, 10, 0}, bitsv[3] = {12, 10, 10};
     for (int pass = 0; pass < 3; ++pass) {
-      if (pass == 0) {
-        if (use[0] || use[1]) build_hist(s, row, V, 0, shifts[0], bitsv[0], true);
-        for (int c = 0; c < 2; ++c)
-          if (use[c]) pick_digit(s, c, target[c], shifts[0], bitsv[0]);
-      } else {
-        for (int c = 0; c < 2; ++c) {
-          if (use[c] && !s.exhausted[c]) {
-            build_hist(s, row, V, s.prefix[c], shifts[pass], bitsv[pass], false);
-            pick_digit(s, c, target[c], shifts[pass], bitsv[pass]);
-          }
-        }
-      }
+      const bool act0 = use[0] && !s.exhausted[0], act1 = use[1] && !s.exhausted[1];  // (uniform: written before a barrier)
+      if (!act0 && !act1) break;
+      const uint32_t pre0 = s.prefix[0], pre1 = s.prefix[1];
+      build_hist(s, r, act0, act1, pre0, pre1, shifts[pass], bitsv[pass], pass == 0);
+      if (act0) pick_digit(s, 0, target[0], shifts[pass], bitsv[pass]);
+      if (act1) pick_digit(s, 1, target[1], shifts[pass], bitsv[pass]);
     }
     const uint32_t tk = use[0] ? s.prefix[0] : 0u, tp = use[1] ? s.prefix[1] : 0u;
     thr = tk > tp ? tk : tp;
   }
 
-  // ---- normaliser (and per-thread chunk sums for the draw): thread t owns elements [t * C, (t + 1) * C)
-  const int C = (V + kT - 1) / kT;
-  const int lo = threadIdx.x * C, hi = lo + C < V ? lo + C : V;
-  unsigned long long mine = 0;
-  for (int i = lo; i < hi; ++i) {
-    const float x = row[i];
-    if (key_of(x) >= thr) mine += fix_of(x);
+  // ---- normaliser: wave w owns the quads [w * QW, (w + 1) * QW) (row order = wave order), a thread adds up its own quads' kept mass
+  // (no cross-lane traffic inside the pass), one wave sum at the end
+  const int QW = ((((r.nq + kT / 64 - 1) / (kT / 64)) + 63) >> 6) << 6;
+  auto kept_mass = [&](int qi, int qend, const float4& v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    const int i0 = qi * 4 - r.mis;
+    unsigned long long m4 = 0;
+    if (qi < qend) {
+      // (as signed integers the bits of a positive float order like its key; negatives are below every threshold; fix_of(NaN) = 0)
+      const int t = (int)thr;
+      const bool k0 = __float_as_int(x[0]) >= t, k1 = __float_as_int(x[1]) >= t, k2 = __float_as_int(x[2]) >= t,
+                 k3 = __float_as_int(x[3]) >= t;
+      if (k0 || k1 || k2 || k3) {
+        const bool full = i0 >= 0 && i0 + 4 <= V;
+        const bool k[4] = {k0, k1, k2, k3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k[j] && (full || (unsigned)(i0 + j) < (unsigned)V)) m4 += fix_of(x[j]);
+      }
+    }
+    return m4;
+  };
+  {
+    const int wq0 = wave * QW, wq1 = wq0 + QW < r.nq ? wq0 + QW : r.nq;
+    unsigned long long mine = 0;
+    for (int q0 = wq0; q0 < wq1; q0 += kU * 64) {
+      float4 v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int qi = q0 + u * 64 + lane;
+        v[u] = r.q[qi < wq1 ? qi : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) mine += kept_mass(q0 + u * 64 + lane, wq1, v[u]);
+    }
+    const unsigned long long wt = wave_sum_u64(mine);
+    __syncthreads();
+    if (lane == 0) s.red64[wave] = wt;
+    __syncthreads();
   }
-  unsigned long long Z;
-  const unsigned long long suf = block_suffix_sum<unsigned long long>(mine, s.red64, Z);
+  unsigned long long Z = 0;
+  for (int i = 0; i < kT / 64; ++i) Z += s.red64[i];
   if (!p.do_sample) {
     const float inv = Z > 0 ? (float)((double)kFix / (double)Z) : 0.f;
     float* orow = p.renorm + (int64_t)b * V;
-    for (int i = threadIdx.x; i < V; i += kT) {
-      const float x = row[i];
-      orow[i] = key_of(x) >= thr ? x * inv : 0.f;
+    if (((reinterpret_cast<uintptr_t>(orow) >> 2) & 3) == (uintptr_t)r.mis) {  // the output's quads line up with the input's
+      float4* oq = reinterpret_cast<float4*>(orow - r.mis);
+      scan_quads(r, [&](int qi, int i0, const float (&x)[4]) {
+        if (qi >= r.nq) return;
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = key_of(x[j]) >= thr ? x[j] * inv : 0.f;
+        if (i0 >= 0 && i0 + 4 <= V) {
+          oq[qi] = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((unsigned)(i0 + j) < (unsigned)V) orow[i0 + j] = y[j];
+        }
+      });
+    } else {
+      scan_row(r, [&](int i, float x) { orow[i] = key_of(x) >= thr ? x * inv : 0.f; });
     }
     return;
   }
-  if (threadIdx.x == 0) s.out_idx = -1;
-  __syncthreads();
-  const Philox rng(p.seed, p.offset, (uint64_t)b);
+  // ---- the draw: the first element, in row order, at which the running kept mass exceeds target = floor(u * Z)
+  const Philox rng(p.seed_ptr ? (uint64_t)*p.seed_ptr : p.seed, p.offset_ptr ? (uint64_t)*p.offset_ptr + p.offset : p.offset, (uint64_t)b);
   const unsigned long long u = ((unsigned long long)rng.c[0] << 32) | rng.c[1];
   const unsigned long long target = __umul64hi(u, Z);  // in [0, Z)
-  const unsigned long long before = Z - suf;            // mass of the threads before me
-  if (Z > 0 && mine > 0 && before <= target && target < before + mine) {
-    unsigned long long acc = before;
-    int pickd = hi - 1;
-    for (int i = lo; i < hi; ++i) {
-      const float x = row[i];
-      if (key_of(x) >= thr) {
-        acc += fix_of(x);
-        if (acc > target) { pickd = i; break; }
+  int W = -1;  // the wave whose quads hold it (uniform: every thread reads the same 16 totals)
+  unsigned long long wbefore = 0;
+  {
+    unsigned long long acc = 0;
+    for (int i = 0; i < kT / 64; ++i) {
+      const unsigned long long t = s.red64[i];
+      if (W < 0 && t > 0 && target < acc + t) { W = i; wbefore = acc; }
+      acc += t;
+    }
+  }
+  if (threadIdx.x == 0) { s.out_idx = -1; s.pick_block = -1; }
+  __syncthreads();
+  if (W >= 0) {
+    // that wave's quads in runs of G * 64 (G = 1 up to 4M elements): all waves add up run masses, one block scan finds the run,
+    // one wave scans the run
+    const int wq0 = W * QW, wq1 = wq0 + QW < r.nq ? wq0 + QW : r.nq;
+    const int steps = (wq1 - wq0 + 63) >> 6, G = (steps + kBlocks - 1) / kBlocks, runs = (steps + G - 1) / G;
+    for (int run = wave; run < runs; run += kT / 64) {
+      unsigned long long m = 0;
+      for (int g = 0; g < G; ++g) {
+        const int qi = wq0 + (run * G + g) * 64 + lane;
+        m += kept_mass(qi, wq1, r.q[qi < wq1 ? qi : 0]);
+      }
+      m = wave_sum_u64(m);
+      if (lane == 0) s.bsum[run] = m;
+    }
+    __syncthreads();
+    const unsigned long long mine = (int)threadIdx.x < runs ? s.bsum[threadIdx.x] : 0ull;
+    unsigned long long Zw;
+    const unsigned long long suf = block_suffix_sum<unsigned long long>(mine, s.red64, Zw);
+    const unsigned long long before = wbefore + Zw - suf;  // mass before my run
+    if (mine > 0 && before <= target && target < before + mine) {
+      s.pick_block = (int)threadIdx.x;
+      s.pick_before = before;
+    }
+    __syncthreads();
+    if (wave == 0 && s.pick_block >= 0) {
+      unsigned long long run_mass = s.pick_before;
+      bool done = false;
+      for (int g = 0; g < G && !done; ++g) {
+        const int qi = wq0 + (s.pick_block * G + g) * 64 + lane;
+        const float4 v = r.q[qi < wq1 ? qi : 0];
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        const int i0 = qi * 4 - r.mis;
+        unsigned long long m[4], m4 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          m[j] = (qi < wq1 && (unsigned)(i0 + j) < (unsigned)V && key_of(x[j]) >= thr) ? fix_of(x[j]) : 0ull;
+          m4 += m[j];
+        }
+        unsigned long long incl = m4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned long long t = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += t;
+        }
+        const unsigned long long lo_mass = run_mass + incl - m4;
+        const bool hit = m4 > 0 && lo_mass <= target && target < lo_mass + m4;
+        if (hit) {
+          unsigned long long acc = lo_mass;
+          int pick = i0 + 3;
+          bool found = false;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (!found && m[j] > 0) {
+              acc += m[j];
+              if (acc > target) { pick = i0 + j; found = true; }
+            }
+          }
+          s.out_idx = pick;
+        }
+        done = __any(hit);
+        run_mass += __shfl(incl, 63, 64);
       }
     }
-    s.out_idx = pickd;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int r = s.out_idx;
-    if (r < 0) r = 0;  // an all-zero row has no mass to draw from
-    p.out[b] = r;
+    int r_ = s.out_idx;
+    if (r_ < 0) r_ = 0;  // an all-zero row has no mass to draw from
+    p.out[b] = r_;
   }
 }
 
@@ -308,6 +511,20 @@ extern "C" int sglk_top_k_top_p_sampling_from_probs(sglk_stream_t stream, int32_
   return run((hipStream_t)stream, p, batch, use_top_k ? "top_k_top_p_sampling_from_probs" : "top_p_sampling_from_probs");
 }
 
+extern "C" int sglk_top_k_top_p_sampling_from_probs_graph(sglk_stream_t stream, int32_t* output, const float* probs,
+                                                          const int64_t* indices, const int32_t* top_k_arr, int64_t top_k_val,
+                                                          const float* top_p_arr, float top_p_val, int use_top_k, int64_t batch,
+                                                          int64_t vocab, const int64_t* philox_seed_ptr,
+                                                          const int64_t* philox_offset_ptr, uint64_t offset_intragraph) {
+  using namespace sglk;
+  SGLK_REQUIRE(philox_seed_ptr && philox_offset_ptr, "top_k_top_p_sampling_from_probs_graph: the generator state pointers are NULL");
+  SampleParams p{};
+  p.probs = probs; p.out = output; p.indices = indices; p.k_arr = top_k_arr; p.k_is_i64 = 0; p.k_val = top_k_val;
+  p.p_arr = top_p_arr; p.p_val = top_p_val; p.V = (int)vocab; p.use_k = use_top_k; p.use_p = 1; p.do_sample = 1;
+  p.seed_ptr = philox_seed_ptr; p.offset_ptr = philox_offset_ptr; p.offset = offset_intragraph;
+  return run((hipStream_t)stream, p, batch, use_top_k ? "top_k_top_p_sampling_from_probs" : "top_p_sampling_from_probs");
+}
+
 extern "C" int sglk_min_p_sampling_from_probs(sglk_stream_t stream, int32_t* output, const float* probs, const int64_t* indices,
                                               const float* min_p_arr, float min_p_val, int64_t batch, int64_t vocab,
                                               uint64_t philox_seed, uint64_t philox_offset) {
@@ -315,5 +532,17 @@ extern "C" int sglk_min_p_sampling_from_probs(sglk_stream_t stream, int32_t* out
   SampleParams p{};
   p.probs = probs; p.out = output; p.indices = indices; p.p_arr = min_p_arr; p.p_val = min_p_val; p.V = (int)vocab;
   p.use_minp = 1; p.do_sample = 1; p.seed = philox_seed; p.offset = philox_offset;
+  return run((hipStream_t)stream, p, batch, "min_p_sampling_from_probs");
+}
+
+extern "C" int sglk_min_p_sampling_from_probs_graph(sglk_stream_t stream, int32_t* output, const float* probs, const int64_t* indices,
+                                                    const float* min_p_arr, float min_p_val, int64_t batch, int64_t vocab,
+                                                    const int64_t* philox_seed_ptr, const int64_t* philox_offset_ptr,
+                                                    uint64_t offset_intragraph) {
+  using namespace sglk;
+  SGLK_REQUIRE(philox_seed_ptr && philox_offset_ptr, "min_p_sampling_from_probs_graph: the generator state pointers are NULL");
+  SampleParams p{};
+  p.probs = probs; p.out = output; p.indices = indices; p.p_arr = min_p_arr; p.p_val = min_p_val; p.V = (int)vocab;
+  p.use_minp = 1; p.do_sample = 1; p.seed_ptr = philox_seed_ptr; p.offset_ptr = philox_offset_ptr; p.offset = offset_intragraph;
   return run((hipStream_t)stream, p, batch, "min_p_sampling_from_probs");
 }

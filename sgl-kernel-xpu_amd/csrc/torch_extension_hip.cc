@@ -1174,11 +1174,13 @@ const T* optional_row_array(const std::optional<Tensor>& t, at::ScalarType dt, i
   return t->data_ptr<T>();
 }
 
-// (seed, offset) of the generator's Philox stream; the kernel consumes one 128-bit block per row
-std::pair<uint64_t, uint64_t> philox_inputs(const std::optional<at::Generator>& gen) {
+// The generator's Philox stream, one 128-bit block per row. Outside a capture: (seed, offset) as host scalars, as the reference reads
+// them. While the stream is capturing: pointers to the state torch keeps on the device for the graph plus this launch's offset
+// inside it, so that each replay draws fresh numbers (the generator must be registered with the graph - the default one is).
+at::PhiloxCudaState philox_state(const std::optional<at::Generator>& gen) {
   auto* impl = at::get_generator_or_default<at::CUDAGeneratorImpl>(gen, at::cuda::detail::getDefaultCUDAGenerator());
   std::lock_guard<std::mutex> lock(impl->mutex_);
-  return impl->philox_engine_inputs(4);
+  return impl->philox_cuda_state(4);
 }
 
 void top_k_renorm_probs(const Tensor& probs, Tensor& renorm_probs, const std::optional<Tensor>& maybe_top_k_arr, int64_t top_k_val) {
@@ -1230,10 +1232,17 @@ void top_k_top_p_sampling_from_probs(Tensor probs, Tensor output, std::optional<
   if (!k) TORCH_CHECK(top_k_val > 0 && top_k_val <= probs.size(1), "top_k_val must be within (0, vocab_size]");
   const float* pa = optional_row_array<float>(maybe_top_p_arr, at::kFloat, batch, "maybe_top_p_arr");
   if (!pa) TORCH_CHECK(top_p_val > 0.0 && top_p_val <= 1.0, "top_p_val must be within (0, 1]");
-  const auto ph = philox_inputs(gen);
   const c10::OptionalDeviceGuard guard(probs.device());
+  const auto ph = philox_state(gen);
+  if (ph.captured_) {
+    SGLK_CALL(sglk_top_k_top_p_sampling_from_probs_graph(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices,
+                                                         k, top_k_val, pa, (float)top_p_val, 1, batch, probs.size(1), ph.seed_.ptr,
+                                                         ph.offset_.ptr, ph.offset_intragraph_));
+    return;
+  }
   SGLK_CALL(sglk_top_k_top_p_sampling_from_probs(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices, k,
-                                                 top_k_val, pa, (float)top_p_val, 1, batch, probs.size(1), ph.first, ph.second));
+                                                 top_k_val, pa, (float)top_p_val, 1, batch, probs.size(1), ph.seed_.val,
+                                                 ph.offset_.val));
 }
 
 void top_p_sampling_from_probs(Tensor probs, Tensor output, std::optional<Tensor> maybe_indices, std::optional<Tensor> maybe_top_p_arr,
@@ -1244,10 +1253,17 @@ void top_p_sampling_from_probs(Tensor probs, Tensor output, std::optional<Tensor
   sampling_common("top_p_sampling_from_probs", probs, output, maybe_indices, batch, indices);
   const float* pa = optional_row_array<float>(maybe_top_p_arr, at::kFloat, batch, "maybe_top_p_arr");
   if (!pa) TORCH_CHECK(top_p_val > 0.0 && top_p_val <= 1.0, "top_p_val must be within (0, 1]");
-  const auto ph = philox_inputs(gen);
   const c10::OptionalDeviceGuard guard(probs.device());
+  const auto ph = philox_state(gen);
+  if (ph.captured_) {
+    SGLK_CALL(sglk_top_k_top_p_sampling_from_probs_graph(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices,
+                                                         nullptr, 0, pa, (float)top_p_val, 0, batch, probs.size(1), ph.seed_.ptr,
+                                                         ph.offset_.ptr, ph.offset_intragraph_));
+    return;
+  }
   SGLK_CALL(sglk_top_k_top_p_sampling_from_probs(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices,
-                                                 nullptr, 0, pa, (float)top_p_val, 0, batch, probs.size(1), ph.first, ph.second));
+                                                 nullptr, 0, pa, (float)top_p_val, 0, batch, probs.size(1), ph.seed_.val,
+                                                 ph.offset_.val));
 }
 
 void min_p_sampling_from_probs(const Tensor& probs, Tensor& output, const std::optional<Tensor>& maybe_indices,
@@ -1258,10 +1274,16 @@ void min_p_sampling_from_probs(const Tensor& probs, Tensor& output, const std::o
   const int64_t* indices;
   sampling_common("min_p_sampling_from_probs", probs, output, maybe_indices, batch, indices);
   const float* pa = optional_row_array<float>(maybe_min_p_arr, at::kFloat, batch, "maybe_min_p_arr");
-  const auto ph = philox_inputs(gen);
   const c10::OptionalDeviceGuard guard(probs.device());
+  const auto ph = philox_state(gen);
+  if (ph.captured_) {
+    SGLK_CALL(sglk_min_p_sampling_from_probs_graph(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices, pa,
+                                                   (float)min_p_val, batch, probs.size(1), ph.seed_.ptr, ph.offset_.ptr,
+                                                   ph.offset_intragraph_));
+    return;
+  }
   SGLK_CALL(sglk_min_p_sampling_from_probs(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices, pa,
-                                           (float)min_p_val, batch, probs.size(1), ph.first, ph.second));
+                                           (float)min_p_val, batch, probs.size(1), ph.seed_.val, ph.offset_.val));
 }
 
 // ---- DeepSeek-style routers (reference src/sycl/TopKSigMoid.cpp, BiasedTopK.cpp:457-520, MoE_fused_gate.cpp:486-600) ----

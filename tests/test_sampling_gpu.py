@@ -128,6 +128,78 @@ def test_draws_are_reproducible_and_distributed_like_the_filtered_probs(sglk, de
         sglk.top_k_top_p_sampling_from_probs(pr, 1, 0.5, filter_apply_order="p_first")
 
 
+def test_draw_is_the_inverse_cdf_in_row_order(sglk, dev):
+    # The draw of row b is the first index at which the running (fixed-point) mass exceeds u_b * Z, u_b = Philox(seed; offset, b).
+    # u_b is recovered to 17 bits from a draw over 2^17 equal probabilities at the same generator state; the index drawn from any other
+    # row of probabilities must then own a CDF interval that meets [u_lo, u_hi). Rows start at every 16-byte misalignment (V odd) and
+    # the longest one is cut into two-step runs (more than 262141 elements).
+    B, Vu = 64, 1 << 17
+    uni = torch.full((B, Vu), 1.0 / Vu, device=dev)
+    g = torch.Generator(device=dev).manual_seed(99)
+    iu = sglk.top_p_sampling_from_probs(uni, 1.0, generator=g).cpu().double()
+    u_lo, u_hi = iu / Vu, (iu + 1) / Vu
+    assert iu.unique().numel() > B // 2
+    rows = torch.arange(B)
+    for V in (111, 4099, 128256, 300001):
+        pr = make_probs(B, V, seed=5)
+        g = torch.Generator(device=dev).manual_seed(99)
+        s = sglk.top_p_sampling_from_probs(pr.to(dev), 1.0, generator=g).cpu().long()
+        fix = (pr.double() * 2.0 ** 40).floor()
+        cdf = fix.cumsum(-1)
+        Z = cdf[:, -1]
+        hi = cdf[rows, s] / Z
+        lo = (cdf[rows, s] - fix[rows, s]) / Z
+        assert torch.all(hi > u_lo - 1e-9) and torch.all(lo < u_hi + 1e-9), V
+        # min-p and joint draws share the stream: with everything kept they are the same draws
+        g = torch.Generator(device=dev).manual_seed(99)
+        assert torch.equal(sglk.min_p_sampling_from_probs(pr.to(dev), 0.0, generator=g).cpu().long(), s)
+
+
+def test_rows_longer_than_262141_elements(sglk, dev):
+    B, V = 3, 300001
+    pr = make_probs(B, V, seed=11)
+    out = sglk.top_k_renorm_prob(pr.to(dev), 1000).cpu()
+    mask = osamp.top_k_mask(pr, 1000)
+    assert torch.equal(out > 0, mask & (pr > 0))
+    torch.testing.assert_close(out, osamp.renorm(pr, mask), rtol=1e-3, atol=1e-3)
+    out = sglk.top_p_renorm_prob(pr.to(dev), 0.3).cpu()
+    torch.testing.assert_close(out.sum(dim=-1), torch.ones(B), rtol=1e-5, atol=1e-5)
+    keep = out > 0
+    assert torch.all((pr * keep).sum(-1) >= 0.3 - 1e-4)
+    jm = osamp.top_k_mask(pr, 5000) & keep
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for _ in range(30):
+        smp = sglk.top_k_top_p_sampling_from_probs(pr.to(dev), 5000, 0.3, filter_apply_order="joint", generator=gen).cpu().long()
+        assert torch.all(jm[torch.arange(B), smp])
+
+
+def test_draws_recorded_into_a_graph_follow_the_generator(sglk, dev):
+    # A sampling launch recorded into a HIP graph reads the generator state from the device at replay (the C-ABI's *_graph entries):
+    # every replay draws fresh numbers, and they are the numbers the eager op draws from the same generator state.
+    V, B = 4096, 256
+    pr = make_probs(B, V, seed=7).to(dev)
+    torch.cuda.manual_seed(2024)
+    eager = [(sglk.top_k_top_p_sampling_from_probs(pr, 50, 0.9, filter_apply_order="joint"), sglk.top_p_sampling_from_probs(pr, 0.8),
+              sglk.min_p_sampling_from_probs(pr, 0.01)) for _ in range(3)]
+    assert not torch.equal(eager[0][0], eager[1][0])
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            a = sglk.top_k_top_p_sampling_from_probs(pr, 50, 0.9, filter_apply_order="joint")
+            b = sglk.top_p_sampling_from_probs(pr, 0.8)
+            c = sglk.min_p_sampling_from_probs(pr, 0.01)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.manual_seed(2024)
+    for want in eager:
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, w in zip((a, b, c), want):
+            assert torch.equal(got, w)
+
+
 def test_sampling_golden(sglk, dev):
     gold = load_golden("sampling")
     mv = lambda v: v.to(dev) if isinstance(v, torch.Tensor) else v

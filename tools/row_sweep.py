@@ -152,4 +152,65 @@ if what == "sample":
         t2 = timeit(lambda: sgl_kernel.top_p_renorm_prob(probs, pp), it=10)
         t3 = timeit(lambda: sgl_kernel.top_k_top_p_sampling_from_probs(probs, k, pp), it=10)
         t4 = timeit(lambda: sgl_kernel.min_p_sampling_from_probs(probs, pp * 0.1), it=10)
-        print(f"sampling vocab {V} bs={bs}: top_k_renorm {t1:.0f} us | top_p_renorm {t2:.0f} us | top_k_top_p_sampling {t3:.0f} us | min_p_sampling {t4:.0f} us")
+        t5 = timeit(lambda: sgl_kernel.top_k_top_p_sampling_from_probs(probs, k, pp, filter_apply_order="joint"), it=10)
+        t6 = timeit(lambda: sgl_kernel.top_p_sampling_from_probs(probs, pp), it=10)
+        t7 = timeit(lambda: sgl_kernel.top_p_renorm_prob(probs, 1.0), it=10)    # normaliser + write only
+        t8 = timeit(lambda: sgl_kernel.top_p_sampling_from_probs(probs, 1.0), it=10)  # normaliser + draw only
+        print(f"sampling vocab {V} bs={bs}: top_k_renorm {t1:.0f} us | top_p_renorm {t2:.0f} us | top_k_top_p_sampling {t3:.0f} us | min_p_sampling {t4:.0f} us"
+              f" | joint {t5:.0f} | top_p_sampling {t6:.0f} | p = 1: renorm {t7:.0f}, sampling {t8:.0f}")
+if what == "elem3":
+    def safe(f):
+        try:
+            return timeit(f)
+        except Exception as e:  # a refused call: print why once and go on
+            print("    [refused]", str(e).splitlines()[0][:160])
+            return float("nan")
+    # decode- to prefill-sized calls of the small ops around attention and routing (tokens sweep at Llama / DeepSeek widths)
+    from sgl_kernel import elementwise as ew, moe as moe_api, attention as att
+    for tokens in (1, 8, 64, 256, 1024, 4096, 16384):
+        hq, hk, d = 32, 8, 128
+        pos = torch.randint(0, 4096, (tokens,), device=dev)
+        q = torch.randn(tokens, hq * d, device=dev, dtype=torch.bfloat16)
+        k = torch.randn(tokens, hk * d, device=dev, dtype=torch.bfloat16)
+        cache = torch.randn(4096, d, device=dev, dtype=torch.bfloat16)
+        t1 = safe(lambda: ew.rotary_embedding(pos, q, k, d, cache, True))
+        q3, k3 = q.view(tokens, hq, d), k.view(tokens, hk, d)
+        wq = torch.ones(d, device=dev, dtype=torch.bfloat16)
+        cache32 = torch.randn(4096, d, device=dev, dtype=torch.float32)
+        t2 = safe(lambda: ew.fused_inplace_qknorm_rope(q3, k3, wq, wq, cache32, pos, True))
+        qkv = torch.randn(tokens, (hq + 2 * hk) * d, device=dev, dtype=torch.bfloat16)
+        t3 = safe(lambda: ew.fused_qk_norm_rope(qkv, hq, hk, hk, d, 1e-6, wq, wq, 10000.0, True, pos.int()))
+        kc = torch.empty(65536, hk * d, device=dev, dtype=torch.bfloat16)
+        vc = torch.empty(65536, hk * d, device=dev, dtype=torch.bfloat16)
+        loc = torch.randperm(65536, device=dev)[:tokens]
+        t4 = safe(lambda: ew.store_cache_xpu(k, k, kc, vc, loc))
+        va = torch.randn(tokens, hq, d, device=dev, dtype=torch.bfloat16); sa = torch.randn(tokens, hq, device=dev)
+        vm = torch.empty_like(va); sm = torch.empty_like(sa)
+        t5 = safe(lambda: att.merge_state_v2(va, sa, va, sa, vm, sm))
+        print(f"tokens={tokens}: rotary_embedding {t1:.1f} us | fused_inplace_qknorm_rope {t2:.1f} | fused_qk_norm_rope {t3:.1f} | "
+              f"store_cache {t4:.1f} | merge_state_v2 {t5:.1f} ({tokens * hq * d * 6 / t5 / 1e6:.2f} TB/s)")
+        for E, topk in ((8, 2), (128, 8), (256, 8)):
+            g = torch.randn(tokens, E, device=dev, dtype=torch.bfloat16)
+            tw = torch.empty(tokens, topk, device=dev); ti = torch.empty(tokens, topk, device=dev, dtype=torch.int32)
+            r1 = safe(lambda: moe_api.topk_softmax(tw, ti, g, True))
+            r2 = safe(lambda: moe_api.topk_sigmoid(tw, ti, g, True))
+            r3 = float("nan")
+            if E == 256:
+                bias = torch.randn(E, device=dev, dtype=torch.bfloat16)
+                r3 = safe(lambda: moe_api.moe_fused_gate(g, bias, 8, 4, topk))
+            block = 64
+            cap = tokens * topk + E * (block - 1)
+            sorted_ids = torch.empty(cap, device=dev, dtype=torch.int32); eids = torch.empty(cap // block + 1, device=dev, dtype=torch.int32)
+            npost = torch.empty(1, device=dev, dtype=torch.int32); cum = torch.empty(E + 1, device=dev, dtype=torch.int32)
+            r4 = safe(lambda: moe_api.moe_align_block_size(ti, E, block, sorted_ids, eids, npost, cum))
+            print(f"    E={E} topk={topk}: topk_softmax {r1:.1f} us | topk_sigmoid {r2:.1f} | moe_fused_gate {r3:.1f} | moe_align_block_size {r4:.1f}")
+        x = torch.randn(tokens, 4096, device=dev, dtype=torch.bfloat16)
+        qo = torch.empty(tokens, 4096, device=dev, dtype=torch.float8_e4m3fn); so = torch.zeros(1, device=dev)
+        p1 = safe(lambda: sgl_kernel.sgl_per_tensor_quant_fp8(x, qo, so, False))
+        p2 = safe(lambda: sgl_kernel.sgl_per_tensor_quant_fp8(x, qo, so, True))
+        print(f"    per_tensor_quant_fp8 dynamic {p1:.1f} us | static {p2:.1f} us")
+    for n in (4096, 14336):
+        qw = torch.randint(0, 2 ** 31 - 1, (4096, n // 8), device=dev, dtype=torch.int32)
+        sc = torch.rand(4096 // 128, n, device=dev, dtype=torch.float16); zz = torch.randint(0, 2 ** 31 - 1, (4096 // 128, n // 8), device=dev, dtype=torch.int32)
+        t = safe(lambda: sgl_kernel.awq_dequantize(qw, sc, zz))
+        print(f"awq_dequantize 4096 x {n}: {t:.1f} us  {(4096 * n * 2.5) / t / 1e6:.2f} TB/s")
