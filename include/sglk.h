@@ -147,6 +147,18 @@ SGLK_API int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, const
                                           int64_t ldb, int64_t ldc, int64_t sa_stride_m,
                                           int64_t sa_stride_k, int64_t sb_stride_k,
                                           int64_t sb_stride_n, int out_dtype);
+/* The same product with a scratch buffer the caller owns (the reference's op allocates nothing and has no counterpart):
+ * few rows over a deep K (M = 65 .. 512 with at most 256 / S half tiles of 128 x 256 - Llama-3-8B's down projection at
+ * N = 4096, K = 14336) run as tile x K-slice units that store fp32 partial tiles into S slabs of [M, N], added in
+ * slice order and rounded once by a second kernel. _workspace_size returns the bytes the shape can use (0: the plain
+ * entry's path is taken whatever is passed); a NULL or smaller workspace is not an error - the call then runs unsplit.
+ * Results are a pure function of the inputs for a given workspace size class (deterministic, graph-capturable). */
+SGLK_API int64_t sglk_fp8_blockwise_scaled_mm_workspace_size(int64_t M, int64_t N, int64_t K);
+SGLK_API int sglk_fp8_blockwise_scaled_mm_ws(sglk_stream_t stream, void* out, const void* a, const void* b,
+                                             const float* sa, const float* sb, int64_t M, int64_t N, int64_t K,
+                                             int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_stride_m,
+                                             int64_t sa_stride_k, int64_t sb_stride_k, int64_t sb_stride_n,
+                                             int out_dtype, void* workspace, int64_t workspace_bytes);
 
 /* ---- per-token / per-channel scaled GEMM ------------------------------------
  * fp8_scaled_mm / int8_scaled_mm: declared in reference

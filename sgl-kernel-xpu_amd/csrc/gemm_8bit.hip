@@ -1130,12 +1130,14 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
     char* smem, OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
     int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves,
-    uint32_t* __restrict__ stamps) {
+    uint32_t* __restrict__ stamps, int ksplit, int64_t slab) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int nkb = K / BK;  // >= 2
+  // K split (OutT = float, few rows x deep K: see launch()): unit = tile x slice; slice s multiplies K blocks [s nkb, (s + 1) nkb)
+  // and stores its fp32 partial tile into slab s of `out` (slab elements apart); a second kernel adds the slabs up.
+  const int nkb = K / BK / ksplit;  // >= 3
   constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || (PROBE >= 12 && PROBE <= 19);
   // LDS stage of this phase: a rows [64 MS][128 B], b^T rows [256][128 B], 256 row scales (+ 1 KiB spare). Whole tiles: two
   // stages of 66 KiB. Half tiles: THREE stages of 50 KiB - with 1024 cycles of MFMAs per K block and the block's data
@@ -1152,7 +1154,8 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
   // loads into registers (fetch, no LDS write); results are garbage, no stores
 
   // ---- this workgroup's units: the tile walk of gemm_8bit_persist_kernel
-  const int nt = tiles_m * tiles_n;
+  constexpr bool kSlabs = sizeof(OutT) == 4;
+  const int nt = tiles_m * tiles_n * ksplit;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int q8 = nt >> 3, rem = nt & 7;
   const int run_first = xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8;
@@ -1172,7 +1175,9 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
     const int ht = slot + unit * slots;
     const int local = !live ? 0 : (kHalf && all_halves) ? (ht >> 1) : kHalf ? rounds * slots + (slot >> 1) : slot + unit * slots;
     const int lower = all_halves ? (ht & 1) : (slot & 1);
-    const int tile = run_first + local;
+    const int tile_s = run_first + local;
+    const int tile = kSlabs ? tile_s / ksplit : tile_s;
+    const int ks = kSlabs ? tile_s - tile * ksplit : 0;
     constexpr int GM = 4;
     const int group = tile / (GM * tiles_n);
     const int first_m = group * GM;
@@ -1188,17 +1193,18 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
     d.wrows = MS * 32;
     d.m0 = m0;
     d.n0 = n0;
-    d.pa = a + (int64_t)m0 * lda;
-    d.pb = b + (int64_t)n0 * ldb;
-    d.ps = sa + (int64_t)m0 * sa_sm;
-    d.po = (void*)(out + (int64_t)m0 * ldc + n0);
-    d.nrec_a = (live && PROBE != 5) ? (uint32_t)((int64_t)(rows_a - 1) * lda + K) : 0u;
-    d.nrec_b = (live && PROBE != 5) ? (uint32_t)((int64_t)(rows_b - 1) * ldb + K) : 0u;
+    const int kb0 = ks * nkb;  // the slice's first K block
+    d.pa = a + (int64_t)m0 * lda + kb0 * BK;
+    d.pb = b + (int64_t)n0 * ldb + kb0 * BK;
+    d.ps = sa + (int64_t)m0 * sa_sm + (int64_t)kb0 * sa_sk;
+    d.po = (void*)(out + (kSlabs ? (int64_t)ks * slab : 0) + (int64_t)m0 * ldc + n0);
+    d.nrec_a = (live && PROBE != 5) ? (uint32_t)((int64_t)(rows_a - 1) * lda + nkb * BK) : 0u;
+    d.nrec_b = (live && PROBE != 5) ? (uint32_t)((int64_t)(rows_b - 1) * ldb + nkb * BK) : 0u;
     d.nrec_s = (live && wave < 4) ? (uint32_t)(((int64_t)(rows_a - 1) * sa_sm + (int64_t)(nkb - 1) * sa_sk + 1) * 4) : 0u;
     d.nrec_o = (live && kStore) ? (uint32_t)(((int64_t)(rows_a - 1) * ldc + rows_b) * (int64_t)sizeof(OutT)) : 0u;
     int nblk = (n0 + wn * 64) >> 7;
     nblk = nblk < nblk_max ? nblk : nblk_max;
-    d.sbw = sb + (int64_t)nblk * sb_sn;
+    d.sbw = sb + (int64_t)nblk * sb_sn + (int64_t)kb0 * sb_sk;
     // (probe 16: consecutive units of a workgroup share their a panel - the tile index advances by the slot count, a multiple of
     //  the group of four m-tiles; odd units walk K backwards, so the panel's last blocks are re-read while the XCD's L2 holds them)
     d.rev = (PROBE == 16) ? (unit & 1) : 0;
@@ -1309,6 +1315,24 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
       return;
     }
     const int soff = __builtin_amdgcn_readfirstlane(mf * 32 * (int)ldc * (int)sizeof(OutT));
+    if constexpr (kSlabs) {  // fp32 partial tile of a K slice: the lane's 8 columns are two 16-byte stores
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int hv = 0; hv < 2; ++hv) {
+          const uint32_t vo = (wn * 64 + nf * 32 + hv * 16 + lh * 8 < d.ncols)
+                                  ? orow_off + (uint32_t)((nf * 32 + hv * 16) * 4) : 0x80000000u;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float f0 = accm[nf][hv * 8 + q * 4 + 0], f1 = accm[nf][hv * 8 + q * 4 + 1], f2 = accm[nf][hv * 8 + q * 4 + 2],
+                        f3 = accm[nf][hv * 8 + q * 4 + 3];
+            const v4i data = {(int)__float_as_uint(f0), (int)__float_as_uint(f1), (int)__float_as_uint(f2), (int)__float_as_uint(f3)};
+            __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo + q * 16, soff, 0);
+            asm volatile("s_nop 4" ::"v"(data));
+          }
+        }
+      return;
+    } else {
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
@@ -1322,6 +1346,7 @@ __device__ __forceinline__ void gemm_fp8bw_x32_phase(
         __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo, soff, PROBE == 12 ? 2 : PROBE == 13 ? 3 : PROBE == 14 ? 17 : 0);  /* probes 12..14: nt / nt + sc0 / sc0 sc1 stores - 0.306 / 0.307 / 0.244 ms against 0.233 with the default policy (write-back through L2) */
         asm volatile("s_nop 4" ::"v"(data));  // (store data is read for a few cycles after issue: see the kernel above)
       }
+    }
   };
 
   float acc[MS][2][16];
@@ -1621,7 +1646,7 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
     OutT* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ sa, const float* __restrict__ sb, int M, int N, int K, int64_t lda, int64_t ldb,
     int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m, int tiles_n, int all_halves,
-    int stagger, uint32_t* __restrict__ stamps) {
+    int stagger, uint32_t* __restrict__ stamps, int ksplit, int64_t slab) {
   __shared__ __attribute__((aligned(256))) char smem[3 * (kStageBytes - kTileBytes / 2)];  // half tiles: 3 x 50 KiB; whole tiles 2 x 66 KiB
   const int slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const bool half_first = all_halves || (stagger == 1 ? 2 * slot >= slots : stagger == 2 ? ((slot >> 1) & 1) != 0
@@ -1630,10 +1655,10 @@ __global__ __launch_bounds__(512) void gemm_fp8bw_x32_kernel(
   for (int ph = 0; ph < (all_halves ? 1 : 2); ++ph) {
     if ((ph == 0) == half_first) {
       gemm_fp8bw_x32_phase<OutT, 2, PROBE>(smem, out, a, b, sa, sb, M, N, K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn,
-                                          tiles_m, tiles_n, all_halves, stamps);
+                                          tiles_m, tiles_n, all_halves, stamps, ksplit, slab);
     } else {
       gemm_fp8bw_x32_phase<OutT, 4, PROBE>(smem, out, a, b, sa, sb, M, N, K, lda, ldb, ldc, sa_sm, sa_sk, sb_sk, sb_sn,
-                                          tiles_m, tiles_n, 0, stamps);
+                                          tiles_m, tiles_n, 0, stamps, ksplit, slab);
     }
     // (the phase has drained its own LDS reads and DMA; no wave may start the next prologue's DMA while another still
     // reads the stages)
@@ -1908,10 +1933,58 @@ constexpr int g_gemm_stagger = 0;
 constexpr uint32_t* g_clock_stamps = nullptr;
 #endif
 
+// K split of fp8_blockwise_scaled_mm (round 5, late): few rows over a deep K leave the tile pipeline a handful of long units -
+// M = 129 .. 512, N = 4096, K = 14336 (Llama-3-8B's down projection) is 32 .. 64 half tiles of 112 K blocks on 256 CUs, 84 - 90 us
+// whichever kernel ran. With a caller-provided workspace the units are tile x K slice (S slices, fp32 partial tiles into S slabs
+// of [M, N]) and a second kernel adds the slabs in slice order (deterministic) and rounds once. Returns S (0: no split).
+#ifdef SGLK_PROBES
+static int g_gemm_splitk = -1;  // -1: the rule below; 0: never; S: forced where the shape allows
+#else
+constexpr int g_gemm_splitk = -1;
+#endif
+static int fp8bw_splitk_slices(int64_t M, int64_t N, int64_t K) {
+  if (g_gemm_splitk == 0 || g_gemm_variant != 4) return 0;
+  if (M <= 48 || M > 1024 || N % 8 != 0 || K % BK != 0) return 0;
+  // (lease zv, forced slice counts against the rule, one box: N = 4096, K = 14336 - 8 slices 27 - 36 us at 65 .. 256 rows against 50 - 86
+  //  unsplit, 4 slices 46 / 53 at 384 / 512 against 88 / 91, 2 slices 76 / 85 at 768 / 1024 against 92 / 96; 8192^2 4 slices 28 - 37
+  //  against 52 - 55 up to 256 rows; N = 6144, K = 4096 4 slices of 8 blocks 22 - 27 against 28 (65 .. 128 rows) and 55 (192, 256);
+  //  N = 14336, K = 4096 2 slices 27 - 31 against 33 up to 128 rows. Up to 128 rows a small weight matrix is faster as one stream:
+  //  N = K = 4096 18.5 us against 20 - 26 for every slice count.)
+  //  49 .. 64 rows: N = 4096, K = 14336 and 8192^2 26 - 28 us sliced against 29 - 32; N = 6144, K = 4096 21 against 17 - 18.)
+  if (g_gemm_splitk < 0 && ((M <= 128 && N * K <= (20ll << 20)) || (M <= 64 && N * K <= (32ll << 20)))) return 0;
+  const int64_t units = 2 * cdiv(M, 256) * cdiv(N, 256), nkb = K / BK;  // half tiles (a 256-row tile's empty lower half runs along)
+  for (int s = 8; s >= 2; s >>= 1) {
+    if (g_gemm_splitk > 0 && s != g_gemm_splitk) continue;
+    if (nkb % s == 0 && nkb / s >= (g_gemm_splitk > 0 ? 3 : 8) && units * s <= num_cus()) return s;
+  }
+  return 0;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void gemm_splitk_sum_kernel(OutT* __restrict__ out, const float* __restrict__ ws, int64_t M,
+                                                               int64_t N, int64_t ldc, int slices) {
+  // 8 columns per thread: slabs added in slice order, rounded once
+  const int64_t n8 = N >> 3, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * n8) return;
+  const int64_t m = i / n8, c = (i - m * n8) << 3;
+  const float* p = ws + m * N + c;
+  float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + 4);
+  for (int s = 1; s < slices; ++s) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p + (int64_t)s * M * N), b1 = *reinterpret_cast<const float4*>(p + (int64_t)s * M * N + 4);
+    a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+    a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+  }
+  Vec<OutT, 8> v;
+  v[0] = (OutT)a0.x; v[1] = (OutT)a0.y; v[2] = (OutT)a0.z; v[3] = (OutT)a0.w;
+  v[4] = (OutT)a1.x; v[5] = (OutT)a1.y; v[6] = (OutT)a1.z; v[7] = (OutT)a1.w;
+  store_vec<OutT, 8>(out + m * ldc + c, v);
+}
+
 template <typename OutT, int MODE>
 static int launch(hipStream_t st, void* out, const void* a, const void* b, const float* sa, const float* sb,
                   const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
-                  int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, bool hw_scale) {
+                  int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, bool hw_scale, void* ws = nullptr,
+                  int64_t ws_bytes = 0) {
   const int tiles_m = (int)cdiv(M, BM), tiles_n = (int)cdiv(N, BN);
   const unsigned grid = (unsigned)(tiles_m * tiles_n);
   const bool vec = (N % 4 == 0) && (ldc % 4 == 0) && ((uintptr_t)out % 8 == 0);
@@ -1929,6 +2002,20 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
     for (int len = q; len <= q + (r8 ? 1 : 0); ++len) {
       const int left = len - (len / slots) * slots;
       tail_halves = tail_halves || (left > 0 && 2 * left <= slots);
+    }
+  }
+  if constexpr (MODE == MODE_BLOCKWISE) {
+    const int S = ws != nullptr ? fp8bw_splitk_slices(M, N, K) : 0;
+    if (S > 0 && persist_ok && ws_bytes >= (int64_t)S * M * N * 4 && (uintptr_t)ws % 16 == 0) {
+      const unsigned units = 2 * grid * (unsigned)S;  // half tiles x slices
+      const unsigned sgrid = units < (unsigned)num_cus() ? ((units + 7) / 8) * 8 : (unsigned)num_cus();
+      gemm_fp8bw_x32_kernel<float, 0><<<sgrid, 512, 0, st>>>((float*)ws, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N,
+                                                            (int)K, lda, ldb, /*ldc=*/N, sa_sm, sa_sk, sb_sk, sb_sn, tiles_m, tiles_n,
+                                                            1, 0, nullptr, S, M * N);
+      if (int rc = check_launch("gemm_8bit(k slices)")) return rc;
+      const int64_t n = M * (N >> 3);
+      gemm_splitk_sum_kernel<OutT><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((OutT*)out, (const float*)ws, M, N, ldc, S);
+      return check_launch("gemm_8bit(k slices: sum)");
     }
   }
   // few rows: the weight-streaming kernel (variant 5 forces it, 7 forces it without the K split, 6 forbids it)
@@ -2012,7 +2099,7 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
   if constexpr (MODE == MODE_BLOCKWISE) {                                                                    \
     gemm_fp8bw_x32_kernel<OutT, P><<<all_halves ? hgrid : pgrid, 512, 0, st>>>(                              \
         (OutT*)out, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M, (int)N, (int)K, lda, ldb, ldc, sa_sm, sa_sk, \
-        sb_sk, sb_sn, tiles_m, tiles_n, all_halves ? 1 : 0, tail_halves ? g_gemm_stagger : 0, g_clock_stamps);     \
+        sb_sk, sb_sn, tiles_m, tiles_n, all_halves ? 1 : 0, tail_halves ? g_gemm_stagger : 0, g_clock_stamps, 1, 0);  \
   }
 #ifdef SGLK_PROBES
 #define SGLK_GO(V, H)                                                                                        \
@@ -2149,6 +2236,7 @@ extern "C" SGLK_API void sglk_debug_set_gemm_variant(int v) { sglk::g_gemm_varia
 extern "C" SGLK_API void sglk_debug_set_gemm_stamps(uint32_t* p) { sglk::g_gemm_stamps = p; sglk::g_clock_stamps = p; }
 extern "C" SGLK_API void sglk_debug_set_gemm_stagger(int s) { sglk::g_gemm_stagger = s; }
 extern "C" SGLK_API void sglk_debug_set_skinny_la_rows(int r) { sglk::g_skinny_la_rows = r; }
+extern "C" SGLK_API void sglk_debug_set_gemm_splitk(int s) { sglk::g_gemm_splitk = s; }
 #else
 constexpr int g_fp8_hw_scale = 1;
 #endif
@@ -2167,6 +2255,29 @@ extern "C" int sglk_fp8_blockwise_scaled_mm(sglk_stream_t stream, void* out, con
                                         sa_stride_k, sb_stride_k, sb_stride_n, g_fp8_hw_scale != 0);
   return launch<f16, MODE_BLOCKWISE>(st, out, a, b, sa, sb, nullptr, M, N, K, lda, ldb, ldc, sa_stride_m,
                                      sa_stride_k, sb_stride_k, sb_stride_n, g_fp8_hw_scale != 0);
+}
+
+extern "C" int64_t sglk_fp8_blockwise_scaled_mm_workspace_size(int64_t M, int64_t N, int64_t K) {
+  using namespace sglk;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (int64_t)fp8bw_splitk_slices(M, N, K) * M * N * 4;
+}
+
+extern "C" int sglk_fp8_blockwise_scaled_mm_ws(sglk_stream_t stream, void* out, const void* a, const void* b,
+                                               const float* sa, const float* sb, int64_t M, int64_t N,
+                                               int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                                               int64_t sa_stride_m, int64_t sa_stride_k,
+                                               int64_t sb_stride_k, int64_t sb_stride_n, int out_dtype,
+                                               void* workspace, int64_t workspace_bytes) {
+  using namespace sglk;
+  if (int rc = check_common("fp8_blockwise_scaled_mm", a, b, M, N, K, lda, ldb, out_dtype)) return rc;
+  if (M == 0) return SGLK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == SGLK_BF16)
+    return launch<bf16, MODE_BLOCKWISE>(st, out, a, b, sa, sb, nullptr, M, N, K, lda, ldb, ldc, sa_stride_m,
+                                        sa_stride_k, sb_stride_k, sb_stride_n, g_fp8_hw_scale != 0, workspace, workspace_bytes);
+  return launch<f16, MODE_BLOCKWISE>(st, out, a, b, sa, sb, nullptr, M, N, K, lda, ldb, ldc, sa_stride_m,
+                                     sa_stride_k, sb_stride_k, sb_stride_n, g_fp8_hw_scale != 0, workspace, workspace_bytes);
 }
 
 extern "C" int sglk_scaled_mm(sglk_stream_t stream, void* out, const void* a, const void* b, const float* sa,

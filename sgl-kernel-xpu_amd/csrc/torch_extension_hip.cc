@@ -269,11 +269,15 @@ Tensor fp8_blockwise_scaled_mm(const Tensor& mat_a, const Tensor& mat_b, const T
   Tensor out = at::empty({M, N}, mat_a.options().dtype(out_dtype));
   if (M == 0) return out;
   const c10::OptionalDeviceGuard guard(mat_a.device());
-  SGLK_CALL(sglk_fp8_blockwise_scaled_mm(stream_of(mat_a), out.data_ptr(), mat_a.data_ptr(), mat_b.data_ptr(),
-                                         scales_a.data_ptr<float>(), scales_b.data_ptr<float>(), M, N, K,
-                                         mat_a.stride(0), mat_b.stride(1), out.stride(0), scales_a.stride(0),
-                                         scales_a.stride(1), scales_b.stride(0), scales_b.stride(1),
-                                         dtype_code(out_dtype, "out_dtype")));
+  // few rows over a deep K: K-slice units with fp32 partial tiles in a scratch tensor (include/sglk.h; 0 bytes: not that shape)
+  const int64_t ws_bytes = sglk_fp8_blockwise_scaled_mm_workspace_size(M, N, K);
+  Tensor ws;
+  if (ws_bytes > 0) ws = at::empty({ws_bytes}, mat_a.options().dtype(at::kByte));
+  SGLK_CALL(sglk_fp8_blockwise_scaled_mm_ws(stream_of(mat_a), out.data_ptr(), mat_a.data_ptr(), mat_b.data_ptr(),
+                                            scales_a.data_ptr<float>(), scales_b.data_ptr<float>(), M, N, K,
+                                            mat_a.stride(0), mat_b.stride(1), out.stride(0), scales_a.stride(0),
+                                            scales_a.stride(1), scales_b.stride(0), scales_b.stride(1),
+                                            dtype_code(out_dtype, "out_dtype"), ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes));
   return out;
 }
 

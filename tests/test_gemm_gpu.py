@@ -81,6 +81,53 @@ def test_fp8_blockwise_tile_pipeline_edges(sglk, dev, M, N, K):
     torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-3)
 
 
+@pytest.mark.parametrize("M", [65, 100, 128, 129, 200, 256, 300, 385, 512])
+@pytest.mark.parametrize("N,K", [(4096, 14336), (1024, 7168), (640, 3072), (2056, 12288), (136, 16384), (4096, 3584)])
+def test_fp8_blockwise_k_slices(sglk, dev, M, N, K):
+    """few rows over a deep K: tile x K-slice units with fp32 partial tiles in a scratch tensor, added in slice order (8, 4 or 2 slices
+    by the number of half tiles; ragged rows / columns; the last shape's 28 K blocks are too few to split) - every output element
+    against the oracle, and twice the same bits"""
+    dtype = torch.bfloat16 if (M + N) % 2 else torch.float16
+    a, b, sa, sb = make_blockwise(M, N, K, seed=M + N + K)
+    out = run_blockwise(sglk, dev, a, b, sa, sb, dtype)
+    ref = ogemm.fp8_blockwise_scaled_mm(a, b, sa, sb, dtype)
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-3)
+    assert torch.equal(out, run_blockwise(sglk, dev, a, b, sa, sb, dtype))
+
+
+def test_fp8_blockwise_workspace_entry(dev):
+    """C-ABI: _workspace_size names the scratch bytes of the K-slice path; _ws with no / a short workspace runs unsplit and agrees
+    with the split result to output rounding"""
+    lib = ctypes.CDLL(os.path.join(PKG, "sgl_kernel", "libsglk.so"))
+    lib.sglk_fp8_blockwise_scaled_mm_workspace_size.restype = ctypes.c_int64
+    lib.sglk_fp8_blockwise_scaled_mm_workspace_size.argtypes = [ctypes.c_int64] * 3
+    M, N, K = 256, 4096, 14336
+    size = lib.sglk_fp8_blockwise_scaled_mm_workspace_size(M, N, K)
+    assert size == 8 * M * N * 4
+    assert lib.sglk_fp8_blockwise_scaled_mm_workspace_size(4096, 14336, 4096) == 0
+    assert lib.sglk_fp8_blockwise_scaled_mm_workspace_size(16, N, K) == 0
+    a, b, sa, sb = make_blockwise(M, N, K, seed=5)
+    ad, bd, sad, sbd = a.to(dev), to_dev_colmajor(b, dev), to_dev_colmajor(sa, dev), to_dev_colmajor(sb, dev)
+    outs = []
+    for ws_bytes in (size, size - 16, 0):
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        vp = ctypes.c_void_p
+        i64 = ctypes.c_int64
+        rc = lib.sglk_fp8_blockwise_scaled_mm_ws(vp(torch.cuda.current_stream().cuda_stream), vp(out.data_ptr()), vp(ad.data_ptr()),
+                                                 vp(bd.data_ptr()), vp(sad.data_ptr()), vp(sbd.data_ptr()), i64(M), i64(N), i64(K),
+                                                 i64(ad.stride(0)), i64(bd.stride(1)), i64(N), i64(sad.stride(0)), i64(sad.stride(1)),
+                                                 i64(sbd.stride(0)), i64(sbd.stride(1)), ctypes.c_int(2),  # (SGLK_BF16)
+                                                 vp(ws.data_ptr()) if ws_bytes else vp(None), i64(ws_bytes))
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    ref = ogemm.fp8_blockwise_scaled_mm(a, b, sa, sb, torch.bfloat16)
+    for o in outs:
+        torch.testing.assert_close(o.float(), ref.float(), rtol=2e-2, atol=2e-3)
+    assert torch.equal(outs[1], outs[2])  # both unsplit
+
+
 @pytest.mark.parametrize("M", [1, 3, 5, 127, 128, 512, 1024, 4096])
 @pytest.mark.parametrize("N", [128, 512, 1024, 4096, 8192, 14080])
 @pytest.mark.parametrize("K", [512, 1024, 4096, 8192, 14080, 16384])

@@ -214,3 +214,18 @@ if what == "elem3":
         sc = torch.rand(4096 // 128, n, device=dev, dtype=torch.float16); zz = torch.randint(0, 2 ** 31 - 1, (4096 // 128, n // 8), device=dev, dtype=torch.int32)
         t = safe(lambda: sgl_kernel.awq_dequantize(qw, sc, zz))
         print(f"awq_dequantize 4096 x {n}: {t:.1f} us  {(4096 * n * 2.5) / t / 1e6:.2f} TB/s")
+if what == "gemmbw":
+    if os.environ.get("GEMM_SPLITK"):  # diagnostic build only (LD_PRELOAD=.../build/libsglk_probes.so): forced slice count (0: never)
+        import ctypes
+        ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
+                    ).sglk_debug_set_gemm_splitk(int(os.environ["GEMM_SPLITK"]))
+    # fp8_blockwise_scaled_mm only, rows across the dispatch boundaries at the four Llama-3-8B projections (+ a deep square)
+    for N, K in ((4096, 14336), (14336, 4096), (4096, 4096), (6144, 4096), (8192, 8192)):
+        g = torch.Generator().manual_seed(0)
+        b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).to(FP8).to(dev).t()
+        sb = (torch.rand(K // 128, N // 128, generator=g) + 0.5).to(dev)
+        for M in [int(m) for m in os.environ.get("GEMM_MS", "32,64,65,72,73,96,128,129,192,256,257,384,512,513,768,1024").split(",")]:
+            a = ((torch.rand(M, K, generator=g) - 0.5) * 2 * 448).to(FP8).to(dev)
+            sa = (torch.rand(M, K // 128, generator=g) + 0.5).to(dev)
+            t1 = timeit(lambda: sgl_kernel.fp8_blockwise_scaled_mm(a, b, sa, sb, torch.bfloat16))
+            print(f"N={N} K={K} M={M}: fp8 blockwise {t1:.1f} us  {2.0 * M * N * K / t1 / 1e6:.0f} TFLOP/s  weights {N * K / t1 / 1e6:.2f} TB/s")
