@@ -171,6 +171,16 @@ SGLK_API int sglk_scaled_mm(sglk_stream_t stream, void* out, const void* a, cons
                             const float* sa, const float* sb, const void* bias, int64_t M,
                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                             int in_dtype, int out_dtype);
+/* The same products with a scratch buffer the caller owns (as sglk_fp8_blockwise_scaled_mm_ws above): 129 .. 1024 rows over a
+ * deep K run as tile x K-slice units that store their raw accumulators (fp32; int32 for int8 inputs) into slabs of
+ * [M, N]; a second kernel adds the slabs and applies row scale, column scale and bias in the order stated above - int8
+ * results are bit-identical to the unsplit path (integer sums), fp8 results differ by the fp32 association of the K sum.
+ * _workspace_size: bytes the shape can use (0: unsplit whatever is passed). */
+SGLK_API int64_t sglk_scaled_mm_workspace_size(int64_t M, int64_t N, int64_t K);
+SGLK_API int sglk_scaled_mm_ws(sglk_stream_t stream, void* out, const void* a, const void* b, const float* sa,
+                               const float* sb, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
+                               int64_t ldb, int64_t ldc, int in_dtype, int out_dtype, void* workspace,
+                               int64_t workspace_bytes);
 
 /* ---- quantisation steps around the scaled GEMMs ---------------------------------
  * sgl_per_token_quant_fp8: reference src/sycl/per_token_quant_fp8.cpp:201 (schema torch_extension_sycl.cc:410).

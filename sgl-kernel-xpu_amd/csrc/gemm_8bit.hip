@@ -444,16 +444,20 @@ __device__ __forceinline__ void gemm_8bit_persist_phase(
     const float* __restrict__ sa, const float* __restrict__ sb, const OutT* __restrict__ bias, int M, int N, int K,
     int64_t lda, int64_t ldb, int64_t ldc, int64_t sa_sm, int64_t sa_sk, int64_t sb_sk, int64_t sb_sn, int tiles_m,
     int tiles_n, int all_halves, uint32_t* __restrict__ stamps, const void* __restrict__ x0,
-    const void* __restrict__ x1) {
+    const void* __restrict__ x1, int ksplit = 1, int64_t slab = 0) {
   constexpr bool kBW = MODE == MODE_BLOCKWISE;
   constexpr bool kW4 = MODE == MODE_W4A8_CHN || MODE == MODE_W4A8_GRP, kGrp = MODE == MODE_W4A8_GRP;
+  // K slices (row / column scale modes, OutT = float as a 4-byte carrier; see launch()): unit = tile x slice, slice s multiplies K
+  // blocks [s nkb, (s + 1) nkb) and stores its RAW accumulators (fp32, or int32 bits for int8) into slab s of `out`; the sum kernel
+  // adds the slabs and applies scales and bias in the epilogue's order (int8: bit-identical to the unsplit result).
+  constexpr bool kRaw = sizeof(OutT) == 4 && !kBW && !kW4;
   constexpr bool kI8 = MODE == MODE_INT8_ROWCOL || kW4;
   using AccT = typename std::conditional<kI8, v4i, v4f>::type;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int nkb = K / BK;  // >= 2
+  const int nkb = kRaw ? K / BK / ksplit : K / BK;  // >= 2
   constexpr bool kDma = PROBE == 0 || PROBE >= 3, kStore = PROBE == 0 || PROBE == 1 || PROBE >= 5;
   // schedule experiments with correct results (diagnostic build): 6 = all LDS-DMA issued by waves 0..3 (the older wave of
   // each SIMD, which wins the issue arbitration and otherwise waits ~900 cycles per K block at the barrier for the
@@ -468,7 +472,7 @@ __device__ __forceinline__ void gemm_8bit_persist_phase(
 
   // ---- this workgroup's tiles: workgroups b, b+8, ... share an XCD; each XCD owns a contiguous run of tiles,
   // walked in groups of 4 m-tiles so that the 32 tiles in flight on an XCD share a and b panels in its L2
-  const int nt = tiles_m * tiles_n;
+  const int nt = tiles_m * tiles_n * (kRaw ? ksplit : 1);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int q = nt >> 3, rem = nt & 7;
   const int run_first = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
@@ -497,7 +501,9 @@ __device__ __forceinline__ void gemm_8bit_persist_phase(
     const int ht = slot + unit * slots;  // half-tile index in the all_halves walk
     const int local = !live ? 0 : (half && all_halves) ? (ht >> 1) : half ? rounds * slots + (slot >> 1) : slot + unit * slots;
     const int lower = all_halves ? (ht & 1) : (slot & 1);
-    const int tile = run_first + local;
+    const int tile_s = run_first + local;
+    const int tile = kRaw ? tile_s / ksplit : tile_s;
+    const int kb0 = kRaw ? (tile_s - tile * ksplit) * nkb : 0;  // the slice's first K block
     constexpr int GM = 4;
     const int group = tile / (GM * tiles_n);
     const int first_m = group * GM;
@@ -513,12 +519,13 @@ __device__ __forceinline__ void gemm_8bit_persist_phase(
     d.wrows = MS * 16;
     d.m0 = m0;
     d.n0 = n0;
-    d.pa = a + (int64_t)m0 * lda;
-    d.pb = kW4 ? b + (int64_t)n0 * (K >> 1) : b + (int64_t)n0 * ldb;  // (W4: 32-column groups of K/32 512-byte blocks)
+    d.pa = a + (int64_t)m0 * lda + kb0 * BK;
+    d.pb = kW4 ? b + (int64_t)n0 * (K >> 1) : b + (int64_t)n0 * ldb + kb0 * BK;  // (W4: 32-column groups of K/32 512-byte blocks)
     d.ps = kBW ? sa + (int64_t)m0 * sa_sm : sa;
-    d.po = (void*)(out + (int64_t)m0 * ldc + n0);
-    d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * lda + K) : 0u;
-    d.nrec_b = !live ? 0u : kW4 ? (uint32_t)((int64_t)(rows_b >> 5) * (K >> 5) * 512) : (uint32_t)((int64_t)(rows_b - 1) * ldb + K);
+    d.po = (void*)(out + (kRaw ? (int64_t)(kb0 / nkb) * slab : 0) + (int64_t)m0 * ldc + n0);
+    const int kdepth = kRaw ? nkb * BK : K;
+    d.nrec_a = live ? (uint32_t)((int64_t)(rows_a - 1) * lda + kdepth) : 0u;
+    d.nrec_b = !live ? 0u : kW4 ? (uint32_t)((int64_t)(rows_b >> 5) * (K >> 5) * 512) : (uint32_t)((int64_t)(rows_b - 1) * ldb + kdepth);
     // row scales: waves 0..3 fetch 64 rows each (4 B per lane); waves 4..7 fetch nothing (zeros into the spare KiB)
     d.nrec_s = (kBW && live && wave < 4) ? (uint32_t)(((int64_t)(rows_a - 1) * sa_sm + (int64_t)(nkb - 1) * sa_sk + 1) * 4) : 0u;
     d.nrec_o = (live && kStore) ? (uint32_t)(((int64_t)(rows_a - 1) * ldc + rows_b) * (int64_t)sizeof(OutT)) : 0u;
@@ -679,6 +686,19 @@ __device__ __forceinline__ void gemm_8bit_persist_phase(
       }
       return;
     }
+    if constexpr (kRaw) {  // the lane's 8 accumulators of a fragment pair as they are: two 16-byte stores
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t vo = (wn * 64 + h * 32 + g * 8 < d.ncols) ? orow_off + h * 32 * 4u : 0x80000000u;
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          const auto a4 = accm[2 * h + q2];
+          const v4i data = __builtin_bit_cast(v4i, a4);
+          __builtin_amdgcn_raw_buffer_store_b128(data, ro, (int)vo + q2 * 16, soff, 0);
+          asm volatile("s_nop 4" ::"v"(data));
+        }
+      }
+    } else {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       Vec<OutT, 8> v;
@@ -705,6 +725,7 @@ __device__ __forceinline__ void gemm_8bit_persist_phase(
       // a scalar offset register has no such hazard and lets the next VALU op overwrite the registers (seen:
       // dword 1 of lanes 12-15 of each row corrupted). Keep them alive across a short nop.
       asm volatile("s_nop 4" ::"v"(data));
+    }
     }
   };
 
@@ -1980,6 +2001,84 @@ __global__ __launch_bounds__(256) void gemm_splitk_sum_kernel(OutT* __restrict__
   store_vec<OutT, 8>(out + m * ldc + c, v);
 }
 
+// fp8_scaled_mm / int8_scaled_mm with K slices: the half-tile phase of the persistent pipeline over tile x slice units, raw
+// accumulators into slabs; then the sum with the epilogue (row scale, column scale, bias in the tile kernel's rounding order).
+template <int MODE, bool HW_SCALE>
+__global__ __launch_bounds__(512) void gemm_8bit_slices_kernel(float* __restrict__ ws, const uint8_t* __restrict__ a,
+                                                               const uint8_t* __restrict__ b, const float* __restrict__ sa,
+                                                               const float* __restrict__ sb, int M, int N, int K, int64_t lda,
+                                                               int64_t ldb, int tiles_m, int tiles_n, int ksplit, int64_t slab) {
+  __shared__ __attribute__((aligned(256))) char smem[kStages * kStageBytes];
+  gemm_8bit_persist_phase<float, MODE, HW_SCALE, 0, 4>(smem, ws, a, b, sa, sb, nullptr, M, N, K, lda, ldb, /*ldc=*/N, 0, 0, 0, 0,
+                                                       tiles_m, tiles_n, 1, nullptr, nullptr, nullptr, ksplit, slab);
+}
+
+template <typename OutT, int MODE>
+__global__ __launch_bounds__(256) void gemm_rowcol_slices_sum_kernel(OutT* __restrict__ out, const float* __restrict__ ws,
+                                                                     const float* __restrict__ sa, const float* __restrict__ sb,
+                                                                     const OutT* __restrict__ bias, int64_t M, int64_t N,
+                                                                     int64_t ldc, int slices) {
+  const int64_t n8 = N >> 3, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * n8) return;
+  const int64_t m = i / n8, c = (i - m * n8) << 3;
+  float acc[8];
+  if constexpr (MODE == MODE_INT8_ROWCOL) {
+    const int* p = reinterpret_cast<const int*>(ws) + m * N + c;
+    int t[8];
+    const v4i a0 = *reinterpret_cast<const v4i*>(p), a1 = *reinterpret_cast<const v4i*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[j] = a0[j]; t[4 + j] = a1[j]; }
+    for (int s = 1; s < slices; ++s) {
+      const v4i b0 = *reinterpret_cast<const v4i*>(p + (int64_t)s * M * N), b1 = *reinterpret_cast<const v4i*>(p + (int64_t)s * M * N + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { t[j] += b0[j]; t[4 + j] += b1[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (float)t[j];
+  } else {
+    const float* p = ws + m * N + c;
+    const v4f a0 = *reinterpret_cast<const v4f*>(p), a1 = *reinterpret_cast<const v4f*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j] = a0[j]; acc[4 + j] = a1[j]; }
+    for (int s = 1; s < slices; ++s) {
+      const v4f b0 = *reinterpret_cast<const v4f*>(p + (int64_t)s * M * N), b1 = *reinterpret_cast<const v4f*>(p + (int64_t)s * M * N + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] += b0[j]; acc[4 + j] += b1[j]; }
+    }
+  }
+  const float rs = sa[m];
+  Vec<OutT, 8> v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float t = (acc[j] * rs) * sb[c + j];  // (the tile kernel's / the oracle's rounding order)
+    if constexpr (MODE == MODE_FP8_ROWCOL) {
+      v[j] = (OutT)t;
+      if (bias != nullptr) v[j] = (OutT)((float)v[j] + (float)bias[c + j]);
+    } else {
+      v[j] = (bias != nullptr) ? (OutT)(t + (float)bias[c + j]) : (OutT)t;
+    }
+  }
+  store_vec<OutT, 8>(out + m * ldc + c, v);
+}
+
+// slices of the row / column scale modes (lease zw: N = 4096, K = 14336 28 us up to 128 rows on the weight stream, then 40 / 70 /
+// 117 us at 129 / 257 / 513 rows - the block-scale mode's cliff before its slices)
+static int rowcol_splitk_slices(int64_t M, int64_t N, int64_t K) {
+  if (g_gemm_splitk == 0 || g_gemm_variant != 4) return 0;
+  if (M <= 128 || M > 1024 || N % 8 != 0 || K % BK != 0) return 0;
+  // (lease zx, forced slice counts on one box, fp8 / int8 alike: N = 4096, K = 14336 8 slices 33 - 37 us at 129 .. 256 rows against 41,
+  //  4 slices 49 / 54 at 384 / 512 against 70, 2 slices 79 / 86 at 768 / 1024 against 117; N = 14336, K = 4096 2 slices 35 / 39 at 129 / 192
+  //  against 41; a small weight matrix stays on the weight stream - N = K = 4096 15 us up to 256 rows against 23 - 26 sliced, N = 6144
+  //  even)
+  if (g_gemm_splitk < 0 && N * K <= (32ll << 20)) return 0;
+  const int64_t units = 2 * cdiv(M, 256) * cdiv(N, 256), nkb = K / BK;
+  for (int s = 8; s >= 2; s >>= 1) {
+    if (g_gemm_splitk > 0 && s != g_gemm_splitk) continue;
+    if (nkb % s == 0 && nkb / s >= (g_gemm_splitk > 0 ? 2 : 8) && units * s <= num_cus()) return s;
+  }
+  return 0;
+}
+
 template <typename OutT, int MODE>
 static int launch(hipStream_t st, void* out, const void* a, const void* b, const float* sa, const float* sb,
                   const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
@@ -2015,6 +2114,23 @@ static int launch(hipStream_t st, void* out, const void* a, const void* b, const
       if (int rc = check_launch("gemm_8bit(k slices)")) return rc;
       const int64_t n = M * (N >> 3);
       gemm_splitk_sum_kernel<OutT><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((OutT*)out, (const float*)ws, M, N, ldc, S);
+      return check_launch("gemm_8bit(k slices: sum)");
+    }
+  }
+  if constexpr (MODE == MODE_FP8_ROWCOL || MODE == MODE_INT8_ROWCOL) {
+    const int S = ws != nullptr ? rowcol_splitk_slices(M, N, K) : 0;
+    if (S > 0 && persist_ok && ws_bytes >= (int64_t)S * M * N * 4 && (uintptr_t)ws % 16 == 0 && M * N * 4 < (1ll << 32)) {
+      const unsigned units = 2 * grid * (unsigned)S;
+      const unsigned sgrid = units < (unsigned)num_cus() ? ((units + 7) / 8) * 8 : (unsigned)num_cus();
+      SGLK_HW(hw_scale,
+              (gemm_8bit_slices_kernel<MODE, true><<<sgrid, 512, 0, st>>>((float*)ws, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M,
+                                                                          (int)N, (int)K, lda, ldb, tiles_m, tiles_n, S, M * N)),
+              (gemm_8bit_slices_kernel<MODE, false><<<sgrid, 512, 0, st>>>((float*)ws, (const uint8_t*)a, (const uint8_t*)b, sa, sb, (int)M,
+                                                                           (int)N, (int)K, lda, ldb, tiles_m, tiles_n, S, M * N)))
+      if (int rc = check_launch("gemm_8bit(k slices)")) return rc;
+      const int64_t n = M * (N >> 3);
+      gemm_rowcol_slices_sum_kernel<OutT, MODE><<<(unsigned)cdiv(n, 256), 256, 0, st>>>((OutT*)out, (const float*)ws, sa, sb,
+                                                                                       (const OutT*)bias, M, N, ldc, S);
       return check_launch("gemm_8bit(k slices: sum)");
     }
   }
@@ -2278,6 +2394,35 @@ extern "C" int sglk_fp8_blockwise_scaled_mm_ws(sglk_stream_t stream, void* out, 
                                         sa_stride_k, sb_stride_k, sb_stride_n, g_fp8_hw_scale != 0, workspace, workspace_bytes);
   return launch<f16, MODE_BLOCKWISE>(st, out, a, b, sa, sb, nullptr, M, N, K, lda, ldb, ldc, sa_stride_m,
                                      sa_stride_k, sb_stride_k, sb_stride_n, g_fp8_hw_scale != 0, workspace, workspace_bytes);
+}
+
+extern "C" int64_t sglk_scaled_mm_workspace_size(int64_t M, int64_t N, int64_t K) {
+  using namespace sglk;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (int64_t)rowcol_splitk_slices(M, N, K) * M * N * 4;
+}
+
+extern "C" int sglk_scaled_mm_ws(sglk_stream_t stream, void* out, const void* a, const void* b, const float* sa,
+                                 const float* sb, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                 int64_t ldb, int64_t ldc, int in_dtype, int out_dtype, void* workspace,
+                                 int64_t workspace_bytes) {
+  using namespace sglk;
+  const char* op = in_dtype == SGLK_INT8 ? "int8_scaled_mm" : "fp8_scaled_mm";
+  SGLK_REQUIRE(in_dtype == SGLK_INT8 || in_dtype == SGLK_FP8_E4M3, "scaled_mm: inputs must be Int8 or Float8_e4m3fn");
+  if (int rc = check_common(op, a, b, M, N, K, lda, ldb, out_dtype)) return rc;
+  if (M == 0) return SGLK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool hw = g_fp8_hw_scale != 0;
+  void* w = workspace;
+  const int64_t wb = workspace_bytes;
+  if (in_dtype == SGLK_INT8) {
+    if (out_dtype == SGLK_BF16)
+      return launch<bf16, MODE_INT8_ROWCOL>(st, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, hw, w, wb);
+    return launch<f16, MODE_INT8_ROWCOL>(st, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, hw, w, wb);
+  }
+  if (out_dtype == SGLK_BF16)
+    return launch<bf16, MODE_FP8_ROWCOL>(st, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, hw, w, wb);
+  return launch<f16, MODE_FP8_ROWCOL>(st, out, a, b, sa, sb, bias, M, N, K, lda, ldb, ldc, 0, 0, 0, 0, hw, w, wb);
 }
 
 extern "C" int sglk_scaled_mm(sglk_stream_t stream, void* out, const void* a, const void* b, const float* sa,

@@ -49,6 +49,7 @@ __device__ __forceinline__ void better(float& v, int& i, float ov, int oi) {
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void gate_kernel(GateParams p) {
   __shared__ float s_score[4][kMaxE];
+  __shared__ float s_choice[MODE == GATE_GROUPED ? 4 : 1][MODE == GATE_GROUPED ? kMaxE : 1];  // score + bias (the group scan's operand)
   __shared__ float s_group[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void gate_kernel(GateParams p) {
       if (p.bias != nullptr) b = p.bias_is_f32 ? reinterpret_cast<const float*>(p.bias)[e] : (float)reinterpret_cast<const T*>(p.bias)[e];
       c = s + b;
       sc[e] = s;
+      if constexpr (MODE == GATE_GROUPED) s_choice[wave][e] = c;
     }
     score[i] = s;
     choice[i] = c;
@@ -96,15 +98,13 @@ __global__ __launch_bounds__(256) void gate_kernel(GateParams p) {
     const int G = p.groups, gs = E / G;
     float* sg = s_group[wave];
     __builtin_amdgcn_wave_barrier();
-    // (choice values of other lanes' experts: recompute from LDS score + bias)
     float gscore = -INFINITY;
     if (lane < G) {
       float m1 = -INFINITY, m2 = -INFINITY;
+      // (the biased scores from LDS: this loop used to fetch its gs bias values from global memory one after the other - most of
+      //  the op's 15 us at decode)
       for (int j = 0; j < gs; ++j) {
-        const int e = lane * gs + j;
-        float b = 0.f;
-        if (p.bias != nullptr) b = p.bias_is_f32 ? reinterpret_cast<const float*>(p.bias)[e] : (float)reinterpret_cast<const T*>(p.bias)[e];
-        const float c = sc[e] + b;
+        const float c = s_choice[wave][lane * gs + j];
         if (c > m1) { m2 = m1; m1 = c; } else if (c > m2) { m2 = c; }
       }
       gscore = p.scoring == SCORE_SOFTMAX ? m1 : m1 + m2;

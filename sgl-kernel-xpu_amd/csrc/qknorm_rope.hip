@@ -28,6 +28,7 @@ struct RopeParams {
   const void* positions;
   int pos_is_i64;
   int rope_dim;
+  int cs_vec;  // the cached angles of a 16-byte chunk can be read as 16-byte loads (set by launch_all)
   float eps;
   // analytic mode
   float log2_base, factor, low, high, attention_factor;
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ q, T* 
   const int heads = Hq + Hk;
   const bool live = row < tokens * heads;
   const int64_t rr = live ? row : 0;
-  const int64_t tok = rr / heads;
+  // (a 64-bit division is ~100 vector instructions per thread - more than the rest of the kernel; the row count fits 32 bits in
+  //  every call a server makes)
+  const int64_t tok = (tokens * heads < (1ll << 32)) ? (int64_t)((uint32_t)rr / (uint32_t)heads) : rr / heads;
   const int head = (int)(rr - tok * heads);
   const bool is_q = head < Hq;
   T* base = is_q ? q + tok * q_ts + (int64_t)head * q_hs : k + tok * k_ts + (int64_t)(head - Hq) * k_hs;
@@ -111,8 +114,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ q, T* 
   auto angle = [&](int half_idx, float& c, float& s) {
     if constexpr (ANALYTIC) {
       const float theta = (float)pos * yarn_freq(p.log2_base, rope, half_idx, p.factor, p.low, p.high);
-      c = cosf(theta);
-      s = sinf(theta);
+      sincosf(theta, &s, &c);  // (one range reduction for both)
     } else {
       const float* row_cs = p.cos_sin_cache + pos * rope;
       c = row_cs[half_idx];
@@ -120,6 +122,27 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ q, T* 
     }
   };
   float out[8];
+  // cached angles of a chunk as 16-byte loads where the layout allows (8 | half, the cache 16-byte aligned: cv / sv = cos / sin of the
+  // chunk's eight (NeoX) or four (interleaved) frequencies)
+  float cv[8], sv[8];
+  bool vec_cs = false;
+  if constexpr (!ANALYTIC) {
+    vec_cs = p.cs_vec != 0 && d0 < rope;
+    if (vec_cs) {
+      const float* row_cs = p.cos_sin_cache + pos * rope;
+      if constexpr (NEOX) {
+        const int h0 = d0 < half ? d0 : d0 - half;
+        const float4 c0 = *reinterpret_cast<const float4*>(row_cs + h0), c1 = *reinterpret_cast<const float4*>(row_cs + h0 + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(row_cs + half + h0), s1 = *reinterpret_cast<const float4*>(row_cs + half + h0 + 4);
+        cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
+        sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w; sv[4] = s1.x; sv[5] = s1.y; sv[6] = s1.z; sv[7] = s1.w;
+      } else {
+        const float4 c0 = *reinterpret_cast<const float4*>(row_cs + (d0 >> 1)), s0 = *reinterpret_cast<const float4*>(row_cs + half + (d0 >> 1));
+        cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w;
+        sv[0] = s0.x; sv[1] = s0.y; sv[2] = s0.z; sv[3] = s0.w;
+      }
+    }
+  }
   if constexpr (NEOX) {
     // partner values: y[p] = x_raw[p] * (rms * w[p]); whole 16-byte chunks when the halves are chunk aligned
     float y2[8];
@@ -146,7 +169,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ q, T* 
       const int d = d0 + i;
       if (d < rope) {
         float c, s;
-        angle(d < half ? d : d - half, c, s);
+        if (vec_cs) { c = cv[i]; s = sv[i]; } else angle(d < half ? d : d - half, c, s);
         float r = x[i] * c + (d < half ? -y2[i] : y2[i]) * s;
         if constexpr (ANALYTIC) r *= p.attention_factor;
         out[i] = r;
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ q, T* 
       const int d = d0 + i;
       if (d < rope) {
         float c, s;
-        angle(d >> 1, c, s);
+        if (vec_cs) { c = cv[i >> 1]; s = sv[i >> 1]; } else angle(d >> 1, c, s);
         float re = x[i] * c - x[i + 1] * s, im = x[i] * s + x[i + 1] * c;
         if constexpr (ANALYTIC) { re *= p.attention_factor; im *= p.attention_factor; }
         out[i] = re;
@@ -226,6 +249,7 @@ extern "C" int sglk_fused_qknorm_rope_cache(sglk_stream_t stream, void* q, void*
   p.pos_is_i64 = positions_are_int64;
   p.rope_dim = (int)rope_dim;
   p.eps = eps;
+  p.cs_vec = (rope_dim % 16 == 0 && (uintptr_t)cos_sin_cache % 16 == 0) ? 1 : 0;
   return launch_all("fused_inplace_qknorm_rope", (hipStream_t)stream, q, k, q_weight, k_weight, p, tokens, num_q_heads,
                     num_k_heads, head_dim, q_token_stride, q_head_stride, k_token_stride, k_head_stride, is_neox != 0, false,
                     dtype);

@@ -312,10 +312,15 @@ Tensor scaled_mm_impl(const Tensor& mat_a, const Tensor& mat_b, const Tensor& sc
   Tensor out = at::empty({M, N}, mat_a.options().dtype(out_dtype));
   if (M == 0) return out;
   const c10::OptionalDeviceGuard guard(mat_a.device());
-  SGLK_CALL(sglk_scaled_mm(stream_of(mat_a), out.data_ptr(), mat_a.data_ptr(), mat_b.data_ptr(),
-                           scales_a.data_ptr<float>(), scales_b.data_ptr<float>(), bias_ptr, M, N, K,
-                           mat_a.stride(0), mat_b.stride(1), out.stride(0),
-                           is_int8 ? SGLK_INT8 : SGLK_FP8_E4M3, dtype_code(out_dtype, "out_dtype")));
+  // 129 .. 1024 rows over a deep K: K-slice units with raw accumulators in a scratch tensor (include/sglk.h; 0 bytes: not that shape)
+  const int64_t ws_bytes = sglk_scaled_mm_workspace_size(M, N, K);
+  Tensor ws;
+  if (ws_bytes > 0) ws = at::empty({ws_bytes}, mat_a.options().dtype(at::kByte));
+  SGLK_CALL(sglk_scaled_mm_ws(stream_of(mat_a), out.data_ptr(), mat_a.data_ptr(), mat_b.data_ptr(),
+                              scales_a.data_ptr<float>(), scales_b.data_ptr<float>(), bias_ptr, M, N, K,
+                              mat_a.stride(0), mat_b.stride(1), out.stride(0),
+                              is_int8 ? SGLK_INT8 : SGLK_FP8_E4M3, dtype_code(out_dtype, "out_dtype"),
+                              ws_bytes > 0 ? ws.data_ptr() : nullptr, ws_bytes));
   return out;
 }
 

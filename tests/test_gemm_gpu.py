@@ -250,6 +250,40 @@ def test_int8_scaled_mm(sglk, dev, M, N, K, with_bias, dtype):
 
 
 @pytest.mark.parametrize("kind", ["fp8", "int8"])
+@pytest.mark.parametrize("M", [129, 200, 256, 300, 512, 1000])
+@pytest.mark.parametrize("N,K", [(4096, 14336), (1024, 7168), (640, 4096), (2056, 12288)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_scaled_mm_k_slices(sglk, dev, kind, M, N, K, with_bias):
+    """129 .. 1024 rows over a deep K: tile x K-slice units with raw accumulators in a scratch tensor, summed and scaled by a second
+    kernel in the epilogue's order (8, 4 or 2 slices; ragged rows / columns) - every output element against the oracle; int8 as exact
+    as the unsplit path (integer sums), twice the same bits"""
+    dtype = torch.bfloat16 if (M + N) % 2 else torch.float16
+    g = torch.Generator().manual_seed(M + N + K)
+    if kind == "fp8":
+        a = ((torch.rand(M, K, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8)
+        b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * FMAX).clamp(-FMAX, FMAX).to(FP8).t()
+        sa, sb = torch.randn(M, generator=g) * 0.001, torch.randn(N, generator=g) * 0.001
+        bias = torch.randn(N, generator=g).to(dtype) if with_bias else None
+        run = lambda: sglk.fp8_scaled_mm(a.to(dev), to_dev_colmajor(b, dev), sa.to(dev), sb.to(dev), dtype,
+                                         bias.to(dev) if with_bias else None).cpu()
+        out = run()
+        ref = ogemm.fp8_scaled_mm(a, b, sa, sb, dtype, bias)
+        torch.testing.assert_close(out.float(), ref.float(), rtol=2e-2, atol=2e-2)
+    else:
+        a = torch.round((torch.randn(M, K, generator=g) * 5).clamp(-128, 127)).to(torch.int8)
+        b = torch.round((torch.randn(N, K, generator=g) * 5).clamp(-128, 127)).to(torch.int8).t()
+        sa, sb = torch.randn(M, generator=g), torch.randn(N, generator=g)
+        bias = (torch.randn(N, generator=g).to(dtype) * 10) if with_bias else None
+        run = lambda: sglk.int8_scaled_mm(a.to(dev), to_dev_colmajor(b, dev), sa.to(dev), sb.to(dev), dtype,
+                                          bias.to(dev) if with_bias else None).cpu()
+        out = run()
+        ref = ogemm.int8_scaled_mm(a, b, sa, sb, dtype, bias)
+        torch.testing.assert_close(out, ref)
+        assert (out != ref).float().mean() < 1e-3
+    assert torch.equal(out, run())
+
+
+@pytest.mark.parametrize("kind", ["fp8", "int8"])
 @pytest.mark.parametrize("M,N,K", [(4096, 14336, 4096), (2304, 7424, 1024), (1024, 4096, 14336), (640, 4104, 512)])
 def test_scaled_mm_full_size_sampled(sglk, dev, kind, M, N, K):
     """The persistent pipeline in the row / column scale modes at sizes the CPU oracle cannot cover whole: whole rounds

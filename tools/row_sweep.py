@@ -28,8 +28,12 @@ def timeit(f, it=20):
 
 what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
 if what == "gemm":
-    Ms = [1, 16, 64, 65, 96, 128, 129, 192, 256, 257, 384, 512, 513, 768, 1024, 2048]
-    for N, K in ((14336, 4096), (4096, 14336)):
+    if os.environ.get("GEMM_SPLITK"):  # diagnostic build only (LD_PRELOAD=.../build/libsglk_probes.so): forced slice count (0: never)
+        import ctypes
+        ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
+                    ).sglk_debug_set_gemm_splitk(int(os.environ["GEMM_SPLITK"]))
+    Ms = [int(m) for m in os.environ.get("GEMM_MS", "1,16,64,65,96,128,129,192,256,257,384,512,513,768,1024,2048").split(",")]
+    for N, K in ((14336, 4096), (4096, 14336), (4096, 4096), (6144, 4096)):
         g = torch.Generator().manual_seed(0)
         b = ((torch.rand(N, K, generator=g) - 0.5) * 2 * 448).to(FP8).to(dev).t()
         sb = (torch.rand(K // 128, N // 128, generator=g) + 0.5).to(dev)
