@@ -111,10 +111,34 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ q, T* 
   const int rope = p.rope_dim, half = rope >> 1;
   const int64_t pos = p.pos_is_i64 ? reinterpret_cast<const int64_t*>(p.positions)[tok]
                                    : (int64_t) reinterpret_cast<const int32_t*>(p.positions)[tok];
+  // analytic angles: the workgroup's rows belong to a few consecutive tokens (RW rows, heads per token), and every head of a token
+  // rotates by the same rope / 2 angles - one table per workgroup ((cos, sin) per token and frequency, at most RW * D / 2 = 1024
+  // entries) instead of eight sincos per thread (16384 tokens x 40 heads: 142 -> see NOTEBOOK round 5 (22))
+  __shared__ float2 s_cs[ANALYTIC ? 1024 : 1];
+  int64_t tok_first = 0;
+  if constexpr (ANALYTIC) {
+    const int64_t total = tokens * heads;
+    const int64_t r0 = (int64_t)blockIdx.x * RW, r1 = r0 + RW - 1 < total ? r0 + RW - 1 : total - 1;
+    const bool small = total < (1ll << 32);
+    tok_first = small ? (int64_t)((uint32_t)r0 / (uint32_t)heads) : r0 / heads;
+    const int64_t tok_last = small ? (int64_t)((uint32_t)r1 / (uint32_t)heads) : r1 / heads;
+    const int n = (int)(tok_last - tok_first + 1) * half;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int t = i / half, jf = i - t * half;
+      const int64_t pt = p.pos_is_i64 ? reinterpret_cast<const int64_t*>(p.positions)[tok_first + t]
+                                      : (int64_t) reinterpret_cast<const int32_t*>(p.positions)[tok_first + t];
+      const float theta = (float)pt * yarn_freq(p.log2_base, rope, jf, p.factor, p.low, p.high);
+      float sn, cs;
+      sincosf(theta, &sn, &cs);  // (one range reduction for both)
+      s_cs[i] = make_float2(cs, sn);
+    }
+    __syncthreads();
+  }
   auto angle = [&](int half_idx, float& c, float& s) {
     if constexpr (ANALYTIC) {
-      const float theta = (float)pos * yarn_freq(p.log2_base, rope, half_idx, p.factor, p.low, p.high);
-      sincosf(theta, &s, &c);  // (one range reduction for both)
+      const float2 v = s_cs[(int)(tok - tok_first) * half + half_idx];
+      c = v.x;
+      s = v.y;
     } else {
       const float* row_cs = p.cos_sin_cache + pos * rope;
       c = row_cs[half_idx];
