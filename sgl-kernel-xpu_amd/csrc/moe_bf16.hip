@@ -269,11 +269,17 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* w, c
                     int64_t total_m, int E, int N, int K, int64_t ldb, int64_t w_stride_e, int fuse) {
   // tile policy by average rows per expert, as the reference (GroupGemmXe20.cpp:226-274); tail mode: total_m is the worst case
   // that sizes the launch, the tails of routed experts are a few dozen rows
-  const int64_t avg = t_tail_flag ? std::min<int64_t>(total_m / E, 24) : total_m / E;
-  // (ragged counts: a tile that holds ~1.5x the average rows, a second row block of an expert streams its weights again)
-  if (avg <= 10) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
-  if (avg <= 24) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
-  if (avg <= 96) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  // (round 5, late - a token sweep with routed counts, Mixtral shapes, 16-bit weights: 554 us at 64 tokens, 721 at 96, 570 at 128; 606
+  //  at 192, 828 at 256. A second row block of an expert streams its weights again, and with an average of 24 rows on 32-row tiles
+  //  two or three of eight experts had one. The tile now holds the average plus three standard deviations of a routed count
+  //  (avg + 3 sqrt(avg)) up to 32 rows; the 128-row tile's eight-wave kernel streams slower (~750 us against ~560), so the 64-row tile
+  //  stays until about a quarter of the experts overflow it (average 60: 606 us at 192 tokens, 828 -> 759 at 256). A tail launch takes
+  //  the 64-row tile: one pass behind 128-row blocks, at most two behind 256-row blocks (the 32-row tile took up to four passes over
+  //  an expert's weights at 1536 tokens: 2018 us; the 128-row tile cost the short tails of 1024 tokens 180 us).)
+  const int64_t avg = t_tail_flag ? 43 : total_m / E;
+  if (avg <= 7) return launch<T, 1, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  if (avg <= 18) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  if (avg <= 60) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   // (eight waves share the staged activation tile, 128 x 256: half the activation traffic and barriers per flop)
   if (g_bf16_wv != 4) return launch<T, 8, 2, 8>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   return launch<T, 8, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);

@@ -233,3 +233,26 @@ if what == "gemmbw":
             sa = (torch.rand(M, K // 128, generator=g) + 0.5).to(dev)
             t1 = timeit(lambda: sgl_kernel.fp8_blockwise_scaled_mm(a, b, sa, sb, torch.bfloat16))
             print(f"N={N} K={K} M={M}: fp8 blockwise {t1:.1f} us  {2.0 * M * N * K / t1 / 1e6:.0f} TFLOP/s  weights {N * K / t1 / 1e6:.2f} TB/s")
+if what == "moe2":
+    # fused_experts with 16-bit and mxfp4 weights across the token counts where the 4-bit int path had its dispatch boundaries
+    E, Hd, I, topk = 8, 4096, 14336, 2
+    Ts = (1, 4, 16, 32, 48, 64, 96, 128, 192, 256, 383, 384, 512, 640, 768, 1024, 1536, 2048)
+    for fmt in ("bf16", "mxfp4"):
+        if fmt == "bf16":
+            w1 = (torch.randn(E, 2 * I, Hd, device=dev) * 0.02).to(torch.bfloat16)
+            w2 = (torch.randn(E, Hd, I, device=dev) * 0.02).to(torch.bfloat16)
+            kw = {}
+        else:
+            w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
+            w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
+            kw = dict(use_mxfp4_w4a16=True, w1_scale=torch.randint(118, 124, (E, 2 * I, Hd // 32), device=dev, dtype=torch.uint8),
+                      w2_scale=torch.randint(118, 124, (E, Hd, I // 32), device=dev, dtype=torch.uint8))
+        for T in Ts:
+            x = torch.randn(T, Hd, device=dev, dtype=torch.bfloat16) * 0.1
+            logits = torch.randn(T, E, device=dev, dtype=torch.bfloat16)
+            tw = torch.empty(T, topk, device=dev, dtype=torch.float32)
+            ti = torch.empty(T, topk, device=dev, dtype=torch.int32)
+            sgl_kernel.topk_softmax(tw, ti, logits, True)
+            t = timeit(lambda: sgl_kernel.fused_experts(x, w1, w2, tw, ti, **kw), it=10)
+            print(f"fused_experts {fmt} Mixtral T={T}: {t:.0f} us  ({t / T:.2f} us per token)  {2.0 * T * topk * 3 * Hd * I / t / 1e6:.0f} TFLOP/s")
+        del w1, w2
