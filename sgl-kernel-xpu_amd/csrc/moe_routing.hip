@@ -87,7 +87,47 @@ __global__ __launch_bounds__(256) void topk_softmax_kernel(float* __restrict__ w
 }
 
 // ------------------------------------------------------------------------------- moe_align_block_size
+// Counting of a prefill-sized id list by many workgroups (one workgroup takes ~1 us per 1024 ids: 131072 ids - 16384 tokens, top-8 -
+// were 90 - 127 us): LDS counters per workgroup, flushed into `cumsum` (zeroed by the caller), which moe_align_kernel<PRE> then reads.
 template <typename IdT>
+__global__ __launch_bounds__(1024) void moe_align_count_kernel(const IdT* __restrict__ topk_ids, int32_t* cumsum, int num_experts,
+                                                               int64_t numel) {
+  extern __shared__ int32_t sh[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < num_experts; i += 1024) sh[i] = 0;
+  __syncthreads();
+  const bool aggregate = num_experts <= 32;
+  for (int64_t i0 = (int64_t)blockIdx.x * 8 * 1024; i0 < numel; i0 += (int64_t)gridDim.x * 8 * 1024) {
+    int bs[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t i = i0 + r * 1024 + tid;
+      const int b = i < numel ? (int)topk_ids[i] + 1 : -1;
+      bs[r] = b < num_experts ? b : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int b = bs[r];
+      if (!aggregate) {
+        if (b >= 0) atomicAdd(&sh[b], 1);
+        continue;
+      }
+      unsigned long long todo = __ballot(b >= 0);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int b0 = __shfl(b, leader, 64);
+        const unsigned long long same = __ballot(b == b0);
+        if ((tid & 63) == leader) atomicAdd(&sh[b0], __builtin_popcountll(same));
+        todo &= ~same;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < num_experts; i += 1024)
+    if (sh[i]) atomicAdd(&cumsum[i], sh[i]);
+}
+
+template <typename IdT, bool PRE = false>  // PRE: the bucket counts are in cumsum[0 .. num_experts) (moe_align_count_kernel)
 __global__ __launch_bounds__(1024) void moe_align_kernel(const IdT* __restrict__ topk_ids, int32_t* sorted_token_ids,
                                                          int32_t* expert_ids, int32_t* total_tokens_post_pad,
                                                          int32_t* cumsum, int num_experts, int block_size,
@@ -96,14 +136,15 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const IdT* __restrict__
   int32_t* counts = sh;
   int32_t* prefix = sh + num_experts;
   const int tid = threadIdx.x;
-  for (int i = tid; i < num_experts; i += 1024) counts[i] = 0;
+  for (int i = tid; i < num_experts; i += 1024) counts[i] = PRE ? cumsum[i] : 0;
   __syncthreads();
+
   // Counting. Eight ids per thread are requested before any is used (one memory round trip per 8192 ids instead of one per
   // 1024: the single workgroup is latency-bound). With few buckets (a top-2-of-8 routing puts 8192 ids on 9 counters)
   // the lanes of a wave that hit the same bucket send ONE atomic; with many buckets plain atomics collide rarely and the
   // aggregation loop (one trip per distinct bucket of the wave) would cost more than it saves.
   const bool aggregate = num_experts <= 32;
-  for (int64_t i0 = 0; i0 < numel; i0 += 8 * 1024) {
+  for (int64_t i0 = 0; i0 < (PRE ? 0 : numel); i0 += 8 * 1024) {
     int bs[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -353,13 +394,55 @@ __global__ __launch_bounds__(256) void shuffle_mul_sum_splitk_kernel(const T* __
   }
 }
 
+// Prefill-sized lists: a workgroup ranks its 8192 ids per bucket with returning LDS atomics and reserves one run per bucket with
+// ONE global atomic (131072 ids on 128 buckets were 131072 returning global atomics on 128 addresses - most of the op's time).
+template <typename IdT>
+__global__ __launch_bounds__(1024) void moe_align_sort_chunk_kernel(const IdT* __restrict__ topk_ids, int32_t* sorted_token_ids,
+                                                                    int32_t* cumsum, int num_experts, int64_t numel) {
+  extern __shared__ int32_t sh[];  // cnt[num_experts], base[num_experts]
+  int32_t* cnt = sh;
+  int32_t* base = sh + num_experts;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < num_experts; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * 8 * 1024;
+  int bs[8], rk[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = i0 + r * 1024 + tid;
+    const int b = i < numel ? (int)topk_ids[i] + 1 : -1;
+    bs[r] = b < num_experts ? b : -1;
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) rk[r] = bs[r] >= 0 ? atomicAdd(&cnt[bs[r]], 1) : 0;
+  __syncthreads();
+  for (int i = tid; i < num_experts; i += 1024) base[i] = cnt[i] ? atomicAdd(&cumsum[i], cnt[i]) : 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (bs[r] >= 0) sorted_token_ids[base[bs[r]] + rk[r]] = (int32_t)(i0 + r * 1024 + tid);
+}
+
 template <typename IdT>
 static int align_launch(hipStream_t st, const void* ids, int32_t* sorted, int32_t* eids, int32_t* total,
                         int32_t* cumsum, int num_experts, int block_size, int64_t numel, bool pad) {
   const size_t lds = (size_t)(2 * num_experts + 1) * sizeof(int32_t);
-  moe_align_kernel<IdT><<<1, 1024, lds, st>>>((const IdT*)ids, sorted, eids, total, cumsum, num_experts, block_size,
-                                               numel, pad);
+  if (numel >= 16384) {  // prefill-sized: count on many CUs (three more launch slots, ~100 us less at 131072 ids)
+    if (hipMemsetAsync(cumsum, 0, (size_t)num_experts * sizeof(int32_t), st) != hipSuccess) return check_launch("moe_align_block_size(zero)");
+    const int64_t wgs = cdiv(numel, 8 * 1024);
+    moe_align_count_kernel<IdT><<<(unsigned)(wgs < 256 ? wgs : 256), 1024, (size_t)num_experts * sizeof(int32_t), st>>>(
+        (const IdT*)ids, cumsum, num_experts, numel);
+    if (int rc = check_launch("moe_align_block_size(count)")) return rc;
+    moe_align_kernel<IdT, true><<<1, 1024, lds, st>>>((const IdT*)ids, sorted, eids, total, cumsum, num_experts, block_size, numel, pad);
+  } else {
+    moe_align_kernel<IdT><<<1, 1024, lds, st>>>((const IdT*)ids, sorted, eids, total, cumsum, num_experts, block_size, numel, pad);
+  }
   if (int rc = check_launch("moe_align_block_size")) return rc;
+  if (numel >= 16384 && cdiv(numel, 8 * 1024) < (1ll << 31)) {
+    moe_align_sort_chunk_kernel<IdT><<<(unsigned)cdiv(numel, 8 * 1024), 1024, (size_t)2 * num_experts * sizeof(int32_t), st>>>(
+        (const IdT*)ids, sorted, cumsum, num_experts, numel);
+    return check_launch("moe_align_block_size(sort)");
+  }
   if (numel > 0) {
     const int64_t want = cdiv(numel, 256);
     moe_align_sort_kernel<IdT><<<(unsigned)(want < 1024 ? want : 1024), 256, 0, st>>>((const IdT*)ids, sorted, cumsum,
