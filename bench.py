@@ -339,6 +339,24 @@ def side_metrics(sgl_kernel, dev):
             sb1 = torch.rand(N, 1, device=dev) * 1e-3 + 1e-4
             ms = timeit(lambda: sgl_kernel.fp8_scaled_mm(am, bw, sa1, sb1, torch.bfloat16), iters=50)
             out[f"fp8_scaled_mm_M{m}_us"] = round(ms * 1e3, 1)
+    # the down projection of the same layer (N = 4096, K = 14336) at decode-batch .. chunk rows: K-slice units since round 5
+    # (50 - 96 us unsliced for the block-scale mode, 41 - 117 for the row / column scale modes)
+    bwd = ((torch.rand(K, N, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev).t()  # [N -> K rows of 14336] as [14336, 4096]^T
+    sbd = (torch.rand(K // 128, N // 128, generator=g) * 1e-3 + 1e-4).to(dev).t()
+    bid = torch.randint(-127, 128, (K, N), generator=g, dtype=torch.int8).to(dev).t()
+    sbcol = torch.rand(K, 1, device=dev) * 1e-3 + 1e-4
+    for m in (128, 256, 512, 1024):
+        amd = ((torch.rand(m, N, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev)
+        samd = (torch.rand(N // 128, m, generator=g) * 1e-3 + 1e-4).to(dev).t()
+        ms = timeit(lambda: sgl_kernel.fp8_blockwise_scaled_mm(amd, bwd, samd, sbd, torch.bfloat16), iters=30)
+        out[f"fp8_blockwise_gemm_down_N4096_K14336_M{m}_us"] = round(ms * 1e3, 1)
+        sarow = torch.rand(m, 1, device=dev) * 1e-3 + 1e-4
+        ms = timeit(lambda: sgl_kernel.fp8_scaled_mm(amd, bwd, sarow, sbcol, torch.bfloat16), iters=30)
+        out[f"fp8_scaled_mm_down_N4096_K14336_M{m}_us"] = round(ms * 1e3, 1)
+        aid = torch.randint(-127, 128, (m, N), generator=g, dtype=torch.int8).to(dev)
+        ms = timeit(lambda: sgl_kernel.int8_scaled_mm(aid, bid, sarow, sbcol, torch.bfloat16), iters=30)
+        out[f"int8_scaled_mm_down_N4096_K14336_M{m}_us"] = round(ms * 1e3, 1)
+    del bwd, bid
     # fp8_scaled_mm / int8_scaled_mm at the headline shape (row x column scales: the persistent pipeline without block scales)
     am = ((torch.rand(M, K, generator=g) - 0.5) * 2 * 448).clamp(-448, 448).to(FP8).to(dev)
     sa1 = torch.rand(M, 1, device=dev) * 1e-3 + 1e-4
@@ -511,8 +529,46 @@ def side_metrics(sgl_kernel, dev):
             ((kcd.numel() + vcd.numel()) * kcd.element_size() + 2 * qdd.numel() * 2) / ms / 1e6, 1)
         out[f"fwd_decode_bs16_h32_kv8_{tag}_seq4096_ms"] = round(ms, 4)
         del kcd, vcd
+    # a chunk of ONE long sequence (128 queries over 32768 keys): KV splits in the 128-row-block kernel since round 5 (654 us unsplit)
+    ctx = 32768
+    kcl = torch.randn(ctx // page, page, hk, d, device=dev, dtype=torch.bfloat16)
+    vcl = torch.randn(ctx // page, page, hk, d, device=dev, dtype=torch.bfloat16)
+    ptl = torch.randperm(ctx // page, device=dev).to(torch.int32).view(1, ctx // page)
+    ql = torch.randn(128, hq, d, device=dev, dtype=torch.bfloat16)
+    lens1 = torch.full((1,), ctx, device=dev, dtype=torch.int32)
+    cu1 = torch.tensor([0, 128], device=dev, dtype=torch.int32)
+    ms = timeit(lambda: flash_attn_with_kvcache(ql, kcl, vcl, cache_seqlens=lens1, page_table=ptl, cu_seqlens_q=cu1,
+                                                max_seqlen_q=128, causal=True), iters=10)
+    out["fwd_chunk_prefill_bs1_q128_ctx32768_us"] = round(ms * 1e3, 1)
+    del kcl, vcl
+    # sampling at a Llama-3 vocabulary (reference benchmark: none; tests/test_sampling.py sizes), decode batch sizes
+    for sb_ in (1, 64):
+        probs = torch.softmax(torch.randn(sb_, 128256, device=dev), dim=-1)
+        kk = torch.full((sb_,), 50, device=dev, dtype=torch.int32)
+        pp = torch.full((sb_,), 0.9, device=dev, dtype=torch.float32)
+        ms = timeit(lambda: sgl_kernel.top_k_renorm_prob(probs, kk), iters=10)
+        out[f"top_k_renorm_probs_bs{sb_}_vocab128256_us"] = round(ms * 1e3, 1)
+        ms = timeit(lambda: sgl_kernel.top_k_top_p_sampling_from_probs(probs, kk, pp), iters=10)
+        out[f"top_k_top_p_sampling_bs{sb_}_vocab128256_us"] = round(ms * 1e3, 1)
+        ms = timeit(lambda: sgl_kernel.top_k_top_p_sampling_from_probs(probs, kk, pp, filter_apply_order="joint"), iters=10)
+        out[f"top_k_top_p_sampling_joint_bs{sb_}_vocab128256_us"] = round(ms * 1e3, 1)
+        ms = timeit(lambda: sgl_kernel.min_p_sampling_from_probs(probs, pp * 0.1), iters=10)
+        out[f"min_p_sampling_bs{sb_}_vocab128256_us"] = round(ms * 1e3, 1)
+    # qk-norm + rope over a 4096-token chunk (32 + 8 heads of 128): cached angles / computed angles
+    from sgl_kernel import elementwise as _ew
+    q3 = torch.randn(4096, hq, d, device=dev, dtype=torch.bfloat16)
+    k3 = torch.randn(4096, hk, d, device=dev, dtype=torch.bfloat16)
+    wn = torch.ones(d, device=dev, dtype=torch.bfloat16)
+    cs32 = torch.randn(8192, d, device=dev, dtype=torch.float32)
+    posi = torch.randint(0, 8192, (4096,), device=dev)
+    ms = timeit(lambda: _ew.fused_inplace_qknorm_rope(q3, k3, wn, wn, cs32, posi, True), iters=30)
+    out["fused_inplace_qknorm_rope_T4096_h32_kv8_d128_GBs"] = round(2.0 * (q3.numel() + k3.numel()) * 2 / ms / 1e6, 1)
+    qkv = torch.randn(4096, (hq + 2 * hk) * d, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: _ew.fused_qk_norm_rope(qkv, hq, hk, hk, d, 1e-6, wn, wn, 10000.0, True, posi.int()), iters=30)
+    out["fused_qk_norm_rope_T4096_h32_kv8_d128_GBs"] = round(2.0 * (q3.numel() + k3.numel()) * 2 / ms / 1e6, 1)
+    del q3, k3, qkv
     # MoE routing latencies (reference benchmark/bench_moe_align_block_size.py, bench_moe_topk_softmax.py)
-    for toks, ne, tk in ((4096, 8, 2), (4096, 256, 8)):
+    for toks, ne, tk in ((4096, 8, 2), (4096, 256, 8), (16384, 256, 8)):
         logits = torch.randn(toks, ne, device=dev, dtype=torch.float32)
         tw = torch.empty(toks, tk, device=dev, dtype=torch.float32)
         ti = torch.empty(toks, tk, device=dev, dtype=torch.int32)
