@@ -8,6 +8,8 @@
 #   prefill_*: tools/attn_prefill_bench.py, one run per shape (ATTN_PREFILL_ONLY = 128 / 64 / chunk / softcap): the kernel
 #              stats rows are per shape, not an average over three workloads
 #   moe      : tools/moe_bench.py 64 512 2048 (fused_experts int4 W4A16)
+#   gemm_slices / sampling / prefill_long : tools/row_sweep.py gemm (256 / 512 / 1024 rows: the K-slice units and their sum kernels),
+#              sample (vocab 128256), prefill1 (chunks of one long sequence: KV splits of the 128-row-block kernel) - kernel trace only
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 export PROF_ROUND=r05
@@ -24,6 +26,9 @@ for s in $SETS; do
     prefill_chunk) ATTN_PREFILL_ONLY=chunk tools/gpu_prof.sh attn_prefill_chunk128 python3 $R/tools/attn_prefill_bench.py ;;
     prefill_softcap) ATTN_PREFILL_ONLY=softcap tools/gpu_prof.sh attn_prefill_softcap python3 $R/tools/attn_prefill_bench.py ;;
     moe) MOE_BENCH_INT4_ONLY=1 tools/gpu_prof.sh moe python3 $R/tools/moe_bench.py 64 512 2048 ;;
+    gemm_slices) GEMM_MS=256,512,1024 tools/gpu_prof.sh gemm_slices python3 $R/tools/row_sweep.py gemm ;;
+    sampling) tools/gpu_prof.sh sampling python3 $R/tools/row_sweep.py sample ;;
+    prefill_long) tools/gpu_prof.sh attn_prefill_one_sequence python3 $R/tools/row_sweep.py prefill1 ;;
   esac
 done > $R/gpurun_out/r05/prof_all.log 2>&1
 ls $R/gpurun_out/r05/prof/digest
