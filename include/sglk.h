@@ -541,6 +541,20 @@ SGLK_API int sglk_min_p_sampling_from_probs_graph(sglk_stream_t stream, int32_t*
                                                   const int64_t* indices, const float* min_p_arr, float min_p_val,
                                                   int64_t batch, int64_t vocab, const int64_t* philox_seed_ptr,
                                                   const int64_t* philox_offset_ptr, uint64_t offset_intragraph);
+/* The five ops above for a decode batch over a long vocabulary, with a scratch buffer the caller owns (no counterpart in the
+ * reference): up to 64 rows of at least 32768 entries are cut into several workgroups per row, the select's passes become
+ * launches and the rows' histograms meet in the workspace - the same bits as the entries above (every sum is an integer),
+ * ~3x sooner at batch 1 .. 8. op: 0 top_k_renorm_probs, 1 top_p_renorm_probs, 2 top_k_top_p_sampling_from_probs (both
+ * filters), 3 top_p_sampling_from_probs, 4 min_p_sampling_from_probs; result = renorm_probs (float) or output (int32);
+ * top_k_arr int64 (top_k_is_int64 = 1, the renorm op) or int32; p_arr / p_val = top-p or min-p; the generator state by value, or
+ * by pointer (both non-NULL: a launch recorded into a HIP graph, philox_offset then is the offset inside the graph).
+ * _workspace_size: bytes (0: one workgroup per row, whatever is passed); a NULL or short workspace is not an error. */
+SGLK_API int64_t sglk_sampling_workspace_size(int64_t batch, int64_t vocab);
+SGLK_API int sglk_sampling_ws(sglk_stream_t stream, int op, void* result, const float* probs, const int64_t* indices,
+                              const void* top_k_arr, int top_k_is_int64, int64_t top_k_val, const float* p_arr,
+                              float p_val, int64_t batch, int64_t vocab, uint64_t philox_seed, uint64_t philox_offset,
+                              const int64_t* philox_seed_ptr, const int64_t* philox_offset_ptr, void* workspace,
+                              int64_t workspace_bytes);
 
 #ifdef __cplusplus
 }

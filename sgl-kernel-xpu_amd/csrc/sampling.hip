@@ -34,6 +34,7 @@ constexpr int kT = 1024;
 constexpr int kBins1 = 4096;
 constexpr float kFix = 1099511627776.0f;  // 2^40
 
+struct RowWs;
 struct SampleParams {
   const float* probs;       // [rows_in, V]
   float* renorm;            // renorm ops: [B, V]
@@ -47,6 +48,8 @@ struct SampleParams {
   int V;
   int use_k, use_p, use_minp, do_sample;
   uint64_t seed, offset;
+  struct RowWs* ws;           // cluster form (several workgroups per row, one launch per pass): per-row scratch, zeroed by run()
+  int slices;                 // workgroups per row there
   const int64_t* seed_ptr;    // generator state resident on the device (a launch recorded into a HIP graph): seed = *seed_ptr,
   const int64_t* offset_ptr;  // offset = *offset_ptr + offset; NULL: the scalars above
 };
@@ -116,22 +119,38 @@ struct Shared {
 
 // A row as aligned 16-byte quads: quad qi holds the row's elements 4 * qi - mis + {0, 1, 2, 3}; the first and the last quad may
 // reach up to three floats outside the row (never outside their own aligned 16 bytes, which hold at least one row element).
+// (qb .. nq: the quads this workgroup owns - the whole row, or one of `slices` runs of it in the cluster form)
 struct RowQuads {
   const float4* q;
-  int mis, V, nq;
-  __device__ RowQuads(const float* row, int V_) {
+  int mis, V, nq, qb;
+  __device__ RowQuads(const float* row, int V_, int slice = 0, int slices = 1) {
     mis = (int)((reinterpret_cast<uintptr_t>(row) >> 2) & 3);
     q = reinterpret_cast<const float4*>(row - mis);
     V = V_;
-    nq = (V_ + mis + 3) >> 2;
+    const int all = (V_ + mis + 3) >> 2;
+    const int per = (((all + slices - 1) / slices + 63) >> 6) << 6;
+    qb = slice * per < all ? slice * per : all;
+    nq = qb + per < all ? qb + per : all;
   }
+};
+
+// Scratch of one row in the cluster form: the histograms of the three passes summed over the row's workgroups (bins 0 .. 4095 pass
+// 0, 4096 .. 5119 pass 1, 5120 .. 6143 pass 2), the select state after each pick, the slices' kept masses.
+struct RowWs {
+  unsigned long long mass[6144];
+  uint32_t cnt[6144];
+  unsigned long long wsum[32];
+  unsigned long long above[2];
+  uint32_t prefix[2];
+  int exhausted[2];
+  uint32_t fmax_bits, thr;
 };
 
 // f(qi, i0, x[4]) for every quad of the row (i0 = the row index of x[0]; may be < 0 or i0 + j >= V at the two ends), kU loads per
 // thread issued before the first is used: a pass is bound by the CU's L2 read rate, not by kU-fold load latency.
 template <typename F>
 __device__ __forceinline__ void scan_quads(const RowQuads& r, F&& f) {
-  for (int q0 = 0; q0 < r.nq; q0 += kU * kT) {
+  for (int q0 = r.qb; q0 < r.nq; q0 += kU * kT) {
     float4 v[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -261,31 +280,67 @@ __device__ void pick_digit(Shared& s, int crit, unsigned long long target, int s
   __syncthreads();
 }
 
-template <int DUMMY>
+// global <-> LDS traffic of the cluster form: a workgroup's histogram of pass `pass` added into the row's, and the row's read back
+__device__ void flush_hist(Shared& s, RowWs* ws, int pass) {
+  const int nb = pass == 0 ? 4096 : 1024, off = pass == 0 ? 0 : pass == 1 ? 4096 : 5120;
+  for (int i = threadIdx.x; i < nb; i += kT) {
+    if (s.cnt[i]) atomicAdd(&ws->cnt[off + i], s.cnt[i]);
+    if (s.mass[i]) atomicAdd(&ws->mass[off + i], s.mass[i]);
+  }
+}
+__device__ void load_hist(Shared& s, const RowWs* ws, int pass) {
+  const int nb = pass == 0 ? 4096 : 1024, off = pass == 0 ? 0 : pass == 1 ? 4096 : 5120;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += kT) { s.cnt[i] = ws->cnt[off + i]; s.mass[i] = ws->mass[off + i]; }
+  __syncthreads();
+}
+
+// STAGE 0: the whole op, one workgroup per row (grid = rows). STAGE 1 .. 5: the cluster form for a few rows of a long vocabulary
+// (grid = (slices, rows); a launch per pass, kernel boundaries are the barriers between a row's workgroups; every workgroup of a row
+// repeats the - deterministic - pick from the row's summed histogram, workgroup 0 records the state for the next launch):
+//   1: histogram of pass 0 (min-p: the row maximum)     2: pick 0, histogram 1     3: pick 1, histogram 2
+//   4: pick 2 -> threshold; the slice's kept mass        5: normaliser from the slices' masses; renorm write or the draw
+// All sums are integers: the cluster form returns the bits of the one-workgroup form.
+template <int STAGE>
 __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
   __shared__ Shared s;
-  const int b = blockIdx.x;
+  const int b = STAGE == 0 ? blockIdx.x : blockIdx.y;
+  const int slice = STAGE == 0 ? 0 : blockIdx.x, slices = STAGE == 0 ? 1 : p.slices;
   const int V = p.V;
   const int64_t src_row = p.indices ? p.indices[b] : b;
   const float* row = p.probs + src_row * (int64_t)V;
-  const RowQuads r(row, V);
+  const RowQuads r(row, V, slice, slices);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  RowWs* ws = STAGE == 0 ? nullptr : p.ws + b;
 
   uint32_t thr = 0;  // keep key >= thr
   if (p.use_minp) {
-    float m = 0.f;
-    scan_row(r, [&](int, float x) { m = fmaxf(m, x); });
-    m = wave_max(m);
-    if (lane == 0) s.red32[wave] = __float_as_uint(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float mm = 0.f;
-      for (int i = 0; i < kT / 64; ++i) mm = fmaxf(mm, __uint_as_float(s.red32[i]));
-      s.fmax_ = mm;
+    if constexpr (STAGE == 2 || STAGE == 3) return;
+    if constexpr (STAGE <= 1) {
+      float m = 0.f;
+      scan_row(r, [&](int, float x) { m = fmaxf(m, x); });
+      m = wave_max(m);
+      if (lane == 0) s.red32[wave] = __float_as_uint(m);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float mm = 0.f;
+        for (int i = 0; i < kT / 64; ++i) mm = fmaxf(mm, __uint_as_float(s.red32[i]));
+        s.fmax_ = mm;
+        if constexpr (STAGE == 1) atomicMax(&ws->fmax_bits, __float_as_uint(mm));  // (non-negative floats order like their bits)
+      }
+      __syncthreads();
+      if constexpr (STAGE == 1) return;
     }
-    __syncthreads();
-    const float mp = p.p_arr ? p.p_arr[b] : p.p_val;
-    thr = key_of(mp * s.fmax_);
+    if constexpr (STAGE == 5) {
+      thr = ws->thr;
+    } else {
+      const float fmax_row = STAGE == 4 ? __uint_as_float(ws->fmax_bits) : s.fmax_;
+      const float mp = p.p_arr ? p.p_arr[b] : p.p_val;
+      thr = key_of(mp * fmax_row);
+      if (STAGE == 4 && slice == 0 && threadIdx.x == 0) ws->thr = thr;
+    }
+  } else if constexpr (STAGE == 5) {
+    thr = ws->thr;
   } else {
     unsigned long long target[2] = {0, 0};
     bool use[2] = {p.use_k != 0, p.use_p != 0};
@@ -302,27 +357,56 @@ __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
       if (pp >= 1.0f) use[1] = false;  // p = 1: everything is kept (the row sum may fall short of 1 by rounding)
     }
     if (threadIdx.x == 0) {
-      s.prefix[0] = s.prefix[1] = 0;
-      s.above[0] = s.above[1] = 0;
-      s.exhausted[0] = s.exhausted[1] = 0;
+      // (cluster form: the state the previous launch's workgroup 0 recorded; all zero before the first pick)
+      s.prefix[0] = STAGE >= 2 ? ws->prefix[0] : 0;  s.prefix[1] = STAGE >= 2 ? ws->prefix[1] : 0;
+      s.above[0] = STAGE >= 2 ? ws->above[0] : 0;    s.above[1] = STAGE >= 2 ? ws->above[1] : 0;
+      s.exhausted[0] = STAGE >= 2 ? ws->exhausted[0] : 0;  s.exhausted[1] = STAGE >= 2 ? ws->exhausted[1] : 0;
     }
     __syncthreads();
     const int shifts[3] = {20, 10, 0}, bitsv[3] = {12, 10, 10};
-    for (int pass = 0; pass < 3; ++pass) {
-      const bool act0 = use[0] && !s.exhausted[0], act1 = use[1] && !s.exhausted[1];  // (uniform: written before a barrier)
-      if (!act0 && !act1) break;
-      const uint32_t pre0 = s.prefix[0], pre1 = s.prefix[1];
-      build_hist(s, r, act0, act1, pre0, pre1, shifts[pass], bitsv[pass], pass == 0);
-      if (act0) pick_digit(s, 0, target[0], shifts[pass], bitsv[pass]);
-      if (act1) pick_digit(s, 1, target[1], shifts[pass], bitsv[pass]);
+    if constexpr (STAGE == 0) {
+      for (int pass = 0; pass < 3; ++pass) {
+        const bool act0 = use[0] && !s.exhausted[0], act1 = use[1] && !s.exhausted[1];  // (uniform: written before a barrier)
+        if (!act0 && !act1) break;
+        const uint32_t pre0 = s.prefix[0], pre1 = s.prefix[1];
+        build_hist(s, r, act0, act1, pre0, pre1, shifts[pass], bitsv[pass], pass == 0);
+        if (act0) pick_digit(s, 0, target[0], shifts[pass], bitsv[pass]);
+        if (act1) pick_digit(s, 1, target[1], shifts[pass], bitsv[pass]);
+      }
+    } else {
+      if constexpr (STAGE >= 2) {  // the pick of pass STAGE - 2 from the row's summed histogram
+        constexpr int pk = STAGE - 2;
+        const bool a0 = use[0] && !s.exhausted[0], a1 = use[1] && !s.exhausted[1];
+        if (a0 || a1) {
+          load_hist(s, ws, pk);
+          if (a0) pick_digit(s, 0, target[0], shifts[pk], bitsv[pk]);
+          if (a1) pick_digit(s, 1, target[1], shifts[pk], bitsv[pk]);
+          if (slice == 0 && threadIdx.x == 0) {
+            ws->prefix[0] = s.prefix[0];  ws->prefix[1] = s.prefix[1];
+            ws->above[0] = s.above[0];    ws->above[1] = s.above[1];
+            ws->exhausted[0] = s.exhausted[0];  ws->exhausted[1] = s.exhausted[1];
+          }
+        }
+      }
+      if constexpr (STAGE <= 3) {  // this workgroup's share of the histogram of pass STAGE - 1
+        constexpr int ps = STAGE - 1;
+        const bool act0 = use[0] && !s.exhausted[0], act1 = use[1] && !s.exhausted[1];
+        if (act0 || act1) {
+          const uint32_t pre0 = s.prefix[0], pre1 = s.prefix[1];
+          build_hist(s, r, act0, act1, pre0, pre1, shifts[ps], bitsv[ps], ps == 0);
+          flush_hist(s, ws, ps);
+        }
+        return;
+      }
     }
     const uint32_t tk = use[0] ? s.prefix[0] : 0u, tp = use[1] ? s.prefix[1] : 0u;
     thr = tk > tp ? tk : tp;
+    if (STAGE == 4 && slice == 0 && threadIdx.x == 0) ws->thr = thr;
   }
 
   // ---- normaliser: wave w owns the quads [w * QW, (w + 1) * QW) (row order = wave order), a thread adds up its own quads' kept mass
   // (no cross-lane traffic inside the pass), one wave sum at the end
-  const int QW = ((((r.nq + kT / 64 - 1) / (kT / 64)) + 63) >> 6) << 6;
+  const int QW = ((((r.nq - r.qb + kT / 64 - 1) / (kT / 64)) + 63) >> 6) << 6;
   auto kept_mass = [&](int qi, int qend, const float4& v) {
     const float x[4] = {v.x, v.y, v.z, v.w};
     const int i0 = qi * 4 - r.mis;
@@ -343,7 +427,7 @@ __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
     return m4;
   };
   {
-    const int wq0 = wave * QW, wq1 = wq0 + QW < r.nq ? wq0 + QW : r.nq;
+    const int wq0 = r.qb + wave * QW < r.nq ? r.qb + wave * QW : r.nq, wq1 = wq0 + QW < r.nq ? wq0 + QW : r.nq;
     unsigned long long mine = 0;
     for (int q0 = wq0; q0 < wq1; q0 += kU * 64) {
       float4 v[kU];
@@ -362,6 +446,21 @@ __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
   }
   unsigned long long Z = 0;
   for (int i = 0; i < kT / 64; ++i) Z += s.red64[i];
+  unsigned long long slice_before = 0;  // (cluster form) kept mass of the slices in front of mine
+  if constexpr (STAGE == 4) {
+    if (threadIdx.x == 0) ws->wsum[slice] = Z;
+    return;
+  }
+  if constexpr (STAGE == 5) {
+    const unsigned long long mine_z = Z;
+    Z = 0;
+    for (int i = 0; i < slices; ++i) {
+      const unsigned long long t = ws->wsum[i];
+      if (i < slice) slice_before += t;
+      Z += t;
+    }
+    (void)mine_z;
+  }
   if (!p.do_sample) {
     const float inv = Z > 0 ? (float)((double)kFix / (double)Z) : 0.f;
     float* orow = p.renorm + (int64_t)b * V;
@@ -392,10 +491,10 @@ __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
   int W = -1;  // the wave whose quads hold it (uniform: every thread reads the same 16 totals)
   unsigned long long wbefore = 0;
   {
-    unsigned long long acc = 0;
+    unsigned long long acc = slice_before;  // (cluster form: a slice that does not hold the target finds no wave and writes nothing)
     for (int i = 0; i < kT / 64; ++i) {
       const unsigned long long t = s.red64[i];
-      if (W < 0 && t > 0 && target < acc + t) { W = i; wbefore = acc; }
+      if (W < 0 && t > 0 && acc <= target && target < acc + t) { W = i; wbefore = acc; }
       acc += t;
     }
   }
@@ -404,7 +503,7 @@ __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
   if (W >= 0) {
     // that wave's quads in runs of G * 64 (G = 1 up to 4M elements): all waves add up run masses, one block scan finds the run,
     // one wave scans the run
-    const int wq0 = W * QW, wq1 = wq0 + QW < r.nq ? wq0 + QW : r.nq;
+    const int wq0 = r.qb + W * QW < r.nq ? r.qb + W * QW : r.nq, wq1 = wq0 + QW < r.nq ? wq0 + QW : r.nq;
     const int steps = (wq1 - wq0 + 63) >> 6, G = (steps + kBlocks - 1) / kBlocks, runs = (steps + G - 1) / G;
     for (int run = wave; run < runs; run += kT / 64) {
       unsigned long long m = 0;
@@ -468,15 +567,51 @@ __global__ __launch_bounds__(kT) void sampling_kernel(SampleParams p) {
   __syncthreads();
   if (threadIdx.x == 0) {
     int r_ = s.out_idx;
-    if (r_ < 0) r_ = 0;  // an all-zero row has no mass to draw from
-    p.out[b] = r_;
+    if constexpr (STAGE == 5) {
+      if (r_ >= 0) p.out[b] = r_;  // (the one slice that holds the target)
+      else if (Z == 0 && slice == 0) p.out[b] = 0;  // an all-zero row has no mass to draw from
+    } else {
+      if (r_ < 0) r_ = 0;  // an all-zero row has no mass to draw from
+      p.out[b] = r_;
+    }
   }
 }
 
-static int run(hipStream_t st, const SampleParams& p, int64_t batch, const char* op) {
-  SGLK_REQUIRE(p.V > 0, "%s: vocab size must be positive", op);
+// Cluster form: up to 64 rows of a long vocabulary (a decode batch) leave most CUs idle with one workgroup per row, and a row pass
+// is bound by that one CU's vector issue (63 - 113 us at 128k entries). With a scratch buffer the row is cut into `slices` runs,
+// one workgroup each, and the passes become launches (see sampling_kernel). Returns the slice count (0: one workgroup per row).
+static int cluster_slices(int64_t batch, int64_t vocab) {
+  // (lease zu: vocab 128256 - 32 slices at 1 .. 8 rows 40 / 82 / 52 us for top-k renorm / top-k-first draw / joint draw against 63 / 113 / 94
+  //  on one workgroup per row; 8 slices at 32 rows 48 / 95 / 60 against 68 / 121 / 96; 4 slices at 64 rows 62 / 118 / 72 against 73 / 127 / 99;
+  //  2 slices at 96 and 128 rows lose. A launch costs ~4 us: six of them are most of what is left at one row.)
+  if (batch <= 0 || batch > 64 || vocab < 32768) return 0;
+  int64_t sl = num_cus() / batch;
+  sl = sl > 32 ? 32 : sl;
+  const int64_t by_len = (vocab / 4) / 512;  // at least 512 quads per slice
+  sl = sl > by_len ? by_len : sl;
+  return sl >= 2 ? (int)sl : 0;
+}
+
+static int run(hipStream_t st, const SampleParams& p0, int64_t batch, const char* op, void* ws = nullptr, int64_t ws_bytes = 0) {
+  SGLK_REQUIRE(p0.V > 0, "%s: vocab size must be positive", op);
   if (batch == 0) return SGLK_OK;
-  sampling_kernel<0><<<(unsigned)batch, kT, 0, st>>>(p);
+  const int slices = ws != nullptr ? cluster_slices(batch, p0.V) : 0;
+  if (slices > 1 && ws_bytes >= batch * (int64_t)sizeof(RowWs) && (uintptr_t)ws % 8 == 0) {
+    SampleParams p = p0;
+    p.ws = reinterpret_cast<RowWs*>(ws);
+    p.slices = slices;
+    if (hipMemsetAsync(ws, 0, (size_t)batch * sizeof(RowWs), st) != hipSuccess) return check_launch(op);
+    const dim3 grid((unsigned)slices, (unsigned)batch);
+    sampling_kernel<1><<<grid, kT, 0, st>>>(p);
+    if (!p.use_minp) {
+      sampling_kernel<2><<<grid, kT, 0, st>>>(p);
+      sampling_kernel<3><<<grid, kT, 0, st>>>(p);
+    }
+    sampling_kernel<4><<<grid, kT, 0, st>>>(p);
+    sampling_kernel<5><<<grid, kT, 0, st>>>(p);
+    return check_launch(op);
+  }
+  sampling_kernel<0><<<(unsigned)batch, kT, 0, st>>>(p0);
   return check_launch(op);
 }
 
@@ -545,4 +680,33 @@ extern "C" int sglk_min_p_sampling_from_probs_graph(sglk_stream_t stream, int32_
   p.probs = probs; p.out = output; p.indices = indices; p.p_arr = min_p_arr; p.p_val = min_p_val; p.V = (int)vocab;
   p.use_minp = 1; p.do_sample = 1; p.seed_ptr = philox_seed_ptr; p.offset_ptr = philox_offset_ptr; p.offset = offset_intragraph;
   return run((hipStream_t)stream, p, batch, "min_p_sampling_from_probs");
+}
+
+
+extern "C" int64_t sglk_sampling_workspace_size(int64_t batch, int64_t vocab) {
+  using namespace sglk;
+  return cluster_slices(batch, vocab) > 1 ? batch * (int64_t)sizeof(RowWs) : 0;
+}
+
+extern "C" int sglk_sampling_ws(sglk_stream_t stream, int op, void* result, const float* probs, const int64_t* indices,
+                                const void* top_k_arr, int top_k_is_int64, int64_t top_k_val, const float* p_arr, float p_val,
+                                int64_t batch, int64_t vocab, uint64_t philox_seed, uint64_t philox_offset,
+                                const int64_t* philox_seed_ptr, const int64_t* philox_offset_ptr, void* workspace,
+                                int64_t workspace_bytes) {
+  using namespace sglk;
+  SGLK_REQUIRE(op >= 0 && op <= 4, "sampling_ws: op must be 0 (top-k renorm), 1 (top-p renorm), 2 (top-k + top-p draw), 3 (top-p draw) or 4 (min-p draw)");
+  SGLK_REQUIRE((philox_seed_ptr == nullptr) == (philox_offset_ptr == nullptr), "sampling_ws: the generator state pointers come as a pair");
+  SampleParams p{};
+  p.probs = probs; p.V = (int)vocab; p.indices = indices;
+  p.k_arr = top_k_arr; p.k_is_i64 = top_k_is_int64; p.k_val = top_k_val; p.p_arr = p_arr; p.p_val = p_val;
+  p.seed = philox_seed; p.offset = philox_offset; p.seed_ptr = philox_seed_ptr; p.offset_ptr = philox_offset_ptr;
+  const char* name = "sampling";
+  switch (op) {
+    case 0: p.renorm = (float*)result; p.use_k = 1; p.indices = nullptr; name = "top_k_renorm_probs"; break;
+    case 1: p.renorm = (float*)result; p.use_p = 1; p.indices = nullptr; name = "top_p_renorm_probs"; break;
+    case 2: p.out = (int32_t*)result; p.use_k = 1; p.use_p = 1; p.do_sample = 1; name = "top_k_top_p_sampling_from_probs"; break;
+    case 3: p.out = (int32_t*)result; p.use_p = 1; p.do_sample = 1; name = "top_p_sampling_from_probs"; break;
+    default: p.out = (int32_t*)result; p.use_minp = 1; p.do_sample = 1; name = "min_p_sampling_from_probs"; break;
+  }
+  return run((hipStream_t)stream, p, batch, name, workspace, workspace_bytes);
 }

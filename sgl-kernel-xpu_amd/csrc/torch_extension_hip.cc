@@ -1192,6 +1192,20 @@ at::PhiloxCudaState philox_state(const std::optional<at::Generator>& gen) {
   return impl->philox_cuda_state(4);
 }
 
+// A decode batch over a long vocabulary: several workgroups per row with a scratch tensor (include/sglk.h, sglk_sampling_ws).
+// Returns false when the shape is not that case and the caller takes the one-workgroup-per-row entry.
+bool sampling_cluster(int op, const Tensor& probs, void* result, const int64_t* indices, const void* k_arr, int k_is_i64, int64_t k_val,
+                      const float* p_arr, float p_val, int64_t batch, const at::PhiloxCudaState* ph) {
+  const int64_t ws_bytes = sglk_sampling_workspace_size(batch, probs.size(1));
+  if (ws_bytes <= 0) return false;
+  Tensor ws = at::empty({ws_bytes}, probs.options().dtype(at::kByte));
+  const bool cap = ph != nullptr && ph->captured_;
+  SGLK_CALL(sglk_sampling_ws(stream_of(probs), op, result, probs.data_ptr<float>(), indices, k_arr, k_is_i64, k_val, p_arr, p_val, batch,
+                             probs.size(1), (ph && !cap) ? ph->seed_.val : 0, ph ? (cap ? ph->offset_intragraph_ : ph->offset_.val) : 0,
+                             cap ? ph->seed_.ptr : nullptr, cap ? ph->offset_.ptr : nullptr, ws.data_ptr(), ws_bytes));
+  return true;
+}
+
 void top_k_renorm_probs(const Tensor& probs, Tensor& renorm_probs, const std::optional<Tensor>& maybe_top_k_arr, int64_t top_k_val) {
   check_probs(probs, "top_k_renorm_probs");
   CHECK_GPU(renorm_probs);
@@ -1201,6 +1215,7 @@ void top_k_renorm_probs(const Tensor& probs, Tensor& renorm_probs, const std::op
   const int64_t* k = optional_row_array<int64_t>(maybe_top_k_arr, at::kLong, probs.size(0), "maybe_top_k_arr");
   if (!k) TORCH_CHECK(top_k_val > 0, "top_k_val must be positive");
   const c10::OptionalDeviceGuard guard(probs.device());
+  if (sampling_cluster(0, probs, renorm_probs.data_ptr<float>(), nullptr, k, 1, top_k_val, nullptr, 0.f, probs.size(0), nullptr)) return;
   SGLK_CALL(sglk_top_k_renorm_probs(stream_of(probs), renorm_probs.data_ptr<float>(), probs.data_ptr<float>(), k, top_k_val,
                                     probs.size(0), probs.size(1)));
 }
@@ -1214,6 +1229,7 @@ void top_p_renorm_probs(const Tensor& probs, Tensor& renorm_probs, const std::op
   const float* pa = optional_row_array<float>(maybe_top_p_arr, at::kFloat, probs.size(0), "maybe_top_p_arr");
   if (!pa) TORCH_CHECK(top_p_val > 0.0 && top_p_val <= 1.0, "top_p_val must be within (0, 1]");
   const c10::OptionalDeviceGuard guard(probs.device());
+  if (sampling_cluster(1, probs, renorm_probs.data_ptr<float>(), nullptr, nullptr, 0, 0, pa, (float)top_p_val, probs.size(0), nullptr)) return;
   SGLK_CALL(sglk_top_p_renorm_probs(stream_of(probs), renorm_probs.data_ptr<float>(), probs.data_ptr<float>(), pa, (float)top_p_val,
                                     probs.size(0), probs.size(1)));
 }
@@ -1243,6 +1259,7 @@ void top_k_top_p_sampling_from_probs(Tensor probs, Tensor output, std::optional<
   if (!pa) TORCH_CHECK(top_p_val > 0.0 && top_p_val <= 1.0, "top_p_val must be within (0, 1]");
   const c10::OptionalDeviceGuard guard(probs.device());
   const auto ph = philox_state(gen);
+  if (sampling_cluster(2, probs, output.data_ptr<int32_t>(), indices, k, 0, top_k_val, pa, (float)top_p_val, batch, &ph)) return;
   if (ph.captured_) {
     SGLK_CALL(sglk_top_k_top_p_sampling_from_probs_graph(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices,
                                                          k, top_k_val, pa, (float)top_p_val, 1, batch, probs.size(1), ph.seed_.ptr,
@@ -1264,6 +1281,7 @@ void top_p_sampling_from_probs(Tensor probs, Tensor output, std::optional<Tensor
   if (!pa) TORCH_CHECK(top_p_val > 0.0 && top_p_val <= 1.0, "top_p_val must be within (0, 1]");
   const c10::OptionalDeviceGuard guard(probs.device());
   const auto ph = philox_state(gen);
+  if (sampling_cluster(3, probs, output.data_ptr<int32_t>(), indices, nullptr, 0, 0, pa, (float)top_p_val, batch, &ph)) return;
   if (ph.captured_) {
     SGLK_CALL(sglk_top_k_top_p_sampling_from_probs_graph(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices,
                                                          nullptr, 0, pa, (float)top_p_val, 0, batch, probs.size(1), ph.seed_.ptr,
@@ -1285,6 +1303,7 @@ void min_p_sampling_from_probs(const Tensor& probs, Tensor& output, const std::o
   const float* pa = optional_row_array<float>(maybe_min_p_arr, at::kFloat, batch, "maybe_min_p_arr");
   const c10::OptionalDeviceGuard guard(probs.device());
   const auto ph = philox_state(gen);
+  if (sampling_cluster(4, probs, output.data_ptr<int32_t>(), indices, nullptr, 0, 0, pa, (float)min_p_val, batch, &ph)) return;
   if (ph.captured_) {
     SGLK_CALL(sglk_min_p_sampling_from_probs_graph(stream_of(probs), output.data_ptr<int32_t>(), probs.data_ptr<float>(), indices, pa,
                                                    (float)min_p_val, batch, probs.size(1), ph.seed_.ptr, ph.offset_.ptr,

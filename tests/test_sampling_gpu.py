@@ -173,6 +173,49 @@ def test_rows_longer_than_262141_elements(sglk, dev):
         assert torch.all(jm[torch.arange(B), smp])
 
 
+@pytest.mark.parametrize("B", [1, 5, 32, 64])
+@pytest.mark.parametrize("V", [32768, 128256, 151936])
+def test_cluster_form_returns_the_bits_of_the_one_workgroup_form(sglk, dev, B, V):
+    # up to 64 rows of >= 32768 entries run as several workgroups per row with a scratch tensor (sglk_sampling_ws); the same rows inside
+    # a batch of 80 run one workgroup per row: equal renormalised rows, equal draws from equal generator states - eager and in a graph
+    big = make_probs(80, V, seed=B + V).to(dev)
+    small = big[:B].contiguous()
+    kk = torch.randint(5, 400, (80,), generator=torch.Generator().manual_seed(1)).to(dev)
+    pp = (torch.rand(80, generator=torch.Generator().manual_seed(2)) * 0.8 + 0.1).to(dev)
+    assert torch.equal(sglk.top_k_renorm_prob(small, kk[:B]), sglk.top_k_renorm_prob(big, kk)[:B])
+    assert torch.equal(sglk.top_p_renorm_prob(small, pp[:B]), sglk.top_p_renorm_prob(big, pp)[:B])
+    assert torch.equal(sglk.top_p_renorm_prob(small, 1.0), sglk.top_p_renorm_prob(big, 1.0)[:B])
+    calls = (lambda pr, n, g: sglk.top_k_top_p_sampling_from_probs(pr, kk[:n].int(), pp[:n], filter_apply_order="joint", generator=g),
+             lambda pr, n, g: sglk.top_k_top_p_sampling_from_probs(pr, 20, 0.7, generator=g),
+             lambda pr, n, g: sglk.top_p_sampling_from_probs(pr, pp[:n], generator=g),
+             lambda pr, n, g: sglk.top_p_sampling_from_probs(pr, 1.0, generator=g),
+             lambda pr, n, g: sglk.min_p_sampling_from_probs(pr, pp[:n] * 0.05, generator=g),
+             lambda pr, n, g: sglk.min_p_sampling_from_probs(pr, 0.0, generator=g))
+    for f in calls:
+        for rep in range(3):
+            g1 = torch.Generator(device=dev).manual_seed(77 + rep)
+            g2 = torch.Generator(device=dev).manual_seed(77 + rep)
+            assert torch.equal(f(small, B, g1), f(big, 80, g2)[:B])
+    # all-zero rows draw index 0 in both forms
+    z = torch.zeros(B, V, device=dev)
+    assert torch.all(sglk.top_p_sampling_from_probs(z, 0.5) == 0)
+    # recorded into a graph: replays follow the default generator as the eager calls do
+    torch.cuda.manual_seed(11)
+    eager = [sglk.top_k_top_p_sampling_from_probs(small, 50, 0.9, filter_apply_order="joint").clone() for _ in range(2)]
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out = sglk.top_k_top_p_sampling_from_probs(small, 50, 0.9, filter_apply_order="joint")
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.manual_seed(11)
+    for want in eager:
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+
+
 def test_draws_recorded_into_a_graph_follow_the_generator(sglk, dev):
     # A sampling launch recorded into a HIP graph reads the generator state from the device at replay (the C-ABI's *_graph entries):
     # every replay draws fresh numbers, and they are the numbers the eager op draws from the same generator state.

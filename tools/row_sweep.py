@@ -148,7 +148,7 @@ if what == "prefill1":
         del kc, vc
 if what == "sample":
     V = 128256
-    for bs in (1, 8, 64, 256):
+    for bs in (1, 8, 32, 64, 65, 256):
         probs = torch.softmax(torch.randn(bs, V, device=dev), dim=-1)
         k = torch.full((bs,), 50, device=dev, dtype=torch.int32)
         pp = torch.full((bs,), 0.9, device=dev, dtype=torch.float32)
