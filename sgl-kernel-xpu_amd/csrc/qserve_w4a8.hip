@@ -699,11 +699,21 @@ static int launch(hipStream_t st, void* out, const void* a, const void* w, const
   // bit-identical. A round of one-m-tile workgroups takes ~12 us, of two-m-tile ones ~19 us (K = 4096); the form with the smaller
   // estimate runs when it beats the other paths' floor - always up to 128 rows, up to ~36 us above.
   bool stream32 = false, two_tiles = false;
-  if (M > 64 && M <= 512 && g_qserve_cfg != 1) {
+  if (M > 64 && M <= 1024 && g_qserve_cfg != 1) {
     const int64_t quads = cdiv(N, 128), cus = num_cus() > 0 ? num_cus() : 256;
     const int64_t e1 = cdiv(quads * cdiv(M, 32), cus) * 12, e2 = cdiv(quads * cdiv(M, 64), cus) * 19;
-    const int64_t kscale = K > 4096 ? (K + 4095) / 4096 : 1;  // (the estimates are for K = 4096)
-    stream32 = M <= 128 || std::min(e1, e2) * kscale <= (GROUP ? 46 : 38);  // (the persistent pipeline per group: ~53 us)
+    // (round 5, late: both sides of the comparison scale with K. The rule compared the stream's estimate, scaled by K / 4096, with the
+    //  pipeline's floor AT K = 4096 - so at the down projection's shape, N = 4096, K = 14336, everything from 129 rows on went to the
+    //  pipeline: 125 us per channel / 156 per group whatever the rows, against 30 at 128 rows. The pipeline runs a K block of a half
+    //  tile in ~1.12 us per channel, ~1.4 per group, one round per 256 half tiles (128 x 256; whole tiles above 512 rows unless they
+    //  fill at most half of the CUs).)
+    const double kscale = (double)K / 4096.0;  // (the stream estimates are for K = 4096)
+    const int64_t tiles = cdiv(M, 256) * cdiv(N, 256);
+    const int64_t units = (M <= 512 || tiles <= cus / 2) ? 2 * tiles : tiles;
+    const double pipe = (double)cdiv(units, cus) * (double)(K / 128) * (GROUP ? 1.4 : 1.12) * (units == tiles ? 1.6 : 1.0);
+    // (0.8: the stream's repeats come from L2 and run under their estimates - N = 4096, K = 14336 at 256 / 512 rows 30 / 48 us against
+    //  estimates of 42 / 66; at a tie the stream wins - 8192^2 at 257 rows 58 against 75 us, N = 14336, K = 4096 at 256 rows 37 against 44)
+    stream32 = M <= 128 || 0.8 * (double)std::min(e1, e2) * kscale <= pipe;
     two_tiles = e2 < e1;
   }
   if (stream32) {

@@ -77,6 +77,26 @@ def test_wide_n_33_to_64_rows(sglk, dev, M, N, K):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("M", [129, 300, 513, 800, 1024])
+@pytest.mark.parametrize("N,K", [(1024, 14336), (4096, 7168), (640, 2048)])
+def test_deep_k_129_to_1024_rows(sglk, dev, M, N, K):
+    """few hundred rows over a deep K: the 32-row stream (one or two m-tiles per workgroup, the weights streamed per workgroup row) runs
+    where its estimate beats the tile pipeline's, which scales with K too (N = 4096, K = 14336: 125 us whatever the rows before)"""
+    a, b = make(M, N, K, M + N + K)
+    a_q, a_scale = oq.sym_quantize(a)
+    b_q, b_scale, b_zero = oq.asym_quantize_u4(b)
+    w, ws, wsz = oq.per_chn_inputs(b_q, b_scale, b_zero)
+    a_sum_q = (a_q.float().sum(dim=-1, keepdim=True) * a_scale.float()).to(torch.float16)
+    out = sglk.qserve_w4a8_per_chn_gemm(a_q.to(dev), w.to(dev), ws.to(dev), a_scale.to(dev), wsz.to(dev), a_sum_q.to(dev))
+    ref = oq.w4a8_per_chn_gemm(a_q, b_q, a_scale, b_scale, b_zero)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), rtol=2e-3, atol=2e-3)
+    b_q, chn, s8, z8 = oq.progressive_group_quantize(b)
+    w, ws, s8f, z8f = oq.per_group_inputs(b_q, chn, s8, z8)
+    out = sglk.qserve_w4a8_per_group_gemm(a_q.to(dev), w.to(dev), z8f.to(dev), s8f.to(dev), ws.to(dev), a_scale.to(dev))
+    ref = oq.w4a8_per_group_gemm(a_q, b_q, a_scale, chn, s8, z8)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-5)
+
+
 def test_golden_vectors(sglk, dev):
     g = load_golden("qserve_w4a8")
     for c in g["chn"]:

@@ -1,13 +1,10 @@
 #!/bin/bash
-# r05 lease zq: fused_experts at 130 - 190 rows per expert: 256-row blocks from a lower average (MOE_MIN_ROWS) against the default 192
+# r05 lease zq: QServe W4A8 over a deep K (N = 4096, K = 14336; 8192^2) across rows: parity + timing
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r05_zq
 mkdir -p $OUT
 export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
 cd $R
-for rep in 1 2; do
-  for mr in 192 160 136; do
-    echo "== MOE_MIN_ROWS=$mr"
-    MOE_MIN_ROWS=$mr MOE_BENCH_INT4_ONLY=1 LD_PRELOAD=$R/sgl-kernel-xpu_amd/build/libsglk_probes.so timeout 300 python3 tools/moe_bench.py 512 544 576 640 704 767 2>&1 | grep "fused_experts T"
-  done
-done | tee $OUT/minrows.log
+timeout 1200 python3 -m pytest tests/test_qserve_gpu.py -m gpu -q > $OUT/pytest.log 2>&1
+tail -3 $OUT/pytest.log
+QSERVE_SHAPES="4096x14336,8192x8192,4096x4096,14336x4096" timeout 600 python3 tools/qserve_bench.py 64 128 129 192 256 257 384 512 513 768 1024 1025 2048 2>&1 | grep "N=" | tee $OUT/qserve.log

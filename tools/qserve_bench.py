@@ -35,7 +35,10 @@ def timeit(f, it=30):
     return sorted(ts)[1]
 
 
-for N, K in ((4096, 4096), (14336, 4096)):
+shapes = ((4096, 4096), (14336, 4096))
+if os.environ.get("QSERVE_SHAPES"):  # e.g. "4096x14336,8192x8192" (N x K)
+    shapes = tuple(tuple(int(v) for v in t.split("x")) for t in os.environ["QSERVE_SHAPES"].split(","))
+for N, K in shapes:
     w = torch.randint(-128, 128, (N, K // 2), device=dev, dtype=torch.int8)
     ws = (torch.rand(N, device=dev) * 0.01).half()
     wz = (torch.rand(N, device=dev) * 0.01).half()
