@@ -65,6 +65,8 @@ else:
         print(f"fwd bs16 seq4096 h32/8 d128, {q} query tokens per sequence ({q * hq // hk} packed rows): {t:.1f} us  {by / t / 1e6:.0f} GB/s  {fl / t / 1e6:.0f} TFLOP/s")
 if what == "moe":
     E, Hd, I, gs, topk = 8, 4096, 14336, 128, 2
+    if os.environ.get("MOE_SHAPE"):  # "experts,hidden,inter,topk" - e.g. 128,2048,768,8 (Qwen3-30B-A3B) or 256,7168,2048,8 (DeepSeek-V3)
+        E, Hd, I, topk = (int(v) for v in os.environ["MOE_SHAPE"].split(","))
     w1 = torch.randint(0, 256, (E, 2 * I, Hd // 2), device=dev, dtype=torch.uint8)
     w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
     s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01
@@ -76,7 +78,8 @@ if what == "moe":
         ti = torch.empty(T, topk, device=dev, dtype=torch.int32)
         sgl_kernel.topk_softmax(tw, ti, logits, True)
         t = timeit(lambda: sgl_kernel.fused_experts(x, w1, w2, tw, ti, use_int4_w4a16=True, w1_scale=s1, w2_scale=s2), it=10)
-        print(f"fused_experts int4 Mixtral T={T}: {t:.0f} us  ({t / T:.2f} us per token)")
+        wbytes = (w1.numel() + w2.numel()) * min(1.0, T * topk / E)
+        print(f"fused_experts int4 E={E} hidden={Hd} inter={I} top{topk} T={T}: {t:.0f} us  ({t / T:.2f} us per token)  {2.0 * T * topk * 3 * Hd * I / t / 1e6:.0f} TFLOP/s  ~{wbytes / t / 1e6:.2f} TB/s of weights")
 if what == "mla":
     from sgl_kernel.attention import flash_mla_decode, flash_mla_get_workspace_size
     page = 64
