@@ -312,27 +312,40 @@ __global__ __launch_bounds__(256) void shuffle_mul_sum_kernel(const T* __restric
                                                               float rsf, bool use_rsf) {
   constexpr int V = 16 / sizeof(T);
   const int64_t tok = blockIdx.x;
-  for (int c = threadIdx.x * V; c < hidden; c += 256 * V) {
-    float acc[V];
+  // (a workgroup per token and 256 * V columns, the rows of up to eight top-k slots requested before the first is used: one token of
+  //  a top-8 router over 7168 columns was 32 dependent round trips - 13 us; the sum keeps its slot order)
+  const int c = ((int)blockIdx.y * 256 + (int)threadIdx.x) * V;
+  if (c >= hidden) return;
+  float acc[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] = 0.f;
-    for (int j = 0; j < topk; ++j) {
+  for (int i = 0; i < V; ++i) acc[i] = 0.f;
+  for (int j0 = 0; j0 < topk; j0 += 8) {
+    Vec<T, V> x[8];
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u < topk ? j0 + u : topk - 1;
       const int64_t src = perm[tok * topk + j];
-      const float w = factors ? (float)factors[tok * topk + j] : 1.0f;
-      const Vec<T, V> x = load_vec<T, V>(in + src * hidden + c);
+      w[u] = factors ? (float)factors[tok * topk + j] : 1.0f;
+      x[u] = load_vec<T, V>(in + src * hidden + c);
+    }
 #pragma unroll
-      for (int i = 0; i < V; ++i) {
-        // explicit roundings (no fma contraction): acc += (x * w) [* rsf], as the reference spells it
-        float t = __fmul_rn((float)x[i], w);
-        if (use_rsf) t = __fmul_rn(t, rsf);
-        acc[i] = __fadd_rn(acc[i], t);
+    for (int u = 0; u < 8; ++u) {
+      if (j0 + u < topk) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          // explicit roundings (no fma contraction): acc += (x * w) [* rsf], as the reference spells it
+          float t = __fmul_rn((float)x[u][i], w[u]);
+          if (use_rsf) t = __fmul_rn(t, rsf);
+          acc[i] = __fadd_rn(acc[i], t);
+        }
       }
     }
-    Vec<T, V> o;
-#pragma unroll
-    for (int i = 0; i < V; ++i) o[i] = (T)acc[i];
-    store_vec<T, V>(out + tok * hidden + c, o);
   }
+  Vec<T, V> o;
+#pragma unroll
+  for (int i = 0; i < V; ++i) o[i] = (T)acc[i];
+  store_vec<T, V>(out + tok * hidden + c, o);
 }
 
 // The same combine behind a down projection whose K range was split in two (moe_persist.hip, KSPL = 2): source row r of a full
@@ -535,12 +548,12 @@ extern "C" int sglk_apply_shuffle_mul_sum(sglk_stream_t stream, const void* inpu
     SGLK_REQUIRE((hidden * sizeof(T)) % 16 == 0 && (uintptr_t)input % 16 == 0 && (uintptr_t)output % 16 == 0,
                  "apply_shuffle_mul_sum: rows must be multiples of 16 bytes");
     if (factors == nullptr) {
-      shuffle_mul_sum_kernel<T, T><<<(unsigned)tokens, 256, 0, st>>>((const T*)input, (T*)output, permutation, nullptr,
+      shuffle_mul_sum_kernel<T, T><<<dim3((unsigned)tokens, (unsigned)cdiv(hidden, 256 * (16 / (int64_t)sizeof(T)))), 256, 0, st>>>((const T*)input, (T*)output, permutation, nullptr,
                                                                      (int)topk, (int)hidden, routed_scaling_factor,
                                                                      use_rsf);
     } else {
       SGLK_DISPATCH_FLOAT(factors_dtype, W, {
-        shuffle_mul_sum_kernel<T, W><<<(unsigned)tokens, 256, 0, st>>>((const T*)input, (T*)output, permutation,
+        shuffle_mul_sum_kernel<T, W><<<dim3((unsigned)tokens, (unsigned)cdiv(hidden, 256 * (16 / (int64_t)sizeof(T)))), 256, 0, st>>>((const T*)input, (T*)output, permutation,
                                                                        (const W*)factors, (int)topk, (int)hidden,
                                                                        routed_scaling_factor, use_rsf);
       });

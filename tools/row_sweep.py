@@ -71,7 +71,7 @@ if what == "moe":
     w2 = torch.randint(0, 256, (E, Hd, I // 2), device=dev, dtype=torch.uint8)
     s1 = torch.rand(E, 2 * I, Hd // gs, device=dev).to(torch.bfloat16) * 0.01
     s2 = torch.rand(E, Hd, I // gs, device=dev).to(torch.bfloat16) * 0.01
-    for T in (1, 2, 4, 8, 16, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 256, 320, 383, 384, 448, 512, 640, 767, 768, 1024, 1280, 1536, 2048):
+    for T in [int(t) for t in os.environ.get("MOE_TS", "1,2,4,8,16,24,32,40,48,64,80,96,128,160,192,256,320,383,384,448,512,640,767,768,1024,1280,1536,2048").split(",")]:
         x = torch.randn(T, Hd, device=dev, dtype=torch.bfloat16) * 0.1
         logits = torch.randn(T, E, device=dev, dtype=torch.bfloat16)
         tw = torch.empty(T, topk, device=dev, dtype=torch.float32)
