@@ -259,3 +259,35 @@ if what == "moe2":
             t = timeit(lambda: sgl_kernel.fused_experts(x, w1, w2, tw, ti, **kw), it=10)
             print(f"fused_experts {fmt} Mixtral T={T}: {t:.0f} us  ({t / T:.2f} us per token)  {2.0 * T * topk * 3 * Hd * I / t / 1e6:.0f} TFLOP/s")
         del w1, w2
+if what == "fwdcfg":
+    # fwd across head layouts and page sizes (the sweeps above hold 32 / 8 heads of 128, 64-token pages): decode bs 16 x 4096 keys,
+    # causal prefill bs 4 x 1024, a 128-query chunk over 4096 keys
+    for hq, hk, d, page in ((32, 8, 128, 64), (32, 32, 128, 64), (64, 8, 128, 64), (8, 1, 128, 64), (28, 4, 128, 64), (40, 8, 128, 64),
+                            (32, 8, 128, 16), (32, 8, 128, 32), (32, 8, 128, 128), (32, 8, 128, 256), (32, 8, 64, 16), (16, 8, 256, 64),
+                            (48, 8, 128, 64), (96, 8, 128, 64), (16, 16, 64, 64), (24, 8, 96, 64), (16, 2, 192, 64)):
+        bs, seq = 16, 4096
+        n_pages = bs * seq // page
+        try:
+            kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+            vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+            pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, seq // page)
+            lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+            qd = torch.randn(bs, 1, hq, d, device=dev, dtype=torch.bfloat16)
+            t1 = timeit(lambda: flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, page_table=pt, causal=True))
+            qc = torch.randn(bs * 128, hq, d, device=dev, dtype=torch.bfloat16)
+            cu = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * 128
+            t2 = timeit(lambda: flash_attn_with_kvcache(qc, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu, max_seqlen_q=128,
+                                                        causal=True), it=5)
+            b4, s4 = 4, 1024
+            lens4 = torch.full((b4,), s4, device=dev, dtype=torch.int32)
+            pt4 = pt[:b4, : s4 // page].contiguous()
+            qp = torch.randn(b4 * s4, hq, d, device=dev, dtype=torch.bfloat16)
+            cu4 = torch.arange(0, b4 + 1, device=dev, dtype=torch.int32) * s4
+            t3 = timeit(lambda: flash_attn_with_kvcache(qp, kc, vc, cache_seqlens=lens4, page_table=pt4, cu_seqlens_q=cu4, max_seqlen_q=s4,
+                                                        causal=True), it=5)
+            by = 2.0 * bs * seq * hk * d * 2
+            print(f"fwdcfg hq={hq} hk={hk} d={d} page={page}: decode {t1:.1f} us {by / t1 / 1e6:.2f} TB/s | chunk q128 {t2:.0f} us "
+                  f"{4.0 * bs * hq * d * 128 * (seq - 64) / t2 / 1e6:.0f} TFLOP/s | prefill 4x1024 {t3:.0f} us {4.0 * b4 * hq * d * s4 * s4 / 2 / t3 / 1e6:.0f} TFLOP/s")
+            del kc, vc
+        except Exception as e:
+            print(f"fwdcfg hq={hq} hk={hk} d={d} page={page}: refused: {str(e).splitlines()[0][:140]}")
