@@ -1403,10 +1403,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
                                           : (int64_t)hk * (p.paged ? p.v_s2 : p.v_s1));
   const int last_key = seqlen_k - 1;
   auto tile_of = [&](int j) { return t_lo + wave + NW * (j < nw ? j : nw - 1); };  // (past the end: the last tile again)
-  auto fetch_page = [&](int t) -> int {
+  // (a tile's two 16-token halves may lie in two pages - 16-token pages, round 5 late: the ids travel as one 64-bit value, low word
+  //  = the first half's; from 32-token pages on both words are the same id)
+  auto fetch_page = [&](int t) -> long long {
     int pos = t * kTile;
     pos = pos < last_key ? pos : last_key;
-    return pg_src[(pos + pos_base) >> pos_shift];
+    const int a = pg_src[(pos + pos_base) >> pos_shift];
+    int b2 = a;
+    if (pos_shift < 5) {
+      int pos2 = t * kTile + 16;
+      pos2 = pos2 < last_key ? pos2 : last_key;
+      b2 = pg_src[(pos2 + pos_base) >> pos_shift];
+    }
+    return (long long)(((unsigned long long)(uint32_t)b2 << 32) | (unsigned long long)(uint32_t)a);
   };
   // K fragment registers: [ks][half] token 16 half + tau(l15), dims 32 ks + 8 pig .. (16-bit: 16 bytes; fp8: 8 bytes,
   // widened right before the MFMA)
@@ -1425,24 +1434,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
   const int v_piece = lane % CPR, v_tok = lane / CPR;  // this lane's piece of the row, its token within a load
   constexpr int CPRA = DA * ES / 16;                   // real pieces of a row; the positions past them re-fetch real ones
   const int v_src = v_piece < CPRA ? v_piece : v_piece - (CPR - CPRA);
-  auto issue_k = [&](int t, int page, KRegs& r) {
+  auto issue_k = [&](int t, long long page2, KRegs& r) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int pos = t * kTile + 16 * h + tau;
       pos = pos < last_key ? pos : last_key;
       const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
-      const int64_t off = (int64_t)((uint64_t)(uint32_t)page * kpg + ((uint64_t)cp * kst + (uint64_t)kbase_off));
+      const uint32_t page = h ? (uint32_t)((unsigned long long)page2 >> 32) : (uint32_t)page2;
+      const int64_t off = (int64_t)((uint64_t)page * kpg + ((uint64_t)cp * kst + (uint64_t)kbase_off));
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) r.k[2 * ks + h] = *reinterpret_cast<const KV*>(kcache + (off + 32 * ks) * ES);
     }
   };
-  auto issue_v = [&](int t, int page, VRegs& r) {
+  auto issue_v = [&](int t, long long page2, VRegs& r) {
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       int pos = t * kTile + TPL * i + v_tok;
       pos = pos < last_key ? pos : last_key;
       const uint32_t cp = (uint32_t)((pos + pos_base) & pos_mask);
-      const int64_t off = (int64_t)((uint64_t)(uint32_t)page * vpg + ((uint64_t)cp * vst + (uint64_t)vbase_row));
+      const uint32_t page = (TPL * i >= 16) ? (uint32_t)((unsigned long long)page2 >> 32) : (uint32_t)page2;  // (16 % TPL == 0)
+      const int64_t off = (int64_t)((uint64_t)page * vpg + ((uint64_t)cp * vst + (uint64_t)vbase_row));
       r.v[i] = *reinterpret_cast<const v4i*>(vcache + off * ES + 16 * v_src);
     }
   };
@@ -1497,7 +1508,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
   // image and the scores are out of the matrix pipe, both register sets are free: V(j + 1) and K(j + 2) are requested
   // before the softmax. In flight per wave: K(j + 1), then V(j + 1) and K(j + 2).
   VRegs vr;
-  auto compute = [&](int j, KRegs& kr, int buf, int page_v, int page_k) {
+  auto compute = [&](int j, KRegs& kr, int buf, long long page_v, long long page_k) {
     const int t = tile_of(j);
     v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1607,15 +1618,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 2 : (D <= 128 ? 2 : 1))) void a
   // j + 3: fetched one step before they are first used, in front of the loads that follow.
   if (nw > 0) {
     KRegs ka, kb;
-    int p0 = fetch_page(tile_of(0)), p1 = fetch_page(tile_of(1)), p2 = fetch_page(tile_of(2));
+    long long p0 = fetch_page(tile_of(0)), p1 = fetch_page(tile_of(1)), p2 = fetch_page(tile_of(2));
     issue_k(tile_of(0), p0, ka);
     issue_v(tile_of(0), p0, vr);
     issue_k(tile_of(1), p1, kb);
     int j = 0;
     for (; j + 2 <= nw; j += 2) {
-      int p3 = fetch_page(tile_of(j + 3));
+      long long p3 = fetch_page(tile_of(j + 3));
       compute(j, ka, 0, p1, p2);       // requests V(j + 1), K(j + 2)
-      const int p4 = fetch_page(tile_of(j + 4));
+      const long long p4 = fetch_page(tile_of(j + 4));
       compute(j + 1, kb, 1, p2, p3);   // requests V(j + 2), K(j + 3)
       p1 = p3;
       p2 = p4;
@@ -1911,7 +1922,7 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p_in, const void* q, c
   }
   // decode-sized problems at head dims 64 / 128 / 256 (16-bit or fp8 cache): every sequence has at most 16 packed rows per
   // kv head; a tile within one page
-  if ((d == 64 || d == 128 || d == 256) && max_rows <= kDecodeRowsMax && (p.paged != 1 || p.page_shift >= 5) &&
+  if ((d == 64 || d == 128 || d == 256) && max_rows <= kDecodeRowsMax && (p.paged != 1 || p.page_shift >= 4) &&
       p.leftpad_k == nullptr && p.q_s0 % 8 == 0 &&
       (kv8 == 0 || (p.k_s0 % 16 == 0 && p.k_s1 % 16 == 0 && p.k_s2 % 16 == 0 && p.v_s0 % 16 == 0 && p.v_s1 % 16 == 0 &&
                     p.v_s2 % 16 == 0 && (uintptr_t)v % 16 == 0))) {  // (fp8: V rows are fetched in 16-byte pieces)
@@ -1926,7 +1937,7 @@ static int dispatch_dim(hipStream_t st, const AttnParams& p_in, const void* q, c
   }
   // (head dims 96 / 192 - the reference's paged decode builds them, FMHADecodeXe20.cmake:13-16 - inside the 128 / 256 forms of the
   //  same kernel since round 5; 16-byte loads of 192- / 384-byte rows: strides and bases in whole chunks)
-  if ((d == 96 || d == 192) && max_rows <= kDecodeRowsMax && (p.paged != 1 || p.page_shift >= 5) && p.leftpad_k == nullptr &&
+  if ((d == 96 || d == 192) && max_rows <= kDecodeRowsMax && (p.paged != 1 || p.page_shift >= 4) && p.leftpad_k == nullptr &&
       p.q_s0 % 8 == 0 && p.q_s1 % 8 == 0 && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0 && (uintptr_t)v % 16 == 0 &&
       p.k_s0 % 16 == 0 && p.k_s1 % 16 == 0 && p.k_s2 % 16 == 0 && p.v_s0 % 16 == 0 && p.v_s1 % 16 == 0 && p.v_s2 % 16 == 0) {
 #define SGLK_DEC_GO_A(DD, DA_)                                                                                  \

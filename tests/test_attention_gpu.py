@@ -218,8 +218,18 @@ def test_decode_kernel_features(sglk, dev, dtype, heads, sq, feature):
     seqs_q = [min(sq, k) for k in seqs_k]
     kw = dict(causal="causal" in feature, window=(100, 0) if feature == "local" else (-1, -1),
               softcap=20.0 if feature == "softcap" else 0.0, use_sink="sinks" in feature)
-    for page, splits in ((32, 0), (64, 1), (64, 16), (256, 3)):
+    for page, splits in ((16, 0), (16, 5), (32, 0), (64, 1), (64, 16), (256, 3)):  # (16: a tile's two halves in two pages, round 5 late)
         run_paged(sglk, dev, dtype, seqs_q, seqs_k, Hq, Hk, 128, page, num_splits=splits, seed=sq + Hq, **kw)
+
+
+@pytest.mark.parametrize("D", [64, 96, 128, 192, 256])
+def test_decode_kernel_16_token_pages(sglk, dev, D):
+    """pages of 16 tokens on the decode kernel at every head dim it has (a 32-token tile = two pages: two ids per tile), lengths that
+    end in the first / second half of a tile, 1 .. 40 packed rows (fp8 caches over 16-token pages: test_fp8_kvcache)"""
+    for sq, heads in ((1, (16, 4)), (3, (8, 8)), (10, (16, 4))):
+        seqs_k = [1, 15, 16, 17, 47, 48, 49, 1000 + sq]
+        run_paged(sglk, dev, torch.bfloat16, [min(sq, k) for k in seqs_k], seqs_k, heads[0], heads[1], D, 16, causal=True,
+                  seed=D + sq)
 
 
 def test_decode_full_size_config_sampled(sglk, dev):
@@ -365,7 +375,7 @@ def test_missing_max_seqlen_q_is_safe(sglk, dev):
 @pytest.mark.parametrize("fp8_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("heads", [(8, 8), (8, 2)])
 @pytest.mark.parametrize("D", [64, 128, 256])
-@pytest.mark.parametrize("page", [64, 128])
+@pytest.mark.parametrize("page", [16, 64, 128])
 @pytest.mark.parametrize("sq", [1, 32, 64, 200])
 @pytest.mark.parametrize("sk", [256, 512])
 @pytest.mark.parametrize("causal", [False, True])
