@@ -291,3 +291,22 @@ if what == "fwdcfg":
             del kc, vc
         except Exception as e:
             print(f"fwdcfg hq={hq} hk={hk} d={d} page={page}: refused: {str(e).splitlines()[0][:140]}")
+if what == "mlacfg":
+    # flash_mla_decode / prefill across page sizes (the mla mode holds 64-token pages): bs 32 x 4096 keys; prefill 4 x 256 queries
+    from sgl_kernel.attention import flash_mla_decode, flash_mla_get_workspace_size, flash_mla_prefill, flash_mla_prefill_get_workspace_size
+    for H in (16, 128):
+        for page in (1, 16, 32, 64, 128, 256):
+            bs, seq = 32, 4096
+            n_pages = bs * seq // page
+            try:
+                cache = torch.randn(n_pages, page, 576, device=dev, dtype=torch.bfloat16)
+                qn = torch.randn(bs, H, 512, device=dev, dtype=torch.bfloat16)
+                qp = torch.randn(bs, H, 64, device=dev, dtype=torch.bfloat16)
+                lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+                table = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, -1)
+                ws = torch.empty(flash_mla_get_workspace_size(seq, bs, H, page, -1), device=dev, dtype=torch.uint8)
+                t = timeit(lambda: flash_mla_decode(qn, qp, cache, lens, table, ws, 0.1, -1), it=10)
+                print(f"mlacfg decode H={H} page={page}: {t:.1f} us  {bs * seq * 576 * 2 / t / 1e6:.2f} TB/s")
+                del cache
+            except Exception as e:
+                print(f"mlacfg decode H={H} page={page}: refused: {str(e).splitlines()[0][:150]}")
