@@ -1988,8 +1988,19 @@ extern "C" int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int
   if (wgs >= target * 3 / 4) return 1;
   const int64_t tiles = (max_seqlen_k + 31) / 32;
   int64_t s = target / (wgs > 0 ? wgs : 1);
-  const int64_t cap = tiles / 8;
-  if (s > cap) s = cap;
+  if (max_rows_per_kv_head <= 64) {
+    // (lease zh, explicit split counts against this rule, bs x keys, us: 16 x 512 / 1024 / 2048 one split 15.6 / 21.2 / 30.8 against 17.2 /
+    //  23.9 / 33.1 with two - half a round of workgroups is not worth a reduce launch below 128 tiles; 1 x 4096 eight splits 18.5 against
+    //  22.5 / 23.1 with four / sixteen, 4 x 1024 and 1 x 1024 eight splits of 4 tiles 13.8 / 14.0 against 16 with four: splits of at least 4
+    //  tiles, at most eight of them unless a split would then be longer than 64 tiles)
+    if (wgs >= target / 2 && tiles < 128) return 1;
+    const int64_t cap = tiles / 4, most = tiles / 64 > 8 ? tiles / 64 : 8;
+    if (s > cap) s = cap;
+    if (s > most) s = most;
+  } else {
+    const int64_t cap = tiles / 8;
+    if (s > cap) s = cap;
+  }
   if (s > 64) s = 64;
   return s < 1 ? 1 : s;
 }

@@ -310,3 +310,21 @@ if what == "mlacfg":
                 del cache
             except Exception as e:
                 print(f"mlacfg decode H={H} page={page}: refused: {str(e).splitlines()[0][:150]}")
+if what == "fwdsplit":
+    # fwd decode at short contexts: the auto split count against explicit ones (is the reduce launch worth it?)
+    hq, hk, page, d = 32, 8, 64, 128
+    for bs, seq in ((16, 256), (16, 512), (16, 1024), (16, 2048), (64, 512), (64, 1024), (4, 1024), (4, 4096), (1, 4096), (1, 1024)):
+        n_pages = bs * seq // page
+        kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+        vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+        pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, seq // page)
+        lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+        qd = torch.randn(bs, 1, hq, d, device=dev, dtype=torch.bfloat16)
+        row = []
+        for ns in (0, 1, 2, 4, 8, 16):
+            try:
+                t = timeit(lambda: flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, page_table=pt, causal=True, num_splits=ns))
+                row.append(f"{ns}: {t:.1f}")
+            except Exception as e:
+                row.append(f"{ns}: refused")
+        print(f"fwdsplit bs={bs} seq={seq}: us by num_splits (0 = auto)  " + " | ".join(row))
