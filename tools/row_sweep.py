@@ -328,3 +328,25 @@ if what == "fwdsplit":
             except Exception as e:
                 row.append(f"{ns}: refused")
         print(f"fwdsplit bs={bs} seq={seq}: us by num_splits (0 = auto)  " + " | ".join(row))
+if what == "mlasplit":
+    # flash_mla_decode: the auto split count (-1) against explicit ones
+    from sgl_kernel.attention import flash_mla_decode, flash_mla_get_workspace_size
+    page = 64
+    for H in (16, 128):
+        for bs, seq in ((1, 2048), (1, 8192), (4, 2048), (4, 8192), (16, 2048), (16, 8192), (32, 4096), (64, 2048)):
+            n_pages = bs * seq // page
+            cache = torch.randn(n_pages, page, 576, device=dev, dtype=torch.bfloat16)
+            qn = torch.randn(bs, H, 512, device=dev, dtype=torch.bfloat16)
+            qp = torch.randn(bs, H, 64, device=dev, dtype=torch.bfloat16)
+            lens = torch.full((bs,), seq, device=dev, dtype=torch.int32)
+            table = torch.arange(n_pages, device=dev, dtype=torch.int32).view(bs, -1)
+            row = []
+            for ns in (-1, 1, 2, 4, 8, 16, 32, 64):
+                try:
+                    ws = torch.empty(flash_mla_get_workspace_size(seq, bs, H, page, ns), device=dev, dtype=torch.uint8)
+                    t = timeit(lambda: flash_mla_decode(qn, qp, cache, lens, table, ws, 0.1, ns), it=10)
+                    row.append(f"{ns}: {t:.1f}")
+                except Exception as e:
+                    row.append(f"{ns}: refused")
+            print(f"mlasplit H={H} bs={bs} seq={seq}: us by num_kv_splits (-1 = auto)  " + " | ".join(row))
+            del cache
