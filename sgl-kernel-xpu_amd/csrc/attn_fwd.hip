@@ -1983,7 +1983,10 @@ extern "C" SGLK_API void sglk_debug_set_attn_prefill_stamps(unsigned long long* 
 extern "C" int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
                                          int64_t max_seqlen_k) {
   // (up to 64 packed rows: the decode kernel, one workgroup per 16-row group)
-  const int64_t wgs = batch * num_heads_k * (max_rows_per_kv_head <= 64 ? (max_rows_per_kv_head + 15) / 16 : (max_rows_per_kv_head + 63) / 64);
+  // (above: the 128-row-block kernel. This counted 64-row units until a sweep of explicit counts - lease zi - showed the rule at half
+  //  the best count everywhere: bs 1 x 512 queries over 8192 / 32768 keys 118 / 360 us with its 2 splits, 93 / 281 with 4; bs 2 / 4 x 128
+  //  over 32768 230 / 482 against 167 / 328; and splits shorter than 512 keys lose - 128 queries over 4096 keys 33 us with 8, 42 with 16)
+  const int64_t wgs = batch * num_heads_k * (max_rows_per_kv_head <= 64 ? (max_rows_per_kv_head + 15) / 16 : (max_rows_per_kv_head + 127) / 128);
   const int64_t target = max_rows_per_kv_head <= 64 ? 256 : 512;
   if (wgs >= target * 3 / 4) return 1;
   const int64_t tiles = (max_seqlen_k + 31) / 32;
@@ -1998,7 +2001,10 @@ extern "C" int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int
     if (s > cap) s = cap;
     if (s > most) s = most;
   } else {
-    const int64_t cap = tiles / 8;
+    // (one workgroup per CU over fewer than 16384 keys: a second one per CU through splits costs more than it brings - bs 16 x 64
+    //  queries over 4096 keys 110 us unsplit, 122 with 2)
+    if (wgs >= target / 2 && tiles < 512) return 1;
+    const int64_t cap = tiles / 16;
     if (s > cap) s = cap;
   }
   if (s > 64) s = 64;

@@ -350,3 +350,25 @@ if what == "mlasplit":
                     row.append(f"{ns}: refused")
             print(f"mlasplit H={H} bs={bs} seq={seq}: us by num_kv_splits (-1 = auto)  " + " | ".join(row))
             del cache
+if what == "prefillsplit":
+    # chunks of long sequences on the 128-row-block kernel: the auto split count against explicit ones
+    hq, hk, page, d = 32, 8, 64, 128
+    for bs, q, ctx in ((1, 128, 4096), (1, 128, 32768), (1, 512, 8192), (1, 512, 32768), (2, 128, 32768), (4, 128, 32768), (4, 128, 4096),
+                       (1, 2048, 32768), (8, 64, 8192)):
+        n_pages = bs * ctx // page
+        kc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+        vc = torch.randn(n_pages, page, hk, d, device=dev, dtype=torch.bfloat16)
+        pt = torch.randperm(n_pages, device=dev).to(torch.int32).view(bs, ctx // page)
+        lens = torch.full((bs,), ctx, device=dev, dtype=torch.int32)
+        qq = torch.randn(bs * q, hq, d, device=dev, dtype=torch.bfloat16)
+        cu = torch.arange(0, bs + 1, device=dev, dtype=torch.int32) * q
+        row = []
+        for ns in (0, 1, 2, 4, 8, 16, 32):
+            try:
+                t = timeit(lambda: flash_attn_with_kvcache(qq, kc, vc, cache_seqlens=lens, page_table=pt, cu_seqlens_q=cu, max_seqlen_q=q,
+                                                           causal=True, num_splits=ns), it=5)
+                row.append(f"{ns}: {t:.0f}")
+            except Exception as e:
+                row.append(f"{ns}: refused")
+        print(f"prefillsplit bs={bs} q={q} ctx={ctx}: us by num_splits (0 = auto)  " + " | ".join(row))
+        del kc, vc
