@@ -281,7 +281,10 @@ static int dispatch(hipStream_t st, void* out, const void* act, const void* w, c
   if (avg <= 18) return launch<T, 2, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   if (avg <= 60) return launch<T, 4, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   // (eight waves share the staged activation tile, 128 x 256: half the activation traffic and barriers per flop)
-  if (g_bf16_wv != 4) return launch<T, 8, 2, 8>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
+  // (61 .. 96 rows on average - below the tile pipeline's 88 or where it refuses the shape: the 128-row tile on four waves streams
+  //  faster than on eight, 256 / 288 / 320 tokens 742 / 754 / 755 -> 678 / 676 / 694 us, lease zn)
+  // (diagnostic build: 4 forces four waves, 9 eight, 8 = this rule)
+  if (g_bf16_wv == 9 || (g_bf16_wv == 8 && avg > 96)) return launch<T, 8, 2, 8>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
   return launch<T, 8, 2>(st, out, act, w, bias, rows, total_m, E, N, K, ldb, w_stride_e, fuse);
 }
 

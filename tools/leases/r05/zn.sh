@@ -1,10 +1,10 @@
 #!/bin/bash
-# r05 lease zn: QServe W4A8 at 65 - 512 rows on the 32x32x32 stream kernel where its estimate beats the other paths: parity, timing
+# r05 lease zn: 16-bit fused_experts at 61 .. 96 rows per expert on the four-wave 128-row streaming tile: MoE parity + token sweep
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/r05_zn
 mkdir -p $OUT
 export PYTHONPATH=$R:$R/sgl-kernel-xpu_amd/python
 cd $R
-timeout 900 python3 -m pytest tests/test_qserve_gpu.py tests/test_determinism_gpu.py tests/test_cabi.py -m gpu -q -k "qserve or cabi or golden or per_" > $OUT/pytest.log 2>&1
-tail -4 $OUT/pytest.log
-timeout 600 python3 tools/qserve_bench.py 64 65 96 128 192 256 384 512 1024 2>&1 | grep "N=" | tee $OUT/qserve.log
+timeout 1500 python3 -m pytest tests/test_moe_gpu.py tests/test_full_size_gpu.py -m gpu -q > $OUT/pytest.log 2>&1
+tail -3 $OUT/pytest.log
+MOE_FMTS=bf16 MOE_TS=128,192,256,288,320,352,384 timeout 600 python3 tools/row_sweep.py moe2 2>&1 | grep "fused_experts" | tee $OUT/moe2.log

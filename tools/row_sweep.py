@@ -239,8 +239,12 @@ if what == "gemmbw":
 if what == "moe2":
     # fused_experts with 16-bit and mxfp4 weights across the token counts where the 4-bit int path had its dispatch boundaries
     E, Hd, I, topk = 8, 4096, 14336, 2
-    Ts = (1, 4, 16, 32, 48, 64, 96, 128, 192, 256, 383, 384, 512, 640, 768, 1024, 1536, 2048)
-    for fmt in ("bf16", "mxfp4"):
+    Ts = [int(t) for t in os.environ.get("MOE_TS", "1,4,16,32,48,64,96,128,192,256,383,384,512,640,768,1024,1536,2048").split(",")]
+    if os.environ.get("MOE_BF16_WAVES"):  # diagnostic build only: 4 = the 128-row streaming tile on four waves instead of eight
+        import ctypes
+        ctypes.CDLL(os.path.join(os.path.dirname(__file__), "..", "sgl-kernel-xpu_amd", "build", "libsglk_probes.so")
+                    ).sglk_debug_set_moe_bf16_waves(int(os.environ["MOE_BF16_WAVES"]))
+    for fmt in os.environ.get("MOE_FMTS", "bf16,mxfp4").split(","):
         if fmt == "bf16":
             w1 = (torch.randn(E, 2 * I, Hd, device=dev) * 0.02).to(torch.bfloat16)
             w2 = (torch.randn(E, Hd, I, device=dev) * 0.02).to(torch.bfloat16)
