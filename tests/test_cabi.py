@@ -66,3 +66,29 @@ def test_release_library_has_no_debug_switches():
     # (round 3 shipped clock-stamp hooks under another prefix: process-global pointers every later launch wrote through)
     assert b"sglk_diag_" not in data, "the release libsglk.so exports sglk_diag_* hooks"
     assert b"SGLK_FP8_BLOCKWISE_SCHEDULE" not in data, "the release libsglk.so reads a schedule switch from the environment"
+
+
+def test_auto_split_rules_are_pinned():
+    """host-only arithmetic: the split counts the library picks when the caller passes 0 / -1 (measured against explicit counts on the
+    GPU: NOTEBOOK.md round 5 (28) - (30)); a change of these numbers is a performance change and should be a deliberate one"""
+    lib = ctypes.CDLL(LIB)
+    i64 = ctypes.c_int64
+    lib.sglk_attn_auto_splits.restype = i64
+    lib.sglk_attn_auto_splits.argtypes = [i64] * 4
+    lib.sglk_mla_decode_auto_splits.restype = i64
+    lib.sglk_mla_decode_auto_splits.argtypes = [i64] * 2
+    a = lambda batch, hk, rows, keys: lib.sglk_attn_auto_splits(batch, hk, rows, keys)
+    # fwd decode (rows per kv head <= 64: one workgroup per 16-row group)
+    assert a(16, 8, 4, 512) == 1 and a(16, 8, 4, 2048) == 1      # 128 workgroups, under 128 tiles: no reduce launch
+    assert a(16, 8, 4, 4096) == 2                                 # ... from 128 tiles on
+    assert a(1, 8, 4, 4096) == 8 and a(4, 8, 4, 1024) == 8        # splits of >= 4 tiles, at most eight
+    assert a(1, 8, 4, 65536) == 32                                # ... unless a split would be longer than 64 tiles
+    assert a(64, 8, 4, 4096) == 1
+    # fwd prefill-sized (128-row blocks)
+    assert a(1, 8, 512, 4096) == 8 and a(1, 8, 512, 32768) == 16  # 128 queries x 4 heads per kv head: 32 blocks
+    assert a(1, 8, 2048, 8192) == 4 and a(4, 8, 512, 32768) == 4
+    assert a(16, 8, 256, 4096) == 1                               # one workgroup per CU below 16384 keys: unsplit
+    assert a(16, 8, 512, 4096) == 1
+    m = lambda batch, keys: lib.sglk_mla_decode_auto_splits(batch, keys)
+    assert m(1, 8192) == 32 and m(4, 8192) == 32 and m(16, 8192) == 16 and m(128, 8192) == 2
+    assert m(1, 2048) == 16 and m(1, 65536) == 64
