@@ -392,8 +392,11 @@ SGLK_API int sglk_apply_shuffle_mul_sum_splitk(sglk_stream_t stream, const void*
  *          seqlens_k = cumulative [b+1].
  *   is_causal / window (left,right; < 0 = unlimited), bottom-right aligned; softcap 0 = off;
  *   sinks fp32 [Hq] or NULL; num_splits >= 1 (> 1 needs part_o fp32 [splits,total_q,Hq,D] and
- *   part_lse fp32 [splits,Hq,total_q]); sglk_attn_auto_splits gives the "0 = auto" choice (about one workgroup per
- *   CU for decode-sized batches - at most 16 packed rows per kv head - two otherwise, never for prefill).
+ *   part_lse fp32 [splits,Hq,total_q]); sglk_attn_auto_splits gives the "0 = auto" choice: up to 64 packed rows
+ *   per kv head (the decode kernel) about one workgroup per CU in splits of at least 4 tiles of 32 keys, at most eight of
+ *   them unless a split would exceed 64 tiles, unsplit from 128 workgroups on below 4096 keys; above (128-row blocks) about
+ *   two workgroups per CU in splits of at least 512 keys, unsplit from one workgroup per CU on below 16384 keys - the counts
+ *   are pinned by tests/test_cabi.py.
  *   All k / v strides are in elements, non-negative and below 2^31. */
 SGLK_API int64_t sglk_attn_auto_splits(int64_t batch, int64_t num_heads_k, int64_t max_rows_per_kv_head,
                                        int64_t max_seqlen_k);
